@@ -1,0 +1,378 @@
+"""CPU restatement (fp32, torch-CPU tensor math + the C index oracle) of PPT's point-cloud
+encoder hot path.  PARITY PINNED by tests/golden/*.npz, which tests/golden/make_golden.py
+produced by importing the upstream reference (/root/reference) in the build container.
+
+TEST INFRASTRUCTURE ONLY: only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline`
+leg may import this module, and only as the checker / reported CPU baseline.  Nothing under
+ppt_amd/ imports it; the product path raises if the HIP library is missing.
+
+Everything is a pure function over a flat {state-dict key: tensor} mapping using the reference's
+key names.  Citations are relative to /root/reference/.
+"""
+import ctypes
+import math
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libppt_oracle.so")
+_lib = None
+
+ERF_GELU = "gelu"
+QUICK_GELU = "quick_gelu"
+
+
+# ------------------------------------------------------------------------------------------------
+# C index oracle (oracle/ppt_oracle.c)
+# ------------------------------------------------------------------------------------------------
+def build_c_oracle(force=False):
+    src = os.path.join(_HERE, "ppt_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(_SO), exist_ok=True)
+        subprocess.check_call(["gcc", "-O2", "-std=c11", "-ffp-contract=off", "-fno-fast-math",
+                               "-shared", "-fPIC", src, "-o", _SO, "-lm"])
+    return _SO
+
+
+def _c():
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(build_c_oracle())
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def fps(xyz, M, start):
+    """misc.py:44-69 farthest_point_sample with the start index injected.
+    xyz [B,N,3] f32, start [B] -> idx [B,M] int64 (numpy in, numpy out)."""
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    start = np.ascontiguousarray(start, np.int64)
+    B, N, _ = xyz.shape
+    out = np.empty((B, M), np.int64)
+    _c().oracle_fps_f32(_fp(xyz), B, N, M, _fp(start), _fp(out))
+    return out
+
+
+def square_distance(src, dst):
+    """dvae.py:130-149.  src [B,S,3], dst [B,N,3] -> [B,S,N]."""
+    src = np.ascontiguousarray(src, np.float32)
+    dst = np.ascontiguousarray(dst, np.float32)
+    B, S, _ = src.shape
+    N = dst.shape[1]
+    out = np.empty((B, S, N), np.float32)
+    _c().oracle_square_distance_f32(_fp(src), _fp(dst), B, S, N, _fp(out))
+    return out
+
+
+def knn(xyz, query, k):
+    """dvae.py:116-127 knn_point -> (idx [B,S,k] sorted by (d, index), kth [B,S,2])."""
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    query = np.ascontiguousarray(query, np.float32)
+    B, N, _ = xyz.shape
+    S = query.shape[1]
+    idx = np.empty((B, S, k), np.int64)
+    kth = np.empty((B, S, 2), np.float32)
+    _c().oracle_knn_f32(_fp(xyz), _fp(query), B, N, S, k, _fp(idx), _fp(kth))
+    return idx, kth
+
+
+def group(xyz, center_idx, k):
+    """dvae.py:159-181 Group.forward given the FPS indices.
+    -> nbr_idx [B,G,k], neighborhood [B,G,k,3], center [B,G,3]."""
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    center_idx = np.ascontiguousarray(center_idx, np.int64)
+    B, N, _ = xyz.shape
+    G = center_idx.shape[1]
+    nbr = np.empty((B, G, k), np.int64)
+    nb = np.empty((B, G, k, 3), np.float32)
+    ce = np.empty((B, G, 3), np.float32)
+    _c().oracle_group_f32(_fp(xyz), _fp(center_idx), B, N, G, k, _fp(nbr), _fp(nb), _fp(ce))
+    return nbr, nb, ce
+
+
+def ball_query(xyz, query, radius, K):
+    """pointnet2/pointnet2_utils.py:87-107 query_ball_point -> idx [B,S,K]."""
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    query = np.ascontiguousarray(query, np.float32)
+    B, N, _ = xyz.shape
+    S = query.shape[1]
+    idx = np.empty((B, S, K), np.int64)
+    _c().oracle_ball_query_f32(_fp(xyz), _fp(query), B, N, S, ctypes.c_double(radius), K, _fp(idx))
+    return idx
+
+
+def three_nn(xyz1, xyz2):
+    """pointbert/pointnet2_utils.py:333-343 -> idx [B,N,3], weight [B,N,3]."""
+    xyz1 = np.ascontiguousarray(xyz1, np.float32)
+    xyz2 = np.ascontiguousarray(xyz2, np.float32)
+    B, N, _ = xyz1.shape
+    S = xyz2.shape[1]
+    idx = np.empty((B, N, 3), np.int64)
+    w = np.empty((B, N, 3), np.float32)
+    _c().oracle_three_nn_f32(_fp(xyz1), _fp(xyz2), B, N, S, _fp(idx), _fp(w))
+    return idx, w
+
+
+# ------------------------------------------------------------------------------------------------
+# elementary tensor math (written out; no nn.Module / functional wrappers)
+# ------------------------------------------------------------------------------------------------
+def layer_norm(x, w, b, eps=1e-5):
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * w + b
+
+
+def gelu_erf(x):
+    return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
+
+
+def quick_gelu(x):
+    """ULIP_models.py:30-32."""
+    return x * torch.sigmoid(1.702 * x)
+
+
+def linear(x, w, b=None):
+    y = x @ w.t()
+    return y if b is None else y + b
+
+
+def batch_norm_rows(x, sd, prefix, train, eps=1e-5, momentum=0.1, new_stats=None):
+    """nn.BatchNorm1d over a [rows, C] matrix (the Conv1d layout [BG,C,n] flattened to rows).
+    train: biased batch variance normalises; running stats get the UNBIASED variance with
+    momentum 0.1.  new_stats (dict) receives the updated running buffers."""
+    w, b = sd[prefix + "weight"], sd[prefix + "bias"]
+    if train:
+        mean = x.mean(0)
+        var = ((x - mean) ** 2).mean(0)
+        if new_stats is not None:
+            n = x.shape[0]
+            new_stats[prefix + "running_mean"] = (1 - momentum) * sd[prefix + "running_mean"] + momentum * mean.detach()
+            new_stats[prefix + "running_var"] = (1 - momentum) * sd[prefix + "running_var"] \
+                + momentum * var.detach() * (n / (n - 1))
+            new_stats[prefix + "num_batches_tracked"] = sd[prefix + "num_batches_tracked"] + 1
+    else:
+        mean, var = sd[prefix + "running_mean"], sd[prefix + "running_var"]
+    return (x - mean) / torch.sqrt(var + eps) * w + b
+
+
+# ------------------------------------------------------------------------------------------------
+# point branch
+# ------------------------------------------------------------------------------------------------
+def mini_pointnet(sd, neighborhood, train, prefix="point_encoder.encoder.", new_stats=None):
+    """dvae.py:184-215 Encoder.forward.  neighborhood [B,G,n,3] -> [B,G,256].
+    The k=1 Conv1d layers are per-point linear maps, so the [BG,C,n] tensors are handled as
+    [BG*n, C] row matrices."""
+    B, G, n, _ = neighborhood.shape
+    x = neighborhood.reshape(B * G * n, 3)
+    f = linear(x, sd[prefix + "first_conv.0.weight"][:, :, 0], sd[prefix + "first_conv.0.bias"])
+    f = torch.relu(batch_norm_rows(f, sd, prefix + "first_conv.1.", train, new_stats=new_stats))
+    f = linear(f, sd[prefix + "first_conv.3.weight"][:, :, 0], sd[prefix + "first_conv.3.bias"])   # [BGn,256]
+    f = f.reshape(B * G, n, 256)
+    g = f.max(dim=1, keepdim=True)[0]                                   # dvae.py:210
+    f = torch.cat([g.expand(-1, n, -1), f], dim=2).reshape(B * G * n, 512)   # dvae.py:211 (global first)
+    f = linear(f, sd[prefix + "second_conv.0.weight"][:, :, 0], sd[prefix + "second_conv.0.bias"])
+    f = torch.relu(batch_norm_rows(f, sd, prefix + "second_conv.1.", train, new_stats=new_stats))
+    f = linear(f, sd[prefix + "second_conv.3.weight"][:, :, 0], sd[prefix + "second_conv.3.bias"])
+    return f.reshape(B * G, n, -1).max(dim=1)[0].reshape(B, G, -1)      # dvae.py:213-214
+
+
+def vit_attention(x, w_qkv, w_proj, b_proj, heads):
+    """point_encoder.py:33-58: no qkv bias, scale applied AFTER q@k^T."""
+    B, T, C = x.shape
+    hd = C // heads
+    qkv = linear(x, w_qkv).reshape(B, T, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    a = (q @ k.transpose(-2, -1)) * (hd ** -0.5)
+    a = torch.softmax(a, dim=-1)
+    o = (a @ v).transpose(1, 2).reshape(B, T, C)
+    return linear(o, w_proj, b_proj)
+
+
+def vit_block(sd, p, x, heads, dp1=None, dp2=None):
+    """point_encoder.py:61-79 Block.forward.  dp1/dp2: per-sample DropPath factors [B]
+    (0 or 1/keep; timm 0.4.12 semantics) or None."""
+    a = vit_attention(layer_norm(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"]),
+                      sd[p + "attn.qkv.weight"], sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"], heads)
+    if dp1 is not None:
+        a = a * dp1.view(-1, 1, 1)
+    x = x + a
+    h = layer_norm(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"])
+    h = gelu_erf(linear(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]))
+    h = linear(h, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+    if dp2 is not None:
+        h = h * dp2.view(-1, 1, 1)
+    return x + h
+
+
+def point_tokens(sd, neighborhood, center, train, prefix="point_encoder.", new_stats=None):
+    """point_encoder.py:238-247: tokens + positional embeddings [B,513,384] each."""
+    B = neighborhood.shape[0]
+    tok = mini_pointnet(sd, neighborhood, train, prefix + "encoder.", new_stats)
+    tok = linear(tok, sd[prefix + "reduce_dim.weight"], sd[prefix + "reduce_dim.bias"])
+    pos = gelu_erf(linear(center, sd[prefix + "pos_embed.0.weight"], sd[prefix + "pos_embed.0.bias"]))
+    pos = linear(pos, sd[prefix + "pos_embed.2.weight"], sd[prefix + "pos_embed.2.bias"])
+    x = torch.cat([sd[prefix + "cls_token"].expand(B, -1, -1), tok], dim=1)
+    pos = torch.cat([sd[prefix + "cls_pos"].expand(B, -1, -1), pos], dim=1)
+    return x, pos
+
+
+def point_transformer(sd, pc, fps_start, train=False, dp_masks=None, prefix="point_encoder.",
+                      num_group=512, group_size=32, heads=6, depth=12, new_stats=None, aux=None):
+    """point_encoder.py:234-257 PointTransformer.forward -> [B,768].
+    pc [B,N,3] tensor; fps_start [B] (injected RNG); dp_masks[l] = (dp1, dp2) or None."""
+    pc_np = pc.detach().numpy()
+    cidx = fps(pc_np, num_group, np.asarray(fps_start))
+    nbr, nb, ce = group(pc_np, cidx, group_size)
+    if aux is not None:
+        aux.update(center_idx=cidx, nbr_idx=nbr, neighborhood=nb, center=ce)
+    x, pos = point_tokens(sd, torch.from_numpy(nb), torch.from_numpy(ce), train, prefix, new_stats)
+    for l in range(depth):                                  # point_encoder.py:102-103: block(x + pos)
+        dp = dp_masks[l] if dp_masks is not None else (None, None)
+        x = vit_block(sd, f"{prefix}blocks.blocks.{l}.", x + pos, heads, dp[0], dp[1])
+    x = layer_norm(x, sd[prefix + "norm.weight"], sd[prefix + "norm.bias"])
+    return torch.cat([x[:, 0], x[:, 1:].max(1)[0]], dim=-1)  # point_encoder.py:251
+
+
+# ------------------------------------------------------------------------------------------------
+# text branch
+# ------------------------------------------------------------------------------------------------
+def splice_prompts(embedding, learnable_tokens, name_lengths, position="middle"):
+    """ULIP_models.py:104-151 PromptLearner.forward.  embedding [C,77,512] frozen,
+    learnable_tokens [n_ctx,512] -> prompts [C,77,512]."""
+    C = embedding.shape[0]
+    n_ctx = learnable_tokens.shape[0]
+    prefix, suffix = embedding[:, :1], embedding[:, 1 + n_ctx:]
+    if position == "end":
+        return torch.cat([prefix, learnable_tokens.unsqueeze(0).expand(C, -1, -1), suffix], dim=1)
+    rows = []
+    half = n_ctx // 2
+    for i in range(C):
+        L = name_lengths[i]
+        if position == "middle":
+            parts = [prefix[i], learnable_tokens[:half], suffix[i, :L], learnable_tokens[half:], suffix[i, L:]]
+        elif position == "front":
+            parts = [prefix[i], suffix[i, :L], learnable_tokens, suffix[i, L:]]
+        else:
+            raise ValueError(position)
+        rows.append(torch.cat(parts, dim=0))
+    return torch.stack(rows, dim=0)
+
+
+def clip_attention(x, w_in, b_in, w_out, b_out, heads):
+    """nn.MultiheadAttention(512, 8) as used by ULIP_models.py:38,49-51 with the additive causal
+    mask of :224-230.  x [C,L,D] (batch-first here; the reference permutes to LND, :214-216).
+    q is scaled by hd^-0.5 BEFORE the product (torch MHA), unlike the ViT blocks."""
+    C, L, D = x.shape
+    hd = D // heads
+    qkv = linear(x, w_in, b_in).reshape(C, L, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0] * (hd ** -0.5), qkv[1], qkv[2]
+    a = q @ k.transpose(-2, -1)
+    mask = torch.full((L, L), float("-inf")).triu(1)
+    a = torch.softmax(a + mask, dim=-1)
+    o = (a @ v).transpose(1, 2).reshape(C, L, D)
+    return linear(o, w_out, b_out)
+
+
+def text_tower(sd, prompts, eot_pos, heads=8, layers=12):
+    """ULIP_models.py:203-222 encode_text -> [C,512] (before L2 normalisation)."""
+    x = prompts + sd["positional_embedding"].unsqueeze(0)
+    for i in range(layers):                                     # ULIP_models.py:53-56
+        p = f"transformer.resblocks.{i}."
+        h = layer_norm(x, sd[p + "ln_1.weight"], sd[p + "ln_1.bias"])
+        x = x + clip_attention(h, sd[p + "attn.in_proj_weight"], sd[p + "attn.in_proj_bias"],
+                               sd[p + "attn.out_proj.weight"], sd[p + "attn.out_proj.bias"], heads)
+        h = layer_norm(x, sd[p + "ln_2.weight"], sd[p + "ln_2.bias"])
+        h = quick_gelu(linear(h, sd[p + "mlp.c_fc.weight"], sd[p + "mlp.c_fc.bias"]))
+        x = x + linear(h, sd[p + "mlp.c_proj.weight"], sd[p + "mlp.c_proj.bias"])
+    x = layer_norm(x, sd["ln_final.weight"], sd["ln_final.bias"])
+    x = x[torch.arange(x.shape[0]), torch.as_tensor(eot_pos)]
+    return x @ sd["text_projection"]
+
+
+# ------------------------------------------------------------------------------------------------
+# whole model / training step
+# ------------------------------------------------------------------------------------------------
+def ulip_logits(sd, pc, fps_start, embedding, name_lengths, eot_pos, position="middle",
+                train=False, dp_masks=None, new_stats=None, aux=None):
+    """ULIP_models.py:250-283 ULIP_WITH_IMAGE.forward (task='cls') -> logits [B,C]."""
+    pc_feat = point_transformer(sd, pc, fps_start, train, dp_masks, new_stats=new_stats, aux=aux)
+    pc_embed = pc_feat @ sd["pc_projection"]                    # :257 (not normalised)
+    prompts = splice_prompts(embedding, sd["prompt_learner.learnable_tokens"], name_lengths, position)
+    te = text_tower(sd, prompts, eot_pos)
+    te = te / te.norm(dim=-1, keepdim=True)                     # :277
+    if aux is not None:
+        aux.update(pc_feat=pc_feat.detach(), pc_embed=pc_embed.detach(), text_embed=te.detach())
+    return sd["logit_scale"].exp() * pc_embed @ te.t()          # :279-281
+
+
+def cross_entropy_ls(logits, labels, smoothing):
+    """nn.CrossEntropyLoss(label_smoothing=s), mean reduction (main_cls.py:52):
+    (1-s)*nll + s*mean_c(-log p_c)."""
+    logp = logits - torch.logsumexp(logits, dim=1, keepdim=True)
+    nll = -logp[torch.arange(logits.shape[0]), labels]
+    return ((1 - smoothing) * nll + smoothing * (-logp.mean(dim=1))).mean()
+
+
+TRAINABLE_TIERS = {   # ULIP_models.py:461-470 (cumulative)
+    1: ["norm2.weight", "norm2.bias", "mlp.fc2.weight", "mlp.fc2.bias"],
+    2: ["norm1.weight", "norm1.bias", "mlp.fc1.weight", "mlp.fc1.bias"],
+    3: ["attn.qkv.weight", "attn.proj.weight", "attn.proj.bias"],
+}
+
+
+def trainable_keys(head_type):
+    keys = ["prompt_learner.learnable_tokens"]
+    for t in (1, 2, 3):
+        if head_type >= t:
+            keys += ["point_encoder.blocks.blocks.11." + k for k in TRAINABLE_TIERS[t]]
+    return keys
+
+
+def adamw_update(p, g, state, lr, betas=(0.9, 0.98), eps=1e-8, wd=0.1):
+    """torch.optim.AdamW single-tensor step (main_cls.py:58-60 hyper-parameters)."""
+    state["step"] = state.get("step", 0) + 1
+    m = state.setdefault("m", torch.zeros_like(p))
+    v = state.setdefault("v", torch.zeros_like(p))
+    t = state["step"]
+    p = p * (1 - lr * wd)
+    m.mul_(betas[0]).add_(g, alpha=1 - betas[0])
+    v.mul_(betas[1]).addcmul_(g, g, value=1 - betas[1])
+    denom = v.sqrt() / math.sqrt(1 - betas[1] ** t) + eps
+    return p - (lr / (1 - betas[0] ** t)) * m / denom
+
+
+def train_step(sd, pc, labels, fps_start, embedding, name_lengths, eot_pos, head_type=0,
+               position="middle", smoothing=0.2, lr=3e-3, dp_masks=None, opt_state=None,
+               train=True):
+    """One iteration of main_cls.py:179-214 (zero_grad, forward, CE, backward, AdamW, clamp).
+    Returns dict(logits, loss, grads{key}, new_params{key}, new_stats{key})."""
+    sd = dict(sd)
+    keys = trainable_keys(head_type)
+    for k in keys:
+        sd[k] = sd[k].detach().clone().requires_grad_(True)
+    new_stats = {}
+    logits = ulip_logits(sd, pc, fps_start, embedding, name_lengths, eot_pos, position,
+                         train=train, dp_masks=dp_masks, new_stats=new_stats)
+    loss = cross_entropy_ls(logits, labels, smoothing)
+    grads = torch.autograd.grad(loss, [sd[k] for k in keys])
+    opt_state = {} if opt_state is None else opt_state
+    new_params = {}
+    for k, g in zip(keys, grads):
+        new_params[k] = adamw_update(sd[k].detach(), g, opt_state.setdefault(k, {}), lr)
+    return dict(logits=logits.detach(), loss=loss.detach(), grads=dict(zip(keys, grads)),
+                new_params=new_params, new_stats=new_stats, opt_state=opt_state)
+
+
+def cosine_scheduler(base_value, final_value, epochs, niter_per_ep, warmup_epochs=0, start_warmup_value=0.0):
+    """utils/utils.py:253-264: linear warm-up then half-cosine, one value per iteration."""
+    warm = warmup_epochs * niter_per_ep
+    head = np.linspace(start_warmup_value, base_value, warm) if warmup_epochs > 0 else np.array([])
+    it = np.arange(epochs * niter_per_ep - warm)
+    tail = final_value + 0.5 * (base_value - final_value) * (1 + np.cos(np.pi * it / len(it)))
+    return np.concatenate((head, tail))

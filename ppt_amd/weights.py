@@ -1,0 +1,146 @@
+"""Deterministic, name-keyed synthetic weights for the ULIP + PointBERT state dict.
+
+No checkpoints exist in this environment (reference models/ULIP_models.py:474-485 loads
+./data/pretrained_models/pointbert.pt and ./data/initialize_models/slip_base_100ep.pt), so both
+the product and the oracle side of every test -- and bench.py -- draw the SAME values from this
+generator: every tensor is seeded by crc32(key) and produced with numpy's PCG64, which is
+identical on every machine.  Keys and shapes are the reference's.
+"""
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+
+TRANS_DIM, DEPTH, HEADS, ENC_DIM = 384, 12, 6, 256          # PointTransformer_8192point.yaml:15-25
+TXT_WIDTH, TXT_LAYERS, TXT_HEADS, CTX_LEN, EMBED = 512, 12, 8, 77, 512   # ULIP_models.py:456-459
+VOCAB = 49408
+
+
+def pointbert_spec(prefix="point_encoder."):
+    """(key, shape) list of PointTransformer.state_dict() (point_encoder.py:113-152)."""
+    p, s = prefix, []
+    s += [(p + "cls_token", (1, 1, TRANS_DIM)), (p + "cls_pos", (1, 1, TRANS_DIM))]
+    e = p + "encoder."
+    s += [(e + "first_conv.0.weight", (128, 3, 1)), (e + "first_conv.0.bias", (128,))]
+    s += [(e + "first_conv.1." + k, (128,)) for k in ("weight", "bias", "running_mean", "running_var")]
+    s += [(e + "first_conv.1.num_batches_tracked", ())]
+    s += [(e + "first_conv.3.weight", (256, 128, 1)), (e + "first_conv.3.bias", (256,))]
+    s += [(e + "second_conv.0.weight", (512, 512, 1)), (e + "second_conv.0.bias", (512,))]
+    s += [(e + "second_conv.1." + k, (512,)) for k in ("weight", "bias", "running_mean", "running_var")]
+    s += [(e + "second_conv.1.num_batches_tracked", ())]
+    s += [(e + "second_conv.3.weight", (ENC_DIM, 512, 1)), (e + "second_conv.3.bias", (ENC_DIM,))]
+    s += [(p + "reduce_dim.weight", (TRANS_DIM, ENC_DIM)), (p + "reduce_dim.bias", (TRANS_DIM,))]
+    s += [(p + "pos_embed.0.weight", (128, 3)), (p + "pos_embed.0.bias", (128,)),
+          (p + "pos_embed.2.weight", (TRANS_DIM, 128)), (p + "pos_embed.2.bias", (TRANS_DIM,))]
+    for i in range(DEPTH):
+        b = f"{p}blocks.blocks.{i}."
+        s += [(b + "norm1.weight", (TRANS_DIM,)), (b + "norm1.bias", (TRANS_DIM,)),
+              (b + "norm2.weight", (TRANS_DIM,)), (b + "norm2.bias", (TRANS_DIM,)),
+              (b + "mlp.fc1.weight", (4 * TRANS_DIM, TRANS_DIM)), (b + "mlp.fc1.bias", (4 * TRANS_DIM,)),
+              (b + "mlp.fc2.weight", (TRANS_DIM, 4 * TRANS_DIM)), (b + "mlp.fc2.bias", (TRANS_DIM,)),
+              (b + "attn.qkv.weight", (3 * TRANS_DIM, TRANS_DIM)),
+              (b + "attn.proj.weight", (TRANS_DIM, TRANS_DIM)), (b + "attn.proj.bias", (TRANS_DIM,))]
+    s += [(p + "norm.weight", (TRANS_DIM,)), (p + "norm.bias", (TRANS_DIM,))]
+    return s
+
+
+def ulip_spec(pc_feat_dims=768, with_token_embedding=True):
+    """(key, shape) list of ULIP_WITH_IMAGE.state_dict() minus the point encoder
+    (ULIP_models.py:154-201)."""
+    s = [("positional_embedding", (CTX_LEN, TXT_WIDTH)), ("text_projection", (TXT_WIDTH, EMBED)),
+         ("pc_projection", (pc_feat_dims, EMBED)), ("logit_scale", ())]
+    for i in range(TXT_LAYERS):
+        b = f"transformer.resblocks.{i}."
+        s += [(b + "attn.in_proj_weight", (3 * TXT_WIDTH, TXT_WIDTH)), (b + "attn.in_proj_bias", (3 * TXT_WIDTH,)),
+              (b + "attn.out_proj.weight", (TXT_WIDTH, TXT_WIDTH)), (b + "attn.out_proj.bias", (TXT_WIDTH,)),
+              (b + "ln_1.weight", (TXT_WIDTH,)), (b + "ln_1.bias", (TXT_WIDTH,)),
+              (b + "mlp.c_fc.weight", (4 * TXT_WIDTH, TXT_WIDTH)), (b + "mlp.c_fc.bias", (4 * TXT_WIDTH,)),
+              (b + "mlp.c_proj.weight", (TXT_WIDTH, 4 * TXT_WIDTH)), (b + "mlp.c_proj.bias", (TXT_WIDTH,)),
+              (b + "ln_2.weight", (TXT_WIDTH,)), (b + "ln_2.bias", (TXT_WIDTH,))]
+    if with_token_embedding:
+        s += [("token_embedding.weight", (VOCAB, TXT_WIDTH))]
+    s += [("ln_final.weight", (TXT_WIDTH,)), ("ln_final.bias", (TXT_WIDTH,))]
+    s += [("prompt_learner.learnable_tokens", (32, TXT_WIDTH))]
+    return s
+
+
+def _rng(key, seed):
+    return np.random.default_rng([zlib.crc32(key.encode()), seed])
+
+
+def synth_tensor(key, shape, seed=0):
+    """One synthetic tensor (numpy).  Scales are chosen so activations stay O(1) through the depth
+    of both towers (fan-in scaled weights), norm scales hover around 1 and every bias / running
+    statistic is non-trivial, so that a kernel that drops a bias, a gamma or an eps is caught."""
+    r = _rng(key, seed)
+    leaf = key.rsplit(".", 1)[-1]
+    if leaf == "num_batches_tracked":
+        return np.zeros((), np.int64)
+    if key == "logit_scale":
+        return np.asarray(np.log(1 / 0.07), np.float32)
+    if leaf == "running_mean":
+        return (0.1 * r.standard_normal(shape)).astype(np.float32)
+    if leaf == "running_var":
+        return (1.0 + 0.5 * r.random(shape)).astype(np.float32)
+    is_norm = any(t in key for t in (".norm1.", ".norm2.", ".norm.", ".ln_1.", ".ln_2.", "ln_final.",
+                                     "first_conv.1.", "second_conv.1.", "mlp_bns", ".bn"))
+    if is_norm and leaf == "weight":
+        return (1.0 + 0.1 * r.standard_normal(shape)).astype(np.float32)
+    if leaf in ("bias", "in_proj_bias"):
+        return (0.02 * r.standard_normal(shape)).astype(np.float32)
+    if key.endswith("cls_token") or key.endswith("cls_pos") or key == "token_embedding.weight" \
+            or key.endswith("learnable_tokens"):
+        return (0.02 * r.standard_normal(shape)).astype(np.float32)
+    if key == "positional_embedding":
+        return (0.01 * r.standard_normal(shape)).astype(np.float32)
+    if key == "prompt_learner.embedding":      # default nn.Embedding N(0,1) draws
+        return r.standard_normal(shape).astype(np.float32)
+    if key in ("text_projection", "pc_projection"):
+        return ((512 ** -0.5) * r.standard_normal(shape)).astype(np.float32)
+    fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else int(shape[0])
+    return ((fan_in ** -0.5) * r.standard_normal(shape)).astype(np.float32)
+
+
+def synth_state_dict(spec, seed=0, as_torch=True):
+    out = OrderedDict()
+    for key, shape in spec:
+        a = synth_tensor(key, shape, seed)
+        if as_torch:
+            import torch
+            a = torch.from_numpy(np.ascontiguousarray(a))
+        out[key] = a
+    return out
+
+
+def ulip_pointbert_state_dict(seed=0, with_token_embedding=False, n_ctx=32, as_torch=True):
+    """Full synthetic state dict for ULIP_PointBERT.  token_embedding.weight (25 M values, used
+    only at construction -- SURVEY Q1) is skipped unless asked for."""
+    spec = [(k, (n_ctx, TXT_WIDTH)) if k.endswith("learnable_tokens") else (k, s)
+            for k, s in ulip_spec(768, with_token_embedding)]
+    return synth_state_dict(spec + pointbert_spec(), seed, as_torch)
+
+
+def synth_prompt_embedding(num_classes, seed=0, as_torch=True):
+    """The frozen [C,77,512] token embeddings PromptLearner caches at construction
+    (ULIP_models.py:102; SURVEY Q1: N(0,1) draws, neither parameter nor buffer)."""
+    a = synth_tensor("prompt_learner.embedding", (num_classes, CTX_LEN, TXT_WIDTH), seed)
+    if as_torch:
+        import torch
+        a = torch.from_numpy(a)
+    return a
+
+
+def synth_clouds(B, N, seed=1234, duplicates=False):
+    """Synthetic unit-sphere clouds + labels + FPS start indices.
+    uniform [-1,1]^3, then per-cloud pc_normalize (centre, scale by max radius --
+    data/dataset_3d.py:33-38).  duplicates=True resamples every cloud with replacement
+    (ShapeNetPart loader behaviour, dataset_3d.py:752)."""
+    r = np.random.default_rng([seed, B, N])
+    pc = r.random((B, N, 3), dtype=np.float32) * 2 - 1
+    if duplicates:
+        sel = r.integers(0, N, size=(B, N))
+        pc = np.take_along_axis(pc, sel[:, :, None], axis=1)
+    pc = pc - pc.mean(axis=1, keepdims=True)
+    pc = pc / np.sqrt((pc ** 2).sum(-1)).max(axis=1)[:, None, None]
+    start = r.integers(0, N, size=(B,)).astype(np.int64)
+    return np.ascontiguousarray(pc.astype(np.float32)), start

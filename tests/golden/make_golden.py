@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by running the UPSTREAM REFERENCE
+(/root/reference, imported through tests/golden/ref_import.py) on deterministic synthetic
+inputs and weights (ppt_amd.weights).  Build container only; the fixtures (data: inputs are
+regenerated from seeds, expected outputs are stored) are committed, this script documents
+how they were made.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz and
+                                                  # ppt_amd/data/classnames.json
+
+While generating, every oracle function (oracle/oracle.py, oracle/ppt_oracle.c) is checked
+against the reference output; the script aborts if the oracle is off.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_import as R                     # noqa: E402
+from ppt_amd import weights as W           # noqa: E402
+from oracle import oracle as O             # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def sets_equal_or_tied(ref_idx, ora_idx, kth):
+    """neighbour sets equal, except rows whose k-th and (k+1)-th distances tie exactly."""
+    a = np.sort(ref_idx, -1)
+    b = np.sort(ora_idx, -1)
+    bad = (a != b).any(-1)
+    tied = kth[..., 0] == kth[..., 1]
+    return int((bad & ~tied).sum()), int(bad.sum()), int(tied.sum())
+
+
+def gen_tokens():
+    labels = json.load(open(os.path.join(R.REF_ROOT, "data", "labels.json")))
+    with R.reference_context():
+        from utils.tokenizer import SimpleTokenizer
+        tk = SimpleTokenizer()
+        names = {}
+        for ds, lst in labels.items():
+            for n in lst:
+                n2 = n.replace("_", " ")
+                names[n2] = tk.encode(n2)
+        out = {"_comment": "class lists = reference data/labels.json; token ids = reference "
+                           "utils/tokenizer.py SimpleTokenizer.encode(name) captured by "
+                           "tests/golden/make_golden.py (CLIP BPE; SURVEY.md §8(f) N3)",
+               "sot": tk.encoder["<|startoftext|>"], "eot": tk.encoder["<|endoftext|>"],
+               "placeholder": tk.encode("X")[0], "period": tk.encode(".")[0],
+               "datasets": labels, "name_tokens": names}
+        # sanity: full prompt tokenisation == our composition rule
+        for n2, ids in list(names.items())[:20]:
+            full = tk(" ".join(["X"] * 32) + " " + n2 + ".").tolist()
+            mine = [out["sot"]] + [out["placeholder"]] * 32 + ids + [out["period"], out["eot"]]
+            mine += [0] * (77 - len(mine))
+            assert full == mine, n2
+    os.makedirs(os.path.join(ROOT, "ppt_amd", "data"), exist_ok=True)
+    with open(os.path.join(ROOT, "ppt_amd", "data", "classnames.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    return out
+
+
+def gen_index():
+    """G1 FPS / G2 kNN / G3 ball-query fixtures from the reference's own functions."""
+    out = {}
+    with R.reference_context():
+        from models.pointbert import misc, dvae
+        from models.pointnet2 import pointnet2_utils as pn2
+        cases = [("a", 4, 1024, False), ("b", 2, 2048, True), ("c", 1, 8192, False)]
+        for tag, B, N, dup in cases:
+            pc, start = W.synth_clouds(B, N, seed=1234, duplicates=dup)
+            xyz = torch.from_numpy(pc)
+            orig = torch.randint
+            torch.randint = lambda *a, **k: torch.from_numpy(start)
+            try:
+                ref = misc.farthest_point_sample(xyz, 512).numpy()
+            finally:
+                torch.randint = orig
+            ora = O.fps(pc, 512, start)
+            assert np.array_equal(ref, ora), f"FPS oracle mismatch case {tag}"
+            out[f"fps_{tag}_idx"] = ref.astype(np.int16)
+            center = misc.index_points(xyz, torch.from_numpy(ref))
+            for k in (32, 4):
+                ridx = dvae.knn_point(k, xyz, center).numpy()
+                oidx, kth = O.knn(pc, center.numpy(), k)
+                hard, bad, tied = sets_equal_or_tied(ridx, oidx, kth)
+                print(f"knn {tag} k={k}: set mismatches {bad} (tied rows {tied}, non-tied mismatches {hard})")
+                assert hard == 0
+                out[f"knn_{tag}_k{k}"] = np.sort(ridx, -1).astype(np.int16)
+            # reference square_distance bit-identical to the C restatement
+            rd = dvae.square_distance(center, xyz).numpy()
+            od = O.square_distance(center.numpy(), pc)
+            print(f"square_distance {tag}: bit-identical = {np.array_equal(rd, od)}, "
+                  f"max|diff| = {np.abs(rd - od).max():.3e}, min = {rd.min():.3e}")
+            assert np.array_equal(rd, od)
+            if tag in ("a", "c"):
+                for r, K in ((0.1, 16), (0.2, 32), (0.4, 128)):
+                    rb = pn2.query_ball_point(r, K, xyz, center).numpy()
+                    ob = O.ball_query(pc, center.numpy(), r, K)
+                    assert np.array_equal(rb, ob), f"ball query mismatch {tag} r={r}"
+                    out[f"ball_{tag}_r{r}_K{K}"] = rb.astype(np.int16)
+    np.savez_compressed(os.path.join(HERE, "g_index.npz"), **out)
+    print("g_index.npz:", {k: v.shape for k, v in out.items()})
+
+
+def load_into_reference(m, sd, embedding):
+    msd = m.state_dict()
+    missing = [k for k in msd if k not in sd and k != "token_embedding.weight"]
+    assert not missing, missing
+    m.load_state_dict({k: v for k, v in sd.items() if k in msd}, strict=False)
+    m.prompt_learner.embedding = embedding.clone()
+
+
+def set_droppath(m, masks):
+    """Force the stub DropPath modules (ref_import) to use injected per-sample factors."""
+    for l, blk in enumerate(m.point_encoder.blocks.blocks):
+        mk = masks[l]
+        calls = {"n": 0}
+
+        def fwd(x, mk=mk, calls=calls):
+            f = mk[calls["n"] % 2]
+            calls["n"] += 1
+            return x * f.view(-1, 1, 1)
+        blk.drop_path.forward = fwd
+
+
+def gen_encoder_and_step(tok):
+    names = tok["datasets"]["modelnet40"]
+    name_lengths = [len(tok["name_tokens"][n.replace("_", " ")]) for n in names]
+    sd = W.ulip_pointbert_state_dict(seed=0)
+    emb = W.synth_prompt_embedding(len(names), seed=0)
+    B, N = 4, 1024
+    pc_np, start = W.synth_clouds(B, N, seed=77)
+    pc = torch.from_numpy(pc_np)
+    rng = np.random.default_rng(5)
+    labels = torch.from_numpy(rng.integers(0, len(names), size=(B,)))
+    rates = np.linspace(0, 0.1, 12)
+    masks = []
+    for l in range(12):
+        keep = 1.0 - rates[l]
+        row = []
+        for _ in range(2):
+            row.append(torch.from_numpy((np.floor(keep + rng.random(B)) / keep).astype(np.float32)))
+        masks.append(tuple(row))
+    # make sure at least one sample is actually dropped somewhere (else the fixture is weak)
+    masks[11] = (masks[11][0], torch.tensor([1 / 0.9, 0.0, 1 / 0.9, 1 / 0.9]))
+    masks[6] = (torch.tensor([0.0, 1 / (1 - rates[6]), 1 / (1 - rates[6]), 1 / (1 - rates[6])], dtype=torch.float32), masks[6][1])
+
+    for head_type in (0, 3):
+        m = R.build_reference_ulip_pointbert(names, head_type=head_type)
+        load_into_reference(m, sd, emb)
+        eot = m.tokenized_prompts.argmax(-1).numpy()
+        assert m.prompt_learner.name_lengths == name_lengths
+
+        if head_type == 0:
+            # ---- G4: mini-PointNet in eval and train BN modes (dvae.py:184-215)
+            cidx = O.fps(pc_np, 512, start)
+            _, nb, ce = O.group(pc_np, cidx, 32)
+            enc = {}
+            for mode in ("eval", "train"):
+                m.point_encoder.encoder.train(mode == "train")
+                m.load_state_dict({k: v for k, v in sd.items() if "running" in k or "num_batches" in k}, strict=False)
+                with torch.no_grad():
+                    ref = m.point_encoder.encoder(torch.from_numpy(nb))
+                ns = {}
+                with torch.no_grad():
+                    ora = O.mini_pointnet(sd, torch.from_numpy(nb), mode == "train", new_stats=ns)
+                err = (ref - ora).abs().max().item()
+                print(f"mini-PointNet {mode}: max|ref-oracle| = {err:.3e} (|ref|max {ref.abs().max():.3f})")
+                assert err < 2e-4
+                enc[f"{mode}_sub"] = ref[:, ::8].numpy()
+                enc[f"{mode}_sum"] = np.float64(ref.double().sum().item())
+                enc[f"{mode}_sqsum"] = np.float64((ref.double() ** 2).sum().item())
+                if mode == "train":
+                    msd = m.state_dict()
+                    for k, v in ns.items():
+                        r = msd[k]
+                        e = (r.float() - v.float()).abs().max().item()
+                        assert e < 1e-5, (k, e)
+                        enc["stat_" + k] = r.numpy()
+            np.savez_compressed(os.path.join(HERE, "g_encoder.npz"), **enc)
+            m.load_state_dict({k: v for k, v in sd.items() if "running" in k or "num_batches" in k}, strict=False)
+
+        # ---- G7: full train step (main_cls.py:179-214) with injected FPS starts + DropPath masks
+        m.train()
+        set_droppath(m, masks)
+        opt = torch.optim.AdamW([p for p in m.parameters()], lr=3e-3, betas=(0.9, 0.98), eps=1e-8,
+                                weight_decay=0.1)
+        crit = torch.nn.CrossEntropyLoss(label_smoothing=0.2)
+        orig = torch.randint
+        torch.randint = lambda *a, **k: torch.from_numpy(start)
+        try:
+            opt.zero_grad()
+            pred = m(pc)
+            loss = crit(pred, labels)
+            loss.backward(retain_graph=True)
+        finally:
+            torch.randint = orig
+        grads = {k: p.grad.clone() for k, p in m.named_parameters() if p.requires_grad}
+        opt.step()
+        newp = {k: p.detach().clone() for k, p in m.named_parameters() if p.requires_grad}
+        msd = m.state_dict()
+
+        res = O.train_step(sd, pc, labels, start, emb, name_lengths, eot, head_type=head_type,
+                           dp_masks=masks)
+        print(f"[h{head_type}] loss ref {loss.item():.6f} oracle {res['loss'].item():.6f}")
+        e = (pred.detach() - res["logits"]).abs().max().item()
+        print(f"[h{head_type}] logits max|diff| {e:.3e} (|logits|max {pred.abs().max().item():.2f})")
+        assert e < 5e-3 and abs(loss.item() - res["loss"].item()) < 1e-4
+        assert sorted(grads) == sorted(res["grads"]), (sorted(grads), sorted(res["grads"]))
+        fx = dict(logits=pred.detach().numpy(), loss=np.float32(loss.item()), labels=labels.numpy(),
+                  eot=eot.astype(np.int16), fps_start=start,
+                  dp_masks=np.stack([np.stack([a.numpy(), b.numpy()]) for a, b in masks]))
+        for k in grads:
+            g, go = grads[k], res["grads"][k]
+            rel = ((g - go).norm() / (g.norm() + 1e-30)).item()
+            # AdamW's first step is ~lr*sign(g): feed the oracle's update rule the REFERENCE gradient
+            # so that the optimiser restatement is pinned tightly, independent of gradient noise.
+            pe = (newp[k] - O.adamw_update(sd[k], g, {}, 3e-3)).abs().max().item()
+            print(f"[h{head_type}] grad {k}: |g| {g.norm().item():.3e} rel.err {rel:.2e}; post-AdamW max|diff| {pe:.2e}")
+            assert rel < 2e-3 and pe < 1e-6
+            if g.numel() <= 20000:
+                fx["grad_" + k] = g.numpy()
+                fx["new_" + k] = newp[k].numpy()
+            else:       # big matrices: a strided sub-block + norms
+                fx["gradsub_" + k] = g.flatten()[::97].numpy()
+                fx["newsub_" + k] = newp[k].flatten()[::97].numpy()
+                fx["gradnorm_" + k] = np.float64(g.double().norm().item())
+        for k, v in res["new_stats"].items():
+            ee = (msd[k].float() - v.float()).abs().max().item()
+            assert ee < 1e-5, (k, ee)
+            fx["stat_" + k] = msd[k].numpy()
+        np.savez_compressed(os.path.join(HERE, f"g_step_h{head_type}.npz"), **fx)
+
+        if head_type == 0:
+            # eval-mode forward (validate(), main_cls.py:237-299): running stats, no DropPath
+            m.load_state_dict({k: v for k, v in sd.items()}, strict=False)
+            m.prompt_learner.embedding = emb.clone()
+            m.eval()
+            for blk in m.point_encoder.blocks.blocks:
+                blk.drop_path.forward = lambda x: x
+            torch.randint = lambda *a, **k: torch.from_numpy(start)
+            try:
+                with torch.no_grad():
+                    pe_feat = m.point_encoder(pc)
+                    lg = m(pc)
+                    prompts = m.prompt_learner()
+                    te = m.encode_text(prompts, m.tokenized_prompts)
+            finally:
+                torch.randint = orig
+            aux = {}
+            with torch.no_grad():
+                lo = O.ulip_logits(sd, pc, start, emb, name_lengths, eot, train=False, aux=aux)
+                to = O.text_tower(sd, O.splice_prompts(emb, sd["prompt_learner.learnable_tokens"], name_lengths), eot)
+            print("eval: pc_feat diff", (pe_feat - aux["pc_feat"]).abs().max().item(),
+                  "text diff", (te - to).abs().max().item(), "logits diff", (lg - lo).abs().max().item())
+            assert (pe_feat - aux["pc_feat"]).abs().max().item() < 1e-3
+            assert (te - to).abs().max().item() < 1e-4
+            np.savez_compressed(os.path.join(HERE, "g_eval.npz"), pc_feat=pe_feat.numpy(),
+                                text_feat=te.numpy(), logits=lg.numpy(), prompts_sub=prompts[:, ::4, ::8].numpy())
+
+
+if __name__ == "__main__":
+    assert R.reference_available(), "needs /root/reference"
+    O.build_c_oracle(force=True)
+    tok = gen_tokens()
+    gen_index()
+    gen_encoder_and_step(tok)
+    print("done")
