@@ -1,0 +1,182 @@
+/*
+ * ppt_hip.h -- C ABI of libppt_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the PPT
+ * point-cloud encoder hot path.  The reference has NO native code on this
+ * path (it is a sequence of PyTorch ops); each entry point below therefore names the reference
+ * Python it replaces (file:line relative to the upstream repo) instead of an FFI symbol.
+ *
+ * Conventions:
+ *   - every pointer is a DEVICE pointer to a contiguous row-major array; the library never
+ *     allocates, frees or retains device memory -- outputs and workspaces are caller-owned;
+ *   - kernels are enqueued on the caller's stream (`stream` is a hipStream_t passed as void*;
+ *     NULL = the default stream); no device-wide synchronisation inside; graph-capturable;
+ *   - return 0 on success, a negative PPT_E* code otherwise (never exit(), never throws);
+ *     ppt_strerror() names the code;
+ *   - re-entrant and thread-safe (no global mutable state).
+ *   - `dtype`: PPT_BF16 = bf16 operands / fp32 accumulate on the MFMA pipes (performance mode),
+ *     PPT_F32 = fp32 operands on the fp32 MFMA / VALU (parity mode).  Index outputs are int64,
+ *     as in the reference.
+ */
+#ifndef PPT_HIP_H
+#define PPT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PPT_OK 0
+#define PPT_EINVAL (-1)   /* bad argument (shape, alignment, NULL pointer) */
+#define PPT_ELAUNCH (-2)  /* hipGetLastError() after launch reported a failure */
+#define PPT_EUNSUPPORTED (-3)
+
+#define PPT_F32 0
+#define PPT_BF16 1
+
+const char *ppt_strerror(int code);
+/* ABI version of this header; bumped on any signature change. */
+int ppt_abi_version(void);
+
+/* ---- H1: farthest point sampling ---------------------------------------------------------
+ * Replaces models/pointbert/misc.py:44-69 farthest_point_sample (+ the fps/index_points gather,
+ * misc.py:12-42) and its twins models/pointbert/pointnet2_utils.py:95-116,
+ * models/pointnet2/pointnet2_utils.py:63-84.  Bit-exact indices: distance ((dx*dx+dy*dy)+dz*dz)
+ * without FMA contraction, first-maximum tie rule (torch.max), start index injected.
+ *   xyz [B,N,3] f32, start [B] i64 -> out_idx [B,M] i64, out_xyz [B,M,3] f32 (may be NULL).
+ * One workgroup per cloud; points and running distances live in registers, the cloud's
+ * coordinates are never re-read from HBM.  N <= 16384. */
+int ppt_fps_f32(const float *xyz, int B, int N, int M, const int64_t *start, int64_t *out_idx,
+                float *out_xyz, void *stream);
+
+/* ---- H2: kNN grouping -----------------------------------------------------------------------
+ * Replaces models/pointbert/dvae.py:116-149 (knn_point + square_distance) and the gather /
+ * centre-subtract of Group.forward, dvae.py:171-180.  Expanded-form distances with the exact
+ * rounding sequence of the reference; the k nearest under the total order
+ * (distance, index), emitted in that order; the [B,G,N] distance matrix is never materialised.
+ *   xyz [B,N,3], center [B,G,3] -> nbr_idx [B,G,k] i64 (may be NULL),
+ *   neighborhood [B,G,k,3] f32 = xyz[nbr] - center (may be NULL).   k <= 64, k <= N <= 8192. */
+int ppt_knn_group_f32(const float *xyz, const float *center, int B, int N, int G, int k,
+                      int64_t *nbr_idx, float *neighborhood, void *stream);
+
+/* ---- H7: ball query ---------------------------------------------------------------------------
+ * Replaces models/pointnet2/pointnet2_utils.py:87-107 query_ball_point: first K indices in
+ * ascending order with d <= r^2 (expanded-form distance), padded with the first hit. */
+int ppt_ball_query_f32(const float *xyz, const float *center, int B, int N, int S, float radius_sq,
+                       int K, int64_t *idx, void *stream);
+
+/* ---- GEMM with fused prologue / epilogue ----------------------------------------------------
+ * C[M,N] = epilogue( prologue(A)[M,K] . B[N,K]^T ).  A and B are K-contiguous (torch Linear /
+ * k=1 Conv1d weight layout [out,in]).  Replaces every nn.Linear / Conv1d(k=1) on the path:
+ * models/pointbert/dvae.py:188-199, point_encoder.py:18-20,41-43,133,138-142,
+ * models/ULIP_models.py:38-46 (in_proj/out_proj/c_fc/c_proj), :222, :257, :281.
+ * bf16: v_mfma_f32_32x32x16_bf16, fp32 accumulate; f32: v_mfma_f32_32x32x2_f32.
+ */
+typedef struct ppt_gemm_params {
+    /* operands */
+    const void *A; int64_t lda;      /* [M,K] dtype (ignored when a_mode == PPT_A_CONV1) */
+    const void *B; int64_t ldb;      /* [N,K] dtype */
+    void *C; int64_t ldc;            /* [M,N] c_dtype (may be NULL when only pooled output wanted) */
+    int M, N, K;
+    int dtype;                       /* operand dtype of A and B */
+    int c_dtype;                     /* dtype of C */
+    /* A prologue */
+    int a_mode;                      /* PPT_A_PLAIN / PPT_A_AFFINE_RELU / PPT_A_CONV1 */
+    const float *a_scale;            /* [K]  AFFINE_RELU: a' = relu(a*scale[k]+shift[k]) (BatchNorm+ReLU) */
+    const float *a_shift;            /* [K] */
+    const float *pts;                /* CONV1: points [M,3] f32; a'[m][c] = relu(scale[c]*(w1[c].p_m + b1[c]) + shift[c]) */
+    const float *w1;                 /* CONV1: [K,3] f32 */
+    const float *b1;                 /* CONV1: [K] f32 */
+    /* epilogue, applied in this order */
+    const float *bias;               /* [N] f32 or NULL */
+    const float *group_add;          /* [M/group_rows, N] f32 or NULL: + group_add[m/group_rows][n] */
+    int group_rows;
+    int act;                         /* PPT_ACT_*: v = act(v); or, when dact_pre != NULL, v *= act'(dact_pre) instead */
+    const void *dact_pre;            /* [M,N] operand dtype or NULL: saved pre-activation (backward through act) */
+    int64_t ld_dact;
+    const float *row_scale;          /* [M/row_scale_rows] f32 or NULL (DropPath factor per sample) */
+    int row_scale_rows;
+    const float *residual;           /* [M,N] f32 or NULL: + residual (ld = ld_res) */
+    int64_t ld_res;
+    const float *residual2;          /* [M,N] f32 or NULL: + residual2 (positional embedding re-add) */
+    int64_t ld_res2;
+    /* side outputs */
+    void *C2; int64_t ldc2; int c2_dtype;  /* optional second copy of the result in another dtype */
+    float *col_sum;                  /* [ceil(M/64), N] partial per-column sums of the pre-activation... */
+    float *col_sqsum;                /* ... and sums of squares (BatchNorm batch statistics), or NULL */
+    void *pool_max;                  /* [M/32, N] pool_dtype: max over each 32-row group (mini-PointNet max-pool) */
+    int pool_dtype;
+    /* batching (blockIdx.z): pointer offsets in ELEMENTS per batch */
+    int batch; int64_t strideA, strideB, strideC;
+} ppt_gemm_params;
+
+#define PPT_A_PLAIN 0
+#define PPT_A_AFFINE_RELU 1
+#define PPT_A_CONV1 2
+
+#define PPT_ACT_NONE 0
+#define PPT_ACT_RELU 1
+#define PPT_ACT_GELU 2       /* exact erf GELU, point_encoder.py:17 */
+#define PPT_ACT_QUICKGELU 3  /* x*sigmoid(1.702x), ULIP_models.py:30-32 */
+
+int ppt_gemm(const ppt_gemm_params *p, void *stream);
+
+/* ---- LayerNorm --------------------------------------------------------------------------------
+ * Replaces nn.LayerNorm at point_encoder.py:65,69,152 and ULIP_models.py:21-27,39,46,176.
+ * fwd: xs = x (+ add); y = LN(xs)*w + b.  x, add, xs f32 [M,D] (xs may alias x, may be NULL);
+ *      y in `y_dtype`; mean/rstd [M] f32 saved for the backward (may be NULL).
+ *      add_rows > 0: `add` has add_rows rows and row m uses add[m % add_rows] (positional table).
+ * bwd: dx = LN'(dy); optional dw/db partials [ceil(M/rows_per_block), D] reduced by the caller. */
+int ppt_layernorm_fwd(const float *x, const float *add, int add_rows, float *xs, const float *w,
+                      const float *b, void *y, int y_dtype, float *mean, float *rstd, int M, int D,
+                      float eps, void *stream);
+int ppt_layernorm_bwd(const float *dy, const float *xs, const float *w, const float *mean,
+                      const float *rstd, float *dx, int accumulate_dx, float *dw_partial,
+                      float *db_partial, int partial_rows, int M, int D, void *stream);
+
+/* ---- Attention ---------------------------------------------------------------------------------
+ * softmax(scale * q k^T [+ causal mask]) v per (batch, head).  Replaces
+ * point_encoder.py:46-55 (scale after the product, non-causal, T=513) and nn.MultiheadAttention at
+ * ULIP_models.py:38,49-51 with the causal mask of :224-230 (L=77).
+ * qkv [Bt, T, 3, H, hd] packed as produced by the qkv / in_proj GEMM (row stride 3*H*hd);
+ * out [Bt, T, H*hd]; lse [Bt, H, T] f32 (log-sum-exp of the scaled scores, for the backward).
+ * hd == 64.  bf16: flash-style MFMA kernel; f32: VALU kernel (parity mode). */
+int ppt_attention_fwd(const void *qkv, void *out, float *lse, int Bt, int T, int H, int hd,
+                      float scale, int causal, int dtype, void *stream);
+/* dqkv [Bt,T,3,H,hd] (dtype) from dout [Bt,T,H*hd] (dtype); `delta` [Bt,H,T] f32 workspace. */
+int ppt_attention_bwd(const void *qkv, const void *out, const void *dout, const float *lse,
+                      float *delta, void *dqkv, int Bt, int T, int H, int hd, float scale,
+                      int causal, int dtype, void *stream);
+
+/* ---- mini-PointNet helpers -----------------------------------------------------------------------
+ * BatchNorm1d in train mode inside dvae.py:188-199.
+ * conv1_stats: per-channel partial sums of y = w1.p + b1 over all points (K=3 layer, VALU).
+ * bn_finalize: partial sums -> scale = g/sqrt(var+eps), shift = b - mean*scale; running-stat update
+ * (momentum 0.1, unbiased variance) when running_mean != NULL.  train == 0: scale/shift from the
+ * running statistics (eval mode), partials ignored. */
+int ppt_conv1_stats(const float *pts, int64_t M, const float *w1, const float *b1, int C,
+                    float *part_sum, float *part_sqsum, int *n_partials, void *stream);
+int ppt_bn_finalize(const float *part_sum, const float *part_sqsum, int n_partials, int64_t count,
+                    int C, const float *gamma, const float *beta, float eps, int train,
+                    float momentum, float *running_mean, float *running_var,
+                    int64_t *num_batches_tracked, float *scale, float *shift, void *stream);
+int ppt_conv1_stats_max_partials(int64_t M);
+
+/* ---- small fused ops ---------------------------------------------------------------------------
+ * pos_embed first layer + GELU (point_encoder.py:138-140): y[m][c] = gelu(w[c].p_m + b[c]), K=3. */
+int ppt_linear3_gelu(const float *pts, int64_t M, const float *w, const float *b, int C, void *y,
+                     int y_dtype, void *stream);
+/* point_encoder.py:251: out[b] = cat(x[b,0,:], max_t x[b,1:,:]) -> [B, 2D]; argmax [B,D] i32 for bwd. */
+int ppt_cls_max_pool(const void *x, int x_dtype, int B, int T, int D, float *out, int32_t *argmax,
+                     void *stream);
+/* dtype conversion / transposition helpers (weights are converted once, activations never). */
+int ppt_convert(const void *src, int src_dtype, void *dst, int dst_dtype, int64_t n, void *stream);
+int ppt_transpose(const void *src, int src_dtype, void *dst, int dst_dtype, int rows, int cols,
+                  void *stream);
+/* sum the [P, D] partial buffers produced by col_sum / dw_partial style outputs -> [D] */
+int ppt_reduce_rows(const float *partial, int P, int D, float *out, int accumulate, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPT_HIP_H */

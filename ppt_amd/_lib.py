@@ -1,0 +1,82 @@
+"""ctypes binding of libppt_hip.so (include/ppt_hip.h).  The product path has NO fallback: if
+the library is missing this raises, loudly, instead of computing anything on the CPU."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libppt_hip.so")
+_lib = None
+
+PPT_F32, PPT_BF16 = 0, 1
+A_PLAIN, A_AFFINE_RELU, A_CONV1 = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_QUICKGELU = 0, 1, 2, 3
+
+c_void_p, c_int, c_int64, c_float, c_size_t = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                               ctypes.c_float, ctypes.c_size_t)
+
+
+class GemmParams(ctypes.Structure):
+    """struct ppt_gemm_params (include/ppt_hip.h) -- field order must match the header."""
+    _fields_ = [
+        ("A", c_void_p), ("lda", c_int64), ("B", c_void_p), ("ldb", c_int64),
+        ("C", c_void_p), ("ldc", c_int64), ("M", c_int), ("N", c_int), ("K", c_int),
+        ("dtype", c_int), ("c_dtype", c_int),
+        ("a_mode", c_int), ("a_scale", c_void_p), ("a_shift", c_void_p), ("pts", c_void_p),
+        ("w1", c_void_p), ("b1", c_void_p),
+        ("bias", c_void_p), ("group_add", c_void_p), ("group_rows", c_int), ("act", c_int),
+        ("dact_pre", c_void_p), ("ld_dact", c_int64),
+        ("row_scale", c_void_p), ("row_scale_rows", c_int),
+        ("residual", c_void_p), ("ld_res", c_int64), ("residual2", c_void_p), ("ld_res2", c_int64),
+        ("C2", c_void_p), ("ldc2", c_int64), ("c2_dtype", c_int),
+        ("col_sum", c_void_p), ("col_sqsum", c_void_p), ("pool_max", c_void_p), ("pool_dtype", c_int),
+        ("batch", c_int), ("strideA", c_int64), ("strideB", c_int64), ("strideC", c_int64),
+    ]
+
+
+_SIGNATURES = {
+    "ppt_abi_version": (c_int, []),
+    "ppt_fps_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ppt_knn_group_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "ppt_ball_query_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
+    "ppt_gemm": (c_int, [ctypes.POINTER(GemmParams), c_void_p]),
+    "ppt_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                  c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "ppt_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                  c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ppt_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int,
+                                  c_int, c_void_p]),
+    "ppt_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                  c_int, c_int, c_float, c_int, c_int, c_void_p]),
+    "ppt_conv1_stats": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                ctypes.POINTER(c_int), c_void_p]),
+    "ppt_conv1_stats_max_partials": (c_int, [c_int64]),
+    "ppt_bn_finalize": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_float, c_int,
+                                c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ppt_linear3_gelu": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "ppt_cls_max_pool": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "ppt_convert": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
+    "ppt_transpose": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ppt_reduce_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension is not built (run `python -m ppt_amd.build` "
+                "or __graft_entry__.build()).  ppt_amd has no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        L.ppt_strerror.restype = ctypes.c_char_p
+        L.ppt_strerror.argtypes = [c_int]
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(code, what=""):
+    if code != 0:
+        raise RuntimeError(f"libppt_hip: {what} failed: {lib().ppt_strerror(code).decode()} ({code})")

@@ -1,0 +1,15 @@
+// api.hip -- error strings / ABI version of libppt_hip.so.
+#include "ppt_common.h"
+
+extern "C" const char *ppt_strerror(int code)
+{
+    switch (code) {
+    case PPT_OK: return "ok";
+    case PPT_EINVAL: return "invalid argument (shape, alignment or NULL pointer)";
+    case PPT_ELAUNCH: return "kernel launch failed (hipGetLastError)";
+    case PPT_EUNSUPPORTED: return "unsupported configuration";
+    default: return "unknown ppt error";
+    }
+}
+
+extern "C" int ppt_abi_version(void) { return 1; }

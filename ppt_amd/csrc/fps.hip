@@ -1,0 +1,132 @@
+// fps.hip -- H1: farthest point sampling for gfx950.
+//
+// Replaces the Python loop of models/pointbert/misc.py:44-69 (5 ATen launches x M iterations).
+// One workgroup per cloud.  Every thread keeps PPT points (x,y,z) AND their running minimum
+// distance in VGPRs for the whole kernel, so the cloud is read from HBM exactly once
+// (12*N bytes) and the M dependent steps touch no memory but 32 B of LDS per wave:
+//
+//   per step:  PPT distance updates / thread            (VALU, ((dx*dx+dy*dy)+dz*dz), no FMA)
+//              wave arg-max via two 6-stage DPP reductions (max distance bits, then min index)
+//              owner lane publishes {dist, idx, x, y, z} to an LDS slot  (parity double-buffered)
+//              ONE s_barrier; every thread folds the W slots redundantly.
+//
+// Tie rule = torch.max: the FIRST maximal index.  Distances are >= +0, so their IEEE bit patterns
+// are monotone as unsigned integers and the arg-max is an integer max followed by an integer min
+// over the tied lanes' indices.
+#include "ppt_common.h"
+
+namespace {
+
+struct __align__(16) fps_slot {
+    uint32_t dist_bits;
+    uint32_t idx;
+    float x, y;
+    float z;
+    uint32_t pad[3];
+};
+
+template <int PPT, int W>
+__global__ __launch_bounds__(W * 64) void fps_kernel(const float *__restrict__ xyz, int N, int M,
+                                                     const int64_t *__restrict__ start,
+                                                     int64_t *__restrict__ out_idx,
+                                                     float *__restrict__ out_xyz)
+{
+    constexpr int T = W * 64;
+    extern __shared__ __align__(16) unsigned char smem[];
+    fps_slot *slots = reinterpret_cast<fps_slot *>(smem);                 // [2][W]
+    int32_t *idx_list = reinterpret_cast<int32_t *>(smem + sizeof(fps_slot) * 2 * W);
+    float *xyz_list = reinterpret_cast<float *>(idx_list + M);           // [M][3]
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int b = blockIdx.x;
+    const float *p = xyz + (size_t)b * N * 3;
+
+    float px[PPT], py[PPT], pz[PPT], dist[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int i = t + j * T;
+        if (i < N) {
+            px[j] = p[i * 3 + 0]; py[j] = p[i * 3 + 1]; pz[j] = p[i * 3 + 2];
+            dist[j] = 1e10f;                      // misc.py:57
+        } else {
+            px[j] = py[j] = pz[j] = 0.0f;
+            dist[j] = 0.0f;                       // padding: never beats a real point (index >= N loses ties)
+        }
+    }
+
+    int cur = (int)start[b];
+    float cx = p[cur * 3 + 0], cy = p[cur * 3 + 1], cz = p[cur * 3 + 2];
+
+    for (int it = 0; it < M; ++it) {
+        if (t == 0) {
+            idx_list[it] = cur;
+            xyz_list[it * 3 + 0] = cx; xyz_list[it * 3 + 1] = cy; xyz_list[it * 3 + 2] = cz;
+        }
+        float best = -1.0f, bx = 0.f, by = 0.f, bz = 0.f;
+        uint32_t bi = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const float dx = __fsub_rn(px[j], cx), dy = __fsub_rn(py[j], cy), dz = __fsub_rn(pz[j], cz);
+            const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+            const float nd = fminf(dist[j], d);   // misc.py:66
+            dist[j] = nd;
+            if (nd > best) {                      // strict: lowest j (= lowest index of this thread) wins ties
+                best = nd; bi = (uint32_t)(t + j * T); bx = px[j]; by = py[j]; bz = pz[j];
+            }
+        }
+        const uint32_t bits = __float_as_uint(best);
+        const uint32_t wmax = wave_reduce_umax(bits);
+        const uint32_t widx = wave_reduce_umin(bits == wmax ? bi : 0xFFFFFFFFu);
+        fps_slot *sl = slots + (it & 1) * W;
+        if (bits == wmax && bi == widx) {         // exactly one lane per wave
+            sl[w].dist_bits = wmax; sl[w].idx = widx; sl[w].x = bx; sl[w].y = by; sl[w].z = bz;
+        }
+        __syncthreads();
+        uint32_t gd = sl[0].dist_bits, gi = sl[0].idx;
+        float gx = sl[0].x, gy = sl[0].y, gz = sl[0].z;
+#pragma unroll
+        for (int k = 1; k < W; ++k) {
+            const uint32_t d2 = sl[k].dist_bits, i2 = sl[k].idx;
+            const bool take = d2 > gd || (d2 == gd && i2 < gi);
+            if (take) { gd = d2; gi = i2; gx = sl[k].x; gy = sl[k].y; gz = sl[k].z; }
+        }
+        cur = (int)gi; cx = gx; cy = gy; cz = gz;
+        (void)lane;
+    }
+    __syncthreads();
+    for (int i = t; i < M; i += T) out_idx[(size_t)b * M + i] = (int64_t)idx_list[i];
+    if (out_xyz)
+        for (int i = t; i < M * 3; i += T) out_xyz[(size_t)b * M * 3 + i] = xyz_list[i];
+}
+
+template <int PPT, int W>
+int launch_fps(const float *xyz, int B, int N, int M, const int64_t *start, int64_t *out_idx,
+               float *out_xyz, hipStream_t s)
+{
+    const size_t lds = sizeof(fps_slot) * 2 * W + (size_t)M * 4 + (size_t)M * 12;
+    if (lds > 160 * 1024) return PPT_EUNSUPPORTED;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute((const void *)fps_kernel<PPT, W>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return PPT_ELAUNCH;
+    }
+    hipLaunchKernelGGL((fps_kernel<PPT, W>), dim3(B), dim3(W * 64), lds, s, xyz, N, M, start, out_idx, out_xyz);
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
+}  // namespace
+
+extern "C" int ppt_fps_f32(const float *xyz, int B, int N, int M, const int64_t *start, int64_t *out_idx,
+                           float *out_xyz, void *stream)
+{
+    if (!xyz || !start || !out_idx || B <= 0 || N <= 0 || M <= 0 || N > 16384) return PPT_EINVAL;
+    hipStream_t s = ppt_stream(stream);
+    if (N <= 256) return launch_fps<1, 4>(xyz, B, N, M, start, out_idx, out_xyz, s);
+    if (N <= 512) return launch_fps<2, 4>(xyz, B, N, M, start, out_idx, out_xyz, s);
+    if (N <= 1024) return launch_fps<4, 4>(xyz, B, N, M, start, out_idx, out_xyz, s);
+    if (N <= 2048) return launch_fps<4, 8>(xyz, B, N, M, start, out_idx, out_xyz, s);
+    if (N <= 4096) return launch_fps<8, 8>(xyz, B, N, M, start, out_idx, out_xyz, s);
+    if (N <= 8192) return launch_fps<8, 16>(xyz, B, N, M, start, out_idx, out_xyz, s);
+    return launch_fps<16, 16>(xyz, B, N, M, start, out_idx, out_xyz, s);
+}

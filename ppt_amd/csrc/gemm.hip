@@ -1,0 +1,352 @@
+// gemm.hip -- C[M,N] = epilogue( prologue(A)[M,K] . B[N,K]^T ) on the gfx950 matrix cores.
+//
+// One kernel family serves every nn.Linear / Conv1d(k=1) of the path (see include/ppt_hip.h):
+//   * 128x128 output tile per 256-thread workgroup, 4 waves as 2x2, each wave 64x64 =
+//     2x2 MFMA tiles of 32x32 (v_mfma_f32_32x32x16_bf16, or v_mfma_f32_32x32x2_f32 in parity mode),
+//     fp32 accumulators in registers;
+//   * K is walked in 128-BYTE slabs (64 bf16 / 32 f32) so both dtypes share one LDS image:
+//     [128 rows][8 x 16-B chunks], chunk index XOR-swizzled with (row>>1)&7, which makes the
+//     ds_read_b128 fragment reads of the 32x32x16 operand conflict-free;
+//   * register-staged double buffering: the global loads of slab t+1 are issued before the MFMAs
+//     of slab t and written to the other LDS buffer afterwards -> one barrier per slab.  Staging
+//     through registers (rather than LDS-DMA) is what lets the A operand be TRANSFORMED on the way
+//     in: BatchNorm+ReLU of the previous layer (A_AFFINE_RELU) or the whole K=3 first conv of the
+//     mini-PointNet (A_CONV1) never touch HBM;
+//   * epilogue on the accumulator registers: bias, per-group additive term, activation or its
+//     derivative, DropPath row scale, up to two residual adds, a second output copy, BatchNorm
+//     column statistics and the 32-row max-pool of the mini-PointNet (one MFMA row-tile == one
+//     kNN group, so the pool is 15 v_max + one cross-half exchange).
+#include "ppt_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+constexpr int BM = 128, BN = 128, ROWB = 128, NT = 256;
+constexpr int TILE_BYTES = BM * ROWB;   // 16 KiB per operand per stage
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+__device__ __forceinline__ float act_fwd(float v, int act)
+{
+    switch (act) {
+    case PPT_ACT_RELU: return fmaxf(v, 0.0f);
+    case PPT_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+    case PPT_ACT_QUICKGELU: return v / (1.0f + __expf(-1.702f * v));
+    default: return v;
+    }
+}
+__device__ __forceinline__ float act_bwd(float x, int act)   // d act(x) / dx
+{
+    switch (act) {
+    case PPT_ACT_RELU: return x > 0.0f ? 1.0f : 0.0f;
+    case PPT_ACT_GELU: {
+        const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+        return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+    }
+    case PPT_ACT_QUICKGELU: {
+        const float s = 1.0f / (1.0f + __expf(-1.702f * x));
+        return s * (1.0f + 1.702f * x * (1.0f - s));
+    }
+    default: return 1.0f;
+    }
+}
+
+template <typename T> __device__ __forceinline__ float load_as_f32(const void *p, int64_t i);
+template <> __device__ __forceinline__ float load_as_f32<float>(const void *p, int64_t i) { return ((const float *)p)[i]; }
+template <> __device__ __forceinline__ float load_as_f32<bf16_t>(const void *p, int64_t i) { return bf16_to_f32(((const bf16_t *)p)[i]); }
+
+__device__ __forceinline__ void store_dt(void *p, int dtype, int64_t i, float v)
+{
+    if (dtype == PPT_BF16) ((bf16_t *)p)[i] = f32_to_bf16(v);
+    else ((float *)p)[i] = v;
+}
+
+// ---- A / B slab loaders ---------------------------------------------------------------------
+// thread t owns chunk column ch = t&7 of rows (t>>3) + 32*i, i = 0..3, in every slab.
+template <typename T> struct Stage { uint4 v[4]; };
+
+template <typename T>
+__device__ __forceinline__ void load_plain(Stage<T> &st, const T *base, int64_t ld, int rows, int K, int r0, int k0)
+{
+    constexpr int EPC = 16 / sizeof(T);
+    const int t = threadIdx.x, ch = t & 7;
+    const int k = k0 + ch * EPC;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + (t >> 3) + 32 * i;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r < rows && k < K) v = *reinterpret_cast<const uint4 *>(base + (int64_t)r * ld + k);
+        st.v[i] = v;
+    }
+}
+
+template <typename T> __device__ __forceinline__ void affine_relu_chunk(uint4 &v, const float *sc, const float *sh);
+template <>
+__device__ __forceinline__ void affine_relu_chunk<bf16_t>(uint4 &v, const float *sc, const float *sh)
+{
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float lo = fmaxf(fmaf(__uint_as_float(w[e] << 16), sc[2 * e], sh[2 * e]), 0.0f);
+        const float hi = fmaxf(fmaf(__uint_as_float(w[e] & 0xFFFF0000u), sc[2 * e + 1], sh[2 * e + 1]), 0.0f);
+        w[e] = pack_bf16x2(lo, hi);
+    }
+    v = make_uint4(w[0], w[1], w[2], w[3]);
+}
+template <>
+__device__ __forceinline__ void affine_relu_chunk<float>(uint4 &v, const float *sc, const float *sh)
+{
+    float f[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f[e] = fmaxf(fmaf(f[e], sc[e], sh[e]), 0.0f);
+    v = make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+}
+
+template <typename T, int A_MODE>
+__device__ __forceinline__ void load_A(Stage<T> &st, const ppt_gemm_params &p, const T *A, int m0, int k0)
+{
+    constexpr int EPC = 16 / sizeof(T);
+    const int t = threadIdx.x, ch = t & 7;
+    const int k = k0 + ch * EPC;
+    if constexpr (A_MODE == PPT_A_PLAIN) {
+        load_plain<T>(st, A, p.lda, p.M, p.K, m0, k0);
+    } else if constexpr (A_MODE == PPT_A_AFFINE_RELU) {
+        load_plain<T>(st, A, p.lda, p.M, p.K, m0, k0);
+        if (k < p.K) {
+            float sc[EPC], sh[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) { sc[e] = p.a_scale[k + e]; sh[e] = p.a_shift[k + e]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = m0 + (t >> 3) + 32 * i;
+                if (r < p.M) affine_relu_chunk<T>(st.v[i], sc, sh);   // rows >= M stay zero
+            }
+        }
+    } else {   // PPT_A_CONV1: a'[m][c] = relu(scale[c]*(w1[c].p_m + b1[c]) + shift[c]), c = k index
+        float wx[EPC], wy[EPC], wz[EPC], wb[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const int c = k + e;
+            if (c < p.K) {
+                const float s = p.a_scale ? p.a_scale[c] : 1.0f;
+                const float h = p.a_shift ? p.a_shift[c] : 0.0f;
+                wx[e] = s * p.w1[c * 3 + 0]; wy[e] = s * p.w1[c * 3 + 1]; wz[e] = s * p.w1[c * 3 + 2];
+                wb[e] = fmaf(s, p.b1[c], h);
+            } else { wx[e] = wy[e] = wz[e] = 0.f; wb[e] = 0.f; }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = m0 + (t >> 3) + 32 * i;
+            float f[EPC];
+            if (r < p.M) {
+                const float x = p.pts[(int64_t)r * 3 + 0], y = p.pts[(int64_t)r * 3 + 1], z = p.pts[(int64_t)r * 3 + 2];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) f[e] = fmaxf(fmaf(wz[e], z, fmaf(wy[e], y, fmaf(wx[e], x, wb[e]))), 0.0f);
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) f[e] = 0.f;
+            }
+            if constexpr (sizeof(T) == 2)
+                st.v[i] = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]),
+                                     pack_bf16x2(f[6], f[7]));
+            else
+                st.v[i] = make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]),
+                                     __float_as_uint(f[3]));
+        }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void write_stage(const Stage<T> &st, unsigned char *tile)
+{
+    const int t = threadIdx.x, ch = t & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (t >> 3) + 32 * i;
+        *reinterpret_cast<uint4 *>(tile + lds_off(row, ch)) = st.v[i];
+    }
+}
+
+// ---- one 128-byte K slab of MFMAs for this wave's 64x64 -------------------------------------
+template <typename T>
+__device__ __forceinline__ void mma_slab(const unsigned char *As, const unsigned char *Bs, int wm, int wn, int lane,
+                                         f32x16_t (&acc)[2][2])
+{
+    const int r = lane & 31, h = lane >> 5;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8_t a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(As + lds_off(wm * 64 + i * 32 + r, kk * 2 + h)));
+                b[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(Bs + lds_off(wn * 64 + i * 32 + r, kk * 2 + h)));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const int kq = 2 * kk + h;      // k index (in floats) inside the 32-float slab
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *reinterpret_cast<const float *>(As + lds_off(wm * 64 + i * 32 + r, kq >> 2) + (kq & 3) * 4);
+                b[i] = *reinterpret_cast<const float *>(Bs + lds_off(wn * 64 + i * 32 + r, kq >> 2) + (kq & 3) * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+}
+
+template <typename T, int A_MODE>
+__global__ __launch_bounds__(NT, 2) void gemm_kernel(const ppt_gemm_params p)
+{
+    __shared__ __align__(16) unsigned char smem[4 * TILE_BYTES];   // A0 A1 B0 B1
+    constexpr int BK = ROWB / sizeof(T);
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    const T *A = reinterpret_cast<const T *>(p.A) + (int64_t)blockIdx.z * p.strideA;
+    const T *B = reinterpret_cast<const T *>(p.B) + (int64_t)blockIdx.z * p.strideB;
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nslab = (p.K + BK - 1) / BK;
+    Stage<T> sa, sb;
+    load_A<T, A_MODE>(sa, p, A, m0, 0);
+    load_plain<T>(sb, B, p.ldb, p.N, p.K, n0, 0);
+    write_stage<T>(sa, smem);
+    write_stage<T>(sb, smem + 2 * TILE_BYTES);
+    __syncthreads();
+    for (int s = 0; s < nslab; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < nslab) {
+            load_A<T, A_MODE>(sa, p, A, m0, (s + 1) * BK);
+            load_plain<T>(sb, B, p.ldb, p.N, p.K, n0, (s + 1) * BK);
+        }
+        mma_slab<T>(smem + cur * TILE_BYTES, smem + (2 + cur) * TILE_BYTES, wm, wn, lane, acc);
+        if (s + 1 < nslab) {
+            write_stage<T>(sa, smem + (cur ^ 1) * TILE_BYTES);
+            write_stage<T>(sb, smem + (2 + (cur ^ 1)) * TILE_BYTES);
+        }
+        __syncthreads();
+    }
+
+    // ---------------- epilogue ----------------
+    // The operand tiles are dead (the loop ends on a barrier): every wave parks its 64x64 fp32
+    // accumulators in its own 16 KiB of LDS, row-major, and walks them row by row with lane == column.
+    // That turns the MFMA C layout (column on the lane, rows scattered over 16 registers) into
+    // full-row 128/256-byte global stores, makes the BatchNorm column sums and the 32-row max-pool
+    // plain per-lane running values, and keeps the flag-driven epilogue body out of the unroller.
+    float *ct = reinterpret_cast<float *>(smem) + w * (64 * 64);
+    {
+        const int h = lane >> 5, cl = lane & 31;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ct[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 64 + j * 32 + cl] = acc[i][j][r];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    const int n = n0 + wn * 64 + lane;
+    const bool nok = n < p.N;
+    const int mw = m0 + wm * 64;
+    const float bias = (p.bias && nok) ? p.bias[n] : 0.0f;
+    const int64_t zc = (int64_t)blockIdx.z * p.strideC;
+    float csum = 0.f, csq = 0.f, pmax = -INFINITY;
+#pragma unroll 1
+    for (int rr = 0; rr < 64; ++rr) {
+        const int m = mw + rr;
+        if (m >= p.M) break;                    // wave-uniform
+        if (nok) {
+            float v = ct[rr * 64 + lane] + bias;
+            if (p.group_add) v += p.group_add[(int64_t)(m / p.group_rows) * p.N + n];
+            csum += v; csq += v * v;
+            if (p.dact_pre) {                   // backward through an activation: * act'(saved pre-activation)
+                const float x = p.dtype == PPT_BF16 ? load_as_f32<bf16_t>(p.dact_pre, (int64_t)m * p.ld_dact + n)
+                                                     : load_as_f32<float>(p.dact_pre, (int64_t)m * p.ld_dact + n);
+                v *= act_bwd(x, p.act);
+            } else {
+                v = act_fwd(v, p.act);
+            }
+            if (p.row_scale) v *= p.row_scale[m / p.row_scale_rows];
+            if (p.residual) v += p.residual[(int64_t)m * p.ld_res + n];
+            if (p.residual2) v += p.residual2[(int64_t)m * p.ld_res2 + n];
+            if (p.C) store_dt(p.C, p.c_dtype, zc + (int64_t)m * p.ldc + n, v);
+            if (p.C2) store_dt(p.C2, p.c2_dtype, (int64_t)m * p.ldc2 + n, v);
+            pmax = fmaxf(pmax, v);
+        }
+        if (p.pool_max && (rr & 31) == 31) {
+            if (nok) store_dt(p.pool_max, p.pool_dtype, (int64_t)(m >> 5) * p.N + n, pmax);
+            pmax = -INFINITY;
+        }
+    }
+    if (p.col_sum && nok && mw < p.M) {
+        const int prow = (m0 >> 6) + wm;
+        p.col_sum[(int64_t)prow * p.N + n] = csum;
+        p.col_sqsum[(int64_t)prow * p.N + n] = csq;
+    }
+}
+
+template <typename T>
+int launch_gemm(const ppt_gemm_params &p, hipStream_t s)
+{
+    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.batch > 0 ? p.batch : 1);
+    if (grid.y > 65535 || grid.z > 65535) return PPT_EUNSUPPORTED;
+    switch (p.a_mode) {
+    case PPT_A_PLAIN: hipLaunchKernelGGL((gemm_kernel<T, PPT_A_PLAIN>), grid, dim3(NT), 0, s, p); break;
+    case PPT_A_AFFINE_RELU: hipLaunchKernelGGL((gemm_kernel<T, PPT_A_AFFINE_RELU>), grid, dim3(NT), 0, s, p); break;
+    case PPT_A_CONV1: hipLaunchKernelGGL((gemm_kernel<T, PPT_A_CONV1>), grid, dim3(NT), 0, s, p); break;
+    default: return PPT_EINVAL;
+    }
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
+}  // namespace
+
+extern "C" int ppt_gemm(const ppt_gemm_params *pp, void *stream)
+{
+    if (!pp) return PPT_EINVAL;
+    const ppt_gemm_params &p = *pp;
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || !p.B) return PPT_EINVAL;
+    if (p.dtype != PPT_F32 && p.dtype != PPT_BF16) return PPT_EINVAL;
+    const int epc = p.dtype == PPT_BF16 ? 8 : 4;
+    if (p.K % epc || p.ldb % epc || ((uintptr_t)p.B & 15)) return PPT_EINVAL;
+    if (p.a_mode == PPT_A_CONV1) {
+        if (!p.pts || !p.w1 || !p.b1) return PPT_EINVAL;
+    } else {
+        if (!p.A || p.lda % epc || ((uintptr_t)p.A & 15)) return PPT_EINVAL;
+        if (p.a_mode == PPT_A_AFFINE_RELU && (!p.a_scale || !p.a_shift)) return PPT_EINVAL;
+    }
+    if ((p.col_sum == nullptr) != (p.col_sqsum == nullptr)) return PPT_EINVAL;
+    if (p.group_add && p.group_rows <= 0) return PPT_EINVAL;
+    if (p.row_scale && p.row_scale_rows <= 0) return PPT_EINVAL;
+    if (p.batch > 1 && (p.C2 || p.col_sum || p.pool_max || p.residual || p.residual2 || p.dact_pre || p.group_add))
+        return PPT_EUNSUPPORTED;
+    hipStream_t s = ppt_stream(stream);
+    return p.dtype == PPT_BF16 ? launch_gemm<bf16_t>(p, s) : launch_gemm<float>(p, s);
+}

@@ -1,0 +1,118 @@
+// misc.hip -- small memory-bound helpers: cls/max pooling head (point_encoder.py:251), dtype
+// conversion, transposition (weight preparation and the dW operands), partial-row reduction.
+#include "ppt_common.h"
+
+namespace {
+
+template <typename TX>
+__global__ void cls_max_pool_kernel(const TX *__restrict__ x, int T, int D, float *__restrict__ out,
+                                    int32_t *__restrict__ argmax)
+{
+    const int b = blockIdx.x;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        const TX *xb = x + (size_t)b * T * D + d;
+        out[(size_t)b * 2 * D + d] = dt<TX>::load(xb);
+        float best = -INFINITY;
+        int bi = 1;
+        for (int t = 1; t < T; ++t) {
+            const float v = dt<TX>::load(xb + (size_t)t * D);
+            if (v > best) { best = v; bi = t; }     // first maximum, as torch.max
+        }
+        out[(size_t)b * 2 * D + D + d] = best;
+        if (argmax) argmax[(size_t)b * D + d] = bi;
+    }
+}
+
+template <typename TS, typename TD>
+__global__ void convert_kernel(const TS *__restrict__ s, TD *__restrict__ d, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dt<TD>::store(d + i, dt<TS>::load(s + i));
+}
+
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void transpose_kernel(const TS *__restrict__ s, TD *__restrict__ d, int rows, int cols)
+{
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? dt<TS>::load(s + (size_t)r * cols + c) : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;            // output row = c, output col = r
+        if (c < cols && r < rows) dt<TD>::store(d + (size_t)c * rows + r, tile[tx][i]);
+    }
+}
+
+__global__ void reduce_rows_kernel(const float *__restrict__ part, int P, int D, float *__restrict__ out, int accumulate)
+{
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    double s = 0.0;
+    for (int p = 0; p < P; ++p) s += (double)part[(size_t)p * D + d];
+    out[d] = accumulate ? out[d] + (float)s : (float)s;
+}
+
+template <typename TS>
+int convert_from(const void *src, void *dst, int dd, int64_t n, hipStream_t s)
+{
+    const unsigned grid = (unsigned)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    if (dd == PPT_BF16) hipLaunchKernelGGL((convert_kernel<TS, bf16_t>), dim3(grid), dim3(256), 0, s, (const TS *)src, (bf16_t *)dst, n);
+    else if (dd == PPT_F32) hipLaunchKernelGGL((convert_kernel<TS, float>), dim3(grid), dim3(256), 0, s, (const TS *)src, (float *)dst, n);
+    else return PPT_EINVAL;
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
+template <typename TS>
+int transpose_from(const void *src, void *dst, int dd, int rows, int cols, hipStream_t s)
+{
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32);
+    if (dd == PPT_BF16) hipLaunchKernelGGL((transpose_kernel<TS, bf16_t>), grid, dim3(256), 0, s, (const TS *)src, (bf16_t *)dst, rows, cols);
+    else if (dd == PPT_F32) hipLaunchKernelGGL((transpose_kernel<TS, float>), grid, dim3(256), 0, s, (const TS *)src, (float *)dst, rows, cols);
+    else return PPT_EINVAL;
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
+}  // namespace
+
+extern "C" int ppt_cls_max_pool(const void *x, int x_dtype, int B, int T, int D, float *out, int32_t *argmax, void *stream)
+{
+    if (!x || !out || B <= 0 || T < 2 || D <= 0) return PPT_EINVAL;
+    if (x_dtype == PPT_F32)
+        hipLaunchKernelGGL(cls_max_pool_kernel<float>, dim3(B), dim3(128), 0, ppt_stream(stream), (const float *)x, T, D, out, argmax);
+    else if (x_dtype == PPT_BF16)
+        hipLaunchKernelGGL(cls_max_pool_kernel<bf16_t>, dim3(B), dim3(128), 0, ppt_stream(stream), (const bf16_t *)x, T, D, out, argmax);
+    else
+        return PPT_EINVAL;
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
+extern "C" int ppt_convert(const void *src, int src_dtype, void *dst, int dst_dtype, int64_t n, void *stream)
+{
+    if (!src || !dst || n <= 0) return PPT_EINVAL;
+    if (src_dtype == PPT_F32) return convert_from<float>(src, dst, dst_dtype, n, ppt_stream(stream));
+    if (src_dtype == PPT_BF16) return convert_from<bf16_t>(src, dst, dst_dtype, n, ppt_stream(stream));
+    return PPT_EINVAL;
+}
+
+extern "C" int ppt_transpose(const void *src, int src_dtype, void *dst, int dst_dtype, int rows, int cols, void *stream)
+{
+    if (!src || !dst || rows <= 0 || cols <= 0) return PPT_EINVAL;
+    if (src_dtype == PPT_F32) return transpose_from<float>(src, dst, dst_dtype, rows, cols, ppt_stream(stream));
+    if (src_dtype == PPT_BF16) return transpose_from<bf16_t>(src, dst, dst_dtype, rows, cols, ppt_stream(stream));
+    return PPT_EINVAL;
+}
+
+extern "C" int ppt_reduce_rows(const float *partial, int P, int D, float *out, int accumulate, void *stream)
+{
+    if (!partial || !out || P <= 0 || D <= 0) return PPT_EINVAL;
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((D + 127) / 128), dim3(128), 0, ppt_stream(stream), partial, P, D, out, accumulate);
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}

@@ -1,0 +1,148 @@
+// norm.hip -- LayerNorm forward / backward (point_encoder.py:65,69,152; ULIP_models.py:21-27).
+// One wave per token row (D <= 1024): the row lives in registers, mean and variance are the
+// two-pass forms the reference computes, reductions are wave-wide shuffles -- no LDS, no barrier.
+// The forward optionally fuses the `x + pos` of TransformerEncoder.forward (point_encoder.py:103)
+// and of encode_text (ULIP_models.py:210), writing the updated residual stream back.
+#include "ppt_common.h"
+
+namespace {
+
+constexpr int MAX_EPL = 16;   // elements per lane -> D <= 1024
+
+template <typename TY>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x, const float *__restrict__ add,
+                                                     int add_rows, float *__restrict__ xs,
+                                                     const float *__restrict__ w, const float *__restrict__ b,
+                                                     TY *__restrict__ y, float *__restrict__ mean_out,
+                                                     float *__restrict__ rstd_out, int M, int D, float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float *xr = x + (size_t)row * D;
+    const float *ar = add ? add + (size_t)(add_rows > 0 ? row % add_rows : row) * D : nullptr;
+    float v[MAX_EPL];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAX_EPL; ++j) {
+        const int e = lane + 64 * j;
+        float t = 0.f;
+        if (e < D) { t = xr[e]; if (ar) t += ar[e]; }
+        v[j] = t; s += t;
+    }
+    const float mean = wave_reduce_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAX_EPL; ++j) {
+        const int e = lane + 64 * j;
+        const float d = e < D ? v[j] - mean : 0.f;
+        q += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(wave_reduce_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int j = 0; j < MAX_EPL; ++j) {
+        const int e = lane + 64 * j;
+        if (e < D) {
+            if (xs) xs[(size_t)row * D + e] = v[j];
+            dt<TY>::store(y + (size_t)row * D + e, (v[j] - mean) * rstd * w[e] + b[e]);
+        }
+    }
+    if (lane == 0) {
+        if (mean_out) mean_out[row] = mean;
+        if (rstd_out) rstd_out[row] = rstd;
+    }
+}
+
+// wave g handles rows [g*rpw, (g+1)*rpw); dw/db partial row g.
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ xs,
+                                                     const float *__restrict__ w, const float *__restrict__ mean,
+                                                     const float *__restrict__ rstd, float *__restrict__ dx,
+                                                     int accumulate, float *__restrict__ dw_part,
+                                                     float *__restrict__ db_part, int rpw, int M, int D)
+{
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int r0 = g * rpw, r1 = min(M, r0 + rpw);
+    if (r0 >= M) return;
+    float wv[MAX_EPL], dwa[MAX_EPL], dba[MAX_EPL];
+#pragma unroll
+    for (int j = 0; j < MAX_EPL; ++j) {
+        const int e = lane + 64 * j;
+        wv[j] = e < D ? w[e] : 0.f;
+        dwa[j] = 0.f; dba[j] = 0.f;
+    }
+    for (int row = r0; row < r1; ++row) {
+        const float mu = mean[row], rs = rstd[row];
+        float gv[MAX_EPL], xh[MAX_EPL];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAX_EPL; ++j) {
+            const int e = lane + 64 * j;
+            float d = 0.f, xhat = 0.f;
+            if (e < D) { d = dy[(size_t)row * D + e]; xhat = (xs[(size_t)row * D + e] - mu) * rs; }
+            dwa[j] += d * xhat; dba[j] += d;
+            gv[j] = d * wv[j]; xh[j] = xhat;
+            s1 += gv[j]; s2 += gv[j] * xhat;
+        }
+        s1 = wave_reduce_sum(s1) / (float)D;
+        s2 = wave_reduce_sum(s2) / (float)D;
+#pragma unroll
+        for (int j = 0; j < MAX_EPL; ++j) {
+            const int e = lane + 64 * j;
+            if (e < D) {
+                const float r = rs * (gv[j] - s1 - xh[j] * s2);
+                float *o = dx + (size_t)row * D + e;
+                *o = accumulate ? *o + r : r;
+            }
+        }
+    }
+    if (dw_part) {
+#pragma unroll
+        for (int j = 0; j < MAX_EPL; ++j) {
+            const int e = lane + 64 * j;
+            if (e < D) { dw_part[(size_t)g * D + e] = dwa[j]; db_part[(size_t)g * D + e] = dba[j]; }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ppt_layernorm_fwd(const float *x, const float *add, int add_rows, float *xs, const float *w,
+                                 const float *b, void *y, int y_dtype, float *mean, float *rstd, int M, int D,
+                                 float eps, void *stream)
+{
+    if (!x || !w || !b || !y || M <= 0 || D <= 0 || D > 64 * MAX_EPL) return PPT_EINVAL;
+    dim3 grid((M + 3) / 4);
+    if (y_dtype == PPT_BF16)
+        hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, dim3(256), 0, ppt_stream(stream), x, add, add_rows, xs, w, b,
+                           (bf16_t *)y, mean, rstd, M, D, eps);
+    else if (y_dtype == PPT_F32)
+        hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, dim3(256), 0, ppt_stream(stream), x, add, add_rows, xs, w, b,
+                           (float *)y, mean, rstd, M, D, eps);
+    else
+        return PPT_EINVAL;
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
+extern "C" int ppt_layernorm_bwd(const float *dy, const float *xs, const float *w, const float *mean,
+                                 const float *rstd, float *dx, int accumulate_dx, float *dw_partial,
+                                 float *db_partial, int partial_rows, int M, int D, void *stream)
+{
+    if (!dy || !xs || !w || !mean || !rstd || !dx || M <= 0 || D <= 0 || D > 64 * MAX_EPL) return PPT_EINVAL;
+    if ((dw_partial == nullptr) != (db_partial == nullptr)) return PPT_EINVAL;
+    if (dw_partial && partial_rows <= 0) return PPT_EINVAL;
+    const int waves = dw_partial ? partial_rows : M;
+    const int rpw = (M + waves - 1) / waves;
+    // every partial row must be written (rows past the data get zeros from an empty range): the
+    // kernel returns early for empty ranges, so clear the tail partial rows here.
+    const int used = (M + rpw - 1) / rpw;
+    if (dw_partial && used < partial_rows) {
+        (void)hipMemsetAsync(dw_partial + (size_t)used * D, 0, sizeof(float) * (size_t)(partial_rows - used) * D, ppt_stream(stream));
+        (void)hipMemsetAsync(db_partial + (size_t)used * D, 0, sizeof(float) * (size_t)(partial_rows - used) * D, ppt_stream(stream));
+    }
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3((used + 3) / 4), dim3(256), 0, ppt_stream(stream), dy, xs, w, mean, rstd, dx,
+                       accumulate_dx, dw_partial, db_partial, rpw, M, D);
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}

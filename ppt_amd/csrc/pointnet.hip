@@ -1,0 +1,125 @@
+// pointnet.hip -- BatchNorm bookkeeping of the mini-PointNet (dvae.py:188-199) and the K=3 layers.
+//
+// model.train() keeps the "frozen" tokenizer's BatchNorm layers in batch-statistics mode
+// (SURVEY.md App. A Q3), which puts two global reductions inside the GEMM chain:
+//   BN1: statistics of y1 = w1.p + b1 (K=3) -- ppt_conv1_stats recomputes y1 on the VALU from the
+//        12-byte points (y1 itself is never stored: the conv2 GEMM rebuilds it in its A prologue);
+//   BN2: statistics of the 512-wide conv3 output -- produced by the GEMM epilogue (col_sum/col_sqsum).
+// Both land in [partials, C] fp32 buffers; ppt_bn_finalize folds them in fp64 (deterministic, no
+// atomics), emits the per-channel affine (scale, shift) the next GEMM applies on its A operand and
+// updates running_mean / running_var / num_batches_tracked exactly as nn.BatchNorm1d does.
+#include "ppt_common.h"
+
+namespace {
+
+constexpr int STAT_ROWS = 2048;   // points per partial
+
+__global__ __launch_bounds__(256) void conv1_stats_kernel(const float *__restrict__ pts, int64_t M,
+                                                          const float *__restrict__ w1, const float *__restrict__ b1,
+                                                          int C, float *__restrict__ psum, float *__restrict__ psq)
+{
+    __shared__ float P[STAT_ROWS * 3];
+    const int64_t r0 = (int64_t)blockIdx.x * STAT_ROWS;
+    const int nrow = (int)min((int64_t)STAT_ROWS, M - r0);
+    for (int i = threadIdx.x; i < nrow * 3; i += blockDim.x) P[i] = pts[r0 * 3 + i];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float wx = w1[c * 3 + 0], wy = w1[c * 3 + 1], wz = w1[c * 3 + 2], wb = b1[c];
+        float s = 0.f, q = 0.f;
+        for (int r = 0; r < nrow; ++r) {
+            const float y = fmaf(wz, P[r * 3 + 2], fmaf(wy, P[r * 3 + 1], fmaf(wx, P[r * 3 + 0], wb)));
+            s += y; q = fmaf(y, y, q);
+        }
+        psum[(size_t)blockIdx.x * C + c] = s;
+        psq[(size_t)blockIdx.x * C + c] = q;
+    }
+}
+
+__global__ void bn_finalize_kernel(const float *__restrict__ psum, const float *__restrict__ psq, int P, double count,
+                                   int C, const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                   int train, float momentum, float *__restrict__ rmean, float *__restrict__ rvar,
+                                   int64_t *__restrict__ nbt, float *__restrict__ scale, float *__restrict__ shift)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float mean_f, var_f;
+    if (train) {
+        double s = 0.0, q = 0.0;
+        for (int p = 0; p < P; ++p) { s += (double)psum[(size_t)p * C + c]; q += (double)psq[(size_t)p * C + c]; }
+        const double mean = s / count;
+        double var = q / count - mean * mean;           // biased variance normalises (nn.BatchNorm1d)
+        if (var < 0.0) var = 0.0;
+        mean_f = (float)mean; var_f = (float)var;
+        if (rmean) {
+            const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+            rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean_f;
+            rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (float)unbiased;
+            if (c == 0 && nbt) *nbt += 1;
+        }
+    } else {
+        mean_f = rmean[c]; var_f = rvar[c];
+    }
+    const float sc = gamma[c] / sqrtf(var_f + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - mean_f * sc;
+}
+
+template <typename TY>
+__global__ __launch_bounds__(256) void linear3_gelu_kernel(const float *__restrict__ pts, int64_t M,
+                                                           const float *__restrict__ w, const float *__restrict__ b,
+                                                           int C, TY *__restrict__ y)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * C) return;
+    const int64_t m = i / C;
+    const int c = (int)(i % C);
+    const float v = fmaf(w[c * 3 + 2], pts[m * 3 + 2], fmaf(w[c * 3 + 1], pts[m * 3 + 1], fmaf(w[c * 3 + 0], pts[m * 3 + 0], b[c])));
+    dt<TY>::store(y + i, 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)));
+}
+
+}  // namespace
+
+extern "C" int ppt_conv1_stats_max_partials(int64_t M) { return (int)((M + STAT_ROWS - 1) / STAT_ROWS); }
+
+extern "C" int ppt_conv1_stats(const float *pts, int64_t M, const float *w1, const float *b1, int C, float *part_sum,
+                               float *part_sqsum, int *n_partials, void *stream)
+{
+    if (!pts || !w1 || !b1 || !part_sum || !part_sqsum || M <= 0 || C <= 0) return PPT_EINVAL;
+    const int P = ppt_conv1_stats_max_partials(M);
+    if (n_partials) *n_partials = P;
+    hipLaunchKernelGGL(conv1_stats_kernel, dim3(P), dim3(256), 0, ppt_stream(stream), pts, M, w1, b1, C, part_sum,
+                       part_sqsum);
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
+extern "C" int ppt_bn_finalize(const float *part_sum, const float *part_sqsum, int n_partials, int64_t count, int C,
+                               const float *gamma, const float *beta, float eps, int train, float momentum,
+                               float *running_mean, float *running_var, int64_t *num_batches_tracked, float *scale,
+                               float *shift, void *stream)
+{
+    if (!gamma || !beta || !scale || !shift || C <= 0) return PPT_EINVAL;
+    if (train && (!part_sum || !part_sqsum || n_partials <= 0 || count <= 0)) return PPT_EINVAL;
+    if (!train && (!running_mean || !running_var)) return PPT_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, ppt_stream(stream), part_sum, part_sqsum,
+                       n_partials, (double)count, C, gamma, beta, eps, train, momentum, running_mean, running_var,
+                       num_batches_tracked, scale, shift);
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
+extern "C" int ppt_linear3_gelu(const float *pts, int64_t M, const float *w, const float *b, int C, void *y, int y_dtype,
+                                void *stream)
+{
+    if (!pts || !w || !b || !y || M <= 0 || C <= 0) return PPT_EINVAL;
+    const int64_t n = M * C;
+    dim3 grid((unsigned)((n + 255) / 256));
+    if (y_dtype == PPT_BF16)
+        hipLaunchKernelGGL(linear3_gelu_kernel<bf16_t>, grid, dim3(256), 0, ppt_stream(stream), pts, M, w, b, C, (bf16_t *)y);
+    else if (y_dtype == PPT_F32)
+        hipLaunchKernelGGL(linear3_gelu_kernel<float>, grid, dim3(256), 0, ppt_stream(stream), pts, M, w, b, C, (float *)y);
+    else
+        return PPT_EINVAL;
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}

@@ -1,0 +1,104 @@
+// ppt_common.h -- shared device helpers for the gfx950 kernels of libppt_hip.so.
+// gfx950 only: wave64, DPP row_bcast, MFMA 32x32x16 bf16.  No portability layer on purpose.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ppt_hip.h"
+
+#define PPT_WAVE 64
+
+#define PPT_CHECK_LAUNCH()                                  \
+    do {                                                    \
+        hipError_t e__ = hipGetLastError();                 \
+        if (e__ != hipSuccess) return PPT_ELAUNCH;          \
+    } while (0)
+
+typedef uint16_t bf16_t;   // raw bf16 bits
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even; NaN stays NaN through the plain cast path hipcc lowers to v_cvt_pk_bf16_f32
+__device__ __forceinline__ bf16_t f32_to_bf16(float f)
+{
+    __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, h);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi)
+{
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+template <typename T> struct dt;
+template <> struct dt<float> {
+    static __device__ __forceinline__ float load(const float *p) { return *p; }
+    static __device__ __forceinline__ void store(float *p, float v) { *p = v; }
+    static constexpr int code = PPT_F32;
+};
+template <> struct dt<bf16_t> {
+    static __device__ __forceinline__ float load(const bf16_t *p) { return bf16_to_f32(*p); }
+    static __device__ __forceinline__ void store(bf16_t *p, float v) { *p = f32_to_bf16(v); }
+    static constexpr int code = PPT_BF16;
+};
+
+// ---- wave64 reductions over DPP (no LDS, no ds_bpermute) -----------------------------------
+// butterfly inside each row of 16 lanes, then row_bcast15 / row_bcast31 fold the four rows;
+// lane 63 ends with the full result, which v_readlane turns into a wave-uniform SGPR value.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+
+#define PPT_DEFINE_WAVE_REDUCE(NAME, OP)                                        \
+    __device__ __forceinline__ uint32_t NAME(uint32_t v)                        \
+    {                                                                           \
+        v = OP(v, dpp_mov<0xB1, 0xf>(v));  /* quad_perm [1,0,3,2] */             \
+        v = OP(v, dpp_mov<0x4E, 0xf>(v));  /* quad_perm [2,3,0,1] */             \
+        v = OP(v, dpp_mov<0x141, 0xf>(v)); /* row_half_mirror     */             \
+        v = OP(v, dpp_mov<0x140, 0xf>(v)); /* row_mirror          */             \
+        v = OP(v, dpp_mov<0x142, 0xa>(v)); /* row_bcast15 -> rows 1,3 */         \
+        v = OP(v, dpp_mov<0x143, 0xc>(v)); /* row_bcast31 -> rows 2,3 */         \
+        return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);                 \
+    }
+
+__device__ __forceinline__ uint32_t ppt_umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t ppt_umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+PPT_DEFINE_WAVE_REDUCE(wave_reduce_umax, ppt_umax)
+PPT_DEFINE_WAVE_REDUCE(wave_reduce_umin, ppt_umin)
+
+__device__ __forceinline__ float wave_reduce_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_reduce_max(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// ---- the reference's expanded-form squared distance ---------------------
+// dvae.py:146-148:  ((-2 * dot) + |src|^2) + |dst|^2, dot = fma(a2,b2, fma(a1,b1, a0*b0)),
+// |a|^2 = (x*x + y*y) + z*z; every step rounded to fp32 -- explicit _rn intrinsics so that no
+// compiler flag can contract or reassociate them.
+__device__ __forceinline__ float sqnorm3_rn(float x, float y, float z)
+{
+    return __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
+}
+__device__ __forceinline__ float expanded_sqdist_rn(float qx, float qy, float qz, float nq, float px,
+                                                    float py, float pz, float np)
+{
+    const float dot = __fmaf_rn(qz, pz, __fmaf_rn(qy, py, __fmul_rn(qx, px)));
+    return __fadd_rn(__fadd_rn(__fmul_rn(-2.0f, dot), nq), np);
+}
+// order-preserving map float -> uint32 (handles the slightly negative distances of the expanded form)
+__device__ __forceinline__ uint32_t float_order_key(float f)
+{
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+static inline hipStream_t ppt_stream(void *s) { return (hipStream_t)s; }

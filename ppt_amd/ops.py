@@ -1,0 +1,262 @@
+"""Thin torch-tensor wrappers over the C ABI of libppt_hip.so (include/ppt_hip.h).
+
+PyTorch is plumbing here: it owns device memory (caching allocator) and the stream; every
+operation below is ONE call into a hand-written gfx950 kernel.  Tensors must be CUDA(HIP),
+contiguous, of the stated dtype; wrappers allocate outputs and raise RuntimeError on any error
+code.  There is no CPU path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, A_AFFINE_RELU, A_CONV1, A_PLAIN,
+                   PPT_BF16, PPT_F32, GemmParams)
+
+_DT = {torch.float32: PPT_F32, torch.bfloat16: PPT_BF16}
+_TORCH_DT = {PPT_F32: torch.float32, PPT_BF16: torch.bfloat16}
+
+
+def dtype_code(t):
+    return _DT[t.dtype if isinstance(t, torch.Tensor) else t]
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _chk(t, dtype=None, name="tensor"):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a CUDA/HIP tensor (ppt_amd has no CPU path)")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected {dtype}, got {t.dtype}")
+
+
+# ---------------------------------------------------------------------------------------------
+def fps(xyz, M, start):
+    """H1.  xyz [B,N,3] f32, start [B] i64 -> (idx [B,M] i64, center [B,M,3] f32)."""
+    _chk(xyz, torch.float32, "xyz"); _chk(start, torch.int64, "start")
+    B, N, _ = xyz.shape
+    idx = torch.empty((B, M), dtype=torch.int64, device=xyz.device)
+    ctr = torch.empty((B, M, 3), dtype=torch.float32, device=xyz.device)
+    _lib.check(_lib.lib().ppt_fps_f32(_p(xyz), B, N, M, _p(start), _p(idx), _p(ctr), _stream()), "ppt_fps_f32")
+    return idx, ctr
+
+
+def knn_group(xyz, center, k, want_idx=True, want_nbhd=True):
+    """H2.  xyz [B,N,3], center [B,G,3] -> (nbr_idx [B,G,k] i64, neighborhood [B,G,k,3] f32)."""
+    _chk(xyz, torch.float32, "xyz"); _chk(center, torch.float32, "center")
+    B, N, _ = xyz.shape
+    G = center.shape[1]
+    idx = torch.empty((B, G, k), dtype=torch.int64, device=xyz.device) if want_idx else None
+    nb = torch.empty((B, G, k, 3), dtype=torch.float32, device=xyz.device) if want_nbhd else None
+    _lib.check(_lib.lib().ppt_knn_group_f32(_p(xyz), _p(center), B, N, G, k, _p(idx), _p(nb), _stream()),
+               "ppt_knn_group_f32")
+    return idx, nb
+
+
+def ball_query(xyz, center, radius, K):
+    """H7.  -> idx [B,S,K] i64 (query_ball_point semantics)."""
+    _chk(xyz, torch.float32, "xyz"); _chk(center, torch.float32, "center")
+    B, N, _ = xyz.shape
+    S = center.shape[1]
+    idx = torch.empty((B, S, K), dtype=torch.int64, device=xyz.device)
+    import numpy as np
+    r2 = float(np.float32(radius * radius))
+    _lib.check(_lib.lib().ppt_ball_query_f32(_p(xyz), _p(center), B, N, S, r2, K, _p(idx), _stream()),
+               "ppt_ball_query_f32")
+    return idx
+
+
+# ---------------------------------------------------------------------------------------------
+def gemm(A, B, *, out=None, out_dtype=None, M=None, bias=None, act=ACT_NONE, dact_pre=None,
+         group_add=None, group_rows=0, row_scale=None, row_scale_rows=0, residual=None,
+         residual2=None, out2=None, col_stats=None, pool_max=None,
+         a_mode=A_PLAIN, a_scale=None, a_shift=None, pts=None, w1=None, b1=None, want_out=True):
+    """C[M,N] = epilogue(prologue(A)[M,K] @ B[N,K]^T) -- see struct ppt_gemm_params.
+    A [M,K] (or None with a_mode=A_CONV1 and pts [M,3]); B [N,K]; 2-D, last-dim contiguous
+    (row stride may exceed K).  Returns out (or None when want_out=False)."""
+    p = GemmParams()
+    N, K = B.shape
+    if a_mode == A_CONV1:
+        M = pts.shape[0]
+        dev = pts.device
+    else:
+        M = A.shape[0] if M is None else M
+        dev = A.device
+        assert A.shape[1] == K and A.stride(1) == 1 and A.dtype == B.dtype
+        p.A, p.lda = _p(A), A.stride(0)
+    assert B.stride(1) == 1
+    p.B, p.ldb = _p(B), B.stride(0)
+    p.M, p.N, p.K = M, N, K
+    p.dtype = dtype_code(B)
+    if out is None and want_out:
+        out = torch.empty((M, N), dtype=out_dtype or B.dtype, device=dev)
+    if out is not None:
+        assert out.stride(1) == 1
+        p.C, p.ldc, p.c_dtype = _p(out), out.stride(0), dtype_code(out)
+    p.a_mode = a_mode
+    p.a_scale, p.a_shift, p.pts, p.w1, p.b1 = _p(a_scale), _p(a_shift), _p(pts), _p(w1), _p(b1)
+    p.bias = _p(bias)
+    p.group_add, p.group_rows = _p(group_add), group_rows
+    p.act = act
+    if dact_pre is not None:
+        assert dact_pre.dtype == B.dtype and dact_pre.stride(1) == 1
+        p.dact_pre, p.ld_dact = _p(dact_pre), dact_pre.stride(0)
+    p.row_scale, p.row_scale_rows = _p(row_scale), row_scale_rows
+    if residual is not None:
+        assert residual.dtype == torch.float32 and residual.stride(-1) == 1
+        p.residual, p.ld_res = _p(residual), residual.stride(-2)
+    if residual2 is not None:
+        assert residual2.dtype == torch.float32 and residual2.stride(-1) == 1
+        p.residual2, p.ld_res2 = _p(residual2), residual2.stride(-2)
+    if out2 is not None:
+        p.C2, p.ldc2, p.c2_dtype = _p(out2), out2.stride(-2), dtype_code(out2)
+    if col_stats is not None:
+        p.col_sum, p.col_sqsum = _p(col_stats[0]), _p(col_stats[1])
+    if pool_max is not None:
+        p.pool_max, p.pool_dtype = _p(pool_max), dtype_code(pool_max)
+    p.batch = 1
+    _lib.check(_lib.lib().ppt_gemm(ctypes.byref(p), _stream()), "ppt_gemm")
+    return out
+
+
+def layernorm_fwd(x, w, b, y_dtype, add=None, add_rows=0, write_xs=None, save_stats=False, eps=1e-5):
+    """y = LN(x (+ add)); x f32 [..., D].  write_xs: f32 tensor receiving x+add (may be x itself).
+    Returns (y, mean, rstd)."""
+    _chk(x, torch.float32, "x")
+    D = x.shape[-1]
+    M = x.numel() // D
+    y = torch.empty(x.shape, dtype=y_dtype, device=x.device)
+    mean = torch.empty((M,), dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = torch.empty((M,), dtype=torch.float32, device=x.device) if save_stats else None
+    _lib.check(_lib.lib().ppt_layernorm_fwd(_p(x), _p(add), add_rows, _p(write_xs), _p(w), _p(b), _p(y),
+                                            dtype_code(y), _p(mean), _p(rstd), M, D, eps, _stream()),
+               "ppt_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, xs, w, mean, rstd, dx=None, accumulate=False, want_wgrad=False, partial_rows=256):
+    """-> (dx, dw, db).  dx f32; accumulate=True adds into the given dx."""
+    _chk(dy, torch.float32, "dy"); _chk(xs, torch.float32, "xs")
+    D = xs.shape[-1]
+    M = xs.numel() // D
+    if dx is None:
+        dx = torch.empty_like(xs)
+        accumulate = False
+    dwp = dbp = None
+    if want_wgrad:
+        dwp = torch.empty((partial_rows, D), dtype=torch.float32, device=xs.device)
+        dbp = torch.empty((partial_rows, D), dtype=torch.float32, device=xs.device)
+    _lib.check(_lib.lib().ppt_layernorm_bwd(_p(dy), _p(xs), _p(w), _p(mean), _p(rstd), _p(dx), int(accumulate),
+                                            _p(dwp), _p(dbp), partial_rows, M, D, _stream()), "ppt_layernorm_bwd")
+    if want_wgrad:
+        return dx, reduce_rows(dwp), reduce_rows(dbp)
+    return dx, None, None
+
+
+def attention_fwd(qkv, Bt, T, H, scale, causal, want_lse=True):
+    """qkv [Bt*T, 3*H*64] -> out [Bt*T, H*64], lse [Bt,H,T] f32."""
+    _chk(qkv, None, "qkv")
+    out = torch.empty((Bt * T, H * 64), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((Bt, H, T), dtype=torch.float32, device=qkv.device) if want_lse else None
+    _lib.check(_lib.lib().ppt_attention_fwd(_p(qkv), _p(out), _p(lse), Bt, T, H, 64, scale, int(causal),
+                                            dtype_code(qkv), _stream()), "ppt_attention_fwd")
+    return out, lse
+
+
+def attention_bwd(qkv, out, dout, lse, Bt, T, H, scale, causal):
+    _chk(qkv, None, "qkv"); _chk(out, qkv.dtype, "out"); _chk(dout, qkv.dtype, "dout")
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((Bt, H, T), dtype=torch.float32, device=qkv.device)
+    _lib.check(_lib.lib().ppt_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), Bt, T, H, 64,
+                                            scale, int(causal), dtype_code(qkv), _stream()), "ppt_attention_bwd")
+    return dqkv
+
+
+def conv1_stats(pts, w1, b1):
+    """partial (sum, sumsq) of y = w1.p + b1 over points [M,3] -> ([P,C], [P,C])."""
+    _chk(pts, torch.float32, "pts")
+    M = pts.shape[0]
+    C = w1.shape[0]
+    P = _lib.lib().ppt_conv1_stats_max_partials(M)
+    ps = torch.empty((P, C), dtype=torch.float32, device=pts.device)
+    pq = torch.empty((P, C), dtype=torch.float32, device=pts.device)
+    n = ctypes.c_int(0)
+    _lib.check(_lib.lib().ppt_conv1_stats(_p(pts), M, _p(w1), _p(b1), C, _p(ps), _p(pq), ctypes.byref(n), _stream()),
+               "ppt_conv1_stats")
+    return ps, pq
+
+
+def bn_finalize(gamma, beta, train, partials=None, count=0, running_mean=None, running_var=None,
+                num_batches_tracked=None, eps=1e-5, momentum=0.1, update_running=True):
+    """-> (scale, shift) f32 [C]; updates the running buffers in place when train."""
+    C = gamma.shape[0]
+    scale = torch.empty((C,), dtype=torch.float32, device=gamma.device)
+    shift = torch.empty((C,), dtype=torch.float32, device=gamma.device)
+    ps, pq = partials if partials is not None else (None, None)
+    upd = train and update_running
+    _lib.check(_lib.lib().ppt_bn_finalize(_p(ps), _p(pq), 0 if ps is None else ps.shape[0], count, C, _p(gamma),
+                                          _p(beta), eps, int(train), momentum,
+                                          _p(running_mean) if (upd or not train) else None,
+                                          _p(running_var) if (upd or not train) else None,
+                                          _p(num_batches_tracked) if upd else None, _p(scale), _p(shift), _stream()),
+               "ppt_bn_finalize")
+    return scale, shift
+
+
+def linear3_gelu(pts, w, b, y_dtype):
+    _chk(pts, torch.float32, "pts")
+    M, C = pts.shape[0], w.shape[0]
+    y = torch.empty((M, C), dtype=y_dtype, device=pts.device)
+    _lib.check(_lib.lib().ppt_linear3_gelu(_p(pts), M, _p(w), _p(b), C, _p(y), dtype_code(y), _stream()),
+               "ppt_linear3_gelu")
+    return y
+
+
+def cls_max_pool(x, want_argmax=False):
+    """x [B,T,D] -> feat [B,2D] f32 (+ argmax [B,D] i32)."""
+    _chk(x, None, "x")
+    B, T, D = x.shape
+    out = torch.empty((B, 2 * D), dtype=torch.float32, device=x.device)
+    am = torch.empty((B, D), dtype=torch.int32, device=x.device) if want_argmax else None
+    _lib.check(_lib.lib().ppt_cls_max_pool(_p(x), dtype_code(x), B, T, D, _p(out), _p(am), _stream()), "ppt_cls_max_pool")
+    return out, am
+
+
+def convert(src, dst_dtype):
+    _chk(src, None, "src")
+    if src.dtype == dst_dtype:
+        return src
+    dst = torch.empty(src.shape, dtype=dst_dtype, device=src.device)
+    _lib.check(_lib.lib().ppt_convert(_p(src), dtype_code(src), _p(dst), dtype_code(dst), src.numel(), _stream()),
+               "ppt_convert")
+    return dst
+
+
+def transpose(src, dst_dtype=None):
+    """[R,C] -> [C,R] (optionally converting)."""
+    _chk(src, None, "src")
+    R, C = src.shape
+    dst = torch.empty((C, R), dtype=dst_dtype or src.dtype, device=src.device)
+    _lib.check(_lib.lib().ppt_transpose(_p(src), dtype_code(src), _p(dst), dtype_code(dst), R, C, _stream()),
+               "ppt_transpose")
+    return dst
+
+
+def reduce_rows(partial, out=None, accumulate=False):
+    _chk(partial, torch.float32, "partial")
+    P, D = partial.shape
+    if out is None:
+        out = torch.empty((D,), dtype=torch.float32, device=partial.device)
+        accumulate = False
+    _lib.check(_lib.lib().ppt_reduce_rows(_p(partial), P, D, _p(out), int(accumulate), _stream()), "ppt_reduce_rows")
+    return out

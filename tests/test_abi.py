@@ -1,0 +1,56 @@
+"""CPU: the C-ABI library loads and exports every symbol include/ppt_hip.h declares."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "ppt_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ppt_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from ppt_amd import build, _lib
+    build.build(verbose=False)
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    syms = declared_symbols()
+    assert len(syms) >= 15
+    missing = [s for s in syms if not hasattr(L, s)]
+    assert not missing, missing
+
+
+def test_binding_covers_header():
+    from ppt_amd import _lib
+    syms = set(declared_symbols()) - {"ppt_strerror"}
+    assert syms == set(_lib._SIGNATURES), syms ^ set(_lib._SIGNATURES)
+    assert _lib.lib().ppt_abi_version() == 1
+    assert b"invalid" in _lib.lib().ppt_strerror(-1)
+
+
+def test_gemm_params_struct_matches_header_order():
+    from ppt_amd import _lib
+    src = open(os.path.join(ROOT, "include", "ppt_hip.h")).read()
+    body = src[src.index("typedef struct ppt_gemm_params {"):src.index("} ppt_gemm_params;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for stmt in body.split("{", 1)[1].split(";"):
+        stmt = stmt.strip()
+        if not stmt:
+            continue
+        first, *rest = stmt.split(",")
+        names.append(re.findall(r"(\w+)\s*$", first.strip())[0])
+        names += [r.strip().lstrip("*") for r in rest]
+    assert names == [f[0] for f in _lib.GemmParams._fields_]
+
+
+def test_arg_validation_without_gpu():
+    """pure host-side argument checks return PPT_EINVAL before any launch."""
+    from ppt_amd import _lib
+    L = _lib.lib()
+    assert L.ppt_fps_f32(None, 1, 1, 1, None, None, None, None) == -1
+    assert L.ppt_gemm(None, None) == -1
+    p = _lib.GemmParams()
+    assert L.ppt_gemm(ctypes.byref(p), None) == -1

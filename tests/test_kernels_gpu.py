@@ -1,0 +1,302 @@
+"""GPU: every HIP kernel, called through the C ABI (ppt_amd.ops -> libppt_hip.so), against the
+oracle (index work: bit-exact) or plain fp32 torch-CPU math (floating point: tolerance stated per test)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from ppt_amd import weights as W
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from ppt_amd import ops as _ops
+    return _ops
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a
+    t = t.cuda()
+    return t.to(dtype) if dtype is not None else t
+
+
+# ------------------------------------------------------------------ FPS
+@pytest.mark.parametrize("B,N,M,dup", [(4, 1024, 512, False), (2, 2048, 512, True), (1, 8192, 512, False),
+                                        (3, 512, 128, False), (2, 100, 100, False), (2, 64, 70, True),
+                                        (1, 16384, 64, False), (5, 1000, 333, False)])
+def test_fps_bit_exact(ops, B, N, M, dup):
+    pc, start = W.synth_clouds(B, N, seed=1234, duplicates=dup)
+    ref = O.fps(pc, M, start)
+    idx, ctr = ops.fps(dev(pc), M, dev(start))
+    assert np.array_equal(idx.cpu().numpy(), ref)
+    assert np.array_equal(ctr.cpu().numpy(), np.take_along_axis(pc, ref[:, :, None], axis=1))
+
+
+def test_fps_golden(ops):
+    g = np.load(os.path.join(G, "g_index.npz"))
+    for tag, (B, N, dup) in {"a": (4, 1024, False), "b": (2, 2048, True), "c": (1, 8192, False)}.items():
+        pc, start = W.synth_clouds(B, N, seed=1234, duplicates=dup)
+        idx, _ = ops.fps(dev(pc), 512, dev(start))
+        assert np.array_equal(idx.cpu().numpy(), g[f"fps_{tag}_idx"].astype(np.int64))
+
+
+def test_fps_all_duplicate_points(ops):
+    pc = np.tile(np.float32([[0.25, -0.5, 0.125]]), (2, 300, 1))
+    start = np.array([7, 299], np.int64)
+    idx, _ = ops.fps(dev(pc), 20, dev(start))
+    assert np.array_equal(idx.cpu().numpy(), O.fps(pc, 20, start))
+
+
+# ------------------------------------------------------------------ kNN / group
+@pytest.mark.parametrize("B,N,G_,k,dup", [(4, 1024, 512, 32, False), (2, 2048, 512, 32, True), (1, 8192, 512, 32, False),
+                                           (2, 2048, 256, 4, True), (3, 200, 50, 8, False), (2, 64, 64, 64, False),
+                                           (1, 33, 7, 5, False)])
+def test_knn_group_bit_exact(ops, B, N, G_, k, dup):
+    pc, start = W.synth_clouds(B, N, seed=99, duplicates=dup)
+    cidx = O.fps(pc, G_, start)
+    nbr_ref, nb_ref, ce_ref = O.group(pc, cidx, k)
+    idx, nb = ops.knn_group(dev(pc), dev(ce_ref), k)
+    assert np.array_equal(idx.cpu().numpy(), nbr_ref)        # same total order (distance, index)
+    assert np.array_equal(nb.cpu().numpy(), nb_ref)
+
+
+def test_knn_golden_sets(ops):
+    g = np.load(os.path.join(G, "g_index.npz"))
+    pc, _ = W.synth_clouds(4, 1024, seed=1234)
+    cidx = g["fps_a_idx"].astype(np.int64)
+    center = np.take_along_axis(pc, cidx[:, :, None], axis=1)
+    idx, _ = ops.knn_group(dev(pc), dev(center), 32)
+    assert np.array_equal(np.sort(idx.cpu().numpy(), -1), g["knn_a_k32"].astype(np.int64))
+
+
+def test_knn_degenerate_overflow_path(ops):
+    """hundreds of exact ties overflow the survivor list -> exact fallback path."""
+    rng = np.random.default_rng(3)
+    pc = rng.random((2, 1024, 3), dtype=np.float32)
+    pc[0, 100:900] = pc[0, 100]           # 800 copies of one point
+    pc[1, :] = pc[1, 0]                   # every point identical
+    center = pc[:, [100, 5, 950, 0]].copy()
+    nbr_ref, _ = O.knn(pc, center, 32)
+    idx, nb = ops.knn_group(dev(pc), dev(center), 32)
+    assert np.array_equal(idx.cpu().numpy(), nbr_ref)
+
+
+@pytest.mark.parametrize("N,r,K", [(1024, 0.1, 16), (1024, 0.2, 32), (1024, 0.4, 128), (8192, 0.2, 32), (8192, 0.4, 128)])
+def test_ball_query(ops, N, r, K):
+    pc, start = W.synth_clouds(2, N, seed=5)
+    cidx = O.fps(pc, 128, start)
+    center = np.take_along_axis(pc, cidx[:, :, None], axis=1)
+    ref = O.ball_query(pc, center, r, K)
+    out = ops.ball_query(dev(pc), dev(center), r, K)
+    assert np.array_equal(out.cpu().numpy(), ref)
+
+
+# ------------------------------------------------------------------ GEMM
+def _gemm_case(ops, dtype, M, N, K, tol, **kw):
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    Bm = (rng.standard_normal((N, K)) / math.sqrt(K)).astype(np.float32)
+    a, b = dev(A, dtype), dev(Bm, dtype)
+    ref = a.float().cpu() @ b.float().cpu().t()
+    out = ops.gemm(a, b, out_dtype=torch.float32, **kw)
+    torch.cuda.synchronize()
+    err = (out.cpu() - ref).abs().max().item()
+    assert err < tol, err
+    return out
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 384), (513, 1152, 384), (1000, 40, 512), (32, 512, 768),
+                                    (77, 2048, 512), (130, 130, 136), (4104, 384, 1536)])
+def test_gemm_bf16_plain(ops, M, N, K):
+    # operands are exactly representable (bf16-rounded before the fp32 reference) -> only fp32
+    # accumulation-order error remains: 1e-3 absolute on O(1) outputs is generous
+    _gemm_case(ops, torch.bfloat16, M, N, K, 2e-3)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (513, 384, 384), (77, 512, 2048), (130, 136, 132)])
+def test_gemm_f32_plain(ops, M, N, K):
+    _gemm_case(ops, torch.float32, M, N, K, 2e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gemm_epilogues(ops, dtype):
+    rng = np.random.default_rng(11)
+    M, N, K = 640, 384, 256
+    A = dev(rng.standard_normal((M, K)).astype(np.float32), dtype)
+    Bm = dev((rng.standard_normal((N, K)) / 16).astype(np.float32), dtype)
+    bias = dev(rng.standard_normal(N).astype(np.float32))
+    res = dev(rng.standard_normal((M, N)).astype(np.float32))
+    res2 = dev(rng.standard_normal((M, N)).astype(np.float32))
+    rs = dev(rng.random(M // 64).astype(np.float32))
+    gadd = dev(rng.standard_normal((M // 32, N)).astype(np.float32))
+    base = A.float().cpu() @ Bm.float().cpu().t()
+    tol = 3e-3 if dtype == torch.bfloat16 else 5e-5
+    for act, fn in ((ops.ACT_NONE, lambda x: x), (ops.ACT_RELU, torch.relu), (ops.ACT_GELU, O.gelu_erf),
+                    (ops.ACT_QUICKGELU, O.quick_gelu)):
+        out = ops.gemm(A, Bm, out_dtype=torch.float32, bias=bias, act=act, row_scale=rs, row_scale_rows=64,
+                       residual=res, residual2=res2, group_add=gadd, group_rows=32)
+        ref = fn(base + bias.cpu() + gadd.cpu().repeat_interleave(32, 0)) * rs.cpu().repeat_interleave(64)[:, None] \
+            + res.cpu() + res2.cpu()
+        assert (out.cpu() - ref).abs().max().item() < tol, act
+    # derivative epilogue
+    pre = dev(rng.standard_normal((M, N)).astype(np.float32), dtype)
+    for act in (ops.ACT_GELU, ops.ACT_QUICKGELU, ops.ACT_RELU):
+        out = ops.gemm(A, Bm, out_dtype=torch.float32, act=act, dact_pre=pre)
+        x = pre.float().cpu().requires_grad_(True)
+        f = {ops.ACT_GELU: O.gelu_erf, ops.ACT_QUICKGELU: O.quick_gelu, ops.ACT_RELU: torch.relu}[act](x)
+        (d,) = torch.autograd.grad(f.sum(), x)
+        assert (out.cpu() - base * d).abs().max().item() < tol * 2, act
+    # second output, pooled max, column statistics
+    out2 = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    pool = torch.empty((M // 32, N), dtype=torch.float32, device="cuda")
+    cs = torch.empty((M // 64, N), dtype=torch.float32, device="cuda")
+    cq = torch.empty_like(cs)
+    out = ops.gemm(A, Bm, out_dtype=torch.float32, bias=bias, out2=out2, pool_max=pool, col_stats=(cs, cq))
+    ref = base + bias.cpu()
+    assert (out.cpu() - ref).abs().max().item() < tol
+    assert (out2.float().cpu() - ref).abs().max().item() < 2e-2
+    assert (pool.cpu() - ref.view(M // 32, 32, N).max(1)[0]).abs().max().item() < tol
+    assert (cs.cpu().sum(0) - ref.sum(0)).abs().max().item() < tol * M
+    assert (cq.cpu().sum(0) - (ref ** 2).sum(0)).abs().max().item() < tol * M * 4
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gemm_prologues(ops, dtype):
+    rng = np.random.default_rng(12)
+    M, N, K = 512, 256, 128
+    Bm = dev((rng.standard_normal((N, K)) / 11).astype(np.float32), dtype)
+    scale = dev((1 + 0.2 * rng.standard_normal(K)).astype(np.float32))
+    shift = dev((0.3 * rng.standard_normal(K)).astype(np.float32))
+    tol = 2e-2 if dtype == torch.bfloat16 else 5e-5
+    # affine + relu on A (BatchNorm -> ReLU fused into the consumer GEMM)
+    A = dev(rng.standard_normal((M, K)).astype(np.float32), dtype)
+    out = ops.gemm(A, Bm, out_dtype=torch.float32, a_mode=ops.A_AFFINE_RELU, a_scale=scale, a_shift=shift)
+    ref = torch.relu(A.float().cpu() * scale.cpu() + shift.cpu()) @ Bm.float().cpu().t()
+    assert (out.cpu() - ref).abs().max().item() < tol
+    # conv1 (K=3) + BN + ReLU producer
+    pts = dev(rng.standard_normal((M, 3)).astype(np.float32))
+    w1 = dev(rng.standard_normal((K, 3)).astype(np.float32))
+    b1 = dev(rng.standard_normal(K).astype(np.float32))
+    out = ops.gemm(None, Bm, out_dtype=torch.float32, a_mode=ops.A_CONV1, pts=pts, w1=w1, b1=b1, a_scale=scale,
+                   a_shift=shift)
+    a = torch.relu((pts.cpu() @ w1.cpu().t() + b1.cpu()) * scale.cpu() + shift.cpu())
+    ref = a @ Bm.float().cpu().t()
+    assert (out.cpu() - ref).abs().max().item() < tol
+
+
+# ------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("M,D", [(513 * 2, 384), (77 * 3, 512), (5, 64), (9, 1000)])
+def test_layernorm_fwd_bwd(ops, M, D):
+    rng = np.random.default_rng(M + D)
+    x = rng.standard_normal((M, D)).astype(np.float32) * 2 + 0.5
+    add = rng.standard_normal((M, D)).astype(np.float32)
+    w = (1 + 0.1 * rng.standard_normal(D)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(D)).astype(np.float32)
+    dy = rng.standard_normal((M, D)).astype(np.float32)
+    xs_t = (torch.from_numpy(x) + torch.from_numpy(add)).requires_grad_(True)
+    wt, bt = torch.from_numpy(w).requires_grad_(True), torch.from_numpy(b).requires_grad_(True)
+    ref = O.layer_norm(xs_t, wt, bt)
+    ref.backward(torch.from_numpy(dy))
+    xd = dev(x)
+    y, mean, rstd = ops.layernorm_fwd(xd, dev(w), dev(b), torch.float32, add=dev(add), write_xs=xd, save_stats=True)
+    assert (y.cpu() - ref.detach()).abs().max().item() < 2e-5
+    assert (xd.cpu() - xs_t.detach()).abs().max().item() == 0
+    dx0 = dev(np.ones((M, D), np.float32))
+    dx, dw, db = ops.layernorm_bwd(dev(dy), xd, dev(w), mean, rstd, dx=dx0, accumulate=True, want_wgrad=True,
+                                   partial_rows=64)
+    assert (dx.cpu() - 1 - xs_t.grad).abs().max().item() < 5e-5
+    assert (dw.cpu() - wt.grad).abs().max().item() < 1e-3
+    assert (db.cpu() - bt.grad).abs().max().item() < 1e-3
+    # bf16 output + broadcast positional table
+    tab = rng.standard_normal((7, D)).astype(np.float32)
+    y2, _, _ = ops.layernorm_fwd(dev(x), dev(w), dev(b), torch.bfloat16, add=dev(tab), add_rows=7)
+    ref2 = O.layer_norm(torch.from_numpy(x) + torch.from_numpy(tab).repeat((M + 6) // 7, 1)[:M], wt.detach(), bt.detach())
+    assert (y2.float().cpu() - ref2).abs().max().item() < 3e-2
+
+
+# ------------------------------------------------------------------ attention
+def _attn_ref(qkv, Bt, T, H, scale, causal):
+    q, k, v = qkv.view(Bt, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    a = (q @ k.transpose(-2, -1)) * scale
+    if causal:
+        a = a + torch.full((T, T), float("-inf")).triu(1)
+    a = torch.softmax(a, -1)
+    return (a @ v).transpose(1, 2).reshape(Bt * T, H * 64)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("Bt,T,H,causal", [(2, 513, 6, False), (3, 77, 8, True), (1, 64, 1, False), (2, 100, 2, True)])
+def test_attention_fwd_bwd(ops, dtype, tol, Bt, T, H, causal):
+    rng = np.random.default_rng(T + H)
+    qkv = rng.standard_normal((Bt * T, 3 * H * 64)).astype(np.float32)
+    qd = dev(qkv, dtype)
+    q32 = qd.float().cpu().requires_grad_(True)
+    ref = _attn_ref(q32, Bt, T, H, 0.125, causal)
+    out, lse = ops.attention_fwd(qd, Bt, T, H, 0.125, causal)
+    assert (out.float().cpu() - ref.detach()).abs().max().item() < tol
+    dout = rng.standard_normal((Bt * T, H * 64)).astype(np.float32)
+    dd = dev(dout, dtype)
+    ref.backward(dd.float().cpu())
+    dqkv = ops.attention_bwd(qd, out, dd, lse, Bt, T, H, 0.125, causal)
+    err = (dqkv.float().cpu() - q32.grad).abs().max().item()
+    assert err < tol * 4, err
+
+
+# ------------------------------------------------------------------ small ops
+def test_conv1_stats_bn_finalize(ops):
+    rng = np.random.default_rng(21)
+    M, C = 2048 * 3 + 100, 128
+    pts = rng.standard_normal((M, 3)).astype(np.float32) * 0.1
+    w1 = rng.standard_normal((C, 3)).astype(np.float32)
+    b1 = rng.standard_normal(C).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(C)).astype(np.float32)
+    be = (0.1 * rng.standard_normal(C)).astype(np.float32)
+    rm = rng.standard_normal(C).astype(np.float32)
+    rv = (1 + rng.random(C)).astype(np.float32)
+    y = torch.from_numpy(pts) @ torch.from_numpy(w1).t() + torch.from_numpy(b1)
+    mean, var = y.mean(0), y.var(0, unbiased=False)
+    part = ops.conv1_stats(dev(pts), dev(w1), dev(b1))
+    rmd, rvd = dev(rm), dev(rv)
+    nbt = torch.zeros((), dtype=torch.int64, device="cuda")
+    sc, sh = ops.bn_finalize(dev(g), dev(be), True, partials=part, count=M, running_mean=rmd, running_var=rvd,
+                             num_batches_tracked=nbt)
+    sc_ref = torch.from_numpy(g) / torch.sqrt(var + 1e-5)
+    assert (sc.cpu() - sc_ref).abs().max().item() < 1e-4 * sc_ref.abs().max().item()
+    assert (sh.cpu() - (torch.from_numpy(be) - mean * sc_ref)).abs().max().item() < 1e-4
+    assert (rmd.cpu() - (0.9 * torch.from_numpy(rm) + 0.1 * mean)).abs().max().item() < 1e-5
+    assert (rvd.cpu() - (0.9 * torch.from_numpy(rv) + 0.1 * y.var(0, unbiased=True))).abs().max().item() < 1e-5
+    assert nbt.item() == 1
+    sc2, sh2 = ops.bn_finalize(dev(g), dev(be), False, running_mean=dev(rm), running_var=dev(rv))
+    ref = torch.from_numpy(g) / torch.sqrt(torch.from_numpy(rv) + 1e-5)
+    assert (sc2.cpu() - ref).abs().max().item() < 1e-6
+    assert (sh2.cpu() - (torch.from_numpy(be) - torch.from_numpy(rm) * ref)).abs().max().item() < 1e-6
+
+
+def test_misc_ops(ops):
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal((3, 513, 384)).astype(np.float32)
+    out, am = ops.cls_max_pool(dev(x), want_argmax=True)
+    xt = torch.from_numpy(x)
+    ref = torch.cat([xt[:, 0], xt[:, 1:].max(1)[0]], -1)
+    assert torch.equal(out.cpu(), ref)
+    assert torch.equal(am.cpu().long(), xt[:, 1:].max(1)[1] + 1)
+    a = rng.standard_normal((130, 70)).astype(np.float32)
+    t = ops.transpose(dev(a), torch.bfloat16)
+    assert torch.equal(t.cpu(), torch.from_numpy(a).t().contiguous().to(torch.bfloat16))
+    assert torch.equal(ops.convert(dev(a), torch.bfloat16).cpu(), torch.from_numpy(a).to(torch.bfloat16))
+    pts = rng.standard_normal((1000, 3)).astype(np.float32)
+    w = rng.standard_normal((128, 3)).astype(np.float32)
+    b = rng.standard_normal(128).astype(np.float32)
+    y = ops.linear3_gelu(dev(pts), dev(w), dev(b), torch.float32)
+    ref = O.gelu_erf(torch.from_numpy(pts) @ torch.from_numpy(w).t() + torch.from_numpy(b))
+    assert (y.cpu() - ref).abs().max().item() < 1e-5
+    p = rng.standard_normal((50, 384)).astype(np.float32)
+    assert (ops.reduce_rows(dev(p)).cpu() - torch.from_numpy(p).sum(0)).abs().max().item() < 1e-4

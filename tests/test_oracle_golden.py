@@ -1,0 +1,127 @@
+"""CPU: the oracle (oracle/ppt_oracle.c + oracle/oracle.py) against the golden fixtures that
+tests/golden/make_golden.py captured from the upstream reference."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from ppt_amd import weights as W
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+CASES = {"a": (4, 1024, False), "b": (2, 2048, True), "c": (1, 8192, False)}
+
+
+@pytest.fixture(scope="module")
+def gidx():
+    return np.load(os.path.join(G, "g_index.npz"))
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_fps_bit_exact(gidx, tag):
+    B, N, dup = CASES[tag]
+    pc, start = W.synth_clouds(B, N, seed=1234, duplicates=dup)
+    idx = O.fps(pc, 512, start)
+    assert np.array_equal(idx, gidx[f"fps_{tag}_idx"].astype(np.int64))
+    # prefix property: FPS for M' < M is the prefix
+    assert np.array_equal(O.fps(pc, 128, start), idx[:, :128])
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+@pytest.mark.parametrize("k", [32, 4])
+def test_knn_sets(gidx, tag, k):
+    B, N, dup = CASES[tag]
+    pc, start = W.synth_clouds(B, N, seed=1234, duplicates=dup)
+    cidx = gidx[f"fps_{tag}_idx"].astype(np.int64)
+    center = np.take_along_axis(pc, cidx[:, :, None], axis=1)
+    idx, kth = O.knn(pc, center, k)
+    ref = gidx[f"knn_{tag}_k{k}"].astype(np.int64)
+    mism = (np.sort(idx, -1) != ref).any(-1)
+    tied = kth[..., 0] == kth[..., 1]
+    assert not (mism & ~tied).any()
+    # on exact boundary ties torch.topk's choice is unspecified: the multiset of distances must agree
+    d = O.square_distance(center, pc)
+    dr = np.sort(np.take_along_axis(d, ref, -1), -1)
+    do = np.sort(np.take_along_axis(d, idx, -1), -1)
+    assert np.array_equal(dr, do)
+
+
+@pytest.mark.parametrize("tag", ["a", "c"])
+def test_ball_query(gidx, tag):
+    B, N, dup = CASES[tag]
+    pc, _ = W.synth_clouds(B, N, seed=1234, duplicates=dup)
+    cidx = gidx[f"fps_{tag}_idx"].astype(np.int64)
+    center = np.take_along_axis(pc, cidx[:, :, None], axis=1)
+    for r, K in ((0.1, 16), (0.2, 32), (0.4, 128)):
+        assert np.array_equal(O.ball_query(pc, center, r, K), gidx[f"ball_{tag}_r{r}_K{K}"].astype(np.int64))
+
+
+def _setup():
+    tok = json.load(open(os.path.join(ROOT, "ppt_amd", "data", "classnames.json")))
+    names = tok["datasets"]["modelnet40"]
+    nl = [len(tok["name_tokens"][n.replace("_", " ")]) for n in names]
+    sd = W.ulip_pointbert_state_dict(seed=0)
+    emb = W.synth_prompt_embedding(len(names), seed=0)
+    pc, start = W.synth_clouds(4, 1024, seed=77)
+    return sd, emb, nl, torch.from_numpy(pc), start
+
+
+def test_mini_pointnet_modes():
+    sd, emb, nl, pc, start = _setup()
+    g = np.load(os.path.join(G, "g_encoder.npz"))
+    cidx = O.fps(pc.numpy(), 512, start)
+    _, nb, _ = O.group(pc.numpy(), cidx, 32)
+    for mode in ("eval", "train"):
+        ns = {}
+        with torch.no_grad():
+            out = O.mini_pointnet(sd, torch.from_numpy(nb), mode == "train", new_stats=ns)
+        assert np.abs(out[:, ::8].numpy() - g[f"{mode}_sub"]).max() < 2e-5
+        assert abs(out.double().sum().item() - float(g[f"{mode}_sum"])) < 1e-2
+        if mode == "train":
+            for k, v in ns.items():
+                assert np.abs(v.numpy().astype(np.float64) - g["stat_" + k]).max() < 1e-5
+
+
+def test_eval_forward():
+    sd, emb, nl, pc, start = _setup()
+    g = np.load(os.path.join(G, "g_eval.npz"))
+    f0 = np.load(os.path.join(G, "g_step_h0.npz"))
+    aux = {}
+    with torch.no_grad():
+        lg = O.ulip_logits(sd, pc, start, emb, nl, f0["eot"].astype(np.int64), train=False, aux=aux)
+    assert np.abs(aux["pc_feat"].numpy() - g["pc_feat"]).max() < 2e-5
+    assert np.abs(lg.numpy() - g["logits"]).max() < 5e-4
+    pr = O.splice_prompts(emb, sd["prompt_learner.learnable_tokens"], nl)
+    assert np.array_equal(pr[:, ::4, ::8].numpy(), g["prompts_sub"])
+
+
+@pytest.mark.parametrize("head_type", [0, 3])
+def test_train_step(head_type):
+    sd, emb, nl, pc, start = _setup()
+    g = np.load(os.path.join(G, f"g_step_h{head_type}.npz"))
+    masks = [(torch.from_numpy(m[0]), torch.from_numpy(m[1])) for m in g["dp_masks"]]
+    res = O.train_step(sd, pc, torch.from_numpy(g["labels"]), g["fps_start"], emb, nl, g["eot"].astype(np.int64),
+                       head_type=head_type, dp_masks=masks)
+    assert np.abs(res["logits"].numpy() - g["logits"]).max() < 5e-4
+    assert abs(res["loss"].item() - float(g["loss"])) < 1e-4
+    for k, gr in res["grads"].items():
+        if "grad_" + k in g:
+            ref = g["grad_" + k]
+            assert np.linalg.norm(gr.numpy() - ref) / np.linalg.norm(ref) < 1e-4, k
+            upd = O.adamw_update(sd[k], torch.from_numpy(ref), {}, 3e-3)
+            assert np.abs(upd.numpy() - g["new_" + k]).max() < 1e-6
+        else:
+            ref = g["gradsub_" + k]
+            sub = gr.flatten()[::97].numpy()
+            assert np.linalg.norm(sub - ref) / np.linalg.norm(ref) < 1e-4, k
+            assert abs(gr.double().norm().item() / float(g["gradnorm_" + k]) - 1) < 1e-4
+    for k, v in res["new_stats"].items():
+        assert np.abs(v.numpy().astype(np.float64) - g["stat_" + k]).max() < 1e-5
+
+
+def test_cosine_scheduler():
+    s = O.cosine_scheduler(3e-3, 1e-5, 5, 10, warmup_epochs=1, start_warmup_value=1e-6)
+    assert len(s) == 50 and abs(s[0] - 1e-6) < 1e-12 and abs(s[9] - 3e-3) < 1e-12 and s[-1] > 1e-5
