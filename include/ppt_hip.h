@@ -101,9 +101,10 @@ typedef struct ppt_gemm_params {
     const float *residual2;          /* [M,N] f32 or NULL: + residual2 (positional embedding re-add) */
     int64_t ld_res2;
     /* side outputs */
-    void *C2; int64_t ldc2; int c2_dtype;  /* optional second copy of the result in another dtype */
-    float *col_sum;                  /* [ceil(M/64), N] partial per-column sums of the pre-activation... */
-    float *col_sqsum;                /* ... and sums of squares (BatchNorm batch statistics), or NULL */
+    void *C2; int64_t ldc2; int c2_dtype;  /* optional second output in another dtype: the final value, or ... */
+    int c2_pre;                      /* ... when != 0 the PRE-activation (after bias/group_add): saved for the backward */
+    float *col_sum;                  /* [ceil(M/64), N] per 64-row chunk: column sums of the pre-activation... */
+    float *col_sqsum;                /* ... and M2 = sum (v - chunk mean)^2 (BatchNorm batch statistics), or NULL */
     void *pool_max;                  /* [M/32, N] pool_dtype: max over each 32-row group (mini-PointNet max-pool) */
     int pool_dtype;
     /* batching (blockIdx.z): pointer offsets in ELEMENTS per batch */
@@ -126,13 +127,15 @@ int ppt_gemm(const ppt_gemm_params *p, void *stream);
  * fwd: xs = x (+ add); y = LN(xs)*w + b.  x, add, xs f32 [M,D] (xs may alias x, may be NULL);
  *      y in `y_dtype`; mean/rstd [M] f32 saved for the backward (may be NULL).
  *      add_rows > 0: `add` has add_rows rows and row m uses add[m % add_rows] (positional table).
- * bwd: dx = LN'(dy); optional dw/db partials [ceil(M/rows_per_block), D] reduced by the caller. */
+ * bwd: dx (+)= LN'(dy) (f32; accumulate_dx adds into the residual-stream gradient); dx_copy (may be
+ *      NULL) receives the final dx in `dx_copy_dtype` (the next GEMM's operand); optional dw/db
+ *      partials [partial_rows, D] reduced by the caller (ppt_reduce_rows). */
 int ppt_layernorm_fwd(const float *x, const float *add, int add_rows, float *xs, const float *w,
                       const float *b, void *y, int y_dtype, float *mean, float *rstd, int M, int D,
                       float eps, void *stream);
 int ppt_layernorm_bwd(const float *dy, const float *xs, const float *w, const float *mean,
-                      const float *rstd, float *dx, int accumulate_dx, float *dw_partial,
-                      float *db_partial, int partial_rows, int M, int D, void *stream);
+                      const float *rstd, float *dx, int accumulate_dx, void *dx_copy, int dx_copy_dtype,
+                      float *dw_partial, float *db_partial, int partial_rows, int M, int D, void *stream);
 
 /* ---- Attention ---------------------------------------------------------------------------------
  * softmax(scale * q k^T [+ causal mask]) v per (batch, head).  Replaces
@@ -150,17 +153,20 @@ int ppt_attention_bwd(const void *qkv, const void *out, const void *dout, const 
 
 /* ---- mini-PointNet helpers -----------------------------------------------------------------------
  * BatchNorm1d in train mode inside dvae.py:188-199.
- * conv1_stats: per-channel partial sums of y = w1.p + b1 over all points (K=3 layer, VALU).
- * bn_finalize: partial sums -> scale = g/sqrt(var+eps), shift = b - mean*scale; running-stat update
+ * conv1_stats: per-channel (sum, M2 about the chunk mean) of y = w1.p + b1 per chunk of
+ *   ppt_conv1_stats_rows_per_partial() points (K=3 layer, VALU).  The GEMM's col_sum/col_sqsum use
+ *   the same (sum, M2) form with 64-row chunks.
+ * bn_finalize: chunk partials (merged with the parallel-variance formula in fp64) -> scale = g/sqrt(var+eps), shift = b - mean*scale; running-stat update
  * (momentum 0.1, unbiased variance) when running_mean != NULL.  train == 0: scale/shift from the
  * running statistics (eval mode), partials ignored. */
 int ppt_conv1_stats(const float *pts, int64_t M, const float *w1, const float *b1, int C,
                     float *part_sum, float *part_sqsum, int *n_partials, void *stream);
-int ppt_bn_finalize(const float *part_sum, const float *part_sqsum, int n_partials, int64_t count,
-                    int C, const float *gamma, const float *beta, float eps, int train,
+int ppt_bn_finalize(const float *part_sum, const float *part_sqsum, int n_partials,
+                    int rows_per_partial, int64_t count, int C, const float *gamma, const float *beta, float eps, int train,
                     float momentum, float *running_mean, float *running_var,
                     int64_t *num_batches_tracked, float *scale, float *shift, void *stream);
 int ppt_conv1_stats_max_partials(int64_t M);
+int ppt_conv1_stats_rows_per_partial(void);
 
 /* ---- small fused ops ---------------------------------------------------------------------------
  * pos_embed first layer + GELU (point_encoder.py:138-140): y[m][c] = gelu(w[c].p_m + b[c]), K=3. */
@@ -173,6 +179,8 @@ int ppt_cls_max_pool(const void *x, int x_dtype, int B, int T, int D, float *out
 int ppt_convert(const void *src, int src_dtype, void *dst, int dst_dtype, int64_t n, void *stream);
 int ppt_transpose(const void *src, int src_dtype, void *dst, int dst_dtype, int rows, int cols,
                   void *stream);
+/* column sums of x [M,D] (any dtype) -> partial [ceil(M/256), D] f32 (bias gradients); reduce with ppt_reduce_rows */
+int ppt_col_sums(const void *x, int x_dtype, int M, int D, int64_t ldx, float *partial, void *stream);
 /* sum the [P, D] partial buffers produced by col_sum / dw_partial style outputs -> [D] */
 int ppt_reduce_rows(const float *partial, int P, int D, float *out, int accumulate, void *stream);
 

@@ -27,7 +27,7 @@ class GemmParams(ctypes.Structure):
         ("dact_pre", c_void_p), ("ld_dact", c_int64),
         ("row_scale", c_void_p), ("row_scale_rows", c_int),
         ("residual", c_void_p), ("ld_res", c_int64), ("residual2", c_void_p), ("ld_res2", c_int64),
-        ("C2", c_void_p), ("ldc2", c_int64), ("c2_dtype", c_int),
+        ("C2", c_void_p), ("ldc2", c_int64), ("c2_dtype", c_int), ("c2_pre", c_int),
         ("col_sum", c_void_p), ("col_sqsum", c_void_p), ("pool_max", c_void_p), ("pool_dtype", c_int),
         ("batch", c_int), ("strideA", c_int64), ("strideB", c_int64), ("strideC", c_int64),
     ]
@@ -42,7 +42,8 @@ _SIGNATURES = {
     "ppt_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                   c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "ppt_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                  c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+                                  c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ppt_col_sums": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p]),
     "ppt_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int,
                                   c_int, c_void_p]),
     "ppt_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
@@ -50,7 +51,8 @@ _SIGNATURES = {
     "ppt_conv1_stats": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                 ctypes.POINTER(c_int), c_void_p]),
     "ppt_conv1_stats_max_partials": (c_int, [c_int64]),
-    "ppt_bn_finalize": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_float, c_int,
+    "ppt_conv1_stats_rows_per_partial": (c_int, []),
+    "ppt_bn_finalize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_float, c_int,
                                 c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ppt_linear3_gelu": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "ppt_cls_max_pool": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

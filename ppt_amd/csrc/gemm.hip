@@ -284,7 +284,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const ppt_gemm_params p)
         if (nok) {
             float v = ct[rr * 64 + lane] + bias;
             if (p.group_add) v += p.group_add[(int64_t)(m / p.group_rows) * p.N + n];
-            csum += v; csq += v * v;
+            if (p.col_sum) { csum += v; ct[rr * 64 + lane] = v; }   // keep the pre-activation for the M2 pass
+            if (p.C2 && p.c2_pre) store_dt(p.C2, p.c2_dtype, (int64_t)m * p.ldc2 + n, v);
             if (p.dact_pre) {                   // backward through an activation: * act'(saved pre-activation)
                 const float x = p.dtype == PPT_BF16 ? load_as_f32<bf16_t>(p.dact_pre, (int64_t)m * p.ld_dact + n)
                                                      : load_as_f32<float>(p.dact_pre, (int64_t)m * p.ld_dact + n);
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const ppt_gemm_params p)
             if (p.residual) v += p.residual[(int64_t)m * p.ld_res + n];
             if (p.residual2) v += p.residual2[(int64_t)m * p.ld_res2 + n];
             if (p.C) store_dt(p.C, p.c_dtype, zc + (int64_t)m * p.ldc + n, v);
-            if (p.C2) store_dt(p.C2, p.c2_dtype, (int64_t)m * p.ldc2 + n, v);
+            if (p.C2 && !p.c2_pre) store_dt(p.C2, p.c2_dtype, (int64_t)m * p.ldc2 + n, v);
             pmax = fmaxf(pmax, v);
         }
         if (p.pool_max && (rr & 31) == 31) {
@@ -305,6 +306,14 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const ppt_gemm_params p)
         }
     }
     if (p.col_sum && nok && mw < p.M) {
+        // BatchNorm statistics without cancellation: per 64-row chunk (sum, M2 about the chunk mean);
+        // ppt_bn_finalize merges the chunks with the parallel-variance formula in fp64.
+        const int nrow = min(64, p.M - mw);
+        const float cmean = csum / (float)nrow;
+        for (int rr = 0; rr < nrow; ++rr) {
+            const float d = ct[rr * 64 + lane] - cmean;
+            csq = fmaf(d, d, csq);
+        }
         const int prow = (m0 >> 6) + wm;
         p.col_sum[(int64_t)prow * p.N + n] = csum;
         p.col_sqsum[(int64_t)prow * p.N + n] = csq;

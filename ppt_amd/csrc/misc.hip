@@ -47,6 +47,18 @@ __global__ __launch_bounds__(256) void transpose_kernel(const TS *__restrict__ s
     }
 }
 
+template <typename TX>
+__global__ __launch_bounds__(256) void col_sums_kernel(const TX *__restrict__ x, int M, int D, int64_t ldx,
+                                                       float *__restrict__ part)
+{
+    const int r0 = blockIdx.y * 256, r1 = min(M, r0 + 256);
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= D) return;
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += dt<TX>::load(x + (int64_t)r * ldx + d);
+    part[(size_t)blockIdx.y * D + d] = s;
+}
+
 __global__ void reduce_rows_kernel(const float *__restrict__ part, int P, int D, float *__restrict__ out, int accumulate)
 {
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
@@ -107,6 +119,20 @@ extern "C" int ppt_transpose(const void *src, int src_dtype, void *dst, int dst_
     if (src_dtype == PPT_F32) return transpose_from<float>(src, dst, dst_dtype, rows, cols, ppt_stream(stream));
     if (src_dtype == PPT_BF16) return transpose_from<bf16_t>(src, dst, dst_dtype, rows, cols, ppt_stream(stream));
     return PPT_EINVAL;
+}
+
+extern "C" int ppt_col_sums(const void *x, int x_dtype, int M, int D, int64_t ldx, float *partial, void *stream)
+{
+    if (!x || !partial || M <= 0 || D <= 0) return PPT_EINVAL;
+    dim3 grid((D + 255) / 256, (M + 255) / 256);
+    if (x_dtype == PPT_F32)
+        hipLaunchKernelGGL(col_sums_kernel<float>, grid, dim3(256), 0, ppt_stream(stream), (const float *)x, M, D, ldx, partial);
+    else if (x_dtype == PPT_BF16)
+        hipLaunchKernelGGL(col_sums_kernel<bf16_t>, grid, dim3(256), 0, ppt_stream(stream), (const bf16_t *)x, M, D, ldx, partial);
+    else
+        return PPT_EINVAL;
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
 }
 
 extern "C" int ppt_reduce_rows(const float *partial, int P, int D, float *out, int accumulate, void *stream)

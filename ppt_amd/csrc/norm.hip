@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ xs,
                                                      const float *__restrict__ w, const float *__restrict__ mean,
                                                      const float *__restrict__ rstd, float *__restrict__ dx,
-                                                     int accumulate, float *__restrict__ dw_part,
+                                                     int accumulate, void *__restrict__ dx_copy, int copy_dtype,
+                                                     float *__restrict__ dw_part,
                                                      float *__restrict__ db_part, int rpw, int M, int D)
 {
     const int lane = threadIdx.x & 63;
@@ -92,7 +93,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ d
             if (e < D) {
                 const float r = rs * (gv[j] - s1 - xh[j] * s2);
                 float *o = dx + (size_t)row * D + e;
-                *o = accumulate ? *o + r : r;
+                const float t = accumulate ? *o + r : r;
+                *o = t;
+                if (dx_copy) {
+                    if (copy_dtype == PPT_BF16) ((bf16_t *)dx_copy)[(size_t)row * D + e] = f32_to_bf16(t);
+                    else ((float *)dx_copy)[(size_t)row * D + e] = t;
+                }
             }
         }
     }
@@ -126,8 +132,8 @@ extern "C" int ppt_layernorm_fwd(const float *x, const float *add, int add_rows,
 }
 
 extern "C" int ppt_layernorm_bwd(const float *dy, const float *xs, const float *w, const float *mean,
-                                 const float *rstd, float *dx, int accumulate_dx, float *dw_partial,
-                                 float *db_partial, int partial_rows, int M, int D, void *stream)
+                                 const float *rstd, float *dx, int accumulate_dx, void *dx_copy, int dx_copy_dtype,
+                                 float *dw_partial, float *db_partial, int partial_rows, int M, int D, void *stream)
 {
     if (!dy || !xs || !w || !mean || !rstd || !dx || M <= 0 || D <= 0 || D > 64 * MAX_EPL) return PPT_EINVAL;
     if ((dw_partial == nullptr) != (db_partial == nullptr)) return PPT_EINVAL;
@@ -142,7 +148,7 @@ extern "C" int ppt_layernorm_bwd(const float *dy, const float *xs, const float *
         (void)hipMemsetAsync(db_partial + (size_t)used * D, 0, sizeof(float) * (size_t)(partial_rows - used) * D, ppt_stream(stream));
     }
     hipLaunchKernelGGL(ln_bwd_kernel, dim3((used + 3) / 4), dim3(256), 0, ppt_stream(stream), dy, xs, w, mean, rstd, dx,
-                       accumulate_dx, dw_partial, db_partial, rpw, M, D);
+                       accumulate_dx, dx_copy, dx_copy_dtype, dw_partial, db_partial, rpw, M, D);
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }

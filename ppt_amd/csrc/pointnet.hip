@@ -26,9 +26,12 @@ __global__ __launch_bounds__(256) void conv1_stats_kernel(const float *__restric
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         const float wx = w1[c * 3 + 0], wy = w1[c * 3 + 1], wz = w1[c * 3 + 2], wb = b1[c];
         float s = 0.f, q = 0.f;
+        for (int r = 0; r < nrow; ++r)
+            s += fmaf(wz, P[r * 3 + 2], fmaf(wy, P[r * 3 + 1], fmaf(wx, P[r * 3 + 0], wb)));
+        const float cmean = s / (float)nrow;      // second pass: M2 about the chunk mean (no cancellation)
         for (int r = 0; r < nrow; ++r) {
-            const float y = fmaf(wz, P[r * 3 + 2], fmaf(wy, P[r * 3 + 1], fmaf(wx, P[r * 3 + 0], wb)));
-            s += y; q = fmaf(y, y, q);
+            const float d = fmaf(wz, P[r * 3 + 2], fmaf(wy, P[r * 3 + 1], fmaf(wx, P[r * 3 + 0], wb))) - cmean;
+            q = fmaf(d, d, q);
         }
         psum[(size_t)blockIdx.x * C + c] = s;
         psq[(size_t)blockIdx.x * C + c] = q;
@@ -36,7 +39,7 @@ __global__ __launch_bounds__(256) void conv1_stats_kernel(const float *__restric
 }
 
 __global__ void bn_finalize_kernel(const float *__restrict__ psum, const float *__restrict__ psq, int P, double count,
-                                   int C, const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                   int rpp, int C, const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
                                    int train, float momentum, float *__restrict__ rmean, float *__restrict__ rvar,
                                    int64_t *__restrict__ nbt, float *__restrict__ scale, float *__restrict__ shift)
 {
@@ -44,11 +47,16 @@ __global__ void bn_finalize_kernel(const float *__restrict__ psum, const float *
     if (c >= C) return;
     float mean_f, var_f;
     if (train) {
-        double s = 0.0, q = 0.0;
-        for (int p = 0; p < P; ++p) { s += (double)psum[(size_t)p * C + c]; q += (double)psq[(size_t)p * C + c]; }
+        double s = 0.0;
+        for (int p = 0; p < P; ++p) s += (double)psum[(size_t)p * C + c];
         const double mean = s / count;
-        double var = q / count - mean * mean;           // biased variance normalises (nn.BatchNorm1d)
-        if (var < 0.0) var = 0.0;
+        double m2 = 0.0;                                // parallel-variance merge of the chunk (sum, M2) pairs
+        for (int p = 0; p < P; ++p) {
+            const double n = fmin((double)rpp, count - (double)p * rpp);
+            const double d = (double)psum[(size_t)p * C + c] / n - mean;
+            m2 += (double)psq[(size_t)p * C + c] + n * d * d;
+        }
+        const double var = m2 / count;                  // biased variance normalises (nn.BatchNorm1d)
         mean_f = (float)mean; var_f = (float)var;
         if (rmean) {
             const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
@@ -80,6 +88,7 @@ __global__ __launch_bounds__(256) void linear3_gelu_kernel(const float *__restri
 }  // namespace
 
 extern "C" int ppt_conv1_stats_max_partials(int64_t M) { return (int)((M + STAT_ROWS - 1) / STAT_ROWS); }
+extern "C" int ppt_conv1_stats_rows_per_partial(void) { return STAT_ROWS; }
 
 extern "C" int ppt_conv1_stats(const float *pts, int64_t M, const float *w1, const float *b1, int C, float *part_sum,
                                float *part_sqsum, int *n_partials, void *stream)
@@ -93,16 +102,19 @@ extern "C" int ppt_conv1_stats(const float *pts, int64_t M, const float *w1, con
     return PPT_OK;
 }
 
-extern "C" int ppt_bn_finalize(const float *part_sum, const float *part_sqsum, int n_partials, int64_t count, int C,
+extern "C" int ppt_bn_finalize(const float *part_sum, const float *part_sqsum, int n_partials, int rows_per_partial,
+                               int64_t count, int C,
                                const float *gamma, const float *beta, float eps, int train, float momentum,
                                float *running_mean, float *running_var, int64_t *num_batches_tracked, float *scale,
                                float *shift, void *stream)
 {
     if (!gamma || !beta || !scale || !shift || C <= 0) return PPT_EINVAL;
-    if (train && (!part_sum || !part_sqsum || n_partials <= 0 || count <= 0)) return PPT_EINVAL;
+    if (train && (!part_sum || !part_sqsum || n_partials <= 0 || count <= 0 || rows_per_partial <= 0 ||
+                  (int64_t)n_partials * rows_per_partial < count))
+        return PPT_EINVAL;
     if (!train && (!running_mean || !running_var)) return PPT_EINVAL;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, ppt_stream(stream), part_sum, part_sqsum,
-                       n_partials, (double)count, C, gamma, beta, eps, train, momentum, running_mean, running_var,
+                       n_partials, (double)count, rows_per_partial, C, gamma, beta, eps, train, momentum, running_mean, running_var,
                        num_batches_tracked, scale, shift);
     PPT_CHECK_LAUNCH();
     return PPT_OK;

@@ -1,0 +1,313 @@
+"""Hand-scheduled kernel pipelines for the two towers of ULIP/PointBERT.
+
+Instead of an autograd graph of hundreds of tiny ops (the reference) or a tracing compiler, the
+forward AND backward of each tower are explicit Python sequences of C-ABI kernel launches
+(ppt_amd.ops) over caller-visible tensors; torch.autograd sees ONE node per tower
+(ppt_amd.models.*).  All launches go to the current stream, nothing synchronises, so a whole
+training step can be captured in a hipGraph.
+
+dtype T is the operand dtype of the MFMA kernels: torch.bfloat16 (performance mode) or
+torch.float32 (parity mode).  The residual streams, LayerNorm statistics, BatchNorm statistics and
+all gradients that are accumulated stay fp32 in both modes.
+
+Reference citations are relative to the upstream repo.
+"""
+import torch
+
+from . import ops
+from .ops import ACT_GELU, ACT_NONE, ACT_QUICKGELU, A_AFFINE_RELU, A_CONV1
+
+ATTN_SCALE = 64 ** -0.5
+
+
+class WeightCache:
+    """Operand-dtype / pre-transposed copies of parameters.  Frozen parameters are converted once;
+    a trainable parameter is re-converted when the optimiser has bumped its version counter."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+        self._c = {}
+
+    def get(self, t, kind="w", cols=None):
+        """kind 'w': [N,K] operand copy (optionally a column slice) in self.dtype;
+        'wt': transposed [K,N] copy (the B operand of dX = dY @ W); 'f32': fp32 2-D view."""
+        key = (id(t), kind, cols)
+        ent = self._c.get(key)
+        if ent is not None and ent[0] is t and ent[1] == t._version:
+            return ent[2]
+        with torch.no_grad():
+            w = t.detach()
+            w = w.reshape(w.shape[0], -1)                   # Conv1d [out,in,1] -> [out,in]
+            if cols is not None:
+                w = w[:, cols[0]:cols[1]].contiguous()
+            if kind == "w":
+                out = ops.convert(w.contiguous(), self.dtype)
+            elif kind == "wt":
+                out = ops.transpose(w.contiguous(), self.dtype)
+            elif kind == "f32":
+                out = w.contiguous()
+            else:
+                raise ValueError(kind)
+        self._c[key] = (t, t._version, out)
+        return out
+
+
+def _bn_params(sd, p):
+    return (sd[p + "weight"], sd[p + "bias"], sd[p + "running_mean"], sd[p + "running_var"],
+            sd[p + "num_batches_tracked"])
+
+
+# =================================================================================================
+# point branch
+# =================================================================================================
+def group_points(pc, num_group, group_size, fps_start):
+    """Group.forward (dvae.py:159-181): FPS centres + kNN neighbourhoods (centre-subtracted)."""
+    _, center = ops.fps(pc, num_group, fps_start)
+    _, nbhd = ops.knn_group(pc, center, group_size, want_idx=False)
+    return nbhd, center
+
+
+def mini_pointnet(sd, p, wc, nbhd, bn_train, update_running=True):
+    """Encoder.forward (dvae.py:201-215): [B,G,n,3] -> [B*G,256] in wc.dtype.  n must be 32
+    (one MFMA row-tile == one group, pooled in the GEMM epilogue)."""
+    B, G, n, _ = nbhd.shape
+    assert n == 32, "the fused max-pool epilogue assumes group_size == 32"
+    T = wc.dtype
+    M = B * G * n
+    pts = nbhd.view(M, 3)
+    dev = pts.device
+    w1 = wc.get(sd[p + "first_conv.0.weight"], "f32")
+    b1 = sd[p + "first_conv.0.bias"]
+    g1, be1, rm1, rv1, nb1 = _bn_params(sd, p + "first_conv.1.")
+    if bn_train:
+        ps, pq, rpp = ops.conv1_stats(pts, w1, b1)
+        sc1, sh1 = ops.bn_finalize(g1, be1, True, partials=(ps, pq), rows_per_partial=rpp, count=M,
+                                   running_mean=rm1, running_var=rv1, num_batches_tracked=nb1,
+                                   update_running=update_running)
+    else:
+        sc1, sh1 = ops.bn_finalize(g1, be1, False, running_mean=rm1, running_var=rv1)
+    # conv1 + BN1 + ReLU live in the A-prologue of the conv2 GEMM; epilogue: +bias, group max
+    gmax = torch.empty((M // 32, 256), dtype=T, device=dev)
+    y2 = ops.gemm(None, wc.get(sd[p + "first_conv.3.weight"]), out_dtype=T, a_mode=A_CONV1, pts=pts, w1=w1, b1=b1,
+                  a_scale=sc1, a_shift=sh1, bias=sd[p + "first_conv.3.bias"], pool_max=gmax)
+    # cat([global, local]) @ W3^T  ==  local @ W3[:,256:]^T + (global @ W3[:,:256]^T + b3) per group
+    w3 = sd[p + "second_conv.0.weight"]
+    gterm = ops.gemm(gmax, wc.get(w3, cols=(0, 256)), out_dtype=torch.float32, bias=sd[p + "second_conv.0.bias"])
+    g2, be2, rm2, rv2, nb2 = _bn_params(sd, p + "second_conv.1.")
+    if bn_train:
+        cs = torch.empty((M // 64, 512), dtype=torch.float32, device=dev)
+        cq = torch.empty_like(cs)
+        y3 = ops.gemm(y2, wc.get(w3, cols=(256, 512)), out_dtype=T, group_add=gterm, group_rows=32, col_stats=(cs, cq))
+        sc2, sh2 = ops.bn_finalize(g2, be2, True, partials=(cs, cq), rows_per_partial=64, count=M,
+                                   running_mean=rm2, running_var=rv2, num_batches_tracked=nb2,
+                                   update_running=update_running)
+    else:
+        y3 = ops.gemm(y2, wc.get(w3, cols=(256, 512)), out_dtype=T, group_add=gterm, group_rows=32)
+        sc2, sh2 = ops.bn_finalize(g2, be2, False, running_mean=rm2, running_var=rv2)
+    # BN2 + ReLU in the A-prologue of conv4; only the pooled maximum is written
+    tok = torch.empty((M // 32, sd[p + "second_conv.3.weight"].shape[0]), dtype=T, device=dev)
+    ops.gemm(y3, wc.get(sd[p + "second_conv.3.weight"]), a_mode=A_AFFINE_RELU, a_scale=sc2, a_shift=sh2,
+             bias=sd[p + "second_conv.3.bias"], pool_max=tok, want_out=False)
+    return tok
+
+
+def vit_block_forward(sd, p, wc, x, pos, B, Tn, heads, dp1, dp2, save=None):
+    """Block.forward on block(x + pos) (point_encoder.py:76-79,103).  x [B*Tn, D] fp32 is updated in
+    place unless `save` (a dict) is given: then every intermediate the backward needs is kept."""
+    T = wc.dtype
+    keep = save is not None
+    xs = torch.empty_like(x) if keep else x
+    h, mean1, rstd1 = ops.layernorm_fwd(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], T, add=pos, write_xs=xs,
+                                        save_stats=keep)
+    qkv = ops.gemm(h, wc.get(sd[p + "attn.qkv.weight"]), out_dtype=T)
+    a, lse = ops.attention_fwd(qkv, B, Tn, heads, ATTN_SCALE, False, want_lse=keep)
+    x_mid = torch.empty_like(x) if keep else xs
+    ops.gemm(a, wc.get(sd[p + "attn.proj.weight"]), out=x_mid, bias=sd[p + "attn.proj.bias"], row_scale=dp1,
+             row_scale_rows=Tn, residual=xs)
+    h2, mean2, rstd2 = ops.layernorm_fwd(x_mid, sd[p + "norm2.weight"], sd[p + "norm2.bias"], T, save_stats=keep)
+    pre = torch.empty((x.shape[0], sd[p + "mlp.fc1.weight"].shape[0]), dtype=T, device=x.device) if keep else None
+    f = ops.gemm(h2, wc.get(sd[p + "mlp.fc1.weight"]), out_dtype=T, bias=sd[p + "mlp.fc1.bias"], act=ACT_GELU,
+                 out2=pre, out2_pre=True)
+    x_out = torch.empty_like(x) if keep else x_mid
+    ops.gemm(f, wc.get(sd[p + "mlp.fc2.weight"]), out=x_out, bias=sd[p + "mlp.fc2.bias"], row_scale=dp2,
+             row_scale_rows=Tn, residual=x_mid)
+    if keep:
+        save.update(xs=xs, mean1=mean1, rstd1=rstd1, h=h, qkv=qkv, a=a, lse=lse, x_mid=x_mid, mean2=mean2,
+                    rstd2=rstd2, h2=h2, pre=pre, f=f, dp1=dp1, dp2=dp2)
+    return x_out
+
+
+def point_encoder_forward(sd, p, wc, pc, fps_start, dp, bn_train, save_tier, cfg, update_running=True):
+    """PointTransformer.forward (point_encoder.py:234-257) -> (feat [B,2*D] fp32, saved | None).
+    dp: DropPath factors [depth,2,B] fp32 or None; save_tier > 0 keeps block-(depth-1) activations."""
+    T = wc.dtype
+    B = pc.shape[0]
+    G, D, depth, heads = cfg["num_group"], cfg["trans_dim"], cfg["depth"], cfg["num_heads"]
+    Tn = G + 1
+    dev = pc.device
+    nbhd, center = group_points(pc, G, cfg["group_size"], fps_start)
+    tok = mini_pointnet(sd, p + "encoder.", wc, nbhd, bn_train, update_running)
+    x = torch.empty((B, Tn, D), dtype=torch.float32, device=dev)
+    pos = torch.empty((B, Tn, D), dtype=torch.float32, device=dev)
+    x[:, 0] = sd[p + "cls_token"].view(D)
+    pos[:, 0] = sd[p + "cls_pos"].view(D)
+    x2, pos2 = x.view(B * Tn, D), pos.view(B * Tn, D)
+    # reduce_dim and pos_embed write straight into rows 1.. of every sample (batched GEMM)
+    ops.gemm(tok, wc.get(sd[p + "reduce_dim.weight"]), out=x2[1:], M=G, bias=sd[p + "reduce_dim.bias"], batch=B,
+             strideA=G * tok.shape[1], strideC=Tn * D)
+    pe = ops.linear3_gelu(center.view(B * G, 3), sd[p + "pos_embed.0.weight"], sd[p + "pos_embed.0.bias"], T)
+    ops.gemm(pe, wc.get(sd[p + "pos_embed.2.weight"]), out=pos2[1:], M=G, bias=sd[p + "pos_embed.2.bias"], batch=B,
+             strideA=G * pe.shape[1], strideC=Tn * D)
+    saved = None
+    for l in range(depth):
+        bp = f"{p}blocks.blocks.{l}."
+        d1 = dp[l, 0] if dp is not None else None
+        d2 = dp[l, 1] if dp is not None else None
+        if save_tier > 0 and l == depth - 1:
+            saved = {}
+            x2 = vit_block_forward(sd, bp, wc, x2, pos2, B, Tn, heads, d1, d2, save=saved)
+        else:
+            x2 = vit_block_forward(sd, bp, wc, x2, pos2, B, Tn, heads, d1, d2)
+    keep = saved is not None
+    xn, meanf, rstdf = ops.layernorm_fwd(x2, sd[p + "norm.weight"], sd[p + "norm.bias"], torch.float32, save_stats=keep)
+    feat, argmax = ops.cls_max_pool(xn.view(B, Tn, D), want_argmax=keep)
+    if keep:
+        saved.update(x_out=x2, meanf=meanf, rstdf=rstdf, argmax=argmax, B=B, Tn=Tn, D=D, heads=heads,
+                     prefix=f"{p}blocks.blocks.{depth - 1}.", norm_w=sd[p + "norm.weight"])
+    return feat, saved
+
+
+def _wgrad(dy_t, x_t):
+    """dW[N,K] = dY[M,N]^T @ X[M,K]: both operands are M-major, so transpose both and run the NT GEMM."""
+    return ops.gemm(ops.transpose(dy_t), ops.transpose(x_t), out_dtype=torch.float32)
+
+
+def point_encoder_backward(sd, wc, s, dfeat, tier):
+    """Backward of the un-frozen part (ULIP_models.py:461-470): final LN -> block depth-1.
+    Returns {param name: grad} for the tier's parameters."""
+    T = wc.dtype
+    B, Tn, D, heads, p = s["B"], s["Tn"], s["D"], s["heads"], s["prefix"]
+    M = B * Tn
+    grads = {}
+    # cat(cls, max) backward: scatter into the final-LN output gradient
+    dxn = torch.zeros((B, Tn, D), dtype=torch.float32, device=dfeat.device)
+    dxn[:, 0] = dfeat[:, :D]
+    dxn.scatter_(1, s["argmax"].view(B, 1, D).long(), dfeat[:, D:].reshape(B, 1, D))
+    g, _, _ = ops.layernorm_bwd(dxn.view(M, D), s["x_out"], s["norm_w"], s["meanf"], s["rstdf"])
+    dp1, dp2 = s["dp1"], s["dp2"]
+    # ---- MLP branch: x_out = x_mid + dp2 * (gelu(h2 W1^T + b1) W2^T + b2)
+    gs = g if dp2 is None else (g.view(B, Tn, D) * dp2.view(B, 1, 1)).view(M, D)
+    gs_t = ops.convert(gs, T)
+    grads[p + "mlp.fc2.weight"] = _wgrad(gs_t, s["f"])
+    grads[p + "mlp.fc2.bias"] = ops.col_sums(gs)
+    d_pre = ops.gemm(gs_t, wc.get(sd[p + "mlp.fc2.weight"], "wt"), out_dtype=T, act=ACT_GELU, dact_pre=s["pre"])
+    d_h2 = ops.gemm(d_pre, wc.get(sd[p + "mlp.fc1.weight"], "wt"), out_dtype=torch.float32)
+    if tier >= 2:
+        grads[p + "mlp.fc1.weight"] = _wgrad(d_pre, s["h2"])
+        grads[p + "mlp.fc1.bias"] = ops.col_sums(d_pre)
+    _, dw, db = ops.layernorm_bwd(d_h2, s["x_mid"], sd[p + "norm2.weight"], s["mean2"], s["rstd2"], dx=g,
+                                  accumulate=True, want_wgrad=True)
+    grads[p + "norm2.weight"], grads[p + "norm2.bias"] = dw, db
+    if tier < 2:
+        return grads
+    # ---- attention branch: x_mid = xs + dp1 * (attn(LN1(xs)) Wp^T + bp)
+    gs = g if dp1 is None else (g.view(B, Tn, D) * dp1.view(B, 1, 1)).view(M, D)
+    gs_t = ops.convert(gs, T)
+    if tier >= 3:
+        grads[p + "attn.proj.weight"] = _wgrad(gs_t, s["a"])
+        grads[p + "attn.proj.bias"] = ops.col_sums(gs)
+    d_a = ops.gemm(gs_t, wc.get(sd[p + "attn.proj.weight"], "wt"), out_dtype=T)
+    d_qkv = ops.attention_bwd(s["qkv"], s["a"], d_a, s["lse"], B, Tn, heads, ATTN_SCALE, False)
+    if tier >= 3:
+        grads[p + "attn.qkv.weight"] = _wgrad(d_qkv, s["h"])
+    d_h = ops.gemm(d_qkv, wc.get(sd[p + "attn.qkv.weight"], "wt"), out_dtype=torch.float32)
+    _, dw, db = ops.layernorm_bwd(d_h, s["xs"], sd[p + "norm1.weight"], s["mean1"], s["rstd1"], want_wgrad=True)
+    grads[p + "norm1.weight"], grads[p + "norm1.bias"] = dw, db
+    return grads
+
+
+# =================================================================================================
+# text branch (CLIP text transformer, ULIP_models.py:35-67, 203-222)
+# =================================================================================================
+def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save):
+    """encode_text: prompts [C,L,W] fp32 -> text features [C,E] fp32 (before L2 normalisation).
+    save=True keeps what the input-gradient backward needs."""
+    T = wc.dtype
+    C, L, Wd = prompts.shape
+    M = C * L
+    dev = prompts.device
+    saved = {"layers": []} if save else None
+    x = torch.empty((M, Wd), dtype=torch.float32, device=dev)
+    add, add_rows = sd["positional_embedding"], L                 # x = prompts + pos (ULIP_models.py:210)
+    xin = prompts.reshape(M, Wd)
+    for i in range(layers):
+        p = f"transformer.resblocks.{i}."
+        h, mean1, rstd1 = ops.layernorm_fwd(xin, sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], T, add=add,
+                                            add_rows=add_rows, write_xs=x if add is not None else None,
+                                            save_stats=save)
+        add, add_rows = None, 0
+        qkv = ops.gemm(h, wc.get(sd[p + "attn.in_proj_weight"]), out_dtype=T, bias=sd[p + "attn.in_proj_bias"])
+        a, lse = ops.attention_fwd(qkv, C, L, heads, ATTN_SCALE, True, want_lse=save)
+        x_mid = torch.empty_like(x)
+        ops.gemm(a, wc.get(sd[p + "attn.out_proj.weight"]), out=x_mid, bias=sd[p + "attn.out_proj.bias"], residual=x)
+        h2, mean2, rstd2 = ops.layernorm_fwd(x_mid, sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], T, save_stats=save)
+        pre = torch.empty((M, sd[p + "mlp.c_fc.weight"].shape[0]), dtype=T, device=dev) if save else None
+        f = ops.gemm(h2, wc.get(sd[p + "mlp.c_fc.weight"]), out_dtype=T, bias=sd[p + "mlp.c_fc.bias"],
+                     act=ACT_QUICKGELU, out2=pre, out2_pre=True)
+        x_next = torch.empty_like(x)
+        ops.gemm(f, wc.get(sd[p + "mlp.c_proj.weight"]), out=x_next, bias=sd[p + "mlp.c_proj.bias"], residual=x_mid)
+        if save:
+            saved["layers"].append(dict(x=x, mean1=mean1, rstd1=rstd1, qkv=qkv, a=a, lse=lse, x_mid=x_mid, mean2=mean2,
+                                        rstd2=rstd2, pre=pre))
+        x = x_next
+        xin = x
+    rows = torch.arange(C, device=dev) * L + eot_pos                # EOT pooling (ULIP_models.py:222)
+    x_eot = x.index_select(0, rows)
+    hn, meanf, rstdf = ops.layernorm_fwd(x_eot, sd["ln_final.weight"], sd["ln_final.bias"], torch.float32,
+                                         save_stats=save)
+    wc32 = _f32_cache(wc)
+    out = ops.gemm(hn, wc32.get(sd["text_projection"], "wt"), out_dtype=torch.float32)
+    if save:
+        saved.update(x_eot=x_eot, meanf=meanf, rstdf=rstdf, rows=rows, C=C, L=L, W=Wd, heads=heads)
+    return out, saved
+
+
+_F32_CACHES = {}
+
+
+def _f32_cache(wc):
+    """fp32 operand cache riding along a WeightCache (head GEMMs always run in fp32)."""
+    c = _F32_CACHES.get(id(wc))
+    if c is None or c[0] is not wc:
+        c = (wc, WeightCache(torch.float32))
+        _F32_CACHES[id(wc)] = c
+    return c[1]
+
+
+def text_tower_backward(sd, wc, s, dout):
+    """Input gradient of encode_text: dout [C,E] -> d prompts [C,L,W] fp32.  The tower is frozen
+    (ULIP_models.py:487-507), so no weight gradient is ever formed: 4 dX GEMMs, 2 LayerNorm
+    backwards and one attention backward per layer."""
+    T = wc.dtype
+    C, L, Wd, heads = s["C"], s["L"], s["W"], s["heads"]
+    M = C * L
+    wc32 = _f32_cache(wc)
+    d_hn = ops.gemm(dout.contiguous(), wc32.get(sd["text_projection"], "w"), out_dtype=torch.float32)
+    d_eot, _, _ = ops.layernorm_bwd(d_hn, s["x_eot"], sd["ln_final.weight"], s["meanf"], s["rstdf"])
+    g = torch.zeros((M, Wd), dtype=torch.float32, device=dout.device)
+    g.index_copy_(0, s["rows"], d_eot)
+    g_t = ops.convert(g, T)
+    for i in reversed(range(len(s["layers"]))):
+        p = f"transformer.resblocks.{i}."
+        ly = s["layers"][i]
+        d_pre = ops.gemm(g_t, wc.get(sd[p + "mlp.c_proj.weight"], "wt"), out_dtype=T, act=ACT_QUICKGELU,
+                         dact_pre=ly["pre"])
+        d_h2 = ops.gemm(d_pre, wc.get(sd[p + "mlp.c_fc.weight"], "wt"), out_dtype=torch.float32)
+        _, _, _, g_t = ops.layernorm_bwd(d_h2, ly["x_mid"], sd[p + "ln_2.weight"], ly["mean2"], ly["rstd2"], dx=g,
+                                         accumulate=True, copy_dtype=T)
+        d_a = ops.gemm(g_t, wc.get(sd[p + "attn.out_proj.weight"], "wt"), out_dtype=T)
+        d_qkv = ops.attention_bwd(ly["qkv"], ly["a"], d_a, ly["lse"], C, L, heads, ATTN_SCALE, True)
+        d_h = ops.gemm(d_qkv, wc.get(sd[p + "attn.in_proj_weight"], "wt"), out_dtype=torch.float32)
+        _, _, _, g_t = ops.layernorm_bwd(d_h, ly["x"], sd[p + "ln_1.weight"], ly["mean1"], ly["rstd1"], dx=g,
+                                         accumulate=True, copy_dtype=T)
+    return g.view(C, L, Wd)

@@ -1,0 +1,425 @@
+"""Mirror of models/ULIP_models.py for the hot path: LayerNorm, QuickGELU, ResidualAttentionBlock,
+Transformer, PromptLearner, ULIP_WITH_IMAGE and the ULIP_PointBERT factory (ULIP_models.py:21-283,
+443-512), with the reference's attribute names and state-dict keys so that main_cls.py-style
+callers (`model(pc)`, `.prompt_learner`, `.point_encoder.blocks.blocks[-1]`, `.logit_scale`) and
+ULIP checkpoints work unchanged.  Compute runs on libppt_hip.so through ppt_amd.engine.
+"""
+import json
+import os
+from collections import OrderedDict
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import engine, ops
+
+_DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data")
+CONTEXT_LENGTH = 77
+
+
+class LayerNorm(nn.LayerNorm):
+    """ULIP_models.py:21-27 (parameter container; fp32 statistics are what the kernel computes)."""
+
+
+class QuickGELU(nn.Module):
+    """ULIP_models.py:30-32."""
+
+    def forward(self, x):
+        return x * torch.sigmoid(1.702 * x)
+
+
+class ResidualAttentionBlock(nn.Module):
+    """ULIP_models.py:35-56 (keys: attn.in_proj_weight/bias, attn.out_proj.*, ln_1, mlp.c_fc, mlp.c_proj, ln_2)."""
+
+    def __init__(self, d_model, n_head, attn_mask=None):
+        super().__init__()
+        self.attn = nn.MultiheadAttention(d_model, n_head)
+        self.ln_1 = LayerNorm(d_model)
+        self.mlp = nn.Sequential(OrderedDict([("c_fc", nn.Linear(d_model, d_model * 4)), ("gelu", QuickGELU()),
+                                              ("c_proj", nn.Linear(d_model * 4, d_model))]))
+        self.ln_2 = LayerNorm(d_model)
+        self.attn_mask = attn_mask
+
+
+class Transformer(nn.Module):
+    """ULIP_models.py:59-67."""
+
+    def __init__(self, width, layers, heads, attn_mask=None):
+        super().__init__()
+        self.width = width
+        self.layers = layers
+        self.heads = heads
+        self.resblocks = nn.Sequential(*[ResidualAttentionBlock(width, heads, attn_mask) for _ in range(layers)])
+
+
+# ---- prompt tokenisation (token-id table captured from the reference tokenizer)
+_TOKENS = None
+
+
+def _token_table():
+    global _TOKENS
+    if _TOKENS is None:
+        with open(os.path.join(_DATA, "classnames.json")) as f:
+            _TOKENS = json.load(f)
+    return _TOKENS
+
+
+def dataset_classnames(name):
+    """class-name list of reference data/labels.json (utils/utils.py:118 loads it into args.classnames)."""
+    return list(_token_table()["datasets"][name])
+
+
+def tokenize_prompts(classnames, n_ctx, template_tokens=None):
+    """Token ids of "X X ... X <name>." per class (ULIP_models.py:87-100) -> (ids [C,77] int64, name_lengths).
+    Class names must be in ppt_amd/data/classnames.json (all reference datasets are); a full BPE
+    tokenizer is the 'next' row N3."""
+    tab = _token_table()
+    ids, lens = [], []
+    for name in classnames:
+        key = name.replace("_", " ")
+        if key not in tab["name_tokens"]:
+            raise KeyError(f"class name {key!r} has no captured token ids (ppt_amd/data/classnames.json); "
+                           "BPE tokenisation of arbitrary names is not built yet (SURVEY.md §8(f) N3)")
+        nt = tab["name_tokens"][key]
+        ctx = template_tokens if template_tokens is not None else [tab["placeholder"]] * n_ctx
+        row = [tab["sot"]] + list(ctx) + nt + [tab["period"], tab["eot"]]
+        if len(row) > CONTEXT_LENGTH:
+            raise RuntimeError(f"prompt for {name!r} exceeds the context length {CONTEXT_LENGTH}")
+        ids.append(row + [0] * (CONTEXT_LENGTH - len(row)))
+        lens.append(len(nt))
+    return torch.tensor(ids, dtype=torch.long), lens
+
+
+class PromptLearner(nn.Module):
+    """ULIP_models.py:70-151.  The only parameter is `learnable_tokens` [n_ctx, width]."""
+
+    def __init__(self, token_embeding, kwargs):
+        super().__init__()
+        self.class_name_position = kwargs.class_name_position
+        self.classnames = kwargs.classnames
+        self.transformer_width = kwargs.transformer_width
+        self.device = kwargs.device
+        template_tokens = None
+        if kwargs.template_init != '':
+            words = kwargs.template_init.replace("_", " ").split(' ')
+            tab = _token_table()
+            template_tokens = []
+            for wd in words:
+                if wd not in tab["name_tokens"] or len(tab["name_tokens"][wd]) != 1:
+                    raise KeyError(f"template word {wd!r} has no captured single token id (SURVEY.md §8(f) N3)")
+                template_tokens += tab["name_tokens"][wd]
+            self.num_learnable_prompt_tokens = len(words)
+        else:
+            self.num_learnable_prompt_tokens = kwargs.num_learnable_prompt_tokens
+        self.learnable_tokens = nn.Parameter(torch.empty(self.num_learnable_prompt_tokens, self.transformer_width))
+        self.tokenized_prompts, self.name_lengths = tokenize_prompts(self.classnames, self.num_learnable_prompt_tokens,
+                                                                     template_tokens)
+        # the frozen prefix / class-name / suffix embeddings are looked up ONCE at
+        # construction (before any weight is initialised or loaded) and are neither parameter nor buffer.
+        with torch.no_grad():
+            self.embedding = token_embeding(self.tokenized_prompts).detach().clone()
+        self._index = None
+
+    def _apply(self, fn, *a, **k):
+        super()._apply(fn, *a, **k)
+        self.embedding = fn(self.embedding)
+        self._index = None
+        return self
+
+    def _scatter_index(self, device):
+        """(class, position, token) triplets of every learnable-token slot (ULIP_models.py:112-148)."""
+        if self._index is None or self._index[0].device != device:
+            n = self.num_learnable_prompt_tokens
+            C = len(self.classnames)
+            pos = torch.empty((C, n), dtype=torch.long)
+            for i in range(C):
+                L = self.name_lengths[i]
+                if self.class_name_position == "end":
+                    pos[i] = 1 + torch.arange(n)
+                elif self.class_name_position == "middle":
+                    half = n // 2
+                    pos[i, :half] = 1 + torch.arange(half)
+                    pos[i, half:] = 1 + half + L + torch.arange(n - half)
+                elif self.class_name_position == "front":
+                    pos[i] = 1 + L + torch.arange(n)
+                else:
+                    raise ValueError(f'`class_name_position`: {self.class_name_position} not in supported modes '
+                                     f'["front", "middle", "end"]')
+            src = torch.empty((C, CONTEXT_LENGTH), dtype=torch.long)     # where every output slot comes from
+            for i in range(C):
+                L = self.name_lengths[i]
+                order = list(range(CONTEXT_LENGTH))
+                if self.class_name_position == "middle":
+                    half = n // 2
+                    # [prefix | ctx[:half] | class | ctx[half:] | rest]; the cached embedding is [prefix | ctx | class | rest]
+                    order = [0] + list(range(1, 1 + half)) + list(range(1 + n, 1 + n + L)) \
+                        + list(range(1 + half, 1 + n)) + list(range(1 + n + L, CONTEXT_LENGTH))
+                elif self.class_name_position == "front":
+                    order = [0] + list(range(1 + n, 1 + n + L)) + list(range(1, 1 + n)) + list(range(1 + n + L, CONTEXT_LENGTH))
+                src[i] = torch.tensor(order)
+            cls = torch.arange(C).view(C, 1).expand(C, n)
+            self._index = (cls.to(device), pos.to(device), src.to(device))
+        return self._index
+
+    def forward(self):
+        """-> prompts [C,77,width]: frozen embeddings with the learnable tokens spliced in."""
+        if self.class_name_position not in ("front", "middle", "end"):
+            raise ValueError(f'`class_name_position`: {self.class_name_position} not in supported modes '
+                             f'["front", "middle", "end"]')
+        dev = self.learnable_tokens.device
+        cls, pos, src = self._scatter_index(dev)
+        emb = self.embedding.to(dev)
+        base = torch.gather(emb, 1, src.unsqueeze(-1).expand(-1, -1, emb.shape[-1]))
+        return base.index_put((cls, pos), self.learnable_tokens.unsqueeze(0).expand(cls.shape[0], -1, -1))
+
+    def eot_positions(self):
+        return self.tokenized_prompts.argmax(dim=-1)
+
+
+class _TextTowerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, prompts):
+        sd = model._live_state()
+        save = prompts.requires_grad and torch.is_grad_enabled()
+        out, saved = engine.text_tower_forward(sd, model._cache(), prompts.contiguous().float(), model._eot(prompts.device),
+                                               model.transformer.heads, model.transformer.layers, save)
+        ctx.model, ctx.saved = model, saved
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        m = ctx.model
+        return None, engine.text_tower_backward(m._live_state(), m._cache(), ctx.saved, dout.float())
+
+
+class _MatmulNT(torch.autograd.Function):
+    """a [M,K] @ b[N,K]^T in fp32 on the fp32 MFMA (tiny head products: projection, logits)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous().float(), b.contiguous().float()
+        ctx.save_for_backward(a, b)
+        return ops.gemm(a, b, out_dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, dc):
+        a, b = ctx.saved_tensors
+        dc = dc.contiguous().float()
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = ops.gemm(dc, ops.transpose(b), out_dtype=torch.float32)              # [M,N] @ [N,K]
+        if ctx.needs_input_grad[1]:
+            db = ops.gemm(ops.transpose(dc), ops.transpose(a), out_dtype=torch.float32)   # [N,M] @ [M,K]
+        return da, db
+
+
+def matmul_nt(a, b):
+    return _MatmulNT.apply(a, b)
+
+
+class ULIP_WITH_IMAGE(nn.Module):
+    """ULIP_models.py:154-283 (text transformer + PromptLearner + point encoder + projections)."""
+
+    def __init__(self, point_encoder, **kwargs):
+        super().__init__()
+        kwargs = SimpleNamespace(**kwargs)
+        self.task = kwargs.task
+        self.context_length = kwargs.context_length
+        self.device = kwargs.device
+        self.transformer = Transformer(width=kwargs.transformer_width, layers=kwargs.transformer_layers,
+                                       heads=kwargs.transformer_heads, attn_mask=self.build_attention_mask())
+        self.vocab_size = kwargs.vocab_size
+        self.token_embedding = nn.Embedding(kwargs.vocab_size, kwargs.transformer_width)
+        self.positional_embedding = nn.Parameter(torch.empty(self.context_length, kwargs.transformer_width))
+        self.ln_final = LayerNorm(kwargs.transformer_width)
+        self.text_projection = nn.Parameter(torch.empty(kwargs.transformer_width, kwargs.embed_dim))
+        self.pc_projection = nn.Parameter(torch.empty(kwargs.pc_feat_dims, kwargs.embed_dim))
+        self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
+        self.point_encoder = point_encoder
+        self.prompt_learner = PromptLearner(self.token_embedding, kwargs)
+        self.tokenized_prompts = self.prompt_learner.tokenized_prompts
+        self.initialize_parameters()
+        self._wc = None
+        self._sd = None
+        self._eot_pos = None
+        self._text_stream = None
+        self.overlap_text_tower = True      # run the (input-independent) text tower on a side stream
+
+    # ---- reference helpers ------------------------------------------------------------------
+    def build_attention_mask(self):
+        """ULIP_models.py:224-230 (kept for API parity; the attention kernel applies the causal mask itself)."""
+        mask = torch.empty(self.context_length, self.context_length)
+        mask.fill_(float("-inf"))
+        mask.triu_(1)
+        return mask
+
+    def initialize_parameters(self):
+        """ULIP_models.py:232-248."""
+        nn.init.normal_(self.token_embedding.weight, std=0.02)
+        nn.init.normal_(self.positional_embedding, std=0.01)
+        nn.init.normal_(self.prompt_learner.learnable_tokens, std=0.02)
+        proj_std = (self.transformer.width ** -0.5) * ((2 * self.transformer.layers) ** -0.5)
+        attn_std = self.transformer.width ** -0.5
+        fc_std = (2 * self.transformer.width) ** -0.5
+        for block in self.transformer.resblocks:
+            nn.init.normal_(block.attn.in_proj_weight, std=attn_std)
+            nn.init.normal_(block.attn.out_proj.weight, std=proj_std)
+            nn.init.normal_(block.mlp.c_fc.weight, std=fc_std)
+            nn.init.normal_(block.mlp.c_proj.weight, std=proj_std)
+        nn.init.normal_(self.text_projection, std=self.transformer.width ** -0.5)
+        nn.init.normal_(self.pc_projection, std=512 ** -0.5)
+
+    # ---- plumbing -----------------------------------------------------------------------------
+    @property
+    def precision(self):
+        return getattr(self.point_encoder, "precision", torch.bfloat16)
+
+    def set_precision(self, dtype):
+        """torch.bfloat16 (performance mode) or torch.float32 (parity mode) for both towers."""
+        self.point_encoder.precision = dtype
+        if hasattr(self.point_encoder, "encoder"):
+            self.point_encoder.encoder.precision = dtype
+        return self
+
+    def _cache(self):
+        if self._wc is None or self._wc.dtype != self.precision:
+            self._wc = engine.WeightCache(self.precision)
+        return self._wc
+
+    def _live_state(self):
+        ref = self.positional_embedding
+        if self._sd is None or self._sd[1] is not ref or self._sd[2] != ref.device:
+            sd = {k: v for k, v in self.state_dict(keep_vars=True).items() if not k.startswith("point_encoder.")}
+            self._sd = (sd, ref, ref.device)
+        return self._sd[0]
+
+    def _apply(self, fn, *a, **k):
+        self._sd = None
+        self._eot_pos = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._sd = None
+        return super().load_state_dict(*a, **k)
+
+    def _eot(self, device):
+        if self._eot_pos is None or self._eot_pos.device != device:
+            self._eot_pos = self.tokenized_prompts.argmax(dim=-1).to(device)
+        return self._eot_pos
+
+    # ---- reference API ------------------------------------------------------------------------
+    def encode_text(self, prompts, tokenized_prompts=None):
+        """ULIP_models.py:203-222: prompts [C,77,W] -> [C,embed_dim]."""
+        return _TextTowerFn.apply(self, prompts)
+
+    def encode_pc(self, pc, cls_label=None):
+        """ULIP_models.py:250-258."""
+        if self.task == 'partseg':
+            pc_feat = self.point_encoder(pc, cls_label)
+        else:
+            pc_feat = self.point_encoder(pc)
+        wt = engine._f32_cache(self._cache()).get(self.pc_projection, "wt")     # [embed, feat]
+        lead = pc_feat.shape[:-1]
+        return matmul_nt(pc_feat.reshape(-1, pc_feat.shape[-1]), wt).view(*lead, -1)
+
+    def _text_embed(self):
+        prompts = self.prompt_learner()
+        text_embed = self.encode_text(prompts, self.tokenized_prompts)
+        return text_embed / text_embed.norm(dim=-1, keepdim=True)
+
+    def forward(self, pc, cls_label=None):
+        """ULIP_models.py:260-283 -> logits [B,C] (partseg: [B,N,C])."""
+        cur = torch.cuda.current_stream()
+        side = None
+        if self.overlap_text_tower and pc.is_cuda:
+            if self._text_stream is None:
+                self._text_stream = torch.cuda.Stream()
+            side = self._text_stream
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                text_embed = self._text_embed()
+        pc_embed = self.encode_pc(pc, cls_label) if self.task == 'partseg' else self.encode_pc(pc)
+        if side is not None:
+            cur.wait_stream(side)
+            text_embed.record_stream(cur)
+        else:
+            text_embed = self._text_embed()
+        logit_scale = self.logit_scale.exp()
+        lead = pc_embed.shape[:-1]
+        logits = matmul_nt((logit_scale * pc_embed).reshape(-1, pc_embed.shape[-1]), text_embed)
+        return logits.view(*lead, -1)
+
+
+def get_metric_names():
+    """ULIP_models.py:290-291."""
+    return ['loss', 'acc']
+
+
+def cfg_from_yaml_file(cfg_file):
+    """data/dataset_3d.py:841-847 equivalent for the model yaml: nested attribute namespace."""
+    import yaml
+
+    def wrap(d):
+        return SimpleNamespace(**{k: wrap(v) if isinstance(v, dict) else v for k, v in d.items()})
+    with open(cfg_file) as f:
+        return wrap(yaml.load(f, Loader=yaml.FullLoader))
+
+
+POINTBERT_CONFIG = SimpleNamespace(NAME="PointTransformer", trans_dim=384, depth=12, drop_path_rate=0.1, cls_dim=40,
+                                   num_heads=6, group_size=32, num_group=512, encoder_dims=256)
+"""models/pointbert/PointTransformer_8192point.yaml:15-25 (`model:` section)."""
+
+
+def unfreeze_list(head_type):
+    """ULIP_models.py:461-470."""
+    p = 'point_encoder.blocks.blocks.11.'
+    mods = []
+    if head_type > 0:
+        mods += [p + 'norm2.weight', p + 'norm2.bias', p + 'mlp.fc2.weight', p + 'mlp.fc2.bias']
+    if head_type > 1:
+        mods += [p + 'norm1.weight', p + 'norm1.bias', p + 'mlp.fc1.weight', p + 'mlp.fc1.bias']
+    if head_type > 2:
+        mods += [p + 'attn.qkv.weight', p + 'attn.proj.weight', p + 'attn.proj.bias']
+    return mods
+
+
+def _load_and_freeze(model, args, point_ckpt, skip):
+    """ULIP_models.py:472-507: copy pretrained values (when the checkpoint files exist) and freeze
+    everything except `skip`.  Un-frozen parameters are NOT loaded."""
+    point_params = slip_params = None
+    slip_ckpt = './data/initialize_models/slip_base_100ep.pt'
+    if os.path.exists(point_ckpt) and os.path.exists(slip_ckpt):
+        strip = lambda sd: {k.replace('module.', ''): v for k, v in sd.items()}
+        point_params = strip(torch.load(point_ckpt, map_location='cpu')['state_dict'])
+        slip_params = strip(torch.load(slip_ckpt, map_location='cpu')['state_dict'])
+    for name, param in model.named_parameters():
+        if name == 'prompt_learner.learnable_tokens' or 'point_encoder.cls_head' in name or name in skip:
+            continue
+        param.requires_grad = False
+        if point_params is not None:
+            src = point_params[name] if name in point_params else slip_params[name]
+            param.data.copy_(src.data if isinstance(src, nn.Parameter) else src)
+
+
+def ULIP_PointBERT(args):
+    """ULIP_models.py:443-512.  args: classnames, template_init, class_name_position,
+    num_learnable_prompt_tokens, gpu, task, head_type, evaluate_3d, ulip2."""
+    from .pointbert.point_encoder import PointTransformer
+    config_addr = './models/pointbert/PointTransformer_8192point.yaml'
+    config = cfg_from_yaml_file(config_addr).model if os.path.exists(config_addr) else POINTBERT_CONFIG
+    point_encoder = PointTransformer(config, args=args)
+    model = ULIP_WITH_IMAGE(embed_dim=512, point_encoder=point_encoder, context_length=77, vocab_size=49408,
+                            classnames=args.classnames, template_init=args.template_init,
+                            class_name_position=args.class_name_position,
+                            num_learnable_prompt_tokens=args.num_learnable_prompt_tokens, transformer_width=512,
+                            transformer_heads=8, transformer_layers=12, pc_feat_dims=768, device=args.gpu,
+                            task=args.task)
+    if not getattr(args, "evaluate_3d", False):
+        ckpt = './data/pretrained_models/pointbert_ulip2.pt' if getattr(args, "ulip2", False) \
+            else './data/pretrained_models/pointbert.pt'
+        _load_and_freeze(model, args, ckpt, set(unfreeze_list(args.head_type)))
+    params = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    print('\n====================\n\tNumber of learnable params:', params, '\n====================\n')
+    return model

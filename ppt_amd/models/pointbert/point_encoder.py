@@ -1,0 +1,204 @@
+"""Mirror of models/pointbert/point_encoder.py:14-257 (Mlp, Attention, Block, TransformerEncoder,
+PointTransformer): identical constructor signatures, attribute names and state-dict keys; the
+forward of PointTransformer is ONE autograd node running ppt_amd.engine's kernel pipeline."""
+import torch
+import torch.nn as nn
+
+from ... import engine
+from .dvae import Encoder, Group
+
+
+class Mlp(nn.Module):
+    """point_encoder.py:14-30 (parameter container; computed inside engine.vit_block_forward)."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+
+
+class Attention(nn.Module):
+    """point_encoder.py:33-58 (qkv_bias=False; scale applied after q@k^T)."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        self.scale = qk_scale or head_dim ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+
+
+class DropPath(nn.Module):
+    """timm 0.4.12 DropPath semantics: per-sample factor floor(keep + U[0,1)) / keep in train()."""
+
+    def __init__(self, drop_prob=None):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+
+class Block(nn.Module):
+    """point_encoder.py:61-79."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0., attn_drop=0.,
+                 drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        mlp_hidden_dim = int(dim * mlp_ratio)
+        self.mlp = Mlp(in_features=dim, hidden_features=mlp_hidden_dim, act_layer=act_layer, drop=drop)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop,
+                              proj_drop=drop)
+
+
+class TransformerEncoder(nn.Module):
+    """point_encoder.py:82-110."""
+
+    def __init__(self, embed_dim=768, depth=4, num_heads=12, mlp_ratio=4., qkv_bias=False, qk_scale=None,
+                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0.):
+        super().__init__()
+        self.blocks = nn.ModuleList([
+            Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                  drop=drop_rate, attn_drop=attn_drop_rate,
+                  drop_path=drop_path_rate[i] if isinstance(drop_path_rate, list) else drop_path_rate)
+            for i in range(depth)])
+
+
+TIER_PARAMS = {   # ULIP_models.py:461-470, cumulative
+    1: ["norm2.weight", "norm2.bias", "mlp.fc2.weight", "mlp.fc2.bias"],
+    2: ["norm1.weight", "norm1.bias", "mlp.fc1.weight", "mlp.fc1.bias"],
+    3: ["attn.qkv.weight", "attn.proj.weight", "attn.proj.bias"],
+}
+
+
+class _PointEncoderFn(torch.autograd.Function):
+    """feat = PointTransformer(pc); gradients only for the un-frozen last-block parameters."""
+
+    @staticmethod
+    def forward(ctx, module, pc, fps_start, dp, tier, names, *params):
+        sd = module._live_state()
+        feat, saved = engine.point_encoder_forward(sd, "", module._cache(), pc, fps_start, dp, module.training, tier,
+                                                   module._cfg())
+        ctx.module, ctx.saved, ctx.tier, ctx.names = module, saved, tier, names
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        m = ctx.module
+        grads = engine.point_encoder_backward(m._live_state(), m._cache(), ctx.saved, dfeat.contiguous().float(), ctx.tier)
+        out = []
+        for n in ctx.names:
+            g = grads[n]
+            out.append(g.view_as(m._live_state()[n]))
+        return (None, None, None, None, None, None) + tuple(out)
+
+
+class PointTransformer(nn.Module):
+    """point_encoder.py:113-257.  `config` carries trans_dim, depth, drop_path_rate, cls_dim,
+    num_heads, group_size, num_group, encoder_dims (PointTransformer_8192point.yaml:15-25).
+
+    Extra, build-specific knobs (not in the reference): `precision` (torch.bfloat16 performance mode /
+    torch.float32 parity mode) and the injection hooks `fps_start` / `drop_path_factors` used by the
+    parity tests (SURVEY.md App. A Q8, §7 'RNG parity')."""
+
+    def __init__(self, config, **kwargs):
+        super().__init__()
+        self.config = config
+        self.args = kwargs.get("args")
+        self.trans_dim = config.trans_dim
+        self.depth = config.depth
+        self.drop_path_rate = config.drop_path_rate
+        self.cls_dim = config.cls_dim
+        self.num_heads = config.num_heads
+        self.group_size = config.group_size
+        self.num_group = config.num_group
+        self.group_divider = Group(num_group=self.num_group, group_size=self.group_size)
+        self.encoder_dims = config.encoder_dims
+        self.encoder = Encoder(encoder_channel=self.encoder_dims)
+        self.reduce_dim = nn.Linear(self.encoder_dims, self.trans_dim)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, self.trans_dim))
+        self.cls_pos = nn.Parameter(torch.randn(1, 1, self.trans_dim))
+        self.pos_embed = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, self.trans_dim))
+        dpr = [x.item() for x in torch.linspace(0, self.drop_path_rate, self.depth)]
+        self.dpr = dpr
+        self.blocks = TransformerEncoder(embed_dim=self.trans_dim, depth=self.depth, drop_path_rate=dpr,
+                                         num_heads=self.num_heads)
+        self.norm = nn.LayerNorm(self.trans_dim)
+        self.precision = torch.bfloat16
+        self.fps_start = None            # [B] int64: injected FPS start indices (else torch.randint)
+        self.drop_path_factors = None    # [depth,2,B] fp32: injected DropPath factors (else drawn on device)
+        self._wc = None
+        self._sd = None
+
+    # ---- plumbing -------------------------------------------------------------------------
+    def _cache(self):
+        if self._wc is None or self._wc.dtype != self.precision:
+            self._wc = engine.WeightCache(self.precision)
+        return self._wc
+
+    def _live_state(self):
+        ref = self.cls_token
+        if self._sd is None or self._sd[1] is not ref or self._sd[2] != ref.device:
+            self._sd = (self.state_dict(keep_vars=True), ref, ref.device)
+        return self._sd[0]
+
+    def _apply(self, fn, *a, **k):
+        self._sd = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._sd = None
+        return super().load_state_dict(*a, **k)
+
+    def _cfg(self):
+        return dict(num_group=self.num_group, group_size=self.group_size, trans_dim=self.trans_dim, depth=self.depth,
+                    num_heads=self.num_heads)
+
+    def _tier(self):
+        """head_type tier implied by the requires_grad flags of the last block (ULIP_models.py:461-470)."""
+        sd = dict(self.blocks.blocks[-1].named_parameters())
+        tier = 0
+        for t in (1, 2, 3):
+            if tier == t - 1 and all(sd[n].requires_grad for n in TIER_PARAMS[t]):
+                tier = t
+        expected = {n for t in (1, 2, 3) if t <= tier for n in TIER_PARAMS[t]}
+        actual = {n for n, q in sd.items() if q.requires_grad}
+        if actual != expected:
+            raise RuntimeError("un-frozen last-block parameters must follow the cumulative head_type tiers of "
+                               f"ULIP_models.py:461-470; got {sorted(actual)}")
+        return tier
+
+    def _draw_drop_path(self, B, device):
+        """timm DropPath factors for both residual branches of every block (train mode only)."""
+        if self.drop_path_factors is not None:
+            return self.drop_path_factors.to(device=device, dtype=torch.float32).contiguous()
+        if not self.training or self.drop_path_rate <= 0:
+            return None
+        keep = 1.0 - torch.tensor(self.dpr, dtype=torch.float32, device=device).view(-1, 1, 1)
+        u = torch.rand((self.depth, 2, B), dtype=torch.float32, device=device)
+        return (torch.floor(keep + u) / keep).contiguous()
+
+    # ---- reference API ---------------------------------------------------------------------
+    def forward(self, pts):
+        """pts [B,N,3] -> cat(cls, max) features [B, 2*trans_dim] (point_encoder.py:234-257)."""
+        pts = pts.contiguous().float()
+        B, N, _ = pts.shape
+        start = self.fps_start
+        if start is None:
+            start = torch.randint(0, N, (B,), dtype=torch.long, device=pts.device)   # misc.py:59
+        start = start.to(pts.device).contiguous()
+        dp = self._draw_drop_path(B, pts.device)
+        tier = self._tier() if torch.is_grad_enabled() else 0
+        names = []
+        for t in (1, 2, 3):
+            if tier >= t:
+                names += [f"blocks.blocks.{self.depth - 1}.{n}" for n in TIER_PARAMS[t]]
+        sd = self._live_state()
+        return _PointEncoderFn.apply(self, pts, start, dp, tier, names, *[sd[n] for n in names])

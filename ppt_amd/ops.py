@@ -79,7 +79,8 @@ def ball_query(xyz, center, radius, K):
 # ---------------------------------------------------------------------------------------------
 def gemm(A, B, *, out=None, out_dtype=None, M=None, bias=None, act=ACT_NONE, dact_pre=None,
          group_add=None, group_rows=0, row_scale=None, row_scale_rows=0, residual=None,
-         residual2=None, out2=None, col_stats=None, pool_max=None,
+         residual2=None, out2=None, out2_pre=False, col_stats=None, pool_max=None,
+         batch=1, strideA=0, strideB=0, strideC=0,
          a_mode=A_PLAIN, a_scale=None, a_shift=None, pts=None, w1=None, b1=None, want_out=True):
     """C[M,N] = epilogue(prologue(A)[M,K] @ B[N,K]^T) -- see struct ppt_gemm_params.
     A [M,K] (or None with a_mode=A_CONV1 and pts [M,3]); B [N,K]; 2-D, last-dim contiguous
@@ -119,12 +120,12 @@ def gemm(A, B, *, out=None, out_dtype=None, M=None, bias=None, act=ACT_NONE, dac
         assert residual2.dtype == torch.float32 and residual2.stride(-1) == 1
         p.residual2, p.ld_res2 = _p(residual2), residual2.stride(-2)
     if out2 is not None:
-        p.C2, p.ldc2, p.c2_dtype = _p(out2), out2.stride(-2), dtype_code(out2)
+        p.C2, p.ldc2, p.c2_dtype, p.c2_pre = _p(out2), out2.stride(-2), dtype_code(out2), int(out2_pre)
     if col_stats is not None:
         p.col_sum, p.col_sqsum = _p(col_stats[0]), _p(col_stats[1])
     if pool_max is not None:
         p.pool_max, p.pool_dtype = _p(pool_max), dtype_code(pool_max)
-    p.batch = 1
+    p.batch, p.strideA, p.strideB, p.strideC = batch, strideA, strideB, strideC
     _lib.check(_lib.lib().ppt_gemm(ctypes.byref(p), _stream()), "ppt_gemm")
     return out
 
@@ -144,8 +145,10 @@ def layernorm_fwd(x, w, b, y_dtype, add=None, add_rows=0, write_xs=None, save_st
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, xs, w, mean, rstd, dx=None, accumulate=False, want_wgrad=False, partial_rows=256):
-    """-> (dx, dw, db).  dx f32; accumulate=True adds into the given dx."""
+def layernorm_bwd(dy, xs, w, mean, rstd, dx=None, accumulate=False, want_wgrad=False, partial_rows=256,
+                  copy_dtype=None):
+    """-> (dx, dw, db[, dx_copy]).  dx f32; accumulate=True adds into the given dx; copy_dtype: also
+    return the final dx converted to that dtype (operand of the next GEMM)."""
     _chk(dy, torch.float32, "dy"); _chk(xs, torch.float32, "xs")
     D = xs.shape[-1]
     M = xs.numel() // D
@@ -156,11 +159,12 @@ def layernorm_bwd(dy, xs, w, mean, rstd, dx=None, accumulate=False, want_wgrad=F
     if want_wgrad:
         dwp = torch.empty((partial_rows, D), dtype=torch.float32, device=xs.device)
         dbp = torch.empty((partial_rows, D), dtype=torch.float32, device=xs.device)
+    cp = torch.empty(xs.shape, dtype=copy_dtype, device=xs.device) if copy_dtype is not None else None
     _lib.check(_lib.lib().ppt_layernorm_bwd(_p(dy), _p(xs), _p(w), _p(mean), _p(rstd), _p(dx), int(accumulate),
+                                            _p(cp), dtype_code(cp) if cp is not None else 0,
                                             _p(dwp), _p(dbp), partial_rows, M, D, _stream()), "ppt_layernorm_bwd")
-    if want_wgrad:
-        return dx, reduce_rows(dwp), reduce_rows(dbp)
-    return dx, None, None
+    dw, db = (reduce_rows(dwp), reduce_rows(dbp)) if want_wgrad else (None, None)
+    return (dx, dw, db, cp) if copy_dtype is not None else (dx, dw, db)
 
 
 def attention_fwd(qkv, Bt, T, H, scale, causal, want_lse=True):
@@ -193,10 +197,10 @@ def conv1_stats(pts, w1, b1):
     n = ctypes.c_int(0)
     _lib.check(_lib.lib().ppt_conv1_stats(_p(pts), M, _p(w1), _p(b1), C, _p(ps), _p(pq), ctypes.byref(n), _stream()),
                "ppt_conv1_stats")
-    return ps, pq
+    return ps, pq, _lib.lib().ppt_conv1_stats_rows_per_partial()
 
 
-def bn_finalize(gamma, beta, train, partials=None, count=0, running_mean=None, running_var=None,
+def bn_finalize(gamma, beta, train, partials=None, rows_per_partial=0, count=0, running_mean=None, running_var=None,
                 num_batches_tracked=None, eps=1e-5, momentum=0.1, update_running=True):
     """-> (scale, shift) f32 [C]; updates the running buffers in place when train."""
     C = gamma.shape[0]
@@ -204,7 +208,7 @@ def bn_finalize(gamma, beta, train, partials=None, count=0, running_mean=None, r
     shift = torch.empty((C,), dtype=torch.float32, device=gamma.device)
     ps, pq = partials if partials is not None else (None, None)
     upd = train and update_running
-    _lib.check(_lib.lib().ppt_bn_finalize(_p(ps), _p(pq), 0 if ps is None else ps.shape[0], count, C, _p(gamma),
+    _lib.check(_lib.lib().ppt_bn_finalize(_p(ps), _p(pq), 0 if ps is None else ps.shape[0], rows_per_partial, count, C, _p(gamma),
                                           _p(beta), eps, int(train), momentum,
                                           _p(running_mean) if (upd or not train) else None,
                                           _p(running_var) if (upd or not train) else None,
@@ -250,6 +254,14 @@ def transpose(src, dst_dtype=None):
     _lib.check(_lib.lib().ppt_transpose(_p(src), dtype_code(src), _p(dst), dtype_code(dst), R, C, _stream()),
                "ppt_transpose")
     return dst
+
+
+def col_sums(x):
+    """sum over the rows of x [M,D] (any dtype, row stride free) -> [D] f32."""
+    M, D = x.shape
+    part = torch.empty(((M + 255) // 256, D), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().ppt_col_sums(_p(x), dtype_code(x), M, D, x.stride(0), _p(part), _stream()), "ppt_col_sums")
+    return reduce_rows(part)
 
 
 def reduce_rows(partial, out=None, accumulate=False):

@@ -1,0 +1,124 @@
+"""Training-step harness reproducing the caller of the hot path, main_cls.py:155-234 (train()):
+zero_grad, per-iteration LR, forward, CrossEntropy(label_smoothing), backward, AdamW, logit-scale
+clamp -- plus the MI355X-native replacement of DistributedDataParallel (main_cls.py:47-49):
+ONE RCCL all-reduce per step over a flat fp32 buffer holding the PromptLearner / PointAdapter
+gradients, and a broadcast of the BatchNorm running statistics from rank 0 (DDP broadcast_buffers).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch import nn
+
+
+def cosine_scheduler(base_value, final_value, epochs, niter_per_ep, warmup_epochs=0, start_warmup_value=0.0):
+    """utils/utils.py:253-264: one learning rate per iteration (linear warm-up, then half cosine)."""
+    warm = warmup_epochs * niter_per_ep
+    head = np.linspace(start_warmup_value, base_value, warm) if warmup_epochs > 0 else np.array([])
+    it = np.arange(epochs * niter_per_ep - warm)
+    tail = final_value + 0.5 * (base_value - final_value) * (1 + np.cos(np.pi * it / len(it)))
+    sched = np.concatenate((head, tail))
+    assert len(sched) == epochs * niter_per_ep
+    return sched
+
+
+class FlatGradSync:
+    """Data parallelism for prompt tuning: the trainable parameters' .grad tensors are views into one
+    flat fp32 buffer; after backward a single all-reduce (SUM) + 1/world gives DDP's averaged
+    gradients.  64 KiB (head_type 0) ... 7.2 MB (head_type 3) per step -- latency-bound on xGMI, so
+    one call beats any bucketing."""
+
+    def __init__(self, params, process_group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = process_group
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+        off = 0
+        for p in self.params:          # re-attach views if an optimizer / zero_grad(set_to_none) dropped them
+            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * off:
+                p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def all_reduce(self):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat.div_(dist.get_world_size(self.group))
+
+
+class BufferBroadcast:
+    """DDP(broadcast_buffers=True) equivalent for the BatchNorm running statistics of the tokenizer,
+    which keep updating because model.train() leaves the frozen BN layers in train mode
+    (SURVEY.md App. A Q3): the float buffers are re-bound as views of one flat tensor that rank 0
+    broadcasts before every forward."""
+
+    def __init__(self, model, process_group=None):
+        self.group = process_group
+        bufs = [(m, n, b) for m in model.modules() for n, b in m._buffers.items()
+                if b is not None and b.dtype == torch.float32]
+        self.flat = None
+        if bufs:
+            n = sum(b.numel() for _, _, b in bufs)
+            self.flat = torch.empty(n, dtype=torch.float32, device=bufs[0][2].device)
+            off = 0
+            for m, name, b in bufs:
+                view = self.flat[off:off + b.numel()].view_as(b)
+                view.copy_(b)
+                m._buffers[name] = view
+                off += b.numel()
+
+    def broadcast(self):
+        if self.flat is not None and dist.is_available() and dist.is_initialized() \
+                and dist.get_world_size(self.group) > 1:
+            dist.broadcast(self.flat, src=0, group=self.group)
+
+
+class Trainer:
+    """One object per rank.  `step(pc, label)` == one iteration of main_cls.py:179-214."""
+
+    def __init__(self, model, lr=3e-3, betas=(0.9, 0.98), eps=1e-8, wd=0.1, label_smoothing=0.2,
+                 lr_schedule=None, distributed=None, capturable=False):
+        self.model = model
+        self.criterion = nn.CrossEntropyLoss(label_smoothing=label_smoothing)       # main_cls.py:52
+        # main_cls.py:55-60: AdamW over ALL parameters; frozen ones never get a grad and are skipped
+        self.optimizer = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=lr, betas=betas,
+                                           eps=eps, weight_decay=wd, capturable=capturable)
+        self.lr_schedule = lr_schedule
+        self.it = 0
+        if distributed is None:
+            distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.distributed = distributed
+        self.sync = FlatGradSync(model.parameters())
+        self.bcast = BufferBroadcast(model) if distributed else None
+        if hasattr(model, "_sd"):
+            model._sd = None
+        if hasattr(getattr(model, "point_encoder", None), "_sd"):
+            model.point_encoder._sd = None
+
+    def step(self, pc, label, check_finite=False):
+        model = self.model
+        self.sync.zero()                                            # optimizer.zero_grad()
+        if self.lr_schedule is not None:                            # main_cls.py:184-185
+            for g in self.optimizer.param_groups:
+                g['lr'] = float(self.lr_schedule[min(self.it, len(self.lr_schedule) - 1)])
+        if self.bcast is not None:
+            self.bcast.broadcast()
+        pred = model(pc)                                            # main_cls.py:194
+        loss = self.criterion(pred, label)
+        loss.backward()                                             # (retain_graph only served Q2)
+        if self.distributed:
+            self.sync.all_reduce()
+        self.optimizer.step()
+        if check_finite and not math.isfinite(loss.item()):         # main_cls.py:205-207
+            raise FloatingPointError(f"Loss is {loss.item()}, stopping training")
+        model.logit_scale.data.clamp_(0, 4.6052)                    # main_cls.py:213
+        self.it += 1
+        return loss, pred
