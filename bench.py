@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the PPT hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1], "C2"): ModelNet40 class list, 1024-point clouds, PointBERT
+(ULIP_PointBERT, head_type=0: frozen backbone + PromptLearner), batch 32 PER GPU, model.train()
+(batch-statistics BatchNorm + DropPath), forward + CrossEntropy(label_smoothing 0.2) + backward +
+AdamW, bf16 MFMA operands / fp32 accumulate.  One step == one iteration of main_cls.py:179-214.
+Synthetic clouds (resident in HBM before the timed region) and deterministic random weights.
+
+Prints ONE JSON line (rank 0): metric/value/unit..., plus
+  "roofline":     the dominant kernel (the bf16 MFMA GEMM family) -- algorithmic FLOPs / its summed launch
+                  time measured with HIP events on the launch stream during a second, instrumented pass
+                  over the same K steps -- against the 2.5 PFLOP/s dense bf16 peak;
+  "cpu_baseline": the oracle (CPU restatement of the reference, `kind: "port"`) timed on this host's cores
+                  on the reference's CPU-runnable case C1 (batch 8), rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PER_GPU_BATCH = 32
+NPOINTS = 1024
+HEAD_TYPE = 0
+PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def build_model(dataset="modelnet40", head_type=HEAD_TYPE, precision=torch.bfloat16):
+    from ppt_amd import weights as W
+    from ppt_amd.models import ULIP_models as M
+    import contextlib
+    import io
+    args = SimpleNamespace(classnames=M.dataset_classnames(dataset), template_init='', class_name_position='middle',
+                           num_learnable_prompt_tokens=32, gpu=torch.cuda.current_device(), task='cls',
+                           head_type=head_type, evaluate_3d=False, ulip2=False)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = M.ULIP_PointBERT(args)
+    m.load_state_dict(W.ulip_pointbert_state_dict(seed=0), strict=False)
+    m.prompt_learner.embedding = W.synth_prompt_embedding(len(args.classnames), seed=0)
+    m.cuda()
+    m.set_precision(precision)
+    return m
+
+
+def cpu_baseline(max_seconds=30.0):
+    """Oracle train_step on the host cores, config C1 (B=8, N=1024, head_type 0)."""
+    from oracle import oracle as O
+    from ppt_amd import weights as W
+    from ppt_amd.models import ULIP_models as M
+    torch.set_num_threads(os.cpu_count() or 1)
+    names = M.dataset_classnames("modelnet40")
+    ids, name_lengths = M.tokenize_prompts(names, 32)
+    eot = ids.argmax(-1).numpy()
+    sd = W.ulip_pointbert_state_dict(seed=0)
+    emb = W.synth_prompt_embedding(len(names), seed=0)
+    B = 8
+    pc, start = W.synth_clouds(B, NPOINTS, seed=1234)
+    labels = torch.from_numpy(np.random.default_rng(0).integers(0, len(names), size=(B,)))
+    pc = torch.from_numpy(pc)
+    O.train_step(sd, pc, labels, start, emb, name_lengths, eot, head_type=0)          # warm-up
+    times = []
+    t_all = time.time()
+    while len(times) < 5 and (time.time() - t_all) < max_seconds:
+        t0 = time.time()
+        O.train_step(sd, pc, labels, start, emb, name_lengths, eot, head_type=0)
+        times.append(time.time() - t0)
+    med = float(np.median(times))
+    return {"value": round(B / med, 3), "unit": "point-clouds/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle train_step (fwd+CE+bwd+AdamW), C1: batch 8 x 1024 pts, head_type 0, "
+                      f"{len(times)} timed steps after 1 warm-up, median {med:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    from ppt_amd import ops, weights as W
+    from ppt_amd.train import Trainer
+    torch.manual_seed(1234 + rank)                                   # main_cls.py:39: seed + rank
+    model = build_model()
+    model.train()
+    trainer = Trainer(model, lr=3e-3, label_smoothing=0.2, distributed=world > 1)
+    pc_np, _ = W.synth_clouds(PER_GPU_BATCH, NPOINTS, seed=1234 + rank)
+    pc = torch.from_numpy(pc_np).cuda()
+    label = torch.from_numpy(np.random.default_rng(rank).integers(0, 40, size=(PER_GPU_BATCH,))).cuda()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        trainer.step(pc, label)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss, _ = trainer.step(pc, label)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    final_loss = loss.item()
+    assert np.isfinite(final_loss), "loss is not finite"
+
+    roof = None
+    if rank == 0 and not a.no_roofline:
+        # second pass over the same K steps with every launch of the hot kernels bracketed by HIP events
+        ops.profiler = ops.KernelProfiler()
+        for _ in range(a.steps):
+            trainer.step(pc, label)
+        torch.cuda.synchronize()
+        summ = ops.profiler.summary()
+        ops.profiler = None
+        g = summ["gemm_bf16"]
+        achieved = g["work"] / (g["ms"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "gemm_kernel<bf16> (ppt_amd/csrc/gemm.hip)",
+                "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "launches_per_step": g["launches"] // a.steps,
+                "avg_launch_us": round(1e3 * g["ms"] / g["launches"], 2),
+                "algorithmic_gflop_per_launch": round(g["work"] / g["launches"] / 1e9, 3),
+                "per_kernel_ms_per_step": {k: round(v["ms"] / a.steps, 4) for k, v in summ.items()}}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        total = PER_GPU_BATCH * world * a.steps
+        out = {"metric": "point-clouds/sec fwd+bwd, PointBERT 1024-pt ModelNet40",
+               "value": round(total / elapsed, 2), "unit": "point-clouds/s", "n_gpus": world, "steps": a.steps,
+               "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "C2: ModelNet40 1024-pt PointBERT (ULIP_PointBERT head_type=0, frozen backbone + "
+                                      "PromptLearner), train-mode BN + DropPath, fwd + CE(ls 0.2) + bwd + AdamW",
+                          "per_gpu_batch": PER_GPU_BATCH, "global_batch": PER_GPU_BATCH * world, "npoints": NPOINTS,
+                          "classes": 40, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
+               "roofline": roof}
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -177,8 +177,9 @@ int ppt_cls_max_pool(const void *x, int x_dtype, int B, int T, int D, float *out
                      void *stream);
 /* dtype conversion / transposition helpers (weights are converted once, activations never). */
 int ppt_convert(const void *src, int src_dtype, void *dst, int dst_dtype, int64_t n, void *stream);
+/* src [rows, cols] contiguous -> dst [cols, rows] with row stride ld_dst >= rows (padding untouched) */
 int ppt_transpose(const void *src, int src_dtype, void *dst, int dst_dtype, int rows, int cols,
-                  void *stream);
+                  int64_t ld_dst, void *stream);
 /* column sums of x [M,D] (any dtype) -> partial [ceil(M/256), D] f32 (bias gradients); reduce with ppt_reduce_rows */
 int ppt_col_sums(const void *x, int x_dtype, int M, int D, int64_t ldx, float *partial, void *stream);
 /* sum the [P, D] partial buffers produced by col_sum / dw_partial style outputs -> [D] */

@@ -57,7 +57,7 @@ _SIGNATURES = {
     "ppt_linear3_gelu": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "ppt_cls_max_pool": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ppt_convert": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
-    "ppt_transpose": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ppt_transpose": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_void_p]),
     "ppt_reduce_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
 }
 

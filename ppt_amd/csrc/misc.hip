@@ -31,7 +31,8 @@ __global__ void convert_kernel(const TS *__restrict__ s, TD *__restrict__ d, int
 }
 
 template <typename TS, typename TD>
-__global__ __launch_bounds__(256) void transpose_kernel(const TS *__restrict__ s, TD *__restrict__ d, int rows, int cols)
+__global__ __launch_bounds__(256) void transpose_kernel(const TS *__restrict__ s, TD *__restrict__ d, int rows, int cols,
+                                                        int64_t ldd)
 {
     __shared__ float tile[32][33];
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const TS *__restrict__ s
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
         const int c = c0 + i, r = r0 + tx;            // output row = c, output col = r
-        if (c < cols && r < rows) dt<TD>::store(d + (size_t)c * rows + r, tile[tx][i]);
+        if (c < cols && r < rows) dt<TD>::store(d + (size_t)c * ldd + r, tile[tx][i]);
     }
 }
 
@@ -80,11 +81,11 @@ int convert_from(const void *src, void *dst, int dd, int64_t n, hipStream_t s)
 }
 
 template <typename TS>
-int transpose_from(const void *src, void *dst, int dd, int rows, int cols, hipStream_t s)
+int transpose_from(const void *src, void *dst, int dd, int rows, int cols, int64_t ldd, hipStream_t s)
 {
     dim3 grid((cols + 31) / 32, (rows + 31) / 32);
-    if (dd == PPT_BF16) hipLaunchKernelGGL((transpose_kernel<TS, bf16_t>), grid, dim3(256), 0, s, (const TS *)src, (bf16_t *)dst, rows, cols);
-    else if (dd == PPT_F32) hipLaunchKernelGGL((transpose_kernel<TS, float>), grid, dim3(256), 0, s, (const TS *)src, (float *)dst, rows, cols);
+    if (dd == PPT_BF16) hipLaunchKernelGGL((transpose_kernel<TS, bf16_t>), grid, dim3(256), 0, s, (const TS *)src, (bf16_t *)dst, rows, cols, ldd);
+    else if (dd == PPT_F32) hipLaunchKernelGGL((transpose_kernel<TS, float>), grid, dim3(256), 0, s, (const TS *)src, (float *)dst, rows, cols, ldd);
     else return PPT_EINVAL;
     PPT_CHECK_LAUNCH();
     return PPT_OK;
@@ -113,11 +114,12 @@ extern "C" int ppt_convert(const void *src, int src_dtype, void *dst, int dst_dt
     return PPT_EINVAL;
 }
 
-extern "C" int ppt_transpose(const void *src, int src_dtype, void *dst, int dst_dtype, int rows, int cols, void *stream)
+extern "C" int ppt_transpose(const void *src, int src_dtype, void *dst, int dst_dtype, int rows, int cols, int64_t ld_dst,
+                             void *stream)
 {
-    if (!src || !dst || rows <= 0 || cols <= 0) return PPT_EINVAL;
-    if (src_dtype == PPT_F32) return transpose_from<float>(src, dst, dst_dtype, rows, cols, ppt_stream(stream));
-    if (src_dtype == PPT_BF16) return transpose_from<bf16_t>(src, dst, dst_dtype, rows, cols, ppt_stream(stream));
+    if (!src || !dst || rows <= 0 || cols <= 0 || ld_dst < rows) return PPT_EINVAL;
+    if (src_dtype == PPT_F32) return transpose_from<float>(src, dst, dst_dtype, rows, cols, ld_dst, ppt_stream(stream));
+    if (src_dtype == PPT_BF16) return transpose_from<bf16_t>(src, dst, dst_dtype, rows, cols, ld_dst, ppt_stream(stream));
     return PPT_EINVAL;
 }
 

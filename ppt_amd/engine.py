@@ -92,17 +92,19 @@ def mini_pointnet(sd, p, wc, nbhd, bn_train, update_running=True):
                   a_scale=sc1, a_shift=sh1, bias=sd[p + "first_conv.3.bias"], pool_max=gmax)
     # cat([global, local]) @ W3^T  ==  local @ W3[:,256:]^T + (global @ W3[:,:256]^T + b3) per group
     w3 = sd[p + "second_conv.0.weight"]
-    gterm = ops.gemm(gmax, wc.get(w3, cols=(0, 256)), out_dtype=torch.float32, bias=sd[p + "second_conv.0.bias"])
+    gterm = ops.gemm(gmax, wc.get(w3, cols=(0, 256)), out_dtype=torch.float32, bias=sd[p + "second_conv.0.bias"],
+                     algo_k=0)      # its FLOPs are accounted to the 512-wide conv3 (algo_k=512 below)
     g2, be2, rm2, rv2, nb2 = _bn_params(sd, p + "second_conv.1.")
     if bn_train:
         cs = torch.empty((M // 64, 512), dtype=torch.float32, device=dev)
         cq = torch.empty_like(cs)
-        y3 = ops.gemm(y2, wc.get(w3, cols=(256, 512)), out_dtype=T, group_add=gterm, group_rows=32, col_stats=(cs, cq))
+        y3 = ops.gemm(y2, wc.get(w3, cols=(256, 512)), out_dtype=T, group_add=gterm, group_rows=32, col_stats=(cs, cq),
+                      algo_k=512)
         sc2, sh2 = ops.bn_finalize(g2, be2, True, partials=(cs, cq), rows_per_partial=64, count=M,
                                    running_mean=rm2, running_var=rv2, num_batches_tracked=nb2,
                                    update_running=update_running)
     else:
-        y3 = ops.gemm(y2, wc.get(w3, cols=(256, 512)), out_dtype=T, group_add=gterm, group_rows=32)
+        y3 = ops.gemm(y2, wc.get(w3, cols=(256, 512)), out_dtype=T, group_add=gterm, group_rows=32, algo_k=512)
         sc2, sh2 = ops.bn_finalize(g2, be2, False, running_mean=rm2, running_var=rv2)
     # BN2 + ReLU in the A-prologue of conv4; only the pooled maximum is written
     tok = torch.empty((M // 32, sd[p + "second_conv.3.weight"].shape[0]), dtype=T, device=dev)
@@ -179,7 +181,7 @@ def point_encoder_forward(sd, p, wc, pc, fps_start, dp, bn_train, save_tier, cfg
 
 def _wgrad(dy_t, x_t):
     """dW[N,K] = dY[M,N]^T @ X[M,K]: both operands are M-major, so transpose both and run the NT GEMM."""
-    return ops.gemm(ops.transpose(dy_t), ops.transpose(x_t), out_dtype=torch.float32)
+    return ops.gemm(ops.transpose(dy_t, pad_to=8), ops.transpose(x_t, pad_to=8), out_dtype=torch.float32)
 
 
 def point_encoder_backward(sd, wc, s, dfeat, tier):

@@ -182,7 +182,7 @@ class _TextTowerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, prompts):
         sd = model._live_state()
-        save = prompts.requires_grad and torch.is_grad_enabled()
+        save = bool(ctx.needs_input_grad[1])
         out, saved = engine.text_tower_forward(sd, model._cache(), prompts.contiguous().float(), model._eot(prompts.device),
                                                model.transformer.heads, model.transformer.layers, save)
         ctx.model, ctx.saved = model, saved
@@ -209,9 +209,9 @@ class _MatmulNT(torch.autograd.Function):
         dc = dc.contiguous().float()
         da = db = None
         if ctx.needs_input_grad[0]:
-            da = ops.gemm(dc, ops.transpose(b), out_dtype=torch.float32)              # [M,N] @ [N,K]
+            da = ops.gemm(dc, ops.transpose(b, pad_to=4), out_dtype=torch.float32)    # [M,N] @ [N,K]
         if ctx.needs_input_grad[1]:
-            db = ops.gemm(ops.transpose(dc), ops.transpose(a), out_dtype=torch.float32)   # [N,M] @ [M,K]
+            db = ops.gemm(ops.transpose(dc, pad_to=4), ops.transpose(a, pad_to=4), out_dtype=torch.float32)   # [N,M] @ [M,K]
         return da, db
 
 

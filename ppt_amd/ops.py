@@ -17,6 +17,38 @@ _DT = {torch.float32: PPT_F32, torch.bfloat16: PPT_BF16}
 _TORCH_DT = {PPT_F32: torch.float32, PPT_BF16: torch.bfloat16}
 
 
+class KernelProfiler:
+    """Optional per-launch timing with HIP events recorded on the launch stream (used by bench.py for
+    the live roofline numbers).  Off by default: `ops.profiler = KernelProfiler()` turns it on."""
+
+    def __init__(self):
+        self.records = []          # (name, start_event, end_event, algorithmic work)
+
+    def begin(self, name, work):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        self._cur = (name, ev, work)
+
+    def end(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        name, st, work = self._cur
+        self.records.append((name, st, ev, work))
+
+    def summary(self):
+        """-> {name: dict(launches, ms, work)} (call after a device synchronise)."""
+        out = {}
+        for name, st, en, work in self.records:
+            d = out.setdefault(name, dict(launches=0, ms=0.0, work=0.0))
+            d["launches"] += 1
+            d["ms"] += st.elapsed_time(en)
+            d["work"] += work
+        return out
+
+
+profiler = None
+
+
 def dtype_code(t):
     return _DT[t.dtype if isinstance(t, torch.Tensor) else t]
 
@@ -47,7 +79,11 @@ def fps(xyz, M, start):
     B, N, _ = xyz.shape
     idx = torch.empty((B, M), dtype=torch.int64, device=xyz.device)
     ctr = torch.empty((B, M, 3), dtype=torch.float32, device=xyz.device)
+    if profiler is not None:
+        profiler.begin("fps", float(B) * (12 * N + 8 * M))          # algorithmic HBM bytes
     _lib.check(_lib.lib().ppt_fps_f32(_p(xyz), B, N, M, _p(start), _p(idx), _p(ctr), _stream()), "ppt_fps_f32")
+    if profiler is not None:
+        profiler.end()
     return idx, ctr
 
 
@@ -58,8 +94,12 @@ def knn_group(xyz, center, k, want_idx=True, want_nbhd=True):
     G = center.shape[1]
     idx = torch.empty((B, G, k), dtype=torch.int64, device=xyz.device) if want_idx else None
     nb = torch.empty((B, G, k, 3), dtype=torch.float32, device=xyz.device) if want_nbhd else None
+    if profiler is not None:
+        profiler.begin("knn_group", float(B) * (12 * N + 12 * G + 8 * G * k + 12 * G * k))
     _lib.check(_lib.lib().ppt_knn_group_f32(_p(xyz), _p(center), B, N, G, k, _p(idx), _p(nb), _stream()),
                "ppt_knn_group_f32")
+    if profiler is not None:
+        profiler.end()
     return idx, nb
 
 
@@ -81,7 +121,7 @@ def gemm(A, B, *, out=None, out_dtype=None, M=None, bias=None, act=ACT_NONE, dac
          group_add=None, group_rows=0, row_scale=None, row_scale_rows=0, residual=None,
          residual2=None, out2=None, out2_pre=False, col_stats=None, pool_max=None,
          batch=1, strideA=0, strideB=0, strideC=0,
-         a_mode=A_PLAIN, a_scale=None, a_shift=None, pts=None, w1=None, b1=None, want_out=True):
+         a_mode=A_PLAIN, a_scale=None, a_shift=None, pts=None, w1=None, b1=None, want_out=True, algo_k=None):
     """C[M,N] = epilogue(prologue(A)[M,K] @ B[N,K]^T) -- see struct ppt_gemm_params.
     A [M,K] (or None with a_mode=A_CONV1 and pts [M,3]); B [N,K]; 2-D, last-dim contiguous
     (row stride may exceed K).  Returns out (or None when want_out=False)."""
@@ -126,7 +166,12 @@ def gemm(A, B, *, out=None, out_dtype=None, M=None, bias=None, act=ACT_NONE, dac
     if pool_max is not None:
         p.pool_max, p.pool_dtype = _p(pool_max), dtype_code(pool_max)
     p.batch, p.strideA, p.strideB, p.strideC = batch, strideA, strideB, strideC
+    if profiler is not None:
+        kk = K if algo_k is None else algo_k
+        profiler.begin("gemm_" + ("bf16" if p.dtype == PPT_BF16 else "f32"), 2.0 * M * N * kk * max(1, batch))
     _lib.check(_lib.lib().ppt_gemm(ctypes.byref(p), _stream()), "ppt_gemm")
+    if profiler is not None:
+        profiler.end()
     return out
 
 
@@ -172,8 +217,12 @@ def attention_fwd(qkv, Bt, T, H, scale, causal, want_lse=True):
     _chk(qkv, None, "qkv")
     out = torch.empty((Bt * T, H * 64), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((Bt, H, T), dtype=torch.float32, device=qkv.device) if want_lse else None
+    if profiler is not None:
+        profiler.begin("attention_fwd", 4.0 * Bt * H * T * T * 64 * (0.5 if causal else 1.0))
     _lib.check(_lib.lib().ppt_attention_fwd(_p(qkv), _p(out), _p(lse), Bt, T, H, 64, scale, int(causal),
                                             dtype_code(qkv), _stream()), "ppt_attention_fwd")
+    if profiler is not None:
+        profiler.end()
     return out, lse
 
 
@@ -181,8 +230,12 @@ def attention_bwd(qkv, out, dout, lse, Bt, T, H, scale, causal):
     _chk(qkv, None, "qkv"); _chk(out, qkv.dtype, "out"); _chk(dout, qkv.dtype, "dout")
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((Bt, H, T), dtype=torch.float32, device=qkv.device)
+    if profiler is not None:
+        profiler.begin("attention_bwd", 10.0 * Bt * H * T * T * 64 * (0.5 if causal else 1.0))
     _lib.check(_lib.lib().ppt_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), Bt, T, H, 64,
                                             scale, int(causal), dtype_code(qkv), _stream()), "ppt_attention_bwd")
+    if profiler is not None:
+        profiler.end()
     return dqkv
 
 
@@ -246,12 +299,15 @@ def convert(src, dst_dtype):
     return dst
 
 
-def transpose(src, dst_dtype=None):
-    """[R,C] -> [C,R] (optionally converting)."""
+def transpose(src, dst_dtype=None, pad_to=1):
+    """[R,C] -> [C,R] (optionally converting).  pad_to > 1: the result is [C, Rp] with Rp = R rounded up
+    to a multiple of pad_to and a zero tail (so that it can be the K dimension of a GEMM operand)."""
     _chk(src, None, "src")
     R, C = src.shape
-    dst = torch.empty((C, R), dtype=dst_dtype or src.dtype, device=src.device)
-    _lib.check(_lib.lib().ppt_transpose(_p(src), dtype_code(src), _p(dst), dtype_code(dst), R, C, _stream()),
+    Rp = (R + pad_to - 1) // pad_to * pad_to
+    dt_ = dst_dtype or src.dtype
+    dst = torch.empty((C, Rp), dtype=dt_, device=src.device) if Rp == R else torch.zeros((C, Rp), dtype=dt_, device=src.device)
+    _lib.check(_lib.lib().ppt_transpose(_p(src), dtype_code(src), _p(dst), dtype_code(dst), R, C, Rp, _stream()),
                "ppt_transpose")
     return dst
 
