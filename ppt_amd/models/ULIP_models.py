@@ -208,10 +208,12 @@ class _MatmulNT(torch.autograd.Function):
         a, b = ctx.saved_tensors
         dc = dc.contiguous().float()
         da = db = None
-        if ctx.needs_input_grad[0]:
-            da = ops.gemm(dc, ops.transpose(b, pad_to=4), out_dtype=torch.float32)    # [M,N] @ [N,K]
-        if ctx.needs_input_grad[1]:
-            db = ops.gemm(ops.transpose(dc, pad_to=4), ops.transpose(a, pad_to=4), out_dtype=torch.float32)   # [N,M] @ [M,K]
+        if ctx.needs_input_grad[0]:                      # dA[M,K] = dC[M,N] @ B[N,K]; N padded to the chunk size
+            n = dc.shape[1]
+            dcp = dc if n % 4 == 0 else torch.nn.functional.pad(dc, (0, 4 - n % 4))
+            da = ops.gemm(dcp, ops.transpose(b, pad_to=4), out_dtype=torch.float32)
+        if ctx.needs_input_grad[1]:                      # dB[N,K] = dC[M,N]^T @ A[M,K]
+            db = ops.gemm(ops.transpose(dc, pad_to=4), ops.transpose(a, pad_to=4), out_dtype=torch.float32)
         return da, db
 
 
