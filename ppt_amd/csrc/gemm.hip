@@ -209,73 +209,14 @@ __device__ __forceinline__ void mma_slab(const unsigned char *As, const unsigned
     }
 }
 
-template <typename T, int A_MODE>
-__global__ __launch_bounds__(NT, 2) void gemm_kernel(const ppt_gemm_params p)
+// ---- scalar epilogue (any N / alignment): lane == column, one row per iteration -----------------
+__device__ __forceinline__ void epilogue_scalar(const ppt_gemm_params &p, float *ct, int lane, int m0, int wm, int n0, int wn,
+                                             int64_t zc)
 {
-    __shared__ __align__(16) unsigned char smem[4 * TILE_BYTES];   // A0 A1 B0 B1
-    constexpr int BK = ROWB / sizeof(T);
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = w >> 1, wn = w & 1;
-    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
-    const T *A = reinterpret_cast<const T *>(p.A) + (int64_t)blockIdx.z * p.strideA;
-    const T *B = reinterpret_cast<const T *>(p.B) + (int64_t)blockIdx.z * p.strideB;
-
-    f32x16_t acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    const int nslab = (p.K + BK - 1) / BK;
-    Stage<T> sa, sb;
-    load_A<T, A_MODE>(sa, p, A, m0, 0);
-    load_plain<T>(sb, B, p.ldb, p.N, p.K, n0, 0);
-    write_stage<T>(sa, smem);
-    write_stage<T>(sb, smem + 2 * TILE_BYTES);
-    __syncthreads();
-    for (int s = 0; s < nslab; ++s) {
-        const int cur = s & 1;
-        if (s + 1 < nslab) {
-            load_A<T, A_MODE>(sa, p, A, m0, (s + 1) * BK);
-            load_plain<T>(sb, B, p.ldb, p.N, p.K, n0, (s + 1) * BK);
-        }
-        mma_slab<T>(smem + cur * TILE_BYTES, smem + (2 + cur) * TILE_BYTES, wm, wn, lane, acc);
-        if (s + 1 < nslab) {
-            write_stage<T>(sa, smem + (cur ^ 1) * TILE_BYTES);
-            write_stage<T>(sb, smem + (2 + (cur ^ 1)) * TILE_BYTES);
-        }
-        __syncthreads();
-    }
-
-    // ---------------- epilogue ----------------
-    // The operand tiles are dead (the loop ends on a barrier): every wave parks its 64x64 fp32
-    // accumulators in its own 16 KiB of LDS, row-major, and walks them row by row with lane == column.
-    // That turns the MFMA C layout (column on the lane, rows scattered over 16 registers) into
-    // full-row 128/256-byte global stores, makes the BatchNorm column sums and the 32-row max-pool
-    // plain per-lane running values, and keeps the flag-driven epilogue body out of the unroller.
-    float *ct = reinterpret_cast<float *>(smem) + w * (64 * 64);
-    {
-        const int h = lane >> 5, cl = lane & 31;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    ct[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 64 + j * 32 + cl] = acc[i][j][r];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
     const int n = n0 + wn * 64 + lane;
     const bool nok = n < p.N;
     const int mw = m0 + wm * 64;
     const float bias = (p.bias && nok) ? p.bias[n] : 0.0f;
-    const int64_t zc = (int64_t)blockIdx.z * p.strideC;
     float csum = 0.f, csq = 0.f, pmax = -INFINITY;
 #pragma unroll 1
     for (int rr = 0; rr < 64; ++rr) {
@@ -318,6 +259,251 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const ppt_gemm_params p)
         p.col_sum[(int64_t)prow * p.N + n] = csum;
         p.col_sqsum[(int64_t)prow * p.N + n] = csq;
     }
+}
+
+
+
+// ---- vector epilogue: 8 consecutive columns per lane, 8 rows per pass --------------------------
+// global stores are issue-bound, not byte-bound, on this chip (a 2-byte-per-lane store costs the same
+// issue slot as a 16-byte one), so the tile is written as 16-byte pieces: lane = (row-in-pass, column
+// group); 8 passes cover the wave's 64x64 tile.  Column statistics / pooled maxima fold the 8 row-lanes
+// with three xor-shuffles.
+struct f8 { float v[8]; };
+
+__device__ __forceinline__ f8 ld8_f32(const float *p)
+{
+    const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
+    return f8{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+}
+__device__ __forceinline__ void st8_f32(float *p, const f8 &x)
+{
+    *reinterpret_cast<float4 *>(p) = make_float4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    *reinterpret_cast<float4 *>(p + 4) = make_float4(x.v[4], x.v[5], x.v[6], x.v[7]);
+}
+__device__ __forceinline__ f8 ld8_dt(const void *p, int dtype, int64_t i)
+{
+    if (dtype == PPT_BF16) {
+        const uint4 u = *reinterpret_cast<const uint4 *>((const bf16_t *)p + i);
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+        f8 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { r.v[2 * e] = __uint_as_float(w[e] << 16); r.v[2 * e + 1] = __uint_as_float(w[e] & 0xFFFF0000u); }
+        return r;
+    }
+    return ld8_f32((const float *)p + i);
+}
+__device__ __forceinline__ void st8_dt(void *p, int dtype, int64_t i, const f8 &x)
+{
+    if (dtype == PPT_BF16)
+        *reinterpret_cast<uint4 *>((bf16_t *)p + i) = make_uint4(pack_bf16x2(x.v[0], x.v[1]), pack_bf16x2(x.v[2], x.v[3]),
+                                                                 pack_bf16x2(x.v[4], x.v[5]), pack_bf16x2(x.v[6], x.v[7]));
+    else
+        st8_f32((float *)p + i, x);
+}
+
+__device__ __forceinline__ void epilogue_vec8(const ppt_gemm_params &p, float *ct, int lane, int m0, int wm, int n0, int wn,
+                                           int64_t zc)
+{
+    const int cg = lane & 7, rl = lane >> 3;
+    const int n = n0 + wn * 64 + cg * 8;
+    const bool nok = n < p.N;
+    const int mw = m0 + wm * 64;
+    f8 bias, csum, pm;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bias.v[e] = 0.f; csum.v[e] = 0.f; pm.v[e] = -INFINITY; }
+    if (p.bias && nok) bias = ld8_f32(p.bias + n);
+#pragma unroll 1
+    for (int pass = 0; pass < 8; ++pass) {
+        const int rr = pass * 8 + rl;
+        const int m = mw + rr;
+        if (nok && m < p.M) {
+            f8 v = ld8_f32(ct + rr * 64 + cg * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v.v[e] += bias.v[e];
+            if (p.group_add) {
+                const f8 g = ld8_f32(p.group_add + (int64_t)(m / p.group_rows) * p.N + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v.v[e] += g.v[e];
+            }
+            if (p.col_sum) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) csum.v[e] += v.v[e];
+                st8_f32(ct + rr * 64 + cg * 8, v);
+            }
+            if (p.C2 && p.c2_pre) st8_dt(p.C2, p.c2_dtype, (int64_t)m * p.ldc2 + n, v);
+            if (p.dact_pre) {
+                const f8 x = ld8_dt(p.dact_pre, p.dtype, (int64_t)m * p.ld_dact + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v.v[e] *= act_bwd(x.v[e], p.act);
+            } else if (p.act != PPT_ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v.v[e] = act_fwd(v.v[e], p.act);
+            }
+            if (p.row_scale) {
+                const float sc = p.row_scale[m / p.row_scale_rows];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v.v[e] *= sc;
+            }
+            if (p.residual) {
+                const f8 r = ld8_f32(p.residual + (int64_t)m * p.ld_res + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v.v[e] += r.v[e];
+            }
+            if (p.residual2) {
+                const f8 r = ld8_f32(p.residual2 + (int64_t)m * p.ld_res2 + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v.v[e] += r.v[e];
+            }
+            if (p.C) st8_dt(p.C, p.c_dtype, zc + (int64_t)m * p.ldc + n, v);
+            if (p.C2 && !p.c2_pre) st8_dt(p.C2, p.c2_dtype, (int64_t)m * p.ldc2 + n, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pm.v[e] = fmaxf(pm.v[e], v.v[e]);
+        }
+        if (p.pool_max && (pass & 3) == 3) {          // rows [32*(pass>>2), +32) complete
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = pm.v[e];
+                t = fmaxf(t, __shfl_xor(t, 8, 64)); t = fmaxf(t, __shfl_xor(t, 16, 64)); t = fmaxf(t, __shfl_xor(t, 32, 64));
+                pm.v[e] = t;
+            }
+            const int mg = mw + (pass >> 2) * 32;
+            if (rl == 0 && nok && mg < p.M) st8_dt(p.pool_max, p.pool_dtype, (int64_t)(mg >> 5) * p.N + n, pm);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pm.v[e] = -INFINITY;
+        }
+    }
+    if (p.col_sum && mw < p.M) {
+        // (sum, M2 about the chunk mean) per 64-row chunk -- see ppt_bn_finalize
+        const int nrow = min(64, p.M - mw);
+        f8 csq;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float t = csum.v[e];
+            t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+            csum.v[e] = t; csq.v[e] = 0.f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int pass = 0; pass < 8; ++pass) {
+            const int rr = pass * 8 + rl;
+            if (nok && rr < nrow) {
+                const f8 v = ld8_f32(ct + rr * 64 + cg * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v.v[e] - csum.v[e] / (float)nrow; csq.v[e] = fmaf(d, d, csq.v[e]); }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float t = csq.v[e];
+            t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+            csq.v[e] = t;
+        }
+        if (rl == 0 && nok) {
+            const int prow = (m0 >> 6) + wm;
+            st8_f32(p.col_sum + (int64_t)prow * p.N + n, csum);
+            st8_f32(p.col_sqsum + (int64_t)prow * p.N + n, csq);
+        }
+    }
+}
+
+__device__ __forceinline__ bool al16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+// wave-uniform: every pointer / leading dimension the vector epilogue touches is 16-byte friendly
+__device__ __forceinline__ bool vec_epilogue_ok(const ppt_gemm_params &p, int64_t zc)
+{
+    bool ok = (p.N % 8) == 0;
+    if (p.C) ok = ok && (p.ldc % 8) == 0 && (zc % 8) == 0 && al16(p.C);
+    if (p.C2) ok = ok && (p.ldc2 % 8) == 0 && al16(p.C2);
+    if (p.bias) ok = ok && al16(p.bias);
+    if (p.group_add) ok = ok && al16(p.group_add);
+    if (p.dact_pre) ok = ok && (p.ld_dact % 8) == 0 && al16(p.dact_pre);
+    if (p.residual) ok = ok && (p.ld_res % 8) == 0 && al16(p.residual);
+    if (p.residual2) ok = ok && (p.ld_res2 % 8) == 0 && al16(p.residual2);
+    if (p.col_sum) ok = ok && al16(p.col_sum) && al16(p.col_sqsum);
+    if (p.pool_max) ok = ok && al16(p.pool_max);
+    return ok;
+}
+
+template <typename T, int A_MODE>
+__global__ __launch_bounds__(NT, 2) void gemm_kernel(const ppt_gemm_params p)
+{
+    __shared__ __align__(16) unsigned char smem[4 * TILE_BYTES];   // A0 A1 B0 B1
+    constexpr int BK = ROWB / sizeof(T);
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = w >> 1, wn = w & 1;
+#ifdef PPT_DBG_XCD_SWIZZLE
+    // consecutive tiles (same m-tile, n fastest) onto one XCD: blocks are dealt round-robin over 8 XCDs
+    const int nwg = gridDim.x * gridDim.y;
+    const int lin0 = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q8 = nwg / 8, r8 = nwg % 8, xcd = lin0 % 8;
+    const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + lin0 / 8;
+    const int n0 = (lin % gridDim.x) * BN, m0 = (lin / gridDim.x) * BM;
+#else
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+#endif
+    const T *A = reinterpret_cast<const T *>(p.A) + (int64_t)blockIdx.z * p.strideA;
+    const T *B = reinterpret_cast<const T *>(p.B) + (int64_t)blockIdx.z * p.strideB;
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nslab = (p.K + BK - 1) / BK;
+    Stage<T> sa, sb;
+    load_A<T, A_MODE>(sa, p, A, m0, 0);
+    load_plain<T>(sb, B, p.ldb, p.N, p.K, n0, 0);
+    write_stage<T>(sa, smem);
+    write_stage<T>(sb, smem + 2 * TILE_BYTES);
+    __syncthreads();
+    for (int s = 0; s < nslab; ++s) {
+        const int cur = s & 1;
+#ifndef PPT_DBG_SKIP_LOADS
+        if (s + 1 < nslab) {
+            load_A<T, A_MODE>(sa, p, A, m0, (s + 1) * BK);
+            load_plain<T>(sb, B, p.ldb, p.N, p.K, n0, (s + 1) * BK);
+        }
+#endif
+        mma_slab<T>(smem + cur * TILE_BYTES, smem + (2 + cur) * TILE_BYTES, wm, wn, lane, acc);
+        if (s + 1 < nslab) {
+            write_stage<T>(sa, smem + (cur ^ 1) * TILE_BYTES);
+            write_stage<T>(sb, smem + (2 + (cur ^ 1)) * TILE_BYTES);
+        }
+        __syncthreads();
+    }
+
+    // ---------------- epilogue ----------------
+    // The operand tiles are dead (the loop ends on a barrier): every wave parks its 64x64 fp32
+    // accumulators in its own 16 KiB of LDS, row-major, and walks them row by row with lane == column.
+    // That turns the MFMA C layout (column on the lane, rows scattered over 16 registers) into
+    // full-row 128/256-byte global stores, makes the BatchNorm column sums and the 32-row max-pool
+    // plain per-lane running values, and keeps the flag-driven epilogue body out of the unroller.
+    float *ct = reinterpret_cast<float *>(smem) + w * (64 * 64);
+    {
+        const int h = lane >> 5, cl = lane & 31;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ct[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 64 + j * 32 + cl] = acc[i][j][r];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    const int64_t zc = (int64_t)blockIdx.z * p.strideC;
+#ifdef PPT_DBG_SKIP_EPILOGUE
+    if (ct[lane] != 12345.678f) return;
+#endif
+    if (vec_epilogue_ok(p, zc)) epilogue_vec8(p, ct, lane, m0, wm, n0, wn, zc);
+    else epilogue_scalar(p, ct, lane, m0, wm, n0, wn, zc);
 }
 
 template <typename T>

@@ -4,22 +4,36 @@
 
 namespace {
 
+// block = (sample b, 64-column slab): 4 waves stripe the tokens, lane == column (coalesced 256-B rows);
+// the four partial (max, first index) pairs fold through LDS with torch.max's first-maximum rule.
 template <typename TX>
-__global__ void cls_max_pool_kernel(const TX *__restrict__ x, int T, int D, float *__restrict__ out,
-                                    int32_t *__restrict__ argmax)
+__global__ __launch_bounds__(256) void cls_max_pool_kernel(const TX *__restrict__ x, int T, int D, float *__restrict__ out,
+                                                           int32_t *__restrict__ argmax)
 {
-    const int b = blockIdx.x;
-    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    __shared__ float bv[4][64];
+    __shared__ int bi[4][64];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int d = blockIdx.x * 64 + lane;
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    if (d < D) {
         const TX *xb = x + (size_t)b * T * D + d;
-        out[(size_t)b * 2 * D + d] = dt<TX>::load(xb);
-        float best = -INFINITY;
-        int bi = 1;
-        for (int t = 1; t < T; ++t) {
+        for (int t = 1 + w; t < T; t += 4) {
             const float v = dt<TX>::load(xb + (size_t)t * D);
-            if (v > best) { best = v; bi = t; }     // first maximum, as torch.max
+            if (v > best) { best = v; besti = t; }
         }
+    }
+    bv[w][lane] = best; bi[w][lane] = besti;
+    __syncthreads();
+    if (w == 0 && d < D) {
+        for (int k = 1; k < 4; ++k) {
+            const float v = bv[k][lane];
+            const int i = bi[k][lane];
+            if (v > best || (v == best && i < besti)) { best = v; besti = i; }
+        }
+        out[(size_t)b * 2 * D + d] = dt<TX>::load(x + (size_t)b * T * D + d);
         out[(size_t)b * 2 * D + D + d] = best;
-        if (argmax) argmax[(size_t)b * D + d] = bi;
+        if (argmax) argmax[(size_t)b * D + d] = besti;
     }
 }
 
@@ -97,9 +111,9 @@ extern "C" int ppt_cls_max_pool(const void *x, int x_dtype, int B, int T, int D,
 {
     if (!x || !out || B <= 0 || T < 2 || D <= 0) return PPT_EINVAL;
     if (x_dtype == PPT_F32)
-        hipLaunchKernelGGL(cls_max_pool_kernel<float>, dim3(B), dim3(128), 0, ppt_stream(stream), (const float *)x, T, D, out, argmax);
+        hipLaunchKernelGGL(cls_max_pool_kernel<float>, dim3((D + 63) / 64, B), dim3(256), 0, ppt_stream(stream), (const float *)x, T, D, out, argmax);
     else if (x_dtype == PPT_BF16)
-        hipLaunchKernelGGL(cls_max_pool_kernel<bf16_t>, dim3(B), dim3(128), 0, ppt_stream(stream), (const bf16_t *)x, T, D, out, argmax);
+        hipLaunchKernelGGL(cls_max_pool_kernel<bf16_t>, dim3((D + 63) / 64, B), dim3(256), 0, ppt_stream(stream), (const bf16_t *)x, T, D, out, argmax);
     else
         return PPT_EINVAL;
     PPT_CHECK_LAUNCH();

@@ -38,26 +38,48 @@ __global__ __launch_bounds__(256) void conv1_stats_kernel(const float *__restric
     }
 }
 
-__global__ void bn_finalize_kernel(const float *__restrict__ psum, const float *__restrict__ psq, int P, double count,
-                                   int rpp, int C, const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
-                                   int train, float momentum, float *__restrict__ rmean, float *__restrict__ rvar,
-                                   int64_t *__restrict__ nbt, float *__restrict__ scale, float *__restrict__ shift)
+// (count, mean, M2) triples merge associatively (Chan et al.): every thread folds a stripe of the chunk
+// partials in fp64, then the 32 stripes of a channel are folded through LDS.  32 channels per block
+// (coalesced 128-byte rows of the [P, C] partial buffers), 32 stripes -> 1024 threads.
+struct stat3 { double n, mean, m2; };
+__device__ __forceinline__ void stat_merge(stat3 &a, const stat3 &b)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float mean_f, var_f;
+    if (b.n <= 0.0) return;
+    const double tot = a.n + b.n;
+    const double d = b.mean - a.mean;
+    a.mean += d * (b.n / tot);
+    a.m2 += b.m2 + d * d * (a.n * b.n / tot);
+    a.n = tot;
+}
+
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restrict__ psum, const float *__restrict__ psq,
+                                                          int P, double count, int rpp, int C,
+                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                          float eps, int train, float momentum, float *__restrict__ rmean,
+                                                          float *__restrict__ rvar, int64_t *__restrict__ nbt,
+                                                          float *__restrict__ scale, float *__restrict__ shift)
+{
+    __shared__ stat3 red[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
+    float mean_f = 0.f, var_f = 1.f;
     if (train) {
-        double s = 0.0;
-        for (int p = 0; p < P; ++p) s += (double)psum[(size_t)p * C + c];
-        const double mean = s / count;
-        double m2 = 0.0;                                // parallel-variance merge of the chunk (sum, M2) pairs
-        for (int p = 0; p < P; ++p) {
-            const double n = fmin((double)rpp, count - (double)p * rpp);
-            const double d = (double)psum[(size_t)p * C + c] / n - mean;
-            m2 += (double)psq[(size_t)p * C + c] + n * d * d;
+        stat3 acc{0.0, 0.0, 0.0};
+        if (c < C)
+            for (int p = ty; p < P; p += 32) {
+                const double n = fmin((double)rpp, count - (double)p * rpp);
+                if (n > 0.0) stat_merge(acc, stat3{n, (double)psum[(size_t)p * C + c] / n, (double)psq[(size_t)p * C + c]});
+            }
+        red[ty][tx] = acc;
+        __syncthreads();
+        for (int off = 16; off > 0; off >>= 1) {
+            if (ty < off) { stat3 a = red[ty][tx]; stat_merge(a, red[ty + off][tx]); red[ty][tx] = a; }
+            __syncthreads();
         }
-        const double var = m2 / count;                  // biased variance normalises (nn.BatchNorm1d)
-        mean_f = (float)mean; var_f = (float)var;
+        if (ty != 0 || c >= C) return;
+        const stat3 t = red[0][tx];
+        const double var = t.m2 / count;                // biased variance normalises (nn.BatchNorm1d)
+        mean_f = (float)t.mean; var_f = (float)var;
         if (rmean) {
             const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
             rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean_f;
@@ -65,6 +87,7 @@ __global__ void bn_finalize_kernel(const float *__restrict__ psum, const float *
             if (c == 0 && nbt) *nbt += 1;
         }
     } else {
+        if (ty != 0 || c >= C) return;
         mean_f = rmean[c]; var_f = rvar[c];
     }
     const float sc = gamma[c] / sqrtf(var_f + eps);
@@ -113,7 +136,7 @@ extern "C" int ppt_bn_finalize(const float *part_sum, const float *part_sqsum, i
                   (int64_t)n_partials * rows_per_partial < count))
         return PPT_EINVAL;
     if (!train && (!running_mean || !running_var)) return PPT_EINVAL;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, ppt_stream(stream), part_sum, part_sqsum,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, ppt_stream(stream), part_sum, part_sqsum,
                        n_partials, (double)count, rows_per_partial, C, gamma, beta, eps, train, momentum, running_mean, running_var,
                        num_batches_tracked, scale, shift);
     PPT_CHECK_LAUNCH();
