@@ -59,7 +59,7 @@ def cpu_baseline(max_seconds=30.0):
     from oracle import oracle as O
     from ppt_amd import weights as W
     from ppt_amd.models import ULIP_models as M
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))   # 16 was the fastest on the 256-core GPU-box host (tools/cpu_threads.py)
     names = M.dataset_classnames("modelnet40")
     ids, name_lengths = M.tokenize_prompts(names, 32)
     eot = ids.argmax(-1).numpy()
@@ -86,7 +86,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
