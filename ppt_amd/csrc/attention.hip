@@ -14,6 +14,8 @@
 
 extern "C" int ppt_attention_fwd_mfma_bf16(const void *qkv, void *out, float *lse, int Bt, int T, int H,
                                            float scale, int causal, hipStream_t s);
+extern "C" int ppt_attention_bwd_mfma_bf16(const void *qkv, const void *dout, const float *lse, const float *delta,
+                                           void *dqkv, int Bt, int T, int H, float scale, int causal, hipStream_t s);
 
 namespace {
 
@@ -298,7 +300,15 @@ extern "C" int ppt_attention_bwd(const void *qkv, const void *out, const void *d
     if (!qkv || !out || !dout || !lse || !delta || !dqkv || Bt <= 0 || T <= 0 || H <= 0 || hd != HD) return PPT_EINVAL;
     if (dtype == PPT_F32)
         return attn_bwd_t<float>(qkv, out, dout, lse, delta, dqkv, Bt, T, H, scale, causal, ppt_stream(stream));
-    if (dtype == PPT_BF16)
-        return attn_bwd_t<bf16_t>(qkv, out, dout, lse, delta, dqkv, Bt, T, H, scale, causal, ppt_stream(stream));
+    if (dtype == PPT_BF16) {
+        hipStream_t s = ppt_stream(stream);
+        const int64_t rows = (int64_t)Bt * T * H;
+        hipLaunchKernelGGL(attn_delta<bf16_t>, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, s, (const bf16_t *)out,
+                           (const bf16_t *)dout, delta, T, H, rows);
+        PPT_CHECK_LAUNCH();
+        const int rc = ppt_attention_bwd_mfma_bf16(qkv, dout, lse, delta, dqkv, Bt, T, H, scale, causal, s);
+        if (rc != PPT_EUNSUPPORTED) return rc;
+        return attn_bwd_t<bf16_t>(qkv, out, dout, lse, delta, dqkv, Bt, T, H, scale, causal, s);
+    }
     return PPT_EINVAL;
 }

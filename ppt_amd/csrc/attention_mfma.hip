@@ -205,6 +205,300 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const bf16_t *__restrict__ 
     }
 }
 
+
+// =================================================================================================
+// backward: dQ, dK, dV by recomputation from Q, K, V, dO, LSE and delta = rowsum(dO * O).
+// Two kernels, no atomics (deterministic):
+//   attn_bwd_dkv_mfma  wave owns 32 keys (K, V fragments in registers as B operands -> "key on the
+//                      lane"), sweeps the query tiles: S = Q K^T and dP = dO V^T land with the query
+//                      index in the accumulator ROWS, so P and dS are, after a bf16 pack, directly the
+//                      B operands of dV^T += dO^T P and dK^T += Q^T dS (A operands: hardware-transposed
+//                      reads of the row-major Q / dO tiles).
+//   attn_bwd_dq_mfma   wave owns 32 queries (Q, dO fragments in registers), sweeps the key tiles:
+//                      S^T = K Q^T, dP^T = V dO^T, dQ^T += K^T dS^T.
+// Tiles that are read both row-wise (ds_read_b128) and transposed (ds_read_b64_tr_b16) are kept as
+// two LDS images, each with the swizzle that makes its read conflict-free.
+// =================================================================================================
+__device__ __forceinline__ bf16x8_t pack8(const f32x16_t &x, int s)
+{
+    const uint4 u = make_uint4(pack_bf16x2(x[8 * s + 0], x[8 * s + 1]), pack_bf16x2(x[8 * s + 2], x[8 * s + 3]),
+                               pack_bf16x2(x[8 * s + 4], x[8 * s + 5]), pack_bf16x2(x[8 * s + 6], x[8 * s + 7]));
+    return __builtin_bit_cast(bf16x8_t, u);
+}
+
+__device__ __forceinline__ bf16x8_t tr_frag(const unsigned char *img, int row0, int dbyte)
+{
+    struct { s4_t a, b; } f;
+    f.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t *)(img + v_off(row0, dbyte)));
+    f.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t *)(img + v_off(row0 + 8, dbyte)));
+    return __builtin_bit_cast(bf16x8_t, f);
+}
+
+constexpr int QT = 32;                       // query rows per staged tile in the dK/dV kernel
+constexpr int QTILE = QT * 128;              // bytes per 32-row image
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dout,
+                                                         const float *__restrict__ lse, const float *__restrict__ delta,
+                                                         bf16_t *__restrict__ dqkv, int T, int H, float scale)
+{
+    // per stage: Q row image, Q tr image, dO row image, dO tr image (4 KiB each) + lse2[32] + delta[32]
+    __shared__ __align__(16) unsigned char smem[2 * (4 * QTILE + 256)];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.y, b = bh / H, head = bh % H;
+    const int64_t rs = 3 * (int64_t)H * HD, os = (int64_t)H * HD;
+    const bf16_t *qb = qkv + (int64_t)b * T * rs + head * HD;
+    const bf16_t *kb = qb + H * HD, *vb = qb + 2 * H * HD;
+    const bf16_t *gb = dout + (int64_t)b * T * os + head * HD;
+    const int k0 = blockIdx.x * 128 + w * 32;
+    const int key = k0 + r;
+    const float c = scale * 1.4426950408889634f;
+
+    bf16x8_t kf[4], vf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        uint4 a = make_uint4(0, 0, 0, 0), v = make_uint4(0, 0, 0, 0);
+        if (key < T) {
+            a = *reinterpret_cast<const uint4 *>(kb + (int64_t)key * rs + 16 * kk + 8 * h);
+            v = *reinterpret_cast<const uint4 *>(vb + (int64_t)key * rs + 16 * kk + 8 * h);
+        }
+        kf[kk] = __builtin_bit_cast(bf16x8_t, a);
+        vf[kk] = __builtin_bit_cast(bf16x8_t, v);
+    }
+    f32x16_t dvt[2], dkt[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dvt[i][e] = 0.f; dkt[i][e] = 0.f; }
+
+    const int nqt = (T + QT - 1) / QT;
+    const int qt0 = CAUSAL ? (blockIdx.x * 128) / QT : 0;       // queries before the block's first key see none of it
+    uint4 sq, sg;
+    float sl = 0.f, sd = 0.f;
+    const int srow = threadIdx.x >> 3, sch = threadIdx.x & 7;   // staging: one 16-B chunk of Q and of dO per thread
+    auto load_tile = [&](int qt) {
+        const int q = qt * QT + srow;
+        sq = sg = make_uint4(0, 0, 0, 0);
+        if (q < T) {
+            sq = *reinterpret_cast<const uint4 *>(qb + (int64_t)q * rs + sch * 8);
+            sg = *reinterpret_cast<const uint4 *>(gb + (int64_t)q * os + sch * 8);
+        }
+        if (threadIdx.x < QT) {
+            const int q2 = qt * QT + threadIdx.x;
+            sl = q2 < T ? lse[(int64_t)bh * T + q2] * 1.4426950408889634f : INFINITY;   // +inf -> p = 0 for padded rows
+            sd = q2 < T ? delta[(int64_t)bh * T + q2] : 0.f;
+        }
+    };
+    auto write_tile = [&](int buf) {
+        unsigned char *base = smem + buf * (4 * QTILE + 256);
+        *reinterpret_cast<uint4 *>(base + 0 * QTILE + k_off(srow, sch)) = sq;
+        *reinterpret_cast<uint4 *>(base + 1 * QTILE + v_off(srow, sch * 16)) = sq;
+        *reinterpret_cast<uint4 *>(base + 2 * QTILE + k_off(srow, sch)) = sg;
+        *reinterpret_cast<uint4 *>(base + 3 * QTILE + v_off(srow, sch * 16)) = sg;
+        if (threadIdx.x < QT) {
+            reinterpret_cast<float *>(base + 4 * QTILE)[threadIdx.x] = sl;
+            reinterpret_cast<float *>(base + 4 * QTILE + 128)[threadIdx.x] = sd;
+        }
+    };
+    const int g = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+    const int tr_row = 4 * (g >> 1) + tq;
+    const int tr_dbyte = (16 * (g & 1) + 4 * tp) * 2;
+
+    if (qt0 < nqt) {
+        load_tile(qt0);
+        write_tile(0);
+    }
+    __syncthreads();
+    for (int qt = qt0; qt < nqt; ++qt) {
+        const int cur = (qt - qt0) & 1;
+        if (qt + 1 < nqt) load_tile(qt + 1);
+        const bool active = k0 < T && (!CAUSAL || qt * QT + QT - 1 >= k0);       // wave-uniform
+        if (active) {
+            const unsigned char *base = smem + cur * (4 * QTILE + 256);
+            const float *L2 = reinterpret_cast<const float *>(base + 4 * QTILE);
+            const float *DL = reinterpret_cast<const float *>(base + 4 * QTILE + 128);
+            f32x16_t sa, dp;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { sa[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const bf16x8_t qa = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(base + 0 * QTILE + k_off(r, 2 * kk + h)));
+                const bf16x8_t ga = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(base + 2 * QTILE + k_off(r, 2 * kk + h)));
+                sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[kk], sa, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, vf[kk], dp, 0, 0, 0);
+            }
+            const bool diag = CAUSAL && qt * QT < k0 + 32;        // some (q, key) pairs of this tile are masked
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const float4 l4 = *reinterpret_cast<const float4 *>(L2 + 8 * gq + 4 * h);
+                const float4 d4 = *reinterpret_cast<const float4 *>(DL + 8 * gq + 4 * h);
+                const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = 4 * gq + j;
+                    float pv = __builtin_amdgcn_exp2f(fmaf(sa[e], c, -lv[j]));
+                    if (diag && key > qt * QT + 8 * gq + 4 * h + j) pv = 0.f;
+                    sa[e] = pv;
+                    dp[e] = pv * (dp[e] - dv[j]) * scale;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8_t pf = pack8(sa, s), df = pack8(dp, s);
+#pragma unroll
+                for (int dtile = 0; dtile < 2; ++dtile) {
+                    const bf16x8_t gt = tr_frag(base + 3 * QTILE, 16 * s + tr_row, tr_dbyte + 64 * dtile);   // dO^T
+                    dvt[dtile] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gt, pf, dvt[dtile], 0, 0, 0);
+                    const bf16x8_t qt_ = tr_frag(base + 1 * QTILE, 16 * s + tr_row, tr_dbyte + 64 * dtile);  // Q^T
+                    dkt[dtile] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt_, df, dkt[dtile], 0, 0, 0);
+                }
+            }
+        }
+        if (qt + 1 < nqt) write_tile(cur ^ 1);
+        __syncthreads();
+    }
+    if (key < T) {
+        bf16_t *ok = dqkv + ((int64_t)b * T + key) * rs + head * HD + H * HD;
+        bf16_t *ov = ok + H * HD;
+#pragma unroll
+        for (int dtile = 0; dtile < 2; ++dtile)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int d = 32 * dtile + 8 * gq + 4 * h;
+                *reinterpret_cast<uint2 *>(ok + d) = make_uint2(pack_bf16x2(dkt[dtile][4 * gq], dkt[dtile][4 * gq + 1]),
+                                                                 pack_bf16x2(dkt[dtile][4 * gq + 2], dkt[dtile][4 * gq + 3]));
+                *reinterpret_cast<uint2 *>(ov + d) = make_uint2(pack_bf16x2(dvt[dtile][4 * gq], dvt[dtile][4 * gq + 1]),
+                                                                 pack_bf16x2(dvt[dtile][4 * gq + 2], dvt[dtile][4 * gq + 3]));
+            }
+    }
+}
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dout,
+                                                        const float *__restrict__ lse, const float *__restrict__ delta,
+                                                        bf16_t *__restrict__ dqkv, int T, int H, float scale)
+{
+    __shared__ __align__(16) unsigned char smem[2 * 3 * TILE];    // per stage: K row image, K tr image, V row image
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.y, b = bh / H, head = bh % H;
+    const int64_t rs = 3 * (int64_t)H * HD, os = (int64_t)H * HD;
+    const bf16_t *qb = qkv + (int64_t)b * T * rs + head * HD;
+    const bf16_t *kb = qb + H * HD, *vb = qb + 2 * H * HD;
+    const bf16_t *gb = dout + (int64_t)b * T * os + head * HD;
+    const int q0 = blockIdx.x * QB + w * 32;
+    const int qrow = q0 + r;
+    const float c = scale * 1.4426950408889634f;
+
+    bf16x8_t qf[4], gf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        uint4 a = make_uint4(0, 0, 0, 0), v = make_uint4(0, 0, 0, 0);
+        if (qrow < T) {
+            a = *reinterpret_cast<const uint4 *>(qb + (int64_t)qrow * rs + 16 * kk + 8 * h);
+            v = *reinterpret_cast<const uint4 *>(gb + (int64_t)qrow * os + 16 * kk + 8 * h);
+        }
+        qf[kk] = __builtin_bit_cast(bf16x8_t, a);
+        gf[kk] = __builtin_bit_cast(bf16x8_t, v);
+    }
+    const float l2 = qrow < T ? lse[(int64_t)bh * T + qrow] * 1.4426950408889634f : INFINITY;
+    const float dl = qrow < T ? delta[(int64_t)bh * T + qrow] : 0.f;
+
+    uint4 sk[2], sv[2];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int cidx = threadIdx.x + 256 * i;
+            const int kx = kt * KVT + (cidx >> 3), ch = cidx & 7;
+            sk[i] = sv[i] = make_uint4(0, 0, 0, 0);
+            if (kx < T) {
+                sk[i] = *reinterpret_cast<const uint4 *>(kb + (int64_t)kx * rs + ch * 8);
+                sv[i] = *reinterpret_cast<const uint4 *>(vb + (int64_t)kx * rs + ch * 8);
+            }
+        }
+    };
+    auto write_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int cidx = threadIdx.x + 256 * i;
+            const int row = cidx >> 3, ch = cidx & 7;
+            unsigned char *base = smem + buf * 3 * TILE;
+            *reinterpret_cast<uint4 *>(base + 0 * TILE + k_off(row, ch)) = sk[i];
+            *reinterpret_cast<uint4 *>(base + 1 * TILE + v_off(row, ch * 16)) = sk[i];
+            *reinterpret_cast<uint4 *>(base + 2 * TILE + k_off(row, ch)) = sv[i];
+        }
+    };
+    const int q_hi = min(T, (int)(blockIdx.x + 1) * QB) - 1;
+    const int nkt = CAUSAL ? min((T + KVT - 1) / KVT, q_hi / KVT + 1) : (T + KVT - 1) / KVT;
+    f32x16_t dqt[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dqt[i][e] = 0.f;
+    const int g = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+    const int tr_row = 4 * (g >> 1) + tq;
+    const int tr_dbyte = (16 * (g & 1) + 4 * tp) * 2;
+
+    load_tile(0);
+    write_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) load_tile(kt + 1);
+        const bool active = q0 < T && (!CAUSAL || kt * KVT <= q0 + 31);
+        if (active) {
+            const unsigned char *base = smem + cur * 3 * TILE;
+            const bool need_mask = (kt * KVT + KVT > T) || (CAUSAL && kt * KVT + KVT - 1 > q0);
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                f32x16_t sa, dp;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { sa[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const bf16x8_t ka = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(base + 0 * TILE + k_off(32 * sub + r, 2 * kk + h)));
+                    const bf16x8_t va = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(base + 2 * TILE + k_off(32 * sub + r, 2 * kk + h)));
+                    sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[kk], sa, 0, 0, 0);     // S^T  [key][q]
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, gf[kk], dp, 0, 0, 0);     // dP^T [key][q]
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float pv = __builtin_amdgcn_exp2f(fmaf(sa[e], c, -l2));
+                    if (need_mask) {
+                        const int kx = kt * KVT + 32 * sub + (e & 3) + 8 * (e >> 2) + 4 * h;
+                        if (kx >= T || (CAUSAL && kx > qrow)) pv = 0.f;
+                    }
+                    dp[e] = pv * (dp[e] - dl) * scale;
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8_t df = pack8(dp, s);
+#pragma unroll
+                    for (int dtile = 0; dtile < 2; ++dtile) {
+                        const bf16x8_t kt_ = tr_frag(base + 1 * TILE, 32 * sub + 16 * s + tr_row, tr_dbyte + 64 * dtile);   // K^T
+                        dqt[dtile] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt_, df, dqt[dtile], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (kt + 1 < nkt) write_tile(cur ^ 1);
+        __syncthreads();
+    }
+    if (qrow < T) {
+        bf16_t *oq = dqkv + ((int64_t)b * T + qrow) * rs + head * HD;
+#pragma unroll
+        for (int dtile = 0; dtile < 2; ++dtile)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+                *reinterpret_cast<uint2 *>(oq + 32 * dtile + 8 * gq + 4 * h) =
+                    make_uint2(pack_bf16x2(dqt[dtile][4 * gq], dqt[dtile][4 * gq + 1]),
+                               pack_bf16x2(dqt[dtile][4 * gq + 2], dqt[dtile][4 * gq + 3]));
+    }
+}
+
 }  // namespace
 
 extern "C" int ppt_attention_fwd_mfma_bf16(const void *qkv, void *out, float *lse, int Bt, int T, int H, float scale,
@@ -217,6 +511,23 @@ extern "C" int ppt_attention_fwd_mfma_bf16(const void *qkv, void *out, float *ls
         hipLaunchKernelGGL(attn_fwd_mfma<true>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (bf16_t *)out, lse, T, H, c);
     else
         hipLaunchKernelGGL(attn_fwd_mfma<false>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (bf16_t *)out, lse, T, H, c);
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
+// dq / dk / dv of the bf16 path; `delta` must already hold rowsum(dO * O) (attention.hip: attn_delta)
+extern "C" int ppt_attention_bwd_mfma_bf16(const void *qkv, const void *dout, const float *lse, const float *delta,
+                                           void *dqkv, int Bt, int T, int H, float scale, int causal, hipStream_t s)
+{
+    if (((uintptr_t)qkv & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dqkv & 7)) return PPT_EUNSUPPORTED;
+    dim3 grid((T + 127) / 128, Bt * H);
+    if (causal) {
+        hipLaunchKernelGGL(attn_bwd_dkv_mfma<true>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (const bf16_t *)dout, lse, delta, (bf16_t *)dqkv, T, H, scale);
+        hipLaunchKernelGGL(attn_bwd_dq_mfma<true>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (const bf16_t *)dout, lse, delta, (bf16_t *)dqkv, T, H, scale);
+    } else {
+        hipLaunchKernelGGL(attn_bwd_dkv_mfma<false>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (const bf16_t *)dout, lse, delta, (bf16_t *)dqkv, T, H, scale);
+        hipLaunchKernelGGL(attn_bwd_dq_mfma<false>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (const bf16_t *)dout, lse, delta, (bf16_t *)dqkv, T, H, scale);
+    }
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }

@@ -231,16 +231,24 @@ def point_encoder_backward(sd, wc, s, dfeat, tier):
 # =================================================================================================
 # text branch (CLIP text transformer, ULIP_models.py:35-67, 203-222)
 # =================================================================================================
-def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save):
+def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=None):
     """encode_text: prompts [C,L,W] fp32 -> text features [C,E] fp32 (before L2 normalisation).
-    save=True keeps what the input-gradient backward needs."""
+    save=True keeps what the input-gradient backward needs.
+
+    eff_len: the attention is causal (ULIP_models.py:224-230) and only the EOT token is pooled
+    (:222), so positions after the last EOT of any class can influence neither the output nor any
+    gradient; the tower is evaluated on the first eff_len = max(eot)+1 positions only (39 of 77 for
+    the ModelNet40 prompts).  Outputs and gradients are identical to the full-length evaluation."""
     T = wc.dtype
-    C, L, Wd = prompts.shape
+    C, Lfull, Wd = prompts.shape
+    L = Lfull if eff_len is None else min(Lfull, int(eff_len))
+    if L != Lfull:
+        prompts = prompts[:, :L].contiguous()
     M = C * L
     dev = prompts.device
     saved = {"layers": []} if save else None
     x = torch.empty((M, Wd), dtype=torch.float32, device=dev)
-    add, add_rows = sd["positional_embedding"], L                 # x = prompts + pos (ULIP_models.py:210)
+    add, add_rows = sd["positional_embedding"], L                 # x = prompts + pos[:L] (ULIP_models.py:210)
     xin = prompts.reshape(M, Wd)
     for i in range(layers):
         p = f"transformer.resblocks.{i}."
@@ -270,7 +278,7 @@ def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save):
     wc32 = _f32_cache(wc)
     out = ops.gemm(hn, wc32.get(sd["text_projection"], "wt"), out_dtype=torch.float32)
     if save:
-        saved.update(x_eot=x_eot, meanf=meanf, rstdf=rstdf, rows=rows, C=C, L=L, W=Wd, heads=heads)
+        saved.update(x_eot=x_eot, meanf=meanf, rstdf=rstdf, rows=rows, C=C, L=L, Lfull=Lfull, W=Wd, heads=heads)
     return out, saved
 
 
@@ -312,4 +320,8 @@ def text_tower_backward(sd, wc, s, dout):
         d_h = ops.gemm(d_qkv, wc.get(sd[p + "attn.in_proj_weight"], "wt"), out_dtype=torch.float32)
         _, _, _, g_t = ops.layernorm_bwd(d_h, ly["x"], sd[p + "ln_1.weight"], ly["mean1"], ly["rstd1"], dx=g,
                                          accumulate=True, copy_dtype=T)
-    return g.view(C, L, Wd)
+    if L == s["Lfull"]:
+        return g.view(C, L, Wd)
+    full = torch.zeros((C, s["Lfull"], Wd), dtype=torch.float32, device=dout.device)   # positions past the last EOT: zero gradient
+    full[:, :L] = g.view(C, L, Wd)
+    return full

@@ -184,7 +184,8 @@ class _TextTowerFn(torch.autograd.Function):
         sd = model._live_state()
         save = bool(ctx.needs_input_grad[1])
         out, saved = engine.text_tower_forward(sd, model._cache(), prompts.contiguous().float(), model._eot(prompts.device),
-                                               model.transformer.heads, model.transformer.layers, save)
+                                               model.transformer.heads, model.transformer.layers, save,
+                                               eff_len=model._text_len() if model.truncate_text_to_eot else None)
         ctx.model, ctx.saved = model, saved
         return out
 
@@ -248,6 +249,7 @@ class ULIP_WITH_IMAGE(nn.Module):
         self._eot_pos = None
         self._text_stream = None
         self.overlap_text_tower = True      # run the (input-independent) text tower on a side stream
+        self.truncate_text_to_eot = True    # causal mask + EOT pooling: positions after the last EOT are dead work
 
     # ---- reference helpers ------------------------------------------------------------------
     def build_attention_mask(self):
@@ -305,6 +307,9 @@ class ULIP_WITH_IMAGE(nn.Module):
     def load_state_dict(self, *a, **k):
         self._sd = None
         return super().load_state_dict(*a, **k)
+
+    def _text_len(self):
+        return int(self.tokenized_prompts.argmax(dim=-1).max().item()) + 1
 
     def _eot(self, device):
         if self._eot_pos is None or self._eot_pos.device != device:

@@ -106,6 +106,26 @@ def test_eval_forward_matches_golden(precision, tol):
     assert (logits.argmax(1).cpu().numpy() == g["logits"].argmax(1)).all()
 
 
+def test_text_truncation_is_exact():
+    """evaluating the causal text tower only up to the last EOT position changes nothing (fp32 mode: bit-level
+    differences can only come from nothing at all -- every surviving row sees identical operands)."""
+    m, _ = build(0, torch.float32)
+    m.train()
+    pc, start = oracle_inputs()
+    m.point_encoder.fps_start = torch.from_numpy(start).cuda()
+    m.point_encoder.drop_path_factors = torch.ones(12, 2, 4)
+    outs = []
+    for trunc in (False, True):
+        m.truncate_text_to_eot = trunc
+        m.prompt_learner.learnable_tokens.grad = None
+        logits = m(pc.cuda())
+        logits.square().mean().backward()
+        outs.append((logits.detach().clone(), m.prompt_learner.learnable_tokens.grad.clone()))
+    assert m._text_len() == 39
+    assert (outs[0][0] - outs[1][0]).abs().max().item() < 1e-4
+    assert ((outs[0][1] - outs[1][1]).norm() / outs[0][1].norm()).item() < 1e-5
+
+
 def test_overlapped_text_tower_is_identical():
     m, _ = build(0, torch.bfloat16)
     m.eval()
