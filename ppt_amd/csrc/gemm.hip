@@ -1,14 +1,18 @@
 // gemm.hip -- C[M,N] = epilogue( prologue(A)[M,K] . B[N,K]^T ) on the gfx950 matrix cores.
 //
 // One kernel family serves every nn.Linear / Conv1d(k=1) of the path (see include/ppt_hip.h):
-//   * 128x128 output tile per 256-thread workgroup, 4 waves as 2x2, each wave 64x64 =
-//     2x2 MFMA tiles of 32x32 (v_mfma_f32_32x32x16_bf16, or v_mfma_f32_32x32x2_f32 in parity mode),
-//     fp32 accumulators in registers;
+//   * 128x128 (or, for grids that would under-fill the 256 CUs, 64x64) output tile per 256-thread
+//     workgroup, 4 waves as 2x2, each wave (BM/2)x(BN/2) in MFMA tiles of 32x32
+//     (v_mfma_f32_32x32x16_bf16, or v_mfma_f32_32x32x2_f32 in parity mode), fp32 accumulators in registers;
 //   * K is walked in 128-BYTE slabs (64 bf16 / 32 f32) so both dtypes share one LDS image:
 //     [128 rows][8 x 16-B chunks], chunk index XOR-swizzled with (row>>1)&7, which makes the
 //     ds_read_b128 fragment reads of the 32x32x16 operand conflict-free;
-//   * register-staged double buffering: the global loads of slab t+1 are issued before the MFMAs
-//     of slab t and written to the other LDS buffer afterwards -> one barrier per slab.  Staging
+//   * register-staged pipeline, THREE slabs deep: while slab s is multiplied out of LDS, slabs s+1 and
+//     s+2 sit in (or fly into) two register sets and the loads of slab s+3 are issued into the third;
+//     slab s+1 moves to the other LDS buffer after the MFMAs -> one barrier per slab and ~2 slab-times
+//     of latency cover for every global load (the K loop of these shapes is latency-, not
+//     bandwidth-bound: M is huge or the grid is small, K is 128..2048).  Loads are branch-free
+//     (clamped address + select), so the compiler's counted vmcnt keeps two slabs in flight.  Staging
 //     through registers (rather than LDS-DMA) is what lets the A operand be TRANSFORMED on the way
 //     in: BatchNorm+ReLU of the previous layer (A_AFFINE_RELU) or the whole K=3 first conv of the
 //     mini-PointNet (A_CONV1) never touch HBM;
@@ -16,6 +20,7 @@
 //     derivative, DropPath row scale, up to two residual adds, a second output copy, BatchNorm
 //     column statistics and the 32-row max-pool of the mini-PointNet (one MFMA row-tile == one
 //     kNN group, so the pool is 15 v_max + one cross-half exchange).
+#include <stdlib.h>
 #include "ppt_common.h"
 
 namespace {
@@ -23,8 +28,8 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
-constexpr int BM = 128, BN = 128, ROWB = 128, NT = 256;
-constexpr int TILE_BYTES = BM * ROWB;   // 16 KiB per operand per stage
+constexpr int ROWB = 128, NT = 256;
+
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
@@ -64,21 +69,36 @@ __device__ __forceinline__ void store_dt(void *p, int dtype, int64_t i, float v)
 }
 
 // ---- A / B slab loaders ---------------------------------------------------------------------
-// thread t owns chunk column ch = t&7 of rows (t>>3) + 32*i, i = 0..3, in every slab.
-template <typename T> struct Stage { uint4 v[4]; };
+// thread t owns chunk column ch = t&7 of rows (t>>3) + 32*i, i < NR, in every slab.
+template <int NR> struct Stage { uint4 v[NR]; };
 
-template <typename T>
-__device__ __forceinline__ void load_plain(Stage<T> &st, const T *base, int64_t ld, int rows, int K, int r0, int k0)
+template <typename T, int NR>
+__device__ __forceinline__ void load_plain(Stage<NR> &st, const T *base, int64_t ld, int rows, int K, int r0, int k0)
 {
     constexpr int EPC = 16 / sizeof(T);
     const int t = threadIdx.x, ch = t & 7;
     const int k = k0 + ch * EPC;
+    const int kc = min(k, K - EPC);                 // always a valid address; out-of-range chunks are zeroed by mask_plain
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NR; ++i) {
         const int r = r0 + (t >> 3) + 32 * i;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (r < rows && k < K) v = *reinterpret_cast<const uint4 *>(base + (int64_t)r * ld + k);
-        st.v[i] = v;
+        st.v[i] = *reinterpret_cast<const uint4 *>(base + (int64_t)min(r, rows - 1) * ld + kc);
+    }
+}
+
+// zero the chunks that lie outside [rows) x [K): done at LDS-write time, NOT at load time -- a select
+// right behind the load would make the compiler wait for the data immediately (vmcnt(0)) and
+// serialise the whole pipeline.
+template <typename T, int NR>
+__device__ __forceinline__ void mask_plain(Stage<NR> &st, int rows, int K, int r0, int k0)
+{
+    constexpr int EPC = 16 / sizeof(T);
+    const int t = threadIdx.x, ch = t & 7;
+    const bool kok = k0 + ch * EPC < K;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const bool ok = kok && (r0 + (t >> 3) + 32 * i) < rows;
+        if (!ok) st.v[i] = make_uint4(0u, 0u, 0u, 0u);
     }
 }
 
@@ -104,27 +124,43 @@ __device__ __forceinline__ void affine_relu_chunk<float>(uint4 &v, const float *
     v = make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
 }
 
-template <typename T, int A_MODE>
-__device__ __forceinline__ void load_A(Stage<T> &st, const ppt_gemm_params &p, const T *A, int m0, int k0)
+// The A prologues split into the part that touches memory (issue early) and the part that only touches
+// registers (run late, just before the LDS write), so that the transform does not wait for the loads.
+template <typename T, int A_MODE, int NR>
+__device__ __forceinline__ void load_A(Stage<NR> &st, const ppt_gemm_params &p, const T *A, int m0, int k0)
+{
+    if constexpr (A_MODE == PPT_A_CONV1) {          // stage the raw points (12 B / row); the conv happens in finish_A
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int r = min(m0 + (t >> 3) + 32 * i, p.M - 1);
+            st.v[i] = make_uint4(__float_as_uint(p.pts[(int64_t)r * 3 + 0]), __float_as_uint(p.pts[(int64_t)r * 3 + 1]),
+                                 __float_as_uint(p.pts[(int64_t)r * 3 + 2]), 0u);
+        }
+    } else {
+        load_plain<T, NR>(st, A, p.lda, p.M, p.K, m0, k0);
+    }
+}
+
+template <typename T, int A_MODE, int NR>
+__device__ __forceinline__ void finish_A(Stage<NR> &st, const ppt_gemm_params &p, int m0, int k0)
 {
     constexpr int EPC = 16 / sizeof(T);
     const int t = threadIdx.x, ch = t & 7;
     const int k = k0 + ch * EPC;
-    if constexpr (A_MODE == PPT_A_PLAIN) {
-        load_plain<T>(st, A, p.lda, p.M, p.K, m0, k0);
-    } else if constexpr (A_MODE == PPT_A_AFFINE_RELU) {
-        load_plain<T>(st, A, p.lda, p.M, p.K, m0, k0);
+    if constexpr (A_MODE != PPT_A_CONV1) mask_plain<T, NR>(st, p.M, p.K, m0, k0);
+    if constexpr (A_MODE == PPT_A_AFFINE_RELU) {
         if (k < p.K) {
             float sc[EPC], sh[EPC];
 #pragma unroll
             for (int e = 0; e < EPC; ++e) { sc[e] = p.a_scale[k + e]; sh[e] = p.a_shift[k + e]; }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NR; ++i) {
                 const int r = m0 + (t >> 3) + 32 * i;
                 if (r < p.M) affine_relu_chunk<T>(st.v[i], sc, sh);   // rows >= M stay zero
             }
         }
-    } else {   // PPT_A_CONV1: a'[m][c] = relu(scale[c]*(w1[c].p_m + b1[c]) + shift[c]), c = k index
+    } else if constexpr (A_MODE == PPT_A_CONV1) {   // a'[m][c] = relu(scale[c]*(w1[c].p_m + b1[c]) + shift[c]), c = k index
         float wx[EPC], wy[EPC], wz[EPC], wb[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
@@ -137,17 +173,13 @@ __device__ __forceinline__ void load_A(Stage<T> &st, const ppt_gemm_params &p, c
             } else { wx[e] = wy[e] = wz[e] = 0.f; wb[e] = 0.f; }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NR; ++i) {
             const int r = m0 + (t >> 3) + 32 * i;
+            const float x = __uint_as_float(st.v[i].x), y = __uint_as_float(st.v[i].y), z = __uint_as_float(st.v[i].z);
             float f[EPC];
-            if (r < p.M) {
-                const float x = p.pts[(int64_t)r * 3 + 0], y = p.pts[(int64_t)r * 3 + 1], z = p.pts[(int64_t)r * 3 + 2];
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) f[e] = fmaxf(fmaf(wz[e], z, fmaf(wy[e], y, fmaf(wx[e], x, wb[e]))), 0.0f);
-            } else {
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) f[e] = 0.f;
-            }
+            for (int e = 0; e < EPC; ++e)
+                f[e] = r < p.M ? fmaxf(fmaf(wz[e], z, fmaf(wy[e], y, fmaf(wx[e], x, wb[e]))), 0.0f) : 0.0f;
             if constexpr (sizeof(T) == 2)
                 st.v[i] = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]),
                                      pack_bf16x2(f[6], f[7]));
@@ -158,76 +190,80 @@ __device__ __forceinline__ void load_A(Stage<T> &st, const ppt_gemm_params &p, c
     }
 }
 
-template <typename T>
-__device__ __forceinline__ void write_stage(const Stage<T> &st, unsigned char *tile)
+template <int NR>
+__device__ __forceinline__ void write_stage(const Stage<NR> &st, unsigned char *tile)
 {
     const int t = threadIdx.x, ch = t & 7;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NR; ++i) {
         const int row = (t >> 3) + 32 * i;
         *reinterpret_cast<uint4 *>(tile + lds_off(row, ch)) = st.v[i];
     }
 }
 
-// ---- one 128-byte K slab of MFMAs for this wave's 64x64 -------------------------------------
-template <typename T>
-__device__ __forceinline__ void mma_slab(const unsigned char *As, const unsigned char *Bs, int wm, int wn, int lane,
-                                         f32x16_t (&acc)[2][2])
+// ---- one 128-byte K slab of MFMAs for this wave's (32*TI) x (32*TJ) ------------------------------
+template <typename T, int TI, int TJ>
+__device__ __forceinline__ void mma_slab(const unsigned char *As, const unsigned char *Bs, int arow0, int brow0, int lane,
+                                         f32x16_t (&acc)[TI][TJ])
 {
     const int r = lane & 31, h = lane >> 5;
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            bf16x8_t a[2], b[2];
+            bf16x8_t a[TI], b[TJ];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(As + lds_off(wm * 64 + i * 32 + r, kk * 2 + h)));
-                b[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(Bs + lds_off(wn * 64 + i * 32 + r, kk * 2 + h)));
-            }
+            for (int i = 0; i < TI; ++i)
+                a[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(As + lds_off(arow0 + i * 32 + r, kk * 2 + h)));
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < TJ; ++j)
+                b[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(Bs + lds_off(brow0 + j * 32 + r, kk * 2 + h)));
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     } else {
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
             const int kq = 2 * kk + h;      // k index (in floats) inside the 32-float slab
-            float a[2], b[2];
+            float a[TI], b[TJ];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i] = *reinterpret_cast<const float *>(As + lds_off(wm * 64 + i * 32 + r, kq >> 2) + (kq & 3) * 4);
-                b[i] = *reinterpret_cast<const float *>(Bs + lds_off(wn * 64 + i * 32 + r, kq >> 2) + (kq & 3) * 4);
-            }
+            for (int i = 0; i < TI; ++i)
+                a[i] = *reinterpret_cast<const float *>(As + lds_off(arow0 + i * 32 + r, kq >> 2) + (kq & 3) * 4);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < TJ; ++j)
+                b[j] = *reinterpret_cast<const float *>(Bs + lds_off(brow0 + j * 32 + r, kq >> 2) + (kq & 3) * 4);
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     }
 }
 
-// ---- scalar epilogue (any N / alignment): lane == column, one row per iteration -----------------
-__device__ __forceinline__ void epilogue_scalar(const ppt_gemm_params &p, float *ct, int lane, int m0, int wm, int n0, int wn,
-                                             int64_t zc)
+// ---- scalar epilogue (any N / alignment): WN lanes span a row, 64/WN rows per pass ----------------
+template <int WM, int WN>
+__device__ __forceinline__ void epilogue_scalar(const ppt_gemm_params &p, float *ct, int lane, int mw, int nw, int m0, int wm,
+                                                int64_t zc)
 {
-    const int n = n0 + wn * 64 + lane;
+    constexpr int RP = 64 / WN;                     // rows per pass
+    const int cl = lane % WN, rsub = lane / WN;
+    const int n = nw + cl;
     const bool nok = n < p.N;
-    const int mw = m0 + wm * 64;
     const float bias = (p.bias && nok) ? p.bias[n] : 0.0f;
     float csum = 0.f, csq = 0.f, pmax = -INFINITY;
 #pragma unroll 1
-    for (int rr = 0; rr < 64; ++rr) {
+    for (int it = 0; it < WM / RP; ++it) {
+        const int rr = it * RP + rsub;
         const int m = mw + rr;
-        if (m >= p.M) break;                    // wave-uniform
-        if (nok) {
-            float v = ct[rr * 64 + lane] + bias;
+        if (nok && m < p.M) {
+            float v = ct[rr * WN + cl] + bias;
             if (p.group_add) v += p.group_add[(int64_t)(m / p.group_rows) * p.N + n];
-            if (p.col_sum) { csum += v; ct[rr * 64 + lane] = v; }   // keep the pre-activation for the M2 pass
+            if (p.col_sum) { csum += v; ct[rr * WN + cl] = v; }
             if (p.C2 && p.c2_pre) store_dt(p.C2, p.c2_dtype, (int64_t)m * p.ldc2 + n, v);
-            if (p.dact_pre) {                   // backward through an activation: * act'(saved pre-activation)
+            if (p.dact_pre) {
                 const float x = p.dtype == PPT_BF16 ? load_as_f32<bf16_t>(p.dact_pre, (int64_t)m * p.ld_dact + n)
                                                      : load_as_f32<float>(p.dact_pre, (int64_t)m * p.ld_dact + n);
                 v *= act_bwd(x, p.act);
@@ -241,33 +277,32 @@ __device__ __forceinline__ void epilogue_scalar(const ppt_gemm_params &p, float 
             if (p.C2 && !p.c2_pre) store_dt(p.C2, p.c2_dtype, (int64_t)m * p.ldc2 + n, v);
             pmax = fmaxf(pmax, v);
         }
-        if (p.pool_max && (rr & 31) == 31) {
-            if (nok) store_dt(p.pool_max, p.pool_dtype, (int64_t)(m >> 5) * p.N + n, pmax);
-            pmax = -INFINITY;
+        if constexpr (WN == 64) {
+            if (p.pool_max && (rr & 31) == 31) {
+                if (nok && m < p.M) store_dt(p.pool_max, p.pool_dtype, (int64_t)(m >> 5) * p.N + n, pmax);
+                pmax = -INFINITY;
+            }
         }
     }
-    if (p.col_sum && nok && mw < p.M) {
-        // BatchNorm statistics without cancellation: per 64-row chunk (sum, M2 about the chunk mean);
-        // ppt_bn_finalize merges the chunks with the parallel-variance formula in fp64.
-        const int nrow = min(64, p.M - mw);
-        const float cmean = csum / (float)nrow;
-        for (int rr = 0; rr < nrow; ++rr) {
-            const float d = ct[rr * 64 + lane] - cmean;
-            csq = fmaf(d, d, csq);
+    if constexpr (WN == 64) {
+        if (p.col_sum && nok && mw < p.M) {
+            const int nrow = min(64, p.M - mw);
+            const float cmean = csum / (float)nrow;
+            for (int rr = 0; rr < nrow; ++rr) {
+                const float d = ct[rr * 64 + lane] - cmean;
+                csq = fmaf(d, d, csq);
+            }
+            const int prow = (m0 >> 6) + wm;
+            p.col_sum[(int64_t)prow * p.N + n] = csum;
+            p.col_sqsum[(int64_t)prow * p.N + n] = csq;
         }
-        const int prow = (m0 >> 6) + wm;
-        p.col_sum[(int64_t)prow * p.N + n] = csum;
-        p.col_sqsum[(int64_t)prow * p.N + n] = csq;
     }
 }
 
-
-
-// ---- vector epilogue: 8 consecutive columns per lane, 8 rows per pass --------------------------
+// ---- vector epilogue: 8 consecutive columns per lane, 64/(WN/8) rows per pass -------------------
 // global stores are issue-bound, not byte-bound, on this chip (a 2-byte-per-lane store costs the same
 // issue slot as a 16-byte one), so the tile is written as 16-byte pieces: lane = (row-in-pass, column
-// group); 8 passes cover the wave's 64x64 tile.  Column statistics / pooled maxima fold the 8 row-lanes
-// with three xor-shuffles.
+// group).  Column statistics / pooled maxima fold the row-lanes with three xor-shuffles.
 struct f8 { float v[8]; };
 
 __device__ __forceinline__ f8 ld8_f32(const float *p)
@@ -301,23 +336,24 @@ __device__ __forceinline__ void st8_dt(void *p, int dtype, int64_t i, const f8 &
         st8_f32((float *)p + i, x);
 }
 
-__device__ __forceinline__ void epilogue_vec8(const ppt_gemm_params &p, float *ct, int lane, int m0, int wm, int n0, int wn,
-                                           int64_t zc)
+template <int WM, int WN>
+__device__ __forceinline__ void epilogue_vec8(const ppt_gemm_params &p, float *ct, int lane, int mw, int nw, int m0, int wm,
+                                              int64_t zc)
 {
-    const int cg = lane & 7, rl = lane >> 3;
-    const int n = n0 + wn * 64 + cg * 8;
+    constexpr int CGS = WN / 8, RP = 64 / CGS, NPASS = WM / RP;
+    const int cg = lane % CGS, rl = lane / CGS;
+    const int n = nw + cg * 8;
     const bool nok = n < p.N;
-    const int mw = m0 + wm * 64;
     f8 bias, csum, pm;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { bias.v[e] = 0.f; csum.v[e] = 0.f; pm.v[e] = -INFINITY; }
     if (p.bias && nok) bias = ld8_f32(p.bias + n);
 #pragma unroll 1
-    for (int pass = 0; pass < 8; ++pass) {
-        const int rr = pass * 8 + rl;
+    for (int pass = 0; pass < NPASS; ++pass) {
+        const int rr = pass * RP + rl;
         const int m = mw + rr;
         if (nok && m < p.M) {
-            f8 v = ld8_f32(ct + rr * 64 + cg * 8);
+            f8 v = ld8_f32(ct + rr * WN + cg * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v.v[e] += bias.v[e];
             if (p.group_add) {
@@ -328,7 +364,7 @@ __device__ __forceinline__ void epilogue_vec8(const ppt_gemm_params &p, float *c
             if (p.col_sum) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) csum.v[e] += v.v[e];
-                st8_f32(ct + rr * 64 + cg * 8, v);
+                st8_f32(ct + rr * WN + cg * 8, v);
             }
             if (p.C2 && p.c2_pre) st8_dt(p.C2, p.c2_dtype, (int64_t)m * p.ldc2 + n, v);
             if (p.dact_pre) {
@@ -359,50 +395,54 @@ __device__ __forceinline__ void epilogue_vec8(const ppt_gemm_params &p, float *c
 #pragma unroll
             for (int e = 0; e < 8; ++e) pm.v[e] = fmaxf(pm.v[e], v.v[e]);
         }
-        if (p.pool_max && (pass & 3) == 3) {          // rows [32*(pass>>2), +32) complete
+        if constexpr (WN == 64) {
+            if (p.pool_max && (pass & 3) == 3) {          // rows [32*(pass>>2), +32) complete
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float t = pm.v[e];
-                t = fmaxf(t, __shfl_xor(t, 8, 64)); t = fmaxf(t, __shfl_xor(t, 16, 64)); t = fmaxf(t, __shfl_xor(t, 32, 64));
-                pm.v[e] = t;
+                for (int e = 0; e < 8; ++e) {
+                    float t = pm.v[e];
+                    t = fmaxf(t, __shfl_xor(t, 8, 64)); t = fmaxf(t, __shfl_xor(t, 16, 64)); t = fmaxf(t, __shfl_xor(t, 32, 64));
+                    pm.v[e] = t;
+                }
+                const int mg = mw + (pass >> 2) * 32;
+                if (rl == 0 && nok && mg < p.M) st8_dt(p.pool_max, p.pool_dtype, (int64_t)(mg >> 5) * p.N + n, pm);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pm.v[e] = -INFINITY;
             }
-            const int mg = mw + (pass >> 2) * 32;
-            if (rl == 0 && nok && mg < p.M) st8_dt(p.pool_max, p.pool_dtype, (int64_t)(mg >> 5) * p.N + n, pm);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) pm.v[e] = -INFINITY;
         }
     }
-    if (p.col_sum && mw < p.M) {
-        // (sum, M2 about the chunk mean) per 64-row chunk -- see ppt_bn_finalize
-        const int nrow = min(64, p.M - mw);
-        f8 csq;
+    if constexpr (WN == 64) {
+        if (p.col_sum && mw < p.M) {
+            // (sum, M2 about the chunk mean) per 64-row chunk -- see ppt_bn_finalize
+            const int nrow = min(64, p.M - mw);
+            f8 csq;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float t = csum.v[e];
-            t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
-            csum.v[e] = t; csq.v[e] = 0.f;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int pass = 0; pass < 8; ++pass) {
-            const int rr = pass * 8 + rl;
-            if (nok && rr < nrow) {
-                const f8 v = ld8_f32(ct + rr * 64 + cg * 8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { const float d = v.v[e] - csum.v[e] / (float)nrow; csq.v[e] = fmaf(d, d, csq.v[e]); }
+            for (int e = 0; e < 8; ++e) {
+                float t = csum.v[e];
+                t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+                csum.v[e] = t; csq.v[e] = 0.f;
             }
-        }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int pass = 0; pass < 8; ++pass) {
+                const int rr = pass * 8 + rl;
+                if (nok && rr < nrow) {
+                    const f8 v = ld8_f32(ct + rr * 64 + cg * 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float t = csq.v[e];
-            t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
-            csq.v[e] = t;
-        }
-        if (rl == 0 && nok) {
-            const int prow = (m0 >> 6) + wm;
-            st8_f32(p.col_sum + (int64_t)prow * p.N + n, csum);
-            st8_f32(p.col_sqsum + (int64_t)prow * p.N + n, csq);
+                    for (int e = 0; e < 8; ++e) { const float d = v.v[e] - csum.v[e] / (float)nrow; csq.v[e] = fmaf(d, d, csq.v[e]); }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = csq.v[e];
+                t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+                csq.v[e] = t;
+            }
+            if (rl == 0 && nok) {
+                const int prow = (m0 >> 6) + wm;
+                st8_f32(p.col_sum + (int64_t)prow * p.N + n, csum);
+                st8_f32(p.col_sqsum + (int64_t)prow * p.N + n, csq);
+            }
         }
     }
 }
@@ -425,17 +465,20 @@ __device__ __forceinline__ bool vec_epilogue_ok(const ppt_gemm_params &p, int64_
     return ok;
 }
 
-template <typename T, int A_MODE>
+template <typename T, int A_MODE, int BM, int BN>
 __global__ __launch_bounds__(NT, 2) void gemm_kernel(const ppt_gemm_params p)
 {
-    __shared__ __align__(16) unsigned char smem[4 * TILE_BYTES];   // A0 A1 B0 B1
+    constexpr int WM = BM / 2, WN = BN / 2, TI = WM / 32, TJ = WN / 32, NRA = BM / 32, NRB = BN / 32;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+    constexpr int STAGE_BYTES = 2 * (A_BYTES + B_BYTES), PARK_BYTES = 4 * WM * WN * 4;
+    __shared__ __align__(16) unsigned char smem[STAGE_BYTES > PARK_BYTES ? STAGE_BYTES : PARK_BYTES];   // A0 A1 B0 B1
     constexpr int BK = ROWB / sizeof(T);
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = w >> 1, wn = w & 1;
 #ifndef PPT_DBG_NO_XCD_SWIZZLE
     // consecutive tiles (same m-tile, n fastest) onto one XCD: blocks are dealt round-robin over the 8
-    // XCDs, each with a private L2, so without this remap the N/128 column tiles that share one A row
+    // XCDs, each with a private L2, so without this remap the column tiles that share one A row
     // panel land on 8 different L2s (measured +5..8 % on the block GEMMs; speed only, never correctness)
     const int nwg = gridDim.x * gridDim.y;
     const int lin0 = blockIdx.y * gridDim.x + blockIdx.x;
@@ -448,53 +491,81 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const ppt_gemm_params p)
     const T *A = reinterpret_cast<const T *>(p.A) + (int64_t)blockIdx.z * p.strideA;
     const T *B = reinterpret_cast<const T *>(p.B) + (int64_t)blockIdx.z * p.strideB;
 
-    f32x16_t acc[2][2];
+    f32x16_t acc[TI][TJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int nslab = (p.K + BK - 1) / BK;
-    Stage<T> sa, sb;
-    load_A<T, A_MODE>(sa, p, A, m0, 0);
-    load_plain<T>(sb, B, p.ldb, p.N, p.K, n0, 0);
-    write_stage<T>(sa, smem);
-    write_stage<T>(sb, smem + 2 * TILE_BYTES);
-    __syncthreads();
-    for (int s = 0; s < nslab; ++s) {
-        const int cur = s & 1;
-#ifndef PPT_DBG_SKIP_LOADS
-        if (s + 1 < nslab) {
-            load_A<T, A_MODE>(sa, p, A, m0, (s + 1) * BK);
-            load_plain<T>(sb, B, p.ldb, p.N, p.K, n0, (s + 1) * BK);
-        }
-#endif
-        mma_slab<T>(smem + cur * TILE_BYTES, smem + (2 + cur) * TILE_BYTES, wm, wn, lane, acc);
-        if (s + 1 < nslab) {
-            write_stage<T>(sa, smem + (cur ^ 1) * TILE_BYTES);
-            write_stage<T>(sb, smem + (2 + (cur ^ 1)) * TILE_BYTES);
-        }
-        __syncthreads();
+    Stage<NRA> a0, a1, a2;
+    Stage<NRB> b0, b1, b2;
+    unsigned char *const Abuf = smem, *const Bbuf = smem + 2 * A_BYTES;
+
+#define PPT_LOAD(SA, SB, S)                                                   \
+    do {                                                                      \
+        load_A<T, A_MODE, NRA>(SA, p, A, m0, (S) * BK);                       \
+        load_plain<T, NRB>(SB, B, p.ldb, p.N, p.K, n0, (S) * BK);             \
+    } while (0)
+#define PPT_WRITE(SA, SB, S, BUF)                                             \
+    do {                                                                      \
+        finish_A<T, A_MODE, NRA>(SA, p, m0, (S) * BK);                        \
+        mask_plain<T, NRB>(SB, p.N, p.K, n0, (S) * BK);                       \
+        write_stage<NRA>(SA, Abuf + ((BUF) & 1) * A_BYTES);                   \
+        write_stage<NRB>(SB, Bbuf + ((BUF) & 1) * B_BYTES);                   \
+    } while (0)
+    // STEP(s): multiply slab s; FREE set (held slab s) receives slab s+3; NEXT set (slab s+1) moves to LDS.
+    // Loads and LDS writes are UNCONDITIONAL (slab indices clamped to the last slab; the surplus write
+    // lands in the buffer nobody reads again): every path then has the same number of loads in flight
+    // at every wait, which is what lets the compiler emit counted vmcnt(16) instead of draining to 0.
+#define PPT_STEP(S, FA, FB, NA, NB)                                                                       \
+    {                                                                                                     \
+        PPT_LOAD(FA, FB, min((S) + 3, last));                                                             \
+        mma_slab<T, TI, TJ>(Abuf + ((S) & 1) * A_BYTES, Bbuf + ((S) & 1) * B_BYTES, wm * WM, wn * WN, lane, acc); \
+        PPT_WRITE(NA, NB, min((S) + 1, last), (S) + 1);                                                   \
+        __syncthreads();                                                                                  \
     }
 
+    const int last = nslab - 1;
+    PPT_LOAD(a0, b0, 0);
+    PPT_LOAD(a1, b1, min(1, last));
+    PPT_LOAD(a2, b2, min(2, last));
+    PPT_WRITE(a0, b0, 0, 0);
+    __syncthreads();
+#ifdef PPT_DBG_SKIP_LOADS
+#undef PPT_LOAD
+#define PPT_LOAD(SA, SB, S) do { } while (0)
+#endif
+    for (int s = 0;; s += 3) {
+        PPT_STEP(s, a0, b0, a1, b1)
+        if (s + 1 >= nslab) break;
+        PPT_STEP(s + 1, a1, b1, a2, b2)
+        if (s + 2 >= nslab) break;
+        PPT_STEP(s + 2, a2, b2, a0, b0)
+        if (s + 3 >= nslab) break;
+    }
+#undef PPT_STEP
+#undef PPT_WRITE
+#undef PPT_LOAD
+
     // ---------------- epilogue ----------------
-    // The operand tiles are dead (the loop ends on a barrier): every wave parks its 64x64 fp32
-    // accumulators in its own 16 KiB of LDS, row-major, and walks them row by row with lane == column.
-    // That turns the MFMA C layout (column on the lane, rows scattered over 16 registers) into
-    // full-row 128/256-byte global stores, makes the BatchNorm column sums and the 32-row max-pool
-    // plain per-lane running values, and keeps the flag-driven epilogue body out of the unroller.
-    float *ct = reinterpret_cast<float *>(smem) + w * (64 * 64);
+    // The operand tiles are dead (the loop ends on a barrier): every wave parks its fp32 accumulators in
+    // its own slice of LDS, row-major, and walks them in 16-byte pieces.  That turns the MFMA C layout
+    // (column on the lane, rows scattered over 16 registers) into full-row global stores, makes the
+    // BatchNorm column sums and the 32-row max-pool per-lane running values, and keeps the flag-driven
+    // epilogue body out of the unroller.
+    float *ct = reinterpret_cast<float *>(smem) + w * (WM * WN);
     {
         const int h = lane >> 5, cl = lane & 31;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < TJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    ct[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 64 + j * 32 + cl] = acc[i][j][r];
+                    ct[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * WN + j * 32 + cl] = acc[i][j][r];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -504,23 +575,36 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const ppt_gemm_params p)
 #ifdef PPT_DBG_SKIP_EPILOGUE
     if (ct[lane] != 12345.678f) return;
 #endif
-    if (vec_epilogue_ok(p, zc)) epilogue_vec8(p, ct, lane, m0, wm, n0, wn, zc);
-    else epilogue_scalar(p, ct, lane, m0, wm, n0, wn, zc);
+    if (vec_epilogue_ok(p, zc)) epilogue_vec8<WM, WN>(p, ct, lane, m0 + wm * WM, n0 + wn * WN, m0, wm, zc);
+    else epilogue_scalar<WM, WN>(p, ct, lane, m0 + wm * WM, n0 + wn * WN, m0, wm, zc);
 }
 
-template <typename T>
-int launch_gemm(const ppt_gemm_params &p, hipStream_t s)
+template <typename T, int BM, int BN>
+int launch_gemm_tile(const ppt_gemm_params &p, hipStream_t s)
 {
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.batch > 0 ? p.batch : 1);
     if (grid.y > 65535 || grid.z > 65535) return PPT_EUNSUPPORTED;
     switch (p.a_mode) {
-    case PPT_A_PLAIN: hipLaunchKernelGGL((gemm_kernel<T, PPT_A_PLAIN>), grid, dim3(NT), 0, s, p); break;
-    case PPT_A_AFFINE_RELU: hipLaunchKernelGGL((gemm_kernel<T, PPT_A_AFFINE_RELU>), grid, dim3(NT), 0, s, p); break;
-    case PPT_A_CONV1: hipLaunchKernelGGL((gemm_kernel<T, PPT_A_CONV1>), grid, dim3(NT), 0, s, p); break;
+    case PPT_A_PLAIN: hipLaunchKernelGGL((gemm_kernel<T, PPT_A_PLAIN, BM, BN>), grid, dim3(NT), 0, s, p); break;
+    case PPT_A_AFFINE_RELU: hipLaunchKernelGGL((gemm_kernel<T, PPT_A_AFFINE_RELU, BM, BN>), grid, dim3(NT), 0, s, p); break;
+    case PPT_A_CONV1: hipLaunchKernelGGL((gemm_kernel<T, PPT_A_CONV1, BM, BN>), grid, dim3(NT), 0, s, p); break;
     default: return PPT_EINVAL;
     }
     PPT_CHECK_LAUNCH();
     return PPT_OK;
+}
+
+// tile choice: 128x128 is the efficient tile (1 LDS fragment read per MFMA); a grid of fewer than
+// `small_below` such tiles cannot cover the 256 CUs twice, so the K loop would run latency-bound on a
+// mostly idle chip -- those problems (the text tower: M = classes x tokens) take 64x64 tiles instead.
+template <typename T>
+int launch_gemm(const ppt_gemm_params &p, hipStream_t s)
+{
+    static const int small_below = [] { const char *e = getenv("PPT_GEMM_SMALL_BELOW"); return e ? atoi(e) : 512; }();
+    const int64_t tiles128 = (int64_t)((p.N + 127) / 128) * ((p.M + 127) / 128) * (p.batch > 0 ? p.batch : 1);
+    const bool need128 = p.col_sum || p.pool_max;       // their partial layouts are defined on 64-row wave tiles
+    if (!need128 && tiles128 < small_below) return launch_gemm_tile<T, 64, 64>(p, s);
+    return launch_gemm_tile<T, 128, 128>(p, s);
 }
 
 }  // namespace

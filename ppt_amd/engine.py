@@ -237,7 +237,7 @@ def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=No
 
     eff_len: the attention is causal (ULIP_models.py:224-230) and only the EOT token is pooled
     (:222), so positions after the last EOT of any class can influence neither the output nor any
-    gradient; the tower is evaluated on the first eff_len = max(eot)+1 positions only (39 of 77 for
+    gradient; the tower is evaluated on the first eff_len = max(eot)+1 positions only (37 of 77 for
     the ModelNet40 prompts).  Outputs and gradients are identical to the full-length evaluation."""
     T = wc.dtype
     C, Lfull, Wd = prompts.shape
