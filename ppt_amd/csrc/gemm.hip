@@ -344,11 +344,52 @@ __device__ __forceinline__ void epilogue_vec8(const ppt_gemm_params &p, float *c
     const int cg = lane % CGS, rl = lane / CGS;
     const int n = nw + cg * 8;
     const bool nok = n < p.N;
+    const int nc = nok ? n : 0;                       // clamped column for the unconditional prefetches
     f8 bias, csum, pm;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { bias.v[e] = 0.f; csum.v[e] = 0.f; pm.v[e] = -INFINITY; }
     if (p.bias && nok) bias = ld8_f32(p.bias + n);
-#pragma unroll 1
+
+    // Phase A -- the ONE global operand of the epilogue (per-group term, residual or saved pre-activation)
+    // is fetched for ALL passes up front: a load issued inside the pass loop is consumed immediately,
+    // which exposes one full memory latency per pass (8 per tile; measured 2x on conv3 / proj / fc2).
+    // The accumulators are parked in LDS by now, so their 64 registers are free to hold the 8 x 32 bytes.
+    const int kind = p.group_add ? 1 : (p.residual ? 2 : (p.dact_pre ? 3 : 0));
+    uint4 pre[NPASS][2];
+    if (kind != 0) {
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int m = min(mw + pass * RP + rl, p.M - 1);
+            if (kind == 1) {
+                const float *q = p.group_add + (int64_t)(m / p.group_rows) * p.N + nc;
+                pre[pass][0] = *reinterpret_cast<const uint4 *>(q); pre[pass][1] = *reinterpret_cast<const uint4 *>(q + 4);
+            } else if (kind == 2) {
+                const float *q = p.residual + (int64_t)m * p.ld_res + nc;
+                pre[pass][0] = *reinterpret_cast<const uint4 *>(q); pre[pass][1] = *reinterpret_cast<const uint4 *>(q + 4);
+            } else if (p.dtype == PPT_BF16) {
+                pre[pass][0] = *reinterpret_cast<const uint4 *>((const bf16_t *)p.dact_pre + (int64_t)m * p.ld_dact + nc);
+                pre[pass][1] = make_uint4(0, 0, 0, 0);
+            } else {
+                const float *q = (const float *)p.dact_pre + (int64_t)m * p.ld_dact + nc;
+                pre[pass][0] = *reinterpret_cast<const uint4 *>(q); pre[pass][1] = *reinterpret_cast<const uint4 *>(q + 4);
+            }
+        }
+    }
+    auto pre_f8 = [&](int pass, bool packed_bf16) {
+        f8 r;
+        const uint4 a = pre[pass][0], b = pre[pass][1];
+        if (packed_bf16) {
+            const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { r.v[2 * e] = __uint_as_float(w[e] << 16); r.v[2 * e + 1] = __uint_as_float(w[e] & 0xFFFF0000u); }
+        } else {
+            r = f8{{__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w),
+                    __uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w)}};
+        }
+        return r;
+    };
+
+#pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
         const int rr = pass * RP + rl;
         const int m = mw + rr;
@@ -356,8 +397,8 @@ __device__ __forceinline__ void epilogue_vec8(const ppt_gemm_params &p, float *c
             f8 v = ld8_f32(ct + rr * WN + cg * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v.v[e] += bias.v[e];
-            if (p.group_add) {
-                const f8 g = ld8_f32(p.group_add + (int64_t)(m / p.group_rows) * p.N + n);
+            if (kind == 1) {
+                const f8 g = pre_f8(pass, false);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v.v[e] += g.v[e];
             }
@@ -368,7 +409,7 @@ __device__ __forceinline__ void epilogue_vec8(const ppt_gemm_params &p, float *c
             }
             if (p.C2 && p.c2_pre) st8_dt(p.C2, p.c2_dtype, (int64_t)m * p.ldc2 + n, v);
             if (p.dact_pre) {
-                const f8 x = ld8_dt(p.dact_pre, p.dtype, (int64_t)m * p.ld_dact + n);
+                const f8 x = kind == 3 ? pre_f8(pass, p.dtype == PPT_BF16) : ld8_dt(p.dact_pre, p.dtype, (int64_t)m * p.ld_dact + n);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v.v[e] *= act_bwd(x.v[e], p.act);
             } else if (p.act != PPT_ACT_NONE) {
@@ -381,7 +422,7 @@ __device__ __forceinline__ void epilogue_vec8(const ppt_gemm_params &p, float *c
                 for (int e = 0; e < 8; ++e) v.v[e] *= sc;
             }
             if (p.residual) {
-                const f8 r = ld8_f32(p.residual + (int64_t)m * p.ld_res + n);
+                const f8 r = kind == 2 ? pre_f8(pass, false) : ld8_f32(p.residual + (int64_t)m * p.ld_res + n);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v.v[e] += r.v[e];
             }
@@ -594,13 +635,16 @@ int launch_gemm_tile(const ppt_gemm_params &p, hipStream_t s)
     return PPT_OK;
 }
 
-// tile choice: 128x128 is the efficient tile (1 LDS fragment read per MFMA); a grid of fewer than
-// `small_below` such tiles cannot cover the 256 CUs twice, so the K loop would run latency-bound on a
-// mostly idle chip -- those problems (the text tower: M = classes x tokens) take 64x64 tiles instead.
+// tile choice (measured in one process on one MI355X, tools/gemm_shapes.py + bench.py with
+// PPT_GEMM_SMALL_BELOW = 0 / 512 / 1e9 -> 8.14 / 7.50 / 7.08 ms per C2 step): 128x128 tiles read one LDS
+// fragment per MFMA but keep only 2 workgroups (8 waves) on a CU; 64x64 tiles read two but run 4-5
+// workgroups per CU, and for these short-K problems (K = 128..2048, every tile pays a load prologue and a
+// store epilogue) the extra latency hiding wins up to several thousand tiles.  Only the half-gigabyte
+// mini-PointNet GEMMs stay on 128x128 (and those that emit 64-row BatchNorm partials / 32-row pools).
 template <typename T>
 int launch_gemm(const ppt_gemm_params &p, hipStream_t s)
 {
-    static const int small_below = [] { const char *e = getenv("PPT_GEMM_SMALL_BELOW"); return e ? atoi(e) : 512; }();
+    static const int small_below = [] { const char *e = getenv("PPT_GEMM_SMALL_BELOW"); return e ? atoi(e) : 4096; }();
     const int64_t tiles128 = (int64_t)((p.N + 127) / 128) * ((p.M + 127) / 128) * (p.batch > 0 ? p.batch : 1);
     const bool need128 = p.col_sum || p.pool_max;       // their partial layouts are defined on 64-row wave tiles
     if (!need128 && tiles128 < small_below) return launch_gemm_tile<T, 64, 64>(p, s);
