@@ -103,7 +103,7 @@ typedef struct ppt_gemm_params {
     /* side outputs */
     void *C2; int64_t ldc2; int c2_dtype;  /* optional second output in another dtype: the final value, or ... */
     int c2_pre;                      /* ... when != 0 the PRE-activation (after bias/group_add): saved for the backward */
-    float *col_sum;                  /* [ceil(M/64), N] per 64-row chunk: column sums of the pre-activation... */
+    float *col_sum;                  /* [ceil(M/32), N] per 32-row chunk: column sums of the pre-activation... */
     float *col_sqsum;                /* ... and M2 = sum (v - chunk mean)^2 (BatchNorm batch statistics), or NULL */
     void *pool_max;                  /* [M/32, N] pool_dtype: max over each 32-row group (mini-PointNet max-pool) */
     int pool_dtype;
@@ -155,7 +155,7 @@ int ppt_attention_bwd(const void *qkv, const void *out, const void *dout, const 
  * BatchNorm1d in train mode inside dvae.py:188-199.
  * conv1_stats: per-channel (sum, M2 about the chunk mean) of y = w1.p + b1 per chunk of
  *   ppt_conv1_stats_rows_per_partial() points (K=3 layer, VALU).  The GEMM's col_sum/col_sqsum use
- *   the same (sum, M2) form with 64-row chunks.
+ *   the same (sum, M2) form with 32-row chunks.
  * bn_finalize: chunk partials (merged with the parallel-variance formula in fp64) -> scale = g/sqrt(var+eps), shift = b - mean*scale; running-stat update
  * (momentum 0.1, unbiased variance) when running_mean != NULL.  train == 0: scale/shift from the
  * running statistics (eval mode), partials ignored. */

@@ -253,7 +253,7 @@ __device__ __forceinline__ void epilogue_scalar(const ppt_gemm_params &p, float 
     const int n = nw + cl;
     const bool nok = n < p.N;
     const float bias = (p.bias && nok) ? p.bias[n] : 0.0f;
-    float csum = 0.f, csq = 0.f, pmax = -INFINITY;
+    float pmax = -INFINITY;
 #pragma unroll 1
     for (int it = 0; it < WM / RP; ++it) {
         const int rr = it * RP + rsub;
@@ -261,7 +261,6 @@ __device__ __forceinline__ void epilogue_scalar(const ppt_gemm_params &p, float 
         if (nok && m < p.M) {
             float v = ct[rr * WN + cl] + bias;
             if (p.group_add) v += p.group_add[(int64_t)(m / p.group_rows) * p.N + n];
-            if (p.col_sum) { csum += v; ct[rr * WN + cl] = v; }
             if (p.C2 && p.c2_pre) store_dt(p.C2, p.c2_dtype, (int64_t)m * p.ldc2 + n, v);
             if (p.dact_pre) {
                 const float x = p.dtype == PPT_BF16 ? load_as_f32<bf16_t>(p.dact_pre, (int64_t)m * p.ld_dact + n)
@@ -282,19 +281,6 @@ __device__ __forceinline__ void epilogue_scalar(const ppt_gemm_params &p, float 
                 if (nok && m < p.M) store_dt(p.pool_max, p.pool_dtype, (int64_t)(m >> 5) * p.N + n, pmax);
                 pmax = -INFINITY;
             }
-        }
-    }
-    if constexpr (WN == 64) {
-        if (p.col_sum && nok && mw < p.M) {
-            const int nrow = min(64, p.M - mw);
-            const float cmean = csum / (float)nrow;
-            for (int rr = 0; rr < nrow; ++rr) {
-                const float d = ct[rr * 64 + lane] - cmean;
-                csq = fmaf(d, d, csq);
-            }
-            const int prow = (m0 >> 6) + wm;
-            p.col_sum[(int64_t)prow * p.N + n] = csum;
-            p.col_sqsum[(int64_t)prow * p.N + n] = csq;
         }
     }
 }
@@ -336,9 +322,11 @@ __device__ __forceinline__ void st8_dt(void *p, int dtype, int64_t i, const f8 &
         st8_f32((float *)p + i, x);
 }
 
-template <int WM, int WN>
-__device__ __forceinline__ void epilogue_vec8(const ppt_gemm_params &p, float *ct, int lane, int mw, int nw, int m0, int wm,
-                                              int64_t zc)
+// FEAT bit 0: a prefetched global operand (group_add / residual / dact_pre) may be present;
+// FEAT bit 1: column statistics / 32-row pooling may be requested.  Compile-time so that kernels that
+// never use them (the register-heavy row-panel kernel) do not pay their registers.
+template <int WM, int WN, int FEAT = 3>
+__device__ __forceinline__ void epilogue_vec8(const ppt_gemm_params &p, float *ct, int lane, int mw, int nw, int64_t zc)
 {
     constexpr int CGS = WN / 8, RP = 64 / CGS, NPASS = WM / RP;
     const int cg = lane % CGS, rl = lane / CGS;
@@ -354,7 +342,7 @@ __device__ __forceinline__ void epilogue_vec8(const ppt_gemm_params &p, float *c
     // is fetched for ALL passes up front: a load issued inside the pass loop is consumed immediately,
     // which exposes one full memory latency per pass (8 per tile; measured 2x on conv3 / proj / fc2).
     // The accumulators are parked in LDS by now, so their 64 registers are free to hold the 8 x 32 bytes.
-    const int kind = p.group_add ? 1 : (p.residual ? 2 : (p.dact_pre ? 3 : 0));
+    const int kind = (FEAT & 1) ? (p.group_add ? 1 : (p.residual ? 2 : (p.dact_pre ? 3 : 0))) : 0;
     uint4 pre[NPASS][2];
     if (kind != 0) {
 #pragma unroll
@@ -402,13 +390,13 @@ __device__ __forceinline__ void epilogue_vec8(const ppt_gemm_params &p, float *c
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v.v[e] += g.v[e];
             }
-            if (p.col_sum) {
+            if ((FEAT & 2) && p.col_sum) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) csum.v[e] += v.v[e];
                 st8_f32(ct + rr * WN + cg * 8, v);
             }
             if (p.C2 && p.c2_pre) st8_dt(p.C2, p.c2_dtype, (int64_t)m * p.ldc2 + n, v);
-            if (p.dact_pre) {
+            if ((FEAT & 1) && p.dact_pre) {
                 const f8 x = kind == 3 ? pre_f8(pass, p.dtype == PPT_BF16) : ld8_dt(p.dact_pre, p.dtype, (int64_t)m * p.ld_dact + n);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v.v[e] *= act_bwd(x.v[e], p.act);
@@ -421,68 +409,73 @@ __device__ __forceinline__ void epilogue_vec8(const ppt_gemm_params &p, float *c
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v.v[e] *= sc;
             }
-            if (p.residual) {
+            if ((FEAT & 1) && p.residual) {
                 const f8 r = kind == 2 ? pre_f8(pass, false) : ld8_f32(p.residual + (int64_t)m * p.ld_res + n);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v.v[e] += r.v[e];
             }
-            if (p.residual2) {
+            if ((FEAT & 1) && p.residual2) {
                 const f8 r = ld8_f32(p.residual2 + (int64_t)m * p.ld_res2 + n);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v.v[e] += r.v[e];
             }
             if (p.C) st8_dt(p.C, p.c_dtype, zc + (int64_t)m * p.ldc + n, v);
             if (p.C2 && !p.c2_pre) st8_dt(p.C2, p.c2_dtype, (int64_t)m * p.ldc2 + n, v);
+            if (FEAT & 2) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) pm.v[e] = fmaxf(pm.v[e], v.v[e]);
+                for (int e = 0; e < 8; ++e) pm.v[e] = fmaxf(pm.v[e], v.v[e]);
+            }
         }
-        if constexpr (WN == 64) {
-            if (p.pool_max && (pass & 3) == 3) {          // rows [32*(pass>>2), +32) complete
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float t = pm.v[e];
-                    t = fmaxf(t, __shfl_xor(t, 8, 64)); t = fmaxf(t, __shfl_xor(t, 16, 64)); t = fmaxf(t, __shfl_xor(t, 32, 64));
-                    pm.v[e] = t;
-                }
+        if constexpr (WN == 64 && (FEAT & 2) != 0) {
+            if ((pass & 3) == 3) {                        // rows [32*(pass>>2), +32) of the wave tile are complete
                 const int mg = mw + (pass >> 2) * 32;
-                if (rl == 0 && nok && mg < p.M) st8_dt(p.pool_max, p.pool_dtype, (int64_t)(mg >> 5) * p.N + n, pm);
+                if (p.pool_max) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pm.v[e] = -INFINITY;
-            }
-        }
-    }
-    if constexpr (WN == 64) {
-        if (p.col_sum && mw < p.M) {
-            // (sum, M2 about the chunk mean) per 64-row chunk -- see ppt_bn_finalize
-            const int nrow = min(64, p.M - mw);
-            f8 csq;
+                    for (int e = 0; e < 8; ++e) {
+                        float t = pm.v[e];
+                        t = fmaxf(t, __shfl_xor(t, 8, 64)); t = fmaxf(t, __shfl_xor(t, 16, 64)); t = fmaxf(t, __shfl_xor(t, 32, 64));
+                        pm.v[e] = t;
+                    }
+                    if (rl == 0 && nok && mg < p.M) st8_dt(p.pool_max, p.pool_dtype, (int64_t)(mg >> 5) * p.N + n, pm);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float t = csum.v[e];
-                t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
-                csum.v[e] = t; csq.v[e] = 0.f;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            for (int pass = 0; pass < 8; ++pass) {
-                const int rr = pass * 8 + rl;
-                if (nok && rr < nrow) {
-                    const f8 v = ld8_f32(ct + rr * 64 + cg * 8);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { const float d = v.v[e] - csum.v[e] / (float)nrow; csq.v[e] = fmaf(d, d, csq.v[e]); }
+                    for (int e = 0; e < 8; ++e) pm.v[e] = -INFINITY;
                 }
-            }
+                if (p.col_sum && mg < p.M) {
+                    // BatchNorm statistics of this 32-row chunk: (sum, M2 about the chunk mean) -- ppt_bn_finalize
+                    // merges the chunks with the parallel-variance formula in fp64 (no cancellation, no atomics)
+                    const int nrow = min(32, p.M - mg);
+                    f8 csq;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float t = csq.v[e];
-                t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
-                csq.v[e] = t;
-            }
-            if (rl == 0 && nok) {
-                const int prow = (m0 >> 6) + wm;
-                st8_f32(p.col_sum + (int64_t)prow * p.N + n, csum);
-                st8_f32(p.col_sqsum + (int64_t)prow * p.N + n, csq);
+                    for (int e = 0; e < 8; ++e) {
+                        float t = csum.v[e];
+                        t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+                        csum.v[e] = t / (float)nrow; csq.v[e] = 0.f;          // chunk mean
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int r2 = (pass - 3 + q) * 8 + rl;
+                        if (nok && (r2 & 31) < nrow) {
+                            const f8 v = ld8_f32(ct + r2 * 64 + cg * 8);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) { const float d = v.v[e] - csum.v[e]; csq.v[e] = fmaf(d, d, csq.v[e]); }
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float t = csq.v[e];
+                        t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+                        csq.v[e] = t; csum.v[e] *= (float)nrow;               // back to the chunk sum
+                    }
+                    if (rl == 0 && nok) {
+                        st8_f32(p.col_sum + (int64_t)(mg >> 5) * p.N + n, csum);
+                        st8_f32(p.col_sqsum + (int64_t)(mg >> 5) * p.N + n, csq);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) csum.v[e] = 0.f;
+                }
             }
         }
     }
@@ -545,6 +538,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const ppt_gemm_params p)
     Stage<NRB> b0, b1, b2;
     unsigned char *const Abuf = smem, *const Bbuf = smem + 2 * A_BYTES;
 
+#ifdef PPT_DBG_SKIP_LDS_WRITE
+#define PPT_DBG_WRITE(X) do { if (p.M < 0) { X; } } while (0)
+#else
+#define PPT_DBG_WRITE(X) X
+#endif
 #define PPT_LOAD(SA, SB, S)                                                   \
     do {                                                                      \
         load_A<T, A_MODE, NRA>(SA, p, A, m0, (S) * BK);                       \
@@ -554,8 +552,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const ppt_gemm_params p)
     do {                                                                      \
         finish_A<T, A_MODE, NRA>(SA, p, m0, (S) * BK);                        \
         mask_plain<T, NRB>(SB, p.N, p.K, n0, (S) * BK);                       \
-        write_stage<NRA>(SA, Abuf + ((BUF) & 1) * A_BYTES);                   \
-        write_stage<NRB>(SB, Bbuf + ((BUF) & 1) * B_BYTES);                   \
+        PPT_DBG_WRITE(write_stage<NRA>(SA, Abuf + ((BUF) & 1) * A_BYTES));    \
+        PPT_DBG_WRITE(write_stage<NRB>(SB, Bbuf + ((BUF) & 1) * B_BYTES));    \
     } while (0)
     // STEP(s): multiply slab s; FREE set (held slab s) receives slab s+3; NEXT set (slab s+1) moves to LDS.
     // Loads and LDS writes are UNCONDITIONAL (slab indices clamped to the last slab; the surplus write
@@ -616,7 +614,103 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const ppt_gemm_params p)
 #ifdef PPT_DBG_SKIP_EPILOGUE
     if (ct[lane] != 12345.678f) return;
 #endif
-    if (vec_epilogue_ok(p, zc)) epilogue_vec8<WM, WN>(p, ct, lane, m0 + wm * WM, n0 + wn * WN, m0, wm, zc);
+    if (vec_epilogue_ok(p, zc)) epilogue_vec8<WM, WN>(p, ct, lane, m0 + wm * WM, n0 + wn * WN, zc);
+    else epilogue_scalar<WM, WN>(p, ct, lane, m0 + wm * WM, n0 + wn * WN, m0, wm, zc);
+}
+
+// =================================================================================================
+// LDS-DMA variant for plain operands (no A prologue): global_load_lds_dwordx4 writes the slab straight
+// into LDS, so the ~13-cycle-per-instruction ds_write_b128 path that register staging needs -- measured
+// as 35-45 % of the K loop of the register-staged kernel (tools/gemm_tune.py, noloads_noepi vs
+// noloads_noepi_nowrite) -- disappears, and no VGPRs are spent on staging.  Three LDS stages; slab s+2 is
+// issued right behind the barrier that publishes slab s (its stage was last read two slabs ago); each
+// wave waits for its own copies with a COUNTED vmcnt (the youngest slab stays in flight) before a raw
+// s_barrier.  The LDS image is the same XOR-swizzled one: the DMA writes 64 lanes x 16 B linearly, so the
+// swizzle is applied to each lane's SOURCE chunk (same involution as the fragment reads).
+// Requires K % (128 / sizeof(T)) == 0; rows beyond M / N read a clamped (valid) row whose products are
+// never stored.
+// =================================================================================================
+template <typename T, int ROWS>
+__device__ __forceinline__ void glds_slab(const T *base, int64_t ld, int rows, int r0, int k0, unsigned char *tile, int w, int lane)
+{
+    constexpr int EPC = 16 / sizeof(T);
+    constexpr int PER_WAVE = ROWS / 32;                  // 1 KiB pieces (8 rows) per wave
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const int rg = (w * PER_WAVE + i) * 8;           // first tile row of this piece
+        const int r = rg + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);       // source chunk that belongs in LDS slot lane&7 of row r
+        const T *src = base + (int64_t)min(r0 + r, rows - 1) * ld + k0 + c * EPC;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(tile + rg * ROWB), 16, 0, 0);
+    }
+}
+
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(NT) void gemm_kernel_glds(const ppt_gemm_params p)
+{
+    constexpr int WM = BM / 2, WN = BN / 2, TI = WM / 32, TJ = WN / 32;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES, NSTAGE = 3;
+    constexpr int LOADS_PER_SLAB = BM / 32 + BN / 32;    // LDS-DMA instructions per wave per slab
+    constexpr int PARK_BYTES = 4 * WM * WN * 4;
+    __shared__ __align__(16) unsigned char smem[NSTAGE * STAGE > PARK_BYTES ? NSTAGE * STAGE : PARK_BYTES];
+    constexpr int BK = ROWB / sizeof(T);
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    const int nwg = gridDim.x * gridDim.y;
+    const int lin0 = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q8 = nwg / 8, r8 = nwg % 8, xcd = lin0 % 8;
+    const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + lin0 / 8;
+    const int n0 = (lin % gridDim.x) * BN, m0 = (lin / gridDim.x) * BM;
+    const T *A = reinterpret_cast<const T *>(p.A) + (int64_t)blockIdx.z * p.strideA;
+    const T *B = reinterpret_cast<const T *>(p.B) + (int64_t)blockIdx.z * p.strideB;
+
+    f32x16_t acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nslab = p.K / BK, last = nslab - 1;
+    auto issue = [&](int slab, int stage) {
+        glds_slab<T, BM>(A, p.lda, p.M, m0, slab * BK, smem + stage * STAGE, w, lane);
+        glds_slab<T, BN>(B, p.ldb, p.N, n0, slab * BK, smem + stage * STAGE + A_BYTES, w, lane);
+    };
+    issue(0, 0);
+    issue(min(1, last), 1);
+    int stage = 0;
+    for (int s = 0; s < nslab; ++s) {
+        // own copies of slab s have landed (the LOADS_PER_SLAB youngest, slab s+1, may still fly) ...
+        if constexpr (LOADS_PER_SLAB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                     // ... and so have everybody else's: slab s is readable
+        int nstage = stage + 2; if (nstage >= NSTAGE) nstage -= NSTAGE;
+        issue(min(s + 2, last), nstage);                  // stage (s+2)%3 was last read at slab s-1, before this barrier
+        mma_slab<T, TI, TJ>(smem + stage * STAGE, smem + stage * STAGE + A_BYTES, wm * WM, wn * WN, lane, acc);
+        stage = stage + 1 == NSTAGE ? 0 : stage + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // surplus prefetches must not land on the parked accumulators
+    __builtin_amdgcn_s_barrier();
+
+    float *ct = reinterpret_cast<float *>(smem) + w * (WM * WN);
+    {
+        const int h = lane >> 5, cl = lane & 31;
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ct[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * WN + j * 32 + cl] = acc[i][j][r];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int64_t zc = (int64_t)blockIdx.z * p.strideC;
+    if (vec_epilogue_ok(p, zc)) epilogue_vec8<WM, WN>(p, ct, lane, m0 + wm * WM, n0 + wn * WN, zc);
     else epilogue_scalar<WM, WN>(p, ct, lane, m0 + wm * WM, n0 + wn * WN, m0, wm, zc);
 }
 
@@ -625,6 +719,14 @@ int launch_gemm_tile(const ppt_gemm_params &p, hipStream_t s)
 {
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.batch > 0 ? p.batch : 1);
     if (grid.y > 65535 || grid.z > 65535) return PPT_EUNSUPPORTED;
+    static const int use_glds = [] { const char *e = getenv("PPT_GEMM_GLDS"); return e ? atoi(e) : 1; }();
+    constexpr int BKE = ROWB / sizeof(T);
+    // (three 32 KiB stages of the 128x128 tile leave one workgroup per CU: measured slower than register staging)
+    if (use_glds && BM == 64 && p.a_mode == PPT_A_PLAIN && p.K % BKE == 0) {
+        hipLaunchKernelGGL((gemm_kernel_glds<T, BM, BN>), grid, dim3(NT), 0, s, p);
+        PPT_CHECK_LAUNCH();
+        return PPT_OK;
+    }
     switch (p.a_mode) {
     case PPT_A_PLAIN: hipLaunchKernelGGL((gemm_kernel<T, PPT_A_PLAIN, BM, BN>), grid, dim3(NT), 0, s, p); break;
     case PPT_A_AFFINE_RELU: hipLaunchKernelGGL((gemm_kernel<T, PPT_A_AFFINE_RELU, BM, BN>), grid, dim3(NT), 0, s, p); break;
@@ -646,7 +748,7 @@ int launch_gemm(const ppt_gemm_params &p, hipStream_t s)
 {
     static const int small_below = [] { const char *e = getenv("PPT_GEMM_SMALL_BELOW"); return e ? atoi(e) : 4096; }();
     const int64_t tiles128 = (int64_t)((p.N + 127) / 128) * ((p.M + 127) / 128) * (p.batch > 0 ? p.batch : 1);
-    const bool need128 = p.col_sum || p.pool_max;       // their partial layouts are defined on 64-row wave tiles
+    const bool need128 = p.col_sum || p.pool_max;       // 32-row chunk partials / pools need 64-wide wave tiles
     if (!need128 && tiles128 < small_below) return launch_gemm_tile<T, 64, 64>(p, s);
     return launch_gemm_tile<T, 128, 128>(p, s);
 }
@@ -668,6 +770,8 @@ extern "C" int ppt_gemm(const ppt_gemm_params *pp, void *stream)
         if (p.a_mode == PPT_A_AFFINE_RELU && (!p.a_scale || !p.a_shift)) return PPT_EINVAL;
     }
     if ((p.col_sum == nullptr) != (p.col_sqsum == nullptr)) return PPT_EINVAL;
+    if ((p.col_sum || p.pool_max) && ((p.N % 8) || ((uintptr_t)p.col_sum & 15) || ((uintptr_t)p.col_sqsum & 15) || ((uintptr_t)p.pool_max & 15)))
+        return PPT_EUNSUPPORTED;                       // statistics / pooling exist only in the 16-byte epilogue
     if (p.group_add && p.group_rows <= 0) return PPT_EINVAL;
     if (p.row_scale && p.row_scale_rows <= 0) return PPT_EINVAL;
     if (p.batch > 1 && (p.C2 || p.col_sum || p.pool_max || p.residual || p.residual2 || p.dact_pre || p.group_add))

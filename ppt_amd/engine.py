@@ -96,11 +96,11 @@ def mini_pointnet(sd, p, wc, nbhd, bn_train, update_running=True):
                      algo_k=0)      # its FLOPs are accounted to the 512-wide conv3 (algo_k=512 below)
     g2, be2, rm2, rv2, nb2 = _bn_params(sd, p + "second_conv.1.")
     if bn_train:
-        cs = torch.empty((M // 64, 512), dtype=torch.float32, device=dev)
+        cs = torch.empty((M // 32, 512), dtype=torch.float32, device=dev)
         cq = torch.empty_like(cs)
         y3 = ops.gemm(y2, wc.get(w3, cols=(256, 512)), out_dtype=T, group_add=gterm, group_rows=32, col_stats=(cs, cq),
                       algo_k=512)
-        sc2, sh2 = ops.bn_finalize(g2, be2, True, partials=(cs, cq), rows_per_partial=64, count=M,
+        sc2, sh2 = ops.bn_finalize(g2, be2, True, partials=(cs, cq), rows_per_partial=32, count=M,
                                    running_mean=rm2, running_var=rv2, num_batches_tracked=nb2,
                                    update_running=update_running)
     else:

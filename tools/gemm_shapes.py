@@ -47,7 +47,7 @@ def main():
     ms = bench(lambda: ops.gemm(y3, W4, a_mode=ops.A_AFFINE_RELU, a_scale=sc2, a_shift=sh2, pool_max=tok, want_out=False))
     print(f"{'conv4 (AFFINE A)':16s} M={Mm:7d} N={256:5d} K={512:5d}  {ms*1e3:9.1f} us  {2*Mm*256*512/ms/1e9:8.1f} TF")
     W3 = torch.randn(512, 256, device=dev).bfloat16(); gt = torch.randn(Mm // 32, 512, device=dev)
-    cs = torch.empty(Mm // 64, 512, device=dev); cq = torch.empty_like(cs); o3 = torch.empty(Mm, 512, device=dev, dtype=torch.bfloat16)
+    cs = torch.empty(Mm // 32, 512, device=dev); cq = torch.empty_like(cs); o3 = torch.empty(Mm, 512, device=dev, dtype=torch.bfloat16)
     ms = bench(lambda: ops.gemm(y2, W3, out=o3, group_add=gt, group_rows=32, col_stats=(cs, cq)))
     print(f"{'conv3 +stats':16s} M={Mm:7d} N={512:5d} K={256:5d}  {ms*1e3:9.1f} us  {2*Mm*512*256/ms/1e9:8.1f} TF")
 

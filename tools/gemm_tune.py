@@ -7,7 +7,9 @@ import torch
 from ppt_amd import _lib, ops
 
 VARIANTS = {"base": [], "noloads": ["-DPPT_DBG_SKIP_LOADS"], "noepi": ["-DPPT_DBG_SKIP_EPILOGUE"],
-            "noloads_noepi": ["-DPPT_DBG_SKIP_LOADS", "-DPPT_DBG_SKIP_EPILOGUE"], "xcd": ["-DPPT_DBG_XCD_SWIZZLE"]}
+            "noloads_noepi": ["-DPPT_DBG_SKIP_LOADS", "-DPPT_DBG_SKIP_EPILOGUE"],
+            "noloads_noepi_nowrite": ["-DPPT_DBG_SKIP_LOADS", "-DPPT_DBG_SKIP_EPILOGUE", "-DPPT_DBG_SKIP_LDS_WRITE"],
+            "noxcd": ["-DPPT_DBG_NO_XCD_SWIZZLE"]}
 if len(sys.argv) > 1:
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in sys.argv[1:]}
 libs = {}
@@ -15,7 +17,7 @@ os.makedirs("/tmp/gt", exist_ok=True)
 procs = []
 for name, flags in VARIANTS.items():
     out = f"/tmp/gt/lib_{name}.so"
-    cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-shared", "-o", out,
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-shared", "-I" + os.path.join(ROOT, "ppt_amd/csrc"), "-o", out,
            os.path.join(ROOT, "ppt_amd/csrc/gemm.hip")] + flags
     procs.append((name, out, subprocess.Popen(cmd, stderr=subprocess.DEVNULL)))
 for name, out, pr in procs:
