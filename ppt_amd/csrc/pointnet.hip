@@ -39,8 +39,9 @@ __global__ __launch_bounds__(256) void conv1_stats_kernel(const float *__restric
 }
 
 // (count, mean, M2) triples merge associatively (Chan et al.): every thread folds a stripe of the chunk
-// partials in fp64, then the 32 stripes of a channel are folded through LDS.  32 channels per block
-// (coalesced 128-byte rows of the [P, C] partial buffers), 32 stripes -> 1024 threads.
+// partials in fp64, then the 128 stripes of a channel are folded through LDS.  8 channels per block
+// (32-byte pieces of the [P, C] partial rows; C/8 = 64 workgroups for the 512-channel layer, whose
+// P = M/32 = 16 384 partial rows would otherwise be walked by 16 workgroups only), 128 stripes.
 struct stat3 { double n, mean, m2; };
 __device__ __forceinline__ void stat_merge(stat3 &a, const stat3 &b)
 {
@@ -59,20 +60,21 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restri
                                                           float *__restrict__ rvar, int64_t *__restrict__ nbt,
                                                           float *__restrict__ scale, float *__restrict__ shift)
 {
-    __shared__ stat3 red[32][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + tx;
+    constexpr int CH = 8, ST = 128;
+    __shared__ stat3 red[ST][CH + 1];
+    const int tx = threadIdx.x & (CH - 1), ty = threadIdx.x / CH;
+    const int c = blockIdx.x * CH + tx;
     float mean_f = 0.f, var_f = 1.f;
     if (train) {
         stat3 acc{0.0, 0.0, 0.0};
         if (c < C)
-            for (int p = ty; p < P; p += 32) {
+            for (int p = ty; p < P; p += ST) {
                 const double n = fmin((double)rpp, count - (double)p * rpp);
                 if (n > 0.0) stat_merge(acc, stat3{n, (double)psum[(size_t)p * C + c] / n, (double)psq[(size_t)p * C + c]});
             }
         red[ty][tx] = acc;
         __syncthreads();
-        for (int off = 16; off > 0; off >>= 1) {
+        for (int off = ST / 2; off > 0; off >>= 1) {
             if (ty < off) { stat3 a = red[ty][tx]; stat_merge(a, red[ty + off][tx]); red[ty][tx] = a; }
             __syncthreads();
         }
@@ -136,7 +138,7 @@ extern "C" int ppt_bn_finalize(const float *part_sum, const float *part_sqsum, i
                   (int64_t)n_partials * rows_per_partial < count))
         return PPT_EINVAL;
     if (!train && (!running_mean || !running_var)) return PPT_EINVAL;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, ppt_stream(stream), part_sum, part_sqsum,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(1024), 0, ppt_stream(stream), part_sum, part_sqsum,
                        n_partials, (double)count, rows_per_partial, C, gamma, beta, eps, train, momentum, running_mean, running_var,
                        num_batches_tracked, scale, shift);
     PPT_CHECK_LAUNCH();

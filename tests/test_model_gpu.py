@@ -106,6 +106,32 @@ def test_eval_forward_matches_golden(precision, tol):
     assert (logits.argmax(1).cpu().numpy() == g["logits"].argmax(1)).all()
 
 
+def test_c3_shape_head3_2048pts_15classes_parity():
+    """BASELINE config C3 in miniature: ScanObjectNN class list (15 classes), 2048-point clouds with duplicate
+    points (resampled with replacement), head_type=3, parity mode vs the oracle."""
+    from ppt_amd.train import Trainer
+    m, sd = build(3, torch.float32, "scanobjectnn")
+    emb = W.synth_prompt_embedding(15, seed=0)
+    m.prompt_learner.embedding = emb.clone().cuda()
+    pc_np, start = W.synth_clouds(2, 2048, seed=5, duplicates=True)
+    labels = torch.tensor([3, 14])
+    m.train()
+    m.point_encoder.fps_start = torch.from_numpy(start).cuda()
+    rng = np.random.default_rng(0)
+    dpf = torch.from_numpy((np.floor(0.9 + rng.random((12, 2, 2))) / 0.9).astype(np.float32))
+    m.point_encoder.drop_path_factors = dpf.cuda()
+    tr = Trainer(m, distributed=False)
+    loss, pred = tr.step(torch.from_numpy(pc_np).cuda(), labels.cuda())
+    eot = m.tokenized_prompts.argmax(-1).numpy()
+    res = O.train_step(sd, torch.from_numpy(pc_np), labels, start, emb, m.prompt_learner.name_lengths, eot, head_type=3,
+                       dp_masks=[(dpf[l, 0], dpf[l, 1]) for l in range(12)])
+    assert (pred.detach().cpu() - res["logits"]).abs().max().item() < 2e-3
+    live = dict(m.named_parameters())
+    for k, go in res["grads"].items():
+        rel = ((live[k].grad.cpu() - go).norm() / go.norm()).item()
+        assert rel < 1e-3, (k, rel)
+
+
 def test_text_truncation_is_exact():
     """evaluating the causal text tower only up to the last EOT position changes nothing (fp32 mode: bit-level
     differences can only come from nothing at all -- every surviving row sees identical operands)."""
