@@ -63,7 +63,8 @@ int ppt_knn_group_f32(const float *xyz, const float *center, int B, int N, int G
  * Replaces models/pointnet2/pointnet2_utils.py:87-107 query_ball_point: first K indices in
  * ascending order with d <= r^2 (expanded-form distance), padded with the first hit. */
 int ppt_ball_query_f32(const float *xyz, const float *center, int B, int N, int S, float radius_sq,
-                       int K, int64_t *idx, void *stream);
+                       int K, int64_t *idx, float *grouped_xyz /* [B,S,K,3] = xyz[idx] - center, or NULL */,
+                       void *stream);
 
 /* ---- GEMM with fused prologue / epilogue ----------------------------------------------------
  * C[M,N] = epilogue( prologue(A)[M,K] . B[N,K]^T ).  A and B are K-contiguous (torch Linear /
@@ -105,8 +106,10 @@ typedef struct ppt_gemm_params {
     int c2_pre;                      /* ... when != 0 the PRE-activation (after bias/group_add): saved for the backward */
     float *col_sum;                  /* [ceil(M/32), N] per 32-row chunk: column sums of the pre-activation... */
     float *col_sqsum;                /* ... and M2 = sum (v - chunk mean)^2 (BatchNorm batch statistics), or NULL */
-    void *pool_max;                  /* [M/32, N] pool_dtype: max over each 32-row group (mini-PointNet max-pool) */
+    void *pool_max;                  /* [M/pool_rows, N] pool_dtype: max over each group of pool_rows consecutive rows */
     int pool_dtype;
+    int pool_rows;                   /* 16, 32 or 64 (0 = 32): one kNN / ball-query group per pool_rows rows */
+    void *pool_min;                  /* optional [M/pool_rows, N] minimum (BatchNorm with a negative scale flips the max) */
     /* batching (blockIdx.z): pointer offsets in ELEMENTS per batch */
     int batch; int64_t strideA, strideB, strideC;
 } ppt_gemm_params;
@@ -175,6 +178,20 @@ int ppt_linear3_gelu(const float *pts, int64_t M, const float *w, const float *b
 /* point_encoder.py:251: out[b] = cat(x[b,0,:], max_t x[b,1:,:]) -> [B, 2D]; argmax [B,D] i32 for bwd. */
 int ppt_cls_max_pool(const void *x, int x_dtype, int B, int T, int D, float *out, int32_t *argmax,
                      void *stream);
+/* ---- PointNet2 set-abstraction helpers (models/pointnet2/pointnet2_utils.py:228-266) ------------------------
+ * A 1x1 convolution over gathered neighbours is linear, so the first layer of a grouped MLP is evaluated per
+ * SOURCE point (P = W.[feat|xyz], a small GEMM) and per centre (Q = b - W_xyz.centre) and then gathered:
+ *   y[b,s,k,:] = P[b, idx[b,s,k], :] + Q[b,s,:]      (ppt_gather_add; also emits the 32-row (sum, M2) BN partials)
+ * instead of gathering 323-wide inputs and multiplying K times more rows.
+ * pool_finish: out[g, c] = relu(scale[c] * (scale[c] >= 0 ? max : min)[g, c] + shift[c]) folded over `fold`
+ *   consecutive pooled rows, written with leading dimension ld_out (concatenation of the MSG branches).
+ * bn_act_rows: y = relu(x*scale + shift) * mask (mask may be NULL): the BatchNorm1d+ReLU+Dropout of the FC head. */
+int ppt_gather_add(const void *P, int p_dtype, const float *Q, const int64_t *idx, int B, int Nsrc, int S, int K,
+                   int C, void *y, int y_dtype, float *part_sum, float *part_m2, void *stream);
+int ppt_pool_finish(const void *pmax, const void *pmin, int p_dtype, int G, int fold, int C, const float *scale,
+                    const float *shift, void *out, int out_dtype, int64_t ld_out, void *stream);
+int ppt_bn_act_rows(const float *x, int M, int C, const float *scale, const float *shift, const float *mask,
+                    void *y, int y_dtype, void *stream);
 /* dtype conversion / transposition helpers (weights are converted once, activations never). */
 int ppt_convert(const void *src, int src_dtype, void *dst, int dst_dtype, int64_t n, void *stream);
 /* src [rows, cols] contiguous -> dst [cols, rows] with row stride ld_dst >= rows (padding untouched) */

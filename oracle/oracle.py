@@ -240,6 +240,68 @@ def point_transformer(sd, pc, fps_start, train=False, dp_masks=None, prefix="poi
 
 
 # ------------------------------------------------------------------------------------------------
+# PointNet2-MSG encoder (models/pointnet2/pointnet2.py:40-73, pointnet2_utils.py:161-266)
+# ------------------------------------------------------------------------------------------------
+PN2_MSG = dict(
+    sa1=dict(npoint=512, radii=[0.1, 0.2, 0.4], nsample=[16, 32, 128]),
+    sa2=dict(npoint=128, radii=[0.2, 0.4, 0.8], nsample=[32, 64, 128]))
+
+
+def _conv_bn_relu_stack(sd, x, conv_fmt, bn_fmt, n_layers, train, new_stats):
+    """x [rows, C]: 1x1 Conv2d == per-row linear; BatchNorm2d over (B, K, S) == over all rows."""
+    for j in range(n_layers):
+        w = sd[conv_fmt.format(j) + "weight"]
+        x = linear(x, w.reshape(w.shape[0], -1), sd[conv_fmt.format(j) + "bias"])
+        x = torch.relu(batch_norm_rows(x, sd, bn_fmt.format(j), train, new_stats=new_stats))
+    return x
+
+
+def _sa_msg(sd, p, cfg, xyz, feats, start, train, new_stats):
+    """PointNetSetAbstractionMsg.forward (pointnet2_utils.py:228-266).  xyz [B,N,3] numpy, feats [B,N,D] tensor|None
+    -> new_xyz [B,S,3] numpy, new_feats [B,S,sum C] tensor."""
+    B, N, _ = xyz.shape
+    S = cfg["npoint"]
+    cidx = fps(xyz, S, start)
+    new_xyz = np.take_along_axis(xyz, cidx[:, :, None], axis=1)
+    outs = []
+    for i, (r, K) in enumerate(zip(cfg["radii"], cfg["nsample"])):
+        gidx = ball_query(xyz, new_xyz, r, K)                                    # [B,S,K]
+        g = torch.from_numpy(np.take_along_axis(xyz[:, None], gidx[..., None], axis=2) if False else
+                             xyz[np.arange(B)[:, None, None], gidx])             # [B,S,K,3]
+        g = g - torch.from_numpy(new_xyz)[:, :, None, :]
+        if feats is not None:
+            gf = feats[torch.arange(B)[:, None, None], torch.from_numpy(gidx)]   # [B,S,K,D]
+            g = torch.cat([gf, g], dim=-1)                                       # features first (:250)
+        n_layers = sum(1 for k in sd if k.startswith(f"{p}conv_blocks.{i}.") and k.endswith("weight"))
+        y = _conv_bn_relu_stack(sd, g.reshape(B * S * K, -1), p + f"conv_blocks.{i}." + "{}.", p + f"bn_blocks.{i}." + "{}.",
+                                n_layers, train, new_stats)
+        outs.append(y.reshape(B, S, K, -1).max(dim=2)[0])
+    return new_xyz, torch.cat(outs, dim=-1)
+
+
+def pointnet2_msg(sd, pc, fps_starts, train=False, drop_masks=None, prefix="point_encoder.", new_stats=None):
+    """Pointnet2_Msg.forward (pointnet2.py:56-73) -> [B,256].  fps_starts = (start level 1 [B], start level 2 [B]);
+    drop_masks = (mask1 [B,512], mask2 [B,256]) multiplicative Dropout factors (0 or 1/(1-p)) or None."""
+    xyz = pc.detach().numpy()
+    B = xyz.shape[0]
+    l1_xyz, l1 = _sa_msg(sd, prefix + "sa1.", PN2_MSG["sa1"], xyz, None, np.asarray(fps_starts[0]), train, new_stats)
+    l2_xyz, l2 = _sa_msg(sd, prefix + "sa2.", PN2_MSG["sa2"], l1_xyz, l1, np.asarray(fps_starts[1]), train, new_stats)
+    g = torch.cat([torch.from_numpy(l2_xyz), l2], dim=-1)                         # group_all: xyz first (:152-157)
+    y = _conv_bn_relu_stack(sd, g.reshape(B * 128, -1), prefix + "sa3.mlp_convs.{}.", prefix + "sa3.mlp_bns.{}.", 3, train,
+                            new_stats)
+    x = y.reshape(B, 128, -1).max(dim=1)[0]                                       # [B,1024]
+    x = torch.relu(batch_norm_rows(linear(x, sd[prefix + "fc1.weight"], sd[prefix + "fc1.bias"]), sd, prefix + "bn1.", train,
+                                   new_stats=new_stats))
+    if drop_masks is not None:
+        x = x * drop_masks[0]
+    x = torch.relu(batch_norm_rows(linear(x, sd[prefix + "fc2.weight"], sd[prefix + "fc2.bias"]), sd, prefix + "bn2.", train,
+                                   new_stats=new_stats))
+    if drop_masks is not None:
+        x = x * drop_masks[1]
+    return x
+
+
+# ------------------------------------------------------------------------------------------------
 # text branch
 # ------------------------------------------------------------------------------------------------
 def splice_prompts(embedding, learnable_tokens, name_lengths, position="middle"):

@@ -28,7 +28,7 @@ class GemmParams(ctypes.Structure):
         ("row_scale", c_void_p), ("row_scale_rows", c_int),
         ("residual", c_void_p), ("ld_res", c_int64), ("residual2", c_void_p), ("ld_res2", c_int64),
         ("C2", c_void_p), ("ldc2", c_int64), ("c2_dtype", c_int), ("c2_pre", c_int),
-        ("col_sum", c_void_p), ("col_sqsum", c_void_p), ("pool_max", c_void_p), ("pool_dtype", c_int),
+        ("col_sum", c_void_p), ("col_sqsum", c_void_p), ("pool_max", c_void_p), ("pool_dtype", c_int), ("pool_rows", c_int), ("pool_min", c_void_p),
         ("batch", c_int), ("strideA", c_int64), ("strideB", c_int64), ("strideC", c_int64),
     ]
 
@@ -37,7 +37,12 @@ _SIGNATURES = {
     "ppt_abi_version": (c_int, []),
     "ppt_fps_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ppt_knn_group_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    "ppt_ball_query_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
+    "ppt_ball_query_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p]),
+    "ppt_gather_add": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                               c_void_p, c_void_p, c_void_p]),
+    "ppt_pool_finish": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64,
+                                c_void_p]),
+    "ppt_bn_act_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ppt_gemm": (c_int, [ctypes.POINTER(GemmParams), c_void_p]),
     "ppt_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                   c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),

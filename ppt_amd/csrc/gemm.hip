@@ -253,7 +253,6 @@ __device__ __forceinline__ void epilogue_scalar(const ppt_gemm_params &p, float 
     const int n = nw + cl;
     const bool nok = n < p.N;
     const float bias = (p.bias && nok) ? p.bias[n] : 0.0f;
-    float pmax = -INFINITY;
 #pragma unroll 1
     for (int it = 0; it < WM / RP; ++it) {
         const int rr = it * RP + rsub;
@@ -274,13 +273,6 @@ __device__ __forceinline__ void epilogue_scalar(const ppt_gemm_params &p, float 
             if (p.residual2) v += p.residual2[(int64_t)m * p.ld_res2 + n];
             if (p.C) store_dt(p.C, p.c_dtype, zc + (int64_t)m * p.ldc + n, v);
             if (p.C2 && !p.c2_pre) store_dt(p.C2, p.c2_dtype, (int64_t)m * p.ldc2 + n, v);
-            pmax = fmaxf(pmax, v);
-        }
-        if constexpr (WN == 64) {
-            if (p.pool_max && (rr & 31) == 31) {
-                if (nok && m < p.M) store_dt(p.pool_max, p.pool_dtype, (int64_t)(m >> 5) * p.N + n, pmax);
-                pmax = -INFINITY;
-            }
         }
     }
 }
@@ -333,9 +325,9 @@ __device__ __forceinline__ void epilogue_vec8(const ppt_gemm_params &p, float *c
     const int n = nw + cg * 8;
     const bool nok = n < p.N;
     const int nc = nok ? n : 0;                       // clamped column for the unconditional prefetches
-    f8 bias, csum, pm;
+    f8 bias, csum, pm, pn;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { bias.v[e] = 0.f; csum.v[e] = 0.f; pm.v[e] = -INFINITY; }
+    for (int e = 0; e < 8; ++e) { bias.v[e] = 0.f; csum.v[e] = 0.f; pm.v[e] = -INFINITY; pn.v[e] = INFINITY; }
     if (p.bias && nok) bias = ld8_f32(p.bias + n);
 
     // Phase A -- the ONE global operand of the epilogue (per-group term, residual or saved pre-activation)
@@ -423,23 +415,32 @@ __device__ __forceinline__ void epilogue_vec8(const ppt_gemm_params &p, float *c
             if (p.C2 && !p.c2_pre) st8_dt(p.C2, p.c2_dtype, (int64_t)m * p.ldc2 + n, v);
             if (FEAT & 2) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pm.v[e] = fmaxf(pm.v[e], v.v[e]);
+                for (int e = 0; e < 8; ++e) { pm.v[e] = fmaxf(pm.v[e], v.v[e]); pn.v[e] = fminf(pn.v[e], v.v[e]); }
             }
         }
         if constexpr (WN == 64 && (FEAT & 2) != 0) {
-            if ((pass & 3) == 3) {                        // rows [32*(pass>>2), +32) of the wave tile are complete
-                const int mg = mw + (pass >> 2) * 32;
-                if (p.pool_max) {
+            if (p.pool_max) {                             // groups of pool_rows (16 / 32 / 64) consecutive rows
+                const int ppg = (p.pool_rows > 0 ? p.pool_rows : 32) / 8;     // passes per group
+                if (((pass + 1) % ppg) == 0) {
+                    const int mg = mw + (pass + 1 - ppg) * 8;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        float t = pm.v[e];
+                        float t = pm.v[e], u = pn.v[e];
                         t = fmaxf(t, __shfl_xor(t, 8, 64)); t = fmaxf(t, __shfl_xor(t, 16, 64)); t = fmaxf(t, __shfl_xor(t, 32, 64));
-                        pm.v[e] = t;
+                        u = fminf(u, __shfl_xor(u, 8, 64)); u = fminf(u, __shfl_xor(u, 16, 64)); u = fminf(u, __shfl_xor(u, 32, 64));
+                        pm.v[e] = t; pn.v[e] = u;
                     }
-                    if (rl == 0 && nok && mg < p.M) st8_dt(p.pool_max, p.pool_dtype, (int64_t)(mg >> 5) * p.N + n, pm);
+                    if (rl == 0 && nok && mg < p.M) {
+                        const int64_t o = (int64_t)(mg / (ppg * 8)) * p.N + n;
+                        st8_dt(p.pool_max, p.pool_dtype, o, pm);
+                        if (p.pool_min) st8_dt(p.pool_min, p.pool_dtype, o, pn);
+                    }
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) pm.v[e] = -INFINITY;
+                    for (int e = 0; e < 8; ++e) { pm.v[e] = -INFINITY; pn.v[e] = INFINITY; }
                 }
+            }
+            if ((pass & 3) == 3) {                        // rows [32*(pass>>2), +32) of the wave tile are complete
+                const int mg = mw + (pass >> 2) * 32;
                 if (p.col_sum && mg < p.M) {
                     // BatchNorm statistics of this 32-row chunk: (sum, M2 about the chunk mean) -- ppt_bn_finalize
                     // merges the chunks with the parallel-variance formula in fp64 (no cancellation, no atomics)
@@ -770,7 +771,9 @@ extern "C" int ppt_gemm(const ppt_gemm_params *pp, void *stream)
         if (p.a_mode == PPT_A_AFFINE_RELU && (!p.a_scale || !p.a_shift)) return PPT_EINVAL;
     }
     if ((p.col_sum == nullptr) != (p.col_sqsum == nullptr)) return PPT_EINVAL;
-    if ((p.col_sum || p.pool_max) && ((p.N % 8) || ((uintptr_t)p.col_sum & 15) || ((uintptr_t)p.col_sqsum & 15) || ((uintptr_t)p.pool_max & 15)))
+    if (p.pool_max && p.pool_rows != 0 && p.pool_rows != 16 && p.pool_rows != 32 && p.pool_rows != 64) return PPT_EINVAL;
+    if (p.pool_min && !p.pool_max) return PPT_EINVAL;
+    if ((p.col_sum || p.pool_max) && ((p.N % 8) || ((uintptr_t)p.pool_min & 15) || ((uintptr_t)p.col_sum & 15) || ((uintptr_t)p.col_sqsum & 15) || ((uintptr_t)p.pool_max & 15)))
         return PPT_EUNSUPPORTED;                       // statistics / pooling exist only in the 16-byte epilogue
     if (p.group_add && p.group_rows <= 0) return PPT_EINVAL;
     if (p.row_scale && p.row_scale_rows <= 0) return PPT_EINVAL;

@@ -160,7 +160,8 @@ __global__ __launch_bounds__(W * 64) void knn_group_kernel(const float *__restri
 template <int W>
 __global__ __launch_bounds__(W * 64) void ball_query_kernel(const float *__restrict__ xyz,
                                                             const float *__restrict__ center, int N, int S,
-                                                            float r2, int K, int cpb, int64_t *__restrict__ idx)
+                                                            float r2, int K, int cpb, int64_t *__restrict__ idx,
+                                                            float *__restrict__ gxyz)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     float4 *cloud = reinterpret_cast<float4 *>(smem);
@@ -196,6 +197,17 @@ __global__ __launch_bounds__(W * 64) void ball_query_kernel(const float *__restr
             }
         }
         for (int j = min(cnt, K) + lane; j < K; j += 64) o[j] = (int64_t)first;
+        if (gxyz) {                                   // grouped_xyz - new_xyz (pointnet2_utils.py:243-244)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float *g = gxyz + ((size_t)b * S + c) * K * 3;
+            for (int j = lane; j < K; j += 64) {
+                const int i = min((int)o[j], N - 1);
+                const float4 pt = cloud[i];
+                g[j * 3 + 0] = __fsub_rn(pt.x, qx); g[j * 3 + 1] = __fsub_rn(pt.y, qy); g[j * 3 + 2] = __fsub_rn(pt.z, qz);
+            }
+        }
     }
 }
 
@@ -222,7 +234,7 @@ extern "C" int ppt_knn_group_f32(const float *xyz, const float *center, int B, i
 }
 
 extern "C" int ppt_ball_query_f32(const float *xyz, const float *center, int B, int N, int S, float radius_sq,
-                                  int K, int64_t *idx, void *stream)
+                                  int K, int64_t *idx, float *grouped_xyz, void *stream)
 {
     if (!xyz || !center || !idx || B <= 0 || N <= 0 || S <= 0 || K <= 0 || N > 10240) return PPT_EINVAL;
     constexpr int W = 8;
@@ -235,7 +247,7 @@ extern "C" int ppt_ball_query_f32(const float *xyz, const float *center, int B, 
     const int cpb = 32;
     dim3 grid((S + cpb - 1) / cpb, B);
     hipLaunchKernelGGL((ball_query_kernel<W>), grid, dim3(W * 64), lds, ppt_stream(stream), xyz, center, N, S,
-                       radius_sq, K, cpb, idx);
+                       radius_sq, K, cpb, idx, grouped_xyz);
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }

@@ -110,7 +110,135 @@ __global__ __launch_bounds__(256) void linear3_gelu_kernel(const float *__restri
     dt<TY>::store(y + i, 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)));
 }
 
+// ---- PointNet2 set abstraction -----------------------------------------------------------------
+// y[b,s,k,:] = P[b, idx[b,s,k], :] + Q[b,s,:]; one workgroup = one 32-row chunk (threads == channels), which is
+// also the chunk of the (sum, M2) BatchNorm partials.
+template <typename TP, typename TY>
+__global__ __launch_bounds__(256) void gather_add_kernel(const TP *__restrict__ P, const float *__restrict__ Q,
+                                                         const int64_t *__restrict__ idx, int Nsrc, int S, int K, int C,
+                                                         int64_t M, TY *__restrict__ y, float *__restrict__ psum,
+                                                         float *__restrict__ pm2)
+{
+    __shared__ int src[32];
+    __shared__ int ctr[32];
+    const int64_t r0 = (int64_t)blockIdx.x * 32;
+    if (threadIdx.x < 32) {
+        const int64_t m = r0 + threadIdx.x;
+        if (m < M) {
+            const int64_t bs = m / K;                      // (b, s)
+            const int b = (int)(bs / S);
+            src[threadIdx.x] = b * Nsrc + (int)min<int64_t>(idx[m], Nsrc - 1);
+            ctr[threadIdx.x] = (int)bs;
+        }
+    }
+    __syncthreads();
+    const int nrow = (int)min<int64_t>(32, M - r0);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float v[32];
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            v[r] = 0.f;
+            if (r < nrow) {
+                v[r] = dt<TP>::load(P + (size_t)src[r] * C + c) + Q[(size_t)ctr[r] * C + c];
+                s += v[r];
+                dt<TY>::store(y + (size_t)(r0 + r) * C + c, v[r]);
+            }
+        }
+        if (psum) {
+            const float mean = s / (float)nrow;
+            float q = 0.f;
+#pragma unroll
+            for (int r = 0; r < 32; ++r) if (r < nrow) { const float d = v[r] - mean; q = fmaf(d, d, q); }
+            psum[(size_t)blockIdx.x * C + c] = s;
+            pm2[(size_t)blockIdx.x * C + c] = q;
+        }
+    }
+}
+
+template <typename TP, typename TO>
+__global__ void pool_finish_kernel(const TP *__restrict__ pmax, const TP *__restrict__ pmin, int G, int fold, int C,
+                                   const float *__restrict__ scale, const float *__restrict__ shift, TO *__restrict__ out,
+                                   int64_t ld)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)G * C) return;
+    const int64_t g = i / C;
+    const int c = (int)(i % C);
+    float mx = -INFINITY, mn = INFINITY;
+    for (int f = 0; f < fold; ++f) {
+        mx = fmaxf(mx, dt<TP>::load(pmax + (size_t)(g * fold + f) * C + c));
+        mn = fminf(mn, dt<TP>::load(pmin + (size_t)(g * fold + f) * C + c));
+    }
+    const float sc = scale[c];
+    dt<TO>::store(out + (size_t)g * ld + c, fmaxf(fmaf(sc, sc >= 0.f ? mx : mn, shift[c]), 0.f));   // max_k relu(bn(y_k))
+}
+
+template <typename TY>
+__global__ void bn_act_rows_kernel(const float *__restrict__ x, int64_t n, int C, const float *__restrict__ scale,
+                                   const float *__restrict__ shift, const float *__restrict__ mask, TY *__restrict__ y)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % C);
+    float v = fmaxf(fmaf(x[i], scale[c], shift[c]), 0.f);
+    if (mask) v *= mask[i];
+    dt<TY>::store(y + i, v);
+}
+
 }  // namespace
+
+extern "C" int ppt_gather_add(const void *P, int p_dtype, const float *Q, const int64_t *idx, int B, int Nsrc, int S, int K,
+                              int C, void *y, int y_dtype, float *part_sum, float *part_m2, void *stream)
+{
+    if (!P || !Q || !idx || !y || B <= 0 || Nsrc <= 0 || S <= 0 || K <= 0 || C <= 0) return PPT_EINVAL;
+    if ((part_sum == nullptr) != (part_m2 == nullptr)) return PPT_EINVAL;
+    const int64_t M = (int64_t)B * S * K;
+    dim3 grid((unsigned)((M + 31) / 32));
+    hipStream_t s = ppt_stream(stream);
+    if (p_dtype == PPT_F32 && y_dtype == PPT_F32)
+        hipLaunchKernelGGL((gather_add_kernel<float, float>), grid, dim3(128), 0, s, (const float *)P, Q, idx, Nsrc, S, K, C, M, (float *)y, part_sum, part_m2);
+    else if (p_dtype == PPT_F32 && y_dtype == PPT_BF16)
+        hipLaunchKernelGGL((gather_add_kernel<float, bf16_t>), grid, dim3(128), 0, s, (const float *)P, Q, idx, Nsrc, S, K, C, M, (bf16_t *)y, part_sum, part_m2);
+    else
+        return PPT_EUNSUPPORTED;
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
+extern "C" int ppt_pool_finish(const void *pmax, const void *pmin, int p_dtype, int G, int fold, int C, const float *scale,
+                               const float *shift, void *out, int out_dtype, int64_t ld_out, void *stream)
+{
+    if (!pmax || !pmin || !scale || !shift || !out || G <= 0 || fold <= 0 || C <= 0 || ld_out < C) return PPT_EINVAL;
+    const int64_t n = (int64_t)G * C;
+    dim3 grid((unsigned)((n + 255) / 256));
+    hipStream_t s = ppt_stream(stream);
+#define PF(TP, TO) hipLaunchKernelGGL((pool_finish_kernel<TP, TO>), grid, dim3(256), 0, s, (const TP *)pmax, (const TP *)pmin, G, fold, C, scale, shift, (TO *)out, ld_out)
+    if (p_dtype == PPT_F32 && out_dtype == PPT_F32) PF(float, float);
+    else if (p_dtype == PPT_F32 && out_dtype == PPT_BF16) PF(float, bf16_t);
+    else if (p_dtype == PPT_BF16 && out_dtype == PPT_BF16) PF(bf16_t, bf16_t);
+    else if (p_dtype == PPT_BF16 && out_dtype == PPT_F32) PF(bf16_t, float);
+    else return PPT_EINVAL;
+#undef PF
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
+extern "C" int ppt_bn_act_rows(const float *x, int M, int C, const float *scale, const float *shift, const float *mask,
+                               void *y, int y_dtype, void *stream)
+{
+    if (!x || !scale || !shift || !y || M <= 0 || C <= 0) return PPT_EINVAL;
+    const int64_t n = (int64_t)M * C;
+    dim3 grid((unsigned)((n + 255) / 256));
+    if (y_dtype == PPT_F32)
+        hipLaunchKernelGGL(bn_act_rows_kernel<float>, grid, dim3(256), 0, ppt_stream(stream), x, n, C, scale, shift, mask, (float *)y);
+    else if (y_dtype == PPT_BF16)
+        hipLaunchKernelGGL(bn_act_rows_kernel<bf16_t>, grid, dim3(256), 0, ppt_stream(stream), x, n, C, scale, shift, mask, (bf16_t *)y);
+    else
+        return PPT_EINVAL;
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
 
 extern "C" int ppt_conv1_stats_max_partials(int64_t M) { return (int)((M + STAT_ROWS - 1) / STAT_ROWS); }
 extern "C" int ppt_conv1_stats_rows_per_partial(void) { return STAT_ROWS; }

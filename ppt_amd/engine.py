@@ -28,10 +28,10 @@ class WeightCache:
         self.dtype = dtype
         self._c = {}
 
-    def get(self, t, kind="w", cols=None):
-        """kind 'w': [N,K] operand copy (optionally a column slice) in self.dtype;
-        'wt': transposed [K,N] copy (the B operand of dX = dY @ W); 'f32': fp32 2-D view."""
-        key = (id(t), kind, cols)
+    def get(self, t, kind="w", cols=None, pad_to=None):
+        """kind 'w': [N,K] operand copy (optionally a column slice; K zero-padded to a multiple of pad_to) in
+        self.dtype; 'wt': transposed [K,N] copy (the B operand of dX = dY @ W); 'f32': fp32 2-D view."""
+        key = (id(t), kind, cols, pad_to)
         ent = self._c.get(key)
         if ent is not None and ent[0] is t and ent[1] == t._version:
             return ent[2]
@@ -40,6 +40,10 @@ class WeightCache:
             w = w.reshape(w.shape[0], -1)                   # Conv1d [out,in,1] -> [out,in]
             if cols is not None:
                 w = w[:, cols[0]:cols[1]].contiguous()
+            if pad_to is not None and w.shape[1] % pad_to:
+                wp = torch.zeros((w.shape[0], (w.shape[1] + pad_to - 1) // pad_to * pad_to), dtype=w.dtype, device=w.device)
+                wp[:, :w.shape[1]] = w
+                w = wp
             if kind == "w":
                 out = ops.convert(w.contiguous(), self.dtype)
             elif kind == "wt":
@@ -226,6 +230,144 @@ def point_encoder_backward(sd, wc, s, dfeat, tier):
     _, dw, db = ops.layernorm_bwd(d_h, s["xs"], sd[p + "norm1.weight"], s["mean1"], s["rstd1"], want_wgrad=True)
     grads[p + "norm1.weight"], grads[p + "norm1.bias"] = dw, db
     return grads
+
+
+# =================================================================================================
+# PointNet2-MSG encoder (models/pointnet2/pointnet2.py:40-73, pointnet2_utils.py:161-266)
+# =================================================================================================
+PN2_MSG = dict(   # pointnet2.py:44-46
+    sa1=dict(npoint=512, radii=[0.1, 0.2, 0.4], nsample=[16, 32, 128]),
+    sa2=dict(npoint=128, radii=[0.2, 0.4, 0.8], nsample=[32, 64, 128]))
+
+
+def _bn_affine(sd, bnp, train, partials, rpp, count, update_running):
+    g, be, rm, rv, nb = _bn_params(sd, bnp)
+    if train:
+        return ops.bn_finalize(g, be, True, partials=partials, rows_per_partial=rpp, count=count, running_mean=rm,
+                               running_var=rv, num_batches_tracked=nb, update_running=update_running)
+    return ops.bn_finalize(g, be, False, running_mean=rm, running_var=rv)
+
+
+def _pad_cols(x, mult, dtype):
+    """[R, C] -> [R, Cp] in `dtype`, zero-padded so that Cp % mult == 0 (GEMM K alignment)."""
+    R, C = x.shape
+    Cp = (C + mult - 1) // mult * mult
+    out = torch.zeros((R, Cp), dtype=dtype, device=x.device)
+    out[:, :C] = x
+    return out
+
+
+def _stats_bufs(M, C, dev, train):
+    if not train:
+        return None
+    return (torch.empty(((M + 31) // 32, C), dtype=torch.float32, device=dev),
+            torch.empty(((M + 31) // 32, C), dtype=torch.float32, device=dev))
+
+
+def _sa_msg_level(sd, p, wc, cfg, xyz, feats, start, train, upd):
+    """PointNetSetAbstractionMsg.forward (pointnet2_utils.py:228-266).  xyz [B,N,3] fp32, feats [B*N, D] (T) or None
+    -> (new_xyz [B,S,3], new_feats [B*S, sum C] (T))."""
+    T = wc.dtype
+    B, N, _ = xyz.shape
+    S = cfg["npoint"]
+    dev = xyz.device
+    _, new_xyz = ops.fps(xyz, S, start)
+    n_br = len(cfg["radii"])
+    c_out = [sd[f"{p}conv_blocks.{i}.2.weight"].shape[0] for i in range(n_br)]
+    out = torch.empty((B * S, sum(c_out)), dtype=T, device=dev)
+    col = 0
+    mult = 8 if T == torch.bfloat16 else 4
+    for i, (r, K) in enumerate(zip(cfg["radii"], cfg["nsample"])):
+        idx, gxyz = ops.ball_query(xyz, new_xyz, r, K, want_grouped=True)
+        M = B * S * K
+        cb, bb = f"{p}conv_blocks.{i}.", f"{p}bn_blocks.{i}."
+        w0, b0 = sd[cb + "0.weight"], sd[cb + "0.bias"]
+        C1 = w0.shape[0]
+        st1 = _stats_bufs(M, sd[cb + "1.weight"].shape[0], dev, train)
+        if feats is None:
+            # layer 0 is a K=3 conv on the centred coordinates: A-prologue (conv + BN + ReLU) of the layer-1 GEMM
+            pts = gxyz.view(M, 3)
+            w03 = wc.get(w0, "f32")
+            part0, rpp0 = None, 0
+            if train:
+                ps, pq, rpp0 = ops.conv1_stats(pts, w03, b0)
+                part0 = (ps, pq)
+            sc0, sh0 = _bn_affine(sd, bb + "0.", train, part0, rpp0, M, upd)
+            y1 = ops.gemm(None, wc.get(sd[cb + "1.weight"]), out_dtype=T, a_mode=A_CONV1, pts=pts, w1=w03, b1=b0,
+                          a_scale=sc0, a_shift=sh0, bias=sd[cb + "1.bias"], col_stats=st1)
+        else:
+            # layer 0 by linearity of the 1x1 conv: per source point P = W.[feat|xyz], per centre Q = b - W_xyz.c
+            D = feats.shape[1]
+            key = (id(w0), "pn2pad")
+            src = torch.zeros((B * N, (D + 3 + mult - 1) // mult * mult), dtype=T, device=dev)
+            src[:, :D] = feats
+            src[:, D:D + 3] = xyz.view(B * N, 3)
+            w0p = wc.get(w0, "w", pad_to=mult)
+            P = ops.gemm(src, w0p, out_dtype=torch.float32)
+            wx = _pad_cols(w0.detach().reshape(C1, -1)[:, D:D + 3], 4, torch.float32)
+            cx = _pad_cols(new_xyz.view(B * S, 3), 4, torch.float32)
+            Q = ops.gemm(cx, wx, out_dtype=torch.float32)
+            Q = b0.view(1, C1) - Q
+            y0, part0 = ops.gather_add(P, Q.contiguous(), idx, N, T, want_stats=train)
+            sc0, sh0 = _bn_affine(sd, bb + "0.", train, part0, 32, M, upd)
+            y1 = ops.gemm(y0, wc.get(sd[cb + "1.weight"]), out_dtype=T, a_mode=A_AFFINE_RELU, a_scale=sc0, a_shift=sh0,
+                          bias=sd[cb + "1.bias"], col_stats=st1)
+        sc1, sh1 = _bn_affine(sd, bb + "1.", train, st1, 32, M, upd)
+        C3 = c_out[i]
+        pr = min(K, 64)
+        pmax = torch.empty((M // pr, C3), dtype=torch.float32, device=dev)
+        pmin = torch.empty_like(pmax)
+        st2 = _stats_bufs(M, C3, dev, train)
+        ops.gemm(y1, wc.get(sd[cb + "2.weight"]), a_mode=A_AFFINE_RELU, a_scale=sc1, a_shift=sh1, bias=sd[cb + "2.bias"],
+                 want_out=False, pool_max=pmax, pool_min=pmin, pool_rows=pr, col_stats=st2)
+        sc2, sh2 = _bn_affine(sd, bb + "2.", train, st2, 32, M, upd)
+        ops.pool_finish(pmax, pmin, K // pr, sc2, sh2, out[:, col:col + C3])
+        col += C3
+    return new_xyz, out
+
+
+def pointnet2_msg_forward(sd, p, wc, pc, fps_starts, train, drop_masks, update_running=True):
+    """Pointnet2_Msg.forward (pointnet2.py:56-73): pc [B,N,3] -> [B,256] fp32.
+    fps_starts = (start level 1 [B], start level 2 [B]); drop_masks = (m1 [B,512], m2 [B,256]) or None."""
+    T = wc.dtype
+    B = pc.shape[0]
+    dev = pc.device
+    mult = 8 if T == torch.bfloat16 else 4
+    l1_xyz, l1 = _sa_msg_level(sd, p + "sa1.", wc, PN2_MSG["sa1"], pc, None, fps_starts[0], train, update_running)
+    l2_xyz, l2 = _sa_msg_level(sd, p + "sa2.", wc, PN2_MSG["sa2"], l1_xyz.contiguous(), l1, fps_starts[1], train,
+                               update_running)
+    # sa3: group_all over the 128 remaining points, channels = [xyz | features] (pointnet2_utils.py:152-157)
+    S2 = l2_xyz.shape[1]
+    M = B * S2
+    D = l2.shape[1]
+    a = torch.zeros((M, (D + 3 + mult - 1) // mult * mult), dtype=T, device=dev)
+    a[:, :3] = l2_xyz.reshape(M, 3)
+    a[:, 3:3 + D] = l2
+    cb, bb = p + "sa3.mlp_convs.", p + "sa3.mlp_bns."
+    st = _stats_bufs(M, 256, dev, train)
+    y0 = ops.gemm(a, wc.get(sd[cb + "0.weight"], "w", pad_to=mult), out_dtype=T, bias=sd[cb + "0.bias"], col_stats=st)
+    sc, sh = _bn_affine(sd, bb + "0.", train, st, 32, M, update_running)
+    st = _stats_bufs(M, 512, dev, train)
+    y1 = ops.gemm(y0, wc.get(sd[cb + "1.weight"]), out_dtype=T, a_mode=A_AFFINE_RELU, a_scale=sc, a_shift=sh,
+                  bias=sd[cb + "1.bias"], col_stats=st)
+    sc, sh = _bn_affine(sd, bb + "1.", train, st, 32, M, update_running)
+    st = _stats_bufs(M, 1024, dev, train)
+    pr = min(S2, 64)
+    pmax = torch.empty((M // pr, 1024), dtype=torch.float32, device=dev)
+    pmin = torch.empty_like(pmax)
+    ops.gemm(y1, wc.get(sd[cb + "2.weight"]), a_mode=A_AFFINE_RELU, a_scale=sc, a_shift=sh, bias=sd[cb + "2.bias"],
+             want_out=False, pool_max=pmax, pool_min=pmin, pool_rows=pr, col_stats=st)
+    sc, sh = _bn_affine(sd, bb + "2.", train, st, 32, M, update_running)
+    x = torch.empty((B, 1024), dtype=T, device=dev)
+    ops.pool_finish(pmax, pmin, S2 // pr, sc, sh, x)
+    # FC head: Linear -> BatchNorm1d (over the batch) -> ReLU -> Dropout, twice (pointnet2.py:69-70)
+    for fc, bn, width, mask in (("fc1.", "bn1.", 512, 0), ("fc2.", "bn2.", 256, 1)):
+        st = _stats_bufs(B, width, dev, train)
+        h = ops.gemm(x, wc.get(sd[p + fc + "weight"]), out_dtype=torch.float32, bias=sd[p + fc + "bias"], col_stats=st)
+        sc, sh = _bn_affine(sd, p + bn, train, st, 32, B, update_running)
+        last = fc == "fc2."
+        x = ops.bn_act_rows(h, sc, sh, torch.float32 if last else T, mask=drop_masks[mask] if drop_masks is not None else None)
+    return x
 
 
 # =================================================================================================

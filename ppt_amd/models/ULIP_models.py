@@ -283,6 +283,7 @@ class ULIP_WITH_IMAGE(nn.Module):
     def set_precision(self, dtype):
         """torch.bfloat16 (performance mode) or torch.float32 (parity mode) for both towers."""
         self.point_encoder.precision = dtype
+        self.point_encoder._wc = None
         if hasattr(self.point_encoder, "encoder"):
             self.point_encoder.encoder.precision = dtype
         return self
@@ -408,6 +409,21 @@ def _load_and_freeze(model, args, point_ckpt, skip):
         if point_params is not None:
             src = point_params[name] if name in point_params else slip_params[name]
             param.data.copy_(src.data if isinstance(src, nn.Parameter) else src)
+
+
+def ULIP_PN_MSG(args):
+    """ULIP_models.py:347-391: PointNet2-MSG point encoder (pc_feat_dims 256); everything except
+    `prompt_learner.learnable_tokens` is frozen."""
+    from .pointnet2.pointnet2 import Pointnet2_Msg
+    point_encoder = Pointnet2_Msg()
+    model = ULIP_WITH_IMAGE(embed_dim=512, point_encoder=point_encoder, context_length=77, vocab_size=49408,
+                            classnames=args.classnames, template_init=args.template_init,
+                            class_name_position=args.class_name_position,
+                            num_learnable_prompt_tokens=args.num_learnable_prompt_tokens, transformer_width=512,
+                            transformer_heads=8, transformer_layers=12, pc_feat_dims=256, device=args.gpu, task=args.task)
+    if not getattr(args, "evaluate_3d", False):
+        _load_and_freeze(model, args, './data/pretrained_models/pointnet2_msg_1kpts.pt', set())
+    return model
 
 
 def ULIP_PointBERT(args):

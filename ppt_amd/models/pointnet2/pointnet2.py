@@ -1,0 +1,93 @@
+"""Mirror of models/pointnet2/pointnet2.py:40-73 (Pointnet2_Msg) and of the set-abstraction containers of
+models/pointnet2/pointnet2_utils.py:161-266: identical constructor signatures and state-dict keys
+(sa1.conv_blocks.{i}.{j}, sa1.bn_blocks.{i}.{j}, sa3.mlp_convs.{j}, sa3.mlp_bns.{j}, fc1, bn1, fc2, bn2); the
+forward runs ppt_amd.engine.pointnet2_msg_forward (FPS + ball query + grouped-MLP GEMM kernels)."""
+import torch
+import torch.nn as nn
+
+from ... import engine
+
+
+class PointNetSetAbstractionMsg(nn.Module):
+    """pointnet2_utils.py:209-226 (parameter container)."""
+
+    def __init__(self, npoint, radius_list, nsample_list, in_channel, mlp_list):
+        super().__init__()
+        self.npoint = npoint
+        self.radius_list = radius_list
+        self.nsample_list = nsample_list
+        self.conv_blocks = nn.ModuleList()
+        self.bn_blocks = nn.ModuleList()
+        for i in range(len(mlp_list)):
+            convs, bns = nn.ModuleList(), nn.ModuleList()
+            last_channel = in_channel + 3
+            for out_channel in mlp_list[i]:
+                convs.append(nn.Conv2d(last_channel, out_channel, 1))
+                bns.append(nn.BatchNorm2d(out_channel))
+                last_channel = out_channel
+            self.conv_blocks.append(convs)
+            self.bn_blocks.append(bns)
+
+
+class PointNetSetAbstraction(nn.Module):
+    """pointnet2_utils.py:161-175 (parameter container; only group_all=True is on the path)."""
+
+    def __init__(self, npoint, radius, nsample, in_channel, mlp, group_all, remove_last=False):
+        super().__init__()
+        self.npoint, self.radius, self.nsample = npoint, radius, nsample
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        last_channel = in_channel
+        for out_channel in mlp:
+            self.mlp_convs.append(nn.Conv2d(last_channel, out_channel, 1))
+            self.mlp_bns.append(nn.BatchNorm2d(out_channel))
+            last_channel = out_channel
+        self.group_all = group_all
+        self.remove_last = remove_last
+
+
+class Pointnet2_Msg(nn.Module):
+    """pointnet2.py:40-73.  forward(xyz [B,N,3]) -> [B,256].
+
+    Build-specific knobs: `precision` (bf16 / fp32 parity), `fps_start` = (start1 [B], start2 [B]) and
+    `dropout_masks` = (m1 [B,512], m2 [B,256]) to inject the three RNG draws of the path in parity tests."""
+
+    def __init__(self, normal_channel=False):
+        super().__init__()
+        if normal_channel:
+            raise NotImplementedError("normal_channel=True is not on the PPT path (pointnet2.py:6-8 default)")
+        self.normal_channel = normal_channel
+        self.sa1 = PointNetSetAbstractionMsg(512, [0.1, 0.2, 0.4], [16, 32, 128], 0, [[32, 32, 64], [64, 64, 128], [64, 96, 128]])
+        self.sa2 = PointNetSetAbstractionMsg(128, [0.2, 0.4, 0.8], [32, 64, 128], 320,
+                                             [[64, 64, 128], [128, 128, 256], [128, 128, 256]])
+        self.sa3 = PointNetSetAbstraction(None, None, None, 640 + 3, [256, 512, 1024], True)
+        self.fc1 = nn.Linear(1024, 512)
+        self.bn1 = nn.BatchNorm1d(512)
+        self.drop1 = nn.Dropout(0.4)
+        self.fc2 = nn.Linear(512, 256)
+        self.bn2 = nn.BatchNorm1d(256)
+        self.drop2 = nn.Dropout(0.5)
+        self.precision = torch.bfloat16
+        self.fps_start = None
+        self.dropout_masks = None
+        self._wc = None
+
+    def forward(self, xyz):
+        xyz = xyz.contiguous().float()
+        B, N, _ = xyz.shape
+        if self._wc is None or self._wc.dtype != self.precision:
+            self._wc = engine.WeightCache(self.precision)
+        if self.fps_start is not None:
+            starts = tuple(s.to(xyz.device).contiguous() for s in self.fps_start)
+        else:
+            starts = (torch.randint(0, N, (B,), dtype=torch.long, device=xyz.device),
+                      torch.randint(0, 512, (B,), dtype=torch.long, device=xyz.device))
+        masks = None
+        if self.dropout_masks is not None:
+            masks = tuple(m.to(device=xyz.device, dtype=torch.float32).contiguous() for m in self.dropout_masks)
+        elif self.training:
+            masks = ((torch.rand((B, 512), device=xyz.device) >= 0.4).float() / 0.6,
+                     (torch.rand((B, 256), device=xyz.device) >= 0.5).float() / 0.5)
+        sd = self.state_dict(keep_vars=True)
+        with torch.no_grad():            # every parameter of this encoder is frozen in PPT (ULIP_models.py:372-389)
+            return engine.pointnet2_msg_forward(sd, "", self._wc, xyz, starts, self.training, masks)

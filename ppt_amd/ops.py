@@ -103,23 +103,24 @@ def knn_group(xyz, center, k, want_idx=True, want_nbhd=True):
     return idx, nb
 
 
-def ball_query(xyz, center, radius, K):
-    """H7.  -> idx [B,S,K] i64 (query_ball_point semantics)."""
+def ball_query(xyz, center, radius, K, want_grouped=False):
+    """H7.  -> idx [B,S,K] i64 (query_ball_point semantics) [, grouped_xyz [B,S,K,3] = xyz[idx] - center]."""
     _chk(xyz, torch.float32, "xyz"); _chk(center, torch.float32, "center")
     B, N, _ = xyz.shape
     S = center.shape[1]
     idx = torch.empty((B, S, K), dtype=torch.int64, device=xyz.device)
     import numpy as np
     r2 = float(np.float32(radius * radius))
-    _lib.check(_lib.lib().ppt_ball_query_f32(_p(xyz), _p(center), B, N, S, r2, K, _p(idx), _stream()),
+    g = torch.empty((B, S, K, 3), dtype=torch.float32, device=xyz.device) if want_grouped else None
+    _lib.check(_lib.lib().ppt_ball_query_f32(_p(xyz), _p(center), B, N, S, r2, K, _p(idx), _p(g), _stream()),
                "ppt_ball_query_f32")
-    return idx
+    return (idx, g) if want_grouped else idx
 
 
 # ---------------------------------------------------------------------------------------------
 def gemm(A, B, *, out=None, out_dtype=None, M=None, bias=None, act=ACT_NONE, dact_pre=None,
          group_add=None, group_rows=0, row_scale=None, row_scale_rows=0, residual=None,
-         residual2=None, out2=None, out2_pre=False, col_stats=None, pool_max=None,
+         residual2=None, out2=None, out2_pre=False, col_stats=None, pool_max=None, pool_min=None, pool_rows=0,
          batch=1, strideA=0, strideB=0, strideC=0,
          a_mode=A_PLAIN, a_scale=None, a_shift=None, pts=None, w1=None, b1=None, want_out=True, algo_k=None):
     """C[M,N] = epilogue(prologue(A)[M,K] @ B[N,K]^T) -- see struct ppt_gemm_params.
@@ -164,7 +165,8 @@ def gemm(A, B, *, out=None, out_dtype=None, M=None, bias=None, act=ACT_NONE, dac
     if col_stats is not None:
         p.col_sum, p.col_sqsum = _p(col_stats[0]), _p(col_stats[1])
     if pool_max is not None:
-        p.pool_max, p.pool_dtype = _p(pool_max), dtype_code(pool_max)
+        p.pool_max, p.pool_dtype, p.pool_rows = _p(pool_max), dtype_code(pool_max), pool_rows
+        p.pool_min = _p(pool_min)
     p.batch, p.strideA, p.strideB, p.strideC = batch, strideA, strideB, strideC
     if profiler is not None:
         kk = K if algo_k is None else algo_k
@@ -268,6 +270,42 @@ def bn_finalize(gamma, beta, train, partials=None, rows_per_partial=0, count=0, 
                                           _p(num_batches_tracked) if upd else None, _p(scale), _p(shift), _stream()),
                "ppt_bn_finalize")
     return scale, shift
+
+
+def gather_add(P, Q, idx, Nsrc, y_dtype, want_stats=True):
+    """y[b,s,k,:] = P[b*Nsrc + idx[b,s,k], :] + Q[b*S + s, :] -> (y [B*S*K, C], (psum, pm2) | None)."""
+    _chk(P, torch.float32, "P"); _chk(Q, torch.float32, "Q"); _chk(idx, torch.int64, "idx")
+    B, S, K = idx.shape
+    C = P.shape[1]
+    M = B * S * K
+    y = torch.empty((M, C), dtype=y_dtype, device=P.device)
+    ps = pm = None
+    if want_stats:
+        ps = torch.empty(((M + 31) // 32, C), dtype=torch.float32, device=P.device)
+        pm = torch.empty_like(ps)
+    _lib.check(_lib.lib().ppt_gather_add(_p(P), dtype_code(P), _p(Q), _p(idx), B, Nsrc, S, K, C, _p(y), dtype_code(y),
+                                         _p(ps), _p(pm), _stream()), "ppt_gather_add")
+    return y, ((ps, pm) if want_stats else None)
+
+
+def pool_finish(pmax, pmin, fold, scale, shift, out):
+    """out[g, :C] = relu(scale * (scale >= 0 ? max : min) + shift) folded over `fold` pooled rows; out is a 2-D
+    view (row stride free) -- e.g. a column slice of the concatenated MSG feature matrix."""
+    G = pmax.shape[0] // fold
+    C = pmax.shape[1]
+    assert out.shape[0] == G and out.shape[1] == C and out.stride(1) == 1
+    _lib.check(_lib.lib().ppt_pool_finish(_p(pmax), _p(pmin), dtype_code(pmax), G, fold, C, _p(scale), _p(shift), _p(out),
+                                          dtype_code(out), out.stride(0), _stream()), "ppt_pool_finish")
+    return out
+
+
+def bn_act_rows(x, scale, shift, y_dtype, mask=None):
+    _chk(x, torch.float32, "x")
+    M, C = x.shape
+    y = torch.empty((M, C), dtype=y_dtype, device=x.device)
+    _lib.check(_lib.lib().ppt_bn_act_rows(_p(x), M, C, _p(scale), _p(shift), _p(mask), _p(y), dtype_code(y), _stream()),
+               "ppt_bn_act_rows")
+    return y
 
 
 def linear3_gelu(pts, w, b, y_dtype):

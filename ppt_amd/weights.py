@@ -64,6 +64,46 @@ def ulip_spec(pc_feat_dims=768, with_token_embedding=True):
     return s
 
 
+PN2_MSG = dict(   # models/pointnet2/pointnet2.py:44-46
+    sa1=dict(npoint=512, radii=[0.1, 0.2, 0.4], nsample=[16, 32, 128], in_channel=0,
+             mlps=[[32, 32, 64], [64, 64, 128], [64, 96, 128]]),
+    sa2=dict(npoint=128, radii=[0.2, 0.4, 0.8], nsample=[32, 64, 128], in_channel=320,
+             mlps=[[64, 64, 128], [128, 128, 256], [128, 128, 256]]),
+    sa3=dict(in_channel=640 + 3, mlp=[256, 512, 1024]))
+
+
+def pointnet2_msg_spec(prefix="point_encoder."):
+    """(key, shape) list of Pointnet2_Msg.state_dict() (models/pointnet2/pointnet2.py:40-55)."""
+    def bn(p, c):
+        return [(p + k, (c,)) for k in ("weight", "bias", "running_mean", "running_var")] + [(p + "num_batches_tracked", ())]
+    s = []
+    for name in ("sa1", "sa2"):
+        cfg = PN2_MSG[name]
+        convs, bns = [], []
+        for i, mlp in enumerate(cfg["mlps"]):
+            last = cfg["in_channel"] + 3
+            for j, out in enumerate(mlp):
+                convs += [(f"{prefix}{name}.conv_blocks.{i}.{j}.weight", (out, last, 1, 1)),
+                          (f"{prefix}{name}.conv_blocks.{i}.{j}.bias", (out,))]
+                bns += bn(f"{prefix}{name}.bn_blocks.{i}.{j}.", out)
+                last = out
+        s += convs + bns
+    last = PN2_MSG["sa3"]["in_channel"]
+    convs, bns = [], []
+    for j, out in enumerate(PN2_MSG["sa3"]["mlp"]):
+        convs += [(f"{prefix}sa3.mlp_convs.{j}.weight", (out, last, 1, 1)), (f"{prefix}sa3.mlp_convs.{j}.bias", (out,))]
+        bns += bn(f"{prefix}sa3.mlp_bns.{j}.", out)
+        last = out
+    s += convs + bns
+    s += [(prefix + "fc1.weight", (512, 1024)), (prefix + "fc1.bias", (512,))] + bn(prefix + "bn1.", 512)
+    s += [(prefix + "fc2.weight", (256, 512)), (prefix + "fc2.bias", (256,))] + bn(prefix + "bn2.", 256)
+    return s
+
+
+def ulip_pn2_msg_state_dict(seed=0, with_token_embedding=False, as_torch=True):
+    return synth_state_dict(ulip_spec(256, with_token_embedding) + pointnet2_msg_spec(), seed, as_torch)
+
+
 def _rng(key, seed):
     return np.random.default_rng([zlib.crc32(key.encode()), seed])
 
@@ -83,7 +123,7 @@ def synth_tensor(key, shape, seed=0):
     if leaf == "running_var":
         return (1.0 + 0.5 * r.random(shape)).astype(np.float32)
     is_norm = any(t in key for t in (".norm1.", ".norm2.", ".norm.", ".ln_1.", ".ln_2.", "ln_final.",
-                                     "first_conv.1.", "second_conv.1.", "mlp_bns", ".bn"))
+                                     "first_conv.1.", "second_conv.1.", "mlp_bns", ".bn", "bn_blocks"))
     if is_norm and leaf == "weight":
         return (1.0 + 0.1 * r.standard_normal(shape)).astype(np.float32)
     if leaf in ("bias", "in_proj_bias"):

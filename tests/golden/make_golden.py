@@ -267,10 +267,61 @@ def gen_encoder_and_step(tok):
                                 text_feat=te.numpy(), logits=lg.numpy(), prompts_sub=prompts[:, ::4, ::8].numpy())
 
 
+def gen_pointnet2_msg():
+    """G-PN2: Pointnet2_Msg forward (eval and train BN) vs the reference module (pointnet2.py:40-73)."""
+    sd_all = W.synth_state_dict(W.pointnet2_msg_spec(prefix=""), seed=0)
+    B, N = 2, 1024
+    pc_np, s1 = W.synth_clouds(B, N, seed=31)
+    _, s2 = W.synth_clouds(B, 512, seed=32)
+    pc = torch.from_numpy(pc_np)
+    rng = np.random.default_rng(9)
+    dm = (torch.from_numpy((rng.random((B, 512)) > 0.4).astype(np.float32) / 0.6),
+          torch.from_numpy((rng.random((B, 256)) > 0.5).astype(np.float32) / 0.5))
+    with R.reference_context():
+        from models.pointnet2.pointnet2 import Pointnet2_Msg
+        m = Pointnet2_Msg()
+    m.load_state_dict(sd_all)
+    out = {}
+    for mode in ("eval", "train"):
+        m.load_state_dict(sd_all)
+        m.train(mode == "train")
+        if mode == "train":
+            m.drop1.forward = lambda x: x * dm[0]
+            m.drop2.forward = lambda x: x * dm[1]
+        starts = [torch.from_numpy(s1), torch.from_numpy(s2)]
+        orig = torch.randint
+        torch.randint = lambda *a, **k: starts.pop(0)
+        try:
+            with torch.no_grad():
+                ref = m(pc)
+        finally:
+            torch.randint = orig
+        ns = {}
+        with torch.no_grad():
+            ora = O.pointnet2_msg(sd_all, pc, (s1, s2), train=(mode == "train"), drop_masks=dm if mode == "train" else None,
+                                  prefix="", new_stats=ns)
+        err = (ref - ora).abs().max().item()
+        print(f"Pointnet2_Msg {mode}: max|ref-oracle| = {err:.3e} (|ref|max {ref.abs().max():.3f})")
+        assert err < 1e-3
+        out[mode] = ref.numpy()
+        if mode == "train":
+            msd = m.state_dict()
+            for k, v in ns.items():
+                e = (msd[k].float() - v.float()).abs().max().item()
+                assert e < 1e-4 * max(1.0, msd[k].float().abs().max().item()), (k, e)
+            for k in ("sa1.bn_blocks.2.2.running_var", "sa2.bn_blocks.1.0.running_mean", "sa3.mlp_bns.2.running_var",
+                      "bn2.running_mean"):
+                out["stat_" + k] = msd[k].numpy()
+    out["drop1"], out["drop2"] = dm[0].numpy(), dm[1].numpy()
+    out["start1"], out["start2"] = s1, s2
+    np.savez_compressed(os.path.join(HERE, "g_pn2msg.npz"), **out)
+
+
 if __name__ == "__main__":
     assert R.reference_available(), "needs /root/reference"
     O.build_c_oracle(force=True)
     tok = gen_tokens()
     gen_index()
     gen_encoder_and_step(tok)
+    gen_pointnet2_msg()
     print("done")

@@ -104,13 +104,18 @@ def reference_context():
              or k == "utils" or k.startswith("utils.") or k == "data" or k.startswith("data.")}
     for k in saved:
         del sys.modules[k]
-    sys.path.insert(0, REF_ROOT)
+    # the reference's `models` is a namespace package (no __init__.py); this repo's `models/` alias package is a
+    # regular one and would win from ANY position on sys.path -- hide the repo root while the reference imports
+    repo_root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    hidden = [q for q in sys.path if os.path.abspath(q or old) == repo_root]
+    saved_path = list(sys.path)
+    sys.path[:] = [REF_ROOT] + [q for q in sys.path if q not in hidden]
     os.chdir(REF_ROOT)
     try:
         yield
     finally:
         os.chdir(old)
-        sys.path.remove(REF_ROOT)
+        sys.path[:] = saved_path
         ref_mods = [k for k in sys.modules if k == "models" or k.startswith("models.")
                     or k == "utils" or k.startswith("utils.") or k == "data" or k.startswith("data.")]
         for k in ref_mods:

@@ -311,3 +311,39 @@ def test_misc_ops(ops):
     assert (y.cpu() - ref).abs().max().item() < 1e-5
     p = rng.standard_normal((50, 384)).astype(np.float32)
     assert (ops.reduce_rows(dev(p)).cpu() - torch.from_numpy(p).sum(0)).abs().max().item() < 1e-4
+
+
+def test_ball_query_grouped_and_pointnet2_helpers(ops):
+    pc, start = W.synth_clouds(2, 1024, seed=8)
+    cidx = O.fps(pc, 64, start)
+    center = np.take_along_axis(pc, cidx[:, :, None], axis=1)
+    idx, g = ops.ball_query(dev(pc), dev(center), 0.3, 32, want_grouped=True)
+    ref = O.ball_query(pc, center, 0.3, 32)
+    assert np.array_equal(idx.cpu().numpy(), ref)
+    gref = pc[np.arange(2)[:, None, None], ref] - center[:, :, None, :]
+    assert np.array_equal(g.cpu().numpy(), gref)
+    rng = np.random.default_rng(1)
+    P = rng.standard_normal((2 * 1024, 64)).astype(np.float32)
+    Q = rng.standard_normal((2 * 64, 64)).astype(np.float32)
+    y, (ps, pm) = ops.gather_add(dev(P), dev(Q), idx, 1024, torch.float32)
+    yref = P.reshape(2, 1024, 64)[np.arange(2)[:, None, None], ref] + Q.reshape(2, 64, 1, 64)
+    assert np.abs(y.cpu().numpy() - yref.reshape(-1, 64)).max() < 1e-6
+    ch = torch.from_numpy(yref.reshape(-1, 32, 64))
+    assert (ps.cpu() - ch.sum(1)).abs().max().item() < 1e-4
+    assert (pm.cpu() - ((ch - ch.mean(1, keepdim=True)) ** 2).sum(1)).abs().max().item() < 1e-3
+    # pooled max/min over 16-row groups + finish with mixed-sign scales
+    M, N, K = 1024, 64, 64
+    A = dev(rng.standard_normal((M, K)).astype(np.float32), torch.bfloat16)
+    Wt = dev((rng.standard_normal((N, K)) / 8).astype(np.float32), torch.bfloat16)
+    pmax = torch.empty((M // 16, N), device="cuda"); pmin = torch.empty_like(pmax)
+    ops.gemm(A, Wt, want_out=False, pool_max=pmax, pool_min=pmin, pool_rows=16)
+    full = (A.float().cpu() @ Wt.float().cpu().t()).view(M // 16, 16, N)
+    assert (pmax.cpu() - full.max(1)[0]).abs().max().item() < 2e-3 and (pmin.cpu() - full.min(1)[0]).abs().max().item() < 2e-3
+    sc = dev(rng.standard_normal(N).astype(np.float32)); sh = dev(rng.standard_normal(N).astype(np.float32))
+    out = torch.zeros((M // 32, 2 * N), device="cuda")
+    ops.pool_finish(pmax, pmin, 2, sc, sh, out[:, N:])
+    want = torch.relu(full.view(M // 32, 32, N) * sc.cpu() + sh.cpu()).max(1)[0]
+    assert (out[:, N:].cpu() - want).abs().max().item() < 5e-3 and out[:, :N].abs().max().item() == 0
+    x = dev(rng.standard_normal((5, N)).astype(np.float32)); mk = dev((rng.random((5, N)) > 0.5).astype(np.float32) * 2)
+    yb = ops.bn_act_rows(x, sc, sh, torch.float32, mask=mk)
+    assert (yb.cpu() - torch.relu(x.cpu() * sc.cpu() + sh.cpu()) * mk.cpu()).abs().max().item() < 1e-6

@@ -193,3 +193,57 @@ def test_group_and_encoder_modules():
                 ref = O.mini_pointnet({"e." + k: v for k, v in sd.items()}, torch.from_numpy(nb_ref), train, prefix="e.")
             err = (out.cpu() - ref).abs().max().item()
             assert err < tol * max(1.0, ref.abs().max().item()), (prec, train, err)
+
+
+# ------------------------------------------------------------------ PointNet2-MSG (BASELINE config C4)
+def _pn2_inputs():
+    g = np.load(os.path.join(G, "g_pn2msg.npz"))
+    pc_np, s1 = W.synth_clouds(2, 1024, seed=31)
+    assert np.array_equal(s1, g["start1"])
+    return g, torch.from_numpy(pc_np)
+
+
+@pytest.mark.parametrize("precision,tol", [(torch.float32, 2e-3), (torch.bfloat16, 6e-2)])
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_pointnet2_msg_matches_golden(mode, precision, tol):
+    """Pointnet2_Msg forward vs the reference output captured in g_pn2msg.npz (tolerance relative to max|ref|;
+    the train-mode FC head normalises over a batch of 2, which amplifies rounding)."""
+    from ppt_amd.models.pointnet2.pointnet2 import Pointnet2_Msg
+    g, pc = _pn2_inputs()
+    m = Pointnet2_Msg()
+    sd = W.synth_state_dict(W.pointnet2_msg_spec(prefix=""), seed=0)
+    m.load_state_dict(sd)
+    m.cuda()
+    m.precision = precision
+    m.train(mode == "train")
+    m.fps_start = (torch.from_numpy(g["start1"]).cuda(), torch.from_numpy(g["start2"]).cuda())
+    if mode == "train":
+        m.dropout_masks = (torch.from_numpy(g["drop1"]), torch.from_numpy(g["drop2"]))
+    out = m(pc.cuda())
+    ref = torch.from_numpy(g[mode])
+    err = (out.cpu() - ref).abs().max().item()
+    assert err < tol * max(ref.abs().max().item(), 0.05), err
+    if mode == "train":
+        msd = m.state_dict()
+        for k in ("sa1.bn_blocks.2.2.running_var", "sa2.bn_blocks.1.0.running_mean", "sa3.mlp_bns.2.running_var"):
+            r = torch.from_numpy(g["stat_" + k])
+            rtol = 1e-4 if precision == torch.float32 else 3e-2
+            assert (msd[k].cpu() - r).abs().max().item() < rtol * max(1.0, r.abs().max().item()), k
+
+
+def test_ulip_pn_msg_train_step_runs_and_only_prompt_trains():
+    from ppt_amd.models import ULIP_models as M
+    from ppt_amd.train import Trainer
+    args = SimpleNamespace(classnames=M.dataset_classnames("modelnet40"), template_init='', class_name_position='middle',
+                           num_learnable_prompt_tokens=32, gpu=0, task='cls', head_type=0, evaluate_3d=False, ulip2=False)
+    m = M.ULIP_PN_MSG(args)
+    m.load_state_dict(W.ulip_pn2_msg_state_dict(seed=0), strict=False)
+    m.prompt_learner.embedding = W.synth_prompt_embedding(40, seed=0)
+    m.cuda().train()
+    assert [n for n, p in m.named_parameters() if p.requires_grad] == ["prompt_learner.learnable_tokens"]
+    pc, _ = W.synth_clouds(4, 2048, seed=3)
+    tr = Trainer(m, distributed=False)
+    before = m.prompt_learner.learnable_tokens.detach().clone()
+    loss, pred = tr.step(torch.from_numpy(pc).cuda(), torch.tensor([1, 2, 3, 4]).cuda())
+    assert pred.shape == (4, 40) and torch.isfinite(pred).all() and np.isfinite(loss.item())
+    assert (m.prompt_learner.learnable_tokens.detach() - before).abs().max().item() > 0
