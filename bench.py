@@ -39,11 +39,16 @@ CONFIGS = {   # BASELINE.json configs[1] (headline) and configs[2] (secondary, -
                name="C2: ModelNet40 1024-pt PointBERT (ULIP_PointBERT head_type=0, frozen backbone + PromptLearner)"),
     "C3": dict(dataset="scanobjectnn", batch=64, npoints=2048, head_type=3,
                name="C3: ScanObjectNN (PB_T50_RS shape) 2048-pt PointBERT + PointAdapter (head_type=3: last block un-frozen)"),
+    "C4": dict(dataset="modelnet40", batch=32, npoints=8192, head_type=0, model="ULIP_PN_MSG",
+               name="C4: ModelNet40 8192-pt PointNet2-MSG encoder (ULIP_PN_MSG, frozen) + PromptLearner, 32 clouds per GPU"),
 }
+METRICS = {"C2": "point-clouds/sec fwd+bwd, PointBERT 1024-pt ModelNet40",
+           "C3": "point-clouds/sec fwd+bwd, PointBERT 2048-pt ScanObjectNN + PointAdapter",
+           "C4": "point-clouds/sec fwd+bwd, PointNet2-MSG 8192-pt ModelNet40"}
 PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def build_model(dataset="modelnet40", head_type=HEAD_TYPE, precision=torch.bfloat16):
+def build_model(dataset="modelnet40", head_type=HEAD_TYPE, precision=torch.bfloat16, model="ULIP_PointBERT"):
     from ppt_amd import weights as W
     from ppt_amd.models import ULIP_models as M
     import contextlib
@@ -52,8 +57,9 @@ def build_model(dataset="modelnet40", head_type=HEAD_TYPE, precision=torch.bfloa
                            num_learnable_prompt_tokens=32, gpu=torch.cuda.current_device(), task='cls',
                            head_type=head_type, evaluate_3d=False, ulip2=False)
     with contextlib.redirect_stdout(io.StringIO()):
-        m = M.ULIP_PointBERT(args)
-    m.load_state_dict(W.ulip_pointbert_state_dict(seed=0), strict=False)
+        m = getattr(M, model)(args)
+    sd = W.ulip_pointbert_state_dict(seed=0) if model == "ULIP_PointBERT" else W.ulip_pn2_msg_state_dict(seed=0)
+    m.load_state_dict(sd, strict=False)
     m.prompt_learner.embedding = W.synth_prompt_embedding(len(args.classnames), seed=0)
     m.cuda()
     m.set_precision(precision)
@@ -112,7 +118,7 @@ def main():
     cfg = CONFIGS[a.config]
     global PER_GPU_BATCH, NPOINTS
     PER_GPU_BATCH, NPOINTS = cfg["batch"], cfg["npoints"]
-    model = build_model(cfg["dataset"], cfg["head_type"])
+    model = build_model(cfg["dataset"], cfg["head_type"], model=cfg.get("model", "ULIP_PointBERT"))
     n_classes = len(model.prompt_learner.classnames)
     model.train()
     trainer = Trainer(model, lr=3e-3, label_smoothing=0.2, distributed=world > 1)
@@ -186,7 +192,7 @@ def main():
 
     if rank == 0:
         total = PER_GPU_BATCH * world * a.steps
-        out = {"metric": "point-clouds/sec fwd+bwd, PointBERT 1024-pt ModelNet40",
+        out = {"metric": METRICS[a.config],
                "value": round(total / elapsed, 2), "unit": "point-clouds/s", "n_gpus": world, "steps": a.steps,
                "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
