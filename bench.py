@@ -108,8 +108,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    force_dist = os.environ.get("PPT_FORCE_DIST") == "1"      # exercise the RCCL path with a single rank (dev aid)
+    if world > 1 or force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     from ppt_amd import ops, weights as W
@@ -121,13 +124,13 @@ def main():
     model = build_model(cfg["dataset"], cfg["head_type"], model=cfg.get("model", "ULIP_PointBERT"))
     n_classes = len(model.prompt_learner.classnames)
     model.train()
-    trainer = Trainer(model, lr=3e-3, label_smoothing=0.2, distributed=world > 1)
+    trainer = Trainer(model, lr=3e-3, label_smoothing=0.2, distributed=world > 1 or force_dist)
     pc_np, _ = W.synth_clouds(PER_GPU_BATCH, NPOINTS, seed=1234 + rank)
     pc = torch.from_numpy(pc_np).cuda()
     label = torch.from_numpy(np.random.default_rng(rank).integers(0, n_classes, size=(PER_GPU_BATCH,))).cuda()
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -139,7 +142,7 @@ def main():
         loss, _ = trainer.step(pc, label)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -187,7 +190,7 @@ def main():
                 "algorithmic_gflop_per_launch": round(g["work"] / g["launches"] / 1e9, 3),
                 "per_kernel_ms_per_step": {k: round((v["ms"] - overhead_ms * v["launches"]) / a.steps, 4)
                                            for k, v in summ.items()}}
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
 
     if rank == 0:
@@ -203,7 +206,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

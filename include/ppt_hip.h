@@ -57,7 +57,8 @@ int ppt_fps_f32(const float *xyz, int B, int N, int M, const int64_t *start, int
  *   xyz [B,N,3], center [B,G,3] -> nbr_idx [B,G,k] i64 (may be NULL),
  *   neighborhood [B,G,k,3] f32 = xyz[nbr] - center (may be NULL).   k <= 64, k <= N <= 8192. */
 int ppt_knn_group_f32(const float *xyz, const float *center, int B, int N, int G, int k,
-                      int64_t *nbr_idx, float *neighborhood, void *stream);
+                      int64_t *nbr_idx, float *neighborhood, float *nbr_dist /* [B,G,k] expanded-form d, or NULL */,
+                      void *stream);
 
 /* ---- H7: ball query ---------------------------------------------------------------------------
  * Replaces models/pointnet2/pointnet2_utils.py:87-107 query_ball_point: first K indices in

@@ -240,6 +240,99 @@ def point_transformer(sd, pc, fps_start, train=False, dp_masks=None, prefix="poi
 
 
 # ------------------------------------------------------------------------------------------------
+# part-segmentation encoder/decoder (models/pointbert/point_encoder.py:347-420, pointnet2_utils.py:297-467)
+# ------------------------------------------------------------------------------------------------
+def group_norm_rows(x, w, b, groups, eps=1e-5):
+    """nn.GroupNorm(groups, C) on [B, C, *]: statistics per (sample, channel group) over the group's channels and
+    all trailing positions."""
+    B, C = x.shape[:2]
+    xg = x.reshape(B, groups, -1)
+    mu = xg.mean(-1, keepdim=True)
+    var = ((xg - mu) ** 2).mean(-1, keepdim=True)
+    xn = ((xg - mu) / torch.sqrt(var + eps)).reshape(x.shape)
+    shape = (1, C) + (1,) * (x.dim() - 2)
+    return xn * w.view(shape) + b.view(shape)
+
+
+def feature_propagation(sd, p, xyz1, xyz2, points1, points2, train, new_stats):
+    """PointNetFeaturePropagation.forward (pointnet2_utils.py:310-368) in row layout.
+    xyz1 [B,N,3] numpy (targets), xyz2 [B,S,3] numpy (sources), points1 [B,N,D1] tensor|None, points2 [B,S,D2] -> [B,N,C]."""
+    B, N, _ = xyz1.shape
+    idx, w = three_nn(xyz1, xyz2)
+    gathered = points2[torch.arange(B)[:, None, None], torch.from_numpy(idx)]            # [B,N,3,D2]
+    interp = (gathered * torch.from_numpy(w)[..., None]).sum(dim=2)
+    x = interp if points1 is None else torch.cat([points1, interp], dim=-1)
+    x = x.reshape(B * N, -1)
+    for j in range(2):
+        wgt = sd[f"{p}mlp_convs.{j}.weight"]
+        x = linear(x, wgt.reshape(wgt.shape[0], -1), sd[f"{p}mlp_convs.{j}.bias"])
+        x = torch.relu(batch_norm_rows(x, sd, f"{p}mlp_bns.{j}.", train, new_stats=new_stats))
+    return x.reshape(B, N, -1)
+
+
+def _graph_feature(coor_q, x_q, coor_k, x_k, k):
+    """DGCNN_Propagation.get_graph_feature (pointnet2_utils.py:392-431): cat(x_k[nn] - x_q, x_q) -> [B,Nq,k,2C]."""
+    B = x_q.shape[0]
+    idx, _ = knn(coor_k, coor_q, k)                                                       # [B,Nq,k]
+    nb = x_k[torch.arange(B)[:, None, None], torch.from_numpy(idx)]                       # [B,Nq,k,C]
+    xq = x_q[:, :, None, :].expand(-1, -1, k, -1)
+    return torch.cat([nb - xq, xq], dim=-1)
+
+
+def dgcnn_propagation(sd, p, coor, f, coor_q, f_q, k=4):
+    """DGCNN_Propagation.forward (pointnet2_utils.py:433-467).  coor [B,S,3] numpy, f [B,S,C], coor_q [B,Nq,3], f_q [B,Nq,C]."""
+    for layer, (ck, fk) in (("layer1", (coor, f)), ("layer2", (coor_q, None))):
+        fk = f_q if fk is None else fk
+        g = _graph_feature(coor_q, f_q, ck, fk, k)                                         # [B,Nq,k,2C]
+        w = sd[f"{p}{layer}.0.weight"]
+        y = g @ w.reshape(w.shape[0], -1).t()                                              # [B,Nq,k,Cout]
+        y = group_norm_rows(y.permute(0, 3, 1, 2), sd[f"{p}{layer}.1.weight"], sd[f"{p}{layer}.1.bias"], 4)
+        y = torch.where(y >= 0, y, 0.2 * y)
+        f_q = y.max(dim=-1)[0].permute(0, 2, 1)                                            # [B,Nq,Cout]
+    return f_q
+
+
+def partseg_features(sd, pc, onehot, fps_starts, train=False, dp_masks=None, drop_mask=None, prefix="point_encoder.",
+                     new_stats=None):
+    """PointTransformer_partseg.forward (point_encoder.py:347-420) -> [B,N,128].
+    fps_starts = (tokenizer [B], level-1 [B], level-2 [B]); drop_mask [B,N,128] multiplicative Dropout(0.5) factors."""
+    pc_np = pc.detach().numpy()
+    B, N, _ = pc_np.shape
+    cidx = fps(pc_np, 512, np.asarray(fps_starts[0]))
+    _, nb, ce = group(pc_np, cidx, 32)
+    x, pos = point_tokens(sd, torch.from_numpy(nb), torch.from_numpy(ce), train, prefix, new_stats)
+    feats = []
+    for l in range(12):
+        dp = dp_masks[l] if dp_masks is not None else (None, None)
+        x = vit_block(sd, f"{prefix}blocks.blocks.{l}.", x + pos, 6, dp[0], dp[1])
+        if l in (3, 7, 11):
+            feats.append(layer_norm(x, sd[prefix + "norm.weight"], sd[prefix + "norm.bias"])[:, 1:])
+    c1 = np.take_along_axis(pc_np, fps(pc_np, 512, np.asarray(fps_starts[1]))[:, :, None], axis=1)
+    c2 = np.take_along_axis(pc_np, fps(pc_np, 256, np.asarray(fps_starts[2]))[:, :, None], axis=1)
+    f0 = torch.cat([onehot[:, None, :].expand(-1, N, -1), pc], dim=-1)                     # [B,N,19]
+    f2 = feature_propagation(sd, prefix + "propagation_2.", c2, ce, torch.from_numpy(c2), feats[1], train, new_stats)
+    f1 = feature_propagation(sd, prefix + "propagation_1.", c1, ce, torch.from_numpy(c1), feats[0], train, new_stats)
+    f2 = dgcnn_propagation(sd, prefix + "dgcnn_pro_2.", ce, feats[2], c2, f2)
+    f1 = dgcnn_propagation(sd, prefix + "dgcnn_pro_1.", c2, f2, c1, f1)
+    f0 = feature_propagation(sd, prefix + "propagation_0.", pc_np, c1, f0, f1, train, new_stats)
+    w = sd[prefix + "conv1.weight"]
+    y = linear(f0.reshape(B * N, -1), w.reshape(w.shape[0], -1), sd[prefix + "conv1.bias"])
+    y = torch.relu(batch_norm_rows(y, sd, prefix + "bn1.", train, new_stats=new_stats)).reshape(B, N, -1)
+    return y if drop_mask is None else y * drop_mask
+
+
+def partseg_logits(sd, pc, onehot, fps_starts, embedding, name_lengths, eot_pos, position="middle", train=False,
+                   dp_masks=None, drop_mask=None, new_stats=None):
+    """ULIP_WITH_IMAGE.forward, task='partseg' (ULIP_models.py:250-283) -> per-point logits [B,N,C]."""
+    feat = partseg_features(sd, pc, onehot, fps_starts, train, dp_masks, drop_mask, new_stats=new_stats)
+    pc_embed = feat @ sd["pc_projection"]
+    prompts = splice_prompts(embedding, sd["prompt_learner.learnable_tokens"], name_lengths, position)
+    te = text_tower(sd, prompts, eot_pos)
+    te = te / te.norm(dim=-1, keepdim=True)
+    return sd["logit_scale"].exp() * pc_embed @ te.t()
+
+
+# ------------------------------------------------------------------------------------------------
 # PointNet2-MSG encoder (models/pointnet2/pointnet2.py:40-73, pointnet2_utils.py:161-266)
 # ------------------------------------------------------------------------------------------------
 PN2_MSG = dict(

@@ -1,0 +1,56 @@
+"""torch.autograd bridges onto the C-ABI GEMM for layers whose WEIGHTS train (the part-segmentation decoder,
+models/pointbert/pointnet2_utils.py:297-467).  The frozen towers do not use these: their forward/backward are
+the hand-scheduled pipelines of ppt_amd.engine."""
+import torch
+
+from . import ops
+
+
+def _pad_k(t, mult, dtype):
+    """[R, K] -> operand copy in `dtype` with K zero-padded to a multiple of `mult`."""
+    R, K = t.shape
+    Kp = (K + mult - 1) // mult * mult
+    if Kp == K:
+        return ops.convert(t.contiguous(), dtype)
+    out = torch.zeros((R, Kp), dtype=dtype, device=t.device)
+    out[:, :K] = t
+    return out
+
+
+class _Linear(torch.autograd.Function):
+    """y[M,N] = x[M,K] @ w[N,K]^T (+ b): forward, dX, dW and db all on ppt_gemm (operand dtype `prec`)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, prec):
+        mult = 8 if prec == torch.bfloat16 else 4
+        x2 = x.detach().float()
+        w2 = w.detach().reshape(w.shape[0], -1).float()
+        xt, wt = _pad_k(x2, mult, prec), _pad_k(w2, mult, prec)
+        y = ops.gemm(xt, wt, out_dtype=torch.float32, bias=b.detach().float().contiguous() if b is not None else None)
+        ctx.save_for_backward(xt, wt)
+        ctx.k, ctx.wshape, ctx.has_bias, ctx.prec = x2.shape[1], w.shape, b is not None, prec
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xt, wt = ctx.saved_tensors
+        prec = ctx.prec
+        dy = dy.contiguous().float()
+        dyt = ops.convert(dy, prec)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm(dyt, ops.transpose(wt), out_dtype=torch.float32)[:, :ctx.k]
+        if ctx.needs_input_grad[1]:
+            mult = 8 if prec == torch.bfloat16 else 4
+            dw = ops.gemm(ops.transpose(dyt, pad_to=mult), ops.transpose(xt, pad_to=mult), out_dtype=torch.float32)
+            dw = dw[:, :ctx.k].reshape(ctx.wshape)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.col_sums(dy)
+        return dx, dw, db, None
+
+
+def linear(x, w, b=None, prec=torch.bfloat16):
+    """x [..., K] -> [..., N] through the MFMA GEMM with gradients for x, w and b."""
+    lead = x.shape[:-1]
+    y = _Linear.apply(x.reshape(-1, x.shape[-1]), w, b, prec)
+    return y.view(*lead, -1)

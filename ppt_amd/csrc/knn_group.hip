@@ -56,7 +56,7 @@ template <int W>
 __global__ __launch_bounds__(W * 64) void knn_group_kernel(const float *__restrict__ xyz,
                                                            const float *__restrict__ center, int N, int G,
                                                            int k, int cpb, int64_t *__restrict__ nbr_idx,
-                                                           float *__restrict__ nbhd)
+                                                           float *__restrict__ nbhd, float *__restrict__ ndist)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     float4 *cloud = reinterpret_cast<float4 *>(smem);                                   // [N]
@@ -106,6 +106,7 @@ __global__ __launch_bounds__(W * 64) void knn_group_kernel(const float *__restri
 
         int64_t *oi = nbr_idx ? nbr_idx + ((size_t)b * G + c) * k : nullptr;
         float *on = nbhd ? nbhd + ((size_t)b * G + c) * k * 3 : nullptr;
+        float *od = ndist ? ndist + ((size_t)b * G + c) * k : nullptr;
         if (cnt <= KNN_CAP) {
             // rank by counting (keys are unique: the index is part of the key)
             for (int e0 = 0; e0 < cnt; e0 += 64) {
@@ -116,6 +117,10 @@ __global__ __launch_bounds__(W * 64) void knn_group_kernel(const float *__restri
                 if (e < cnt && rank < k) {
                     const uint32_t i = (uint32_t)mine;
                     if (oi) oi[rank] = (int64_t)i;
+                    if (od) {
+                        const float4 pt = cloud[i];
+                        od[rank] = expanded_sqdist_rn(qx, qy, qz, nq, pt.x, pt.y, pt.z, pt.w);
+                    }
                     if (on) {
                         const float4 pt = cloud[i];
                         on[rank * 3 + 0] = __fsub_rn(pt.x, qx);
@@ -142,6 +147,10 @@ __global__ __launch_bounds__(W * 64) void knn_group_kernel(const float *__restri
                 have_prev = true;
                 if (lane == 0) {
                     if (oi) oi[r] = (int64_t)ml;
+                    if (od) {
+                        const float4 pt = cloud[ml];
+                        od[r] = expanded_sqdist_rn(qx, qy, qz, nq, pt.x, pt.y, pt.z, pt.w);
+                    }
                     if (on) {
                         const float4 pt = cloud[ml];
                         on[r * 3 + 0] = __fsub_rn(pt.x, qx);
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(W * 64) void ball_query_kernel(const float *__restr
 }  // namespace
 
 extern "C" int ppt_knn_group_f32(const float *xyz, const float *center, int B, int N, int G, int k,
-                                 int64_t *nbr_idx, float *neighborhood, void *stream)
+                                 int64_t *nbr_idx, float *neighborhood, float *nbr_dist, void *stream)
 {
     if (!xyz || !center || B <= 0 || N <= 0 || G <= 0 || k <= 0 || k > 64 || k > N || N > 8192)
         return PPT_EINVAL;
@@ -228,7 +237,7 @@ extern "C" int ppt_knn_group_f32(const float *xyz, const float *center, int B, i
     const int cpb = 32;
     dim3 grid((G + cpb - 1) / cpb, B);
     hipLaunchKernelGGL((knn_group_kernel<W>), grid, dim3(W * 64), lds, ppt_stream(stream), xyz, center, N, G, k,
-                       cpb, nbr_idx, neighborhood);
+                       cpb, nbr_idx, neighborhood, nbr_dist);
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }

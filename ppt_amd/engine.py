@@ -143,7 +143,7 @@ def vit_block_forward(sd, p, wc, x, pos, B, Tn, heads, dp1, dp2, save=None):
     return x_out
 
 
-def point_encoder_forward(sd, p, wc, pc, fps_start, dp, bn_train, save_tier, cfg, update_running=True):
+def point_encoder_forward(sd, p, wc, pc, fps_start, dp, bn_train, save_tier, cfg, update_running=True, fetch=None):
     """PointTransformer.forward (point_encoder.py:234-257) -> (feat [B,2*D] fp32, saved | None).
     dp: DropPath factors [depth,2,B] fp32 or None; save_tier > 0 keeps block-(depth-1) activations."""
     T = wc.dtype
@@ -165,6 +165,7 @@ def point_encoder_forward(sd, p, wc, pc, fps_start, dp, bn_train, save_tier, cfg
     ops.gemm(pe, wc.get(sd[p + "pos_embed.2.weight"]), out=pos2[1:], M=G, bias=sd[p + "pos_embed.2.bias"], batch=B,
              strideA=G * pe.shape[1], strideC=Tn * D)
     saved = None
+    fetched = []
     for l in range(depth):
         bp = f"{p}blocks.blocks.{l}."
         d1 = dp[l, 0] if dp is not None else None
@@ -174,6 +175,11 @@ def point_encoder_forward(sd, p, wc, pc, fps_start, dp, bn_train, save_tier, cfg
             x2 = vit_block_forward(sd, bp, wc, x2, pos2, B, Tn, heads, d1, d2, save=saved)
         else:
             x2 = vit_block_forward(sd, bp, wc, x2, pos2, B, Tn, heads, d1, d2)
+        if fetch is not None and l in fetch:        # part-seg: norm(x)[:, 1:] after blocks 3, 7, 11 (point_encoder.py:100-108,377)
+            fn, _, _ = ops.layernorm_fwd(x2, sd[p + "norm.weight"], sd[p + "norm.bias"], torch.float32)
+            fetched.append(fn.view(B, Tn, D)[:, 1:])
+    if fetch is not None:
+        return fetched, center
     keep = saved is not None
     xn, meanf, rstdf = ops.layernorm_fwd(x2, sd[p + "norm.weight"], sd[p + "norm.bias"], torch.float32, save_stats=keep)
     feat, argmax = ops.cls_max_pool(xn.view(B, Tn, D), want_argmax=keep)

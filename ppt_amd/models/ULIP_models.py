@@ -411,6 +411,31 @@ def _load_and_freeze(model, args, point_ckpt, skip):
             param.data.copy_(src.data if isinstance(src, nn.Parameter) else src)
 
 
+def ULIP_PointBERT_partseg(args):
+    """ULIP_models.py:515-569: PointBERT part-segmentation encoder/decoder (pc_feat_dims 128).  Trainable = the
+    prompt tokens + every point-encoder parameter that the ULIP PointBERT checkpoint does not contain (the
+    decoder); nothing is copied from the checkpoint here, exactly as in the reference."""
+    from .pointbert.point_encoder import PointTransformer, PointTransformer_partseg
+    here = os.path.dirname(os.path.abspath(__file__))
+    config_addr = os.path.join(os.path.dirname(here), 'models/pointbert/PointTransformer_8192point.yaml')
+    config = cfg_from_yaml_file(config_addr).model if os.path.exists(config_addr) else POINTBERT_CONFIG
+    point_encoder = PointTransformer_partseg(config, args=args)
+    model = ULIP_WITH_IMAGE(embed_dim=512, point_encoder=point_encoder, context_length=77, vocab_size=49408,
+                            classnames=args.classnames, template_init=args.template_init,
+                            class_name_position=args.class_name_position,
+                            num_learnable_prompt_tokens=args.num_learnable_prompt_tokens, transformer_width=512,
+                            transformer_heads=8, transformer_layers=12, pc_feat_dims=128, device=args.gpu, task=args.task)
+    if not getattr(args, "evaluate_3d", False):
+        backbone = {"point_encoder." + k for k in PointTransformer(config, args=args).state_dict()}   # keys of the ULIP ckpt
+        for name, param in model.named_parameters():
+            if name.startswith('prompt_learner'):
+                continue
+            if name.startswith('point_encoder.') and name not in backbone:
+                continue
+            param.requires_grad = False
+    return model
+
+
 def ULIP_PN_MSG(args):
     """ULIP_models.py:347-391: PointNet2-MSG point encoder (pc_feat_dims 256); everything except
     `prompt_learner.learnable_tokens` is frozen."""

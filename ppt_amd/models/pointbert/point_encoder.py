@@ -4,7 +4,7 @@ forward of PointTransformer is ONE autograd node running ppt_amd.engine's kernel
 import torch
 import torch.nn as nn
 
-from ... import engine
+from ... import engine, ops
 from .dvae import Encoder, Group
 
 
@@ -202,3 +202,100 @@ class PointTransformer(nn.Module):
                 names += [f"blocks.blocks.{self.depth - 1}.{n}" for n in TIER_PARAMS[t]]
         sd = self._live_state()
         return _PointEncoderFn.apply(self, pts, start, dp, tier, names, *[sd[n] for n in names])
+
+
+class PointTransformer_partseg(nn.Module):
+    """point_encoder.py:260-420.  forward(pts [B,N,3], cls_label one-hot [B,16]) -> per-point features [B,N,128].
+    The PointBERT backbone (tokenizer + 12 blocks, frozen in PPT: ULIP_models.py:550-565) runs on the engine
+    pipeline; the decoder modules keep the reference names (propagation_{0,1,2}, dgcnn_pro_{1,2}, conv1, bn1, drop1,
+    conv2 -- conv2 is unused by forward, as in the reference)."""
+
+    def __init__(self, config, **kwargs):
+        super().__init__()
+        from .pointnet2_utils import DGCNN_Propagation, PointNetFeaturePropagation
+        self.config = config
+        self.trans_dim = config.trans_dim
+        self.depth = config.depth
+        self.drop_path_rate = config.drop_path_rate
+        self.cls_dim = config.cls_dim
+        self.num_heads = config.num_heads
+        self.group_size = config.group_size
+        self.num_group = config.num_group
+        self.group_divider = Group(num_group=self.num_group, group_size=self.group_size)
+        self.encoder_dims = config.encoder_dims
+        self.encoder = Encoder(encoder_channel=self.encoder_dims)
+        self.reduce_dim = nn.Linear(self.encoder_dims, self.trans_dim)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, self.trans_dim))
+        self.cls_pos = nn.Parameter(torch.randn(1, 1, self.trans_dim))
+        self.pos_embed = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, self.trans_dim))
+        dpr = [x.item() for x in torch.linspace(0, self.drop_path_rate, self.depth)]
+        self.dpr = dpr
+        self.blocks = TransformerEncoder(embed_dim=self.trans_dim, depth=self.depth, drop_path_rate=dpr,
+                                         num_heads=self.num_heads)
+        self.norm = nn.LayerNorm(self.trans_dim)
+        self.propagation_2 = PointNetFeaturePropagation(in_channel=self.trans_dim + 3, mlp=[self.trans_dim * 4, self.trans_dim])
+        self.propagation_1 = PointNetFeaturePropagation(in_channel=self.trans_dim + 3, mlp=[self.trans_dim * 4, self.trans_dim])
+        self.propagation_0 = PointNetFeaturePropagation(in_channel=self.trans_dim + 3 + 16,
+                                                        mlp=[self.trans_dim * 4, self.trans_dim])
+        self.dgcnn_pro_1 = DGCNN_Propagation(k=4)
+        self.dgcnn_pro_2 = DGCNN_Propagation(k=4)
+        self.conv1 = nn.Conv1d(self.trans_dim, 128, 1)
+        self.bn1 = nn.BatchNorm1d(128)
+        self.drop1 = nn.Dropout(0.5)
+        self.conv2 = nn.Conv1d(128, self.cls_dim, 1)
+        self._precision = torch.bfloat16
+        self.fps_start = None            # (tokenizer [B], level-1 [B], level-2 [B]) injected FPS starts
+        self.drop_path_factors = None    # [depth,2,B]
+        self.dropout_mask = None         # [B,N,128] multiplicative Dropout(0.5) factors
+        self._wc = None
+        self._sd = None
+
+    @property
+    def precision(self):
+        return self._precision
+
+    @precision.setter
+    def precision(self, dtype):
+        self._precision = dtype
+        for m in (self.propagation_0, self.propagation_1, self.propagation_2, self.dgcnn_pro_1, self.dgcnn_pro_2):
+            m.precision = dtype
+
+    _cache = PointTransformer._cache
+    _cfg = PointTransformer._cfg
+    _draw_drop_path = PointTransformer._draw_drop_path
+
+    def _live_state(self):
+        return self.state_dict(keep_vars=True)
+
+    def forward(self, pts, cls_label):
+        from ...autograd import linear
+        pts = pts.contiguous().float()
+        B, N, _ = pts.shape
+        dev = pts.device
+        if self.fps_start is not None:
+            s0, s1, s2 = (t.to(dev).contiguous() for t in self.fps_start)
+        else:                                        # three independent random starts (SURVEY App. A Q10)
+            s0, s1, s2 = (torch.randint(0, N, (B,), dtype=torch.long, device=dev) for _ in range(3))
+        dp = self._draw_drop_path(B, dev)
+        with torch.no_grad():                        # frozen backbone: features after blocks 3, 7, 11 (+ final LN, cls dropped)
+            feats, center = engine.point_encoder_forward(self._live_state(), "", self._cache(), pts, s0, dp, self.training, 0,
+                                                         self._cfg(), fetch=(3, 7, 11))
+            _, c1 = ops.fps(pts, 512, s1)
+            _, c2 = ops.fps(pts, 256, s2)
+        f0 = torch.cat([cls_label.float().view(B, 1, 16).expand(-1, N, -1), pts], dim=-1)       # [B,N,19]
+        f2 = self.propagation_2(c2, center, c2, feats[1])
+        f1 = self.propagation_1(c1, center, c1, feats[0])
+        f2 = self.dgcnn_pro_2(center, feats[2], c2, f2)
+        f1 = self.dgcnn_pro_1(c2, f2, c1, f1)
+        f0 = self.propagation_0(pts, c1, f0, f1)
+        y = linear(f0.reshape(B * N, -1), self.conv1.weight, self.conv1.bias, self._precision)
+        y = torch.relu(torch.nn.functional.batch_norm(y, self.bn1.running_mean, self.bn1.running_var, self.bn1.weight,
+                                                      self.bn1.bias, self.training, self.bn1.momentum, self.bn1.eps))
+        if self.training:
+            self.bn1.num_batches_tracked += 1
+        y = y.view(B, N, -1)
+        if self.dropout_mask is not None:
+            y = y * self.dropout_mask.to(dev)
+        elif self.training:
+            y = self.drop1(y)
+        return y

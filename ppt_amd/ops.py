@@ -87,8 +87,8 @@ def fps(xyz, M, start):
     return idx, ctr
 
 
-def knn_group(xyz, center, k, want_idx=True, want_nbhd=True):
-    """H2.  xyz [B,N,3], center [B,G,3] -> (nbr_idx [B,G,k] i64, neighborhood [B,G,k,3] f32)."""
+def knn_group(xyz, center, k, want_idx=True, want_nbhd=True, want_dist=False):
+    """H2.  xyz [B,N,3], center [B,G,3] -> (nbr_idx [B,G,k] i64, neighborhood [B,G,k,3] f32[, dist [B,G,k] f32])."""
     _chk(xyz, torch.float32, "xyz"); _chk(center, torch.float32, "center")
     B, N, _ = xyz.shape
     G = center.shape[1]
@@ -96,11 +96,12 @@ def knn_group(xyz, center, k, want_idx=True, want_nbhd=True):
     nb = torch.empty((B, G, k, 3), dtype=torch.float32, device=xyz.device) if want_nbhd else None
     if profiler is not None:
         profiler.begin("knn_group", float(B) * (12 * N + 12 * G + 8 * G * k + 12 * G * k))
-    _lib.check(_lib.lib().ppt_knn_group_f32(_p(xyz), _p(center), B, N, G, k, _p(idx), _p(nb), _stream()),
+    nd = torch.empty((B, G, k), dtype=torch.float32, device=xyz.device) if want_dist else None
+    _lib.check(_lib.lib().ppt_knn_group_f32(_p(xyz), _p(center), B, N, G, k, _p(idx), _p(nb), _p(nd), _stream()),
                "ppt_knn_group_f32")
     if profiler is not None:
         profiler.end()
-    return idx, nb
+    return (idx, nb, nd) if want_dist else (idx, nb)
 
 
 def ball_query(xyz, center, radius, K, want_grouped=False):

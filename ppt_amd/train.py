@@ -49,9 +49,11 @@ class FlatGradSync:
             off += p.numel()
 
     def all_reduce(self):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if dist.is_available() and dist.is_initialized():
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat.div_(dist.get_world_size(self.group))
+            w = dist.get_world_size(self.group)
+            if w > 1:
+                self.flat.div_(w)
 
 
 class BufferBroadcast:
@@ -76,8 +78,7 @@ class BufferBroadcast:
                 off += b.numel()
 
     def broadcast(self):
-        if self.flat is not None and dist.is_available() and dist.is_initialized() \
-                and dist.get_world_size(self.group) > 1:
+        if self.flat is not None and dist.is_available() and dist.is_initialized():
             dist.broadcast(self.flat, src=0, group=self.group)
 
 

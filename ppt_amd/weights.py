@@ -64,6 +64,29 @@ def ulip_spec(pc_feat_dims=768, with_token_embedding=True):
     return s
 
 
+def partseg_decoder_spec(prefix="point_encoder."):
+    """(key, shape) list of the decoder that PointTransformer_partseg adds to the PointBERT backbone
+    (point_encoder.py:299-310)."""
+    p, s = prefix, []
+
+    def bn(q, c):
+        return [(q + k, (c,)) for k in ("weight", "bias", "running_mean", "running_var")] + [(q + "num_batches_tracked", ())]
+    for name, cin in (("propagation_2", 387), ("propagation_1", 387), ("propagation_0", 403)):
+        s += [(f"{p}{name}.mlp_convs.0.weight", (1536, cin, 1)), (f"{p}{name}.mlp_convs.0.bias", (1536,)),
+              (f"{p}{name}.mlp_convs.1.weight", (384, 1536, 1)), (f"{p}{name}.mlp_convs.1.bias", (384,))]
+        s += bn(f"{p}{name}.mlp_bns.0.", 1536) + bn(f"{p}{name}.mlp_bns.1.", 384)
+    for name in ("dgcnn_pro_1", "dgcnn_pro_2"):
+        s += [(f"{p}{name}.layer1.0.weight", (512, 768, 1, 1)), (f"{p}{name}.layer1.1.weight", (512,)), (f"{p}{name}.layer1.1.bias", (512,)),
+              (f"{p}{name}.layer2.0.weight", (384, 1024, 1, 1)), (f"{p}{name}.layer2.1.weight", (384,)), (f"{p}{name}.layer2.1.bias", (384,))]
+    s += [(p + "conv1.weight", (128, 384, 1)), (p + "conv1.bias", (128,))] + bn(p + "bn1.", 128)
+    s += [(p + "conv2.weight", (40, 128, 1)), (p + "conv2.bias", (40,))]
+    return s
+
+
+def ulip_partseg_state_dict(seed=0, with_token_embedding=False, as_torch=True):
+    return synth_state_dict(ulip_spec(128, with_token_embedding) + pointbert_spec() + partseg_decoder_spec(), seed, as_torch)
+
+
 PN2_MSG = dict(   # models/pointnet2/pointnet2.py:44-46
     sa1=dict(npoint=512, radii=[0.1, 0.2, 0.4], nsample=[16, 32, 128], in_channel=0,
              mlps=[[32, 32, 64], [64, 64, 128], [64, 96, 128]]),
@@ -123,7 +146,8 @@ def synth_tensor(key, shape, seed=0):
     if leaf == "running_var":
         return (1.0 + 0.5 * r.random(shape)).astype(np.float32)
     is_norm = any(t in key for t in (".norm1.", ".norm2.", ".norm.", ".ln_1.", ".ln_2.", "ln_final.",
-                                     "first_conv.1.", "second_conv.1.", "mlp_bns", ".bn", "bn_blocks"))
+                                     "first_conv.1.", "second_conv.1.", "mlp_bns", ".bn", "bn_blocks",
+                                     "layer1.1.", "layer2.1."))
     if is_norm and leaf == "weight":
         return (1.0 + 0.1 * r.standard_normal(shape)).astype(np.float32)
     if leaf in ("bias", "in_proj_bias"):

@@ -317,6 +317,88 @@ def gen_pointnet2_msg():
     np.savez_compressed(os.path.join(HERE, "g_pn2msg.npz"), **out)
 
 
+def gen_partseg(tok):
+    """G8: ULIP_PointBERT_partseg train step (main_partseg.py:204-215) on B=2 x 2048 points with duplicates."""
+    import argparse
+    names = tok["datasets"]["shapenetpart"]
+    name_lengths = [len(tok["name_tokens"][n.replace("_", " ")]) for n in names]
+    sd = W.ulip_partseg_state_dict(seed=0)
+    emb = W.synth_prompt_embedding(len(names), seed=0)
+    B, N = 2, 2048
+    pc_np, s0 = W.synth_clouds(B, N, seed=55, duplicates=True)
+    _, s1 = W.synth_clouds(B, N, seed=56)
+    _, s2 = W.synth_clouds(B, N, seed=57)
+    pc = torch.from_numpy(pc_np)
+    rng = np.random.default_rng(6)
+    onehot = torch.zeros(B, 16)
+    onehot[0, 3] = 1
+    onehot[1, 11] = 1
+    labels = torch.from_numpy(rng.integers(0, 50, size=(B, N)))
+    masks = [(torch.from_numpy((np.floor(0.95 + rng.random(B)) / 0.95).astype(np.float32)),
+              torch.from_numpy((np.floor(0.95 + rng.random(B)) / 0.95).astype(np.float32))) for _ in range(12)]
+    drop = torch.from_numpy((rng.random((B, N, 128)) > 0.5).astype(np.float32) * 2.0)
+    with R.reference_context():
+        import models.ULIP_models as M
+        from models.pointbert.point_encoder import PointTransformer_partseg
+        cfg = M.cfg_from_yaml_file("./models/pointbert/PointTransformer_8192point.yaml")
+        pe = PointTransformer_partseg(cfg.model, args=argparse.Namespace())
+        m = M.ULIP_WITH_IMAGE(embed_dim=512, point_encoder=pe, context_length=77, vocab_size=49408, classnames=names,
+                              template_init="", class_name_position="middle", num_learnable_prompt_tokens=32,
+                              transformer_width=512, transformer_heads=8, transformer_layers=12, pc_feat_dims=128, device=0,
+                              task="partseg")
+    backbone = {k for k, _ in W.pointbert_spec()}
+    for name, param in m.named_parameters():        # ULIP_models.py:550-565: backbone + text tower frozen, decoder + prompt train
+        if name.startswith("prompt_learner") or (name.startswith("point_encoder.") and name not in backbone):
+            continue
+        param.requires_grad = False
+    load_into_reference(m, sd, emb)
+    eot = m.tokenized_prompts.argmax(-1).numpy()
+    m.train()
+    set_droppath(m, masks)
+    pe.drop1.forward = lambda x: x * drop.permute(0, 2, 1)
+    starts = [torch.from_numpy(s0), torch.from_numpy(s1), torch.from_numpy(s2)]
+    orig = torch.randint
+    torch.randint = lambda *a, **k: starts.pop(0)
+    try:
+        pred = m(pc, onehot)
+        loss = torch.nn.CrossEntropyLoss(label_smoothing=0.2)(pred.reshape(-1, 50), labels.reshape(-1))
+        loss.backward()
+    finally:
+        torch.randint = orig
+    grads = {k: p.grad.clone() for k, p in m.named_parameters() if p.requires_grad and p.grad is not None}
+    nograd = [k for k, p in m.named_parameters() if p.requires_grad and p.grad is None]
+    print("trainable without grad (unused in forward):", nograd)
+
+    sd2 = dict(sd)
+    keys = sorted(grads)
+    for k in keys:
+        sd2[k] = sd[k].detach().clone().requires_grad_(True)
+    ns = {}
+    lo = O.partseg_logits(sd2, pc, onehot, (s0, s1, s2), emb, name_lengths, eot, train=True, dp_masks=masks, drop_mask=drop,
+                          new_stats=ns)
+    lo_loss = O.cross_entropy_ls(lo.reshape(-1, 50), labels.reshape(-1), 0.2)
+    og = torch.autograd.grad(lo_loss, [sd2[k] for k in keys])
+    e = (pred.detach() - lo.detach()).abs().max().item()
+    print(f"partseg logits max|ref-oracle| {e:.3e} (|logits|max {pred.abs().max().item():.2f}); loss {loss.item():.6f} vs {lo_loss.item():.6f}")
+    assert e < 2e-2 and abs(loss.item() - lo_loss.item()) < 1e-4
+    fx = dict(logits_sub=pred.detach()[:, ::16].numpy(), loss=np.float32(loss.item()), labels=labels.numpy().astype(np.int16),
+              eot=eot.astype(np.int16), s0=s0, s1=s1, s2=s2, onehot=onehot.numpy(),
+              dp_masks=np.stack([np.stack([a.numpy(), b.numpy()]) for a, b in masks]), drop=np.packbits(drop.numpy() > 0))
+    for k, g in zip(keys, og):
+        rel = ((grads[k] - g).norm() / (grads[k].norm() + 1e-30)).item()
+        print(f"  grad {k}: |g| {grads[k].norm().item():.3e} rel.err {rel:.2e}")
+        # a bias in front of BatchNorm has zero gradient (noise only); BN-adjacent sums cancel heavily -> 3e-2
+        assert rel < 3e-2 or grads[k].norm().item() < 1e-4, k
+        fx["gradnorm_" + k] = np.float64(grads[k].double().norm().item())
+        fx["gradsub_" + k] = grads[k].flatten()[::211].numpy()
+    msd = m.state_dict()
+    for k in ("point_encoder.propagation_0.mlp_bns.1.running_var", "point_encoder.bn1.running_mean"):
+        assert (msd[k] - ns[k]).abs().max().item() < 1e-4
+        fx["stat_" + k] = msd[k].numpy()
+    fx["trainable"] = np.array(sorted(k for k, p in m.named_parameters() if p.requires_grad))
+    np.savez_compressed(os.path.join(HERE, "g_partseg.npz"), **fx)
+
+
 if __name__ == "__main__":
     assert R.reference_available(), "needs /root/reference"
     O.build_c_oracle(force=True)
@@ -324,4 +406,5 @@ if __name__ == "__main__":
     gen_index()
     gen_encoder_and_step(tok)
     gen_pointnet2_msg()
+    gen_partseg(tok)
     print("done")
