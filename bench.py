@@ -41,24 +41,29 @@ CONFIGS = {   # BASELINE.json configs[1] (headline) and configs[2] (secondary, -
                name="C3: ScanObjectNN (PB_T50_RS shape) 2048-pt PointBERT + PointAdapter (head_type=3: last block un-frozen)"),
     "C4": dict(dataset="modelnet40", batch=32, npoints=8192, head_type=0, model="ULIP_PN_MSG",
                name="C4: ModelNet40 8192-pt PointNet2-MSG encoder (ULIP_PN_MSG, frozen) + PromptLearner, 32 clouds per GPU"),
+    "C5": dict(dataset="shapenetpart", batch=16, npoints=2048, head_type=0, model="ULIP_PointBERT_partseg", task="partseg",
+               name="C5: ShapeNetPart 2048-pt part segmentation (ULIP_PointBERT_partseg: frozen PointBERT + trainable decoder "
+                    "+ PromptLearner), per-point logits, 16 clouds per GPU"),
 }
 METRICS = {"C2": "point-clouds/sec fwd+bwd, PointBERT 1024-pt ModelNet40",
            "C3": "point-clouds/sec fwd+bwd, PointBERT 2048-pt ScanObjectNN + PointAdapter",
-           "C4": "point-clouds/sec fwd+bwd, PointNet2-MSG 8192-pt ModelNet40"}
+           "C4": "point-clouds/sec fwd+bwd, PointNet2-MSG 8192-pt ModelNet40",
+           "C5": "point-clouds/sec fwd+bwd, PointBERT part-seg 2048-pt ShapeNetPart"}
 PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def build_model(dataset="modelnet40", head_type=HEAD_TYPE, precision=torch.bfloat16, model="ULIP_PointBERT"):
+def build_model(dataset="modelnet40", head_type=HEAD_TYPE, precision=torch.bfloat16, model="ULIP_PointBERT", task="cls"):
     from ppt_amd import weights as W
     from ppt_amd.models import ULIP_models as M
     import contextlib
     import io
     args = SimpleNamespace(classnames=M.dataset_classnames(dataset), template_init='', class_name_position='middle',
-                           num_learnable_prompt_tokens=32, gpu=torch.cuda.current_device(), task='cls',
+                           num_learnable_prompt_tokens=32, gpu=torch.cuda.current_device(), task=task,
                            head_type=head_type, evaluate_3d=False, ulip2=False)
     with contextlib.redirect_stdout(io.StringIO()):
         m = getattr(M, model)(args)
-    sd = W.ulip_pointbert_state_dict(seed=0) if model == "ULIP_PointBERT" else W.ulip_pn2_msg_state_dict(seed=0)
+    sd = {"ULIP_PointBERT": W.ulip_pointbert_state_dict, "ULIP_PN_MSG": W.ulip_pn2_msg_state_dict,
+          "ULIP_PointBERT_partseg": W.ulip_partseg_state_dict}[model](seed=0)
     m.load_state_dict(sd, strict=False)
     m.prompt_learner.embedding = W.synth_prompt_embedding(len(args.classnames), seed=0)
     m.cuda()
@@ -121,13 +126,18 @@ def main():
     cfg = CONFIGS[a.config]
     global PER_GPU_BATCH, NPOINTS
     PER_GPU_BATCH, NPOINTS = cfg["batch"], cfg["npoints"]
-    model = build_model(cfg["dataset"], cfg["head_type"], model=cfg.get("model", "ULIP_PointBERT"))
+    model = build_model(cfg["dataset"], cfg["head_type"], model=cfg.get("model", "ULIP_PointBERT"), task=cfg.get("task", "cls"))
+    partseg = cfg.get("task") == "partseg"
     n_classes = len(model.prompt_learner.classnames)
     model.train()
     trainer = Trainer(model, lr=3e-3, label_smoothing=0.2, distributed=world > 1 or force_dist)
     pc_np, _ = W.synth_clouds(PER_GPU_BATCH, NPOINTS, seed=1234 + rank)
     pc = torch.from_numpy(pc_np).cuda()
-    label = torch.from_numpy(np.random.default_rng(rank).integers(0, n_classes, size=(PER_GPU_BATCH,))).cuda()
+    lab_shape = (PER_GPU_BATCH, NPOINTS) if partseg else (PER_GPU_BATCH,)
+    label = torch.from_numpy(np.random.default_rng(rank).integers(0, n_classes, size=lab_shape)).cuda()
+    if partseg:                                    # main_partseg.py:210: model(pc, one-hot of the 16 shape categories)
+        onehot = torch.nn.functional.one_hot(torch.arange(PER_GPU_BATCH) % 16, 16).float().cuda()
+        trainer.extra_inputs = (onehot,)
 
     def barrier():
         if world > 1 or force_dist:

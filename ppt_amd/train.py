@@ -94,6 +94,7 @@ class Trainer:
                                            eps=eps, weight_decay=wd, capturable=capturable)
         self.lr_schedule = lr_schedule
         self.it = 0
+        self.extra_inputs = ()        # e.g. the one-hot shape category of main_partseg.py:210
         if distributed is None:
             distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         self.distributed = distributed
@@ -112,8 +113,8 @@ class Trainer:
                 g['lr'] = float(self.lr_schedule[min(self.it, len(self.lr_schedule) - 1)])
         if self.bcast is not None:
             self.bcast.broadcast()
-        pred = model(pc)                                            # main_cls.py:194
-        loss = self.criterion(pred, label)
+        pred = model(pc, *self.extra_inputs)                        # main_cls.py:194 / main_partseg.py:210
+        loss = self.criterion(pred.reshape(-1, pred.shape[-1]), label.reshape(-1))     # main_partseg.py:213
         loss.backward()                                             # (retain_graph only served Q2)
         if self.distributed:
             self.sync.all_reduce()
