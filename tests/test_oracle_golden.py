@@ -125,3 +125,37 @@ def test_train_step(head_type):
 def test_cosine_scheduler():
     s = O.cosine_scheduler(3e-3, 1e-5, 5, 10, warmup_epochs=1, start_warmup_value=1e-6)
     assert len(s) == 50 and abs(s[0] - 1e-6) < 1e-12 and abs(s[9] - 3e-3) < 1e-12 and s[-1] > 1e-5
+
+
+def test_pointnet2_msg_oracle_vs_golden():
+    g = np.load(os.path.join(G, "g_pn2msg.npz"))
+    sd = W.synth_state_dict(W.pointnet2_msg_spec(prefix=""), seed=0)
+    pc, s1 = W.synth_clouds(2, 1024, seed=31)
+    dm = (torch.from_numpy(g["drop1"]), torch.from_numpy(g["drop2"]))
+    with torch.no_grad():
+        ev = O.pointnet2_msg(sd, torch.from_numpy(pc), (g["start1"], g["start2"]), train=False, prefix="")
+        ns = {}
+        tr = O.pointnet2_msg(sd, torch.from_numpy(pc), (g["start1"], g["start2"]), train=True, drop_masks=dm, prefix="",
+                             new_stats=ns)
+    assert np.abs(ev.numpy() - g["eval"]).max() < 1e-6
+    assert np.abs(tr.numpy() - g["train"]).max() < 1e-3          # BatchNorm1d over a batch of 2 amplifies rounding
+    for k in ("sa1.bn_blocks.2.2.running_var", "sa3.mlp_bns.2.running_var"):
+        assert np.abs(ns[k].numpy() - g["stat_" + k]).max() < 1e-4 * max(1.0, np.abs(g["stat_" + k]).max())
+
+
+def test_partseg_oracle_forward_vs_golden():
+    g = np.load(os.path.join(G, "g_partseg.npz"))
+    tok = json.load(open(os.path.join(ROOT, "ppt_amd", "data", "classnames.json")))
+    names = tok["datasets"]["shapenetpart"]
+    nl = [len(tok["name_tokens"][n.replace("_", " ")]) for n in names]
+    sd = W.ulip_partseg_state_dict(seed=0)
+    emb = W.synth_prompt_embedding(50, seed=0)
+    pc, _ = W.synth_clouds(2, 2048, seed=55, duplicates=True)
+    masks = [(torch.from_numpy(a[0]), torch.from_numpy(a[1])) for a in g["dp_masks"]]
+    drop = torch.from_numpy(np.unpackbits(g["drop"]).reshape(2, 2048, 128).astype(np.float32) * 2.0)
+    with torch.no_grad():
+        lo = O.partseg_logits(sd, torch.from_numpy(pc), torch.from_numpy(g["onehot"]), (g["s0"], g["s1"], g["s2"]), emb, nl,
+                              g["eot"].astype(np.int64), train=True, dp_masks=masks, drop_mask=drop)
+        loss = O.cross_entropy_ls(lo.reshape(-1, 50), torch.from_numpy(g["labels"].astype(np.int64)).reshape(-1), 0.2)
+    assert np.abs(lo[:, ::16].numpy() - g["logits_sub"]).max() < 2e-3
+    assert abs(loss.item() - float(g["loss"])) < 1e-4

@@ -101,3 +101,22 @@ def test_cpu_tensor_is_rejected_loudly():
     from ppt_amd import ops
     with pytest.raises(RuntimeError, match="no CPU path"):
         ops.fps(torch.zeros(1, 8, 3), 4, torch.zeros(1, dtype=torch.long))
+
+
+def test_other_factories_state_dicts():
+    """ULIP_PN_MSG (C4) and ULIP_PointBERT_partseg (C5): reference state-dict layouts and trainable sets."""
+    import models.ULIP_models as models
+    a = SimpleNamespace(classnames=models.dataset_classnames("shapenetpart"), template_init='', class_name_position='middle',
+                        num_learnable_prompt_tokens=32, gpu=0, task='partseg', head_type=0, evaluate_3d=False, ulip2=False)
+    m = models.ULIP_PointBERT_partseg(a)
+    spec = dict(W.ulip_spec(128, True) + W.pointbert_spec() + W.partseg_decoder_spec())
+    assert set(m.state_dict()) == set(spec)
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == 5242152          # SURVEY.md §2.5
+    a.task, a.classnames = 'cls', models.dataset_classnames("modelnet40")
+    m = models.ULIP_PN_MSG(a)
+    spec = dict(W.ulip_spec(256, True) + W.pointnet2_msg_spec())
+    sd = m.state_dict()
+    assert set(sd) == set(spec) and all(tuple(sd[k].shape) == tuple(v) for k, v in spec.items())
+    assert [n for n, p in m.named_parameters() if p.requires_grad] == ["prompt_learner.learnable_tokens"]
+    from models.pointnet2.pointnet2 import Pointnet2_Msg                                   # noqa: F401
+    from models.pointbert.pointnet2_utils import PointNetFeaturePropagation, DGCNN_Propagation   # noqa: F401
