@@ -248,6 +248,7 @@ class ULIP_WITH_IMAGE(nn.Module):
         self._sd = None
         self._eot_pos = None
         self._text_stream = None
+        self._te_cache = None
         self.overlap_text_tower = True      # run the (input-independent) text tower on a side stream
         self.truncate_text_to_eot = True    # causal mask + EOT pooling: positions after the last EOT are dead work
 
@@ -333,9 +334,18 @@ class ULIP_WITH_IMAGE(nn.Module):
         return matmul_nt(pc_feat.reshape(-1, pc_feat.shape[-1]), wt).view(*lead, -1)
 
     def _text_embed(self):
+        # inference fast path: the text features depend only on the prompt tokens, so
+        # validate() (main_cls.py:237-299) needs them once per epoch, not once per batch
+        tok = self.prompt_learner.learnable_tokens
+        if not torch.is_grad_enabled() and self._te_cache is not None and self._te_cache[0] == (tok._version, tok.data_ptr(),
+                                                                                               self.precision):
+            return self._te_cache[1]
         prompts = self.prompt_learner()
         text_embed = self.encode_text(prompts, self.tokenized_prompts)
-        return text_embed / text_embed.norm(dim=-1, keepdim=True)
+        text_embed = text_embed / text_embed.norm(dim=-1, keepdim=True)
+        if not torch.is_grad_enabled():
+            self._te_cache = ((tok._version, tok.data_ptr(), self.precision), text_embed)
+        return text_embed
 
     def forward(self, pc, cls_label=None):
         """ULIP_models.py:260-283 -> logits [B,C] (partseg: [B,N,C])."""

@@ -124,3 +124,28 @@ class Trainer:
         model.logit_scale.data.clamp_(0, 4.6052)                    # main_cls.py:213
         self.it += 1
         return loss, pred
+
+
+def checkpoint_payload(model, optimizer, epoch, best_acc, args, head_type=0, partseg=False):
+    """The dict the reference writes as checkpoint_best.pt: main_cls.py:118-137 saves the
+    prompt learner ('state_dict' = {'learnable_tokens'}), the last block when head_type > 0, the optimizer and args;
+    main_partseg.py:127-143 saves the whole point encoder under 'state_dict_partseg'.  Keys are the reference's, so
+    save_recog_feats.py:29-35 / interpret_prompt.py:25-28 style readers work on it."""
+    data = {'epoch': epoch + 1, 'state_dict': model.prompt_learner.state_dict(), 'optimizer': optimizer.state_dict(),
+            'best_acc': best_acc, 'args': args}
+    if partseg:
+        data['state_dict_partseg'] = model.point_encoder.state_dict()
+    else:
+        data['last_block'] = model.point_encoder.blocks.blocks[-1].state_dict() if head_type > 0 else None
+    return data
+
+
+def load_prompt_checkpoint(model, ckpt):
+    """Inverse of checkpoint_payload for evaluation (save_recog_feats.py:29-35): prompt tokens + optional last block."""
+    model.prompt_learner.load_state_dict(ckpt['state_dict'])
+    if ckpt.get('last_block'):
+        blk = {'point_encoder.blocks.blocks.11.' + k: v for k, v in ckpt['last_block'].items()}
+        model.load_state_dict(blk, strict=False)
+    if ckpt.get('state_dict_partseg'):
+        model.point_encoder.load_state_dict(ckpt['state_dict_partseg'])
+    return model

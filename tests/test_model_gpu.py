@@ -326,3 +326,19 @@ def test_partseg_train_step_matches_golden(precision):
             # sums with heavy cancellation and are only pinned in fp32 mode.)
             cos = float(np.dot(sub, ref) / (np.linalg.norm(sub) * np.linalg.norm(ref)))
             assert cos > 0.85, (k, cos)
+
+
+def test_eval_text_cache_fast_path():
+    """validate()-style inference: text features are computed once and reused until the prompt tokens change."""
+    m, _ = build(0, torch.bfloat16)
+    m.eval()
+    pc, start = oracle_inputs()
+    m.point_encoder.fps_start = torch.from_numpy(start).cuda()
+    with torch.no_grad():
+        a = m(pc.cuda())
+        te = m._te_cache[1]
+        b = m(pc.cuda())
+        assert m._te_cache[1] is te and torch.equal(a, b)
+        m.prompt_learner.learnable_tokens.add_(0.01)          # in-place update bumps the version -> cache refreshed
+        c = m(pc.cuda())
+        assert m._te_cache[1] is not te and not torch.equal(a, c)

@@ -120,3 +120,19 @@ def test_other_factories_state_dicts():
     assert [n for n, p in m.named_parameters() if p.requires_grad] == ["prompt_learner.learnable_tokens"]
     from models.pointnet2.pointnet2 import Pointnet2_Msg                                   # noqa: F401
     from models.pointbert.pointnet2_utils import PointNetFeaturePropagation, DGCNN_Propagation   # noqa: F401
+
+
+def test_checkpoint_payload_roundtrip(tmp_path):
+    """reference checkpoint_best.pt layout (main_cls.py:132-137) written and read back."""
+    from ppt_amd.train import checkpoint_payload, load_prompt_checkpoint
+    m, _ = make(3)
+    opt = torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-3)
+    payload = checkpoint_payload(m, opt, epoch=4, best_acc=91.5, args={"model": "ULIP_PointBERT"}, head_type=3)
+    assert set(payload) == {'epoch', 'state_dict', 'optimizer', 'best_acc', 'args', 'last_block'}
+    assert list(payload['state_dict']) == ['learnable_tokens'] and 'attn.qkv.weight' in payload['last_block']
+    f = tmp_path / "checkpoint_best.pt"
+    torch.save(payload, f)
+    m2, _ = make(3)
+    load_prompt_checkpoint(m2, torch.load(f, weights_only=False))
+    assert torch.equal(m2.prompt_learner.learnable_tokens, m.prompt_learner.learnable_tokens)
+    assert torch.equal(m2.point_encoder.blocks.blocks[-1].mlp.fc2.weight, m.point_encoder.blocks.blocks[-1].mlp.fc2.weight)
