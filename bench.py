@@ -191,9 +191,13 @@ def main():
         g = summ["gemm_bf16"]
         g_ms = g["ms"] - overhead_ms * g["launches"]
         achieved = g["work"] / (g_ms * 1e-3) / 1e12
+        traffic = None          # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE), see profiles/
+        tf = os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")
+        if a.config == "C2" and os.path.exists(tf):
+            traffic = round(json.load(open(tf))["hbm_bytes_per_launch"])
         roof = {"bound": "mfma", "kernel": "gemm_kernel<bf16> (ppt_amd/csrc/gemm.hip)",
                 "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                 "launches_per_step": g["launches"] // a.steps,
                 "avg_launch_us": round(1e3 * g_ms / g["launches"], 2),
                 "avg_bracket_us": round(1e3 * g["ms"] / g["launches"], 2), "event_overhead_us": round(1e3 * overhead_ms, 2),
