@@ -33,21 +33,37 @@ constexpr int ROWB = 128, NT = 256;
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7): 1 v_rcp + 1 v_exp + 7 FMA instead of libm's branchy
+// erff; used when the result is rounded to bf16 anyway (8 significand bits), never in the fp32 parity mode.
+__device__ __forceinline__ float erf_fast(float x)
+{
+    const float a = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, a, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = 1.0f - poly * t * __expf(-a * a);
+    return copysignf(e, x);
+}
+
+template <bool FAST>
 __device__ __forceinline__ float act_fwd(float v, int act)
 {
     switch (act) {
     case PPT_ACT_RELU: return fmaxf(v, 0.0f);
-    case PPT_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+    case PPT_ACT_GELU: return 0.5f * v * (1.0f + (FAST ? erf_fast(v * 0.70710678118654752f) : erff(v * 0.70710678118654752f)));
     case PPT_ACT_QUICKGELU: return v / (1.0f + __expf(-1.702f * v));
     default: return v;
     }
 }
+template <bool FAST>
 __device__ __forceinline__ float act_bwd(float x, int act)   // d act(x) / dx
 {
     switch (act) {
     case PPT_ACT_RELU: return x > 0.0f ? 1.0f : 0.0f;
     case PPT_ACT_GELU: {
-        const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+        const float cdf = 0.5f * (1.0f + (FAST ? erf_fast(x * 0.70710678118654752f) : erff(x * 0.70710678118654752f)));
         return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
     }
     case PPT_ACT_QUICKGELU: {
@@ -142,8 +158,28 @@ __device__ __forceinline__ void load_A(Stage<NR> &st, const ppt_gemm_params &p, 
     }
 }
 
+// Per-channel constants of the A prologues live in a small LDS table filled once per workgroup
+// (AFFINE: {scale, shift} per k; CONV1: the BN-folded {s*wx, s*wy, s*wz, s*b + shift} per channel).  Fetching them
+// from global memory inside finish_A put one exposed memory latency in front of every LDS write of every slab.
+constexpr int PRO_TAB_K = 1024;                       // max K of a prologue GEMM (8 KiB of float2 / 16 KiB of float4 at K=1024)
+
+template <int A_MODE>
+__device__ __forceinline__ void fill_prologue_table(const ppt_gemm_params &p, float *tab)
+{
+    if constexpr (A_MODE == PPT_A_AFFINE_RELU) {
+        for (int k = threadIdx.x; k < p.K; k += NT) { tab[2 * k] = p.a_scale[k]; tab[2 * k + 1] = p.a_shift[k]; }
+    } else if constexpr (A_MODE == PPT_A_CONV1) {
+        for (int c = threadIdx.x; c < p.K; c += NT) {
+            const float s = p.a_scale ? p.a_scale[c] : 1.0f;
+            const float h = p.a_shift ? p.a_shift[c] : 0.0f;
+            tab[4 * c + 0] = s * p.w1[c * 3 + 0]; tab[4 * c + 1] = s * p.w1[c * 3 + 1]; tab[4 * c + 2] = s * p.w1[c * 3 + 2];
+            tab[4 * c + 3] = fmaf(s, p.b1[c], h);
+        }
+    }
+}
+
 template <typename T, int A_MODE, int NR>
-__device__ __forceinline__ void finish_A(Stage<NR> &st, const ppt_gemm_params &p, int m0, int k0)
+__device__ __forceinline__ void finish_A(Stage<NR> &st, const ppt_gemm_params &p, int m0, int k0, const float *tab)
 {
     constexpr int EPC = 16 / sizeof(T);
     const int t = threadIdx.x, ch = t & 7;
@@ -153,7 +189,10 @@ __device__ __forceinline__ void finish_A(Stage<NR> &st, const ppt_gemm_params &p
         if (k < p.K) {
             float sc[EPC], sh[EPC];
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) { sc[e] = p.a_scale[k + e]; sh[e] = p.a_shift[k + e]; }
+            for (int e = 0; e < EPC; e += 2) {
+                const float4 v = *reinterpret_cast<const float4 *>(tab + 2 * (k + e));
+                sc[e] = v.x; sh[e] = v.y; sc[e + 1] = v.z; sh[e + 1] = v.w;
+            }
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
                 const int r = m0 + (t >> 3) + 32 * i;
@@ -166,10 +205,8 @@ __device__ __forceinline__ void finish_A(Stage<NR> &st, const ppt_gemm_params &p
         for (int e = 0; e < EPC; ++e) {
             const int c = k + e;
             if (c < p.K) {
-                const float s = p.a_scale ? p.a_scale[c] : 1.0f;
-                const float h = p.a_shift ? p.a_shift[c] : 0.0f;
-                wx[e] = s * p.w1[c * 3 + 0]; wy[e] = s * p.w1[c * 3 + 1]; wz[e] = s * p.w1[c * 3 + 2];
-                wb[e] = fmaf(s, p.b1[c], h);
+                const float4 v = *reinterpret_cast<const float4 *>(tab + 4 * c);
+                wx[e] = v.x; wy[e] = v.y; wz[e] = v.z; wb[e] = v.w;
             } else { wx[e] = wy[e] = wz[e] = 0.f; wb[e] = 0.f; }
         }
 #pragma unroll
@@ -264,9 +301,9 @@ __device__ __forceinline__ void epilogue_scalar(const ppt_gemm_params &p, float 
             if (p.dact_pre) {
                 const float x = p.dtype == PPT_BF16 ? load_as_f32<bf16_t>(p.dact_pre, (int64_t)m * p.ld_dact + n)
                                                      : load_as_f32<float>(p.dact_pre, (int64_t)m * p.ld_dact + n);
-                v *= act_bwd(x, p.act);
+                v *= act_bwd<false>(x, p.act);
             } else {
-                v = act_fwd(v, p.act);
+                v = act_fwd<false>(v, p.act);
             }
             if (p.row_scale) v *= p.row_scale[m / p.row_scale_rows];
             if (p.residual) v += p.residual[(int64_t)m * p.ld_res + n];
@@ -390,11 +427,21 @@ __device__ __forceinline__ void epilogue_vec8(const ppt_gemm_params &p, float *c
             if (p.C2 && p.c2_pre) st8_dt(p.C2, p.c2_dtype, (int64_t)m * p.ldc2 + n, v);
             if ((FEAT & 1) && p.dact_pre) {
                 const f8 x = kind == 3 ? pre_f8(pass, p.dtype == PPT_BF16) : ld8_dt(p.dact_pre, p.dtype, (int64_t)m * p.ld_dact + n);
+                if (p.dtype == PPT_BF16) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v.v[e] *= act_bwd(x.v[e], p.act);
+                    for (int e = 0; e < 8; ++e) v.v[e] *= act_bwd<true>(x.v[e], p.act);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v.v[e] *= act_bwd<false>(x.v[e], p.act);
+                }
             } else if (p.act != PPT_ACT_NONE) {
+                if (p.dtype == PPT_BF16) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v.v[e] = act_fwd(v.v[e], p.act);
+                    for (int e = 0; e < 8; ++e) v.v[e] = act_fwd<true>(v.v[e], p.act);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v.v[e] = act_fwd<false>(v.v[e], p.act);
+                }
             }
             if (p.row_scale) {
                 const float sc = p.row_scale[m / p.row_scale_rows];
@@ -506,7 +553,14 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const ppt_gemm_params p)
     constexpr int WM = BM / 2, WN = BN / 2, TI = WM / 32, TJ = WN / 32, NRA = BM / 32, NRB = BN / 32;
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
     constexpr int STAGE_BYTES = 2 * (A_BYTES + B_BYTES), PARK_BYTES = 4 * WM * WN * 4;
-    __shared__ __align__(16) unsigned char smem[STAGE_BYTES > PARK_BYTES ? STAGE_BYTES : PARK_BYTES];   // A0 A1 B0 B1
+    constexpr int MAIN_BYTES = STAGE_BYTES > PARK_BYTES ? STAGE_BYTES : PARK_BYTES;
+    constexpr int TAB_BYTES = A_MODE == PPT_A_PLAIN ? 0 : (A_MODE == PPT_A_CONV1 ? 16 : 8) * PRO_TAB_K;
+    __shared__ __align__(16) unsigned char smem[MAIN_BYTES + TAB_BYTES];   // A0 A1 B0 B1 | prologue table
+    const float *tab = reinterpret_cast<const float *>(smem + MAIN_BYTES);
+    if constexpr (A_MODE != PPT_A_PLAIN) {
+        fill_prologue_table<A_MODE>(p, reinterpret_cast<float *>(smem + MAIN_BYTES));
+        __syncthreads();
+    }
     constexpr int BK = ROWB / sizeof(T);
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -551,7 +605,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const ppt_gemm_params p)
     } while (0)
 #define PPT_WRITE(SA, SB, S, BUF)                                             \
     do {                                                                      \
-        finish_A<T, A_MODE, NRA>(SA, p, m0, (S) * BK);                        \
+        finish_A<T, A_MODE, NRA>(SA, p, m0, (S) * BK, tab);                   \
         mask_plain<T, NRB>(SB, p.N, p.K, n0, (S) * BK);                       \
         PPT_DBG_WRITE(write_stage<NRA>(SA, Abuf + ((BUF) & 1) * A_BYTES));    \
         PPT_DBG_WRITE(write_stage<NRB>(SB, Bbuf + ((BUF) & 1) * B_BYTES));    \
@@ -764,6 +818,7 @@ extern "C" int ppt_gemm(const ppt_gemm_params *pp, void *stream)
     if (p.dtype != PPT_F32 && p.dtype != PPT_BF16) return PPT_EINVAL;
     const int epc = p.dtype == PPT_BF16 ? 8 : 4;
     if (p.K % epc || p.ldb % epc || ((uintptr_t)p.B & 15)) return PPT_EINVAL;
+    if (p.a_mode != PPT_A_PLAIN && p.K > 1024) return PPT_EUNSUPPORTED;      // prologue constants live in an LDS table
     if (p.a_mode == PPT_A_CONV1) {
         if (!p.pts || !p.w1 || !p.b1) return PPT_EINVAL;
     } else {
