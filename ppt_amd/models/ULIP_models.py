@@ -192,6 +192,8 @@ class _TextTowerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         m = ctx.model
+        if dout.is_cuda:
+            dout.record_stream(torch.cuda.current_stream())     # produced on the caller's stream, read on the text stream
         return None, engine.text_tower_backward(m._live_state(), m._cache(), ctx.saved, dout.float())
 
 
@@ -347,14 +349,19 @@ class ULIP_WITH_IMAGE(nn.Module):
             self._te_cache = ((tok._version, tok.data_ptr(), self.precision), text_embed)
         return text_embed
 
+    def text_stream(self):
+        """The HIP stream the prompt side (PromptLearner + text tower, and in training its backward and the
+        optimizer: train.Trainer.step) is queued on."""
+        if self._text_stream is None:
+            self._text_stream = torch.cuda.Stream()
+        return self._text_stream
+
     def forward(self, pc, cls_label=None):
         """ULIP_models.py:260-283 -> logits [B,C] (partseg: [B,N,C])."""
         cur = torch.cuda.current_stream()
         side = None
         if self.overlap_text_tower and pc.is_cuda:
-            if self._text_stream is None:
-                self._text_stream = torch.cuda.Stream()
-            side = self._text_stream
+            side = self.text_stream()
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 text_embed = self._text_embed()

@@ -4,6 +4,7 @@ clamp -- plus the MI355X-native replacement of DistributedDataParallel (main_cls
 ONE RCCL all-reduce per step over a flat fp32 buffer holding the PromptLearner / PointAdapter
 gradients, and a broadcast of the BatchNorm running statistics from rank 0 (DDP broadcast_buffers).
 """
+import contextlib
 import math
 
 import numpy as np
@@ -99,15 +100,37 @@ class Trainer:
             distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         self.distributed = distributed
         self.sync = FlatGradSync(model.parameters())
+        self.run_ahead = True
+        # head_type 0: only the prompt learner trains, so the point tower never reads a parameter the optimizer writes
+        self._point_side_frozen = all(n.startswith("prompt_learner.") or not p.requires_grad
+                                      for n, p in model.named_parameters())
+        self._side_used = None
         self.bcast = BufferBroadcast(model) if distributed else None
         if hasattr(model, "_sd"):
             model._sd = None
         if hasattr(getattr(model, "point_encoder", None), "_sd"):
             model.point_encoder._sd = None
 
-    def step(self, pc, label, check_finite=False):
+    def _prompt_stream(self, pc):
+        """The side stream the text tower runs on (ULIP_WITH_IMAGE.forward), or None on CPU / when disabled."""
         model = self.model
-        self.sync.zero()                                            # optimizer.zero_grad()
+        if not (pc.is_cuda and self.run_ahead and getattr(model, "overlap_text_tower", False)
+                and hasattr(model, "text_stream")):
+            return None
+        return model.text_stream()
+
+    def step(self, pc, label, check_finite=False):
+        """One iteration.  On a GPU the prompt side of the step (zero_grad, text tower, its backward, the
+        gradient all-reduce, AdamW, the logit_scale clamp) is queued on the model's text stream, the point
+        tower and the loss on the caller's stream.  With a fully frozen point side (head_type 0) nothing the
+        point tower reads changes between iterations, so the caller's stream does not wait for the optimizer:
+        iteration i+1's point tower overlaps iteration i's text backward.  `loss` and `pred` are ordinary
+        tensors of the caller's stream; parameters are final after `finish()`."""
+        model = self.model
+        side = self._side_used = self._prompt_stream(pc)
+        main = torch.cuda.current_stream() if side is not None else None
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            self.sync.zero()                                        # optimizer.zero_grad()
         if self.lr_schedule is not None:                            # main_cls.py:184-185
             for g in self.optimizer.param_groups:
                 g['lr'] = float(self.lr_schedule[min(self.it, len(self.lr_schedule) - 1)])
@@ -115,15 +138,25 @@ class Trainer:
             self.bcast.broadcast()
         pred = model(pc, *self.extra_inputs)                        # main_cls.py:194 / main_partseg.py:210
         loss = self.criterion(pred.reshape(-1, pred.shape[-1]), label.reshape(-1))     # main_partseg.py:213
-        loss.backward()                                             # (retain_graph only served Q2)
-        if self.distributed:
-            self.sync.all_reduce()
-        self.optimizer.step()
+        if side is not None:
+            side.wait_stream(main)
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            loss.backward()                                         # (retain_graph only served Q2)
+            if self.distributed:
+                self.sync.all_reduce()
+            self.optimizer.step()
+            model.logit_scale.data.clamp_(0, 4.6052)                # main_cls.py:213
+        if side is not None and not self._point_side_frozen:
+            main.wait_stream(side)                                  # the point tower reads updated parameters
         if check_finite and not math.isfinite(loss.item()):         # main_cls.py:205-207
             raise FloatingPointError(f"Loss is {loss.item()}, stopping training")
-        model.logit_scale.data.clamp_(0, 4.6052)                    # main_cls.py:213
         self.it += 1
         return loss, pred
+
+    def finish(self):
+        """Order the caller's stream after everything `step` queued (call before reading parameters)."""
+        if self._side_used is not None:
+            torch.cuda.current_stream().wait_stream(self._side_used)
 
 
 def checkpoint_payload(model, optimizer, epoch, best_acc, args, head_type=0, partseg=False):
@@ -131,6 +164,8 @@ def checkpoint_payload(model, optimizer, epoch, best_acc, args, head_type=0, par
     prompt learner ('state_dict' = {'learnable_tokens'}), the last block when head_type > 0, the optimizer and args;
     main_partseg.py:127-143 saves the whole point encoder under 'state_dict_partseg'.  Keys are the reference's, so
     save_recog_feats.py:29-35 / interpret_prompt.py:25-28 style readers work on it."""
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()           # Trainer.step leaves the optimizer queued on the model's text stream
     data = {'epoch': epoch + 1, 'state_dict': model.prompt_learner.state_dict(), 'optimizer': optimizer.state_dict(),
             'best_acc': best_acc, 'args': args}
     if partseg:

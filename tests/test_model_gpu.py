@@ -165,6 +165,38 @@ def test_overlapped_text_tower_is_identical():
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("head_type", [0, 3])
+def test_run_ahead_training_is_identical(head_type):
+    """Trainer.step with the prompt side queued on the text stream (and, for head_type 0, the next iteration's
+    point tower running ahead of the optimizer) must produce exactly the parameters of the single-stream step."""
+    from ppt_amd.train import Trainer
+    pc, start = oracle_inputs()
+    label = torch.tensor([3, 17, 0, 39]).cuda()
+    results = []
+    for run_ahead in (False, True):
+        m, _ = build(head_type, torch.bfloat16)
+        m.train()
+        torch.manual_seed(5)                   # DropPath factors are drawn on the device
+        m.point_encoder.fps_start = torch.from_numpy(start).cuda()
+        m.overlap_text_tower = run_ahead
+        tr = Trainer(m, lr=3e-3, label_smoothing=0.2, distributed=False)
+        tr.run_ahead = run_ahead
+        assert tr._point_side_frozen == (head_type == 0)
+        losses = []
+        for it in range(6):
+            loss, pred = tr.step(torch.roll(pc, it, 0).cuda(), label)
+            losses.append(loss)
+        tr.finish()
+        torch.cuda.synchronize()
+        results.append(([l.item() for l in losses], pred.clone(),
+                        {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad}))
+    (la, pa, wa), (lb, pb, wb) = results
+    assert la == lb
+    assert torch.equal(pa, pb)
+    for n in wa:
+        assert torch.equal(wa[n], wb[n]), n
+
+
 def test_group_and_encoder_modules():
     from ppt_amd.models.pointbert.dvae import Encoder, Group, knn_point
     from ppt_amd.models.pointbert import misc
