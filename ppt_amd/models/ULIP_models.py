@@ -13,7 +13,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from .. import engine, ops
+from .. import engine, graphs, ops
 
 _DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data")
 CONTEXT_LENGTH = 77
@@ -179,22 +179,60 @@ class PromptLearner(nn.Module):
 
 
 class _TextTowerFn(torch.autograd.Function):
+    """encode_text as one autograd node.  After graphs.WARMUP_CALLS eager calls the forward (and the input-gradient
+    backward) of a given shape are replayed from a captured hipGraph (ppt_amd/graphs.py)."""
+
     @staticmethod
     def forward(ctx, model, prompts):
-        sd = model._live_state()
+        sd, cache = model._live_state(), model._cache()
         save = bool(ctx.needs_input_grad[1])
-        out, saved = engine.text_tower_forward(sd, model._cache(), prompts.contiguous().float(), model._eot(prompts.device),
-                                               model.transformer.heads, model.transformer.layers, save,
-                                               eff_len=model._text_len() if model.truncate_text_to_eot else None)
-        ctx.model, ctx.saved = model, saved
+        prompts = prompts.contiguous().float()
+        eot = model._eot(prompts.device)
+        heads, layers = model.transformer.heads, model.transformer.layers
+        eff = model._text_len() if model.truncate_text_to_eot else None
+
+        def run(pr):
+            return engine.text_tower_forward(sd, cache, pr, eot, heads, layers, save, eff_len=eff)
+
+        key = ("text_fwd", tuple(prompts.shape), save, eff, cache.dtype)
+        gc = model._graphs
+        ctx.model, ctx.graph = model, None
+        if prompts.is_cuda and model.use_hip_graphs and ops.profiler is None and gc.ready(key):
+            def build():
+                def fn(pr):
+                    out, saved = run(pr)
+                    return (out,), saved
+                return graphs.GraphedCall(fn, [prompts])
+            g = gc.get(key, build)
+            (out,), saved = g(prompts)
+            g.generation = getattr(g, "generation", 0) + 1
+            ctx.graph, ctx.key, ctx.generation = g, key, g.generation
+            out = out.clone()
+        else:
+            out, saved = run(prompts)
+        ctx.saved = saved
         return out
 
     @staticmethod
     def backward(ctx, dout):
         m = ctx.model
+        sd, cache = m._live_state(), m._cache()
+        dout = dout.float()
         if dout.is_cuda:
             dout.record_stream(torch.cuda.current_stream())     # produced on the caller's stream, read on the text stream
-        return None, engine.text_tower_backward(m._live_state(), m._cache(), ctx.saved, dout.float())
+        if ctx.graph is None:
+            return None, engine.text_tower_backward(sd, cache, ctx.saved, dout)
+        if ctx.graph.generation != ctx.generation:
+            raise RuntimeError("the text tower's captured activations were overwritten by a later forward; set "
+                               "model.use_hip_graphs = False to keep several forwards alive before backward")
+        saved, fwd = ctx.saved, ctx.graph
+
+        def build():
+            def fn(d):
+                return (engine.text_tower_backward(sd, cache, saved, d),), None
+            return graphs.GraphedCall(fn, [dout.contiguous()], pool=fwd.pool())
+        (dp,), _ = m._graphs.get(("text_bwd",) + ctx.key[1:], build)(dout)
+        return None, dp.clone()
 
 
 class _MatmulNT(torch.autograd.Function):
@@ -251,6 +289,9 @@ class ULIP_WITH_IMAGE(nn.Module):
         self._eot_pos = None
         self._text_stream = None
         self._te_cache = None
+        self._text_len_cache = None
+        self._graphs = graphs.GraphCache()
+        self.use_hip_graphs = True          # replay the text tower from captured hipGraphs after two eager calls
         self.overlap_text_tower = True      # run the (input-independent) text tower on a side stream
         self.truncate_text_to_eot = True    # causal mask + EOT pooling: positions after the last EOT are dead work
 
@@ -287,6 +328,7 @@ class ULIP_WITH_IMAGE(nn.Module):
         """torch.bfloat16 (performance mode) or torch.float32 (parity mode) for both towers."""
         self.point_encoder.precision = dtype
         self.point_encoder._wc = None
+        self._graphs.clear()
         if hasattr(self.point_encoder, "encoder"):
             self.point_encoder.encoder.precision = dtype
         return self
@@ -306,14 +348,19 @@ class ULIP_WITH_IMAGE(nn.Module):
     def _apply(self, fn, *a, **k):
         self._sd = None
         self._eot_pos = None
+        self._graphs.clear()
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
         self._sd = None
+        self._wc = None                     # operand copies of the (frozen) weights and the graphs that read them
+        self._graphs.clear()
         return super().load_state_dict(*a, **k)
 
     def _text_len(self):
-        return int(self.tokenized_prompts.argmax(dim=-1).max().item()) + 1
+        if self._text_len_cache is None or self._text_len_cache[0] is not self.tokenized_prompts:
+            self._text_len_cache = (self.tokenized_prompts, int(self.tokenized_prompts.argmax(dim=-1).max().item()) + 1)
+        return self._text_len_cache[1]
 
     def _eot(self, device):
         if self._eot_pos is None or self._eot_pos.device != device:

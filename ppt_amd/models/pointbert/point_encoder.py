@@ -128,6 +128,7 @@ class PointTransformer(nn.Module):
         self.pos_embed = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, self.trans_dim))
         dpr = [x.item() for x in torch.linspace(0, self.drop_path_rate, self.depth)]
         self.dpr = dpr
+        self._keep = None
         self.blocks = TransformerEncoder(embed_dim=self.trans_dim, depth=self.depth, drop_path_rate=dpr,
                                          num_heads=self.num_heads)
         self.norm = nn.LayerNorm(self.trans_dim)
@@ -181,7 +182,9 @@ class PointTransformer(nn.Module):
             return self.drop_path_factors.to(device=device, dtype=torch.float32).contiguous()
         if not self.training or self.drop_path_rate <= 0:
             return None
-        keep = 1.0 - torch.tensor(self.dpr, dtype=torch.float32, device=device).view(-1, 1, 1)
+        if self._keep is None or self._keep.device != device:      # (a host->device copy per step would drain the stream)
+            self._keep = 1.0 - torch.tensor(self.dpr, dtype=torch.float32, device=device).view(-1, 1, 1)
+        keep = self._keep
         u = torch.rand((self.depth, 2, B), dtype=torch.float32, device=device)
         return (torch.floor(keep + u) / keep).contiguous()
 
@@ -230,6 +233,7 @@ class PointTransformer_partseg(nn.Module):
         self.pos_embed = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, self.trans_dim))
         dpr = [x.item() for x in torch.linspace(0, self.drop_path_rate, self.depth)]
         self.dpr = dpr
+        self._keep = None
         self.blocks = TransformerEncoder(embed_dim=self.trans_dim, depth=self.depth, drop_path_rate=dpr,
                                          num_heads=self.num_heads)
         self.norm = nn.LayerNorm(self.trans_dim)

@@ -53,8 +53,11 @@ def dtype_code(t):
     return _DT[t.dtype if isinstance(t, torch.Tensor) else t]
 
 
+_raw_stream = torch._C._cuda_getCurrentRawStream      # current HIP stream handle without building a Stream object
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
 
 
 def _p(t):

@@ -168,13 +168,15 @@ def test_overlapped_text_tower_is_identical():
 @pytest.mark.parametrize("head_type", [0, 3])
 def test_run_ahead_training_is_identical(head_type):
     """Trainer.step with the prompt side queued on the text stream (and, for head_type 0, the next iteration's
-    point tower running ahead of the optimizer) must produce exactly the parameters of the single-stream step."""
+    point tower running ahead of the optimizer), without and with the text tower replayed from hipGraphs, must
+    produce exactly the losses and parameters of the single-stream eager step."""
     from ppt_amd.train import Trainer
     pc, start = oracle_inputs()
     label = torch.tensor([3, 17, 0, 39]).cuda()
     results = []
-    for run_ahead in (False, True):
+    for run_ahead, hip_graphs in ((False, False), (True, False), (True, True)):
         m, _ = build(head_type, torch.bfloat16)
+        m.use_hip_graphs = hip_graphs
         m.train()
         torch.manual_seed(5)                   # DropPath factors are drawn on the device
         m.point_encoder.fps_start = torch.from_numpy(start).cuda()
@@ -190,11 +192,13 @@ def test_run_ahead_training_is_identical(head_type):
         torch.cuda.synchronize()
         results.append(([l.item() for l in losses], pred.clone(),
                         {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad}))
-    (la, pa, wa), (lb, pb, wb) = results
-    assert la == lb
-    assert torch.equal(pa, pb)
-    for n in wa:
-        assert torch.equal(wa[n], wb[n]), n
+        assert bool(m._graphs.entries) == hip_graphs          # the text tower really was replayed from a hipGraph
+    la, pa, wa = results[0]
+    for lb, pb, wb in results[1:]:
+        assert la == lb
+        assert torch.equal(pa, pb)
+        for n in wa:
+            assert torch.equal(wa[n], wb[n]), n
 
 
 def test_group_and_encoder_modules():
