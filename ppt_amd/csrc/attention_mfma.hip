@@ -29,16 +29,9 @@ constexpr int HD = 64, KVT = 64, QB = 128, TILE = KVT * 128;   // bytes per K or
 __device__ __forceinline__ int k_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ int v_off(int key, int dbyte) { return key * 128 + (dbyte ^ (((key >> 1) & 1) << 6)); }
 
-__device__ __forceinline__ float lane_xor32_max(float v)
-{
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float lane_xor32_sum(float v)
-{
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
+// (ppt_common.h: v_permlane32_swap with wait states on both sides)
+__device__ __forceinline__ float lane_xor32_max(float v) { return xor32_max(v); }
+__device__ __forceinline__ float lane_xor32_sum(float v) { return xor32_sum(v); }
 
 template <bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_fwd_mfma(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out,

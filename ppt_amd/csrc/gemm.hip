@@ -529,7 +529,7 @@ __device__ __forceinline__ void epilogue_vec8(const ppt_gemm_params &p, float *c
     }
 }
 
-__device__ __forceinline__ bool al16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+__host__ __device__ __forceinline__ bool al16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 // wave-uniform: every pointer / leading dimension the vector epilogue touches is 16-byte friendly
 __device__ __forceinline__ bool vec_epilogue_ok(const ppt_gemm_params &p, int64_t zc)
@@ -545,6 +545,216 @@ __device__ __forceinline__ bool vec_epilogue_ok(const ppt_gemm_params &p, int64_
     if (p.col_sum) ok = ok && al16(p.col_sum) && al16(p.col_sqsum);
     if (p.pool_max) ok = ok && al16(p.pool_max);
     return ok;
+}
+
+// =================================================================================================
+// Register-layout epilogue.  In the 32x32 MFMA C layout a lane owns ONE column (lane & 31) and 16 rows
+// ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) of each tile, so everything that is per column or per row group
+// -- bias, the per-group term, BatchNorm chunk statistics (a 32-row chunk IS one MFMA tile), max / min
+// pooling over 16 / 32 / 64 rows -- is a register loop plus one v_permlane32_swap, with no LDS round trip
+// (the LDS walk of epilogue_vec8 cost more than the K loop on the mini-PointNet GEMMs: conv3 575 us with,
+// 208 us without its epilogue).  Only the C store needs row-major data: neighbouring lanes trade one value
+// over DPP so that each holds two adjacent columns of one row, v_cvt_pk_bf16_f32 packs them, and the tile is
+// parked as bf16 (half the LDS bytes and half the ds_write count of the fp32 park) for 16-byte row stores.
+// Anything with a row-major fp32 operand (residual, saved pre-activation, second output) or an fp32 C stays
+// on epilogue_vec8.
+// =================================================================================================
+template <int TI>
+__host__ __device__ __forceinline__ bool reg_epilogue_ok(const ppt_gemm_params &p, int64_t zc)
+{
+    if (p.residual || p.residual2 || p.dact_pre || p.row_scale || p.C2) return false;
+    if ((p.N % 8) != 0) return false;
+    if (p.C && (p.c_dtype != PPT_BF16 || (p.ldc % 8) != 0 || (zc % 8) != 0 || !al16(p.C))) return false;
+    if (p.group_add && !(p.group_rows == 16 || (p.group_rows > 0 && (p.group_rows % 32) == 0))) return false;
+    if (p.pool_max) {
+        const int pr = p.pool_rows > 0 ? p.pool_rows : 32;
+        if (!(pr == 16 || pr == 32 || (pr == 64 && TI == 2))) return false;
+    }
+    return true;
+}
+
+__device__ __forceinline__ void st_pool(void *base, int dtype, int64_t i, float v)
+{
+    if (dtype == PPT_BF16) reinterpret_cast<bf16_t *>(base)[i] = f32_to_bf16(v);
+    else reinterpret_cast<float *>(base)[i] = v;
+}
+
+// per-column operands of epilogue_regs, fetched BEFORE the K loop (their addresses depend on the tile only), so that
+// the epilogue never waits on memory: bias[j], and the per-group term of each MFMA tile (two for 16-row groups)
+template <int TI, int TJ>
+struct EpiPre { float bias[TJ]; float g[TI][TJ][2]; };
+
+template <int TI, int TJ>
+__device__ __forceinline__ void epilogue_prefetch(const ppt_gemm_params &p, EpiPre<TI, TJ> &e, int lane, int mw, int nw)
+{
+    const int cl = lane & 31;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int n = nw + j * 32 + cl;
+        const int nc = n < p.N ? n : 0;
+        e.bias[j] = p.bias ? p.bias[nc] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int mg = mw + i * 32;
+            e.g[i][j][0] = e.g[i][j][1] = 0.f;
+            if (p.group_add) {
+                const int gr = p.group_rows > 0 ? p.group_rows : 32;
+                e.g[i][j][0] = p.group_add[(int64_t)(min(mg, p.M - 1) / gr) * p.N + nc];
+                e.g[i][j][1] = p.group_add[(int64_t)(min(mg + 16, p.M - 1) / gr) * p.N + nc];
+            }
+        }
+    }
+}
+
+template <int TI, int TJ>
+__device__ __forceinline__ void epilogue_regs(const ppt_gemm_params &p, f32x16_t (&acc)[TI][TJ], const EpiPre<TI, TJ> &pre,
+                                              unsigned char *park, int lane, int mw, int nw, int64_t zc)
+{
+    constexpr int WM = TI * 32, WN = TJ * 32, ROWBYTES = WN * 2;
+    const int cl = lane & 31, h = lane >> 5, odd = cl & 1;
+    const bool fast = p.dtype == PPT_BF16;
+    const int pool_rows = p.pool_rows > 0 ? p.pool_rows : 32;
+    // parked dword of this lane inside a (row pair, column tile): row + odd, columns (cl & ~1, cl | 1); for 64-column
+    // wave tiles odd rows keep their two 64-byte halves swapped, which puts the even-lane row and the odd-lane row of
+    // one ds_write_b32 on disjoint banks (and leaves the ds_read_b128 walk below conflict-free)
+    const int lane_byte = (4 * h + odd) * ROWBYTES + (cl >> 1) * 4;
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int n = nw + j * 32 + cl;
+        const bool nok = n < p.N;
+        const float bias = pre.bias[j];
+        float pmx = -INFINITY, pmn = INFINITY;                       // carried over i for 64-row pools
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int mg = mw + i * 32;                               // first row of this MFMA tile (wave-uniform)
+            const bool full = mg + 32 <= p.M;
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] + bias;
+            if (p.group_add) {                                        // (rows 16-31 of a 32k-row group: g[1] == g[0])
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += pre.g[i][j][r < 8 ? 0 : 1];
+            }
+            bool rv[16];                                              // row of register r exists
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[r] = full || (mg + (r & 3) + 8 * (r >> 2) + 4 * h) < p.M;
+            if (p.col_sum && mg < p.M) {
+                // BatchNorm statistics of this 32-row chunk: (sum, M2 about the chunk mean); ppt_bn_finalize merges
+                // the chunks with the parallel-variance formula in fp64 (no cancellation, no atomics)
+                float sacc = 0.f, q = 0.f, mean;
+                if (full) {                                           // (wave-uniform) no row masks on whole tiles
+#ifdef PPT_DBG_PK
+                    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) { s0 += v[r]; s1 += v[r + 1]; }
+                    sacc = xor32_sum(s0 + s1);
+                    mean = sacc * (1.0f / 32.0f);
+                    float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const float d0 = v[r] - mean, d1 = v[r + 1] - mean;
+                        q0 = fmaf(d0, d0, q0); q1 = fmaf(d1, d1, q1);
+                    }
+                    q = xor32_sum(q0 + q1);
+#else
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc += v[r];
+                    sacc = xor32_sum(sacc);
+                    mean = sacc * (1.0f / 32.0f);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { const float d = v[r] - mean; q = fmaf(d, d, q); }
+                    q = xor32_sum(q);
+#endif
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc += rv[r] ? v[r] : 0.f;
+                    sacc = xor32_sum(sacc);
+                    mean = sacc / (float)min(32, p.M - mg);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { const float d = v[r] - mean; q = rv[r] ? fmaf(d, d, q) : q; }
+                    q = xor32_sum(q);
+                }
+                if (h == 0 && nok) {
+                    p.col_sum[(int64_t)(mg >> 5) * p.N + n] = sacc;
+                    p.col_sqsum[(int64_t)(mg >> 5) * p.N + n] = q;
+                }
+            }
+            if (p.act != PPT_ACT_NONE) {
+                if (fast) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = act_fwd<true>(v[r], p.act);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = act_fwd<false>(v[r], p.act);
+                }
+            }
+            if (p.pool_max) {
+                float a0 = -INFINITY, a1 = -INFINITY, b0 = INFINITY, b1 = INFINITY;   // rows 0-15 / 16-31 of the tile
+                if (full) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) { a0 = fmaxf(a0, v[r]); a1 = fmaxf(a1, v[r + 8]); }
+                    if (p.pool_min) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) { b0 = fminf(b0, v[r]); b1 = fminf(b1, v[r + 8]); }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        a0 = fmaxf(a0, rv[r] ? v[r] : -INFINITY); b0 = fminf(b0, rv[r] ? v[r] : INFINITY);
+                        a1 = fmaxf(a1, rv[r + 8] ? v[r + 8] : -INFINITY); b1 = fminf(b1, rv[r + 8] ? v[r + 8] : INFINITY);
+                    }
+                }
+                if (pool_rows == 16) {
+                    a0 = xor32_max(a0); a1 = xor32_max(a1);
+                    if (p.pool_min) { b0 = xor32_min(b0); b1 = xor32_min(b1); }
+                    if (h == 0 && nok) {
+                        if (mg < p.M) { st_pool(p.pool_max, p.pool_dtype, (int64_t)(mg / 16) * p.N + n, a0);
+                                        if (p.pool_min) st_pool(p.pool_min, p.pool_dtype, (int64_t)(mg / 16) * p.N + n, b0); }
+                        if (mg + 16 < p.M) { st_pool(p.pool_max, p.pool_dtype, (int64_t)(mg / 16 + 1) * p.N + n, a1);
+                                             if (p.pool_min) st_pool(p.pool_min, p.pool_dtype, (int64_t)(mg / 16 + 1) * p.N + n, b1); }
+                    }
+                } else {
+                    pmx = fmaxf(pmx, fmaxf(a0, a1)); pmn = fminf(pmn, fminf(b0, b1));
+                    if (pool_rows == 32 || i == TI - 1) {
+                        const float tmx = xor32_max(pmx);
+                        const int mg0 = pool_rows == 32 ? mg : mw;
+                        if (h == 0 && nok && mg0 < p.M) st_pool(p.pool_max, p.pool_dtype, (int64_t)(mg0 / pool_rows) * p.N + n, tmx);
+                        if (p.pool_min) {
+                            const float tmn = xor32_min(pmn);
+                            if (h == 0 && nok && mg0 < p.M) st_pool(p.pool_min, p.pool_dtype, (int64_t)(mg0 / pool_rows) * p.N + n, tmn);
+                        }
+                        pmx = -INFINITY; pmn = INFINITY;
+                    }
+                }
+            }
+            if (p.C) {
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    // even lane keeps row(r): (own, neighbour's); odd lane keeps row(r+1): (neighbour's, own)
+                    const float give = odd ? v[r] : v[r + 1];
+                    const float got = __uint_as_float(dpp_mov<0xB1, 0xf>(__float_as_uint(give)));   // quad_perm [1,0,3,2]
+                    const uint32_t w = pack_bf16x2(odd ? got : v[r], odd ? v[r + 1] : got);
+                    const int jb = TJ == 2 ? ((j ^ odd) << 6) : 0;     // the written row (r + odd) is odd exactly on odd lanes
+                    *reinterpret_cast<uint32_t *>(park + (i * 32 + (r & 3) + 8 * (r >> 2)) * ROWBYTES + jb + lane_byte) = w;
+                }
+            }
+        }
+    }
+    if (!p.C) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    constexpr int CPR = WN / 8, RP = 64 / CPR;                        // 16-byte chunks per row, rows per pass
+    const int ch = lane % CPR, rl = lane / CPR;
+    const int n = nw + ch * 8;
+    bf16_t *C = reinterpret_cast<bf16_t *>(p.C) + zc;
+#pragma unroll
+    for (int pass = 0; pass < WM / RP; ++pass) {
+        const int row = pass * RP + rl;
+        const int m = mw + row;
+        const uint4 d = *reinterpret_cast<const uint4 *>(park + row * ROWBYTES + ((ch * 16) ^ (TJ == 2 ? (row & 1) << 6 : 0)));
+        if (m < p.M && n < p.N) *reinterpret_cast<uint4 *>(C + (int64_t)m * p.ldc + n) = d;
+    }
 }
 
 template <typename T, int A_MODE, int BM, int BN>
@@ -587,6 +797,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const ppt_gemm_params p)
         for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    EpiPre<TI, TJ> epre;        // (the CONV1 prologue already fills the register file: it fetches these after the K loop)
+    if constexpr (A_MODE != PPT_A_CONV1) epilogue_prefetch<TI, TJ>(p, epre, lane, m0 + wm * WM, n0 + wn * WN);
 
     const int nslab = (p.K + BK - 1) / BK;
     Stage<NRA> a0, a1, a2;
@@ -650,6 +862,17 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const ppt_gemm_params p)
     // (column on the lane, rows scattered over 16 registers) into full-row global stores, makes the
     // BatchNorm column sums and the 32-row max-pool per-lane running values, and keeps the flag-driven
     // epilogue body out of the unroller.
+    const int64_t zc = (int64_t)blockIdx.z * p.strideC;
+#ifdef PPT_DBG_SKIP_EPILOGUE
+    if (acc[0][0][0] != 12345.678f) return;
+#endif
+#ifndef PPT_DBG_NO_REG_EPILOGUE
+    if (reg_epilogue_ok<TI>(p, zc)) {
+        if constexpr (A_MODE == PPT_A_CONV1) epilogue_prefetch<TI, TJ>(p, epre, lane, m0 + wm * WM, n0 + wn * WN);
+        epilogue_regs<TI, TJ>(p, acc, epre, smem + w * (WM * WN * 2), lane, m0 + wm * WM, n0 + wn * WN, zc);
+        return;
+    }
+#endif
     float *ct = reinterpret_cast<float *>(smem) + w * (WM * WN);
     {
         const int h = lane >> 5, cl = lane & 31;
@@ -665,10 +888,6 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const ppt_gemm_params p)
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    const int64_t zc = (int64_t)blockIdx.z * p.strideC;
-#ifdef PPT_DBG_SKIP_EPILOGUE
-    if (ct[lane] != 12345.678f) return;
-#endif
     if (vec_epilogue_ok(p, zc)) epilogue_vec8<WM, WN>(p, ct, lane, m0 + wm * WM, n0 + wn * WN, zc);
     else epilogue_scalar<WM, WN>(p, ct, lane, m0 + wm * WM, n0 + wn * WN, m0, wm, zc);
 }
@@ -728,6 +947,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel_glds(const ppt_gemm_params p)
         for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    EpiPre<TI, TJ> epre;
+    epilogue_prefetch<TI, TJ>(p, epre, lane, m0 + wm * WM, n0 + wn * WN);
 
     const int nslab = p.K / BK, last = nslab - 1;
     auto issue = [&](int slab, int stage) {
@@ -750,6 +971,13 @@ __global__ __launch_bounds__(NT) void gemm_kernel_glds(const ppt_gemm_params p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // surplus prefetches must not land on the parked accumulators
     __builtin_amdgcn_s_barrier();
 
+    const int64_t zc = (int64_t)blockIdx.z * p.strideC;
+#ifndef PPT_DBG_NO_REG_EPILOGUE
+    if (reg_epilogue_ok<TI>(p, zc)) {
+        epilogue_regs<TI, TJ>(p, acc, epre, smem + w * (WM * WN * 2), lane, m0 + wm * WM, n0 + wn * WN, zc);
+        return;
+    }
+#endif
     float *ct = reinterpret_cast<float *>(smem) + w * (WM * WN);
     {
         const int h = lane >> 5, cl = lane & 31;
@@ -764,9 +992,145 @@ __global__ __launch_bounds__(NT) void gemm_kernel_glds(const ppt_gemm_params p)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int64_t zc = (int64_t)blockIdx.z * p.strideC;
     if (vec_epilogue_ok(p, zc)) epilogue_vec8<WM, WN>(p, ct, lane, m0 + wm * WM, n0 + wn * WN, zc);
     else epilogue_scalar<WM, WN>(p, ct, lane, m0 + wm * WM, n0 + wn * WN, m0, wm, zc);
+}
+
+// =================================================================================================
+// Half-slab LDS-DMA kernel for the big plain-operand problems (qkv, fc1, conv3): 128x128 tiles, 64-byte K slabs
+// (32 bf16), three 16 KiB stages = 48 KiB, so THREE workgroups (12 waves) share a CU.
+// Why: tools/lds_fill_bench.hip shows that what a CU can pull out of L2 depends on how many waves are issuing --
+// 4 waves 6.5, 8 waves 11, 12 waves 14, 16 waves 16 TB/s over the chip -- and hardly on the bytes each keeps in
+// flight, and both existing tile loops sit on that line: 64x64 tiles (12 waves, 32 flop per LDS-fill byte) at
+// 11.4 of 14 TB/s, register-staged 128x128 (8 waves, 64 flop/B) at 10 of 11 TB/s.  This kernel takes the 64 flop/B
+// of the big tile AND the 12 waves.  It has only the register-layout epilogue (the fp32 park of epilogue_vec8 would
+// need 64 KiB): the host sends it launches for which reg_epilogue_ok holds.
+// LDS image: 64-byte rows, 16-byte chunk c of row r at slot c ^ ((r >> 2) & 3): four consecutive rows fill one
+// 256-byte bank row, and the lane groups of ds_read_b128 ({0-3,12-15,20-27}, ...) then touch 16 distinct slots.
+// =================================================================================================
+constexpr int ROWH = 64;
+__device__ __forceinline__ int lds_off_h(int row, int chunk) { return row * ROWH + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+template <typename T, int ROWS>
+__device__ __forceinline__ void glds_half(const T *base, int64_t ld, int rows, int r0, int k0, unsigned char *tile, int w, int lane)
+{
+    constexpr int EPC = 16 / sizeof(T);
+    constexpr int PER_WAVE = ROWS / 64;                  // 1 KiB pieces (16 rows) per wave
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const int rg = (w * PER_WAVE + i) * 16;
+        const int r = rg + (lane >> 2);
+        const int c = (lane & 3) ^ ((r >> 2) & 3);       // source chunk that belongs in LDS slot lane&3 of row r
+        const T *src = base + (int64_t)min(r0 + r, rows - 1) * ld + k0 + c * EPC;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(tile + rg * ROWH), 16, 0, 0);
+    }
+}
+
+template <typename T, int TI, int TJ>
+__device__ __forceinline__ void mma_half(const unsigned char *As, const unsigned char *Bs, int arow0, int brow0, int lane,
+                                         f32x16_t (&acc)[TI][TJ])
+{
+    const int r = lane & 31, h = lane >> 5;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t a[TI], b[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+                a[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(As + lds_off_h(arow0 + i * 32 + r, kk * 2 + h)));
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+                b[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(Bs + lds_off_h(brow0 + j * 32 + r, kk * 2 + h)));
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const int kq = 2 * kk + h;      // k index (in floats) inside the 16-float slab
+            float a[TI], b[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+                a[i] = *reinterpret_cast<const float *>(As + lds_off_h(arow0 + i * 32 + r, kq >> 2) + (kq & 3) * 4);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+                b[j] = *reinterpret_cast<const float *>(Bs + lds_off_h(brow0 + j * 32 + r, kq >> 2) + (kq & 3) * 4);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+}
+
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(NT, 3) void gemm_kernel_glds_h(const ppt_gemm_params p)
+{
+    constexpr int WM = BM / 2, WN = BN / 2, TI = WM / 32, TJ = WN / 32;
+    constexpr int A_BYTES = BM * ROWH, B_BYTES = BN * ROWH, STAGE = A_BYTES + B_BYTES, NSTAGE = 3;
+    constexpr int LOADS_PER_SLAB = BM / 64 + BN / 64;    // LDS-DMA instructions per wave per slab
+    static_assert(LOADS_PER_SLAB == 4, "counted vmcnt below");
+    constexpr int PARK_BYTES = 4 * WM * WN * 2;          // bf16 park of epilogue_regs
+    __shared__ __align__(16) unsigned char smem[NSTAGE * STAGE > PARK_BYTES ? NSTAGE * STAGE : PARK_BYTES];
+    constexpr int BK = ROWH / sizeof(T);
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    const int nwg = gridDim.x * gridDim.y;
+    const int lin0 = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q8 = nwg / 8, r8 = nwg % 8, xcd = lin0 % 8;                   // same XCD-aware remap as gemm_kernel
+    const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + lin0 / 8;
+    const int n0 = (lin % gridDim.x) * BN, m0 = (lin / gridDim.x) * BM;
+    const T *A = reinterpret_cast<const T *>(p.A) + (int64_t)blockIdx.z * p.strideA;
+    const T *B = reinterpret_cast<const T *>(p.B) + (int64_t)blockIdx.z * p.strideB;
+
+    f32x16_t acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    EpiPre<TI, TJ> epre;
+    epilogue_prefetch<TI, TJ>(p, epre, lane, m0 + wm * WM, n0 + wn * WN);
+
+    const int nslab = p.K / BK, last = nslab - 1;
+    auto issue = [&](int slab, int stage) {
+        glds_half<T, BM>(A, p.lda, p.M, m0, slab * BK, smem + stage * STAGE, w, lane);
+        glds_half<T, BN>(B, p.ldb, p.N, n0, slab * BK, smem + stage * STAGE + A_BYTES, w, lane);
+    };
+    issue(0, 0);
+    issue(min(1, last), 1);
+    int stage = 0;
+    for (int s = 0; s < nslab; ++s) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // own copies of slab s landed (slab s+1's four may still fly)
+        __builtin_amdgcn_s_barrier();                     // ... and everybody else's: slab s is readable
+        int nstage = stage + 2; if (nstage >= NSTAGE) nstage -= NSTAGE;
+        issue(min(s + 2, last), nstage);                  // stage (s+2)%3 was last read at slab s-1, before this barrier
+        mma_half<T, TI, TJ>(smem + stage * STAGE, smem + stage * STAGE + A_BYTES, wm * WM, wn * WN, lane, acc);
+        stage = stage + 1 == NSTAGE ? 0 : stage + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // surplus prefetches must not land on the parked tile
+    __builtin_amdgcn_s_barrier();
+    epilogue_regs<TI, TJ>(p, acc, epre, smem + w * (WM * WN * 2), lane, m0 + wm * WM, n0 + wn * WN,
+                          (int64_t)blockIdx.z * p.strideC);
+}
+
+// host side of the choice: plain operands, K in whole half-slabs, an epilogue the register path covers for every
+// batch slice, and enough 128x128 tiles to give each CU its three workgroups
+template <typename T>
+bool glds_h_ok(const ppt_gemm_params &p, int64_t tiles128)
+{
+    static const int min_tiles = [] { const char *e = getenv("PPT_GEMM_H128_MIN"); return e ? atoi(e) : 768; }();
+    constexpr int BKH = ROWH / sizeof(T);
+    if (p.a_mode != PPT_A_PLAIN || (p.K % BKH) != 0 || tiles128 < min_tiles) return false;
+    if (p.batch > 1 && (p.strideC % 8) != 0) return false;
+    return reg_epilogue_ok<2>(p, 0);
 }
 
 template <typename T, int BM, int BN>
@@ -804,6 +1168,13 @@ int launch_gemm(const ppt_gemm_params &p, hipStream_t s)
     static const int small_below = [] { const char *e = getenv("PPT_GEMM_SMALL_BELOW"); return e ? atoi(e) : 4096; }();
     const int64_t tiles128 = (int64_t)((p.N + 127) / 128) * ((p.M + 127) / 128) * (p.batch > 0 ? p.batch : 1);
     const bool need128 = p.col_sum || p.pool_max;       // 32-row chunk partials / pools need 64-wide wave tiles
+    if (glds_h_ok<T>(p, tiles128)) {
+        dim3 grid((p.N + 127) / 128, (p.M + 127) / 128, p.batch > 0 ? p.batch : 1);
+        if (grid.y > 65535 || grid.z > 65535) return PPT_EUNSUPPORTED;
+        hipLaunchKernelGGL((gemm_kernel_glds_h<T, 128, 128>), grid, dim3(NT), 0, s, p);
+        PPT_CHECK_LAUNCH();
+        return PPT_OK;
+    }
     if (!need128 && tiles128 < small_below) return launch_gemm_tile<T, 64, 64>(p, s);
     return launch_gemm_tile<T, 128, 128>(p, s);
 }

@@ -50,6 +50,23 @@ __device__ __forceinline__ uint32_t dpp_mov(uint32_t v)
     return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
 }
 
+// Cross-half (lane ^ 32) reductions on v_permlane32_swap, with explicit wait states.  Found the hard way
+// (tools/gemm_determinism.py): when hipcc (ROCm 7.2) feeds the swap from a chain of packed-fp32 ops (v_pk_add_f32 ...
+// s_nop 0, v_mov, s_nop 1, v_permlane32_swap, VALU read) the BatchNorm chunk sums came out wrong in lanes 16-31 of
+// ~1e-4 of the chunks, different chunks on every run; the builtin leaves 0-2 wait states on either side of the swap.
+// The helper therefore does the copy and the swap itself: 8 wait states after whatever produced the value, 4 between
+// copy and swap, 8 after the swap -- ~25 cycles per reduction, nothing next to the MFMA work around it.
+// permlane32_halves(v, lo, hi): every lane l gets lo = v[l & 31], hi = v[32 + (l & 31)].
+__device__ __forceinline__ void permlane32_halves(float v, float &lo, float &hi)
+{
+    uint32_t a = __float_as_uint(v), b;
+    asm volatile("s_nop 7\n\tv_mov_b32 %1, %0\n\ts_nop 3\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 7" : "+v"(a), "=&v"(b));
+    lo = __uint_as_float(a); hi = __uint_as_float(b);
+}
+__device__ __forceinline__ float xor32_sum(float v) { float a, b; permlane32_halves(v, a, b); return a + b; }
+__device__ __forceinline__ float xor32_max(float v) { float a, b; permlane32_halves(v, a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float xor32_min(float v) { float a, b; permlane32_halves(v, a, b); return fminf(a, b); }
+
 #define PPT_DEFINE_WAVE_REDUCE(NAME, OP)                                        \
     __device__ __forceinline__ uint32_t NAME(uint32_t v)                        \
     {                                                                           \

@@ -173,6 +173,75 @@ def test_gemm_epilogues(ops, dtype):
     assert (sc.cpu() - 1 / torch.sqrt(ref.var(0, unbiased=False) + 1e-5)).abs().max().item() < 1e-3
 
 
+@pytest.mark.parametrize("M,N,K,group_rows,pool_rows,stats,act", [
+    (640, 384, 256, 0, 0, False, "gelu"),          # 64x64 LDS-DMA tiles, bias + GELU
+    (1000, 136, 64, 16, 0, False, "none"),         # ragged M and N, 16-row groups
+    (650, 256, 128, 32, 32, True, "none"),         # register-staged 128x128: group term + statistics + pool, ragged M
+    (1040, 128, 64, 64, 16, True, "relu"),         # 16-row pools (max and min)
+    (1088, 128, 64, 0, 64, False, "quickgelu"),    # 64-row pools
+    (12800, 1024, 96, 0, 0, False, "gelu"),        # >= 768 tiles of 128x128: half-slab LDS-DMA kernel
+    (25000, 512, 64, 32, 32, True, "none"),        # the same kernel with the conv3 epilogue, ragged M
+])
+def test_gemm_register_epilogue(ops, M, N, K, group_rows, pool_rows, stats, act):
+    """bf16 C (or none) with per-column / per-row-group epilogue terms: the MFMA-layout epilogue of gemm.hip."""
+    rng = np.random.default_rng(M + N + K)
+    A = dev(rng.standard_normal((M, K)).astype(np.float32), torch.bfloat16)
+    Bm = dev((rng.standard_normal((N, K)) / math.sqrt(K)).astype(np.float32), torch.bfloat16)
+    bias = dev(rng.standard_normal(N).astype(np.float32))
+    kw = dict(bias=bias)
+    ref = A.float().cpu() @ Bm.float().cpu().t() + bias.cpu()
+    if group_rows:
+        ng = (M + group_rows - 1) // group_rows
+        gadd = dev(rng.standard_normal((ng, N)).astype(np.float32))
+        kw.update(group_add=gadd, group_rows=group_rows)
+        ref = ref + gadd.cpu().repeat_interleave(group_rows, 0)[:M]
+    pre = ref
+    code, fn = {"none": (ops.ACT_NONE, lambda x: x), "relu": (ops.ACT_RELU, torch.relu), "gelu": (ops.ACT_GELU, O.gelu_erf),
+                "quickgelu": (ops.ACT_QUICKGELU, O.quick_gelu)}[act]
+    ref = fn(ref)
+    if stats:
+        nchunk = (M + 31) // 32
+        cs = torch.full((nchunk, N), float("nan"), device="cuda"); cq = torch.full_like(cs, float("nan"))
+        kw["col_stats"] = (cs, cq)
+    if pool_rows:
+        npool = (M + pool_rows - 1) // pool_rows
+        pmax = torch.full((npool, N), float("nan"), device="cuda"); pmin = torch.full_like(pmax, float("nan"))
+        kw.update(pool_max=pmax, pool_min=pmin, pool_rows=pool_rows)
+    out = ops.gemm(A, Bm, out_dtype=torch.bfloat16, act=code, **kw)
+    torch.cuda.synchronize()
+    assert torch.allclose(out.float().cpu(), ref, rtol=1e-2, atol=1e-2)
+    if stats:                                        # statistics are taken before the activation, per 32-row chunk
+        for c0 in (0, nchunk // 2, nchunk - 1):
+            rows = pre[c0 * 32:(c0 + 1) * 32]
+            assert torch.allclose(cs[c0].cpu(), rows.sum(0), rtol=1e-4, atol=1e-3)
+            assert torch.allclose(cq[c0].cpu(), ((rows - rows.mean(0)) ** 2).sum(0), rtol=1e-3, atol=1e-3)
+        nfull = M // 32                               # every whole chunk (a rare wrong lane group must not hide)
+        chunks = pre[:nfull * 32].view(nfull, 32, N)
+        assert torch.allclose(cs[:nfull].cpu(), chunks.sum(1), rtol=1e-4, atol=2e-3)
+        assert torch.allclose(cq[:nfull].cpu(), ((chunks - chunks.mean(1, keepdim=True)) ** 2).sum(1), rtol=1e-3, atol=2e-3)
+        # the launch is bit-reproducible
+        cs2 = torch.empty_like(cs); cq2 = torch.empty_like(cq)
+        kw3 = dict(kw); kw3["col_stats"] = (cs2, cq2)
+        for _ in range(3):
+            out_b = ops.gemm(A, Bm, out_dtype=torch.bfloat16, act=code, **kw3)
+            torch.cuda.synchronize()
+            assert torch.equal(out_b, out) and torch.equal(cs2, cs) and torch.equal(cq2, cq)
+    if pool_rows:
+        for g0 in (0, npool // 2, npool - 1):
+            rows = ref[g0 * pool_rows:(g0 + 1) * pool_rows]
+            assert torch.allclose(pmax[g0].cpu(), rows.max(0)[0], rtol=1e-5, atol=1e-5)
+            assert torch.allclose(pmin[g0].cpu(), rows.min(0)[0], rtol=1e-5, atol=1e-5)
+        full = (M // pool_rows) * pool_rows
+        assert torch.allclose(pmax[:M // pool_rows].cpu(), ref[:full].view(-1, pool_rows, N).max(1)[0], rtol=1e-5, atol=1e-5)
+    # the same launch without a C: pooled / statistics-only GEMMs (conv4)
+    if pool_rows:
+        pm2 = torch.empty_like(pmax)
+        kw2 = dict(kw); kw2.update(pool_max=pm2, pool_min=None); kw2.pop("col_stats", None)
+        ops.gemm(A, Bm, act=code, want_out=False, **kw2)
+        torch.cuda.synchronize()
+        assert torch.equal(pm2, pmax)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_gemm_prologues(ops, dtype):
     rng = np.random.default_rng(12)
