@@ -392,6 +392,15 @@ __device__ __forceinline__ void epilogue_vec8(const ppt_gemm_params &p, float *c
             }
         }
     }
+    constexpr bool PRE2 = NPASS <= 2;                      // (64x64 tiles; eight passes of it would spill)
+    uint4 pre2[PRE2 ? NPASS : 1][2];                       // second fp32 residual (the next block's "+ pos")
+    if (PRE2 && (FEAT & 1) && p.residual2) {
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const float *q = p.residual2 + (int64_t)min(mw + pass * RP + rl, p.M - 1) * p.ld_res2 + nc;
+            pre2[pass][0] = *reinterpret_cast<const uint4 *>(q); pre2[pass][1] = *reinterpret_cast<const uint4 *>(q + 4);
+        }
+    }
     auto pre_f8 = [&](int pass, bool packed_bf16) {
         f8 r;
         const uint4 a = pre[pass][0], b = pre[pass][1];
@@ -454,7 +463,14 @@ __device__ __forceinline__ void epilogue_vec8(const ppt_gemm_params &p, float *c
                 for (int e = 0; e < 8; ++e) v.v[e] += r.v[e];
             }
             if ((FEAT & 1) && p.residual2) {
-                const f8 r = ld8_f32(p.residual2 + (int64_t)m * p.ld_res2 + n);
+                f8 r;
+                if constexpr (PRE2) {
+                    const uint4 a = pre2[pass][0], b = pre2[pass][1];
+                    r = f8{{__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w),
+                            __uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w)}};
+                } else {
+                    r = ld8_f32(p.residual2 + (int64_t)m * p.ld_res2 + n);
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v.v[e] += r.v[e];
             }

@@ -117,14 +117,20 @@ def mini_pointnet(sd, p, wc, nbhd, bn_train, update_running=True):
     return tok
 
 
-def vit_block_forward(sd, p, wc, x, pos, B, Tn, heads, dp1, dp2, save=None):
+def vit_block_forward(sd, p, wc, x, pos, B, Tn, heads, dp1, dp2, save=None, pos_in_x=False, add_pos_out=False):
     """Block.forward on block(x + pos) (point_encoder.py:76-79,103).  x [B*Tn, D] fp32 is updated in
-    place unless `save` (a dict) is given: then every intermediate the backward needs is kept."""
+    place unless `save` (a dict) is given: then every intermediate the backward needs is kept.
+    pos_in_x: x already holds x + pos (the previous block's fc2 epilogue added it: add_pos_out there), so norm1
+    neither reads pos nor rewrites the residual stream; the sums are formed in the same order either way."""
     T = wc.dtype
     keep = save is not None
-    xs = torch.empty_like(x) if keep else x
-    h, mean1, rstd1 = ops.layernorm_fwd(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], T, add=pos, write_xs=xs,
-                                        save_stats=keep)
+    if pos_in_x:
+        xs = x
+        h, mean1, rstd1 = ops.layernorm_fwd(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], T, save_stats=keep)
+    else:
+        xs = torch.empty_like(x) if keep else x
+        h, mean1, rstd1 = ops.layernorm_fwd(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], T, add=pos, write_xs=xs,
+                                            save_stats=keep)
     qkv = ops.gemm(h, wc.get(sd[p + "attn.qkv.weight"]), out_dtype=T)
     a, lse = ops.attention_fwd(qkv, B, Tn, heads, ATTN_SCALE, False, want_lse=keep)
     x_mid = torch.empty_like(x) if keep else xs
@@ -136,7 +142,7 @@ def vit_block_forward(sd, p, wc, x, pos, B, Tn, heads, dp1, dp2, save=None):
                  out2=pre, out2_pre=True)
     x_out = torch.empty_like(x) if keep else x_mid
     ops.gemm(f, wc.get(sd[p + "mlp.fc2.weight"]), out=x_out, bias=sd[p + "mlp.fc2.bias"], row_scale=dp2,
-             row_scale_rows=Tn, residual=x_mid)
+             row_scale_rows=Tn, residual=x_mid, residual2=pos if add_pos_out else None)
     if keep:
         save.update(xs=xs, mean1=mean1, rstd1=rstd1, h=h, qkv=qkv, a=a, lse=lse, x_mid=x_mid, mean2=mean2,
                     rstd2=rstd2, h2=h2, pre=pre, f=f, dp1=dp1, dp2=dp2)
@@ -166,15 +172,20 @@ def point_encoder_forward(sd, p, wc, pc, fps_start, dp, bn_train, save_tier, cfg
              strideA=G * pe.shape[1], strideC=Tn * D)
     saved = None
     fetched = []
+    pos_in_x = False
     for l in range(depth):
         bp = f"{p}blocks.blocks.{l}."
         d1 = dp[l, 0] if dp is not None else None
         d2 = dp[l, 1] if dp is not None else None
+        # the next block's "+ pos" rides in this block's fc2 epilogue (unless the block output itself is wanted)
+        add_pos_out = l + 1 < depth and not (fetch is not None and l in fetch)
         if save_tier > 0 and l == depth - 1:
             saved = {}
-            x2 = vit_block_forward(sd, bp, wc, x2, pos2, B, Tn, heads, d1, d2, save=saved)
+            x2 = vit_block_forward(sd, bp, wc, x2, pos2, B, Tn, heads, d1, d2, save=saved, pos_in_x=pos_in_x,
+                                   add_pos_out=add_pos_out)
         else:
-            x2 = vit_block_forward(sd, bp, wc, x2, pos2, B, Tn, heads, d1, d2)
+            x2 = vit_block_forward(sd, bp, wc, x2, pos2, B, Tn, heads, d1, d2, pos_in_x=pos_in_x, add_pos_out=add_pos_out)
+        pos_in_x = add_pos_out
         if fetch is not None and l in fetch:        # part-seg: norm(x)[:, 1:] after blocks 3, 7, 11 (point_encoder.py:100-108,377)
             fn, _, _ = ops.layernorm_fwd(x2, sd[p + "norm.weight"], sd[p + "norm.bias"], torch.float32)
             fetched.append(fn.view(B, Tn, D)[:, 1:])

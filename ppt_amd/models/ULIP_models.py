@@ -329,6 +329,8 @@ class ULIP_WITH_IMAGE(nn.Module):
         self.point_encoder.precision = dtype
         self.point_encoder._wc = None
         self._graphs.clear()
+        if hasattr(self.point_encoder, "_graphs"):
+            self.point_encoder._graphs.clear()
         if hasattr(self.point_encoder, "encoder"):
             self.point_encoder.encoder.precision = dtype
         return self

@@ -4,7 +4,7 @@ forward of PointTransformer is ONE autograd node running ppt_amd.engine's kernel
 import torch
 import torch.nn as nn
 
-from ... import engine, ops
+from ... import engine, graphs, ops
 from .dvae import Encoder, Group
 
 
@@ -83,10 +83,22 @@ class _PointEncoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, module, pc, fps_start, dp, tier, names, *params):
-        sd = module._live_state()
-        feat, saved = engine.point_encoder_forward(sd, "", module._cache(), pc, fps_start, dp, module.training, tier,
-                                                   module._cfg())
-        ctx.module, ctx.saved, ctx.tier, ctx.names = module, saved, tier, names
+        sd, cache, cfg, train = module._live_state(), module._cache(), module._cfg(), module.training
+        ctx.module, ctx.tier, ctx.names = module, tier, names
+        # tier 0 (everything frozen, nothing kept for a backward): ~140 launches whose arguments depend on shapes only --
+        # replayed from a hipGraph after graphs.WARMUP_CALLS eager calls (ppt_amd/graphs.py; 2 us less per launch)
+        key = ("point_fwd", tuple(pc.shape), dp is not None, train, cache.dtype)
+        if (tier == 0 and pc.is_cuda and module.use_hip_graphs and ops.profiler is None and module._graphs.ready(key)):
+            def build():
+                def fn(pc_, start_, *dp_):
+                    feat_, _ = engine.point_encoder_forward(sd, "", cache, pc_, start_, dp_[0] if dp_ else None, train, 0, cfg)
+                    return (feat_,), None
+                return graphs.GraphedCall(fn, [pc, fps_start] + ([dp] if dp is not None else []))
+            (feat,), _ = module._graphs.get(key, build)(pc, fps_start, *([dp] if dp is not None else []))
+            ctx.saved = None
+            return feat.clone()
+        feat, saved = engine.point_encoder_forward(sd, "", cache, pc, fps_start, dp, train, tier, cfg)
+        ctx.saved = saved
         return feat
 
     @staticmethod
@@ -133,6 +145,8 @@ class PointTransformer(nn.Module):
                                          num_heads=self.num_heads)
         self.norm = nn.LayerNorm(self.trans_dim)
         self.precision = torch.bfloat16
+        self._graphs = graphs.GraphCache()
+        self.use_hip_graphs = True
         self.fps_start = None            # [B] int64: injected FPS start indices (else torch.randint)
         self.drop_path_factors = None    # [depth,2,B] fp32: injected DropPath factors (else drawn on device)
         self._wc = None
@@ -152,10 +166,15 @@ class PointTransformer(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._sd = None
+        if hasattr(self, "_graphs"):
+            self._graphs.clear()
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
         self._sd = None
+        self._wc = None
+        if hasattr(self, "_graphs"):
+            self._graphs.clear()
         return super().load_state_dict(*a, **k)
 
     def _cfg(self):

@@ -176,7 +176,7 @@ def test_run_ahead_training_is_identical(head_type):
     results = []
     for run_ahead, hip_graphs in ((False, False), (True, False), (True, True)):
         m, _ = build(head_type, torch.bfloat16)
-        m.use_hip_graphs = hip_graphs
+        m.use_hip_graphs = m.point_encoder.use_hip_graphs = hip_graphs
         m.train()
         torch.manual_seed(5)                   # DropPath factors are drawn on the device
         m.point_encoder.fps_start = torch.from_numpy(start).cuda()
@@ -193,6 +193,7 @@ def test_run_ahead_training_is_identical(head_type):
         results.append(([l.item() for l in losses], pred.clone(),
                         {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad}))
         assert bool(m._graphs.entries) == hip_graphs          # the text tower really was replayed from a hipGraph
+        assert bool(m.point_encoder._graphs.entries) == (hip_graphs and head_type == 0)      # and the frozen point tower
     la, pa, wa = results[0]
     for lb, pb, wb in results[1:]:
         assert la == lb
