@@ -9,9 +9,11 @@ and replayed with its inputs copied into the captured buffers.  Eager execution 
 behaviour: the first `warmup` calls of every key run eagerly (they also populate the operand caches,
 which must not be allocated inside a capture), and `enabled = False` turns replay off globally.
 """
+import os
+
 import torch
 
-enabled = True
+enabled = os.environ.get("PPT_HIP_GRAPHS", "1") != "0"      # PPT_HIP_GRAPHS=0: eager launches only (per-dispatch counters)
 WARMUP_CALLS = 2
 
 

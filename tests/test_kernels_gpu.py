@@ -242,6 +242,35 @@ def test_gemm_register_epilogue(ops, M, N, K, group_rows, pool_rows, stats, act)
         assert torch.equal(pm2, pmax)
 
 
+@pytest.mark.parametrize("dtype,M,N,K", [(torch.bfloat16, 14080, 384, 96), (torch.float32, 14100, 392, 48),
+                                          (torch.bfloat16, 16416, 384, 1536)])
+def test_gemm_residual_epilogue_full_size(ops, dtype, M, N, K):
+    """proj / fc2 at full size: bias, DropPath row scale, fp32 residual stream in and out, the next block's + pos
+    (the LDS-walk epilogue of the 64x64 LDS-DMA kernel), and the GELU-derivative epilogue; bit-reproducible."""
+    rng = np.random.default_rng(M + N)
+    A = dev(rng.standard_normal((M, K)).astype(np.float32), dtype)
+    Bm = dev((rng.standard_normal((N, K)) / math.sqrt(K)).astype(np.float32), dtype)
+    bias = dev(rng.standard_normal(N).astype(np.float32))
+    res = dev(rng.standard_normal((M, N)).astype(np.float32))
+    res2 = dev(rng.standard_normal((M, N)).astype(np.float32))
+    rows = 470
+    rs = dev(rng.random((M + rows - 1) // rows).astype(np.float32))
+    out = ops.gemm(A, Bm, out_dtype=torch.float32, bias=bias, row_scale=rs, row_scale_rows=rows, residual=res, residual2=res2)
+    ref = (A.float().cpu() @ Bm.float().cpu().t() + bias.cpu()) * rs.cpu().repeat_interleave(rows)[:M, None] + res.cpu() + res2.cpu()
+    tol = 3e-3 if dtype == torch.bfloat16 else 5e-5
+    assert (out.cpu() - ref).abs().max().item() < tol * (1 if K < 512 else 4)
+    out_b = ops.gemm(A, Bm, out_dtype=torch.float32, bias=bias, row_scale=rs, row_scale_rows=rows, residual=res, residual2=res2)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out_b)
+    # derivative epilogue with a bf16 / fp32 saved pre-activation
+    pre = dev(rng.standard_normal((M, N)).astype(np.float32), dtype)
+    d = ops.gemm(A, Bm, out_dtype=dtype, act=ops.ACT_GELU, dact_pre=pre)
+    x = pre.float().cpu().requires_grad_(True)
+    (g,) = torch.autograd.grad(O.gelu_erf(x).sum(), x)
+    want = (A.float().cpu() @ Bm.float().cpu().t()) * g
+    assert torch.allclose(d.float().cpu(), want, rtol=2e-2, atol=2e-2)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_gemm_prologues(ops, dtype):
     rng = np.random.default_rng(12)
