@@ -71,18 +71,40 @@ def dataset_classnames(name):
     return list(_token_table()["datasets"][name])
 
 
-def tokenize_prompts(classnames, n_ctx, template_tokens=None):
-    """Token ids of "X X ... X <name>." per class (ULIP_models.py:87-100) -> (ids [C,77] int64, name_lengths).
-    Class names must be in ppt_amd/data/classnames.json (all reference datasets are); a full BPE
-    tokenizer is the 'next' row N3."""
+_BPE = {}
+
+
+def _bpe(bpe_path=None):
+    """The build's CLIP tokenizer (ppt_amd/tokenizer.py), or None when the merge table is not available."""
+    from .. import tokenizer as T
+    path = T.find_vocab(bpe_path)
+    if path is None:
+        return None
+    if path not in _BPE:
+        _BPE[path] = T.SimpleTokenizer(path)
+    return _BPE[path]
+
+
+def name_token_ids(name, bpe_path=None):
+    """BPE ids of one class name / template word: the committed fixture for the reference's datasets, the tokenizer
+     for anything else."""
+    tab = _token_table()
+    key = name.replace("_", " ")
+    if key in tab["name_tokens"]:
+        return list(tab["name_tokens"][key])
+    tok = _bpe(bpe_path)
+    if tok is None:
+        raise KeyError(f"class name {key!r} has no captured token ids (ppt_amd/data/classnames.json) and the CLIP merge "
+                       "table was not found (ppt_amd/tokenizer.py: PPT_BPE_VOCAB or ./utils/bpe_simple_vocab_16e6.txt.gz)")
+    return tok.encode(key)
+
+
+def tokenize_prompts(classnames, n_ctx, template_tokens=None, bpe_path=None):
+    """Token ids of "X X ... X <name>." per class (ULIP_models.py:87-100) -> (ids [C,77] int64, name_lengths)."""
     tab = _token_table()
     ids, lens = [], []
     for name in classnames:
-        key = name.replace("_", " ")
-        if key not in tab["name_tokens"]:
-            raise KeyError(f"class name {key!r} has no captured token ids (ppt_amd/data/classnames.json); "
-                           "BPE tokenisation of arbitrary names is not built yet (SURVEY.md §8(f) N3)")
-        nt = tab["name_tokens"][key]
+        nt = name_token_ids(name, bpe_path)
         ctx = template_tokens if template_tokens is not None else [tab["placeholder"]] * n_ctx
         row = [tab["sot"]] + list(ctx) + nt + [tab["period"], tab["eot"]]
         if len(row) > CONTEXT_LENGTH:
@@ -104,12 +126,12 @@ class PromptLearner(nn.Module):
         template_tokens = None
         if kwargs.template_init != '':
             words = kwargs.template_init.replace("_", " ").split(' ')
-            tab = _token_table()
             template_tokens = []
             for wd in words:
-                if wd not in tab["name_tokens"] or len(tab["name_tokens"][wd]) != 1:
-                    raise KeyError(f"template word {wd!r} has no captured single token id (SURVEY.md §8(f) N3)")
-                template_tokens += tab["name_tokens"][wd]
+                template_tokens += name_token_ids(wd)
+            if len(template_tokens) != len(words):       # ULIP_models.py:82: one learnable token per template WORD
+                raise RuntimeError("every word of template_init must be a single BPE token "
+                                   f"({kwargs.template_init!r} -> {len(template_tokens)} tokens for {len(words)} words)")
             self.num_learnable_prompt_tokens = len(words)
         else:
             self.num_learnable_prompt_tokens = kwargs.num_learnable_prompt_tokens

@@ -1,0 +1,74 @@
+"""N3: the build's own CLIP BPE tokenizer against the token ids captured from the reference's SimpleTokenizer
+(ppt_amd/data/classnames.json, written by tests/golden/make_golden.py).  Needs the public CLIP merge table, which is
+not shipped: found through PPT_BPE_VOCAB / ./utils/ or, in the build container, beside the reference's tokenizer."""
+import json
+import os
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_VOCAB = "/root/reference/utils/bpe_simple_vocab_16e6.txt.gz"
+
+
+def _tokenizer():
+    from ppt_amd import tokenizer as T
+    path = T.find_vocab() or (REF_VOCAB if os.path.exists(REF_VOCAB) else None)
+    if path is None:
+        pytest.skip("CLIP merge table not available")
+    return T.SimpleTokenizer(path)
+
+
+def test_byte_symbol_table_is_a_bijection_without_whitespace():
+    from ppt_amd import tokenizer as T
+    tab = T.byte_symbols()
+    assert len(set(tab.values())) == 256
+    assert not any(c.isspace() for c in tab.values())
+    assert tab[ord("a")] == "a" and tab[ord(" ")] == chr(256 + 32) and tab[0] == chr(256)
+
+
+def test_encode_matches_captured_reference_ids():
+    tok = _tokenizer()
+    tab = json.load(open(os.path.join(ROOT, "ppt_amd", "data", "classnames.json")))
+    assert tok.encoder["<|startoftext|>"] == tab["sot"] and tok.encoder["<|endoftext|>"] == tab["eot"]
+    assert tok.encode("X") == [tab["placeholder"]] and tok.encode(".") == [tab["period"]]
+    for name, ids in tab["name_tokens"].items():
+        assert tok.encode(name) == ids, name
+
+
+def test_prompt_rows_match_the_fixture_path():
+    """tokenizer("X X ... X name.") == the row tokenize_prompts builds from the fixture (ULIP_models.py:87-100)."""
+    tok = _tokenizer()
+    from ppt_amd.models.ULIP_models import dataset_classnames, tokenize_prompts
+    for ds in ("modelnet40", "scanobjectnn", "shapenetpart"):
+        names = dataset_classnames(ds)
+        want, lens = tokenize_prompts(names, 32)
+        got = tok([" ".join(["X"] * 32) + " " + n.replace("_", " ") + "." for n in names])
+        assert torch.equal(got, want)
+        assert lens == [len(tok.encode(n.replace("_", " "))) for n in names]
+
+
+def test_cleaning_contractions_digits_and_round_trip():
+    tok = _tokenizer()
+    assert tok.encode("A  Photo\nof a CAT") == tok.encode("a photo of a cat")
+    assert tok.encode("&amp;amp;") == tok.encode("&")
+    ids = tok.encode("it's 42 tables, isn't it?")
+    assert tok.decode(ids) == "it 's 4 2 tables , isn 't it ? "
+    row = tok("a chair", context_length=8)
+    assert row.tolist()[0] == 49406 and row.tolist()[3] == 49407 and row.tolist()[4:] == [0] * 4
+    long = tok("chair " * 100, context_length=77)
+    assert long.shape == (77,) and int(long[-1]) != 0
+
+
+def test_unknown_class_names_fall_back_to_the_tokenizer():
+    tok = _tokenizer()
+    from ppt_amd.models import ULIP_models as M
+    ids, lens = M.tokenize_prompts(["rocking_horse", "chair"], 4, bpe_path=tok_path())
+    assert lens == [len(tok.encode("rocking horse")), 1]
+    assert ids[0].tolist()[:5] == [49406, 343, 343, 343, 343]
+    assert ids[0].tolist()[5:5 + lens[0]] == tok.encode("rocking horse")
+
+
+def tok_path():
+    from ppt_amd import tokenizer as T
+    return T.find_vocab() or REF_VOCAB
