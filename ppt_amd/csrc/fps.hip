@@ -76,22 +76,42 @@ __global__ __launch_bounds__(W * 64) void fps_kernel(const float *__restrict__ x
         }
         const uint32_t bits = __float_as_uint(best);
         const uint32_t wmax = wave_reduce_umax(bits);
-        const uint32_t widx = wave_reduce_umin(bits == wmax ? bi : 0xFFFFFFFFu);
+        // the lane that holds the wave's arg-max: with a single maximal lane (the common case) a ballot names it; equal
+        // distances in several lanes (duplicated points) go through the index reduction, lowest index wins
+        uint64_t cand = __ballot(bits == wmax);
+        if (__popcll(cand) != 1) {                // wave-uniform
+            const uint32_t wlow = wave_reduce_umin(bits == wmax ? bi : 0xFFFFFFFFu);
+            cand = __ballot(bits == wmax && bi == wlow);
+        }
+        const int wl = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)cand) - 1);
+        const uint32_t widx = (uint32_t)__builtin_amdgcn_readlane((int)bi, wl);
+        const float wx = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(bx), wl));
+        const float wy = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(by), wl));
+        const float wz = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(bz), wl));
         fps_slot *sl = slots + (it & 1) * W;
-        if (bits == wmax && bi == widx) {         // exactly one lane per wave
-            sl[w].dist_bits = wmax; sl[w].idx = widx; sl[w].x = bx; sl[w].y = by; sl[w].z = bz;
+        if (lane == 0) {                          // the wave's winner sits in SGPRs now: one lane publishes it
+            sl[w].dist_bits = wmax; sl[w].idx = widx; sl[w].x = wx; sl[w].y = wy; sl[w].z = wz;
         }
         __syncthreads();
-        uint32_t gd = sl[0].dist_bits, gi = sl[0].idx;
-        float gx = sl[0].x, gy = sl[0].y, gz = sl[0].z;
+        // every thread folds the W slots: ALL slots are fetched first (independent 16-byte reads, one wait) and folded
+        // with selects -- written as a chain of compare-and-reload the compiler emitted W dependent LDS round trips with
+        // a branch each, which was most of the step
+        uint4 sa[W];
+        float sz[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            sa[k] = *reinterpret_cast<const uint4 *>(&sl[k]);
+            sz[k] = sl[k].z;
+        }
+        uint32_t gd = sa[0].x, gi = sa[0].y;
+        float gx = __uint_as_float(sa[0].z), gy = __uint_as_float(sa[0].w), gz = sz[0];
 #pragma unroll
         for (int k = 1; k < W; ++k) {
-            const uint32_t d2 = sl[k].dist_bits, i2 = sl[k].idx;
-            const bool take = d2 > gd || (d2 == gd && i2 < gi);
-            if (take) { gd = d2; gi = i2; gx = sl[k].x; gy = sl[k].y; gz = sl[k].z; }
+            const bool take = (sa[k].x > gd) | ((sa[k].x == gd) & (sa[k].y < gi));      // (no short circuit: no branch)
+            gd = take ? sa[k].x : gd; gi = take ? sa[k].y : gi;
+            gx = take ? __uint_as_float(sa[k].z) : gx; gy = take ? __uint_as_float(sa[k].w) : gy; gz = take ? sz[k] : gz;
         }
         cur = (int)gi; cx = gx; cy = gy; cz = gz;
-        (void)lane;
     }
     __syncthreads();
     for (int i = t; i < M; i += T) out_idx[(size_t)b * M + i] = (int64_t)idx_list[i];
