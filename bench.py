@@ -161,12 +161,19 @@ def main():
 
     roof = None
     if rank == 0 and not a.no_roofline:
-        # second pass over the same K steps with every launch of the hot kernels bracketed by HIP events
-        ops.profiler = ops.KernelProfiler()
-        for _ in range(a.steps):
-            trainer.step(pc, label)
-        torch.cuda.synchronize()
-        summ = ops.profiler.summary()
+        # further passes over the same K steps with every launch of the hot kernels bracketed by HIP events.  These
+        # passes run eagerly (no hipGraph replay: events cannot be recorded inside one) and the host, slowed by two
+        # event records per launch, falls behind the GPU, so how much of the text stream happens to overlap the point
+        # tower's GEMMs -- and with it their duration -- varies from pass to pass (3.0 .. 4.2 ms of GEMM time per step
+        # seen on one box).  Three passes; the median one (by GEMM time) is reported.
+        passes = []
+        for _ in range(3):
+            ops.profiler = ops.KernelProfiler()
+            for _ in range(a.steps):
+                trainer.step(pc, label)
+            torch.cuda.synchronize()
+            passes.append(ops.profiler.summary())
+        summ = sorted(passes, key=lambda d: d["gemm_bf16"]["ms"])[1]
         # an event pair around ANY launch also times the dispatch gaps on both sides of it; calibrate that on a
         # trivial kernel (1-element dtype conversion, ~1.5 us of execution) and take it off every bracket, so that
         # the per-launch figure is comparable with rocprofv3's kernel-only durations (profiles/)

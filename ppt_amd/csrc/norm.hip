@@ -53,6 +53,69 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x
     }
 }
 
+// D % 8 == 0 and D <= 512 (both towers: 384, 512): lane c owns columns 8c .. 8c+7, so a row is two 16-byte loads
+// (+ two for the fused add) and ONE 16-byte bf16 store per lane instead of six 4-byte loads and six 2-byte stores;
+// gamma / beta stay in registers while the wave walks its rows (rows strided by the number of waves in the grid).
+// Same arithmetic as ln_fwd_kernel (two-pass mean / variance), summed in a different lane order.
+template <typename TY>
+__global__ __launch_bounds__(256) void ln_fwd_vec8_kernel(const float *__restrict__ x, const float *__restrict__ add,
+                                                          int add_rows, float *__restrict__ xs,
+                                                          const float *__restrict__ w, const float *__restrict__ b,
+                                                          TY *__restrict__ y, float *__restrict__ mean_out,
+                                                          float *__restrict__ rstd_out, int M, int D, float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const int nw = gridDim.x * 4;
+    const bool on = lane * 8 < D;
+    const int c = on ? lane * 8 : 0;
+    float g[8], be[8];
+    {
+        const float4 g0 = *reinterpret_cast<const float4 *>(w + c), g1 = *reinterpret_cast<const float4 *>(w + c + 4);
+        const float4 b0 = *reinterpret_cast<const float4 *>(b + c), b1 = *reinterpret_cast<const float4 *>(b + c + 4);
+        g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
+        be[0] = b0.x; be[1] = b0.y; be[2] = b0.z; be[3] = b0.w; be[4] = b1.x; be[5] = b1.y; be[6] = b1.z; be[7] = b1.w;
+    }
+    const float inv_d = 1.0f / (float)D;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += nw) {
+        const float *xr = x + (size_t)row * D + c;
+        float4 v0 = *reinterpret_cast<const float4 *>(xr), v1 = *reinterpret_cast<const float4 *>(xr + 4);
+        if (add) {
+            const float *ar = add + (size_t)(add_rows > 0 ? row % add_rows : row) * D + c;
+            const float4 a0 = *reinterpret_cast<const float4 *>(ar), a1 = *reinterpret_cast<const float4 *>(ar + 4);
+            v0.x += a0.x; v0.y += a0.y; v0.z += a0.z; v0.w += a0.w; v1.x += a1.x; v1.y += a1.y; v1.z += a1.z; v1.w += a1.w;
+        }
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
+        const float mean = wave_reduce_sum(on ? s : 0.f) * inv_d;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = v[j] - mean; q = fmaf(d, d, q); }
+        const float rstd = 1.0f / sqrtf(wave_reduce_sum(on ? q : 0.f) * inv_d + eps);
+        if (on) {
+            if (xs) {
+                *reinterpret_cast<float4 *>(xs + (size_t)row * D + c) = v0;
+                *reinterpret_cast<float4 *>(xs + (size_t)row * D + c + 4) = v1;
+            }
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (v[j] - mean) * rstd * g[j] + be[j];
+            if constexpr (sizeof(TY) == 2) {
+                *reinterpret_cast<uint4 *>(y + (size_t)row * D + c) =
+                    make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+            } else {
+                *reinterpret_cast<float4 *>(y + (size_t)row * D + c) = make_float4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<float4 *>(y + (size_t)row * D + c + 4) = make_float4(o[4], o[5], o[6], o[7]);
+            }
+        }
+        if (lane == 0) {
+            if (mean_out) mean_out[row] = mean;
+            if (rstd_out) rstd_out[row] = rstd;
+        }
+    }
+}
+
 // wave g handles rows [g*rpw, (g+1)*rpw); dw/db partial row g.
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ xs,
                                                      const float *__restrict__ w, const float *__restrict__ mean,
@@ -118,6 +181,19 @@ extern "C" int ppt_layernorm_fwd(const float *x, const float *add, int add_rows,
                                  float eps, void *stream)
 {
     if (!x || !w || !b || !y || M <= 0 || D <= 0 || D > 64 * MAX_EPL) return PPT_EINVAL;
+    if (y_dtype != PPT_BF16 && y_dtype != PPT_F32) return PPT_EINVAL;
+    const bool al = (((uintptr_t)x | (uintptr_t)w | (uintptr_t)b | (uintptr_t)y | (uintptr_t)add | (uintptr_t)xs) & 15) == 0;
+    if ((D % 8) == 0 && D <= 512 && al) {
+        dim3 vgrid(min((M + 3) / 4, 256 * 8));         // 8 workgroups per CU; each wave walks rows with that stride
+        if (y_dtype == PPT_BF16)
+            hipLaunchKernelGGL(ln_fwd_vec8_kernel<bf16_t>, vgrid, dim3(256), 0, ppt_stream(stream), x, add, add_rows, xs, w, b,
+                               (bf16_t *)y, mean, rstd, M, D, eps);
+        else
+            hipLaunchKernelGGL(ln_fwd_vec8_kernel<float>, vgrid, dim3(256), 0, ppt_stream(stream), x, add, add_rows, xs, w, b,
+                               (float *)y, mean, rstd, M, D, eps);
+        PPT_CHECK_LAUNCH();
+        return PPT_OK;
+    }
     dim3 grid((M + 3) / 4);
     if (y_dtype == PPT_BF16)
         hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, dim3(256), 0, ppt_stream(stream), x, add, add_rows, xs, w, b,
