@@ -34,7 +34,7 @@ __device__ __forceinline__ float lane_xor32_max(float v) { return xor32_max(v); 
 __device__ __forceinline__ float lane_xor32_sum(float v) { return xor32_sum(v); }
 
 template <bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_fwd_mfma(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out,
+__global__ __launch_bounds__(256, 2) void attn_fwd_mfma(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out,
                                                      float *__restrict__ lse, int T, int H, float c /* scale*log2(e) */)
 {
     __shared__ __align__(16) unsigned char smem[4 * TILE];    // K0 K1 V0 V1
@@ -231,7 +231,7 @@ constexpr int QT = 32;                       // query rows per staged tile in th
 constexpr int QTILE = QT * 128;              // bytes per 32-row image
 
 template <bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dout,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dout,
                                                          const float *__restrict__ lse, const float *__restrict__ delta,
                                                          bf16_t *__restrict__ dqkv, int T, int H, float scale)
 {
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const bf16_t *__restric
 }
 
 template <bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dout,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dout,
                                                         const float *__restrict__ lse, const float *__restrict__ delta,
                                                         bf16_t *__restrict__ dqkv, int T, int H, float scale)
 {

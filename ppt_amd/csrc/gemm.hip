@@ -937,7 +937,7 @@ __device__ __forceinline__ void glds_slab(const T *base, int64_t ld, int rows, i
 }
 
 template <typename T, int BM, int BN>
-__global__ __launch_bounds__(NT) void gemm_kernel_glds(const ppt_gemm_params p)
+__global__ __launch_bounds__(NT, BM == 64 ? 3 : 1) void gemm_kernel_glds(const ppt_gemm_params p)   // (a waves-per-SIMD floor keeps the accumulators out of AGPRs)
 {
     constexpr int WM = BM / 2, WN = BN / 2, TI = WM / 32, TJ = WN / 32;
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES, NSTAGE = 3;
