@@ -484,3 +484,29 @@ def text_tower_backward(sd, wc, s, dout):
     full = torch.zeros((C, s["Lfull"], Wd), dtype=torch.float32, device=dout.device)   # positions past the last EOT: zero gradient
     full[:, :L] = g.view(C, L, Wd)
     return full
+
+
+def head_loss_forward_backward(feat, wt, text_raw, logit_scale, labels, smoothing):
+    """The step between the towers when only the prompt trains (head_type 0): pc_embed = feat @ pc_projection
+    (ULIP_models.py:257), text features L2-normalised (:279), logits = exp(logit_scale) * pc_embed @ text^T (:281),
+    label-smoothed cross entropy with mean reduction (main_cls.py:52,196) -- and, in the same pass, the gradient of the
+    loss w.r.t. the un-normalised text features, which is all the backward needs.  ~20 tiny launches with no autograd
+    bookkeeping in between: shape-static, so the caller replays them from a hipGraph.
+    feat [B,F] f32, wt [E,F] f32 (pc_projection^T), text_raw [C,E] f32, logit_scale 0-d, labels [B] i64
+    -> (loss 0-d, logits [B,C], d loss / d text_raw [C,E])."""
+    B, C = feat.shape[0], text_raw.shape[0]
+    pc = ops.gemm(feat.contiguous(), wt, out_dtype=torch.float32)                       # [B,E]
+    nrm = text_raw.norm(dim=-1, keepdim=True)
+    tn = text_raw / nrm
+    spc = (logit_scale.exp() * pc).contiguous()
+    logits = ops.gemm(spc, tn.contiguous(), out_dtype=torch.float32)                    # [B,C]
+    logp = torch.log_softmax(logits, dim=1)
+    nll = -logp.gather(1, labels.view(B, 1)).squeeze(1)
+    loss = ((1.0 - smoothing) * nll + smoothing * (-logp.mean(dim=1))).mean()
+    target = torch.full_like(logp, smoothing / C)
+    target.scatter_add_(1, labels.view(B, 1), torch.full((B, 1), 1.0 - smoothing, dtype=logp.dtype, device=logp.device))
+    dlogits = (logp.exp() - target) / B
+    # d tn [C,E] = dlogits^T [C,B] @ spc [B,E]   (NT GEMM on the transposed operands, K = B padded to the chunk size)
+    d_tn = ops.gemm(ops.transpose(dlogits, pad_to=4), ops.transpose(spc, pad_to=4), out_dtype=torch.float32)
+    d_raw = (d_tn - tn * (d_tn * tn).sum(dim=-1, keepdim=True)) / nrm
+    return loss, logits, d_raw

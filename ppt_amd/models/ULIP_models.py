@@ -4,6 +4,7 @@ Transformer, PromptLearner, ULIP_WITH_IMAGE and the ULIP_PointBERT factory (ULIP
 callers (`model(pc)`, `.prompt_learner`, `.point_encoder.blocks.blocks[-1]`, `.logit_scale`) and
 ULIP checkpoints work unchanged.  Compute runs on libppt_hip.so through ppt_amd.engine.
 """
+import contextlib
 import json
 import os
 from collections import OrderedDict
@@ -280,6 +281,37 @@ class _MatmulNT(torch.autograd.Function):
         return da, db
 
 
+class _HeadLossFn(torch.autograd.Function):
+    """(loss, logits) of one batch for the frozen-point-side case; the gradient w.r.t. the text features is formed in
+    the forward (engine.head_loss_forward_backward) and handed out by backward.  Replayed from a hipGraph after
+    graphs.WARMUP_CALLS eager calls."""
+
+    @staticmethod
+    def forward(ctx, model, pc_feat, text_raw, labels, smoothing):
+        wt = engine._f32_cache(model._cache()).get(model.pc_projection, "wt")
+        scale = model.logit_scale.detach()
+        feat, traw, lab = pc_feat.detach().float().contiguous(), text_raw.detach().float().contiguous(), labels.contiguous()
+
+        def run(f, t, l):
+            return engine.head_loss_forward_backward(f, wt, t, scale, l, smoothing), None
+
+        key = ("head", tuple(feat.shape), tuple(traw.shape), float(smoothing))
+        gc = model._graphs
+        if feat.is_cuda and model.use_hip_graphs and ops.profiler is None and gc.ready(key):
+            (loss, logits, d_raw), _ = gc.get(key, lambda: graphs.GraphedCall(run, [feat, traw, lab]))(feat, traw, lab)
+            loss, logits, d_raw = loss.clone(), logits.clone(), d_raw.clone()
+        else:
+            (loss, logits, d_raw), _ = run(feat, traw, lab)
+        ctx.save_for_backward(d_raw)
+        ctx.mark_non_differentiable(logits)
+        return loss, logits
+
+    @staticmethod
+    def backward(ctx, dloss, _dlogits):
+        (d_raw,) = ctx.saved_tensors
+        return None, None, d_raw * dloss, None, None
+
+
 def matmul_nt(a, b):
     return _MatmulNT.apply(a, b)
 
@@ -446,6 +478,22 @@ class ULIP_WITH_IMAGE(nn.Module):
         lead = pc_embed.shape[:-1]
         logits = matmul_nt((logit_scale * pc_embed).reshape(-1, pc_embed.shape[-1]), text_embed)
         return logits.view(*lead, -1)
+
+    def forward_loss(self, pc, labels, smoothing):
+        """forward + CrossEntropyLoss(label_smoothing) for the case where nothing on the point side trains (head_type 0):
+        same two-stream schedule as forward(), but everything between the towers is one fused, graph-replayed node
+        (_HeadLossFn) instead of ~25 autograd-tracked launches.  -> (loss, logits)."""
+        cur = torch.cuda.current_stream()
+        side = self.text_stream() if (self.overlap_text_tower and pc.is_cuda) else None
+        if side is not None:
+            side.wait_stream(cur)
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            text_raw = self.encode_text(self.prompt_learner(), self.tokenized_prompts)
+        pc_feat = self.point_encoder(pc)
+        if side is not None:
+            cur.wait_stream(side)
+            text_raw.record_stream(cur)
+        return _HeadLossFn.apply(self, pc_feat, text_raw, labels, smoothing)
 
 
 def get_metric_names():

@@ -101,6 +101,7 @@ class Trainer:
         self.distributed = distributed
         self.sync = FlatGradSync(model.parameters())
         self.run_ahead = True
+        self.fused_head = True        # head_type 0 on a GPU: ULIP_WITH_IMAGE.forward_loss
         # head_type 0: only the prompt learner trains, so the point tower never reads a parameter the optimizer writes
         self._point_side_frozen = all(n.startswith("prompt_learner.") or not p.requires_grad
                                       for n, p in model.named_parameters())
@@ -136,8 +137,13 @@ class Trainer:
                 g['lr'] = float(self.lr_schedule[min(self.it, len(self.lr_schedule) - 1)])
         if self.bcast is not None:
             self.bcast.broadcast()
-        pred = model(pc, *self.extra_inputs)                        # main_cls.py:194 / main_partseg.py:210
-        loss = self.criterion(pred.reshape(-1, pred.shape[-1]), label.reshape(-1))     # main_partseg.py:213
+        if self.fused_head and self._point_side_frozen and not self.extra_inputs and hasattr(model, "forward_loss") \
+                and pc.is_cuda and label.dim() == 1:
+            # nothing on the point side trains: logits, loss and the text-feature gradient in one graph-replayed node
+            loss, pred = model.forward_loss(pc, label, self.criterion.label_smoothing)
+        else:
+            pred = model(pc, *self.extra_inputs)                    # main_cls.py:194 / main_partseg.py:210
+            loss = self.criterion(pred.reshape(-1, pred.shape[-1]), label.reshape(-1))     # main_partseg.py:213
         if side is not None:
             side.wait_stream(main)
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
