@@ -24,6 +24,8 @@ import sys
 import time
 from types import SimpleNamespace
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # two compute streams + RCCL's: see ppt_amd/__init__.py
+
 import numpy as np
 import torch
 import torch.distributed as dist
