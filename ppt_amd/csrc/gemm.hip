@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(NT, BM == 64 ? 3 : 1) void gemm_kernel_glds(const p
 
 // =================================================================================================
 // Half-slab LDS-DMA kernel for the big plain-operand problems (qkv, fc1, conv3): 128x128 tiles, 64-byte K slabs
-// (32 bf16), three 16 KiB stages = 48 KiB, so THREE workgroups (12 waves) share a CU.
+// (32 bf16), 16 KiB stages: two of them (default; FOUR workgroups = 16 waves share a CU) or three (three workgroups).
 // Why: tools/lds_fill_bench.hip shows that what a CU can pull out of L2 depends on how many waves are issuing --
 // 4 waves 6.5, 8 waves 11, 12 waves 14, 16 waves 16 TB/s over the chip -- and hardly on the bytes each keeps in
 // flight, and both existing tile loops sit on that line: 64x64 tiles (12 waves, 32 flop per LDS-fill byte) at
@@ -1084,11 +1084,11 @@ __device__ __forceinline__ void mma_half(const unsigned char *As, const unsigned
     }
 }
 
-template <typename T, int BM, int BN>
-__global__ __launch_bounds__(NT, 3) void gemm_kernel_glds_h(const ppt_gemm_params p)
+template <typename T, int BM, int BN, int NSTAGE = 3>
+__global__ __launch_bounds__(NT, NSTAGE == 3 ? 3 : 4) void gemm_kernel_glds_h(const ppt_gemm_params p)
 {
     constexpr int WM = BM / 2, WN = BN / 2, TI = WM / 32, TJ = WN / 32;
-    constexpr int A_BYTES = BM * ROWH, B_BYTES = BN * ROWH, STAGE = A_BYTES + B_BYTES, NSTAGE = 3;
+    constexpr int A_BYTES = BM * ROWH, B_BYTES = BN * ROWH, STAGE = A_BYTES + B_BYTES;
     constexpr int LOADS_PER_SLAB = BM / 64 + BN / 64;    // LDS-DMA instructions per wave per slab
     static_assert(LOADS_PER_SLAB == 4, "counted vmcnt below");
     constexpr int PARK_BYTES = 4 * WM * WN * 2;          // bf16 park of epilogue_regs
@@ -1121,13 +1121,19 @@ __global__ __launch_bounds__(NT, 3) void gemm_kernel_glds_h(const ppt_gemm_param
         glds_half<T, BN>(B, p.ldb, p.N, n0, slab * BK, smem + stage * STAGE + A_BYTES, w, lane);
     };
     issue(0, 0);
-    issue(min(1, last), 1);
+    if constexpr (NSTAGE == 3) issue(min(1, last), 1);
     int stage = 0;
     for (int s = 0; s < nslab; ++s) {
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // own copies of slab s landed (slab s+1's four may still fly)
-        __builtin_amdgcn_s_barrier();                     // ... and everybody else's: slab s is readable
-        int nstage = stage + 2; if (nstage >= NSTAGE) nstage -= NSTAGE;
-        issue(min(s + 2, last), nstage);                  // stage (s+2)%3 was last read at slab s-1, before this barrier
+        if constexpr (NSTAGE == 3) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // own copies of slab s landed (slab s+1's four may still fly)
+            __builtin_amdgcn_s_barrier();                     // ... and everybody else's: slab s is readable
+            int nstage = stage + 2; if (nstage >= NSTAGE) nstage -= NSTAGE;
+            issue(min(s + 2, last), nstage);                  // stage (s+2)%3 was last read at slab s-1, before this barrier
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            issue(min(s + 1, last), stage ^ 1);               // the other stage was last read at slab s-1, before this barrier
+        }
         mma_half<T, TI, TJ>(smem + stage * STAGE, smem + stage * STAGE + A_BYTES, wm * WM, wn * WN, lane, acc);
         stage = stage + 1 == NSTAGE ? 0 : stage + 1;
     }
@@ -1187,7 +1193,12 @@ int launch_gemm(const ppt_gemm_params &p, hipStream_t s)
     if (glds_h_ok<T>(p, tiles128)) {
         dim3 grid((p.N + 127) / 128, (p.M + 127) / 128, p.batch > 0 ? p.batch : 1);
         if (grid.y > 65535 || grid.z > 65535) return PPT_EUNSUPPORTED;
-        hipLaunchKernelGGL((gemm_kernel_glds_h<T, 128, 128>), grid, dim3(NT), 0, s, p);
+        // two stages (32 KiB, 4 workgroups = 16 waves per CU, prefetch distance 1) beat three (48 KiB, 3 workgroups,
+        // distance 2) in the step: 4.73 vs 4.82 ms on C2, conv3 346 -> 325 us -- the fill rate follows the wave count
+        // (tools/lds_fill_bench.hip) and a fourth co-resident workgroup hides more of the others' epilogues
+        static const int two_stage = [] { const char *e = getenv("PPT_GEMM_H128_STAGES"); return !(e && atoi(e) == 3); }();
+        if (two_stage) hipLaunchKernelGGL((gemm_kernel_glds_h<T, 128, 128, 2>), grid, dim3(NT), 0, s, p);
+        else hipLaunchKernelGGL((gemm_kernel_glds_h<T, 128, 128>), grid, dim3(NT), 0, s, p);
         PPT_CHECK_LAUNCH();
         return PPT_OK;
     }
