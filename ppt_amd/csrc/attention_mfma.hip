@@ -109,14 +109,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(const bf16_t *__restrict
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) st[i][e] = 0.f;
+            // all eight K fragments first (independent ds_read_b128, one wait), then the MFMAs: loaded one by one, each
+            // MFMA waited for its own LDS round trip
+            bf16x8_t kf[4][2];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                for (int sub = 0; sub < 2; ++sub) {
-                    const bf16x8_t kf = __builtin_bit_cast(
+                for (int sub = 0; sub < 2; ++sub)
+                    kf[kk][sub] = __builtin_bit_cast(
                         bf16x8_t, *reinterpret_cast<const uint4 *>(Kc + k_off(32 * sub + r, 2 * kk + h)));
-                    st[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st[sub], 0, 0, 0);
-                }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+                    st[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk][sub], qf[kk], st[sub], 0, 0, 0);
             const bool need_mask = (kt * KVT + KVT > T) || (CAUSAL && kt * KVT + KVT - 1 > q0);
             if (need_mask) {
 #pragma unroll

@@ -24,9 +24,14 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f)
     return __builtin_bit_cast(bf16_t, h);
 }
 
+// two floats -> one dword of bf16 (round-to-nearest-even): the vector conversion lowers to ONE v_cvt_pk_bf16_f32
+// (two scalar casts cost two of them plus a shift and an or)
+typedef float ppt_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 ppt_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi)
 {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    const ppt_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, ppt_bf16x2));
 }
 
 template <typename T> struct dt;
