@@ -157,6 +157,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss, _ = trainer.step(pc, label)
+    trainer.finish()                         # (the deferred BatchNorm-buffer broadcast of a multi-rank run is timed too)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1 or force_dist:

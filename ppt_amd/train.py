@@ -101,6 +101,11 @@ class Trainer:
         self.distributed = distributed
         self.sync = FlatGradSync(model.parameters())
         self.run_ahead = True
+        # DDP re-broadcasts rank 0's buffers before every forward.  The only float buffers here are BatchNorm running
+        # statistics, which a train-mode forward never reads and which rank 0 updates from its own batches alone, so one
+        # broadcast in finish() leaves every rank with exactly the state the per-step broadcast would -- without a
+        # collective on the point tower's stream in every iteration.  True restores DDP's schedule.
+        self.broadcast_buffers_every_step = False
         self.fused_head = True        # head_type 0 on a GPU: ULIP_WITH_IMAGE.forward_loss
         # head_type 0: only the prompt learner trains, so the point tower never reads a parameter the optimizer writes
         self._point_side_frozen = all(n.startswith("prompt_learner.") or not p.requires_grad
@@ -135,7 +140,7 @@ class Trainer:
         if self.lr_schedule is not None:                            # main_cls.py:184-185
             for g in self.optimizer.param_groups:
                 g['lr'] = float(self.lr_schedule[min(self.it, len(self.lr_schedule) - 1)])
-        if self.bcast is not None:
+        if self.bcast is not None and self.broadcast_buffers_every_step:
             self.bcast.broadcast()
         if self.fused_head and self._point_side_frozen and not self.extra_inputs and hasattr(model, "forward_loss") \
                 and pc.is_cuda and label.dim() == 1:
@@ -160,9 +165,12 @@ class Trainer:
         return loss, pred
 
     def finish(self):
-        """Order the caller's stream after everything `step` queued (call before reading parameters)."""
+        """Order the caller's stream after everything `step` queued and bring every rank's BatchNorm running statistics
+        to rank 0's (call before reading parameters or buffers: evaluation, checkpointing)."""
         if self._side_used is not None:
             torch.cuda.current_stream().wait_stream(self._side_used)
+        if self.bcast is not None and not self.broadcast_buffers_every_step:
+            self.bcast.broadcast()
 
 
 def checkpoint_payload(model, optimizer, epoch, best_acc, args, head_type=0, partseg=False):
