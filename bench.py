@@ -116,6 +116,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
+    from ppt_amd import graphs
+    graphs.shared_text_stream()        # before RCCL creates its streams: same hardware-queue position as at N = 1
     force_dist = os.environ.get("PPT_FORCE_DIST") == "1"      # exercise the RCCL path with a single rank (dev aid)
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -66,3 +66,58 @@ class GraphCache:
         if g is None:
             g = self.entries[key] = build()
         return g
+
+
+_TEXT_STREAMS = {}
+
+
+def shared_text_stream(device=None):
+    """The process-wide side stream of `device` (one per GPU, shared by every model): created on first call.
+    Which hardware queue a HIP stream gets depends on how many streams the process created before it, and some
+    positions execute in order with the caller's stream (4.8 -> 6.2 ... 7.5 ms per C2 step, tools/prio_test.py) -- so the
+    stream is created ONCE, and callers that know better create it early: bench.py calls this right after
+    set_device, before init_process_group lets RCCL create its own streams, which puts it in the same position as in
+    the single-GPU run."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    if dev not in _TEXT_STREAMS:
+        with torch.cuda.device(dev):
+            _TEXT_STREAMS[dev] = torch.cuda.Stream()
+    return _TEXT_STREAMS[dev]
+
+
+def _lead_over(ref, cand):
+    """Fraction of `ref`'s busy time by which a tiny kernel queued on `cand` AFTER ref's work finishes BEFORE it:
+    ~1 when the streams sit on different hardware queues, <= 0 when they share one (in-order execution)."""
+    big = torch.empty(64 << 20, dtype=torch.float32, device="cuda")
+    small = torch.empty(1024, dtype=torch.float32, device="cuda")
+    e0, e_ref, e_cand = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    torch.cuda.synchronize()
+    with torch.cuda.stream(ref):
+        e0.record(ref)
+        for _ in range(6):
+            big.fill_(1.0)
+        e_ref.record(ref)
+    with torch.cuda.stream(cand):
+        small.fill_(1.0)
+        e_cand.record(cand)
+    torch.cuda.synchronize()
+    return e_cand.elapsed_time(e_ref) / max(e0.elapsed_time(e_ref), 1e-6)
+
+
+def concurrent_stream(ref=None, tries=8):
+    """A new stream that really runs concurrently with `ref` (default: the current stream).  The HIP runtime deals
+    streams round-robin onto GPU_MAX_HW_QUEUES hardware queues; a stream that lands on ref's queue executes in order
+    with it (seen: the text stream serialised with the point tower after RCCL, or a few unrelated torch.cuda.Stream()
+    objects, had been created -- 4.8 -> 6.2 / 8.0 ms per C2 step).  Each candidate is probed (~1 ms); the first with a
+    clear lead is taken, rejected ones stay alive until then so that the next candidate gets the next queue."""
+    ref = torch.cuda.current_stream() if ref is None else ref
+    rejected, best, best_lead = [], None, -1e9
+    for _ in range(tries):
+        cand = torch.cuda.Stream()
+        lead = _lead_over(ref, cand)
+        if lead > 0.8:
+            return cand
+        if lead > best_lead:
+            best, best_lead = cand, lead
+        rejected.append(cand)
+    return best

@@ -456,7 +456,7 @@ class ULIP_WITH_IMAGE(nn.Module):
         """The HIP stream the prompt side (PromptLearner + text tower, and in training its backward and the
         optimizer: train.Trainer.step) is queued on."""
         if self._text_stream is None:
-            self._text_stream = torch.cuda.Stream()
+            self._text_stream = graphs.shared_text_stream()
         return self._text_stream
 
     def forward(self, pc, cls_label=None):
