@@ -169,6 +169,15 @@ int ppt_bn_finalize(const float *part_sum, const float *part_sqsum, int n_partia
                     int rows_per_partial, int64_t count, int C, const float *gamma, const float *beta, float eps, int train,
                     float momentum, float *running_mean, float *running_var,
                     int64_t *num_batches_tracked, float *scale, float *shift, void *stream);
+/* the same with a caller-provided scratch buffer (ppt_bn_finalize_workspace_bytes(n_partials, C) bytes, 8-byte aligned;
+ * 0 bytes = not needed): thousands of partial rows (conv3: 16 384 x 512) are folded by 32 x C/32 workgroups into
+ * additive fp64 sums first, a second tiny kernel finishes.  Falls back to ppt_bn_finalize without a workspace. */
+size_t ppt_bn_finalize_workspace_bytes(int n_partials, int C);
+int ppt_bn_finalize_ws(const float *part_sum, const float *part_sqsum, int n_partials,
+                       int rows_per_partial, int64_t count, int C, const float *gamma, const float *beta, float eps, int train,
+                       float momentum, float *running_mean, float *running_var,
+                       int64_t *num_batches_tracked, float *scale, float *shift, void *workspace, size_t workspace_bytes,
+                       void *stream);
 int ppt_conv1_stats_max_partials(int64_t M);
 int ppt_conv1_stats_rows_per_partial(void);
 

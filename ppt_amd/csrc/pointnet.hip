@@ -81,12 +81,24 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restri
     const int c = blockIdx.x * CH + tx;
     float mean_f = 0.f, var_f = 1.f;
     if (train) {
-        stat3 acc{0.0, 0.0, 0.0};
+        // Each stripe folds its partials as three fp64 sums -- S1 = sum of sums, S2 = sum of M2, S3 = sum of sum^2 / n --
+        // from which (n, mean, M2) of the stripe follow exactly as from a chain of Chan merges (M2 = S2 + S3 - S1^2 / N;
+        // fp64 leaves ~1e-16 x N x mean^2 of cancellation error, far below the fp32 inputs), without a division per
+        // partial: the walk over the 16 384 x 512 partials of conv3 is then bandwidth-bound (55 -> ~20 us).
+        double s1 = 0.0, s2 = 0.0, s3 = 0.0, ntot = 0.0;
+        const double inv_rpp = 1.0 / (double)rpp;
         if (c < C)
             for (int p = ty; p < P; p += ST) {
                 const double n = fmin((double)rpp, count - (double)p * rpp);
-                if (n > 0.0) stat_merge(acc, stat3{n, (double)psum[(size_t)p * C + c] / n, (double)psq[(size_t)p * C + c]});
+                if (n > 0.0) {
+                    const double sv = (double)psum[(size_t)p * C + c];
+                    s1 += sv; s2 += (double)psq[(size_t)p * C + c];
+                    s3 += sv * sv * (n == (double)rpp ? inv_rpp : 1.0 / n);
+                    ntot += n;
+                }
             }
+        stat3 acc{0.0, 0.0, 0.0};
+        if (ntot > 0.0) acc = stat3{ntot, s1 / ntot, fmax(s2 + s3 - s1 * s1 / ntot, 0.0)};
         red[ty][tx] = acc;
         __syncthreads();
         for (int off = ST / 2; off > 0; off >>= 1) {
@@ -106,6 +118,71 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restri
     } else {
         if (ty != 0 || c >= C) return;
         mean_f = rmean[c]; var_f = rvar[c];
+    }
+    const float sc = gamma[c] / sqrtf(var_f + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - mean_f * sc;
+}
+
+// ---- two-stage fold for many partials (conv3: 16 384 x 512) -----------------------------------------------------
+// stage 1: workgroup (channel group of 32, split) walks its slice of the partial rows with full 128-byte rows per half
+// wave and adds up, per channel, the four fp64 sums {S1 = sum of sums, S2 = sum of M2, S3 = sum of sum^2 / n, N};
+// they are plainly additive, so the splits are reduced by summation in stage 2 (M2 = S2 + S3 - S1^2 / N).
+__global__ __launch_bounds__(1024) void bn_fold_kernel(const float *__restrict__ psum, const float *__restrict__ psq, int P,
+                                                       double count, int rpp, int C, int per_split, double *__restrict__ ws)
+{
+    __shared__ double red[4][32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
+    const int p0 = blockIdx.y * per_split, p1 = min(P, p0 + per_split);
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0, nt = 0.0;
+    const double inv_rpp = 1.0 / (double)rpp;
+    if (c < C)
+        for (int p = p0 + ty; p < p1; p += 32) {
+            const double n = fmin((double)rpp, count - (double)p * rpp);
+            if (n > 0.0) {
+                const double sv = (double)psum[(size_t)p * C + c];
+                s1 += sv; s2 += (double)psq[(size_t)p * C + c];
+                s3 += sv * sv * (n == (double)rpp ? inv_rpp : 1.0 / n);
+                nt += n;
+            }
+        }
+    red[0][ty][tx] = s1; red[1][ty][tx] = s2; red[2][ty][tx] = s3; red[3][ty][tx] = nt;
+    __syncthreads();
+    for (int off = 16; off > 0; off >>= 1) {
+        if (ty < off) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red[k][ty][tx] += red[k][ty + off][tx];
+        }
+        __syncthreads();
+    }
+    if (ty == 0 && c < C) {
+        double *o = ws + ((size_t)blockIdx.y * C + c) * 4;
+        o[0] = red[0][0][tx]; o[1] = red[1][0][tx]; o[2] = red[2][0][tx]; o[3] = red[3][0][tx];
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_finish_kernel(const double *__restrict__ ws, int nsplit, double count, int C,
+                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                        float eps, float momentum, float *__restrict__ rmean,
+                                                        float *__restrict__ rvar, int64_t *__restrict__ nbt,
+                                                        float *__restrict__ scale, float *__restrict__ shift)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int k = 0; k < nsplit; ++k) {
+        const double *o = ws + ((size_t)k * C + c) * 4;
+        s1 += o[0]; s2 += o[1]; s3 += o[2];
+    }
+    const double mean = s1 / count;
+    const double var = fmax(s2 + s3 - s1 * s1 / count, 0.0) / count;      // biased variance normalises (nn.BatchNorm1d)
+    const float mean_f = (float)mean, var_f = (float)var;
+    if (rmean) {
+        const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+        rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean_f;
+        rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (float)unbiased;
+        if (c == 0 && nbt) *nbt += 1;
     }
     const float sc = gamma[c] / sqrtf(var_f + eps);
     scale[c] = sc;
@@ -284,6 +361,36 @@ extern "C" int ppt_bn_finalize(const float *part_sum, const float *part_sqsum, i
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(1024), 0, ppt_stream(stream), part_sum, part_sqsum,
                        n_partials, (double)count, rows_per_partial, C, gamma, beta, eps, train, momentum, running_mean, running_var,
                        num_batches_tracked, scale, shift);
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
+extern "C" size_t ppt_bn_finalize_workspace_bytes(int n_partials, int C)
+{
+    const int nsplit = n_partials >= 2048 ? 32 : 0;          // the single-kernel fold is as fast below that
+    return (size_t)nsplit * (size_t)C * 4 * sizeof(double);
+}
+
+extern "C" int ppt_bn_finalize_ws(const float *part_sum, const float *part_sqsum, int n_partials, int rows_per_partial,
+                                  int64_t count, int C,
+                                  const float *gamma, const float *beta, float eps, int train, float momentum,
+                                  float *running_mean, float *running_var, int64_t *num_batches_tracked, float *scale,
+                                  float *shift, void *workspace, size_t workspace_bytes, void *stream)
+{
+    const size_t need = train ? ppt_bn_finalize_workspace_bytes(n_partials, C) : 0;
+    if (need == 0 || !workspace || workspace_bytes < need || ((uintptr_t)workspace & 7))
+        return ppt_bn_finalize(part_sum, part_sqsum, n_partials, rows_per_partial, count, C, gamma, beta, eps, train, momentum,
+                               running_mean, running_var, num_batches_tracked, scale, shift, stream);
+    if (!gamma || !beta || !scale || !shift || C <= 0 || !part_sum || !part_sqsum || count <= 0 || rows_per_partial <= 0 ||
+        (int64_t)n_partials * rows_per_partial < count)
+        return PPT_EINVAL;
+    const int nsplit = 32, per_split = (n_partials + nsplit - 1) / nsplit;
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 31) / 32, nsplit), dim3(1024), 0, ppt_stream(stream), part_sum, part_sqsum,
+                       n_partials, (double)count, rows_per_partial, C, per_split, (double *)workspace);
+    PPT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, ppt_stream(stream), (const double *)workspace,
+                       nsplit, (double)count, C, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked,
+                       scale, shift);
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }

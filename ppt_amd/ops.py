@@ -267,12 +267,16 @@ def bn_finalize(gamma, beta, train, partials=None, rows_per_partial=0, count=0, 
     shift = torch.empty((C,), dtype=torch.float32, device=gamma.device)
     ps, pq = partials if partials is not None else (None, None)
     upd = train and update_running
-    _lib.check(_lib.lib().ppt_bn_finalize(_p(ps), _p(pq), 0 if ps is None else ps.shape[0], rows_per_partial, count, C, _p(gamma),
-                                          _p(beta), eps, int(train), momentum,
-                                          _p(running_mean) if (upd or not train) else None,
-                                          _p(running_var) if (upd or not train) else None,
-                                          _p(num_batches_tracked) if upd else None, _p(scale), _p(shift), _stream()),
-               "ppt_bn_finalize")
+    P = 0 if ps is None else ps.shape[0]
+    wbytes = _lib.lib().ppt_bn_finalize_workspace_bytes(P, C) if train else 0
+    ws = torch.empty((wbytes // 8,), dtype=torch.float64, device=gamma.device) if wbytes else None
+    _lib.check(_lib.lib().ppt_bn_finalize_ws(_p(ps), _p(pq), P, rows_per_partial, count, C, _p(gamma),
+                                             _p(beta), eps, int(train), momentum,
+                                             _p(running_mean) if (upd or not train) else None,
+                                             _p(running_var) if (upd or not train) else None,
+                                             _p(num_batches_tracked) if upd else None, _p(scale), _p(shift), _p(ws), wbytes,
+                                             _stream()),
+               "ppt_bn_finalize_ws")
     return scale, shift
 
 
