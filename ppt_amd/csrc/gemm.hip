@@ -74,6 +74,37 @@ __device__ __forceinline__ float act_bwd(float x, int act)   // d act(x) / dx
     }
 }
 
+// the activation of N register values with the kind selected ONCE (a switch inside the per-element loop stays a
+// branch per element)
+template <bool FAST, int N>
+__device__ __forceinline__ void act_fwd_n(float (&v)[N], int act)
+{
+    if (act == PPT_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = act_fwd<FAST>(v[e], PPT_ACT_GELU);
+    } else if (act == PPT_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = fmaxf(v[e], 0.0f);
+    } else if (act == PPT_ACT_QUICKGELU) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = act_fwd<FAST>(v[e], PPT_ACT_QUICKGELU);
+    }
+}
+template <bool FAST, int N>
+__device__ __forceinline__ void act_bwd_n(float (&v)[N], const float (&x)[N], int act)      // v *= act'(x)
+{
+    if (act == PPT_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] *= act_bwd<FAST>(x[e], PPT_ACT_GELU);
+    } else if (act == PPT_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = x[e] > 0.0f ? v[e] : 0.0f;
+    } else if (act == PPT_ACT_QUICKGELU) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] *= act_bwd<FAST>(x[e], PPT_ACT_QUICKGELU);
+    }
+}
+
 template <typename T> __device__ __forceinline__ float load_as_f32(const void *p, int64_t i);
 template <> __device__ __forceinline__ float load_as_f32<float>(const void *p, int64_t i) { return ((const float *)p)[i]; }
 template <> __device__ __forceinline__ float load_as_f32<bf16_t>(const void *p, int64_t i) { return bf16_to_f32(((const bf16_t *)p)[i]); }
@@ -436,21 +467,11 @@ __device__ __forceinline__ void epilogue_vec8(const ppt_gemm_params &p, float *c
             if (p.C2 && p.c2_pre) st8_dt(p.C2, p.c2_dtype, (int64_t)m * p.ldc2 + n, v);
             if ((FEAT & 1) && p.dact_pre) {
                 const f8 x = kind == 3 ? pre_f8(pass, p.dtype == PPT_BF16) : ld8_dt(p.dact_pre, p.dtype, (int64_t)m * p.ld_dact + n);
-                if (p.dtype == PPT_BF16) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v.v[e] *= act_bwd<true>(x.v[e], p.act);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v.v[e] *= act_bwd<false>(x.v[e], p.act);
-                }
+                if (p.dtype == PPT_BF16) act_bwd_n<true, 8>(v.v, x.v, p.act);
+                else act_bwd_n<false, 8>(v.v, x.v, p.act);
             } else if (p.act != PPT_ACT_NONE) {
-                if (p.dtype == PPT_BF16) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v.v[e] = act_fwd<true>(v.v[e], p.act);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v.v[e] = act_fwd<false>(v.v[e], p.act);
-                }
+                if (p.dtype == PPT_BF16) act_fwd_n<true, 8>(v.v, p.act);
+                else act_fwd_n<false, 8>(v.v, p.act);
             }
             if (p.row_scale) {
                 const float sc = p.row_scale[m / p.row_scale_rows];
@@ -622,13 +643,31 @@ __device__ __forceinline__ void epilogue_prefetch(const ppt_gemm_params &p, EpiP
     }
 }
 
-template <int TI, int TJ>
+// EPI < 0: every feature tested at run time (the general kernel).  EPI >= 0: fixed at compile time -- 2 per-group
+// term, 4 BatchNorm statistics, 8 pooling, activation kind << 4 -- so that the hot launches (qkv: 0, fc1: GELU, conv3: 6)
+// run an epilogue of a few hundred instructions: with every feature compiled in and the four MFMA tiles unrolled the
+// 128x128 kernels carry ~70 KB of epilogue code, more than the instruction cache two CUs share, and each enabled flag
+// cost microseconds of instruction fetch (bias + ReLU on fc1: +10 us over the plain store).
+constexpr int EPI_GROUP = 2, EPI_STATS = 4, EPI_POOL = 8, EPI_ACT_SHIFT = 4;      // + (activation kind << 4)
+constexpr int EPI_GELU = PPT_ACT_GELU << EPI_ACT_SHIFT;
+__host__ __device__ inline int epi_mask(const ppt_gemm_params &p)
+{
+    return (p.act << EPI_ACT_SHIFT) | (p.group_add ? EPI_GROUP : 0) | (p.col_sum ? EPI_STATS : 0) | (p.pool_max ? EPI_POOL : 0);
+}
+
+// FAST: -1 decided at run time from p.dtype, 1 bf16 operands (A&S erf), 0 fp32 parity (libm erff)
+template <int TI, int TJ, int EPI = -1, int FAST = -1>
 __device__ __forceinline__ void epilogue_regs(const ppt_gemm_params &p, f32x16_t (&acc)[TI][TJ], const EpiPre<TI, TJ> &pre,
                                               unsigned char *park, int lane, int mw, int nw, int64_t zc)
 {
+    const int act = EPI < 0 ? p.act : (EPI >> EPI_ACT_SHIFT);
+    const bool has_act = act != PPT_ACT_NONE;
+    const bool has_group = EPI < 0 ? p.group_add != nullptr : (EPI & EPI_GROUP) != 0;
+    const bool has_stats = EPI < 0 ? p.col_sum != nullptr : (EPI & EPI_STATS) != 0;
+    const bool has_pool = EPI < 0 ? p.pool_max != nullptr : (EPI & EPI_POOL) != 0;
     constexpr int WM = TI * 32, WN = TJ * 32, ROWBYTES = WN * 2;
     const int cl = lane & 31, h = lane >> 5, odd = cl & 1;
-    const bool fast = p.dtype == PPT_BF16;
+    const bool fast = FAST < 0 ? p.dtype == PPT_BF16 : FAST != 0;
     const int pool_rows = p.pool_rows > 0 ? p.pool_rows : 32;
     // parked dword of this lane inside a (row pair, column tile): row + odd, columns (cl & ~1, cl | 1); for 64-column
     // wave tiles odd rows keep their two 64-byte halves swapped, which puts the even-lane row and the odd-lane row of
@@ -647,14 +686,14 @@ __device__ __forceinline__ void epilogue_regs(const ppt_gemm_params &p, f32x16_t
             float v[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] + bias;
-            if (p.group_add) {                                        // (rows 16-31 of a 32k-row group: g[1] == g[0])
+            if (has_group) {                                          // (rows 16-31 of a 32k-row group: g[1] == g[0])
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] += pre.g[i][j][r < 8 ? 0 : 1];
             }
             bool rv[16];                                              // row of register r exists
 #pragma unroll
             for (int r = 0; r < 16; ++r) rv[r] = full || (mg + (r & 3) + 8 * (r >> 2) + 4 * h) < p.M;
-            if (p.col_sum && mg < p.M) {
+            if (has_stats && mg < p.M) {
                 // BatchNorm statistics of this 32-row chunk: (sum, M2 about the chunk mean); ppt_bn_finalize merges
                 // the chunks with the parallel-variance formula in fp64 (no cancellation, no atomics)
                 float sacc = 0.f, q = 0.f, mean;
@@ -695,16 +734,11 @@ __device__ __forceinline__ void epilogue_regs(const ppt_gemm_params &p, f32x16_t
                     p.col_sqsum[(int64_t)(mg >> 5) * p.N + n] = q;
                 }
             }
-            if (p.act != PPT_ACT_NONE) {
-                if (fast) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = act_fwd<true>(v[r], p.act);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = act_fwd<false>(v[r], p.act);
-                }
+            if (has_act) {
+                if (fast) act_fwd_n<true, 16>(v, act);
+                else act_fwd_n<false, 16>(v, act);
             }
-            if (p.pool_max) {
+            if (has_pool) {
                 float a0 = -INFINITY, a1 = -INFINITY, b0 = INFINITY, b1 = INFINITY;   // rows 0-15 / 16-31 of the tile
                 if (full) {
 #pragma unroll
@@ -1084,7 +1118,7 @@ __device__ __forceinline__ void mma_half(const unsigned char *As, const unsigned
     }
 }
 
-template <typename T, int BM, int BN, int NSTAGE = 3>
+template <typename T, int BM, int BN, int NSTAGE = 3, int EPI = -1>
 __global__ __launch_bounds__(NT, NSTAGE == 3 ? 3 : 4) void gemm_kernel_glds_h(const ppt_gemm_params p)
 {
     constexpr int WM = BM / 2, WN = BN / 2, TI = WM / 32, TJ = WN / 32;
@@ -1112,9 +1146,6 @@ __global__ __launch_bounds__(NT, NSTAGE == 3 ? 3 : 4) void gemm_kernel_glds_h(co
         for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    EpiPre<TI, TJ> epre;
-    epilogue_prefetch<TI, TJ>(p, epre, lane, m0 + wm * WM, n0 + wn * WN);
-
     const int nslab = p.K / BK, last = nslab - 1;
     auto issue = [&](int slab, int stage) {
         glds_half<T, BM>(A, p.lda, p.M, m0, slab * BK, smem + stage * STAGE, w, lane);
@@ -1122,6 +1153,8 @@ __global__ __launch_bounds__(NT, NSTAGE == 3 ? 3 : 4) void gemm_kernel_glds_h(co
     };
     issue(0, 0);
     if constexpr (NSTAGE == 3) issue(min(1, last), 1);
+    EpiPre<TI, TJ> epre;                                  // (behind the first slabs: the K loop must not start later for it)
+    epilogue_prefetch<TI, TJ>(p, epre, lane, m0 + wm * WM, n0 + wn * WN);
     int stage = 0;
     for (int s = 0; s < nslab; ++s) {
         if constexpr (NSTAGE == 3) {
@@ -1139,8 +1172,8 @@ __global__ __launch_bounds__(NT, NSTAGE == 3 ? 3 : 4) void gemm_kernel_glds_h(co
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // surplus prefetches must not land on the parked tile
     __builtin_amdgcn_s_barrier();
-    epilogue_regs<TI, TJ>(p, acc, epre, smem + w * (WM * WN * 2), lane, m0 + wm * WM, n0 + wn * WN,
-                          (int64_t)blockIdx.z * p.strideC);
+    epilogue_regs<TI, TJ, EPI, EPI < 0 ? -1 : (sizeof(T) == 2 ? 1 : 0)>(p, acc, epre, smem + w * (WM * WN * 2), lane, m0 + wm * WM,
+                                                                        n0 + wn * WN, (int64_t)blockIdx.z * p.strideC);
 }
 
 // host side of the choice: plain operands, K in whole half-slabs, an epilogue the register path covers for every
@@ -1197,8 +1230,17 @@ int launch_gemm(const ppt_gemm_params &p, hipStream_t s)
         // distance 2) in the step: 4.73 vs 4.82 ms on C2, conv3 346 -> 325 us -- the fill rate follows the wave count
         // (tools/lds_fill_bench.hip) and a fourth co-resident workgroup hides more of the others' epilogues
         static const int two_stage = [] { const char *e = getenv("PPT_GEMM_H128_STAGES"); return !(e && atoi(e) == 3); }();
-        if (two_stage) hipLaunchKernelGGL((gemm_kernel_glds_h<T, 128, 128, 2>), grid, dim3(NT), 0, s, p);
-        else hipLaunchKernelGGL((gemm_kernel_glds_h<T, 128, 128>), grid, dim3(NT), 0, s, p);
+        if (two_stage) {
+            switch (p.C ? epi_mask(p) : -1) {           // the three hot epilogues have their own small kernels
+            case 0: hipLaunchKernelGGL((gemm_kernel_glds_h<T, 128, 128, 2, 0>), grid, dim3(NT), 0, s, p); break;
+            case EPI_GELU: hipLaunchKernelGGL((gemm_kernel_glds_h<T, 128, 128, 2, EPI_GELU>), grid, dim3(NT), 0, s, p); break;
+            case EPI_GROUP | EPI_STATS:
+                hipLaunchKernelGGL((gemm_kernel_glds_h<T, 128, 128, 2, EPI_GROUP | EPI_STATS>), grid, dim3(NT), 0, s, p); break;
+            default: hipLaunchKernelGGL((gemm_kernel_glds_h<T, 128, 128, 2>), grid, dim3(NT), 0, s, p); break;
+            }
+        } else {
+            hipLaunchKernelGGL((gemm_kernel_glds_h<T, 128, 128>), grid, dim3(NT), 0, s, p);
+        }
         PPT_CHECK_LAUNCH();
         return PPT_OK;
     }
