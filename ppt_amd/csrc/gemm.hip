@@ -997,9 +997,6 @@ __global__ __launch_bounds__(NT, BM == 64 ? 3 : 1) void gemm_kernel_glds(const p
         for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    EpiPre<TI, TJ> epre;
-    epilogue_prefetch<TI, TJ>(p, epre, lane, m0 + wm * WM, n0 + wn * WN);
-
     const int nslab = p.K / BK, last = nslab - 1;
     auto issue = [&](int slab, int stage) {
         glds_slab<T, BM>(A, p.lda, p.M, m0, slab * BK, smem + stage * STAGE, w, lane);
@@ -1007,6 +1004,8 @@ __global__ __launch_bounds__(NT, BM == 64 ? 3 : 1) void gemm_kernel_glds(const p
     };
     issue(0, 0);
     issue(min(1, last), 1);
+    EpiPre<TI, TJ> epre;                                  // (behind the first slabs, as in gemm_kernel_glds_h)
+    epilogue_prefetch<TI, TJ>(p, epre, lane, m0 + wm * WM, n0 + wn * WN);
     int stage = 0;
     for (int s = 0; s < nslab; ++s) {
         // own copies of slab s have landed (the LOADS_PER_SLAB youngest, slab s+1, may still fly) ...
