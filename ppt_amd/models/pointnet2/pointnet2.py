@@ -5,7 +5,7 @@ forward runs ppt_amd.engine.pointnet2_msg_forward (FPS + ball query + grouped-ML
 import torch
 import torch.nn as nn
 
-from ... import engine
+from ... import engine, graphs, ops
 
 
 class PointNetSetAbstractionMsg(nn.Module):
@@ -71,6 +71,21 @@ class Pointnet2_Msg(nn.Module):
         self.fps_start = None
         self.dropout_masks = None
         self._wc = None
+        self._sd = None
+        self._graphs = graphs.GraphCache()
+        self.use_hip_graphs = True
+
+    def _apply(self, fn, *a, **k):
+        self._sd = None
+        if hasattr(self, "_graphs"):
+            self._graphs.clear()
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._sd, self._wc = None, None
+        if hasattr(self, "_graphs"):
+            self._graphs.clear()
+        return super().load_state_dict(*a, **k)
 
     def forward(self, xyz):
         xyz = xyz.contiguous().float()
@@ -88,6 +103,17 @@ class Pointnet2_Msg(nn.Module):
         elif self.training:
             masks = ((torch.rand((B, 512), device=xyz.device) >= 0.4).float() / 0.6,
                      (torch.rand((B, 256), device=xyz.device) >= 0.5).float() / 0.5)
-        sd = self.state_dict(keep_vars=True)
+        if self._sd is None or self._sd[1] is not self.fc1.weight:
+            self._sd = (self.state_dict(keep_vars=True), self.fc1.weight)
+        sd, wc, train = self._sd[0], self._wc, self.training
         with torch.no_grad():            # every parameter of this encoder is frozen in PPT (ULIP_models.py:372-389)
-            return engine.pointnet2_msg_forward(sd, "", self._wc, xyz, starts, self.training, masks)
+            # ~90 shape-static launches: replayed from a hipGraph after graphs.WARMUP_CALLS eager calls (ppt_amd/graphs.py)
+            key = ("pn2_msg", tuple(xyz.shape), masks is not None, train, wc.dtype)
+            if xyz.is_cuda and self.use_hip_graphs and ops.profiler is None and self._graphs.ready(key):
+                ins = [xyz, starts[0], starts[1]] + (list(masks) if masks is not None else [])
+
+                def fn(x, s0, s1, *m):
+                    return (engine.pointnet2_msg_forward(sd, "", wc, x, (s0, s1), train, tuple(m) if m else None),), None
+                (feat,), _ = self._graphs.get(key, lambda: graphs.GraphedCall(fn, ins))(*ins)
+                return feat.clone()
+            return engine.pointnet2_msg_forward(sd, "", wc, xyz, starts, train, masks)
