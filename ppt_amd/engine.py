@@ -149,31 +149,42 @@ def vit_block_forward(sd, p, wc, x, pos, B, Tn, heads, dp1, dp2, save=None, pos_
     return x_out
 
 
-def point_encoder_forward(sd, p, wc, pc, fps_start, dp, bn_train, save_tier, cfg, update_running=True, fetch=None):
+def point_encoder_forward(sd, p, wc, pc, fps_start, dp, bn_train, save_tier, cfg, update_running=True, fetch=None,
+                          last_block=None, resume=None):
     """PointTransformer.forward (point_encoder.py:234-257) -> (feat [B,2*D] fp32, saved | None).
-    dp: DropPath factors [depth,2,B] fp32 or None; save_tier > 0 keeps block-(depth-1) activations."""
+    dp: DropPath factors [depth,2,B] fp32 or None; save_tier > 0 keeps block-(depth-1) activations.
+
+    The forward can be cut in front of the last block (the only one that may train, ULIP_models.py:461-470):
+    last_block=False runs the tokenizer and blocks 0 .. depth-2 -- everything that is frozen whatever the head_type --
+    and returns (x2, pos2), both [B*Tn, D] fp32, x2 with the last block's "+ pos" already added;
+    resume=(x2, pos2) runs the last block, the final norm and the pooling on them."""
     T = wc.dtype
-    B = pc.shape[0]
     G, D, depth, heads = cfg["num_group"], cfg["trans_dim"], cfg["depth"], cfg["num_heads"]
     Tn = G + 1
-    dev = pc.device
-    nbhd, center = group_points(pc, G, cfg["group_size"], fps_start)
-    tok = mini_pointnet(sd, p + "encoder.", wc, nbhd, bn_train, update_running)
-    x = torch.empty((B, Tn, D), dtype=torch.float32, device=dev)
-    pos = torch.empty((B, Tn, D), dtype=torch.float32, device=dev)
-    x[:, 0] = sd[p + "cls_token"].view(D)
-    pos[:, 0] = sd[p + "cls_pos"].view(D)
-    x2, pos2 = x.view(B * Tn, D), pos.view(B * Tn, D)
-    # reduce_dim and pos_embed write straight into rows 1.. of every sample (batched GEMM)
-    ops.gemm(tok, wc.get(sd[p + "reduce_dim.weight"]), out=x2[1:], M=G, bias=sd[p + "reduce_dim.bias"], batch=B,
-             strideA=G * tok.shape[1], strideC=Tn * D)
-    pe = ops.linear3_gelu(center.view(B * G, 3), sd[p + "pos_embed.0.weight"], sd[p + "pos_embed.0.bias"], T)
-    ops.gemm(pe, wc.get(sd[p + "pos_embed.2.weight"]), out=pos2[1:], M=G, bias=sd[p + "pos_embed.2.bias"], batch=B,
-             strideA=G * pe.shape[1], strideC=Tn * D)
+    if resume is None:
+        B = pc.shape[0]
+        dev = pc.device
+        nbhd, center = group_points(pc, G, cfg["group_size"], fps_start)
+        tok = mini_pointnet(sd, p + "encoder.", wc, nbhd, bn_train, update_running)
+        x = torch.empty((B, Tn, D), dtype=torch.float32, device=dev)
+        pos = torch.empty((B, Tn, D), dtype=torch.float32, device=dev)
+        x[:, 0] = sd[p + "cls_token"].view(D)
+        pos[:, 0] = sd[p + "cls_pos"].view(D)
+        x2, pos2 = x.view(B * Tn, D), pos.view(B * Tn, D)
+        # reduce_dim and pos_embed write straight into rows 1.. of every sample (batched GEMM)
+        ops.gemm(tok, wc.get(sd[p + "reduce_dim.weight"]), out=x2[1:], M=G, bias=sd[p + "reduce_dim.bias"], batch=B,
+                 strideA=G * tok.shape[1], strideC=Tn * D)
+        pe = ops.linear3_gelu(center.view(B * G, 3), sd[p + "pos_embed.0.weight"], sd[p + "pos_embed.0.bias"], T)
+        ops.gemm(pe, wc.get(sd[p + "pos_embed.2.weight"]), out=pos2[1:], M=G, bias=sd[p + "pos_embed.2.bias"], batch=B,
+                 strideA=G * pe.shape[1], strideC=Tn * D)
+        first, pos_in_x = 0, False
+    else:
+        x2, pos2 = resume
+        B = x2.shape[0] // Tn
+        first, pos_in_x = depth - 1, depth > 1
     saved = None
     fetched = []
-    pos_in_x = False
-    for l in range(depth):
+    for l in range(first, depth - 1 if last_block is False else depth):
         bp = f"{p}blocks.blocks.{l}."
         d1 = dp[l, 0] if dp is not None else None
         d2 = dp[l, 1] if dp is not None else None
@@ -189,6 +200,8 @@ def point_encoder_forward(sd, p, wc, pc, fps_start, dp, bn_train, save_tier, cfg
         if fetch is not None and l in fetch:        # part-seg: norm(x)[:, 1:] after blocks 3, 7, 11 (point_encoder.py:100-108,377)
             fn, _, _ = ops.layernorm_fwd(x2, sd[p + "norm.weight"], sd[p + "norm.bias"], torch.float32)
             fetched.append(fn.view(B, Tn, D)[:, 1:])
+    if last_block is False:
+        return x2, pos2
     if fetch is not None:
         return fetched, center
     keep = saved is not None

@@ -87,6 +87,9 @@ class _PointEncoderFn(torch.autograd.Function):
         ctx.module, ctx.tier, ctx.names = module, tier, names
         # tier 0 (everything frozen, nothing kept for a backward): ~140 launches whose arguments depend on shapes only --
         # replayed from a hipGraph after graphs.WARMUP_CALLS eager calls (ppt_amd/graphs.py; 2 us less per launch)
+        if tier == 0 and module.param_gate is not None and pc.is_cuda:      # e.g. an evaluation right behind a training step
+            torch.cuda.current_stream().wait_event(module.param_gate)
+            module.param_gate = None
         key = ("point_fwd", tuple(pc.shape), dp is not None, train, cache.dtype)
         if (tier == 0 and pc.is_cuda and module.use_hip_graphs and ops.profiler is None and module._graphs.ready(key)):
             def build():
@@ -97,7 +100,26 @@ class _PointEncoderFn(torch.autograd.Function):
             (feat,), _ = module._graphs.get(key, build)(pc, fps_start, *([dp] if dp is not None else []))
             ctx.saved = None
             return feat.clone()
-        feat, saved = engine.point_encoder_forward(sd, "", cache, pc, fps_start, dp, train, tier, cfg)
+        if tier > 0 and pc.is_cuda:
+            # something in the last block trains: everything in front of it is still frozen.  That prefix is replayed
+            # from a hipGraph, and only the rest waits for the optimizer of the previous iteration (module.param_gate,
+            # set by train.Trainer.step) -- the prefix runs ahead of it like the whole tower does for head_type 0.
+            key = ("point_prefix", tuple(pc.shape), dp is not None, train, cache.dtype)
+            if module.use_hip_graphs and ops.profiler is None and module._graphs.ready(key):
+                def build():
+                    def fn(pc_, start_, *dp_):
+                        return engine.point_encoder_forward(sd, "", cache, pc_, start_, dp_[0] if dp_ else None, train, 0, cfg,
+                                                            last_block=False), None
+                    return graphs.GraphedCall(fn, [pc, fps_start] + ([dp] if dp is not None else []))
+                cut, _ = module._graphs.get(key, build)(pc, fps_start, *([dp] if dp is not None else []))
+            else:
+                cut = engine.point_encoder_forward(sd, "", cache, pc, fps_start, dp, train, 0, cfg, last_block=False)
+            gate, module.param_gate = module.param_gate, None
+            if gate is not None:
+                torch.cuda.current_stream().wait_event(gate)
+            feat, saved = engine.point_encoder_forward(sd, "", cache, None, None, dp, train, tier, cfg, resume=cut)
+        else:
+            feat, saved = engine.point_encoder_forward(sd, "", cache, pc, fps_start, dp, train, tier, cfg)
         ctx.saved = saved
         return feat
 
@@ -147,6 +169,7 @@ class PointTransformer(nn.Module):
         self.precision = torch.bfloat16
         self._graphs = graphs.GraphCache()
         self.use_hip_graphs = True
+        self.param_gate = None           # event after which this iteration may read the last block's parameters (Trainer)
         self.fps_start = None            # [B] int64: injected FPS start indices (else torch.randint)
         self.drop_path_factors = None    # [depth,2,B] fp32: injected DropPath factors (else drawn on device)
         self._wc = None

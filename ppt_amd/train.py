@@ -111,6 +111,10 @@ class Trainer:
         self._point_side_frozen = all(n.startswith("prompt_learner.") or not p.requires_grad
                                       for n, p in model.named_parameters())
         self._side_used = None
+        # trainables outside the prompt learner and the point encoder's last block (pc_projection, logit_scale, a
+        # part-seg decoder ...) are read wherever forward() likes: no gating then
+        self._gated = all(n.startswith("prompt_learner.") or n.startswith("point_encoder.blocks.blocks.") or not p.requires_grad
+                          for n, p in model.named_parameters())
         self.bcast = BufferBroadcast(model) if distributed else None
         if hasattr(model, "_sd"):
             model._sd = None
@@ -158,17 +162,31 @@ class Trainer:
             self.optimizer.step()
             model.logit_scale.data.clamp_(0, 4.6052)                # main_cls.py:213
         if side is not None and not self._point_side_frozen:
-            main.wait_stream(side)                                  # the point tower reads updated parameters
+            pe = getattr(model, "point_encoder", None)
+            if self._gated and getattr(pe, "param_gate", False) is None:
+                # PointBERT with an un-frozen last block: only that block (and what follows) must see this update; the
+                # frozen prefix of the next iteration runs ahead (point_encoder._PointEncoderFn waits on the event)
+                pe.param_gate = side.record_event()
+            else:
+                main.wait_stream(side)                              # the point tower reads updated parameters
         if check_finite and not math.isfinite(loss.item()):         # main_cls.py:205-207
             raise FloatingPointError(f"Loss is {loss.item()}, stopping training")
         self.it += 1
         return loss, pred
+
+    def _drain_gate(self):
+        pe = getattr(self.model, "point_encoder", None)
+        gate = getattr(pe, "param_gate", None)
+        if gate is not None:
+            torch.cuda.current_stream().wait_event(gate)
+            pe.param_gate = None
 
     def finish(self):
         """Order the caller's stream after everything `step` queued and bring every rank's BatchNorm running statistics
         to rank 0's (call before reading parameters or buffers: evaluation, checkpointing)."""
         if self._side_used is not None:
             torch.cuda.current_stream().wait_stream(self._side_used)
+        self._drain_gate()
         if self.bcast is not None and not self.broadcast_buffers_every_step:
             self.bcast.broadcast()
 

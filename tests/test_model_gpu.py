@@ -193,7 +193,9 @@ def test_run_ahead_training_is_identical(head_type):
         results.append(([l.item() for l in losses], pred.clone(),
                         {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad}))
         assert bool(m._graphs.entries) == hip_graphs          # the text tower really was replayed from a hipGraph
-        assert bool(m.point_encoder._graphs.entries) == (hip_graphs and head_type == 0)      # and the frozen point tower
+        # ... and the point tower: all of it for head_type 0, the frozen prefix in front of the last block otherwise
+        assert [k[0] for k in m.point_encoder._graphs.entries] == ([] if not hip_graphs else
+                                                                   ["point_fwd" if head_type == 0 else "point_prefix"])
     la, pa, wa = results[0]
     for lb, pb, wb in results[1:]:
         assert la == lb
