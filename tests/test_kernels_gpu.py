@@ -389,6 +389,35 @@ def test_conv1_stats_bn_finalize(ops):
     assert (sh2.cpu() - (torch.from_numpy(be) - torch.from_numpy(rm) * ref)).abs().max().item() < 1e-6
 
 
+@pytest.mark.parametrize("P,C,rpp,tail", [(2048, 512, 32, 0), (5000, 96, 32, 7), (300, 512, 32, 0), (2500, 40, 64, 13)])
+def test_bn_finalize_many_partials(ops, P, C, rpp, tail):
+    """(sum, M2) chunk partials -> scale / shift / running statistics: the two-stage fold (>= 2048 partials, workspace)
+    and the single-kernel one give the statistics of the underlying rows; large mean / small spread included."""
+    rng = np.random.default_rng(P + C)
+    count = P * rpp - (rpp - tail if tail else 0)
+    rows = (rng.standard_normal((count, C)) * rng.random(C) * 3 + rng.standard_normal(C) * 50).astype(np.float32)
+    x = torch.from_numpy(rows).double()
+    ps = torch.zeros((P, C), dtype=torch.float32); pq = torch.zeros((P, C), dtype=torch.float32)
+    for i in range(P):
+        ch = x[i * rpp:min(count, (i + 1) * rpp)]
+        ps[i] = ch.sum(0).float(); pq[i] = ((ch - ch.mean(0)) ** 2).sum(0).float()
+    g = (1 + 0.1 * rng.standard_normal(C)).astype(np.float32); be = (0.1 * rng.standard_normal(C)).astype(np.float32)
+    rm = dev(rng.standard_normal(C).astype(np.float32)); rv = dev((1 + rng.random(C)).astype(np.float32))
+    rm0, rv0 = rm.cpu().clone(), rv.cpu().clone()
+    nbt = torch.zeros((), dtype=torch.int64, device="cuda")
+    sc, sh = ops.bn_finalize(dev(g), dev(be), True, partials=(ps.cuda(), pq.cuda()), rows_per_partial=rpp, count=count,
+                             running_mean=rm, running_var=rv, num_batches_tracked=nbt)
+    mean, var = x.mean(0), x.var(0, unbiased=False)
+    sc_ref = torch.from_numpy(g).double() / torch.sqrt(var + 1e-5)
+    assert torch.allclose(sc.cpu().double(), sc_ref, rtol=2e-5, atol=1e-6)
+    assert torch.allclose(sh.cpu().double(), torch.from_numpy(be).double() - mean * sc_ref, rtol=2e-5, atol=2e-4)
+    assert torch.allclose(rm.cpu().double(), 0.9 * rm0.double() + 0.1 * mean, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(rv.cpu().double(), 0.9 * rv0.double() + 0.1 * x.var(0, unbiased=True), rtol=1e-5, atol=1e-5)
+    assert nbt.item() == 1
+    sc_b, sh_b = ops.bn_finalize(dev(g), dev(be), True, partials=(ps.cuda(), pq.cuda()), rows_per_partial=rpp, count=count)
+    assert torch.equal(sc_b, sc) and torch.equal(sh_b, sh)
+
+
 def test_misc_ops(ops):
     rng = np.random.default_rng(31)
     x = rng.standard_normal((3, 513, 384)).astype(np.float32)
