@@ -176,8 +176,23 @@ size_t ppt_bn_finalize_workspace_bytes(int n_partials, int C);
 int ppt_bn_finalize_ws(const float *part_sum, const float *part_sqsum, int n_partials,
                        int rows_per_partial, int64_t count, int C, const float *gamma, const float *beta, float eps, int train,
                        float momentum, float *running_mean, float *running_var,
-                       int64_t *num_batches_tracked, float *scale, float *shift, void *workspace, size_t workspace_bytes,
-                       void *stream);
+                       int64_t *num_batches_tracked, float *scale, float *shift,
+                       float *mean_out /* [C] or NULL */, float *rstd_out /* [C] or NULL: what a backward needs */,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- BatchNorm1d (+ ReLU) over the rows of a row-major fp32 [M, C] tensor, forward statistics and backward: the
+ * part-segmentation decoder's `F.relu(bn(conv(x)))` (models/pointbert/pointnet2_utils.py:362-366) with trainable
+ * gamma / beta.  rows_stats: (sum, M2) partials per ppt_rows_stats_rows_per_partial() rows, ceil(M / that) x C each, for
+ * ppt_bn_finalize(_ws); the normalisation itself is ppt_bn_act_rows.  Backward, with g = dy * [x*scale+shift > 0] when
+ * relu: bwd_reduce writes the per-chunk partials of sum(g) and sum(g * xhat) (reduce them with ppt_reduce_rows: they are
+ * d beta and d gamma); bwd_apply: dx = scale * (g - sum_g/M - xhat * sum_gx/M) (batch_stats = 0, eval mode: dx = scale*g). */
+int ppt_rows_stats_rows_per_partial(void);
+int ppt_rows_stats_f32(const float *x, int64_t M, int C, float *part_sum, float *part_m2, void *stream);
+int ppt_bn_rows_bwd_reduce(const float *dy, const float *x, const float *scale, const float *shift, const float *mean,
+                           const float *rstd, int relu, int64_t M, int C, float *part_g, float *part_gx, void *stream);
+int ppt_bn_rows_bwd_apply(const float *dy, const float *x, const float *scale, const float *shift, const float *mean,
+                          const float *rstd, const float *sum_g, const float *sum_gx, int relu, int batch_stats, int64_t M,
+                          int C, float *dx, void *stream);
 int ppt_conv1_stats_max_partials(int64_t M);
 int ppt_conv1_stats_rows_per_partial(void);
 

@@ -60,8 +60,14 @@ _SIGNATURES = {
     "ppt_bn_finalize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_float, c_int,
                                 c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ppt_bn_finalize_ws": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_float, c_int,
-                                   c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_size_t,
-                                   c_void_p]),
+                                   c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   ctypes.c_size_t, c_void_p]),
+    "ppt_rows_stats_rows_per_partial": (c_int, []),
+    "ppt_rows_stats_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "ppt_bn_rows_bwd_reduce": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int,
+                                       c_void_p, c_void_p, c_void_p]),
+    "ppt_bn_rows_bwd_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                      c_int, c_int64, c_int, c_void_p, c_void_p]),
     "ppt_bn_finalize_workspace_bytes": (ctypes.c_size_t, [c_int, c_int]),
     "ppt_linear3_gelu": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "ppt_cls_max_pool": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

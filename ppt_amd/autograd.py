@@ -54,3 +54,38 @@ def linear(x, w, b=None, prec=torch.bfloat16):
     lead = x.shape[:-1]
     y = _Linear.apply(x.reshape(-1, x.shape[-1]), w, b, prec)
     return y.view(*lead, -1)
+
+
+class _BatchNormReLURows(torch.autograd.Function):
+    """relu(batch_norm(x)) over the rows of x [M,C] with trainable gamma / beta (pointnet2_utils.py:362-366): statistics,
+    normalisation and the whole backward on the HIP kernels (ppt_rows_stats_f32, ppt_bn_finalize_ws, ppt_bn_act_rows,
+    ppt_bn_rows_bwd_*); running statistics updated in place as nn.BatchNorm1d does."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, num_batches_tracked, training, momentum, eps):
+        x = x.detach().float().contiguous()
+        g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        if training:
+            parts, rpp = ops.rows_stats(x)
+            sc, sh, mean, rstd = ops.bn_finalize(g, b, True, partials=parts, rows_per_partial=rpp, count=x.shape[0],
+                                                 running_mean=running_mean, running_var=running_var,
+                                                 num_batches_tracked=num_batches_tracked, eps=eps, momentum=momentum,
+                                                 want_moments=True)
+        else:
+            sc, sh, mean, rstd = ops.bn_finalize(g, b, False, running_mean=running_mean, running_var=running_var, eps=eps,
+                                                 want_moments=True)
+        ctx.save_for_backward(x, sc, sh, mean, rstd)
+        ctx.training = training
+        return ops.bn_act_rows(x, sc, sh, torch.float32)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, sc, sh, mean, rstd = ctx.saved_tensors
+        dx, dgamma, dbeta = ops.bn_rows_backward(dy.contiguous().float(), x, sc, sh, mean, rstd, True, ctx.training)
+        return dx, dgamma, dbeta, None, None, None, None, None, None
+
+
+def batch_norm_relu_rows(x, bn, training):
+    """F.relu(bn(x)) for x [M,C] and an nn.BatchNorm1d `bn` (momentum must be a number)."""
+    return _BatchNormReLURows.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                    bn.num_batches_tracked if training else None, training, bn.momentum, bn.eps)

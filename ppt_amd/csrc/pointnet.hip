@@ -73,7 +73,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restri
                                                           const float *__restrict__ gamma, const float *__restrict__ beta,
                                                           float eps, int train, float momentum, float *__restrict__ rmean,
                                                           float *__restrict__ rvar, int64_t *__restrict__ nbt,
-                                                          float *__restrict__ scale, float *__restrict__ shift)
+                                                          float *__restrict__ scale, float *__restrict__ shift,
+        float *__restrict__ mean_out, float *__restrict__ rstd_out)
 {
     constexpr int CH = 8, ST = 128;
     __shared__ stat3 red[ST][CH + 1];
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restri
     const float sc = gamma[c] / sqrtf(var_f + eps);
     scale[c] = sc;
     shift[c] = beta[c] - mean_f * sc;
+    if (mean_out) { mean_out[c] = mean_f; rstd_out[c] = 1.0f / sqrtf(var_f + eps); }
 }
 
 // ---- two-stage fold for many partials (conv3: 16 384 x 512) -----------------------------------------------------
@@ -166,7 +168,8 @@ __global__ __launch_bounds__(256) void bn_finish_kernel(const double *__restrict
                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
                                                         float eps, float momentum, float *__restrict__ rmean,
                                                         float *__restrict__ rvar, int64_t *__restrict__ nbt,
-                                                        float *__restrict__ scale, float *__restrict__ shift)
+                                                        float *__restrict__ scale, float *__restrict__ shift,
+        float *__restrict__ mean_out, float *__restrict__ rstd_out)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
@@ -187,6 +190,75 @@ __global__ __launch_bounds__(256) void bn_finish_kernel(const double *__restrict
     const float sc = gamma[c] / sqrtf(var_f + eps);
     scale[c] = sc;
     shift[c] = beta[c] - mean_f * sc;
+    if (mean_out) { mean_out[c] = mean_f; rstd_out[c] = 1.0f / sqrtf(var_f + eps); }
+}
+
+// ---- BatchNorm over the rows of a row-major [M, C] fp32 tensor (the part-segmentation decoder: BatchNorm1d behind every
+// 1x1 convolution, pointnet2_utils.py:297-368).  Threads run along the columns (coalesced rows), a workgroup owns a
+// chunk of RS_ROWS rows: forward statistics by Welford's update (single pass, no cancellation) into the same
+// (sum, M2) partial format bn_finalize folds; backward in two kernels: chunk partials of {sum g, sum g xhat} with
+// g = dy * [y > 0] (the fused ReLU), then dx = scale * (g - mean(g) - xhat * mean(g xhat)).
+constexpr int RS_ROWS = 64;
+
+__global__ __launch_bounds__(256) void rows_stats_kernel(const float *__restrict__ x, int64_t M, int C,
+                                                         float *__restrict__ psum, float *__restrict__ pm2)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int64_t r0 = (int64_t)blockIdx.y * RS_ROWS;
+    const int nrow = (int)min((int64_t)RS_ROWS, M - r0);
+    float mean = 0.f, m2 = 0.f;
+    for (int r = 0; r < nrow; ++r) {
+        const float v = x[(r0 + r) * C + c];
+        const float d = v - mean;
+        mean += d * __builtin_amdgcn_rcpf((float)(r + 1));
+        m2 = fmaf(d, v - mean, m2);
+    }
+    psum[(size_t)blockIdx.y * C + c] = mean * (float)nrow;
+    pm2[(size_t)blockIdx.y * C + c] = m2;
+}
+
+__global__ __launch_bounds__(256) void bn_rows_bwd_reduce_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                                 const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                 const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                                 int relu, int64_t M, int C, float *__restrict__ pg,
+                                                                 float *__restrict__ pgx)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int64_t r0 = (int64_t)blockIdx.y * RS_ROWS;
+    const int nrow = (int)min((int64_t)RS_ROWS, M - r0);
+    const float sc = scale[c], sh = shift[c], mu = mean[c], rs = rstd[c];
+    float sg = 0.f, sgx = 0.f;
+    for (int r = 0; r < nrow; ++r) {
+        const float v = x[(r0 + r) * C + c];
+        float g = dy[(r0 + r) * C + c];
+        if (relu && !(fmaf(v, sc, sh) > 0.f)) g = 0.f;
+        sg += g;
+        sgx = fmaf(g, (v - mu) * rs, sgx);
+    }
+    pg[(size_t)blockIdx.y * C + c] = sg;
+    pgx[(size_t)blockIdx.y * C + c] = sgx;
+}
+
+__global__ __launch_bounds__(256) void bn_rows_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                                const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                                const float *__restrict__ sum_g, const float *__restrict__ sum_gx,
+                                                                int relu, int batch_stats, int64_t M, int C, float *__restrict__ dx)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int64_t r0 = (int64_t)blockIdx.y * RS_ROWS;
+    const int nrow = (int)min((int64_t)RS_ROWS, M - r0);
+    const float sc = scale[c], sh = shift[c], mu = mean[c], rs = rstd[c];
+    const float mg = batch_stats ? sum_g[c] / (float)M : 0.f, mgx = batch_stats ? sum_gx[c] / (float)M : 0.f;
+    for (int r = 0; r < nrow; ++r) {
+        const float v = x[(r0 + r) * C + c];
+        float g = dy[(r0 + r) * C + c];
+        if (relu && !(fmaf(v, sc, sh) > 0.f)) g = 0.f;
+        dx[(r0 + r) * C + c] = sc * (g - mg - (v - mu) * rs * mgx);
+    }
 }
 
 template <typename TY>
@@ -347,22 +419,33 @@ extern "C" int ppt_conv1_stats(const float *pts, int64_t M, const float *w1, con
     return PPT_OK;
 }
 
-extern "C" int ppt_bn_finalize(const float *part_sum, const float *part_sqsum, int n_partials, int rows_per_partial,
-                               int64_t count, int C,
-                               const float *gamma, const float *beta, float eps, int train, float momentum,
-                               float *running_mean, float *running_var, int64_t *num_batches_tracked, float *scale,
-                               float *shift, void *stream)
+static int bn_finalize_single(const float *part_sum, const float *part_sqsum, int n_partials, int rows_per_partial,
+                              int64_t count, int C,
+                              const float *gamma, const float *beta, float eps, int train, float momentum,
+                              float *running_mean, float *running_var, int64_t *num_batches_tracked, float *scale,
+                              float *shift, float *mean_out, float *rstd_out, void *stream)
 {
     if (!gamma || !beta || !scale || !shift || C <= 0) return PPT_EINVAL;
+    if ((mean_out == nullptr) != (rstd_out == nullptr)) return PPT_EINVAL;
     if (train && (!part_sum || !part_sqsum || n_partials <= 0 || count <= 0 || rows_per_partial <= 0 ||
                   (int64_t)n_partials * rows_per_partial < count))
         return PPT_EINVAL;
     if (!train && (!running_mean || !running_var)) return PPT_EINVAL;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(1024), 0, ppt_stream(stream), part_sum, part_sqsum,
                        n_partials, (double)count, rows_per_partial, C, gamma, beta, eps, train, momentum, running_mean, running_var,
-                       num_batches_tracked, scale, shift);
+                       num_batches_tracked, scale, shift, mean_out, rstd_out);
     PPT_CHECK_LAUNCH();
     return PPT_OK;
+}
+
+extern "C" int ppt_bn_finalize(const float *part_sum, const float *part_sqsum, int n_partials, int rows_per_partial,
+                               int64_t count, int C,
+                               const float *gamma, const float *beta, float eps, int train, float momentum,
+                               float *running_mean, float *running_var, int64_t *num_batches_tracked, float *scale,
+                               float *shift, void *stream)
+{
+    return bn_finalize_single(part_sum, part_sqsum, n_partials, rows_per_partial, count, C, gamma, beta, eps, train, momentum,
+                              running_mean, running_var, num_batches_tracked, scale, shift, nullptr, nullptr, stream);
 }
 
 extern "C" size_t ppt_bn_finalize_workspace_bytes(int n_partials, int C)
@@ -375,12 +458,14 @@ extern "C" int ppt_bn_finalize_ws(const float *part_sum, const float *part_sqsum
                                   int64_t count, int C,
                                   const float *gamma, const float *beta, float eps, int train, float momentum,
                                   float *running_mean, float *running_var, int64_t *num_batches_tracked, float *scale,
-                                  float *shift, void *workspace, size_t workspace_bytes, void *stream)
+                                  float *shift, float *mean_out, float *rstd_out, void *workspace, size_t workspace_bytes,
+                                  void *stream)
 {
     const size_t need = train ? ppt_bn_finalize_workspace_bytes(n_partials, C) : 0;
     if (need == 0 || !workspace || workspace_bytes < need || ((uintptr_t)workspace & 7))
-        return ppt_bn_finalize(part_sum, part_sqsum, n_partials, rows_per_partial, count, C, gamma, beta, eps, train, momentum,
-                               running_mean, running_var, num_batches_tracked, scale, shift, stream);
+        return bn_finalize_single(part_sum, part_sqsum, n_partials, rows_per_partial, count, C, gamma, beta, eps, train, momentum,
+                                  running_mean, running_var, num_batches_tracked, scale, shift, mean_out, rstd_out, stream);
+    if ((mean_out == nullptr) != (rstd_out == nullptr)) return PPT_EINVAL;
     if (!gamma || !beta || !scale || !shift || C <= 0 || !part_sum || !part_sqsum || count <= 0 || rows_per_partial <= 0 ||
         (int64_t)n_partials * rows_per_partial < count)
         return PPT_EINVAL;
@@ -390,7 +475,44 @@ extern "C" int ppt_bn_finalize_ws(const float *part_sum, const float *part_sqsum
     PPT_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, ppt_stream(stream), (const double *)workspace,
                        nsplit, (double)count, C, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked,
-                       scale, shift);
+                       scale, shift, mean_out, rstd_out);
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
+extern "C" int ppt_rows_stats_rows_per_partial(void) { return RS_ROWS; }
+
+extern "C" int ppt_rows_stats_f32(const float *x, int64_t M, int C, float *part_sum, float *part_m2, void *stream)
+{
+    if (!x || !part_sum || !part_m2 || M <= 0 || C <= 0 || (M + RS_ROWS - 1) / RS_ROWS > 65535) return PPT_EINVAL;
+    hipLaunchKernelGGL(rows_stats_kernel, dim3((C + 255) / 256, (unsigned)((M + RS_ROWS - 1) / RS_ROWS)), dim3(256), 0,
+                       ppt_stream(stream), x, M, C, part_sum, part_m2);
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
+extern "C" int ppt_bn_rows_bwd_reduce(const float *dy, const float *x, const float *scale, const float *shift,
+                                      const float *mean, const float *rstd, int relu, int64_t M, int C, float *part_g,
+                                      float *part_gx, void *stream)
+{
+    if (!dy || !x || !scale || !shift || !mean || !rstd || !part_g || !part_gx || M <= 0 || C <= 0 ||
+        (M + RS_ROWS - 1) / RS_ROWS > 65535)
+        return PPT_EINVAL;
+    hipLaunchKernelGGL(bn_rows_bwd_reduce_kernel, dim3((C + 255) / 256, (unsigned)((M + RS_ROWS - 1) / RS_ROWS)), dim3(256), 0,
+                       ppt_stream(stream), dy, x, scale, shift, mean, rstd, relu, M, C, part_g, part_gx);
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
+extern "C" int ppt_bn_rows_bwd_apply(const float *dy, const float *x, const float *scale, const float *shift, const float *mean,
+                                     const float *rstd, const float *sum_g, const float *sum_gx, int relu, int batch_stats,
+                                     int64_t M, int C, float *dx, void *stream)
+{
+    if (!dy || !x || !scale || !shift || !mean || !rstd || !dx || M <= 0 || C <= 0 || (M + RS_ROWS - 1) / RS_ROWS > 65535)
+        return PPT_EINVAL;
+    if (batch_stats && (!sum_g || !sum_gx)) return PPT_EINVAL;
+    hipLaunchKernelGGL(bn_rows_bwd_apply_kernel, dim3((C + 255) / 256, (unsigned)((M + RS_ROWS - 1) / RS_ROWS)), dim3(256), 0,
+                       ppt_stream(stream), dy, x, scale, shift, mean, rstd, sum_g, sum_gx, relu, batch_stats, M, C, dx);
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }

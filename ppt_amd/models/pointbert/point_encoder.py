@@ -314,7 +314,7 @@ class PointTransformer_partseg(nn.Module):
         return self.state_dict(keep_vars=True)
 
     def forward(self, pts, cls_label):
-        from ...autograd import linear
+        from ...autograd import batch_norm_relu_rows, linear
         pts = pts.contiguous().float()
         B, N, _ = pts.shape
         dev = pts.device
@@ -335,10 +335,7 @@ class PointTransformer_partseg(nn.Module):
         f1 = self.dgcnn_pro_1(c2, f2, c1, f1)
         f0 = self.propagation_0(pts, c1, f0, f1)
         y = linear(f0.reshape(B * N, -1), self.conv1.weight, self.conv1.bias, self._precision)
-        y = torch.relu(torch.nn.functional.batch_norm(y, self.bn1.running_mean, self.bn1.running_var, self.bn1.weight,
-                                                      self.bn1.bias, self.training, self.bn1.momentum, self.bn1.eps))
-        if self.training:
-            self.bn1.num_batches_tracked += 1
+        y = batch_norm_relu_rows(y, self.bn1, self.training)
         y = y.view(B, N, -1)
         if self.dropout_mask is not None:
             y = y * self.dropout_mask.to(dev)

@@ -2,14 +2,15 @@
 (51), index_points (75), farthest_point_sample (95), PointNetFeaturePropagation (297-368), DGCNN_Propagation
 (371-467) -- identical names / state-dict keys.  Neighbour searches (3-NN, k=4 kNN, FPS) and every 1x1 convolution
 run on the HIP kernels (ppt_knn_group_f32, ppt_fps_f32, ppt_gemm via ppt_amd.autograd.linear, which also
-provides the weight gradients the decoder needs); the memory-bound glue between them (BatchNorm / GroupNorm /
-activations / gathers and their backward) is still ATen ops in this round -- see DESIGN.md section 8."""
+provides the weight gradients the decoder needs) and so does BatchNorm1d + ReLU with its backward
+(ppt_amd.autograd.batch_norm_relu_rows); GroupNorm / LeakyReLU / the gathers of the DGCNN propagation and their backward
+are still ATen ops in this round -- see DESIGN.md section 8."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import ops
-from ...autograd import linear
+from ...autograd import batch_norm_relu_rows, linear
 from .dvae import knn_point, square_distance          # noqa: F401  (same semantics as pointnet2_utils.py:20-72)
 from .misc import farthest_point_sample, index_points  # noqa: F401
 
@@ -50,9 +51,7 @@ class PointNetFeaturePropagation(nn.Module):
         x = x.reshape(B * N, -1)
         for conv, bn in zip(self.mlp_convs, self.mlp_bns):
             x = linear(x, conv.weight, conv.bias, self.precision)
-            x = F.relu(F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, self.training, bn.momentum, bn.eps))
-            if self.training:
-                bn.num_batches_tracked += 1
+            x = batch_norm_relu_rows(x, bn, self.training)        # statistics, ReLU and backward on the HIP kernels
         return x.view(B, N, -1)
 
 

@@ -260,9 +260,11 @@ def conv1_stats(pts, w1, b1):
 
 
 def bn_finalize(gamma, beta, train, partials=None, rows_per_partial=0, count=0, running_mean=None, running_var=None,
-                num_batches_tracked=None, eps=1e-5, momentum=0.1, update_running=True):
-    """-> (scale, shift) f32 [C]; updates the running buffers in place when train."""
+                num_batches_tracked=None, eps=1e-5, momentum=0.1, update_running=True, want_moments=False):
+    """-> (scale, shift) f32 [C] (+ (mean, rstd) with want_moments); updates the running buffers in place when train."""
     C = gamma.shape[0]
+    mean = torch.empty((C,), dtype=torch.float32, device=gamma.device) if want_moments else None
+    rstd = torch.empty((C,), dtype=torch.float32, device=gamma.device) if want_moments else None
     scale = torch.empty((C,), dtype=torch.float32, device=gamma.device)
     shift = torch.empty((C,), dtype=torch.float32, device=gamma.device)
     ps, pq = partials if partials is not None else (None, None)
@@ -274,10 +276,39 @@ def bn_finalize(gamma, beta, train, partials=None, rows_per_partial=0, count=0, 
                                              _p(beta), eps, int(train), momentum,
                                              _p(running_mean) if (upd or not train) else None,
                                              _p(running_var) if (upd or not train) else None,
-                                             _p(num_batches_tracked) if upd else None, _p(scale), _p(shift), _p(ws), wbytes,
-                                             _stream()),
+                                             _p(num_batches_tracked) if upd else None, _p(scale), _p(shift), _p(mean), _p(rstd),
+                                             _p(ws), wbytes, _stream()),
                "ppt_bn_finalize_ws")
-    return scale, shift
+    return (scale, shift, mean, rstd) if want_moments else (scale, shift)
+
+
+def rows_stats(x):
+    """x [M,C] f32 -> ((sum, M2) partials [P,C], rows per partial) for bn_finalize."""
+    _chk(x, torch.float32, "x")
+    M, C = x.shape
+    rpp = _lib.lib().ppt_rows_stats_rows_per_partial()
+    P = (M + rpp - 1) // rpp
+    ps = torch.empty((P, C), dtype=torch.float32, device=x.device)
+    pq = torch.empty_like(ps)
+    _lib.check(_lib.lib().ppt_rows_stats_f32(_p(x), M, C, _p(ps), _p(pq), _stream()), "ppt_rows_stats_f32")
+    return (ps, pq), rpp
+
+
+def bn_rows_backward(dy, x, scale, shift, mean, rstd, relu, batch_stats):
+    """BatchNorm1d(+ReLU) backward over rows: -> (dx [M,C], d gamma [C], d beta [C])."""
+    _chk(dy, torch.float32, "dy"); _chk(x, torch.float32, "x")
+    M, C = x.shape
+    rpp = _lib.lib().ppt_rows_stats_rows_per_partial()
+    P = (M + rpp - 1) // rpp
+    pg = torch.empty((P, C), dtype=torch.float32, device=x.device)
+    pgx = torch.empty_like(pg)
+    _lib.check(_lib.lib().ppt_bn_rows_bwd_reduce(_p(dy), _p(x), _p(scale), _p(shift), _p(mean), _p(rstd), int(relu), M, C,
+                                                 _p(pg), _p(pgx), _stream()), "ppt_bn_rows_bwd_reduce")
+    sg, sgx = reduce_rows(pg), reduce_rows(pgx)
+    dx = torch.empty_like(x)
+    _lib.check(_lib.lib().ppt_bn_rows_bwd_apply(_p(dy), _p(x), _p(scale), _p(shift), _p(mean), _p(rstd), _p(sg), _p(sgx),
+                                                int(relu), int(batch_stats), M, C, _p(dx), _stream()), "ppt_bn_rows_bwd_apply")
+    return dx, sgx, sg
 
 
 def gather_add(P, Q, idx, Nsrc, y_dtype, want_stats=True):

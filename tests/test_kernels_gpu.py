@@ -418,6 +418,34 @@ def test_bn_finalize_many_partials(ops, P, C, rpp, tail):
     assert torch.equal(sc_b, sc) and torch.equal(sh_b, sh)
 
 
+@pytest.mark.parametrize("M,C,training", [(1000, 96, True), (4096, 384, True), (130, 40, False)])
+def test_batch_norm_relu_rows_matches_torch(ops, M, C, training):
+    """relu(BatchNorm1d(x)) over rows with trainable gamma / beta: forward, running statistics, dx, d gamma, d beta."""
+    from ppt_amd.autograd import batch_norm_relu_rows
+    torch.manual_seed(M + C)
+    x = (torch.randn(M, C) * 2 + torch.randn(C) * 3).cuda().requires_grad_(True)
+    bn = torch.nn.BatchNorm1d(C).cuda()
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.2 * torch.randn(C)); bn.bias.copy_(0.3 * torch.randn(C))
+        bn.running_mean.copy_(torch.randn(C)); bn.running_var.copy_(1 + torch.rand(C))
+    ref = torch.nn.BatchNorm1d(C).cuda()
+    ref.load_state_dict(bn.state_dict())
+    bn.train(training); ref.train(training)
+    w = torch.randn(M, C, device="cuda")
+    y = batch_norm_relu_rows(x, bn, training)
+    (y * w).sum().backward()
+    xr = x.detach().clone().requires_grad_(True)
+    yr = torch.relu(ref(xr))
+    (yr * w).sum().backward()
+    assert torch.allclose(y, yr, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(x.grad, xr.grad, rtol=1e-3, atol=2e-4)
+    assert torch.allclose(bn.weight.grad, ref.weight.grad, rtol=1e-3, atol=1e-2)
+    assert torch.allclose(bn.bias.grad, ref.bias.grad, rtol=1e-3, atol=1e-2)
+    assert torch.allclose(bn.running_mean, ref.running_mean, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(bn.running_var, ref.running_var, rtol=1e-5, atol=1e-5)
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked)
+
+
 def test_misc_ops(ops):
     rng = np.random.default_rng(31)
     x = rng.standard_normal((3, 513, 384)).astype(np.float32)
