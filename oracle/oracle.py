@@ -394,6 +394,50 @@ def pointnet2_msg(sd, pc, fps_starts, train=False, drop_masks=None, prefix="poin
     return x
 
 
+PN2_SSG = dict(   # pointnet2.py:11-12
+    sa1=dict(npoint=512, radius=0.2, nsample=32),
+    sa2=dict(npoint=128, radius=0.4, nsample=64))
+
+
+def _sa_ssg(sd, p, cfg, xyz, feats, start, train, new_stats):
+    """PointNetSetAbstraction.forward with sample_and_group (pointnet2_utils.py:110-138,177-206): one radius, channels
+    = [centred xyz | features] (xyz FIRST, :132 -- the MSG module puts the features first).  xyz [B,N,3] numpy,
+    feats [B,N,D] tensor | None -> new_xyz [B,S,3] numpy, new_feats [B,S,C] tensor."""
+    B, N, _ = xyz.shape
+    S, K = cfg["npoint"], cfg["nsample"]
+    cidx = fps(xyz, S, start)
+    new_xyz = np.take_along_axis(xyz, cidx[:, :, None], axis=1)
+    gidx = ball_query(xyz, new_xyz, cfg["radius"], K)                             # [B,S,K]
+    g = torch.from_numpy(xyz[np.arange(B)[:, None, None], gidx]) - torch.from_numpy(new_xyz)[:, :, None, :]
+    if feats is not None:
+        g = torch.cat([g, feats[torch.arange(B)[:, None, None], torch.from_numpy(gidx)]], dim=-1)
+    n_layers = sum(1 for k in sd if k.startswith(p + "mlp_convs.") and k.endswith("weight"))
+    y = _conv_bn_relu_stack(sd, g.reshape(B * S * K, -1), p + "mlp_convs.{}.", p + "mlp_bns.{}.", n_layers, train, new_stats)
+    return new_xyz, y.reshape(B, S, K, -1).max(dim=2)[0]
+
+
+def pointnet2_ssg(sd, pc, fps_starts, train=False, drop_masks=None, prefix="point_encoder.", new_stats=None):
+    """Pointnet2_Ssg.forward (pointnet2.py:22-38) -> [B,256]: two single-scale set abstractions, a group_all one
+    (xyz first, :152-157), and the same FC head as the MSG encoder with Dropout(0.4) twice."""
+    xyz = pc.detach().numpy()
+    B = xyz.shape[0]
+    l1_xyz, l1 = _sa_ssg(sd, prefix + "sa1.", PN2_SSG["sa1"], xyz, None, np.asarray(fps_starts[0]), train, new_stats)
+    l2_xyz, l2 = _sa_ssg(sd, prefix + "sa2.", PN2_SSG["sa2"], l1_xyz, l1, np.asarray(fps_starts[1]), train, new_stats)
+    g = torch.cat([torch.from_numpy(l2_xyz), l2], dim=-1)
+    y = _conv_bn_relu_stack(sd, g.reshape(B * 128, -1), prefix + "sa3.mlp_convs.{}.", prefix + "sa3.mlp_bns.{}.", 3, train,
+                            new_stats)
+    x = y.reshape(B, 128, -1).max(dim=1)[0]                                       # [B,1024]
+    x = torch.relu(batch_norm_rows(linear(x, sd[prefix + "fc1.weight"], sd[prefix + "fc1.bias"]), sd, prefix + "bn1.", train,
+                                   new_stats=new_stats))
+    if drop_masks is not None:
+        x = x * drop_masks[0]
+    x = torch.relu(batch_norm_rows(linear(x, sd[prefix + "fc2.weight"], sd[prefix + "fc2.bias"]), sd, prefix + "bn2.", train,
+                                   new_stats=new_stats))
+    if drop_masks is not None:
+        x = x * drop_masks[1]
+    return x
+
+
 # ------------------------------------------------------------------------------------------------
 # text branch
 # ------------------------------------------------------------------------------------------------

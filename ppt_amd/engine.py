@@ -295,22 +295,29 @@ def _stats_bufs(M, C, dev, train):
 
 
 def _sa_msg_level(sd, p, wc, cfg, xyz, feats, start, train, upd):
-    """PointNetSetAbstractionMsg.forward (pointnet2_utils.py:228-266).  xyz [B,N,3] fp32, feats [B*N, D] (T) or None
-    -> (new_xyz [B,S,3], new_feats [B*S, sum C] (T))."""
+    """PointNetSetAbstractionMsg.forward (pointnet2_utils.py:228-266): one (radius, nsample, MLP) branch per scale,
+    channels = [features | centred xyz] (:250)."""
+    branches = [(r, K, f"{p}conv_blocks.{i}.", f"{p}bn_blocks.{i}.") for i, (r, K) in enumerate(zip(cfg["radii"], cfg["nsample"]))]
+    return _sa_level(sd, branches, wc, cfg["npoint"], xyz, feats, start, train, upd, xyz_first=False)
+
+
+def _sa_level(sd, branches, wc, npoint, xyz, feats, start, train, upd, xyz_first):
+    """FPS + ball query + shared three-layer MLP + max over the group, for every (radius, nsample, conv prefix, bn prefix)
+    branch.  xyz [B,N,3] fp32, feats [B*N, D] (T) or None -> (new_xyz [B,S,3], new_feats [B*S, sum C] (T)).
+    xyz_first: channel order of the first conv's input, [centred xyz | features] (sample_and_group, :132) or
+    [features | centred xyz] (the MSG module, :250)."""
     T = wc.dtype
     B, N, _ = xyz.shape
-    S = cfg["npoint"]
+    S = npoint
     dev = xyz.device
     _, new_xyz = ops.fps(xyz, S, start)
-    n_br = len(cfg["radii"])
-    c_out = [sd[f"{p}conv_blocks.{i}.2.weight"].shape[0] for i in range(n_br)]
+    c_out = [sd[cb + "2.weight"].shape[0] for _, _, cb, _ in branches]
     out = torch.empty((B * S, sum(c_out)), dtype=T, device=dev)
     col = 0
     mult = 8 if T == torch.bfloat16 else 4
-    for i, (r, K) in enumerate(zip(cfg["radii"], cfg["nsample"])):
+    for i, (r, K, cb, bb) in enumerate(branches):
         idx, gxyz = ops.ball_query(xyz, new_xyz, r, K, want_grouped=True)
         M = B * S * K
-        cb, bb = f"{p}conv_blocks.{i}.", f"{p}bn_blocks.{i}."
         w0, b0 = sd[cb + "0.weight"], sd[cb + "0.bias"]
         C1 = w0.shape[0]
         st1 = _stats_bufs(M, sd[cb + "1.weight"].shape[0], dev, train)
@@ -328,13 +335,13 @@ def _sa_msg_level(sd, p, wc, cfg, xyz, feats, start, train, upd):
         else:
             # layer 0 by linearity of the 1x1 conv: per source point P = W.[feat|xyz], per centre Q = b - W_xyz.c
             D = feats.shape[1]
-            key = (id(w0), "pn2pad")
+            fo, xo = (3, 0) if xyz_first else (0, D)              # column offsets of the features / the coordinates
             src = torch.zeros((B * N, (D + 3 + mult - 1) // mult * mult), dtype=T, device=dev)
-            src[:, :D] = feats
-            src[:, D:D + 3] = xyz.view(B * N, 3)
+            src[:, fo:fo + D] = feats
+            src[:, xo:xo + 3] = xyz.view(B * N, 3)
             w0p = wc.get(w0, "w", pad_to=mult)
             P = ops.gemm(src, w0p, out_dtype=torch.float32)
-            wx = _pad_cols(w0.detach().reshape(C1, -1)[:, D:D + 3], 4, torch.float32)
+            wx = _pad_cols(w0.detach().reshape(C1, -1)[:, xo:xo + 3], 4, torch.float32)
             cx = _pad_cols(new_xyz.view(B * S, 3), 4, torch.float32)
             Q = ops.gemm(cx, wx, out_dtype=torch.float32)
             Q = b0.view(1, C1) - Q
@@ -366,6 +373,15 @@ def pointnet2_msg_forward(sd, p, wc, pc, fps_starts, train, drop_masks, update_r
     l1_xyz, l1 = _sa_msg_level(sd, p + "sa1.", wc, PN2_MSG["sa1"], pc, None, fps_starts[0], train, update_running)
     l2_xyz, l2 = _sa_msg_level(sd, p + "sa2.", wc, PN2_MSG["sa2"], l1_xyz.contiguous(), l1, fps_starts[1], train,
                                update_running)
+    return _pn2_tail(sd, p, wc, l2_xyz, l2, train, drop_masks, update_running)
+
+
+def _pn2_tail(sd, p, wc, l2_xyz, l2, train, drop_masks, update_running):
+    """sa3 (group_all) + the FC head shared by Pointnet2_Msg and Pointnet2_Ssg (pointnet2.py:33-36, 67-70)."""
+    T = wc.dtype
+    B = l2_xyz.shape[0]
+    dev = l2_xyz.device
+    mult = 8 if T == torch.bfloat16 else 4
     # sa3: group_all over the 128 remaining points, channels = [xyz | features] (pointnet2_utils.py:152-157)
     S2 = l2_xyz.shape[1]
     M = B * S2
@@ -398,6 +414,20 @@ def pointnet2_msg_forward(sd, p, wc, pc, fps_starts, train, drop_masks, update_r
         last = fc == "fc2."
         x = ops.bn_act_rows(h, sc, sh, torch.float32 if last else T, mask=drop_masks[mask] if drop_masks is not None else None)
     return x
+
+
+PN2_SSG = dict(   # pointnet2.py:11-12
+    sa1=dict(npoint=512, radius=0.2, nsample=32), sa2=dict(npoint=128, radius=0.4, nsample=64))
+
+
+def pointnet2_ssg_forward(sd, p, wc, pc, fps_starts, train, drop_masks, update_running=True):
+    """Pointnet2_Ssg.forward (pointnet2.py:22-38): pc [B,N,3] -> [B,256] fp32; same kernels as the MSG encoder, one
+    scale per level and [centred xyz | features] channel order."""
+    levels, xyz, feats = (("sa1.", PN2_SSG["sa1"]), ("sa2.", PN2_SSG["sa2"])), pc, None
+    for (name, cfg), start in zip(levels, fps_starts):
+        br = [(cfg["radius"], cfg["nsample"], p + name + "mlp_convs.", p + name + "mlp_bns.")]
+        xyz, feats = _sa_level(sd, br, wc, cfg["npoint"], xyz.contiguous(), feats, start, train, update_running, xyz_first=True)
+    return _pn2_tail(sd, p, wc, xyz, feats, train, drop_masks, update_running)
 
 
 # =================================================================================================

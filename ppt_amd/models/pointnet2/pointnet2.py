@@ -51,6 +51,9 @@ class Pointnet2_Msg(nn.Module):
 
     Build-specific knobs: `precision` (bf16 / fp32 parity), `fps_start` = (start1 [B], start2 [B]) and
     `dropout_masks` = (m1 [B,512], m2 [B,256]) to inject the three RNG draws of the path in parity tests."""
+    _engine_forward = staticmethod(engine.pointnet2_msg_forward)
+    _graph_tag = "pn2_msg"
+    _drop_p = (0.4, 0.5)
 
     def __init__(self, normal_channel=False):
         super().__init__()
@@ -101,19 +104,53 @@ class Pointnet2_Msg(nn.Module):
         if self.dropout_masks is not None:
             masks = tuple(m.to(device=xyz.device, dtype=torch.float32).contiguous() for m in self.dropout_masks)
         elif self.training:
-            masks = ((torch.rand((B, 512), device=xyz.device) >= 0.4).float() / 0.6,
-                     (torch.rand((B, 256), device=xyz.device) >= 0.5).float() / 0.5)
+            p1, p2 = self._drop_p
+            masks = ((torch.rand((B, 512), device=xyz.device) >= p1).float() / (1.0 - p1),
+                     (torch.rand((B, 256), device=xyz.device) >= p2).float() / (1.0 - p2))
         if self._sd is None or self._sd[1] is not self.fc1.weight:
             self._sd = (self.state_dict(keep_vars=True), self.fc1.weight)
         sd, wc, train = self._sd[0], self._wc, self.training
         with torch.no_grad():            # every parameter of this encoder is frozen in PPT (ULIP_models.py:372-389)
             # ~90 shape-static launches: replayed from a hipGraph after graphs.WARMUP_CALLS eager calls (ppt_amd/graphs.py)
-            key = ("pn2_msg", tuple(xyz.shape), masks is not None, train, wc.dtype)
+            key = (self._graph_tag, tuple(xyz.shape), masks is not None, train, wc.dtype)
+            fwd = self._engine_forward
             if xyz.is_cuda and self.use_hip_graphs and ops.profiler is None and self._graphs.ready(key):
                 ins = [xyz, starts[0], starts[1]] + (list(masks) if masks is not None else [])
 
                 def fn(x, s0, s1, *m):
-                    return (engine.pointnet2_msg_forward(sd, "", wc, x, (s0, s1), train, tuple(m) if m else None),), None
+                    return (fwd(sd, "", wc, x, (s0, s1), train, tuple(m) if m else None),), None
                 (feat,), _ = self._graphs.get(key, lambda: graphs.GraphedCall(fn, ins))(*ins)
                 return feat.clone()
-            return engine.pointnet2_msg_forward(sd, "", wc, xyz, starts, train, masks)
+            return fwd(sd, "", wc, xyz, starts, train, masks)
+
+
+class Pointnet2_Ssg(Pointnet2_Msg):
+    """pointnet2.py:6-38: single-scale set abstractions (512 x r0.2 x 32, 128 x r0.4 x 64, group_all), the same FC head
+    with Dropout(0.4) twice.  forward(xyz [B,N,3]) -> [B,256]; same knobs as Pointnet2_Msg."""
+    _engine_forward = staticmethod(engine.pointnet2_ssg_forward)
+    _graph_tag = "pn2_ssg"
+    _drop_p = (0.4, 0.4)
+
+    def __init__(self, normal_channel=False):
+        nn.Module.__init__(self)
+        if normal_channel:
+            raise NotImplementedError("normal_channel=True is not on the PPT path (pointnet2.py:7-9 default)")
+        self.normal_channel = normal_channel
+        self.sa1 = PointNetSetAbstraction(npoint=512, radius=0.2, nsample=32, in_channel=3, mlp=[64, 64, 128], group_all=False)
+        self.sa2 = PointNetSetAbstraction(npoint=128, radius=0.4, nsample=64, in_channel=128 + 3, mlp=[128, 128, 256],
+                                          group_all=False)
+        self.sa3 = PointNetSetAbstraction(npoint=None, radius=None, nsample=None, in_channel=256 + 3, mlp=[256, 512, 1024],
+                                          group_all=True, remove_last=True)
+        self.fc1 = nn.Linear(1024, 512)
+        self.bn1 = nn.BatchNorm1d(512)
+        self.drop1 = nn.Dropout(0.4)
+        self.fc2 = nn.Linear(512, 256)
+        self.bn2 = nn.BatchNorm1d(256)
+        self.drop2 = nn.Dropout(0.4)
+        self.precision = torch.bfloat16
+        self.fps_start = None
+        self.dropout_masks = None
+        self._wc = None
+        self._sd = None
+        self._graphs = graphs.GraphCache()
+        self.use_hip_graphs = True

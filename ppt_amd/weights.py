@@ -123,6 +123,33 @@ def pointnet2_msg_spec(prefix="point_encoder."):
     return s
 
 
+PN2_SSG = dict(   # models/pointnet2/pointnet2.py:11-13
+    sa1=dict(in_channel=3, mlp=[64, 64, 128]), sa2=dict(in_channel=128 + 3, mlp=[128, 128, 256]),
+    sa3=dict(in_channel=256 + 3, mlp=[256, 512, 1024]))
+
+
+def pointnet2_ssg_spec(prefix="point_encoder."):
+    """(key, shape) list of Pointnet2_Ssg.state_dict() (models/pointnet2/pointnet2.py:6-20)."""
+    def bn(p, c):
+        return [(p + k, (c,)) for k in ("weight", "bias", "running_mean", "running_var")] + [(p + "num_batches_tracked", ())]
+    s = []
+    for name in ("sa1", "sa2", "sa3"):
+        last = PN2_SSG[name]["in_channel"]
+        convs, bns = [], []
+        for j, out in enumerate(PN2_SSG[name]["mlp"]):
+            convs += [(f"{prefix}{name}.mlp_convs.{j}.weight", (out, last, 1, 1)), (f"{prefix}{name}.mlp_convs.{j}.bias", (out,))]
+            bns += bn(f"{prefix}{name}.mlp_bns.{j}.", out)
+            last = out
+        s += convs + bns
+    s += [(prefix + "fc1.weight", (512, 1024)), (prefix + "fc1.bias", (512,))] + bn(prefix + "bn1.", 512)
+    s += [(prefix + "fc2.weight", (256, 512)), (prefix + "fc2.bias", (256,))] + bn(prefix + "bn2.", 256)
+    return s
+
+
+def ulip_pn2_ssg_state_dict(seed=0, with_token_embedding=False, as_torch=True):
+    return synth_state_dict(ulip_spec(256, with_token_embedding) + pointnet2_ssg_spec(), seed, as_torch)
+
+
 def ulip_pn2_msg_state_dict(seed=0, with_token_embedding=False, as_torch=True):
     return synth_state_dict(ulip_spec(256, with_token_embedding) + pointnet2_msg_spec(), seed, as_torch)
 

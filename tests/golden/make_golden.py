@@ -317,6 +317,54 @@ def gen_pointnet2_msg():
     np.savez_compressed(os.path.join(HERE, "g_pn2msg.npz"), **out)
 
 
+def gen_pointnet2_ssg():
+    """G-PN2S: Pointnet2_Ssg forward (eval and train BN) vs the reference module (pointnet2.py:6-38)."""
+    sd_all = W.synth_state_dict(W.pointnet2_ssg_spec(prefix=""), seed=0)
+    B, N = 2, 1024
+    pc_np, s1 = W.synth_clouds(B, N, seed=41)
+    _, s2 = W.synth_clouds(B, 512, seed=42)
+    pc = torch.from_numpy(pc_np)
+    rng = np.random.default_rng(19)
+    dm = (torch.from_numpy((rng.random((B, 512)) > 0.4).astype(np.float32) / 0.6),
+          torch.from_numpy((rng.random((B, 256)) > 0.4).astype(np.float32) / 0.6))
+    with R.reference_context():
+        from models.pointnet2.pointnet2 import Pointnet2_Ssg
+        m = Pointnet2_Ssg()
+    out = {}
+    for mode in ("eval", "train"):
+        m.load_state_dict(sd_all)
+        m.train(mode == "train")
+        if mode == "train":
+            m.drop1.forward = lambda x: x * dm[0]
+            m.drop2.forward = lambda x: x * dm[1]
+        starts = [torch.from_numpy(s1), torch.from_numpy(s2)]
+        orig = torch.randint
+        torch.randint = lambda *a, **k: starts.pop(0)
+        try:
+            with torch.no_grad():
+                ref = m(pc)
+        finally:
+            torch.randint = orig
+        ns = {}
+        with torch.no_grad():
+            ora = O.pointnet2_ssg(sd_all, pc, (s1, s2), train=(mode == "train"), drop_masks=dm if mode == "train" else None,
+                                  prefix="", new_stats=ns)
+        err = (ref - ora).abs().max().item()
+        print(f"Pointnet2_Ssg {mode}: max|ref-oracle| = {err:.3e} (|ref|max {ref.abs().max():.3f})")
+        assert err < 1e-3
+        out[mode] = ref.numpy()
+        if mode == "train":
+            msd = m.state_dict()
+            for k, v in ns.items():
+                e = (msd[k].float() - v.float()).abs().max().item()
+                assert e < 1e-4 * max(1.0, msd[k].float().abs().max().item()), (k, e)
+            for k in ("sa1.mlp_bns.2.running_var", "sa2.mlp_bns.0.running_mean", "sa3.mlp_bns.2.running_var", "bn2.running_mean"):
+                out["stat_" + k] = msd[k].numpy()
+    out["drop1"], out["drop2"] = dm[0].numpy(), dm[1].numpy()
+    out["start1"], out["start2"] = s1, s2
+    np.savez_compressed(os.path.join(HERE, "g_pn2ssg.npz"), **out)
+
+
 def gen_partseg(tok):
     """G8: ULIP_PointBERT_partseg train step (main_partseg.py:204-215) on B=2 x 2048 points with duplicates."""
     import argparse
@@ -402,9 +450,14 @@ def gen_partseg(tok):
 if __name__ == "__main__":
     assert R.reference_available(), "needs /root/reference"
     O.build_c_oracle(force=True)
-    tok = gen_tokens()
-    gen_index()
-    gen_encoder_and_step(tok)
-    gen_pointnet2_msg()
-    gen_partseg(tok)
+    import sys
+    if sys.argv[1:] == ["pn2ssg"]:              # one fixture only
+        gen_pointnet2_ssg()
+    else:
+        tok = gen_tokens()
+        gen_index()
+        gen_encoder_and_step(tok)
+        gen_pointnet2_msg()
+        gen_pointnet2_ssg()
+        gen_partseg(tok)
     print("done")

@@ -291,6 +291,58 @@ def test_pointnet2_msg_matches_golden(mode, precision, tol):
             assert (msd[k].cpu() - r).abs().max().item() < rtol * max(1.0, r.abs().max().item()), k
 
 
+@pytest.mark.parametrize("precision,tol", [(torch.float32, 2e-3), (torch.bfloat16, 6e-2)])
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_pointnet2_ssg_matches_golden(mode, precision, tol):
+    """N4: Pointnet2_Ssg forward vs the reference output captured in g_pn2ssg.npz (same conventions as the MSG test)."""
+    from ppt_amd.models.pointnet2.pointnet2 import Pointnet2_Ssg
+    g = np.load(os.path.join(G, "g_pn2ssg.npz"))
+    pc_np, s1 = W.synth_clouds(2, 1024, seed=41)
+    assert np.array_equal(s1, g["start1"])
+    m = Pointnet2_Ssg()
+    sd = W.synth_state_dict(W.pointnet2_ssg_spec(prefix=""), seed=0)
+    m.load_state_dict(sd)
+    m.cuda()
+    m.precision = precision
+    m.train(mode == "train")
+    m.fps_start = (torch.from_numpy(g["start1"]).cuda(), torch.from_numpy(g["start2"]).cuda())
+    if mode == "train":
+        m.dropout_masks = (torch.from_numpy(g["drop1"]), torch.from_numpy(g["drop2"]))
+    if mode == "train" and precision == torch.bfloat16:
+        # (batch of 2 through BatchNorm1d: ill-conditioned for bf16 -- compare with the fp32 parity path on a batch of 8)
+        pc8, s8 = W.synth_clouds(8, 1024, seed=43)
+        _, t8 = W.synth_clouds(8, 512, seed=44)
+        rng = np.random.default_rng(5)
+        dm = (torch.from_numpy((rng.random((8, 512)) > 0.4).astype(np.float32) / 0.6),
+              torch.from_numpy((rng.random((8, 256)) > 0.4).astype(np.float32) / 0.6))
+        outs = []
+        for prec in (torch.float32, torch.bfloat16):
+            m.load_state_dict(sd)
+            m.precision, m._wc = prec, None
+            m.fps_start = (torch.from_numpy(s8).cuda(), torch.from_numpy(t8).cuda())
+            m.dropout_masks = dm
+            outs.append(m(torch.from_numpy(pc8).cuda()).cpu())
+        rel = ((outs[0] - outs[1]).norm() / outs[0].norm()).item()
+        assert rel < 0.2, rel              # three BatchNorm'd levels + two batch-of-8 BatchNorm1d layers on bf16 operands
+        return
+    out = m(torch.from_numpy(pc_np).cuda())
+    for _ in range(3):                                   # later calls replay the hipGraph: same result
+        m.load_state_dict(sd) if mode == "train" else None
+        again = m(torch.from_numpy(pc_np).cuda())
+    ref = torch.from_numpy(g[mode])
+    err = (out.cpu() - ref).abs().max().item()
+    assert err < tol * max(ref.abs().max().item(), 0.05), err
+    assert (again.cpu() - ref).abs().max().item() < tol * max(ref.abs().max().item(), 0.05)
+    if mode == "train":
+        m.load_state_dict(sd)
+        m(torch.from_numpy(pc_np).cuda())
+        msd = m.state_dict()
+        for k in ("sa1.mlp_bns.2.running_var", "sa2.mlp_bns.0.running_mean", "sa3.mlp_bns.2.running_var"):
+            r = torch.from_numpy(g["stat_" + k])
+            rtol = 1e-4 if precision == torch.float32 else 3e-2
+            assert (msd[k].cpu() - r).abs().max().item() < rtol * max(1.0, r.abs().max().item()), k
+
+
 def test_ulip_pn_msg_train_step_runs_and_only_prompt_trains():
     from ppt_amd.models import ULIP_models as M
     from ppt_amd.train import Trainer

@@ -143,6 +143,24 @@ def test_pointnet2_msg_oracle_vs_golden():
         assert np.abs(ns[k].numpy() - g["stat_" + k]).max() < 1e-4 * max(1.0, np.abs(g["stat_" + k]).max())
 
 
+def test_pointnet2_ssg_oracle_vs_golden():
+    """N4: Pointnet2_Ssg (pointnet2.py:6-38) restated in the oracle vs the output of the reference module."""
+    g = np.load(os.path.join(G, "g_pn2ssg.npz"))
+    sd = W.synth_state_dict(W.pointnet2_ssg_spec(prefix=""), seed=0)
+    pc, s1 = W.synth_clouds(2, 1024, seed=41)
+    assert np.array_equal(s1, g["start1"])
+    dm = (torch.from_numpy(g["drop1"]), torch.from_numpy(g["drop2"]))
+    with torch.no_grad():
+        ev = O.pointnet2_ssg(sd, torch.from_numpy(pc), (g["start1"], g["start2"]), train=False, prefix="")
+        ns = {}
+        tr = O.pointnet2_ssg(sd, torch.from_numpy(pc), (g["start1"], g["start2"]), train=True, drop_masks=dm, prefix="",
+                             new_stats=ns)
+    assert np.abs(ev.numpy() - g["eval"]).max() < 1e-6
+    assert np.abs(tr.numpy() - g["train"]).max() < 1e-3          # BatchNorm1d over a batch of 2 amplifies rounding
+    for k in ("sa1.mlp_bns.2.running_var", "sa3.mlp_bns.2.running_var"):
+        assert np.abs(ns[k].numpy() - g["stat_" + k]).max() < 1e-4 * max(1.0, np.abs(g["stat_" + k]).max())
+
+
 def test_partseg_oracle_forward_vs_golden():
     g = np.load(os.path.join(G, "g_partseg.npz"))
     tok = json.load(open(os.path.join(ROOT, "ppt_amd", "data", "classnames.json")))
