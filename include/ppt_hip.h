@@ -35,7 +35,7 @@ extern "C" {
 #define PPT_BF16 1
 
 const char *ppt_strerror(int code);
-/* ABI version of this header; bumped on any signature change. */
+/* ABI version of this header (currently 2); bumped on any signature change or added entry point. */
 int ppt_abi_version(void);
 
 /* ---- H1: farthest point sampling ---------------------------------------------------------

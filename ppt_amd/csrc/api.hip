@@ -12,4 +12,4 @@ extern "C" const char *ppt_strerror(int code)
     }
 }
 
-extern "C" int ppt_abi_version(void) { return 1; }
+extern "C" int ppt_abi_version(void) { return 2; }   // 2: + ppt_bn_finalize_ws, ppt_rows_stats_f32, ppt_bn_rows_bwd_*
