@@ -72,34 +72,41 @@ __device__ __forceinline__ float xor32_sum(float v) { float a, b; permlane32_hal
 __device__ __forceinline__ float xor32_max(float v) { float a, b; permlane32_halves(v, a, b); return fmaxf(a, b); }
 __device__ __forceinline__ float xor32_min(float v) { float a, b; permlane32_halves(v, a, b); return fminf(a, b); }
 
-#define PPT_DEFINE_WAVE_REDUCE(NAME, OP)                                        \
-    __device__ __forceinline__ uint32_t NAME(uint32_t v)                        \
-    {                                                                           \
-        v = OP(v, dpp_mov<0xB1, 0xf>(v));  /* quad_perm [1,0,3,2] */             \
-        v = OP(v, dpp_mov<0x4E, 0xf>(v));  /* quad_perm [2,3,0,1] */             \
-        v = OP(v, dpp_mov<0x141, 0xf>(v)); /* row_half_mirror     */             \
-        v = OP(v, dpp_mov<0x140, 0xf>(v)); /* row_mirror          */             \
-        v = OP(v, dpp_mov<0x142, 0xa>(v)); /* row_bcast15 -> rows 1,3 */         \
-        v = OP(v, dpp_mov<0x143, 0xc>(v)); /* row_bcast31 -> rows 2,3 */         \
-        return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);                 \
-    }
+// Full-wave reductions with the DPP modifier ON the arithmetic instruction (v_max_u32_dpp ...): one VALU op per butterfly
+// step instead of copy + DPP move + op.  Inside each row of 16 lanes: quad_perm, quad_perm, row_half_mirror, row_mirror;
+// then row_bcast15 folds row 0 into 1 and 2 into 3, row_bcast31 folds rows 0-1 into 2-3: lane 63 holds the result, which
+// v_readlane returns as a wave-uniform value.  (s_nop 1: a VALU write needs two wait states before a DPP read.)
+#define PPT_DPP_REDUCE_ASM(INSN)                                                                     \
+    "s_nop 1\n\t" INSN " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"            \
+    "s_nop 1\n\t" INSN " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"            \
+    "s_nop 1\n\t" INSN " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"                \
+    "s_nop 1\n\t" INSN " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"                     \
+    "s_nop 1\n\t" INSN " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                   \
+    "s_nop 1\n\t" INSN " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                   \
+    "s_nop 1"
 
+__device__ __forceinline__ uint32_t wave_reduce_umax(uint32_t v)
+{
+    asm volatile(PPT_DPP_REDUCE_ASM("v_max_u32_dpp") : "+v"(v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_reduce_umin(uint32_t v)
+{
+    asm volatile(PPT_DPP_REDUCE_ASM("v_min_u32_dpp") : "+v"(v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ uint32_t ppt_umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 __device__ __forceinline__ uint32_t ppt_umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
-PPT_DEFINE_WAVE_REDUCE(wave_reduce_umax, ppt_umax)
-PPT_DEFINE_WAVE_REDUCE(wave_reduce_umin, ppt_umin)
 
 __device__ __forceinline__ float wave_reduce_sum(float v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    asm volatile(PPT_DPP_REDUCE_ASM("v_add_f32_dpp") : "+v"(v));
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
 }
 __device__ __forceinline__ float wave_reduce_max(float v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
+    asm volatile(PPT_DPP_REDUCE_ASM("v_max_f32_dpp") : "+v"(v));
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
 }
 
 // ---- the reference's expanded-form squared distance ---------------------
