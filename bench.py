@@ -194,7 +194,7 @@ def main():
         blk_o = torch.empty(65536, 512, device="cuda", dtype=torch.bfloat16)
         torch.cuda.synchronize()
         prof, ops.profiler = ops.profiler, None
-        for _ in range(40):                 # keep the GPU busy so that the host runs ahead, as it does in the step
+        for _ in range(120):                # keep the GPU busy for the WHOLE calibration so that the host runs ahead
             ops.gemm(blk_a, blk_w, out=blk_o)
         ops.profiler = prof
         for _ in range(200):
@@ -203,7 +203,9 @@ def main():
             ops.profiler.end()
         torch.cuda.synchronize()
         brackets = sorted(st.elapsed_time(en) for _, st, en, _ in ops.profiler.records)
-        overhead_ms = max(0.0, brackets[len(brackets) // 2] - 0.0015)
+        # lower quartile, not the median: a bracket that the host issued late is longer than the dispatch gap, and
+        # subtracting too much would overstate the rate (the per-launch figure is cross-checked against rocprofv3)
+        overhead_ms = max(0.0, brackets[len(brackets) // 4] - 0.0015)
         ops.profiler = None
         g = summ["gemm_bf16"]
         g_ms = g["ms"] - overhead_ms * g["launches"]

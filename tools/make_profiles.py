@@ -29,10 +29,10 @@ def main():
     ap.add_argument("--round", default="r01")
     ap.add_argument("--bench", required=True)
     ap.add_argument("--trace", required=True)
-    ap.add_argument("--steps-in-trace", type=int, default=15)
+    ap.add_argument("--steps-in-trace", type=int, default=55)
     ap.add_argument("--fetch")
     ap.add_argument("--write")
-    ap.add_argument("--pmc-steps", type=int, default=5)
+    ap.add_argument("--pmc-steps", type=int, default=45)
     a = ap.parse_args()
     out = os.path.join(ROOT, "profiles")
     line = [l for l in open(a.bench).read().splitlines() if l.startswith("{")][-1]
@@ -60,7 +60,7 @@ def main():
         traffic = {
             "kernel": "bf16 GEMM family (gemm_kernel / gemm_kernel_glds / gemm_kernel_glds_h <unsigned short>)",
             "command": "PPT_HIP_GRAPHS=0 rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) --output-format csv -- "
-                       f"python3 bench.py --steps {a.pmc_steps - 2} --warmup 2 --no-cpu-baseline --no-roofline",
+                       "python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline",
             "launches_counted": int(nf), "fetch_size_kb_sum": float(f), "write_size_kb_sum": float(w),
             "correction": "gfx950: FETCH_SIZE reports 1/2 of wide coalesced reads -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact; both in KiB",
             "fetch_bytes_per_launch": 2 * f * 1024 / nf, "write_bytes_per_launch": w * 1024 / nw,
@@ -71,7 +71,7 @@ def main():
     md = [f"# profiles (round {a.round[1:].lstrip('0') or '0'})", "",
           f"`{a.round}_bench_c2.json` -- `python bench.py` (default: C2, 1 GPU, {bench['steps']} steps, {bench['warmup']} warm-up) on one MI355X.", "",
           f"`{a.round}_bench_c2_kernel_stats.csv` -- `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps "
-          f"{n - 5} --warmup 5 --no-cpu-baseline --no-roofline` on the same box ({n} steps in the trace).", "",
+          f"10 --warmup 5 --no-cpu-baseline --no-roofline` on the same box ({n} steps in the trace: 40 burn-in + 5 + 10).", "",
           f"bench: **{bench['value']} clouds/s**, {bench['ms_per_step']} ms/step; roofline (bf16 GEMM family): {roof.get('achieved')} TFLOP/s = "
           f"{100 * (roof.get('frac') or 0):.1f} % of 2.5 PFLOP/s, {roof.get('launches_per_step')} launches/step, avg launch {roof.get('avg_launch_us')} us "
           "(HIP-event brackets around every launch of an eager, un-graphed pass, minus the calibrated dispatch overhead per bracket).", "",
