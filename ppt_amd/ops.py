@@ -196,7 +196,7 @@ def layernorm_fwd(x, w, b, y_dtype, add=None, add_rows=0, write_xs=None, save_st
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, xs, w, mean, rstd, dx=None, accumulate=False, want_wgrad=False, partial_rows=256,
+def layernorm_bwd(dy, xs, w, mean, rstd, dx=None, accumulate=False, want_wgrad=False, partial_rows=None,
                   copy_dtype=None):
     """-> (dx, dw, db[, dx_copy]).  dx f32; accumulate=True adds into the given dx; copy_dtype: also
     return the final dx converted to that dtype (operand of the next GEMM)."""
@@ -207,6 +207,10 @@ def layernorm_bwd(dy, xs, w, mean, rstd, dx=None, accumulate=False, want_wgrad=F
         dx = torch.empty_like(xs)
         accumulate = False
     dwp = dbp = None
+    if partial_rows is None:
+        # one wave per partial row walks M / partial_rows rows: enough waves to fill the chip (256 partial rows left the
+        # 32 832-row LayerNorm backwards of C3 on 64 workgroups, 0.4 ms each), at most ~16 rows per wave
+        partial_rows = max(256, min(4096, (M + 15) // 16))
     if want_wgrad:
         dwp = torch.empty((partial_rows, D), dtype=torch.float32, device=xs.device)
         dbp = torch.empty((partial_rows, D), dtype=torch.float32, device=xs.device)
