@@ -56,6 +56,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(const bf16_t *__restrict
         qf[kk] = __builtin_bit_cast(bf16x8_t, v);
     }
 
+    // T = 64 n + 1 (the ViT's class token: 513): the last key would cost a ninth 64-key tile for ONE key.  It is peeled:
+    // the running (max, sum, O) state is INITIALISED from it -- m = c q.k_last, l = 1, O = v_last -- and the loop covers
+    // the remaining 64 n keys in whole, unmasked tiles.  (Same softmax, another summation order.)
+    const bool peel = !CAUSAL && T > KVT && (T % KVT) == 1;
+    const int Tk = peel ? T - 1 : T;
     uint4 sk[2], sv[2];
     auto load_tile = [&](int kt) {
 #pragma unroll
@@ -63,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(const bf16_t *__restrict
             const int cidx = threadIdx.x + 256 * i;
             const int key = kt * KVT + (cidx >> 3), ch = cidx & 7;
             sk[i] = sv[i] = make_uint4(0, 0, 0, 0);
-            if (key < T) {
+            if (key < Tk) {
                 sk[i] = *reinterpret_cast<const uint4 *>(kb + (int64_t)key * rs + ch * 8);
                 sv[i] = *reinterpret_cast<const uint4 *>(vb + (int64_t)key * rs + ch * 8);
             }
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(const bf16_t *__restrict
     };
 
     const int q_hi = min(T, (int)(blockIdx.x + 1) * QB) - 1;          // last query row of this workgroup
-    const int nkt = CAUSAL ? min((T + KVT - 1) / KVT, q_hi / KVT + 1) : (T + KVT - 1) / KVT;
+    const int nkt = CAUSAL ? min((T + KVT - 1) / KVT, q_hi / KVT + 1) : (Tk + KVT - 1) / KVT;
 
     f32x16_t ot[2];
 #pragma unroll
@@ -88,6 +93,31 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(const bf16_t *__restrict
 #pragma unroll
         for (int e = 0; e < 16; ++e) ot[i][e] = 0.f;
     float m = -INFINITY, l = 0.f;
+    if (peel) {
+        const bf16_t *kl = kb + (int64_t)(T - 1) * rs, *vl = vb + (int64_t)(T - 1) * rs;
+        float dot = 0.f;                                  // this lane's 32 of the 64 dimensions; the other half-wave has the rest
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const uint4 kv = *reinterpret_cast<const uint4 *>(kl + 16 * kk + 8 * h);
+            const uint4 qv = __builtin_bit_cast(uint4, qf[kk]);
+            const uint32_t kw[4] = {kv.x, kv.y, kv.z, kv.w}, qw[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                dot = fmaf(__uint_as_float(kw[e] << 16), __uint_as_float(qw[e] << 16), dot);
+                dot = fmaf(__uint_as_float(kw[e] & 0xFFFF0000u), __uint_as_float(qw[e] & 0xFFFF0000u), dot);
+            }
+        }
+        m = lane_xor32_sum(dot) * c;
+        l = h == 0 ? 1.0f : 0.0f;                         // (the two half-waves' sums are added at the end)
+#pragma unroll
+        for (int dtile = 0; dtile < 2; ++dtile)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const uint2 vv = *reinterpret_cast<const uint2 *>(vl + 32 * dtile + 8 * gq + 4 * h);
+                ot[dtile][4 * gq + 0] = __uint_as_float(vv.x << 16); ot[dtile][4 * gq + 1] = __uint_as_float(vv.x & 0xFFFF0000u);
+                ot[dtile][4 * gq + 2] = __uint_as_float(vv.y << 16); ot[dtile][4 * gq + 3] = __uint_as_float(vv.y & 0xFFFF0000u);
+            }
+    }
 
     // per-lane constant part of the transposed V reads: lane = 16g + 4q + p supplies row q, columns 4p..4p+3
     const int g = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
@@ -123,14 +153,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(const bf16_t *__restrict
 #pragma unroll
                 for (int sub = 0; sub < 2; ++sub)
                     st[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk][sub], qf[kk], st[sub], 0, 0, 0);
-            const bool need_mask = (kt * KVT + KVT > T) || (CAUSAL && kt * KVT + KVT - 1 > q0);
+            const bool need_mask = (kt * KVT + KVT > Tk) || (CAUSAL && kt * KVT + KVT - 1 > q0);
             if (need_mask) {
 #pragma unroll
                 for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int key = kt * KVT + 32 * sub + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        if (key >= T || (CAUSAL && key > qrow)) st[sub][e] = -INFINITY;
+                        if (key >= Tk || (CAUSAL && key > qrow)) st[sub][e] = -INFINITY;
                     }
             }
             float mx = st[0][0];
