@@ -196,6 +196,16 @@ int ppt_bn_rows_bwd_apply(const float *dy, const float *x, const float *scale, c
 int ppt_conv1_stats_max_partials(int64_t M);
 int ppt_conv1_stats_rows_per_partial(void);
 
+/* ---- the step between the towers when only the prompt trains (head_type 0) --------------------------
+ * head_logits: spc[B,E] = exp(logit_scale) * feat[B,F] @ w[F,E] (w = pc_projection as stored, ULIP_models.py:257), logits[B,C] =
+ *   spc @ (text / |text|)^T with text[C,E] the un-normalised text features (:279-281).
+ * head_ce_bwd: loss = CrossEntropyLoss(label_smoothing) with mean reduction (main_cls.py:52,196) of logits / labels[B] (int64)
+ *   and d_text[C,E] = d loss / d text (through the L2 normalisation).  fp32, fixed summation order. */
+int ppt_head_logits(const float *feat, const float *w, const float *text, const float *logit_scale, int B, int F, int E, int C,
+                    float *spc, float *logits, void *stream);
+int ppt_head_ce_bwd(const float *logits, const int64_t *labels, const float *spc, const float *text, float smoothing, int B,
+                    int E, int C, float *loss, float *d_text, void *stream);
+
 /* ---- small fused ops ---------------------------------------------------------------------------
  * pos_embed first layer + GELU (point_encoder.py:138-140): y[m][c] = gelu(w[c].p_m + b[c]), K=3. */
 int ppt_linear3_gelu(const float *pts, int64_t M, const float *w, const float *b, int C, void *y,

@@ -529,15 +529,20 @@ def text_tower_backward(sd, wc, s, dout):
     return full
 
 
-def head_loss_forward_backward(feat, wt, text_raw, logit_scale, labels, smoothing):
+def head_loss_forward_backward(feat, wt, text_raw, logit_scale, labels, smoothing, w=None):
     """The step between the towers when only the prompt trains (head_type 0): pc_embed = feat @ pc_projection
     (ULIP_models.py:257), text features L2-normalised (:279), logits = exp(logit_scale) * pc_embed @ text^T (:281),
     label-smoothed cross entropy with mean reduction (main_cls.py:52,196) -- and, in the same pass, the gradient of the
     loss w.r.t. the un-normalised text features, which is all the backward needs.  ~20 tiny launches with no autograd
     bookkeeping in between: shape-static, so the caller replays them from a hipGraph.
-    feat [B,F] f32, wt [E,F] f32 (pc_projection^T), text_raw [C,E] f32, logit_scale 0-d, labels [B] i64
+    feat [B,F] f32, wt [E,F] f32 (pc_projection^T) or w [F,E] (pc_projection), text_raw [C,E] f32, logit_scale 0-d, labels [B] i64
     -> (loss 0-d, logits [B,C], d loss / d text_raw [C,E])."""
     B, C = feat.shape[0], text_raw.shape[0]
+    if w is not None and w.dtype == torch.float32 and feat.shape[1] <= 8192 and B <= 4096 and logit_scale.dtype == torch.float32:
+        # three small kernels for the whole step (ppt_head_logits, ppt_head_ce_bwd) instead of ~30 tiny launches;
+        # w = pc_projection [F,E] as stored
+        return ops.head_loss(feat.contiguous(), w.contiguous(), text_raw.contiguous(), logit_scale.contiguous(),
+                             labels.contiguous(), smoothing)
     pc = ops.gemm(feat.contiguous(), wt, out_dtype=torch.float32)                       # [B,E]
     nrm = text_raw.norm(dim=-1, keepdim=True)
     tn = text_raw / nrm

@@ -290,10 +290,11 @@ class _HeadLossFn(torch.autograd.Function):
     def forward(ctx, model, pc_feat, text_raw, labels, smoothing):
         wt = engine._f32_cache(model._cache()).get(model.pc_projection, "wt")
         scale = model.logit_scale.detach()
+        proj = model.pc_projection.detach()
         feat, traw, lab = pc_feat.detach().float().contiguous(), text_raw.detach().float().contiguous(), labels.contiguous()
 
         def run(f, t, l):
-            return engine.head_loss_forward_backward(f, wt, t, scale, l, smoothing), None
+            return engine.head_loss_forward_backward(f, wt, t, scale, l, smoothing, w=proj), None
 
         key = ("head", tuple(feat.shape), tuple(traw.shape), float(smoothing))
         gc = model._graphs

@@ -409,3 +409,23 @@ def reduce_rows(partial, out=None, accumulate=False):
         accumulate = False
     _lib.check(_lib.lib().ppt_reduce_rows(_p(partial), P, D, _p(out), int(accumulate), _stream()), "ppt_reduce_rows")
     return out
+
+
+def head_loss(feat, w, text_raw, logit_scale, labels, smoothing):
+    """-> (loss 0-d, logits [B,C], d loss / d text_raw [C,E]): ppt_head_logits + ppt_head_ce_bwd (include/ppt_hip.h)."""
+    for t, n in ((feat, "feat"), (w, "w [F,E]"), (text_raw, "text_raw")):
+        _chk(t, torch.float32, n)
+    _chk(labels, torch.int64, "labels")
+    B, F = feat.shape
+    C, E = text_raw.shape
+    dev = feat.device
+    spc = torch.empty((B, E), dtype=torch.float32, device=dev)
+    logits = torch.empty((B, C), dtype=torch.float32, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    d_text = torch.empty((C, E), dtype=torch.float32, device=dev)
+    L = _lib.lib()
+    _lib.check(L.ppt_head_logits(_p(feat), _p(w), _p(text_raw), _p(logit_scale), B, F, E, C, _p(spc), _p(logits), _stream()),
+               "ppt_head_logits")
+    _lib.check(L.ppt_head_ce_bwd(_p(logits), _p(labels), _p(spc), _p(text_raw), float(smoothing), B, E, C, _p(loss), _p(d_text),
+                                 _stream()), "ppt_head_ce_bwd")
+    return loss, logits, d_text

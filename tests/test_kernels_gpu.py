@@ -446,6 +446,29 @@ def test_batch_norm_relu_rows_matches_torch(ops, M, C, training):
     assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked)
 
 
+@pytest.mark.parametrize("B,F,E,C", [(32, 768, 512, 40), (5, 256, 512, 15), (64, 768, 512, 50)])
+def test_head_loss_matches_autograd(ops, B, F, E, C):
+    """ppt_head_logits + ppt_head_ce_bwd vs torch: projection, normalised-text logits, CrossEntropyLoss(label_smoothing=0.2)
+    and its gradient w.r.t. the un-normalised text features (ULIP_models.py:257,279-281; main_cls.py:52,196)."""
+    torch.manual_seed(B + C)
+    feat = torch.randn(B, F).cuda(); w = (torch.randn(F, E) / math.sqrt(F)).cuda()
+    text = torch.randn(C, E).cuda().requires_grad_(True)
+    scale = torch.tensor(math.log(1 / 0.07)).cuda()
+    labels = torch.randint(0, C, (B,)).cuda()
+    loss, logits, d_text = ops.head_loss(feat, w, text.detach(), scale, labels, 0.2)
+    pc = feat.double() @ w.double()
+    tn = text.double() / text.double().norm(dim=-1, keepdim=True)
+    ref_logits = scale.double().exp() * pc @ tn.t()
+    ref_loss = torch.nn.functional.cross_entropy(ref_logits, labels, label_smoothing=0.2)
+    (g,) = torch.autograd.grad(ref_loss, text)
+    assert torch.allclose(logits.double(), ref_logits, rtol=1e-4, atol=1e-3)
+    assert abs(loss.item() - ref_loss.item()) < 1e-4 * max(1.0, abs(ref_loss.item()))
+    assert torch.allclose(d_text.double(), g.double(), rtol=1e-3, atol=1e-5 * g.abs().max().item() + 1e-8)
+    loss2, logits2, d2 = ops.head_loss(feat, w, text.detach(), scale, labels, 0.2)
+    torch.cuda.synchronize()
+    assert torch.equal(logits, logits2) and torch.equal(d_text, d2) and torch.equal(loss, loss2)
+
+
 def test_misc_ops(ops):
     rng = np.random.default_rng(31)
     x = rng.standard_normal((3, 513, 384)).astype(np.float32)
