@@ -85,40 +85,60 @@ class _PointEncoderFn(torch.autograd.Function):
     def forward(ctx, module, pc, fps_start, dp, tier, names, *params):
         sd, cache, cfg, train = module._live_state(), module._cache(), module._cfg(), module.training
         ctx.module, ctx.tier, ctx.names = module, tier, names
+        B, N = pc.shape[0], pc.shape[1]
+        drawn = fps_start is None            # the caller injected neither RNG draw: they are made here, inside the graph
+
+        def draw():
+            """the two RNG draws of the path (misc.py:59 FPS start, timm DropPath factors), on the device"""
+            return (torch.randint(0, N, (B,), dtype=torch.long, device=pc.device), module._draw_drop_path(B, pc.device))
+
+        use_graph = pc.is_cuda and module.use_hip_graphs and ops.profiler is None
         # tier 0 (everything frozen, nothing kept for a backward): ~140 launches whose arguments depend on shapes only --
         # replayed from a hipGraph after graphs.WARMUP_CALLS eager calls (ppt_amd/graphs.py; 2 us less per launch)
         if tier == 0 and module.param_gate is not None and pc.is_cuda:      # e.g. an evaluation right behind a training step
             torch.cuda.current_stream().wait_event(module.param_gate)
             module.param_gate = None
-        key = ("point_fwd", tuple(pc.shape), dp is not None, train, cache.dtype)
-        if (tier == 0 and pc.is_cuda and module.use_hip_graphs and ops.profiler is None and module._graphs.ready(key)):
+        has_dp = (train and module.drop_path_rate > 0) if drawn else dp is not None
+        key = ("point_fwd", tuple(pc.shape), has_dp, drawn, train, cache.dtype)
+        if tier == 0 and use_graph and module._graphs.ready(key):
+            ins = [pc] if drawn else [pc, fps_start] + ([dp] if dp is not None else [])
+
             def build():
-                def fn(pc_, start_, *dp_):
-                    feat_, _ = engine.point_encoder_forward(sd, "", cache, pc_, start_, dp_[0] if dp_ else None, train, 0, cfg)
+                def fn(pc_, *rest):
+                    start_, dp_ = draw() if drawn else (rest[0], rest[1] if len(rest) > 1 else None)
+                    feat_, _ = engine.point_encoder_forward(sd, "", cache, pc_, start_, dp_, train, 0, cfg)
                     return (feat_,), None
-                return graphs.GraphedCall(fn, [pc, fps_start] + ([dp] if dp is not None else []))
-            (feat,), _ = module._graphs.get(key, build)(pc, fps_start, *([dp] if dp is not None else []))
+                return graphs.GraphedCall(fn, ins)
+            (feat,), _ = module._graphs.get(key, build)(*ins)
             ctx.saved = None
             return feat.clone()
         if tier > 0 and pc.is_cuda:
             # something in the last block trains: everything in front of it is still frozen.  That prefix is replayed
             # from a hipGraph, and only the rest waits for the optimizer of the previous iteration (module.param_gate,
             # set by train.Trainer.step) -- the prefix runs ahead of it like the whole tower does for head_type 0.
-            key = ("point_prefix", tuple(pc.shape), dp is not None, train, cache.dtype)
-            if module.use_hip_graphs and ops.profiler is None and module._graphs.ready(key):
+            key = ("point_prefix", tuple(pc.shape), has_dp, drawn, train, cache.dtype)
+            if use_graph and module._graphs.ready(key):
+                ins = [pc] if drawn else [pc, fps_start] + ([dp] if dp is not None else [])
+
                 def build():
-                    def fn(pc_, start_, *dp_):
-                        return engine.point_encoder_forward(sd, "", cache, pc_, start_, dp_[0] if dp_ else None, train, 0, cfg,
-                                                            last_block=False), None
-                    return graphs.GraphedCall(fn, [pc, fps_start] + ([dp] if dp is not None else []))
-                cut, _ = module._graphs.get(key, build)(pc, fps_start, *([dp] if dp is not None else []))
+                    def fn(pc_, *rest):
+                        start_, dp_ = draw() if drawn else (rest[0], rest[1] if len(rest) > 1 else None)
+                        x2_, pos2_ = engine.point_encoder_forward(sd, "", cache, pc_, start_, dp_, train, 0, cfg, last_block=False)
+                        return (x2_, pos2_) + ((dp_,) if dp_ is not None else ()), None
+                    return graphs.GraphedCall(fn, ins)
+                outs, _ = module._graphs.get(key, build)(*ins)
+                cut, dp = (outs[0], outs[1]), (outs[2] if len(outs) > 2 else None)
             else:
+                if drawn:
+                    fps_start, dp = draw()
                 cut = engine.point_encoder_forward(sd, "", cache, pc, fps_start, dp, train, 0, cfg, last_block=False)
             gate, module.param_gate = module.param_gate, None
             if gate is not None:
                 torch.cuda.current_stream().wait_event(gate)
             feat, saved = engine.point_encoder_forward(sd, "", cache, None, None, dp, train, tier, cfg, resume=cut)
         else:
+            if drawn:
+                fps_start, dp = draw()
             feat, saved = engine.point_encoder_forward(sd, "", cache, pc, fps_start, dp, train, tier, cfg)
         ctx.saved = saved
         return feat
@@ -235,11 +255,14 @@ class PointTransformer(nn.Module):
         """pts [B,N,3] -> cat(cls, max) features [B, 2*trans_dim] (point_encoder.py:234-257)."""
         pts = pts.contiguous().float()
         B, N, _ = pts.shape
-        start = self.fps_start
-        if start is None:
-            start = torch.randint(0, N, (B,), dtype=torch.long, device=pts.device)   # misc.py:59
-        start = start.to(pts.device).contiguous()
-        dp = self._draw_drop_path(B, pts.device)
+        if self.fps_start is None and self.drop_path_factors is None:
+            start = dp = None                    # both draws happen inside _PointEncoderFn (and inside its hipGraph)
+        else:
+            start = self.fps_start
+            if start is None:
+                start = torch.randint(0, N, (B,), dtype=torch.long, device=pts.device)   # misc.py:59
+            start = start.to(pts.device).contiguous()
+            dp = self._draw_drop_path(B, pts.device)
         tier = self._tier() if torch.is_grad_enabled() else 0
         names = []
         for t in (1, 2, 3):

@@ -204,6 +204,28 @@ def test_run_ahead_training_is_identical(head_type):
             assert torch.equal(wa[n], wb[n]), n
 
 
+def test_device_rng_draws_replay_like_eager():
+    """FPS start indices and DropPath factors drawn on the device INSIDE the replayed hipGraph consume the generator
+    exactly as the eager launches do: same seed, same losses."""
+    from ppt_amd.train import Trainer
+    pc, _ = oracle_inputs()
+    label = torch.tensor([3, 17, 0, 39]).cuda()
+    runs = []
+    for hip_graphs in (False, True):
+        m, _ = build(0, torch.bfloat16)
+        m.train()
+        m.use_hip_graphs = m.point_encoder.use_hip_graphs = hip_graphs
+        m.overlap_text_tower = True
+        tr = Trainer(m, lr=3e-3, label_smoothing=0.2, distributed=False)
+        torch.manual_seed(123)
+        losses = [tr.step(pc.cuda(), label)[0] for _ in range(6)]
+        tr.finish()
+        torch.cuda.synchronize()
+        runs.append([l.item() for l in losses])
+        assert bool(m.point_encoder._graphs.entries) == hip_graphs
+    assert runs[0] == runs[1], runs
+
+
 def test_prompt_tuning_converges_on_a_fixed_batch():
     """60 iterations of the full step (two streams, hipGraph replay, fused head) on one fixed batch: the label-smoothed
     loss falls to a quarter of its start and the prompt stays finite -- the optimisation really uses the
