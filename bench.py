@@ -176,6 +176,8 @@ def main():
         # event records per launch, falls behind the GPU, so how much of the text stream happens to overlap the point
         # tower's GEMMs -- and with it their duration -- varies from pass to pass (3.0 .. 4.2 ms of GEMM time per step
         # seen on one box).  Three passes; the median one (by GEMM time) is reported.
+        # (rank 0 only: the instrumented passes must not issue collectives the other ranks never join)
+        trainer.distributed, trainer.bcast = False, None
         passes = []
         for _ in range(3):
             ops.profiler = ops.KernelProfiler()
@@ -240,6 +242,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1 or force_dist:
+        dist.barrier()                       # rank 0 spends a few seconds more (roofline passes): tear down together
         dist.destroy_process_group()
 
 
