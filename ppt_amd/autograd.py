@@ -41,8 +41,7 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.gemm(dyt, ops.transpose(wt), out_dtype=torch.float32)[:, :ctx.k]
         if ctx.needs_input_grad[1]:
-            mult = 8 if prec == torch.bfloat16 else 4
-            dw = ops.gemm(ops.transpose(dyt, pad_to=mult), ops.transpose(xt, pad_to=mult), out_dtype=torch.float32)
+            dw = ops.gemm_tn_splitk(dyt, xt)                          # rows split into slices: few output tiles, long K
             dw = dw[:, :ctx.k].reshape(ctx.wshape)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = ops.col_sums(dy)

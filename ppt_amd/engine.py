@@ -214,8 +214,9 @@ def point_encoder_forward(sd, p, wc, pc, fps_start, dp, bn_train, save_tier, cfg
 
 
 def _wgrad(dy_t, x_t):
-    """dW[N,K] = dY[M,N]^T @ X[M,K]: both operands are M-major, so transpose both and run the NT GEMM."""
-    return ops.gemm(ops.transpose(dy_t, pad_to=8), ops.transpose(x_t, pad_to=8), out_dtype=torch.float32)
+    """dW[N,K] = dY[M,N]^T @ X[M,K]: both operands are M-major, so both are transposed and the NT GEMM runs split over
+    the M rows (ops.gemm_tn_splitk: a 384 x 384 gradient over 32 832 rows is 36 tiles with 513 K slabs each otherwise)."""
+    return ops.gemm_tn_splitk(dy_t, x_t)
 
 
 def point_encoder_backward(sd, wc, s, dfeat, tier):

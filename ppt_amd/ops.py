@@ -429,3 +429,22 @@ def head_loss(feat, w, text_raw, logit_scale, labels, smoothing):
     _lib.check(L.ppt_head_ce_bwd(_p(logits), _p(labels), _p(spc), _p(text_raw), float(smoothing), B, E, C, _p(loss), _p(d_text),
                                  _stream()), "ppt_head_ce_bwd")
     return loss, logits, d_text
+
+
+def gemm_tn_splitk(x_a, x_b, min_blocks=768, max_splits=16):
+    """C[N1,N2] (f32) = x_a[M,N1]^T @ x_b[M,N2] -- a weight gradient: the reduction runs over the M rows, and the output
+    has few tiles (proj: 6 x 6), so the rows are cut into S slices that run as one batched NT GEMM over the transposed
+    operands (slice z = columns [z*Mc, (z+1)*Mc) of both) and the S fp32 partial products are folded by reduce_rows in a
+    fixed order.  S is chosen to reach `min_blocks` 64x64 workgroups."""
+    M, N1 = x_a.shape
+    N2 = x_b.shape[1]
+    tiles = ((N1 + 63) // 64) * ((N2 + 63) // 64)
+    S = max(1, min(max_splits, (min_blocks + tiles - 1) // tiles, (M + 63) // 64))
+    Mc = ((M + S - 1) // S + 63) // 64 * 64
+    at = transpose(x_a, pad_to=S * Mc)                                  # [N1, S*Mc], zero tail
+    bt = transpose(x_b, pad_to=S * Mc)
+    if S == 1:
+        return gemm(at, bt, out_dtype=torch.float32)
+    part = torch.empty((S * N1, N2), dtype=torch.float32, device=x_a.device)
+    gemm(at[:, :Mc], bt[:, :Mc], out=part, batch=S, strideA=Mc, strideB=Mc, strideC=N1 * N2)
+    return reduce_rows(part.view(S, N1 * N2)).view(N1, N2)
