@@ -126,7 +126,10 @@ class _PointEncoderFn(torch.autograd.Function):
                         x2_, pos2_ = engine.point_encoder_forward(sd, "", cache, pc_, start_, dp_, train, 0, cfg, last_block=False)
                         return (x2_, pos2_) + ((dp_,) if dp_ is not None else ()), None
                     return graphs.GraphedCall(fn, ins)
-                outs, _ = module._graphs.get(key, build)(*ins)
+                g = module._graphs.get(key, build)
+                outs, _ = g(*ins)
+                g.generation = getattr(g, "generation", 0) + 1
+                ctx.prefix_graph, ctx.prefix_generation = g, g.generation
                 cut, dp = (outs[0], outs[1]), (outs[2] if len(outs) > 2 else None)
             else:
                 if drawn:
@@ -146,6 +149,10 @@ class _PointEncoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dfeat):
         m = ctx.module
+        g = getattr(ctx, "prefix_graph", None)
+        if g is not None and g.generation != ctx.prefix_generation:
+            raise RuntimeError("the point tower's captured activations were overwritten by a later forward; set "
+                               "model.point_encoder.use_hip_graphs = False to keep several forwards alive before backward")
         grads = engine.point_encoder_backward(m._live_state(), m._cache(), ctx.saved, dfeat.contiguous().float(), ctx.tier)
         out = []
         for n in ctx.names:

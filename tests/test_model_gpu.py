@@ -204,6 +204,27 @@ def test_run_ahead_training_is_identical(head_type):
             assert torch.equal(wa[n], wb[n]), n
 
 
+def test_replayed_activations_are_guarded_against_a_second_forward():
+    """head_type 3 keeps the prefix's activations in the graph's buffers: a backward through a forward that a later
+    forward has overwritten must fail loudly (and work with use_hip_graphs = False)."""
+    m, _ = build(3, torch.bfloat16)
+    m.train()
+    pc, start = oracle_inputs()
+    m.point_encoder.fps_start = torch.from_numpy(start).cuda()
+    x = pc.cuda()
+    for _ in range(3):                                    # two eager calls, then the capture
+        m(x).sum().backward()
+    assert any(k[0] == "point_prefix" for k in m.point_encoder._graphs.entries)
+    first = m(x).sum()
+    m(x)
+    with pytest.raises(RuntimeError, match="overwritten by a later forward"):
+        first.backward()
+    m.use_hip_graphs = m.point_encoder.use_hip_graphs = False
+    first = m(x).sum()
+    m(x)
+    first.backward()
+
+
 def test_device_rng_draws_replay_like_eager():
     """FPS start indices and DropPath factors drawn on the device INSIDE the replayed hipGraph consume the generator
     exactly as the eager launches do: same seed, same losses."""
