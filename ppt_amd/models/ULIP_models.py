@@ -259,12 +259,18 @@ class _TextTowerFn(torch.autograd.Function):
 
 
 class _MatmulNT(torch.autograd.Function):
-    """a [M,K] @ b[N,K]^T in fp32 on the fp32 MFMA (tiny head products: projection, logits)."""
+    """a [M,K] @ b[N,K]^T with fp32 results.  prec = torch.float32: fp32 operands on the fp32 MFMA (the classification
+    heads: projection and logits of a few dozen rows); prec = torch.bfloat16: bf16 operands, fp32 accumulation -- the
+    per-POINT head of part segmentation (32 768 rows x 50 parts) in the bf16 performance mode, where the fp32 MFMA
+    (1/16 of the bf16 rate) cost 1.06 ms of a 14 ms step."""
 
     @staticmethod
-    def forward(ctx, a, b):
+    def forward(ctx, a, b, prec):
         a, b = a.contiguous().float(), b.contiguous().float()
         ctx.save_for_backward(a, b)
+        ctx.prec = prec if (prec == torch.bfloat16 and a.shape[1] % 8 == 0) else torch.float32
+        if ctx.prec == torch.bfloat16:
+            return ops.gemm(ops.convert(a, prec), ops.convert(b, prec), out_dtype=torch.float32)
         return ops.gemm(a, b, out_dtype=torch.float32)
 
     @staticmethod
@@ -272,13 +278,15 @@ class _MatmulNT(torch.autograd.Function):
         a, b = ctx.saved_tensors
         dc = dc.contiguous().float()
         da = db = None
+        T = ctx.prec if ctx.prec == torch.bfloat16 else torch.float32
+        mult = 8 if T == torch.bfloat16 else 4
         if ctx.needs_input_grad[0]:                      # dA[M,K] = dC[M,N] @ B[N,K]; N padded to the chunk size
             n = dc.shape[1]
-            dcp = dc if n % 4 == 0 else torch.nn.functional.pad(dc, (0, 4 - n % 4))
-            da = ops.gemm(dcp, ops.transpose(b, pad_to=4), out_dtype=torch.float32)
+            dcp = dc if n % mult == 0 else torch.nn.functional.pad(dc, (0, mult - n % mult))
+            da = ops.gemm(ops.convert(dcp, T), ops.transpose(ops.convert(b, T), pad_to=mult), out_dtype=torch.float32)
         if ctx.needs_input_grad[1]:                      # dB[N,K] = dC[M,N]^T @ A[M,K]
-            db = ops.gemm(ops.transpose(dc, pad_to=4), ops.transpose(a, pad_to=4), out_dtype=torch.float32)
-        return da, db
+            db = ops.gemm_tn_splitk(ops.convert(dc, T), ops.convert(a, T))
+        return da, db, None
 
 
 class _HeadLossFn(torch.autograd.Function):
@@ -313,8 +321,8 @@ class _HeadLossFn(torch.autograd.Function):
         return None, None, d_raw * dloss, None, None
 
 
-def matmul_nt(a, b):
-    return _MatmulNT.apply(a, b)
+def matmul_nt(a, b, prec=torch.float32):
+    return _MatmulNT.apply(a, b, prec)
 
 
 class ULIP_WITH_IMAGE(nn.Module):
@@ -425,6 +433,10 @@ class ULIP_WITH_IMAGE(nn.Module):
         return self._eot_pos
 
     # ---- reference API ------------------------------------------------------------------------
+    def _head_precision(self):
+        """fp32 head products, except the per-point head of part segmentation in the bf16 performance mode (_MatmulNT)."""
+        return self.precision if (self.task == 'partseg' and self.precision == torch.bfloat16) else torch.float32
+
     def encode_text(self, prompts, tokenized_prompts=None):
         """ULIP_models.py:203-222: prompts [C,77,W] -> [C,embed_dim]."""
         return _TextTowerFn.apply(self, prompts)
@@ -437,7 +449,7 @@ class ULIP_WITH_IMAGE(nn.Module):
             pc_feat = self.point_encoder(pc)
         wt = engine._f32_cache(self._cache()).get(self.pc_projection, "wt")     # [embed, feat]
         lead = pc_feat.shape[:-1]
-        return matmul_nt(pc_feat.reshape(-1, pc_feat.shape[-1]), wt).view(*lead, -1)
+        return matmul_nt(pc_feat.reshape(-1, pc_feat.shape[-1]), wt, self._head_precision()).view(*lead, -1)
 
     def _text_embed(self):
         # inference fast path: the text features depend only on the prompt tokens, so
@@ -477,7 +489,7 @@ class ULIP_WITH_IMAGE(nn.Module):
             text_embed = self._text_embed()
         logit_scale = self.logit_scale.exp()
         lead = pc_embed.shape[:-1]
-        logits = matmul_nt((logit_scale * pc_embed).reshape(-1, pc_embed.shape[-1]), text_embed)
+        logits = matmul_nt((logit_scale * pc_embed).reshape(-1, pc_embed.shape[-1]), text_embed, self._head_precision())
         return logits.view(*lead, -1)
 
     def forward_loss(self, pc, labels, smoothing):
