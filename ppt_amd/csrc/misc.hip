@@ -94,6 +94,17 @@ __global__ __launch_bounds__(1024) void reduce_rows_kernel(const float *__restri
     if (ty == 0 && d < D) out[d] = accumulate ? out[d] + (float)red[0][tx] : (float)red[0][tx];
 }
 
+// few partial rows, many columns (the S slices of a split weight gradient: S x (N1*N2)): one thread per column
+__global__ __launch_bounds__(256) void reduce_rows_small_kernel(const float *__restrict__ part, int P, int64_t D,
+                                                                float *__restrict__ out, int accumulate)
+{
+    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (d >= D) return;
+    double s = 0.0;
+    for (int p = 0; p < P; ++p) s += (double)part[(int64_t)p * D + d];
+    out[d] = accumulate ? out[d] + (float)s : (float)s;
+}
+
 template <typename TS>
 int convert_from(const void *src, void *dst, int dd, int64_t n, hipStream_t s)
 {
@@ -165,7 +176,12 @@ extern "C" int ppt_col_sums(const void *x, int x_dtype, int M, int D, int64_t ld
 extern "C" int ppt_reduce_rows(const float *partial, int P, int D, float *out, int accumulate, void *stream)
 {
     if (!partial || !out || P <= 0 || D <= 0) return PPT_EINVAL;
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((D + 31) / 32), dim3(1024), 0, ppt_stream(stream), partial, P, D, out, accumulate);
+    if (P <= 32)
+        hipLaunchKernelGGL(reduce_rows_small_kernel, dim3((D + 255) / 256), dim3(256), 0, ppt_stream(stream), partial, P,
+                           (int64_t)D, out, accumulate);
+    else
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((D + 31) / 32), dim3(1024), 0, ppt_stream(stream), partial, P, D, out,
+                           accumulate);
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }
