@@ -196,6 +196,13 @@ int ppt_bn_rows_bwd_apply(const float *dy, const float *x, const float *scale, c
 int ppt_conv1_stats_max_partials(int64_t M);
 int ppt_conv1_stats_rows_per_partial(void);
 
+/* ---- weight-gradient GEMM on the operands as stored: part[z][N1][N2] (fp32) = A[z-th M-slice, N1]^T @ B[z-th M-slice, N2],
+ * A [M,N1], B [M,N2] bf16 row-major (dW = dY^T X of nn.Linear / Conv1d(k=1): torch.autograd does this product with its
+ * own transposes).  n_slices cuts M so that the few output tiles fill the chip; fold the slices with ppt_reduce_rows.
+ * Needs M % (32 * n_slices) == 0 and N1, N2, lda, ldb multiples of 8. */
+int ppt_gemm_tn_bf16(const void *A, int64_t lda, const void *B, int64_t ldb, int64_t M, int N1, int N2, int n_slices, float *part,
+                     void *stream);
+
 /* ---- the step between the towers when only the prompt trains (head_type 0) --------------------------
  * head_logits: spc[B,E] = exp(logit_scale) * feat[B,F] @ w[F,E] (w = pc_projection as stored, ULIP_models.py:257), logits[B,C] =
  *   spc @ (text / |text|)^T with text[C,E] the un-normalised text features (:279-281).

@@ -439,6 +439,22 @@ def gemm_tn_splitk(x_a, x_b, min_blocks=768, max_splits=16):
     M, N1 = x_a.shape
     N2 = x_b.shape[1]
     tiles = ((N1 + 63) // 64) * ((N2 + 63) // 64)
+    if (x_a.dtype == torch.bfloat16 and x_b.dtype == torch.bfloat16 and M % 32 == 0 and N1 % 8 == 0 and N2 % 8 == 0
+            and x_a.stride(1) == 1 and x_b.stride(1) == 1 and x_a.stride(0) % 8 == 0 and x_b.stride(0) % 8 == 0):
+        # operands as stored (ppt_gemm_tn_bf16: transposing LDS reads), no transposed copies; the number of slices must
+        # divide the number of 32-row slabs
+        slabs = M // 32
+        big = ((N1 + 127) // 128) * ((N2 + 127) // 128)
+        want = max(1, min(max_splits * 2, (min_blocks + big - 1) // big, slabs))
+        S = max(d for d in range(1, want + 1) if slabs % d == 0)
+        part = torch.empty((S, N1 * N2), dtype=torch.float32, device=x_a.device)
+        if profiler is not None:
+            profiler.begin("gemm_bf16", 2.0 * M * N1 * N2)
+        _lib.check(_lib.lib().ppt_gemm_tn_bf16(_p(x_a), x_a.stride(0), _p(x_b), x_b.stride(0), M, N1, N2, S, _p(part),
+                                               _stream()), "ppt_gemm_tn_bf16")
+        if profiler is not None:
+            profiler.end()
+        return (reduce_rows(part) if S > 1 else part[0]).view(N1, N2)
     S = max(1, min(max_splits, (min_blocks + tiles - 1) // tiles, (M + 63) // 64))
     Mc = ((M + S - 1) // S + 63) // 64 * 64
     at = transpose(x_a, pad_to=S * Mc)                                  # [N1, S*Mc], zero tail

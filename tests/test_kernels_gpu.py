@@ -525,3 +525,23 @@ def test_ball_query_grouped_and_pointnet2_helpers(ops):
     x = dev(rng.standard_normal((5, N)).astype(np.float32)); mk = dev((rng.random((5, N)) > 0.5).astype(np.float32) * 2)
     yb = ops.bn_act_rows(x, sc, sh, torch.float32, mask=mk)
     assert (yb.cpu() - torch.relu(x.cpu() * sc.cpu() + sh.cpu()) * mk.cpu()).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("M,N1,N2", [(64, 64, 64), (32832, 384, 384), (32768, 1536, 384), (4096, 8, 72), (8192, 200, 136)])
+def test_gemm_tn_reads_operands_as_stored(ops, M, N1, N2):
+    """dW = dY^T X without transposed copies (ppt_gemm_tn_bf16): against fp64 on the same bf16 operands, for ragged
+    tile edges, row strides wider than the operand, and run-to-run bit reproducibility of the sliced reduction."""
+    g = torch.Generator(device="cuda").manual_seed(M + N1)
+    a_full = torch.randn(M, N1 + 8, device="cuda", generator=g).to(torch.bfloat16)
+    a = a_full[:, :N1]                                                  # lda = N1 + 8
+    b = torch.randn(M, N2, device="cuda", generator=g).to(torch.bfloat16)
+    c = ops.gemm_tn_splitk(a, b)
+    assert c.shape == (N1, N2) and c.dtype == torch.float32
+    ref = a.double().t() @ b.double()
+    tol = 2e-5 * float(M) ** 0.5 * 4 + 1e-6
+    assert (c.double() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item() / float(M) ** 0.5)
+    assert torch.equal(c, ops.gemm_tn_splitk(a, b))
+    # the transposed-copy path (rows not a multiple of 32) computes the same product
+    c2 = ops.gemm_tn_splitk(a[:M - 3].contiguous(), b[:M - 3])
+    ref2 = a[:M - 3].double().t() @ b[:M - 3].double()
+    assert (c2.double() - ref2).abs().max().item() <= tol * max(1.0, ref2.abs().max().item() / float(M) ** 0.5)
