@@ -438,6 +438,69 @@ def pointnet2_ssg(sd, pc, fps_starts, train=False, drop_masks=None, prefix="poin
     return x
 
 
+POINTMLP = dict(points=1024, k_neighbors=[24] * 4, reducers=[2] * 4, pre_blocks=[2] * 4, pos_blocks=[2] * 4)        # pointMLP.py:359-363
+POINTMLP_ELITE = dict(points=1024, k_neighbors=[24] * 4, reducers=[2] * 4, pre_blocks=[1, 1, 2, 1], pos_blocks=[1, 1, 2, 1])  # :366-370
+
+
+def _res_block(sd, p, x, train, new_stats):
+    """ConvBNReLURes1D.forward (pointMLP.py:188-221, groups=1, bias=False): act(net2(net1(x)) + x) on rows [R, C]."""
+    w1, w2 = sd[p + "net1.0.weight"], sd[p + "net2.0.weight"]
+    h = torch.relu(batch_norm_rows(linear(x, w1.reshape(w1.shape[0], -1)), sd, p + "net1.1.", train, new_stats=new_stats))
+    z = batch_norm_rows(linear(h, w2.reshape(w2.shape[0], -1)), sd, p + "net2.1.", train, new_stats=new_stats)
+    return torch.relu(z + x)
+
+
+def pointmlp(sd, pc, fps_starts, train=False, drop_masks=None, prefix="point_encoder.", new_stats=None, cfg=None):
+    """Model.forward of pointMLP() / pointMLPElite() (pointMLP.py:320-334) -> [B,256]; widths come from the weights.  pc [B,N,3]; fps_starts = the four start indices
+    furthest_point_sample draws (:77, one [B] vector per stage); drop_masks = (m1 [B,512], m2 [B,256]) multiplicative
+    Dropout(0.5) factors of the classifier (:307-316) or None."""
+    xyz = np.ascontiguousarray(pc.detach().numpy(), np.float32)
+    B, N, _ = xyz.shape
+    w = sd[prefix + "embedding.net.0.weight"]
+    x = torch.relu(batch_norm_rows(linear(torch.from_numpy(xyz).reshape(B * N, 3), w.reshape(w.shape[0], -1)), sd,
+                                   prefix + "embedding.net.1.", train, new_stats=new_stats)).reshape(B, N, -1)   # :324
+    cfg = cfg or POINTMLP
+    anchors = cfg["points"]
+    bi = torch.arange(B)[:, None]
+    for i in range(len(cfg["reducers"])):
+        anchors //= cfg["reducers"][i]
+        S, k = anchors, cfg["k_neighbors"][i]
+        # LocalGrouper.forward (:152-181), normalize="anchor", use_xyz=False
+        cidx = fps(xyz, S, np.asarray(fps_starts[i]))                                    # :157
+        new_xyz = np.take_along_axis(xyz, cidx[:, :, None], axis=1)                      # :158
+        anchor = x[bi, torch.from_numpy(cidx)]                                           # :159 [B,S,d]
+        # knn_point (:109-121): topk of the matmul-form distances; the set of k neighbours is all that matters below
+        d2 = torch.from_numpy(square_distance(new_xyz, xyz))
+        nidx = torch.topk(d2, k, dim=-1, largest=False)[1]                               # [B,S,k]
+        grouped = x[bi[:, :, None], nidx]                                                # :163 [B,S,k,d]
+        diff = grouped - anchor[:, :, None, :]                                           # :170-173 mean = anchor
+        std = torch.std(diff.reshape(B, -1), dim=-1, keepdim=True)[:, :, None, None]     # :174 one scalar per cloud
+        g = diff / (std + 1e-5)                                                          # :175
+        g = sd[f"{prefix}local_grouper_list.{i}.affine_alpha"] * g + sd[f"{prefix}local_grouper_list.{i}.affine_beta"]
+        g = torch.cat([g, anchor[:, :, None, :].expand(-1, -1, k, -1)], dim=-1)          # :178 [B,S,k,2d]
+        # PreExtraction.forward (:243-253): rows (b, s, k)
+        pp = f"{prefix}pre_blocks_list.{i}."
+        wt = sd[pp + "transfer.net.0.weight"]
+        y = torch.relu(batch_norm_rows(linear(g.reshape(B * S * k, -1), wt.reshape(wt.shape[0], -1)), sd,
+                                       pp + "transfer.net.1.", train, new_stats=new_stats))
+        for j in range(cfg["pre_blocks"][i]):
+            y = _res_block(sd, f"{pp}operation.{j}.", y, train, new_stats)
+        y = y.reshape(B * S, k, -1).max(dim=1)[0]                                        # :251 adaptive_max_pool1d
+        # PosExtraction.forward (:272-273): rows (b, s)
+        for j in range(cfg["pos_blocks"][i]):
+            y = _res_block(sd, f"{prefix}pos_blocks_list.{i}.operation.{j}.", y, train, new_stats)
+        x, xyz = y.reshape(B, S, -1), np.ascontiguousarray(new_xyz)
+    f = x.max(dim=1)[0]                                                                  # :332 [B,1024]
+    c = prefix + "classifier."
+    f = torch.relu(batch_norm_rows(linear(f, sd[c + "0.weight"], sd[c + "0.bias"]), sd, c + "1.", train, new_stats=new_stats))
+    if drop_masks is not None:
+        f = f * drop_masks[0]
+    f = torch.relu(batch_norm_rows(linear(f, sd[c + "4.weight"], sd[c + "4.bias"]), sd, c + "5.", train, new_stats=new_stats))
+    if drop_masks is not None:
+        f = f * drop_masks[1]
+    return f
+
+
 # ------------------------------------------------------------------------------------------------
 # text branch
 # ------------------------------------------------------------------------------------------------

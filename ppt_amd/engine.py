@@ -55,6 +55,17 @@ class WeightCache:
         self._c[key] = (t, t._version, out)
         return out
 
+    def derived(self, key, tensors, fn):
+        """A value computed from several parameters (folded weights ...): rebuilt when any of them changed."""
+        stamp = tuple((id(t), t._version) for t in tensors)
+        ent = self._c.get(("derived", key))
+        if ent is not None and ent[0] == stamp:
+            return ent[2]
+        with torch.no_grad():
+            out = fn()
+        self._c[("derived", key)] = (stamp, tensors, out)
+        return out
+
 
 def _bn_params(sd, p):
     return (sd[p + "weight"], sd[p + "bias"], sd[p + "running_mean"], sd[p + "running_var"],
@@ -429,6 +440,108 @@ def pointnet2_ssg_forward(sd, p, wc, pc, fps_starts, train, drop_masks, update_r
         br = [(cfg["radius"], cfg["nsample"], p + name + "mlp_convs.", p + name + "mlp_bns.")]
         xyz, feats = _sa_level(sd, br, wc, cfg["npoint"], xyz.contiguous(), feats, start, train, update_running, xyz_first=True)
     return _pn2_tail(sd, p, wc, xyz, feats, train, drop_masks, update_running)
+
+
+POINTMLP = dict(points=1024, k_neighbors=[24] * 4, reducers=[2] * 4, pre_blocks=[2] * 4, pos_blocks=[2] * 4)   # pointMLP.py:359-363
+
+
+def _conv_bn(sd, wc, x, wkey, bnp, train, upd, out_dtype, a_affine=None):
+    """Conv1d(k=1, bias=False) over rows + the folded BatchNorm1d affine of its output: (y [M,C], scale, shift).
+    a_affine = (scale, shift): the input is the raw output of the previous conv, BN + ReLU applied while it is loaded."""
+    M = x.shape[0]
+    w = wc.get(sd[wkey])
+    st = _stats_bufs(M, w.shape[0], x.device, train)
+    kw = dict(a_mode=A_AFFINE_RELU, a_scale=a_affine[0], a_shift=a_affine[1]) if a_affine is not None else {}
+    y = ops.gemm(x, w, out_dtype=out_dtype, col_stats=st, **kw)
+    sc, sh = _bn_affine(sd, bnp, train, st, 32, M, upd)
+    return y, sc, sh
+
+
+def _mlp_res_block(sd, wc, p, x, train, upd, pool=1):
+    """ConvBNReLURes1D.forward (pointMLP.py:188-221; groups=1): relu(BN(conv2(relu(BN(conv1(x))))) + x) on rows [M,C];
+    pool > 1 also takes the max over each `pool` consecutive rows (:251, :332)."""
+    T = wc.dtype
+    c1, sc1, sh1 = _conv_bn(sd, wc, x, p + "net1.0.weight", p + "net1.1.", train, upd, T)
+    c2, sc2, sh2 = _conv_bn(sd, wc, c1, p + "net2.0.weight", p + "net2.1.", train, upd, T, a_affine=(sc1, sh1))
+    return ops.bn_res_act_rows(c2, x, sc2, sh2, T, pool)
+
+
+def pointmlp_forward(sd, p, wc, pc, fps_starts, train, drop_masks, update_running=True, cfg=None):
+    """Model.forward of pointMLP() / pointMLPElite() (pointMLP.py:320-334): pc [B,N,3] -> [B,256] fp32.
+    fps_starts = one start vector [B] per stage (furthest_point_sample's randint, :77); drop_masks = (m1 [B,512],
+    m2 [B,256]) or None.  Rows are (cloud, point) / (cloud, group, neighbour) throughout, channels last.
+
+    LocalGrouper (:152-181, normalize="anchor", use_xyz=False) followed by the transfer conv (:243-247) is linear in the
+    gathered features: with r_b = 1 / (std_b + 1e-5) and W = [Wa | Wb] the transfer weight,
+        W.[alpha*(x_j - a)*r_b + beta | a] = r_b * (Wa*alpha).x_j + (Wa.beta + Wb.a - r_b * (Wa*alpha).a)
+    so the conv runs once per SOURCE point (N rows instead of S*k = 12 N) and ppt_gather_add forms the rows."""
+    cfg = cfg or POINTMLP
+    T = wc.dtype
+    B, N, _ = pc.shape
+    dev = pc.device
+    upd = update_running
+    # embedding (:324): Conv1d(3, E, bias=False) + BN + ReLU, evaluated in the A-prologue of a GEMM against the identity
+    w_e = wc.get(sd[p + "embedding.net.0.weight"], "f32")
+    E = w_e.shape[0]
+    b_e = torch.zeros((E,), dtype=torch.float32, device=dev)
+    pts = pc.reshape(B * N, 3)
+    part, rpp = None, 0
+    if train:
+        ps, pq, rpp = ops.conv1_stats(pts, w_e, b_e)
+        part = (ps, pq)
+    sc, sh = _bn_affine(sd, p + "embedding.net.1.", train, part, rpp, B * N, upd)
+    x = ops.gemm(None, wc.derived(("eye", E), (), lambda: torch.eye(E, dtype=T, device=dev)), out_dtype=T, a_mode=A_CONV1,
+                 pts=pts, w1=w_e, b1=b_e, a_scale=sc, a_shift=sh)
+    xyz = pc
+    S = cfg["points"]
+    n_stage = len(cfg["reducers"])
+    for i in range(n_stage):
+        S //= cfg["reducers"][i]
+        k = cfg["k_neighbors"][i]
+        d = x.shape[1]
+        cidx, new_xyz = ops.fps(xyz, S, fps_starts[i])
+        nidx, _ = ops.knn_group(xyz, new_xyz, k, want_idx=True, want_nbhd=False)
+        # per-cloud std of the anchor-centred neighbour features (:174), unbiased, from per-group (sum, sumsq) in fp64
+        st = ops.group_anchor_stats(x, nidx, cidx, N).double().sum(1)
+        n = float(S * k * d)
+        var = ((st[:, 1] - st[:, 0] * st[:, 0] / n) / (n - 1.0)).clamp_min(0.0)
+        r = (1.0 / (var.sqrt() + 1e-5)).float()
+        pp = f"{p}pre_blocks_list.{i}."
+        g = f"{p}local_grouper_list.{i}."
+        wt, alpha, beta = sd[pp + "transfer.net.0.weight"], sd[g + "affine_alpha"], sd[g + "affine_beta"]
+        C = wt.shape[0]
+
+        def fold(wt=wt, alpha=alpha, beta=beta, d=d):
+            w2 = wt.detach().reshape(wt.shape[0], -1).float()
+            wa = w2[:, :d] * alpha.detach().reshape(1, d)
+            return ops.convert(torch.cat([wa, w2[:, d:]], 0).contiguous(), T), (w2[:, :d] @ beta.detach().reshape(d)).contiguous()
+        wcat, c0 = wc.derived(("pointmlp_transfer", i), (wt, alpha, beta), fold)
+        PQ = ops.gemm(x, wcat, out_dtype=torch.float32)                          # [B*N, 2C]: (Wa*alpha).x | Wb.x
+        P = (PQ[:, :C].reshape(B, N, C) * r.view(B, 1, 1)).reshape(B * N, C)
+        a = (torch.arange(B, device=dev).view(B, 1) * N + cidx).view(-1)
+        Q = (c0.view(1, C) + PQ[:, C:][a] - P[a]).contiguous()
+        M = B * S * k
+        y0, part0 = ops.gather_add(P, Q, nidx, N, torch.float32, want_stats=train)
+        sc0, sh0 = _bn_affine(sd, pp + "transfer.net.1.", train, part0, 32, M, upd)
+        y = ops.bn_act_rows(y0, sc0, sh0, T)
+        nb = cfg["pre_blocks"][i]
+        for j in range(nb):                                                      # PreExtraction (:248-252)
+            y = _mlp_res_block(sd, wc, f"{pp}operation.{j}.", y, train, upd, pool=k if j == nb - 1 else 1)
+        nb = cfg["pos_blocks"][i]
+        for j in range(nb):                                                      # PosExtraction (:272-273), max of :332
+            y = _mlp_res_block(sd, wc, f"{p}pos_blocks_list.{i}.operation.{j}.", y, train, upd,
+                               pool=S if (i == n_stage - 1 and j == nb - 1) else 1)
+        x, xyz, N = y, new_xyz, S
+    # classifier (:307-316): Linear -> BatchNorm1d over the batch -> ReLU -> Dropout(0.5), twice
+    c = p + "classifier."
+    for fc, bn, mask in (("0.", "1.", 0), ("4.", "5.", 1)):
+        w = wc.get(sd[c + fc + "weight"])
+        st = _stats_bufs(B, w.shape[0], dev, train)
+        h = ops.gemm(x, w, out_dtype=torch.float32, bias=sd[c + fc + "bias"], col_stats=st)
+        sc, sh = _bn_affine(sd, c + bn, train, st, 32, B, upd)
+        last = fc == "4."
+        x = ops.bn_act_rows(h, sc, sh, torch.float32 if last else T, mask=drop_masks[mask] if drop_masks is not None else None)
+    return x
 
 
 # =================================================================================================

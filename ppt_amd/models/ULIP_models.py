@@ -615,6 +615,21 @@ def ULIP_PN_SSG(args):
     return model
 
 
+def ULIP_PN_MLP(args):
+    """ULIP_models.py:394-441: PointMLP point encoder (pc_feat_dims 256); everything except
+    `prompt_learner.learnable_tokens` is frozen."""
+    from .pointmlp.pointMLP import pointMLP
+    point_encoder = pointMLP()
+    model = ULIP_WITH_IMAGE(embed_dim=512, point_encoder=point_encoder, context_length=77, vocab_size=49408,
+                            classnames=args.classnames, template_init=args.template_init,
+                            class_name_position=args.class_name_position,
+                            num_learnable_prompt_tokens=args.num_learnable_prompt_tokens, transformer_width=512,
+                            transformer_heads=8, transformer_layers=12, pc_feat_dims=256, device=args.gpu, task=args.task)
+    if not getattr(args, "evaluate_3d", False):
+        _load_and_freeze(model, args, './data/pretrained_models/pointmlp.pt', set())
+    return model
+
+
 def ULIP_PointBERT(args):
     """ULIP_models.py:443-512.  args: classnames, template_init, class_name_position,
     num_learnable_prompt_tokens, gpu, task, head_type, evaluate_3d, ulip2."""

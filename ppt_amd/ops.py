@@ -351,6 +351,28 @@ def bn_act_rows(x, scale, shift, y_dtype, mask=None):
     return y
 
 
+def group_anchor_stats(x, idx, anchor, Nsrc):
+    """x [B*Nsrc, D] (f32 | bf16), idx [B,S,K], anchor [B,S] -> [B,S,2] f32: (sum, sum of squares) of x[idx] - x[anchor] per
+    group (the statistic behind LocalGrouper's per-cloud std, pointMLP.py:170-175)."""
+    _chk(x, None, "x"); _chk(idx, torch.int64, "idx"); _chk(anchor, torch.int64, "anchor")
+    B, S, K = idx.shape
+    out = torch.empty((B, S, 2), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().ppt_group_anchor_stats(_p(x), dtype_code(x), _p(idx), _p(anchor), B, Nsrc, S, K, x.shape[1], _p(out),
+                                                 _stream()), "ppt_group_anchor_stats")
+    return out
+
+
+def bn_res_act_rows(x, res, scale, shift, y_dtype, pool=1):
+    """relu(scale * x + shift + res) over rows [M,C]; pool > 1 returns the max over each `pool` consecutive rows."""
+    _chk(x, None, "x"); _chk(res, None, "res")
+    M, C = x.shape
+    assert res.shape == x.shape and M % pool == 0
+    y = torch.empty((M // pool, C), dtype=y_dtype, device=x.device)
+    _lib.check(_lib.lib().ppt_bn_res_act_rows(_p(x), dtype_code(x), _p(res), dtype_code(res), M, C, pool, _p(scale), _p(shift),
+                                              _p(y), dtype_code(y), _stream()), "ppt_bn_res_act_rows")
+    return y
+
+
 def linear3_gelu(pts, w, b, y_dtype):
     _chk(pts, torch.float32, "pts")
     M, C = pts.shape[0], w.shape[0]

@@ -146,6 +146,40 @@ def pointnet2_ssg_spec(prefix="point_encoder."):
     return s
 
 
+POINTMLP = dict(   # models/pointmlp/pointMLP.py:359-363 pointMLP(): the encoder ULIP_PN_MLP builds (ULIP_models.py:399-400)
+    points=1024, embed_dim=64, k_neighbors=24, stages=4, pre_blocks=2, pos_blocks=2)
+
+
+def pointmlp_spec(prefix="point_encoder."):
+    """(key, shape) list of pointMLP().state_dict() (models/pointmlp/pointMLP.py:261-318; bias=False convs,
+    normalize="anchor", use_xyz=False)."""
+    def bn(p, c):
+        return [(p + k, (c,)) for k in ("weight", "bias", "running_mean", "running_var")] + [(p + "num_batches_tracked", ())]
+
+    def res(p, c):
+        return [(p + "net1.0.weight", (c, c, 1))] + bn(p + "net1.1.", c) + [(p + "net2.0.weight", (c, c, 1))] + bn(p + "net2.1.", c)
+    s = [(prefix + "embedding.net.0.weight", (POINTMLP["embed_dim"], 3, 1))] + bn(prefix + "embedding.net.1.", POINTMLP["embed_dim"])
+    groupers, pres, poss = [], [], []
+    d = POINTMLP["embed_dim"]
+    for i in range(POINTMLP["stages"]):
+        out = 2 * d
+        groupers += [(f"{prefix}local_grouper_list.{i}.affine_alpha", (1, 1, 1, d)), (f"{prefix}local_grouper_list.{i}.affine_beta", (1, 1, 1, d))]
+        pres += [(f"{prefix}pre_blocks_list.{i}.transfer.net.0.weight", (out, 2 * d, 1))] + bn(f"{prefix}pre_blocks_list.{i}.transfer.net.1.", out)
+        for j in range(POINTMLP["pre_blocks"]):
+            pres += res(f"{prefix}pre_blocks_list.{i}.operation.{j}.", out)
+        for j in range(POINTMLP["pos_blocks"]):
+            poss += res(f"{prefix}pos_blocks_list.{i}.operation.{j}.", out)
+        d = out
+    s += groupers + pres + poss
+    s += [(prefix + "classifier.0.weight", (512, d)), (prefix + "classifier.0.bias", (512,))] + bn(prefix + "classifier.1.", 512)
+    s += [(prefix + "classifier.4.weight", (256, 512)), (prefix + "classifier.4.bias", (256,))] + bn(prefix + "classifier.5.", 256)
+    return s
+
+
+def ulip_pn_mlp_state_dict(seed=0, with_token_embedding=False, as_torch=True):
+    return synth_state_dict(ulip_spec(256, with_token_embedding) + pointmlp_spec(), seed, as_torch)
+
+
 def ulip_pn2_ssg_state_dict(seed=0, with_token_embedding=False, as_torch=True):
     return synth_state_dict(ulip_spec(256, with_token_embedding) + pointnet2_ssg_spec(), seed, as_torch)
 
@@ -172,7 +206,12 @@ def synth_tensor(key, shape, seed=0):
         return (0.1 * r.standard_normal(shape)).astype(np.float32)
     if leaf == "running_var":
         return (1.0 + 0.5 * r.random(shape)).astype(np.float32)
-    is_norm = any(t in key for t in (".norm1.", ".norm2.", ".norm.", ".ln_1.", ".ln_2.", "ln_final.",
+    if leaf == "affine_alpha":                 # pointMLP.py:149 (ones at init): a per-channel scale around 1
+        return (1.0 + 0.1 * r.standard_normal(shape)).astype(np.float32)
+    if leaf == "affine_beta":
+        return (0.02 * r.standard_normal(shape)).astype(np.float32)
+    is_norm = any(t in key for t in (".net.1.", ".net1.1.", ".net2.1.", "classifier.1.", "classifier.5.")) \
+        or any(t in key for t in (".norm1.", ".norm2.", ".norm.", ".ln_1.", ".ln_2.", "ln_final.",
                                      "first_conv.1.", "second_conv.1.", "mlp_bns", ".bn", "bn_blocks",
                                      "layer1.1.", "layer2.1."))
     if is_norm and leaf == "weight":

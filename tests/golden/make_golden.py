@@ -365,6 +365,58 @@ def gen_pointnet2_ssg():
     np.savez_compressed(os.path.join(HERE, "g_pn2ssg.npz"), **out)
 
 
+def gen_pointmlp():
+    """G-PMLP: pointMLP() forward (eval and train BN) vs the reference module (pointMLP.py:359-363, 320-334)."""
+    sd_all = W.synth_state_dict(W.pointmlp_spec(prefix=""), seed=0)
+    B, N = 2, 1024
+    pc_np, s1 = W.synth_clouds(B, N, seed=61)
+    starts_np = [s1] + [W.synth_clouds(B, n, seed=62 + i)[1] for i, n in enumerate((512, 256, 128))]
+    pc = torch.from_numpy(pc_np)
+    rng = np.random.default_rng(23)
+    dm = (torch.from_numpy((rng.random((B, 512)) > 0.5).astype(np.float32) / 0.5),
+          torch.from_numpy((rng.random((B, 256)) > 0.5).astype(np.float32) / 0.5))
+    with R.reference_context():
+        from models.pointmlp.pointMLP import pointMLP
+        m = pointMLP()
+    out = {}
+    for mode in ("eval", "train"):
+        m.load_state_dict(sd_all)
+        m.train(mode == "train")
+        if mode == "train":
+            m.classifier[3].forward = lambda x: x * dm[0]
+            m.classifier[7].forward = lambda x: x * dm[1]
+        starts = [torch.from_numpy(s) for s in starts_np]
+        orig = torch.randint
+        torch.randint = lambda *a, **k: starts.pop(0)
+        try:
+            with torch.no_grad():
+                ref = m(pc.permute(0, 2, 1).contiguous().permute(0, 2, 1))       # Model.forward takes [B,N,3] (:321-322)
+        finally:
+            torch.randint = orig
+        assert not starts
+        ns = {}
+        with torch.no_grad():
+            ora = O.pointmlp(sd_all, pc, starts_np, train=(mode == "train"), drop_masks=dm if mode == "train" else None,
+                             prefix="", new_stats=ns)
+        err = (ref - ora).abs().max().item()
+        print(f"pointMLP {mode}: max|ref-oracle| = {err:.3e} (|ref|max {ref.abs().max():.3f})")
+        assert err < 1e-3
+        out[mode] = ref.numpy()
+        if mode == "train":
+            msd = m.state_dict()
+            for k, v in ns.items():
+                e = (msd[k].float() - v.float()).abs().max().item()
+                assert e < 1e-4 * max(1.0, msd[k].float().abs().max().item()), (k, e)
+            for k in ("embedding.net.1.running_var", "pre_blocks_list.0.transfer.net.1.running_mean",
+                      "pre_blocks_list.2.operation.1.net2.1.running_var", "pos_blocks_list.3.operation.0.net1.1.running_mean",
+                      "classifier.5.running_mean"):
+                out["stat_" + k] = msd[k].numpy()
+    out["drop1"], out["drop2"] = dm[0].numpy(), dm[1].numpy()
+    for i, s in enumerate(starts_np):
+        out[f"start{i + 1}"] = s
+    np.savez_compressed(os.path.join(HERE, "g_pointmlp.npz"), **out)
+
+
 def gen_partseg(tok):
     """G8: ULIP_PointBERT_partseg train step (main_partseg.py:204-215) on B=2 x 2048 points with duplicates."""
     import argparse
@@ -453,11 +505,14 @@ if __name__ == "__main__":
     import sys
     if sys.argv[1:] == ["pn2ssg"]:              # one fixture only
         gen_pointnet2_ssg()
+    elif sys.argv[1:] == ["pointmlp"]:
+        gen_pointmlp()
     else:
         tok = gen_tokens()
         gen_index()
         gen_encoder_and_step(tok)
         gen_pointnet2_msg()
         gen_pointnet2_ssg()
+        gen_pointmlp()
         gen_partseg(tok)
     print("done")

@@ -411,6 +411,116 @@ def test_pointnet2_ssg_matches_golden(mode, precision, tol):
             assert (msd[k].cpu() - r).abs().max().item() < rtol * max(1.0, r.abs().max().item()), k
 
 
+@pytest.mark.parametrize("precision,tol", [(torch.float32, 2e-3), (torch.bfloat16, 6e-2)])
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_pointmlp_matches_golden(mode, precision, tol):
+    """N4: pointMLP() forward vs the reference output captured in g_pointmlp.npz (FPS starts and Dropout masks injected)."""
+    from ppt_amd.models.pointmlp.pointMLP import pointMLP
+    g = np.load(os.path.join(G, "g_pointmlp.npz"))
+    pc_np, s1 = W.synth_clouds(2, 1024, seed=61)
+    assert np.array_equal(s1, g["start1"])
+    m = pointMLP()
+    sd = W.synth_state_dict(W.pointmlp_spec(prefix=""), seed=0)
+    m.load_state_dict(sd)
+    m.cuda()
+    m.precision = precision
+    m.train(mode == "train")
+    m.fps_start = tuple(torch.from_numpy(g[f"start{i}"]).cuda() for i in (1, 2, 3, 4))
+    if mode == "train":
+        m.dropout_masks = (torch.from_numpy(g["drop1"]), torch.from_numpy(g["drop2"]))
+    if mode == "train" and precision == torch.bfloat16:
+        # Synthetic uniform clouds give nearly the same global feature for every sample, so the classifier's BatchNorm1d
+        # over the batch divides by a variance that is mostly rounding noise: the OUTPUT of a bf16 run is ill-conditioned
+        # by construction.  What is well-conditioned, and covers every layer, is the batch statistics each BatchNorm
+        # folds into its running buffers: compare those with the fp32 parity path on a batch of 8.
+        pc8, s8 = W.synth_clouds(8, 1024, seed=63)
+        st8 = [s8] + [W.synth_clouds(8, n, seed=64 + i)[1] for i, n in enumerate((512, 256, 128))]
+        stats = []
+        for prec in (torch.float32, torch.bfloat16):
+            m.load_state_dict(sd)
+            m.precision, m._wc = prec, None
+            m.fps_start = tuple(torch.from_numpy(s).cuda() for s in st8)
+            m.dropout_masks = (torch.ones(8, 512), torch.ones(8, 256))
+            out = m(torch.from_numpy(pc8).cuda())
+            assert torch.isfinite(out).all()
+            stats.append({k: v.cpu().clone() for k, v in m.state_dict().items() if "running_" in k})
+        for k in stats[0]:
+            if k.startswith("classifier.") and not k.endswith("1.running_mean"):
+                continue
+            moved = (stats[0][k] - sd[k]).norm().item()
+            assert (stats[0][k] - stats[1][k]).norm().item() < 0.12 * moved, k
+        return
+    out = m(torch.from_numpy(pc_np).cuda())
+    for _ in range(3):                                   # later calls replay the hipGraph: same result
+        m.load_state_dict(sd) if mode == "train" else None
+        again = m(torch.from_numpy(pc_np).cuda())
+    ref = torch.from_numpy(g[mode])
+    err = (out.cpu() - ref).abs().max().item()
+    assert err < tol * max(ref.abs().max().item(), 0.05), err
+    assert (again.cpu() - ref).abs().max().item() < tol * max(ref.abs().max().item(), 0.05)
+    if mode == "train":
+        m.load_state_dict(sd)
+        m(torch.from_numpy(pc_np).cuda())
+        msd = m.state_dict()
+        for k in ("embedding.net.1.running_var", "pre_blocks_list.0.transfer.net.1.running_mean",
+                  "pre_blocks_list.2.operation.1.net2.1.running_var", "pos_blocks_list.3.operation.0.net1.1.running_mean"):
+            r = torch.from_numpy(g["stat_" + k])
+            rtol = 1e-4 if precision == torch.float32 else 3e-2
+            assert (msd[k].cpu() - r).abs().max().item() < rtol * max(1.0, r.abs().max().item()), k
+
+
+def test_pointmlp_elite_matches_oracle():
+    """pointMLPElite() (pointMLP.py:366-370: res_expansion 0.25, uneven block counts) against the oracle on the same inputs."""
+    from ppt_amd.models.pointmlp.pointMLP import pointMLPElite
+    from oracle import oracle as O
+    torch.manual_seed(3)
+    m = pointMLPElite()
+    for n, b in m.named_buffers():
+        if n.endswith("running_var"):
+            b.uniform_(0.8, 1.4)
+        elif n.endswith("running_mean"):
+            b.normal_(0, 0.1)
+    for n, p_ in m.named_parameters():
+        if p_.dim() == 1 or "affine" in n:
+            p_.data.add_(0.05 * torch.randn_like(p_))
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    B = 4
+    pc_np, s0 = W.synth_clouds(B, 1024, seed=71)
+    starts = [s0] + [W.synth_clouds(B, n, seed=72 + i)[1] for i, n in enumerate((512, 256, 128))]
+    with torch.no_grad():
+        ref = O.pointmlp(sd, torch.from_numpy(pc_np), starts, train=False, prefix="", cfg=O.POINTMLP_ELITE)
+    m.cuda().eval()
+    m.precision = torch.float32
+    m.fps_start = tuple(torch.from_numpy(s).cuda() for s in starts)
+    out = m(torch.from_numpy(pc_np).cuda()).cpu()
+    assert (out - ref).abs().max().item() < 2e-3 * max(ref.abs().max().item(), 0.05)
+
+
+def test_ulip_pn_mlp_train_step_runs_and_only_prompt_trains():
+    from ppt_amd.models import ULIP_models as M
+    from ppt_amd.train import Trainer
+    args = SimpleNamespace(classnames=M.dataset_classnames("modelnet40"), template_init='', class_name_position='middle',
+                           num_learnable_prompt_tokens=32, gpu=0, task='cls', head_type=0, evaluate_3d=False, ulip2=False)
+    m = M.ULIP_PN_MLP(args)
+    m.load_state_dict(W.ulip_pn_mlp_state_dict(seed=0), strict=False)
+    m.cuda().train()
+    tr = Trainer(m)
+    pc_np, _ = W.synth_clouds(8, 1024, seed=81)
+    pc = torch.from_numpy(pc_np).cuda()
+    label = torch.arange(8, device="cuda") % 40
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    losses = []
+    for _ in range(4):
+        loss, pred = tr.step(pc, label)
+        losses.append(loss.item())
+    tr.finish()
+    assert all(np.isfinite(losses)) and pred.shape == (8, 40)
+    after = m.state_dict()
+    changed = {k for k in before if before[k].dtype.is_floating_point and not torch.equal(before[k], after[k])
+               and "running_" not in k}
+    assert changed == {"prompt_learner.learnable_tokens"}, changed
+
+
 def test_ulip_pn_msg_train_step_runs_and_only_prompt_trains():
     from ppt_amd.models import ULIP_models as M
     from ppt_amd.train import Trainer

@@ -161,6 +161,24 @@ def test_pointnet2_ssg_oracle_vs_golden():
         assert np.abs(ns[k].numpy() - g["stat_" + k]).max() < 1e-4 * max(1.0, np.abs(g["stat_" + k]).max())
 
 
+def test_pointmlp_oracle_vs_golden():
+    """N4: pointMLP() (pointMLP.py:320-334, 359-363) restated in the oracle vs the output of the reference module."""
+    g = np.load(os.path.join(G, "g_pointmlp.npz"))
+    sd = W.synth_state_dict(W.pointmlp_spec(prefix=""), seed=0)
+    pc, s1 = W.synth_clouds(2, 1024, seed=61)
+    assert np.array_equal(s1, g["start1"])
+    starts = [g[f"start{i}"] for i in (1, 2, 3, 4)]
+    dm = (torch.from_numpy(g["drop1"]), torch.from_numpy(g["drop2"]))
+    with torch.no_grad():
+        ev = O.pointmlp(sd, torch.from_numpy(pc), starts, train=False, prefix="")
+        ns = {}
+        tr = O.pointmlp(sd, torch.from_numpy(pc), starts, train=True, drop_masks=dm, prefix="", new_stats=ns)
+    assert np.abs(ev.numpy() - g["eval"]).max() < 1e-4
+    assert np.abs(tr.numpy() - g["train"]).max() < 1e-3          # BatchNorm1d over a batch of 2 amplifies rounding
+    for k in ("embedding.net.1.running_var", "pre_blocks_list.2.operation.1.net2.1.running_var", "classifier.5.running_mean"):
+        assert np.abs(ns[k].numpy() - g["stat_" + k]).max() < 1e-4 * max(1.0, np.abs(g["stat_" + k]).max())
+
+
 def test_partseg_oracle_forward_vs_golden():
     g = np.load(os.path.join(G, "g_partseg.npz"))
     tok = json.load(open(os.path.join(ROOT, "ppt_amd", "data", "classnames.json")))

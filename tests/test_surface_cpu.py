@@ -123,6 +123,14 @@ def test_other_factories_state_dicts():
     sd = m.state_dict()
     assert set(sd) == set(spec) and all(tuple(sd[k].shape) == tuple(v) for k, v in spec.items())
     assert [n for n, p in m.named_parameters() if p.requires_grad] == ["prompt_learner.learnable_tokens"]
+    m = models.ULIP_PN_MLP(a)
+    spec = dict(W.ulip_spec(256, True) + W.pointmlp_spec())
+    sd = m.state_dict()
+    assert set(sd) == set(spec) and all(tuple(sd[k].shape) == tuple(v) for k, v in spec.items())
+    assert [n for n, p in m.named_parameters() if p.requires_grad] == ["prompt_learner.learnable_tokens"]
+    from models.pointmlp.pointMLP import pointMLP, pointMLPElite
+    assert len(pointMLP().state_dict()) == len(W.pointmlp_spec())
+    assert len(pointMLPElite().state_dict()) > 0
     from models.pointnet2.pointnet2 import Pointnet2_Msg, Pointnet2_Ssg                    # noqa: F401
     from models.pointbert.pointnet2_utils import PointNetFeaturePropagation, DGCNN_Propagation   # noqa: F401
 
