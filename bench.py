@@ -43,6 +43,8 @@ CONFIGS = {   # BASELINE.json configs[1] (headline) and configs[2] (secondary, -
                name="C3: ScanObjectNN (PB_T50_RS shape) 2048-pt PointBERT + PointAdapter (head_type=3: last block un-frozen)"),
     "C4": dict(dataset="modelnet40", batch=32, npoints=8192, head_type=0, model="ULIP_PN_MSG",
                name="C4: ModelNet40 8192-pt PointNet2-MSG encoder (ULIP_PN_MSG, frozen) + PromptLearner, 32 clouds per GPU"),
+    "MLP": dict(dataset="modelnet40", batch=32, npoints=1024, head_type=0, model="ULIP_PN_MLP",
+                name="N4: ModelNet40 1024-pt PointMLP encoder (ULIP_PN_MLP, frozen) + PromptLearner, 32 clouds per GPU"),
     "C5": dict(dataset="shapenetpart", batch=16, npoints=2048, head_type=0, model="ULIP_PointBERT_partseg", task="partseg",
                name="C5: ShapeNetPart 2048-pt part segmentation (ULIP_PointBERT_partseg: frozen PointBERT + trainable decoder "
                     "+ PromptLearner), per-point logits, 16 clouds per GPU"),
@@ -50,6 +52,7 @@ CONFIGS = {   # BASELINE.json configs[1] (headline) and configs[2] (secondary, -
 METRICS = {"C2": "point-clouds/sec fwd+bwd, PointBERT 1024-pt ModelNet40",
            "C3": "point-clouds/sec fwd+bwd, PointBERT 2048-pt ScanObjectNN + PointAdapter",
            "C4": "point-clouds/sec fwd+bwd, PointNet2-MSG 8192-pt ModelNet40",
+           "MLP": "point-clouds/sec fwd+bwd, PointMLP 1024-pt ModelNet40",
            "C5": "point-clouds/sec fwd+bwd, PointBERT part-seg 2048-pt ShapeNetPart"}
 BURN_IN_STEPS = 40               # untimed, before the --warmup steps (clock ramp, graph capture)
 PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
@@ -66,7 +69,7 @@ def build_model(dataset="modelnet40", head_type=HEAD_TYPE, precision=torch.bfloa
     with contextlib.redirect_stdout(io.StringIO()):
         m = getattr(M, model)(args)
     sd = {"ULIP_PointBERT": W.ulip_pointbert_state_dict, "ULIP_PN_MSG": W.ulip_pn2_msg_state_dict,
-          "ULIP_PointBERT_partseg": W.ulip_partseg_state_dict}[model](seed=0)
+          "ULIP_PN_MLP": W.ulip_pn_mlp_state_dict, "ULIP_PointBERT_partseg": W.ulip_partseg_state_dict}[model](seed=0)
     m.load_state_dict(sd, strict=False)
     m.prompt_learner.embedding = W.synth_prompt_embedding(len(args.classnames), seed=0)
     m.cuda()
