@@ -200,11 +200,12 @@ int ppt_conv1_stats_rows_per_partial(void);
  * ppt_group_anchor_stats: LocalGrouper normalize="anchor" (:170-175): out[(b*S+s)*2 + {0,1}] = sum, sum of squares over
  *   j < K, c < D of x[b*Nsrc + idx[b,s,j], c] - x[b*Nsrc + anchor[b,s], c]; x [B*Nsrc, D] f32 or bf16.
  * ppt_bn_res_act_rows: the tail of ConvBNReLURes1D (:220-221) y = relu(scale*x + shift + res) over rows [M, C]; pool > 1
- *   writes the max over every `pool` consecutive rows instead ([M/pool, C]: adaptive_max_pool1d of :251 and :332). */
+ *   writes the max over every `pool` consecutive rows instead ([M/pool, C]: adaptive_max_pool1d of :251 and :332).
+ *   res_scale/res_shift (both or neither): res is a raw conv output, relu(res_scale*res + res_shift) is the block input. */
 int ppt_group_anchor_stats(const void *x, int x_dtype, const int64_t *idx, const int64_t *anchor, int B, int Nsrc, int S, int K,
                            int D, float *out, void *stream);
 int ppt_bn_res_act_rows(const void *x, int x_dtype, const void *res, int res_dtype, int64_t M, int C, int pool, const float *scale,
-                        const float *shift, void *y, int y_dtype, void *stream);
+                        const float *shift, const float *res_scale, const float *res_shift, void *y, int y_dtype, void *stream);
 
 /* ---- weight-gradient GEMM on the operands as stored: part[z][N1][N2] (fp32) = A[z-th M-slice, N1]^T @ B[z-th M-slice, N2],
  * A [M,N1], B [M,N2] bf16 row-major (dW = dY^T X of nn.Linear / Conv1d(k=1): torch.autograd does this product with its

@@ -70,8 +70,8 @@ _SIGNATURES = {
                                       c_int, c_int64, c_int, c_void_p, c_void_p]),
     "ppt_bn_finalize_workspace_bytes": (ctypes.c_size_t, [c_int, c_int]),
     "ppt_group_anchor_stats": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "ppt_bn_res_act_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
-                                    c_void_p]),
+    "ppt_bn_res_act_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_int, c_void_p]),
     "ppt_gemm_tn_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ppt_head_logits": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ppt_head_ce_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p, c_void_p,

@@ -48,22 +48,85 @@ __global__ __launch_bounds__(256) void group_anchor_stats_kernel(const void *__r
     }
 }
 
-// y[r, c] = relu(scale[c] * x[r, c] + shift[c] + res[r, c]);  pool > 1: y[g, c] = max over the pool rows of group g
-__global__ void bn_res_act_rows_kernel(const void *__restrict__ x, int x_dtype, const void *__restrict__ res, int res_dtype,
-                                       int64_t out_rows, int C, int pool, const float *__restrict__ scale,
-                                       const float *__restrict__ shift, void *__restrict__ y, int y_dtype)
+// y[r, c] = relu(scale[c] * x[r, c] + shift[c] + res'[r, c]);  pool > 1: y[g, c] = max over the pool rows of group g.
+// res' = res, or relu(res_scale[c] * res[r, c] + res_shift[c]) when the block input is itself a conv output whose
+// BatchNorm + ReLU was never materialised (the transfer conv in front of the first block).
+// VEC channels per thread (8 when C % 8 == 0: 16-byte bf16 / 2 x 16-byte fp32 accesses).
+template <int VEC>
+__device__ __forceinline__ void load_vec(const void *p, int dtype, int64_t i, float (&v)[VEC])
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= out_rows * C) return;
-    const int c = (int)(i % C);
-    const int64_t r = i / C;
-    const float sc = scale[c], sh = shift[c];
-    float v = 0.f;                                                       // relu output is >= 0
-    for (int j = 0; j < pool; ++j) {
-        const int64_t e = (r * pool + j) * C + c;
-        v = fmaxf(v, fmaf(load_any(x, x_dtype, e), sc, sh) + load_any(res, res_dtype, e));
+    if constexpr (VEC == 8) {
+        if (dtype == PPT_F32) {
+            const float4 a = *reinterpret_cast<const float4 *>((const float *)p + i), b = *reinterpret_cast<const float4 *>((const float *)p + i + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+            const uint4 q = *reinterpret_cast<const uint4 *>((const bf16_t *)p + i);
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[2 * e] = __uint_as_float(w[e] << 16);
+                v[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+            }
+        }
+    } else {
+        v[0] = load_any(p, dtype, i);
     }
-    store_any(y, y_dtype, i, v);
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec(void *p, int dtype, int64_t i, const float (&v)[VEC])
+{
+    if constexpr (VEC == 8) {
+        if (dtype == PPT_F32) {
+            *reinterpret_cast<float4 *>((float *)p + i) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4 *>((float *)p + i + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+            uint4 q;
+            q.x = pack_bf16x2(v[0], v[1]);
+            q.y = pack_bf16x2(v[2], v[3]);
+            q.z = pack_bf16x2(v[4], v[5]);
+            q.w = pack_bf16x2(v[6], v[7]);
+            *reinterpret_cast<uint4 *>((bf16_t *)p + i) = q;
+        }
+    } else {
+        store_any(p, dtype, i, v[0]);
+    }
+}
+
+template <int VEC, bool RES_AFF, bool BF16IO>
+__global__ __launch_bounds__(256) void bn_res_act_rows_kernel(const void *__restrict__ x, int x_dtype, const void *__restrict__ res,
+                                                               int res_dtype, int64_t out_rows, int C, int pool,
+                                                               const float *__restrict__ scale, const float *__restrict__ shift,
+                                                               const float *__restrict__ res_scale, const float *__restrict__ res_shift,
+                                                               void *__restrict__ y, int y_dtype)
+{
+    if constexpr (BF16IO) x_dtype = res_dtype = y_dtype = PPT_BF16;      // the bf16 pipeline: no dtype branches between the loads
+    const int cv = C / VEC;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= out_rows * cv) return;
+    const int64_t r = t / cv;
+    const int c = (int)(t - r * cv) * VEC;
+    float sc[VEC], sh[VEC], rs[VEC], rh[VEC], v[VEC];
+    load_vec<VEC>(scale, PPT_F32, c, sc);                                // straight-line vector loads: no per-element branches
+    load_vec<VEC>(shift, PPT_F32, c, sh);
+    if constexpr (RES_AFF) {
+        load_vec<VEC>(res_scale, PPT_F32, c, rs);
+        load_vec<VEC>(res_shift, PPT_F32, c, rh);
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = 0.f;                            // relu output is >= 0
+    for (int j = 0; j < pool; ++j) {
+        const int64_t e0 = (r * pool + j) * C + c;
+        float xv[VEC], rv[VEC];
+        load_vec<VEC>(x, x_dtype, e0, xv);
+        load_vec<VEC>(res, res_dtype, e0, rv);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float rr = RES_AFF ? fmaxf(fmaf(rv[e], rs[e], rh[e]), 0.f) : rv[e];
+            v[e] = fmaxf(v[e], fmaf(xv[e], sc[e], sh[e]) + rr);
+        }
+    }
+    store_vec<VEC>(y, y_dtype, r * C + c, v);
 }
 
 }  // namespace
@@ -81,14 +144,28 @@ extern "C" int ppt_group_anchor_stats(const void *x, int x_dtype, const int64_t 
 }
 
 extern "C" int ppt_bn_res_act_rows(const void *x, int x_dtype, const void *res, int res_dtype, int64_t M, int C, int pool,
-                                   const float *scale, const float *shift, void *y, int y_dtype, void *stream)
+                                   const float *scale, const float *shift, const float *res_scale, const float *res_shift, void *y,
+                                   int y_dtype, void *stream)
 {
     if (!x || !res || !scale || !shift || !y || M <= 0 || C <= 0 || pool <= 0 || M % pool) return PPT_EINVAL;
+    if ((res_scale == nullptr) != (res_shift == nullptr)) return PPT_EINVAL;
     for (int d : {x_dtype, res_dtype, y_dtype})
         if (d != PPT_F32 && d != PPT_BF16) return PPT_EINVAL;
-    const int64_t n = M / pool * C;
-    hipLaunchKernelGGL(bn_res_act_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ppt_stream(stream), x, x_dtype, res,
-                       res_dtype, M / pool, C, pool, scale, shift, y, y_dtype);
+    const bool vec = C % 8 == 0 && !(((uintptr_t)x | (uintptr_t)res | (uintptr_t)y | (uintptr_t)scale | (uintptr_t)shift |
+                                      (uintptr_t)res_scale | (uintptr_t)res_shift) & 15);
+    const int64_t n = M / pool * (vec ? C / 8 : C);
+    const dim3 grid((unsigned)((n + 255) / 256));
+#define PPT_LAUNCH_BRA(V, R, H)                                                                                         \
+    hipLaunchKernelGGL((bn_res_act_rows_kernel<V, R, H>), grid, dim3(256), 0, ppt_stream(stream), x, x_dtype, res, res_dtype, \
+                       M / pool, C, pool, scale, shift, res_scale, res_shift, y, y_dtype)
+    const bool h = x_dtype == PPT_BF16 && res_dtype == PPT_BF16 && y_dtype == PPT_BF16;
+    if (vec && h && res_scale) PPT_LAUNCH_BRA(8, true, true);
+    else if (vec && h) PPT_LAUNCH_BRA(8, false, true);
+    else if (vec && res_scale) PPT_LAUNCH_BRA(8, true, false);
+    else if (vec) PPT_LAUNCH_BRA(8, false, false);
+    else if (res_scale) PPT_LAUNCH_BRA(1, true, false);
+    else PPT_LAUNCH_BRA(1, false, false);
+#undef PPT_LAUNCH_BRA
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }

@@ -457,13 +457,14 @@ def _conv_bn(sd, wc, x, wkey, bnp, train, upd, out_dtype, a_affine=None):
     return y, sc, sh
 
 
-def _mlp_res_block(sd, wc, p, x, train, upd, pool=1):
+def _mlp_res_block(sd, wc, p, x, train, upd, pool=1, x_affine=None):
     """ConvBNReLURes1D.forward (pointMLP.py:188-221; groups=1): relu(BN(conv2(relu(BN(conv1(x))))) + x) on rows [M,C];
-    pool > 1 also takes the max over each `pool` consecutive rows (:251, :332)."""
+    pool > 1 also takes the max over each `pool` consecutive rows (:251, :332).  x_affine = (scale, shift): x is the raw
+    output of the conv in front of the block and relu(scale * x + shift) is the block input, applied where x is read."""
     T = wc.dtype
-    c1, sc1, sh1 = _conv_bn(sd, wc, x, p + "net1.0.weight", p + "net1.1.", train, upd, T)
+    c1, sc1, sh1 = _conv_bn(sd, wc, x, p + "net1.0.weight", p + "net1.1.", train, upd, T, a_affine=x_affine)
     c2, sc2, sh2 = _conv_bn(sd, wc, c1, p + "net2.0.weight", p + "net2.1.", train, upd, T, a_affine=(sc1, sh1))
-    return ops.bn_res_act_rows(c2, x, sc2, sh2, T, pool)
+    return ops.bn_res_act_rows(c2, x, sc2, sh2, T, pool, res_affine=x_affine)
 
 
 def pointmlp_forward(sd, p, wc, pc, fps_starts, train, drop_masks, update_running=True, cfg=None):
@@ -521,12 +522,13 @@ def pointmlp_forward(sd, p, wc, pc, fps_starts, train, drop_masks, update_runnin
         a = (torch.arange(B, device=dev).view(B, 1) * N + cidx).view(-1)
         Q = (c0.view(1, C) + PQ[:, C:][a] - P[a]).contiguous()
         M = B * S * k
-        y0, part0 = ops.gather_add(P, Q, nidx, N, torch.float32, want_stats=train)
-        sc0, sh0 = _bn_affine(sd, pp + "transfer.net.1.", train, part0, 32, M, upd)
-        y = ops.bn_act_rows(y0, sc0, sh0, T)
+        # the transfer conv's output stays raw: its BN + ReLU (:246) is applied by the two readers of the first block
+        y, part0 = ops.gather_add(P, Q, nidx, N, T, want_stats=train)
+        aff = _bn_affine(sd, pp + "transfer.net.1.", train, part0, 32, M, upd)
         nb = cfg["pre_blocks"][i]
         for j in range(nb):                                                      # PreExtraction (:248-252)
-            y = _mlp_res_block(sd, wc, f"{pp}operation.{j}.", y, train, upd, pool=k if j == nb - 1 else 1)
+            y = _mlp_res_block(sd, wc, f"{pp}operation.{j}.", y, train, upd, pool=k if j == nb - 1 else 1,
+                               x_affine=aff if j == 0 else None)
         nb = cfg["pos_blocks"][i]
         for j in range(nb):                                                      # PosExtraction (:272-273), max of :332
             y = _mlp_res_block(sd, wc, f"{p}pos_blocks_list.{i}.operation.{j}.", y, train, upd,

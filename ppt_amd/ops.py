@@ -362,14 +362,16 @@ def group_anchor_stats(x, idx, anchor, Nsrc):
     return out
 
 
-def bn_res_act_rows(x, res, scale, shift, y_dtype, pool=1):
-    """relu(scale * x + shift + res) over rows [M,C]; pool > 1 returns the max over each `pool` consecutive rows."""
+def bn_res_act_rows(x, res, scale, shift, y_dtype, pool=1, res_affine=None):
+    """relu(scale * x + shift + res') over rows [M,C]; pool > 1 returns the max over each `pool` consecutive rows.
+    res' = res, or relu(rs * res + rh) with res_affine = (rs, rh)."""
     _chk(x, None, "x"); _chk(res, None, "res")
     M, C = x.shape
     assert res.shape == x.shape and M % pool == 0
     y = torch.empty((M // pool, C), dtype=y_dtype, device=x.device)
+    rs, rh = res_affine if res_affine is not None else (None, None)
     _lib.check(_lib.lib().ppt_bn_res_act_rows(_p(x), dtype_code(x), _p(res), dtype_code(res), M, C, pool, _p(scale), _p(shift),
-                                              _p(y), dtype_code(y), _stream()), "ppt_bn_res_act_rows")
+                                              _p(rs), _p(rh), _p(y), dtype_code(y), _stream()), "ppt_bn_res_act_rows")
     return y
 
 
