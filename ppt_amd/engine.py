@@ -161,21 +161,23 @@ def vit_block_forward(sd, p, wc, x, pos, B, Tn, heads, dp1, dp2, save=None, pos_
 
 
 def point_encoder_forward(sd, p, wc, pc, fps_start, dp, bn_train, save_tier, cfg, update_running=True, fetch=None,
-                          last_block=None, resume=None):
+                          last_block=None, resume=None, grouped=None):
     """PointTransformer.forward (point_encoder.py:234-257) -> (feat [B,2*D] fp32, saved | None).
     dp: DropPath factors [depth,2,B] fp32 or None; save_tier > 0 keeps block-(depth-1) activations.
 
     The forward can be cut in front of the last block (the only one that may train, ULIP_models.py:461-470):
     last_block=False runs the tokenizer and blocks 0 .. depth-2 -- everything that is frozen whatever the head_type --
     and returns (x2, pos2), both [B*Tn, D] fp32, x2 with the last block's "+ pos" already added;
-    resume=(x2, pos2) runs the last block, the final norm and the pooling on them."""
+    resume=(x2, pos2) runs the last block, the final norm and the pooling on them.
+    grouped=(neighbourhoods [B,G,n,3], centres [B,G,3]) replaces pc / fps_start."""
     T = wc.dtype
     G, D, depth, heads = cfg["num_group"], cfg["trans_dim"], cfg["depth"], cfg["num_heads"]
     Tn = G + 1
     if resume is None:
-        B = pc.shape[0]
-        dev = pc.device
-        nbhd, center = group_points(pc, G, cfg["group_size"], fps_start)
+        # grouped = (nbhd, center): Group.forward was already run (ahead of the step, on its own stream)
+        nbhd, center = grouped if grouped is not None else group_points(pc, G, cfg["group_size"], fps_start)
+        B = center.shape[0]
+        dev = center.device
         tok = mini_pointnet(sd, p + "encoder.", wc, nbhd, bn_train, update_running)
         x = torch.empty((B, Tn, D), dtype=torch.float32, device=dev)
         pos = torch.empty((B, Tn, D), dtype=torch.float32, device=dev)

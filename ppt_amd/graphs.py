@@ -85,6 +85,20 @@ def shared_text_stream(device=None):
     return _TEXT_STREAMS[dev]
 
 
+_GROUP_STREAMS = {}
+
+
+def shared_group_stream(device=None):
+    """The process-wide stream the grouping stage of the NEXT iteration runs on (FPS + kNN depend on the input cloud
+    only: point_encoder.PointTransformer._group_ahead).  Created once per GPU, like the text stream and for the same
+    reason; callers that care about hardware-queue placement create it right after shared_text_stream()."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    if dev not in _GROUP_STREAMS:
+        with torch.cuda.device(dev):
+            _GROUP_STREAMS[dev] = torch.cuda.Stream()
+    return _GROUP_STREAMS[dev]
+
+
 def _lead_over(ref, cand):
     """Fraction of `ref`'s busy time by which a tiny kernel queued on `cand` AFTER ref's work finishes BEFORE it:
     ~1 when the streams sit on different hardware queues, <= 0 when they share one (in-order execution)."""

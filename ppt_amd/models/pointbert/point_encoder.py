@@ -100,7 +100,23 @@ class _PointEncoderFn(torch.autograd.Function):
             module.param_gate = None
         has_dp = (train and module.drop_path_rate > 0) if drawn else dp is not None
         key = ("point_fwd", tuple(pc.shape), has_dp, drawn, train, cache.dtype)
+        ahead = module.group_ahead if (use_graph and module._graphs.ready(("group", tuple(pc.shape), drawn))) else None
         if tier == 0 and use_graph and module._graphs.ready(key):
+            if ahead is not None:
+                # FPS + kNN ran (or run right now) on the grouping stream, overlapping the previous iteration's blocks
+                grouped, slot = module._group_ahead(pc, fps_start, drawn, ahead)
+                ins = list(grouped) + ([dp] if dp is not None else [])
+
+                def build():
+                    def fn(nb_, ce_, *rest):
+                        dp_ = module._draw_drop_path(B, pc.device) if drawn else (rest[0] if rest else None)
+                        feat_, _ = engine.point_encoder_forward(sd, "", cache, None, None, dp_, train, 0, cfg, grouped=(nb_, ce_))
+                        return (feat_,), None
+                    return graphs.GraphedCall(fn, ins)
+                (feat,), _ = module._graphs.get(key + ("grouped",), build)(*ins)
+                module._group_consumed(slot)
+                ctx.saved = None
+                return feat.clone()
             ins = [pc] if drawn else [pc, fps_start] + ([dp] if dp is not None else [])
 
             def build():
@@ -118,16 +134,32 @@ class _PointEncoderFn(torch.autograd.Function):
             # set by train.Trainer.step) -- the prefix runs ahead of it like the whole tower does for head_type 0.
             key = ("point_prefix", tuple(pc.shape), has_dp, drawn, train, cache.dtype)
             if use_graph and module._graphs.ready(key):
-                ins = [pc] if drawn else [pc, fps_start] + ([dp] if dp is not None else [])
+                slot = None
+                if ahead is not None:
+                    grouped, slot = module._group_ahead(pc, fps_start, drawn, ahead)
+                    ins = list(grouped) + ([dp] if dp is not None else [])
 
-                def build():
-                    def fn(pc_, *rest):
-                        start_, dp_ = draw() if drawn else (rest[0], rest[1] if len(rest) > 1 else None)
-                        x2_, pos2_ = engine.point_encoder_forward(sd, "", cache, pc_, start_, dp_, train, 0, cfg, last_block=False)
-                        return (x2_, pos2_) + ((dp_,) if dp_ is not None else ()), None
-                    return graphs.GraphedCall(fn, ins)
+                    def build():
+                        def fn(nb_, ce_, *rest):
+                            dp_ = module._draw_drop_path(B, pc.device) if drawn else (rest[0] if rest else None)
+                            x2_, pos2_ = engine.point_encoder_forward(sd, "", cache, None, None, dp_, train, 0, cfg,
+                                                                      last_block=False, grouped=(nb_, ce_))
+                            return (x2_, pos2_) + ((dp_,) if dp_ is not None else ()), None
+                        return graphs.GraphedCall(fn, ins)
+                    key = key + ("grouped",)
+                else:
+                    ins = [pc] if drawn else [pc, fps_start] + ([dp] if dp is not None else [])
+
+                    def build():
+                        def fn(pc_, *rest):
+                            start_, dp_ = draw() if drawn else (rest[0], rest[1] if len(rest) > 1 else None)
+                            x2_, pos2_ = engine.point_encoder_forward(sd, "", cache, pc_, start_, dp_, train, 0, cfg, last_block=False)
+                            return (x2_, pos2_) + ((dp_,) if dp_ is not None else ()), None
+                        return graphs.GraphedCall(fn, ins)
                 g = module._graphs.get(key, build)
                 outs, _ = g(*ins)
+                if slot is not None:
+                    module._group_consumed(slot)
                 g.generation = getattr(g, "generation", 0) + 1
                 ctx.prefix_graph, ctx.prefix_generation = g, g.generation
                 cut, dp = (outs[0], outs[1]), (outs[2] if len(outs) > 2 else None)
@@ -197,6 +229,12 @@ class PointTransformer(nn.Module):
         self._graphs = graphs.GraphCache()
         self.use_hip_graphs = True
         self.param_gate = None           # event after which this iteration may read the last block's parameters (Trainer)
+        # stream for the grouping stage (FPS + kNN, a function of the input cloud alone) when the caller vouches that the
+        # cloud is complete in memory at the time of the call (train.Trainer.inputs_ready): it then overlaps the previous
+        # iteration's transformer blocks instead of heading this one's critical path.  None: grouping stays in the tower.
+        self.group_ahead = None
+        self._group_slot = 0
+        self._group_free = [None, None]
         self.fps_start = None            # [B] int64: injected FPS start indices (else torch.randint)
         self.drop_path_factors = None    # [depth,2,B] fp32: injected DropPath factors (else drawn on device)
         self._wc = None
@@ -244,6 +282,36 @@ class PointTransformer(nn.Module):
             raise RuntimeError("un-frozen last-block parameters must follow the cumulative head_type tiers of "
                                f"ULIP_models.py:461-470; got {sorted(actual)}")
         return tier
+
+    def _group_ahead(self, pc, fps_start, drawn, side):
+        """Group.forward (dvae.py:159-181) of `pc` on `side`, replayed from one of two hipGraphs with their own output
+        buffers (the previous tower may still be reading the other pair).  The caller's stream is made to wait for the
+        result; `side` waits for nothing but the tower that last read this pair -- NOT for the caller's stream, which is
+        the point: the caller guarantees `pc` (and `fps_start`) are complete in memory.  -> ((nbhd, center), slot)."""
+        main = torch.cuda.current_stream()
+        slot = self._group_slot = 1 - self._group_slot
+        B, N = pc.shape[0], pc.shape[1]
+        G, n = self.num_group, self.group_size
+        ins = [pc] if drawn else [pc, fps_start]
+
+        def build():
+            def fn(pc_, *rest):
+                start_ = torch.randint(0, N, (B,), dtype=torch.long, device=pc_.device) if drawn else rest[0]   # misc.py:59
+                return tuple(engine.group_points(pc_, G, n, start_)), None
+            return graphs.GraphedCall(fn, ins)
+        with torch.cuda.stream(side):
+            if self._group_free[slot] is not None:
+                side.wait_event(self._group_free[slot])
+            grouped, _ = self._graphs.get(("group", tuple(pc.shape), drawn, slot), build)(*ins)
+            done = side.record_event()
+        for t in ins:
+            t.record_stream(side)
+        main.wait_event(done)
+        return grouped, slot
+
+    def _group_consumed(self, slot):
+        """The tower reading pair `slot` has been queued on the current stream: the pair is free once it has run."""
+        self._group_free[slot] = torch.cuda.current_stream().record_event()
 
     def _draw_drop_path(self, B, device):
         """timm DropPath factors for both residual branches of every block (train mode only)."""

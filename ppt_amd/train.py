@@ -107,6 +107,15 @@ class Trainer:
         # collective on the point tower's stream in every iteration.  True restores DDP's schedule.
         self.broadcast_buffers_every_step = False
         self.fused_head = True        # head_type 0 on a GPU: ULIP_WITH_IMAGE.forward_loss
+        # True: the caller vouches that `pc` is complete in device memory when step() is called (a resident tensor, or a
+        # loader that synchronised its copy stream) -- NOT merely queued on the current stream.  The grouping stage of the
+        # point tower (FPS + kNN, a function of pc alone) then runs on its own stream as soon as step() is called, i.e.
+        # under the previous iteration's transformer blocks (models/pointbert/point_encoder.py: _group_ahead).
+        self.inputs_ready = False
+        # With a fully frozen point side (head_type 0) the tower already runs back to back on its stream with the whole
+        # prompt side underneath it, the step is throughput-bound and hiding FPS buys nothing (C2: 4.22 ms without, 4.29
+        # with); with a trainable last block the caller's stream has bubbles and it does (C3: 8.85 -> 8.28 ms).
+        self.group_ahead_when_frozen = False
         # head_type 0: only the prompt learner trains, so the point tower never reads a parameter the optimizer writes
         self._point_side_frozen = all(n.startswith("prompt_learner.") or not p.requires_grad
                                       for n, p in model.named_parameters())
@@ -138,6 +147,11 @@ class Trainer:
         tensors of the caller's stream; parameters are final after `finish()`."""
         model = self.model
         side = self._side_used = self._prompt_stream(pc)
+        pe = getattr(model, "point_encoder", None)
+        if hasattr(pe, "group_ahead"):
+            from . import graphs
+            use = self.inputs_ready and pc.is_cuda and side is not None and (self.group_ahead_when_frozen or not self._point_side_frozen)
+            pe.group_ahead = graphs.shared_group_stream() if use else None
         main = torch.cuda.current_stream() if side is not None else None
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
             self.sync.zero()                                        # optimizer.zero_grad()

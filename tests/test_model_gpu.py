@@ -168,13 +168,14 @@ def test_overlapped_text_tower_is_identical():
 @pytest.mark.parametrize("head_type", [0, 3])
 def test_run_ahead_training_is_identical(head_type):
     """Trainer.step with the prompt side queued on the text stream (and, for head_type 0, the next iteration's
-    point tower running ahead of the optimizer), without and with the text tower replayed from hipGraphs, must
-    produce exactly the losses and parameters of the single-stream eager step."""
+    point tower running ahead of the optimizer), without and with the text tower replayed from hipGraphs, and with
+    FPS + kNN of an iteration running ahead on the grouping stream, must produce exactly the losses and parameters of the
+    single-stream eager step."""
     from ppt_amd.train import Trainer
     pc, start = oracle_inputs()
     label = torch.tensor([3, 17, 0, 39]).cuda()
     results = []
-    for run_ahead, hip_graphs in ((False, False), (True, False), (True, True)):
+    for run_ahead, hip_graphs, group_ahead in ((False, False, False), (True, False, False), (True, True, False), (True, True, True)):
         m, _ = build(head_type, torch.bfloat16)
         m.use_hip_graphs = m.point_encoder.use_hip_graphs = hip_graphs
         m.train()
@@ -183,6 +184,8 @@ def test_run_ahead_training_is_identical(head_type):
         m.overlap_text_tower = run_ahead
         tr = Trainer(m, lr=3e-3, label_smoothing=0.2, distributed=False)
         tr.run_ahead = run_ahead
+        # (the clouds below are complete on the device when step() is called: pageable host-to-device copies are synchronous)
+        tr.inputs_ready = tr.group_ahead_when_frozen = group_ahead
         assert tr._point_side_frozen == (head_type == 0)
         losses = []
         for it in range(6):
@@ -194,8 +197,9 @@ def test_run_ahead_training_is_identical(head_type):
                         {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad}))
         assert bool(m._graphs.entries) == hip_graphs          # the text tower really was replayed from a hipGraph
         # ... and the point tower: all of it for head_type 0, the frozen prefix in front of the last block otherwise
-        assert [k[0] for k in m.point_encoder._graphs.entries] == ([] if not hip_graphs else
-                                                                   ["point_fwd" if head_type == 0 else "point_prefix"])
+        tower = "point_fwd" if head_type == 0 else "point_prefix"
+        kinds = sorted(k[0] + ("+grouped" if k[-1] == "grouped" else "") for k in m.point_encoder._graphs.entries)
+        assert kinds == ([] if not hip_graphs else [tower] if not group_ahead else ["group", "group", tower + "+grouped"])
     la, pa, wa = results[0]
     for lb, pb, wb in results[1:]:
         assert la == lb

@@ -16,8 +16,11 @@ def main():
     pc_np, _ = W.synth_clouds(cfg["batch"], cfg["npoints"], seed=1)
     pc = torch.from_numpy(pc_np).cuda()
     label = torch.randint(0, 40, (cfg["batch"],), device="cuda")
-    for ra in (True, False, True):
+    from ppt_amd import graphs
+    graphs.shared_text_stream(); graphs.shared_group_stream()
+    for ra, ga in ((True, False), (True, True), (True, False), (True, True)):
         tr.run_ahead = ra
+        tr.inputs_ready = ga
         for _ in range(10):
             tr.step(pc, label)
         torch.cuda.synchronize()
@@ -27,7 +30,7 @@ def main():
         t1 = time.perf_counter()
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        print(f"run_ahead={ra}: host enqueue {1e3*(t1-t0)/50:.3f} ms/step, total {1e3*(t2-t0)/50:.3f} ms/step", flush=True)
+        print(f"run_ahead={ra} group_ahead={ga}: host enqueue {1e3*(t1-t0)/50:.3f} ms/step, total {1e3*(t2-t0)/50:.3f} ms/step", flush=True)
     for burst in (2, 4, 8):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
