@@ -422,10 +422,19 @@ class PointTransformer_partseg(nn.Module):
             s0, s1, s2 = (torch.randint(0, N, (B,), dtype=torch.long, device=dev) for _ in range(3))
         dp = self._draw_drop_path(B, dev)
         with torch.no_grad():                        # frozen backbone: features after blocks 3, 7, 11 (+ final LN, cls dropped)
-            feats, center = engine.point_encoder_forward(self._live_state(), "", self._cache(), pts, s0, dp, self.training, 0,
-                                                         self._cfg(), fetch=(3, 7, 11))
-            _, c1 = ops.fps(pts, 512, s1)
-            _, c2 = ops.fps(pts, 256, s2)
+            # the three farthest-point samplings of the step (group centres, 512 and 256 decoder anchors: point_encoder.py
+            # :360-364) are independent walks over the same clouds and each is one serial workgroup per cloud: run as ONE
+            # launch over 3B clouds; the 256-point sampling is the first 256 picks of a 512-point one from the same start
+            if self.num_group == 512:
+                _, ctr = ops.fps(pts.repeat(3, 1, 1), 512, torch.cat([s0, s1, s2]))
+                center, c1, c2 = ctr[:B], ctr[B:2 * B], ctr[2 * B:, :256].contiguous()
+            else:
+                _, center = ops.fps(pts, self.num_group, s0)
+                _, c1 = ops.fps(pts, 512, s1)
+                _, c2 = ops.fps(pts, 256, s2)
+            _, nbhd = ops.knn_group(pts, center, self.group_size, want_idx=False)
+            feats, center = engine.point_encoder_forward(self._live_state(), "", self._cache(), None, None, dp, self.training, 0,
+                                                         self._cfg(), fetch=(3, 7, 11), grouped=(nbhd, center))
         f0 = torch.cat([cls_label.float().view(B, 1, 16).expand(-1, N, -1), pts], dim=-1)       # [B,N,19]
         f2 = self.propagation_2(c2, center, c2, feats[1])
         f1 = self.propagation_1(c1, center, c1, feats[0])

@@ -545,3 +545,15 @@ def test_gemm_tn_reads_operands_as_stored(ops, M, N1, N2):
     c2 = ops.gemm_tn_splitk(a[:M - 3].contiguous(), b[:M - 3])
     ref2 = a[:M - 3].double().t() @ b[:M - 3].double()
     assert (c2.double() - ref2).abs().max().item() <= tol * max(1.0, ref2.abs().max().item() / float(M) ** 0.5)
+
+
+@pytest.mark.parametrize("M,D,pad", [(32768, 256, 0), (1000, 36, 4), (777, 130, 0), (5, 8, 0)])
+def test_col_sums_matches_torch(ops, M, D, pad):
+    """bias gradients: column sums of an fp32 matrix (vector path for D % 4 == 0, row stride wider than D allowed)."""
+    g = torch.Generator(device="cuda").manual_seed(M)
+    full = torch.randn(M, D + pad, device="cuda", generator=g)
+    x = full[:, :D]
+    out = ops.col_sums(x)
+    ref = x.double().sum(0)
+    assert (out.double() - ref).abs().max().item() < 1e-5 * max(1.0, float(M) ** 0.5)
+    assert torch.equal(out, ops.col_sums(x))
