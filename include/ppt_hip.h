@@ -196,6 +196,14 @@ int ppt_bn_rows_bwd_apply(const float *dy, const float *x, const float *scale, c
 int ppt_conv1_stats_max_partials(int64_t M);
 int ppt_conv1_stats_rows_per_partial(void);
 
+/* ---- first half of the PointBERT mini-PointNet in one kernel (Encoder.first_conv + the group max, dvae.py:188-193,206-210):
+ * y2[m, :] = W2 . relu(a_scale * (w1 . pts[m] + b1) + a_shift) + bias2 (bf16, [M,N]) and gmax[g, :] = max over the 32 rows of
+ * group g (bf16, [M/32, N]).  Same arithmetic as ppt_gemm with PPT_A_CONV1 + bias + pool_max over 32 rows (bit-identical
+ * results), without its tile staging.  C1 = 128, N = 256, M % 32 == 0, W2 [N, C1] bf16; anything else: PPT_EUNSUPPORTED. */
+int ppt_mini_pointnet_conv12_bf16(const float *pts, int64_t M, const float *w1, const float *b1, const float *a_scale,
+                                  const float *a_shift, int C1, const void *W2, const float *bias2, int N, void *y2, void *gmax,
+                                  void *stream);
+
 /* ---- PointMLP (models/pointmlp/pointMLP.py) pieces outside the GEMM / BatchNorm / gather kernels above.
  * ppt_group_anchor_stats: LocalGrouper normalize="anchor" (:170-175): out[(b*S+s)*2 + {0,1}] = sum, sum of squares over
  *   j < K, c < D of x[b*Nsrc + idx[b,s,j], c] - x[b*Nsrc + anchor[b,s], c]; x [B*Nsrc, D] f32 or bf16.

@@ -69,6 +69,8 @@ _SIGNATURES = {
     "ppt_bn_rows_bwd_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                       c_int, c_int64, c_int, c_void_p, c_void_p]),
     "ppt_bn_finalize_workspace_bytes": (ctypes.c_size_t, [c_int, c_int]),
+    "ppt_mini_pointnet_conv12_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                              c_int, c_void_p, c_void_p, c_void_p]),
     "ppt_group_anchor_stats": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ppt_bn_res_act_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int, c_void_p]),

@@ -12,6 +12,8 @@ all gradients that are accumulated stay fp32 in both modes.
 
 Reference citations are relative to the upstream repo.
 """
+import os
+
 import torch
 
 from . import ops
@@ -67,6 +69,9 @@ class WeightCache:
         return out
 
 
+FUSED_CONV12 = os.environ.get("PPT_FUSED_CONV12", "1") != "0"      # 0: the generic PPT_A_CONV1 GEMM (A/B comparisons)
+
+
 def _bn_params(sd, p):
     return (sd[p + "weight"], sd[p + "bias"], sd[p + "running_mean"], sd[p + "running_var"],
             sd[p + "num_batches_tracked"])
@@ -102,9 +107,14 @@ def mini_pointnet(sd, p, wc, nbhd, bn_train, update_running=True):
     else:
         sc1, sh1 = ops.bn_finalize(g1, be1, False, running_mean=rm1, running_var=rv1)
     # conv1 + BN1 + ReLU live in the A-prologue of the conv2 GEMM; epilogue: +bias, group max
-    gmax = torch.empty((M // 32, 256), dtype=T, device=dev)
-    y2 = ops.gemm(None, wc.get(sd[p + "first_conv.3.weight"]), out_dtype=T, a_mode=A_CONV1, pts=pts, w1=w1, b1=b1,
-                  a_scale=sc1, a_shift=sh1, bias=sd[p + "first_conv.3.bias"], pool_max=gmax)
+    w2 = wc.get(sd[p + "first_conv.3.weight"])
+    if T == torch.bfloat16 and FUSED_CONV12 and tuple(w2.shape) == (256, 128) and w2.stride(0) == 128:
+        # the dedicated kernel (csrc/mpn1.hip): same arithmetic, no tile staging (326 -> ~100 us for 524 288 points)
+        y2, gmax = ops.mini_pointnet_conv12(pts, w1, b1, sc1, sh1, w2, sd[p + "first_conv.3.bias"])
+    else:
+        gmax = torch.empty((M // 32, 256), dtype=T, device=dev)
+        y2 = ops.gemm(None, w2, out_dtype=T, a_mode=A_CONV1, pts=pts, w1=w1, b1=b1,
+                      a_scale=sc1, a_shift=sh1, bias=sd[p + "first_conv.3.bias"], pool_max=gmax)
     # cat([global, local]) @ W3^T  ==  local @ W3[:,256:]^T + (global @ W3[:,:256]^T + b3) per group
     w3 = sd[p + "second_conv.0.weight"]
     gterm = ops.gemm(gmax, wc.get(w3, cols=(0, 256)), out_dtype=torch.float32, bias=sd[p + "second_conv.0.bias"],

@@ -351,6 +351,23 @@ def bn_act_rows(x, scale, shift, y_dtype, mask=None):
     return y
 
 
+def mini_pointnet_conv12(pts, w1, b1, a_scale, a_shift, w2, bias2):
+    """pts [M,3] f32 -> (y2 [M,256] bf16, gmax [M/32,256] bf16): conv1 + folded BN + ReLU + conv2 + bias and the max over
+    each group of 32 rows, one kernel (ppt_mini_pointnet_conv12_bf16).  w2 [256,128] bf16."""
+    _chk(pts, torch.float32, "pts"); _chk(w2, torch.bfloat16, "w2")
+    M = pts.shape[0]
+    N, C1 = w2.shape
+    y2 = torch.empty((M, N), dtype=torch.bfloat16, device=pts.device)
+    gmax = torch.empty((M // 32, N), dtype=torch.bfloat16, device=pts.device)
+    if profiler is not None:
+        profiler.begin("gemm_bf16", 2.0 * M * N * C1)
+    _lib.check(_lib.lib().ppt_mini_pointnet_conv12_bf16(_p(pts), M, _p(w1), _p(b1), _p(a_scale), _p(a_shift), C1, _p(w2), _p(bias2),
+                                                        N, _p(y2), _p(gmax), _stream()), "ppt_mini_pointnet_conv12_bf16")
+    if profiler is not None:
+        profiler.end()
+    return y2, gmax
+
+
 def group_anchor_stats(x, idx, anchor, Nsrc):
     """x [B*Nsrc, D] (f32 | bf16), idx [B,S,K], anchor [B,S] -> [B,S,2] f32: (sum, sum of squares) of x[idx] - x[anchor] per
     group (the statistic behind LocalGrouper's per-cloud std, pointMLP.py:170-175)."""

@@ -557,3 +557,27 @@ def test_col_sums_matches_torch(ops, M, D, pad):
     ref = x.double().sum(0)
     assert (out.double() - ref).abs().max().item() < 1e-5 * max(1.0, float(M) ** 0.5)
     assert torch.equal(out, ops.col_sums(x))
+
+
+@pytest.mark.parametrize("groups", [1, 7, 4096])
+def test_mini_pointnet_conv12_is_the_prologue_gemm(ops, groups):
+    """ppt_mini_pointnet_conv12_bf16 against ppt_gemm(PPT_A_CONV1 + bias + pool over 32 rows): same expression, same
+    summation order -> bit-identical y2 and group maxima; and against fp64 within bf16 rounding."""
+    g = torch.Generator(device="cuda").manual_seed(groups)
+    M = groups * 32
+    pts = torch.randn(M, 3, device="cuda", generator=g) * 0.3
+    w1 = torch.randn(128, 3, device="cuda", generator=g)
+    b1 = torch.randn(128, device="cuda", generator=g) * 0.1
+    sc = 1.0 + 0.1 * torch.randn(128, device="cuda", generator=g)
+    sh = 0.1 * torch.randn(128, device="cuda", generator=g)
+    w2 = (torch.randn(256, 128, device="cuda", generator=g) / 128 ** 0.5).to(torch.bfloat16)
+    b2 = torch.randn(256, device="cuda", generator=g) * 0.1
+    y2, gm = ops.mini_pointnet_conv12(pts, w1, b1, sc, sh, w2, b2)
+    gm_ref = torch.empty((groups, 256), dtype=torch.bfloat16, device="cuda")
+    y2_ref = ops.gemm(None, w2, out_dtype=torch.bfloat16, a_mode=ops.A_CONV1, pts=pts, w1=w1, b1=b1, a_scale=sc, a_shift=sh,
+                      bias=b2, pool_max=gm_ref)
+    assert torch.equal(y2, y2_ref) and torch.equal(gm, gm_ref)
+    a = torch.relu(sc.double() * (pts.double() @ w1.double().t() + b1.double()) + sh.double())
+    ref = a.to(torch.bfloat16).double() @ w2.double().t() + b2.double()
+    assert (y2.double() - ref).abs().max().item() < 2e-2 * max(1.0, ref.abs().max().item())
+    assert torch.equal(gm, y2.view(groups, 32, 256).float().amax(1).to(torch.bfloat16))
