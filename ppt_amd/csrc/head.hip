@@ -24,27 +24,36 @@ __device__ __forceinline__ float block_sum(float v, float *red)
     return t;
 }
 
-// projection: thread per output column e (coalesced rows of W[F,E] = pc_projection as stored), feat row in LDS;
-// grid (E / 256, B)
+// projection: workgroup = (sample b, 64 output columns), 4 waves each walk a quarter of F (coalesced 256-byte pieces of
+// the rows of W[F,E] = pc_projection as stored, four independent chains), the four partial sums fold through LDS in a
+// fixed order; feat row in LDS.  grid (E / 64, B).  (One thread per column over all of F was a 768-deep serial walk on 64
+// workgroups: 84 us between the towers.)
 __global__ __launch_bounds__(HT) void head_project_kernel(const float *__restrict__ feat, const float *__restrict__ w,
                                                           const float *__restrict__ logit_scale, int F, int E,
                                                           float *__restrict__ spc)
 {
-    extern __shared__ float sm[];
-    const int b = blockIdx.y, e = blockIdx.x * HT + threadIdx.x;
+    extern __shared__ float sm[];                         // [F] feat row, then [4][64] partials
+    float *part = sm + F;
+    const int b = blockIdx.y, lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
     for (int i = threadIdx.x; i < F; i += HT) sm[i] = feat[(size_t)b * F + i];
     __syncthreads();
-    if (e >= E) return;
+    const int fq = (F + 3) / 4, f0 = q * fq, f1 = min(F, f0 + fq);
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int i = 0;
-    for (; i + 4 <= F; i += 4) {                          // four independent chains: the loads stream, the FMAs do not wait
-        a0 = fmaf(sm[i + 0], w[(size_t)(i + 0) * E + e], a0);
-        a1 = fmaf(sm[i + 1], w[(size_t)(i + 1) * E + e], a1);
-        a2 = fmaf(sm[i + 2], w[(size_t)(i + 2) * E + e], a2);
-        a3 = fmaf(sm[i + 3], w[(size_t)(i + 3) * E + e], a3);
+    if (e < E) {
+        int i = f0;
+        for (; i + 4 <= f1; i += 4) {                     // four independent chains: the loads stream, the FMAs do not wait
+            a0 = fmaf(sm[i + 0], w[(size_t)(i + 0) * E + e], a0);
+            a1 = fmaf(sm[i + 1], w[(size_t)(i + 1) * E + e], a1);
+            a2 = fmaf(sm[i + 2], w[(size_t)(i + 2) * E + e], a2);
+            a3 = fmaf(sm[i + 3], w[(size_t)(i + 3) * E + e], a3);
+        }
+        for (; i < f1; ++i) a0 = fmaf(sm[i], w[(size_t)i * E + e], a0);
     }
-    for (; i < F; ++i) a0 = fmaf(sm[i], w[(size_t)i * E + e], a0);
-    spc[(size_t)b * E + e] = __expf(logit_scale[0]) * ((a0 + a1) + (a2 + a3));
+    part[q * 64 + lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (q == 0 && e < E)
+        spc[(size_t)b * E + e] = __expf(logit_scale[0]) * ((part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]));
 }
 
 // logits[b,c] = spc[b,:] . text[c,:] / |text[c,:]|: one wave per (b, c) pair, 16 waves per workgroup
@@ -127,7 +136,7 @@ extern "C" int ppt_head_logits(const float *feat, const float *w, const float *t
 {
     if (!feat || !w || !text || !logit_scale || !spc || !logits || B <= 0 || F <= 0 || E <= 0 || C <= 0) return PPT_EINVAL;
     if (F > 8192 || B > 65535) return PPT_EUNSUPPORTED;
-    hipLaunchKernelGGL(head_project_kernel, dim3((E + HT - 1) / HT, B), dim3(HT), sizeof(float) * (size_t)F, ppt_stream(stream),
+    hipLaunchKernelGGL(head_project_kernel, dim3((E + 63) / 64, B), dim3(HT), sizeof(float) * (size_t)(F + 256), ppt_stream(stream),
                        feat, w, logit_scale, F, E, spc);
     PPT_CHECK_LAUNCH();
     hipLaunchKernelGGL(head_logits_kernel, dim3((B * C + 15) / 16), dim3(1024), 0, ppt_stream(stream), spc, text, B, E, C, logits);

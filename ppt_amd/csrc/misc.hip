@@ -4,21 +4,32 @@
 
 namespace {
 
-// block = (sample b, 64-column slab): 4 waves stripe the tokens, lane == column (coalesced 256-B rows);
-// the four partial (max, first index) pairs fold through LDS with torch.max's first-maximum rule.
+// block = (sample b, 64-column slab): 16 waves stripe the tokens, lane == column (coalesced 256-B rows), four loads in
+// flight per wave (with 4 waves and one load at a time the 513-token walk was latency: 38 us on the tail of the tower);
+// the partial (max, first index) pairs fold through LDS with torch.max's first-maximum rule.
+constexpr int CMP_W = 16;
 template <typename TX>
-__global__ __launch_bounds__(256) void cls_max_pool_kernel(const TX *__restrict__ x, int T, int D, float *__restrict__ out,
-                                                           int32_t *__restrict__ argmax)
+__global__ __launch_bounds__(CMP_W * 64) void cls_max_pool_kernel(const TX *__restrict__ x, int T, int D, float *__restrict__ out,
+                                                                  int32_t *__restrict__ argmax)
 {
-    __shared__ float bv[4][64];
-    __shared__ int bi[4][64];
+    __shared__ float bv[CMP_W][64];
+    __shared__ int bi[CMP_W][64];
     const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int d = blockIdx.x * 64 + lane;
     float best = -INFINITY;
     int besti = 0x7fffffff;
     if (d < D) {
         const TX *xb = x + (size_t)b * T * D + d;
-        for (int t = 1 + w; t < T; t += 4) {
+        int t = 1 + w;
+        for (; t + 3 * CMP_W < T; t += 4 * CMP_W) {
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = dt<TX>::load(xb + (size_t)(t + k * CMP_W) * D);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (v[k] > best) { best = v[k]; besti = t + k * CMP_W; }
+        }
+        for (; t < T; t += CMP_W) {
             const float v = dt<TX>::load(xb + (size_t)t * D);
             if (v > best) { best = v; besti = t; }
         }
@@ -26,7 +37,7 @@ __global__ __launch_bounds__(256) void cls_max_pool_kernel(const TX *__restrict_
     bv[w][lane] = best; bi[w][lane] = besti;
     __syncthreads();
     if (w == 0 && d < D) {
-        for (int k = 1; k < 4; ++k) {
+        for (int k = 1; k < CMP_W; ++k) {
             const float v = bv[k][lane];
             const int i = bi[k][lane];
             if (v > best || (v == best && i < besti)) { best = v; besti = i; }
@@ -167,9 +178,9 @@ extern "C" int ppt_cls_max_pool(const void *x, int x_dtype, int B, int T, int D,
 {
     if (!x || !out || B <= 0 || T < 2 || D <= 0) return PPT_EINVAL;
     if (x_dtype == PPT_F32)
-        hipLaunchKernelGGL(cls_max_pool_kernel<float>, dim3((D + 63) / 64, B), dim3(256), 0, ppt_stream(stream), (const float *)x, T, D, out, argmax);
+        hipLaunchKernelGGL(cls_max_pool_kernel<float>, dim3((D + 63) / 64, B), dim3(CMP_W * 64), 0, ppt_stream(stream), (const float *)x, T, D, out, argmax);
     else if (x_dtype == PPT_BF16)
-        hipLaunchKernelGGL(cls_max_pool_kernel<bf16_t>, dim3((D + 63) / 64, B), dim3(256), 0, ppt_stream(stream), (const bf16_t *)x, T, D, out, argmax);
+        hipLaunchKernelGGL(cls_max_pool_kernel<bf16_t>, dim3((D + 63) / 64, B), dim3(CMP_W * 64), 0, ppt_stream(stream), (const bf16_t *)x, T, D, out, argmax);
     else
         return PPT_EINVAL;
     PPT_CHECK_LAUNCH();
