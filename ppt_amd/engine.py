@@ -318,29 +318,55 @@ def _stats_bufs(M, C, dev, train):
             torch.empty(((M + 31) // 32, C), dtype=torch.float32, device=dev))
 
 
-def _sa_msg_level(sd, p, wc, cfg, xyz, feats, start, train, upd):
+def _sa_msg_level(sd, p, wc, cfg, xyz, feats, start, train, upd, pre=None):
     """PointNetSetAbstractionMsg.forward (pointnet2_utils.py:228-266): one (radius, nsample, MLP) branch per scale,
     channels = [features | centred xyz] (:250)."""
     branches = [(r, K, f"{p}conv_blocks.{i}.", f"{p}bn_blocks.{i}.") for i, (r, K) in enumerate(zip(cfg["radii"], cfg["nsample"]))]
-    return _sa_level(sd, branches, wc, cfg["npoint"], xyz, feats, start, train, upd, xyz_first=False)
+    return _sa_level(sd, branches, wc, cfg["npoint"], xyz, feats, start, train, upd, xyz_first=False, pre=pre)
 
 
-def _sa_level(sd, branches, wc, npoint, xyz, feats, start, train, upd, xyz_first):
+def _sa_group(xyz, npoint, branches, start, first):
+    """The part of a set-abstraction level that depends on coordinates only: FPS + one ball query per branch.
+    -> [new_xyz [B,S,3], per branch: grouped centred xyz [B,S,K,3] (first level) or neighbour indices [B,S,K]]."""
+    _, new_xyz = ops.fps(xyz, npoint, start)
+    out = [new_xyz]
+    for r, K in branches:
+        idx, gxyz = ops.ball_query(xyz, new_xyz, r, K, want_grouped=True)
+        out.append(gxyz if first else idx)
+    return out
+
+
+def pointnet2_group(pc, fps_starts, levels):
+    """Grouping stage of Pointnet2_Msg / Pointnet2_Ssg (both levels): levels = [(npoint, [(radius, K), ...]), ...].
+    A function of the input cloud and the FPS starts alone, so a trainer may run it ahead of the step."""
+    out, xyz = [], pc
+    for li, ((npoint, branches), start) in enumerate(zip(levels, fps_starts)):
+        g = _sa_group(xyz.contiguous(), npoint, branches, start, first=li == 0)
+        out += g
+        xyz = g[0]
+    return out
+
+
+def _sa_level(sd, branches, wc, npoint, xyz, feats, start, train, upd, xyz_first, pre=None):
     """FPS + ball query + shared three-layer MLP + max over the group, for every (radius, nsample, conv prefix, bn prefix)
     branch.  xyz [B,N,3] fp32, feats [B*N, D] (T) or None -> (new_xyz [B,S,3], new_feats [B*S, sum C] (T)).
     xyz_first: channel order of the first conv's input, [centred xyz | features] (sample_and_group, :132) or
     [features | centred xyz] (the MSG module, :250)."""
     T = wc.dtype
-    B, N, _ = xyz.shape
     S = npoint
-    dev = xyz.device
-    _, new_xyz = ops.fps(xyz, S, start)
+    # pre = _sa_group's list for this level (grouping already done, ahead of the step; xyz may then be None at level 1)
+    new_xyz = pre[0] if pre is not None else ops.fps(xyz, S, start)[1]
+    B, dev = new_xyz.shape[0], new_xyz.device
+    N = xyz.shape[1] if xyz is not None else 0
     c_out = [sd[cb + "2.weight"].shape[0] for _, _, cb, _ in branches]
     out = torch.empty((B * S, sum(c_out)), dtype=T, device=dev)
     col = 0
     mult = 8 if T == torch.bfloat16 else 4
     for i, (r, K, cb, bb) in enumerate(branches):
-        idx, gxyz = ops.ball_query(xyz, new_xyz, r, K, want_grouped=True)
+        if pre is not None:
+            idx = gxyz = pre[1 + i]
+        else:
+            idx, gxyz = ops.ball_query(xyz, new_xyz, r, K, want_grouped=True)
         M = B * S * K
         w0, b0 = sd[cb + "0.weight"], sd[cb + "0.bias"]
         C1 = w0.shape[0]
@@ -387,16 +413,19 @@ def _sa_level(sd, branches, wc, npoint, xyz, feats, start, train, upd, xyz_first
     return new_xyz, out
 
 
-def pointnet2_msg_forward(sd, p, wc, pc, fps_starts, train, drop_masks, update_running=True):
+PN2_MSG_LEVELS = [(c["npoint"], list(zip(c["radii"], c["nsample"]))) for c in (PN2_MSG["sa1"], PN2_MSG["sa2"])]
+
+
+def pointnet2_msg_forward(sd, p, wc, pc, fps_starts, train, drop_masks, update_running=True, grouped=None):
     """Pointnet2_Msg.forward (pointnet2.py:56-73): pc [B,N,3] -> [B,256] fp32.
-    fps_starts = (start level 1 [B], start level 2 [B]); drop_masks = (m1 [B,512], m2 [B,256]) or None."""
-    T = wc.dtype
-    B = pc.shape[0]
-    dev = pc.device
-    mult = 8 if T == torch.bfloat16 else 4
-    l1_xyz, l1 = _sa_msg_level(sd, p + "sa1.", wc, PN2_MSG["sa1"], pc, None, fps_starts[0], train, update_running)
-    l2_xyz, l2 = _sa_msg_level(sd, p + "sa2.", wc, PN2_MSG["sa2"], l1_xyz.contiguous(), l1, fps_starts[1], train,
-                               update_running)
+    fps_starts = (start level 1 [B], start level 2 [B]); drop_masks = (m1 [B,512], m2 [B,256]) or None.
+    grouped = pointnet2_group(pc, fps_starts, PN2_MSG_LEVELS) when the grouping stage already ran."""
+    n1 = 1 + len(PN2_MSG_LEVELS[0][1])
+    pre1, pre2 = (grouped[:n1], grouped[n1:]) if grouped is not None else (None, None)
+    s0, s1 = fps_starts if fps_starts is not None else (None, None)
+    l1_xyz, l1 = _sa_msg_level(sd, p + "sa1.", wc, PN2_MSG["sa1"], pc, None, s0, train, update_running, pre=pre1)
+    l2_xyz, l2 = _sa_msg_level(sd, p + "sa2.", wc, PN2_MSG["sa2"], l1_xyz.contiguous(), l1, s1, train,
+                               update_running, pre=pre2)
     return _pn2_tail(sd, p, wc, l2_xyz, l2, train, drop_masks, update_running)
 
 
@@ -444,13 +473,19 @@ PN2_SSG = dict(   # pointnet2.py:11-12
     sa1=dict(npoint=512, radius=0.2, nsample=32), sa2=dict(npoint=128, radius=0.4, nsample=64))
 
 
-def pointnet2_ssg_forward(sd, p, wc, pc, fps_starts, train, drop_masks, update_running=True):
+PN2_SSG_LEVELS = [(c["npoint"], [(c["radius"], c["nsample"])]) for c in (PN2_SSG["sa1"], PN2_SSG["sa2"])]
+
+
+def pointnet2_ssg_forward(sd, p, wc, pc, fps_starts, train, drop_masks, update_running=True, grouped=None):
     """Pointnet2_Ssg.forward (pointnet2.py:22-38): pc [B,N,3] -> [B,256] fp32; same kernels as the MSG encoder, one
     scale per level and [centred xyz | features] channel order."""
     levels, xyz, feats = (("sa1.", PN2_SSG["sa1"]), ("sa2.", PN2_SSG["sa2"])), pc, None
-    for (name, cfg), start in zip(levels, fps_starts):
+    for li, (name, cfg) in enumerate(levels):
         br = [(cfg["radius"], cfg["nsample"], p + name + "mlp_convs.", p + name + "mlp_bns.")]
-        xyz, feats = _sa_level(sd, br, wc, cfg["npoint"], xyz.contiguous(), feats, start, train, update_running, xyz_first=True)
+        pre = grouped[2 * li:2 * li + 2] if grouped is not None else None
+        start = fps_starts[li] if fps_starts is not None else None
+        xyz, feats = _sa_level(sd, br, wc, cfg["npoint"], xyz.contiguous() if xyz is not None else None, feats, start, train,
+                               update_running, xyz_first=True, pre=pre)
     return _pn2_tail(sd, p, wc, xyz, feats, train, drop_masks, update_running)
 
 

@@ -85,6 +85,36 @@ def shared_text_stream(device=None):
     return _TEXT_STREAMS[dev]
 
 
+class AheadStage:
+    """A shape-static stage that depends on the step's INPUTS only (FPS, ball queries, kNN), replayed on its own stream
+    as soon as the step is called -- under the previous iteration's compute instead of at the head of this one's.  Two
+    captured copies with their own output buffers alternate, because the consumer of the previous outputs may still be
+    running; a copy is reused only after the consumer that read it has finished.  The stage's stream waits for nothing
+    else -- in particular not for the caller's stream: the caller vouches that the inputs are complete in memory."""
+
+    def __init__(self):
+        self.slot = 0
+        self.free = [None, None]
+
+    def run(self, cache, key, fn, ins, side):
+        """fn(*ins) -> (outputs, keepalive) as for GraphedCall.  -> (outputs of this call, slot)."""
+        main = torch.cuda.current_stream()
+        slot = self.slot = 1 - self.slot
+        with torch.cuda.stream(side):
+            if self.free[slot] is not None:
+                side.wait_event(self.free[slot])
+            outs, _ = cache.get(tuple(key) + (slot,), lambda: GraphedCall(fn, ins))(*ins)
+            done = side.record_event()
+        for t in ins:
+            t.record_stream(side)
+        main.wait_event(done)
+        return outs, slot
+
+    def consumed(self, slot):
+        """Call after the consumer of `slot`'s outputs has been queued on the current stream."""
+        self.free[slot] = torch.cuda.current_stream().record_event()
+
+
 _GROUP_STREAMS = {}
 
 

@@ -52,8 +52,12 @@ class Pointnet2_Msg(nn.Module):
     Build-specific knobs: `precision` (bf16 / fp32 parity), `fps_start` = (start1 [B], start2 [B]) and
     `dropout_masks` = (m1 [B,512], m2 [B,256]) to inject the three RNG draws of the path in parity tests."""
     _engine_forward = staticmethod(engine.pointnet2_msg_forward)
+    _group_levels = engine.PN2_MSG_LEVELS
     _graph_tag = "pn2_msg"
     _drop_p = (0.4, 0.5)
+    # FPS + ball queries are ~a quarter of this encoder's time and use 32 workgroups: worth running ahead even though the
+    # encoder is frozen (train.Trainer consults this when the batch is resident)
+    group_ahead_pays_when_frozen = True
 
     def __init__(self, normal_channel=False):
         super().__init__()
@@ -77,6 +81,8 @@ class Pointnet2_Msg(nn.Module):
         self._sd = None
         self._graphs = graphs.GraphCache()
         self.use_hip_graphs = True
+        self.group_ahead = None            # stream for the grouping stage of the next iteration (train.Trainer.inputs_ready)
+        self._ahead = graphs.AheadStage()
 
     def _apply(self, fn, *a, **k):
         self._sd = None
@@ -115,6 +121,29 @@ class Pointnet2_Msg(nn.Module):
             key = (self._graph_tag, tuple(xyz.shape), masks is not None, train, wc.dtype)
             fwd = self._engine_forward
             if xyz.is_cuda and self.use_hip_graphs and ops.profiler is None and self._graphs.ready(key):
+                if self.group_ahead is not None:
+                    # FPS + ball queries of both levels on the grouping stream (graphs.AheadStage), the rest from here
+                    levels = self._group_levels
+                    drawn = self.fps_start is None
+                    n1 = levels[0][0]
+
+                    def gfn(x, *st):
+                        # not injected: the two FPS starts are drawn here, on the grouping stream (the ones drawn above sit on
+                        # the caller's stream, behind the previous tower)
+                        s0, s1 = st if st else (torch.randint(0, N, (B,), dtype=torch.long, device=x.device),
+                                                torch.randint(0, n1, (B,), dtype=torch.long, device=x.device))
+                        return tuple(engine.pointnet2_group(x, (s0, s1), levels)), None
+                    grouped, slot = self._ahead.run(self._graphs, ("pn2_group", tuple(xyz.shape), drawn), gfn,
+                                                    [xyz] + ([] if drawn else [starts[0], starts[1]]), self.group_ahead)
+                    ng = len(grouped)
+                    ins = list(grouped) + (list(masks) if masks is not None else [])
+
+                    def fn2(*a):
+                        m = a[ng:]
+                        return (fwd(sd, "", wc, None, None, train, tuple(m) if m else None, grouped=list(a[:ng])),), None
+                    (feat,), _ = self._graphs.get(key + ("grouped",), lambda: graphs.GraphedCall(fn2, ins))(*ins)
+                    self._ahead.consumed(slot)
+                    return feat.clone()
                 ins = [xyz, starts[0], starts[1]] + (list(masks) if masks is not None else [])
 
                 def fn(x, s0, s1, *m):
@@ -128,6 +157,7 @@ class Pointnet2_Ssg(Pointnet2_Msg):
     """pointnet2.py:6-38: single-scale set abstractions (512 x r0.2 x 32, 128 x r0.4 x 64, group_all), the same FC head
     with Dropout(0.4) twice.  forward(xyz [B,N,3]) -> [B,256]; same knobs as Pointnet2_Msg."""
     _engine_forward = staticmethod(engine.pointnet2_ssg_forward)
+    _group_levels = engine.PN2_SSG_LEVELS
     _graph_tag = "pn2_ssg"
     _drop_p = (0.4, 0.4)
 
@@ -154,3 +184,5 @@ class Pointnet2_Ssg(Pointnet2_Msg):
         self._sd = None
         self._graphs = graphs.GraphCache()
         self.use_hip_graphs = True
+        self.group_ahead = None            # stream for the grouping stage of the next iteration (train.Trainer.inputs_ready)
+        self._ahead = graphs.AheadStage()

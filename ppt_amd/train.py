@@ -150,7 +150,8 @@ class Trainer:
         pe = getattr(model, "point_encoder", None)
         if hasattr(pe, "group_ahead"):
             from . import graphs
-            use = self.inputs_ready and pc.is_cuda and side is not None and (self.group_ahead_when_frozen or not self._point_side_frozen)
+            use = self.inputs_ready and pc.is_cuda and side is not None and (
+                self.group_ahead_when_frozen or not self._point_side_frozen or getattr(pe, "group_ahead_pays_when_frozen", False))
             pe.group_ahead = graphs.shared_group_stream() if use else None
         main = torch.cuda.current_stream() if side is not None else None
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():

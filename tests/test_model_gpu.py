@@ -525,6 +525,44 @@ def test_ulip_pn_mlp_train_step_runs_and_only_prompt_trains():
     assert changed == {"prompt_learner.learnable_tokens"}, changed
 
 
+def test_pointnet2_grouping_ahead_is_identical():
+    """ULIP_PN_MSG training with FPS + ball queries of an iteration replayed on the grouping stream ahead of the step
+    (Trainer.inputs_ready) gives exactly the losses and parameters of the in-order schedule."""
+    from ppt_amd.models import ULIP_models as M
+    from ppt_amd.train import Trainer
+    args = SimpleNamespace(classnames=M.dataset_classnames("modelnet40"), template_init='', class_name_position='middle',
+                           num_learnable_prompt_tokens=32, gpu=0, task='cls', head_type=0, evaluate_3d=False, ulip2=False)
+    B = 4
+    pc_np, s0 = W.synth_clouds(B, 2048, seed=91)
+    _, s1 = W.synth_clouds(B, 512, seed=92)
+    rng = np.random.default_rng(3)
+    dm = (torch.from_numpy((rng.random((B, 512)) > 0.4).astype(np.float32) / 0.6),
+          torch.from_numpy((rng.random((B, 256)) > 0.5).astype(np.float32) / 0.5))
+    label = torch.tensor([1, 5, 9, 30]).cuda()
+    results = []
+    for ahead in (False, True):
+        m = M.ULIP_PN_MSG(args)
+        m.load_state_dict(W.ulip_pn2_msg_state_dict(seed=0), strict=False)
+        m.prompt_learner.embedding = W.synth_prompt_embedding(40, seed=0)
+        m.cuda().train()
+        m.point_encoder.fps_start = (torch.from_numpy(s0).cuda(), torch.from_numpy(s1).cuda())
+        m.point_encoder.dropout_masks = dm
+        tr = Trainer(m, lr=3e-3, label_smoothing=0.2, distributed=False)
+        tr.inputs_ready = ahead
+        losses = []
+        for it in range(6):
+            loss, pred = tr.step(torch.from_numpy(np.roll(pc_np, it, 0)).cuda(), label)
+            losses.append(loss)
+        tr.finish()
+        torch.cuda.synchronize()
+        kinds = sorted(str(k[0]) for k in m.point_encoder._graphs.entries)
+        assert kinds == (["pn2_group", "pn2_group", "pn2_msg"] if ahead else ["pn2_msg"]), kinds
+        results.append(([l.item() for l in losses], pred.clone(), m.prompt_learner.learnable_tokens.detach().clone(),
+                        m.point_encoder.bn2.running_var.clone()))
+    (la, pa, ta, va), (lb, pb, tb, vb) = results
+    assert la == lb and torch.equal(pa, pb) and torch.equal(ta, tb) and torch.equal(va, vb)
+
+
 def test_ulip_pn_msg_train_step_runs_and_only_prompt_trains():
     from ppt_amd.models import ULIP_models as M
     from ppt_amd.train import Trainer
