@@ -123,7 +123,7 @@ def main():
     from ppt_amd import graphs
     graphs.shared_text_stream()        # before RCCL creates its streams: same hardware-queue position as at N = 1
     group_ahead = GROUP_AHEAD and ((CONFIGS[a.config]["head_type"] > 0 and CONFIGS[a.config].get("model", "ULIP_PointBERT") == "ULIP_PointBERT")
-                                   or CONFIGS[a.config].get("model") == "ULIP_PN_MSG")
+                                   or CONFIGS[a.config].get("model") in ("ULIP_PN_MSG", "ULIP_PN_MLP"))
     if group_ahead:                    # (only where Trainer uses it: an extra stream shifts the others' queue positions)
         graphs.shared_group_stream()
     force_dist = os.environ.get("PPT_FORCE_DIST") == "1"      # exercise the RCCL path with a single rank (dev aid)

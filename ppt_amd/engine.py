@@ -514,7 +514,21 @@ def _mlp_res_block(sd, wc, p, x, train, upd, pool=1, x_affine=None):
     return ops.bn_res_act_rows(c2, x, sc2, sh2, T, pool, res_affine=x_affine)
 
 
-def pointmlp_forward(sd, p, wc, pc, fps_starts, train, drop_masks, update_running=True, cfg=None):
+def pointmlp_group(pc, fps_starts, cfg=None):
+    """The grouping of all stages (LocalGrouper's FPS + kNN, pointMLP.py:157-162): a function of the coordinates alone.
+    -> flat list, per stage (anchor indices [B,S], anchor coordinates [B,S,3], neighbour indices [B,S,k])."""
+    cfg = cfg or POINTMLP
+    out, xyz, S = [], pc, cfg["points"]
+    for i in range(len(cfg["reducers"])):
+        S //= cfg["reducers"][i]
+        cidx, new_xyz = ops.fps(xyz, S, fps_starts[i])
+        nidx, _ = ops.knn_group(xyz, new_xyz, cfg["k_neighbors"][i], want_idx=True, want_nbhd=False)
+        out += [cidx, new_xyz, nidx]
+        xyz = new_xyz
+    return out
+
+
+def pointmlp_forward(sd, p, wc, pc, fps_starts, train, drop_masks, update_running=True, cfg=None, grouped=None):
     """Model.forward of pointMLP() / pointMLPElite() (pointMLP.py:320-334): pc [B,N,3] -> [B,256] fp32.
     fps_starts = one start vector [B] per stage (furthest_point_sample's randint, :77); drop_masks = (m1 [B,512],
     m2 [B,256]) or None.  Rows are (cloud, point) / (cloud, group, neighbour) throughout, channels last.
@@ -547,8 +561,11 @@ def pointmlp_forward(sd, p, wc, pc, fps_starts, train, drop_masks, update_runnin
         S //= cfg["reducers"][i]
         k = cfg["k_neighbors"][i]
         d = x.shape[1]
-        cidx, new_xyz = ops.fps(xyz, S, fps_starts[i])
-        nidx, _ = ops.knn_group(xyz, new_xyz, k, want_idx=True, want_nbhd=False)
+        if grouped is not None:                                                  # pointmlp_group ran ahead of the step
+            cidx, new_xyz, nidx = grouped[3 * i:3 * i + 3]
+        else:
+            cidx, new_xyz = ops.fps(xyz, S, fps_starts[i])
+            nidx, _ = ops.knn_group(xyz, new_xyz, k, want_idx=True, want_nbhd=False)
         # per-cloud std of the anchor-centred neighbour features (:174), unbiased, from per-group (sum, sumsq) in fp64
         st = ops.group_anchor_stats(x, nidx, cidx, N).double().sum(1)
         n = float(S * k * d)

@@ -114,6 +114,9 @@ class Model(nn.Module):
         self._sd = None
         self._graphs = graphs.GraphCache()
         self.use_hip_graphs = True
+        self.group_ahead = None            # stream for the grouping stage of the next iteration (train.Trainer.inputs_ready)
+        self.group_ahead_pays_when_frozen = True
+        self._ahead = graphs.AheadStage()
 
     def _apply(self, fn, *a, **k):
         self._sd = None
@@ -166,6 +169,26 @@ class Model(nn.Module):
         with torch.no_grad():            # every parameter of this encoder is frozen in PPT (ULIP_models.py:425-439)
             key = ("pointmlp", tuple(xyz.shape), masks is not None, train, wc.dtype)
             if xyz.is_cuda and self.use_hip_graphs and ops.profiler is None and self._graphs.ready(key):
+                if self.group_ahead is not None:
+                    # FPS + kNN of the four stages on the grouping stream (graphs.AheadStage); starts that are not injected
+                    # are drawn there too (the ones drawn above sit on the caller's stream, behind the previous step)
+                    drawn = self.fps_start is None
+
+                    def gfn(x, *st):
+                        st = st if st else tuple(torch.randint(0, n, (B,), dtype=torch.long, device=x.device) for n in n_src)
+                        return tuple(engine.pointmlp_group(x, st, cfg)), None
+                    grouped, slot = self._ahead.run(self._graphs, ("pointmlp_group", tuple(xyz.shape), drawn), gfn,
+                                                    [xyz] + ([] if drawn else list(starts)), self.group_ahead)
+                    ng = len(grouped)
+                    ins = [xyz] + list(grouped) + (list(masks) if masks is not None else [])
+
+                    def fn2(x_, *a):
+                        m = a[ng:]
+                        return (engine.pointmlp_forward(sd, "", wc, x_, None, train, tuple(m) if m else None, cfg=cfg,
+                                                        grouped=list(a[:ng])),), None
+                    (feat,), _ = self._graphs.get(key + ("grouped",), lambda: graphs.GraphedCall(fn2, ins))(*ins)
+                    self._ahead.consumed(slot)
+                    return feat.clone()
                 ins = [xyz] + list(starts) + (list(masks) if masks is not None else [])
 
                 def fn(x_, *rest):

@@ -513,11 +513,13 @@ def test_ulip_pn_mlp_train_step_runs_and_only_prompt_trains():
     pc = torch.from_numpy(pc_np).cuda()
     label = torch.arange(8, device="cuda") % 40
     before = {k: v.clone() for k, v in m.state_dict().items()}
+    tr.inputs_ready = True            # pc is resident: FPS + kNN of a step run ahead on the grouping stream after warm-up
     losses = []
-    for _ in range(4):
+    for _ in range(6):
         loss, pred = tr.step(pc, label)
         losses.append(loss.item())
     tr.finish()
+    assert sorted(str(k[0]) for k in m.point_encoder._graphs.entries) == ["pointmlp", "pointmlp_group", "pointmlp_group"]
     assert all(np.isfinite(losses)) and pred.shape == (8, 40)
     after = m.state_dict()
     changed = {k for k in before if before[k].dtype.is_floating_point and not torch.equal(before[k], after[k])
