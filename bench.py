@@ -122,8 +122,10 @@ def main():
     torch.cuda.set_device(local)
     from ppt_amd import graphs
     graphs.shared_text_stream()        # before RCCL creates its streams: same hardware-queue position as at N = 1
-    group_ahead = GROUP_AHEAD and ((CONFIGS[a.config]["head_type"] > 0 and CONFIGS[a.config].get("model", "ULIP_PointBERT") == "ULIP_PointBERT")
-                                   or CONFIGS[a.config].get("model") in ("ULIP_PN_MSG", "ULIP_PN_MLP"))
+    frozen_too = os.environ.get("PPT_GROUP_AHEAD_FROZEN") == "1"          # experiment: also for a fully frozen PointBERT (C2)
+    c_ = CONFIGS[a.config]
+    group_ahead = GROUP_AHEAD and (frozen_too or (c_["head_type"] > 0 and c_.get("model", "ULIP_PointBERT") == "ULIP_PointBERT")
+                                   or c_.get("model") in ("ULIP_PN_MSG", "ULIP_PN_MLP"))
     if group_ahead:                    # (only where Trainer uses it: an extra stream shifts the others' queue positions)
         graphs.shared_group_stream()
     force_dist = os.environ.get("PPT_FORCE_DIST") == "1"      # exercise the RCCL path with a single rank (dev aid)
@@ -146,6 +148,7 @@ def main():
     trainer = Trainer(model, lr=3e-3, label_smoothing=0.2, distributed=world > 1 or force_dist)
     # the synthetic batch is resident and complete before the first step: FPS + kNN of a step may start when it is called
     trainer.inputs_ready = group_ahead
+    trainer.group_ahead_when_frozen = frozen_too
     pc_np, _ = W.synth_clouds(PER_GPU_BATCH, NPOINTS, seed=1234 + rank)
     pc = torch.from_numpy(pc_np).cuda()
     lab_shape = (PER_GPU_BATCH, NPOINTS) if partseg else (PER_GPU_BATCH,)
