@@ -161,13 +161,17 @@ class Trainer:
                 g['lr'] = float(self.lr_schedule[min(self.it, len(self.lr_schedule) - 1)])
         if self.bcast is not None and self.broadcast_buffers_every_step:
             self.bcast.broadcast()
-        if self.fused_head and self._point_side_frozen and not self.extra_inputs and hasattr(model, "forward_loss") \
-                and pc.is_cuda and label.dim() == 1:
-            # nothing on the point side trains: logits, loss and the text-feature gradient in one graph-replayed node
-            loss, pred = model.forward_loss(pc, label, self.criterion.label_smoothing)
-        else:
-            pred = model(pc, *self.extra_inputs)                    # main_cls.py:194 / main_partseg.py:210
-            loss = self.criterion(pred.reshape(-1, pred.shape[-1]), label.reshape(-1))     # main_partseg.py:213
+        try:
+            if self.fused_head and self._point_side_frozen and not self.extra_inputs and hasattr(model, "forward_loss") \
+                    and pc.is_cuda and label.dim() == 1:
+                # nothing on the point side trains: logits, loss and the text-feature gradient in one graph-replayed node
+                loss, pred = model.forward_loss(pc, label, self.criterion.label_smoothing)
+            else:
+                pred = model(pc, *self.extra_inputs)                # main_cls.py:194 / main_partseg.py:210
+                loss = self.criterion(pred.reshape(-1, pred.shape[-1]), label.reshape(-1))     # main_partseg.py:213
+        finally:
+            if hasattr(pe, "group_ahead"):
+                pe.group_ahead = None       # the vouching covers this call's `pc` only: a forward outside step() stays in order
         if side is not None:
             side.wait_stream(main)
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():

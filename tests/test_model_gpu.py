@@ -559,6 +559,7 @@ def test_pointnet2_grouping_ahead_is_identical():
         torch.cuda.synchronize()
         kinds = sorted(str(k[0]) for k in m.point_encoder._graphs.entries)
         assert kinds == (["pn2_group", "pn2_group", "pn2_msg"] if ahead else ["pn2_msg"]), kinds
+        assert m.point_encoder.group_ahead is None         # the vouching ends with the step: later forwards run in order
         results.append(([l.item() for l in losses], pred.clone(), m.prompt_learner.learnable_tokens.detach().clone(),
                         m.point_encoder.bn2.running_var.clone()))
     (la, pa, ta, va), (lb, pb, tb, vb) = results
