@@ -196,6 +196,22 @@ int ppt_bn_rows_bwd_apply(const float *dy, const float *x, const float *scale, c
 int ppt_conv1_stats_max_partials(int64_t M);
 int ppt_conv1_stats_rows_per_partial(void);
 
+/* ---- GroupNorm(G, C) + LeakyReLU + max over k of DGCNN_Propagation (models/pointbert/pointnet2_utils.py:371-467), on the
+ * channels-last rows the 1x1 conv writes: y [B][Q][K][C] f32.  Forward: ppt_gn_stats leaves (sum, sumsq) per (cloud, chunk of
+ * rows, group) in part [B][ppt_gn_stats_chunks(Q*K)][G][2] (f64; the caller folds them to mean / rstd [B][G]); ppt_gn_lrelu_max
+ * writes out [B][Q][C] and the maximising neighbour arg [B][Q][C].  Backward: ppt_gn_bwd_sums leaves the two group sums of
+ * the GroupNorm backward in psum [B][ppt_gn_bwd_chunks(Q)][G][2] (f64) and (dgamma, dbeta) partials in pgb [B][chunks][C][2];
+ * ppt_gn_bwd_apply writes dy [B][Q][K][C] given s12n [B][G][2] = the folded sums divided by n = Q*K*C/G. */
+int ppt_gn_stats_chunks(int R);
+int ppt_gn_bwd_chunks(int Q);
+int ppt_gn_stats(const float *y, int B, int R, int C, int G, double *part, void *stream);
+int ppt_gn_lrelu_max(const float *y, const float *mean, const float *rstd, const float *gamma, const float *beta, int B, int Q, int K,
+                     int C, int G, float slope, float *out, int32_t *arg, void *stream);
+int ppt_gn_bwd_sums(const float *y, const float *dout, const float *out, const int32_t *arg, const float *mean, const float *rstd,
+                    const float *gamma, int B, int Q, int K, int C, int G, float slope, double *psum, float *pgb, void *stream);
+int ppt_gn_bwd_apply(const float *y, const float *dout, const float *out, const int32_t *arg, const float *mean, const float *rstd,
+                     const float *gamma, const float *s12n, int B, int Q, int K, int C, int G, float slope, float *dy, void *stream);
+
 /* ---- first half of the PointBERT mini-PointNet in one kernel (Encoder.first_conv + the group max, dvae.py:188-193,206-210):
  * y2[m, :] = W2 . relu(a_scale * (w1 . pts[m] + b1) + a_shift) + bias2 (bf16, [M,N]) and gmax[g, :] = max over the 32 rows of
  * group g (bf16, [M/32, N]).  Same arithmetic as ppt_gemm with PPT_A_CONV1 + bias + pool_max over 32 rows (bit-identical

@@ -69,6 +69,15 @@ _SIGNATURES = {
     "ppt_bn_rows_bwd_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                       c_int, c_int64, c_int, c_void_p, c_void_p]),
     "ppt_bn_finalize_workspace_bytes": (ctypes.c_size_t, [c_int, c_int]),
+    "ppt_gn_stats_chunks": (c_int, [c_int]),
+    "ppt_gn_bwd_chunks": (c_int, [c_int]),
+    "ppt_gn_stats": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ppt_gn_lrelu_max": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
+                                 c_void_p, c_void_p, c_void_p]),
+    "ppt_gn_bwd_sums": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "ppt_gn_bwd_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                 c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "ppt_mini_pointnet_conv12_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                               c_int, c_void_p, c_void_p, c_void_p]),
     "ppt_group_anchor_stats": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

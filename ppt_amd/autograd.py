@@ -84,6 +84,32 @@ class _BatchNormReLURows(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
+class _GroupNormLReLUMax(torch.autograd.Function):
+    """max over k of LeakyReLU(GroupNorm(y)) for the channels-last conv output y [B,Q,K,C] (DGCNN_Propagation,
+    pointbert/pointnet2_utils.py:371-467 -- there: permute to [B,C,Q,K], nn.GroupNorm, nn.LeakyReLU, max(dim=-1)):
+    forward and backward on the HIP kernels of csrc/groupnorm.hip; the normalised tensor is never materialised."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, groups, eps, slope):
+        y = y.contiguous().float()
+        g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        out, arg, mean, rstd = ops.gn_lrelu_max_forward(y, g, b, groups, eps, slope)
+        ctx.save_for_backward(y, out, arg, mean, rstd, g)
+        ctx.groups, ctx.slope = groups, slope
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, out, arg, mean, rstd, g = ctx.saved_tensors
+        dy, dgamma, dbeta = ops.gn_lrelu_max_backward(y, dout.contiguous().float(), out, arg, mean, rstd, g, ctx.groups, ctx.slope)
+        return dy, dgamma, dbeta, None, None, None
+
+
+def group_norm_lrelu_max(y, gn, slope):
+    """y [B,Q,K,C] -> [B,Q,C] for an nn.GroupNorm `gn` over C."""
+    return _GroupNormLReLUMax.apply(y, gn.weight, gn.bias, gn.num_groups, gn.eps, slope)
+
+
 def batch_norm_relu_rows(x, bn, training):
     """F.relu(bn(x)) for x [M,C] and an nn.BatchNorm1d `bn` (momentum must be a number)."""
     return _BatchNormReLURows.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var,

@@ -1,0 +1,183 @@
+// groupnorm.hip -- GroupNorm + LeakyReLU + max over the k neighbours of DGCNN_Propagation (pointbert/pointnet2_utils.py
+// :371-467: Conv2d(1x1, no bias) -> GroupNorm(4, C) -> LeakyReLU(0.2) -> max over k), forward and backward, on the
+// channels-last rows the 1x1 conv GEMM writes: y [B][Q][K][C] fp32.  torch runs this as permute-copy + RowwiseMoments +
+// elementwise + reduce (+ their backward kernels); here the normalised tensor is never written:
+//   forward : (sum, sumsq) per (cloud, row chunk, group) -> [host fold: mean, rstd per (cloud, group)] -> one pass that
+//             normalises, applies LeakyReLU and keeps the maximum over k with its index;
+//   backward: the gradient enters only at the arg-max elements; one pass forms the two group sums of the GroupNorm
+//             backward (and dgamma / dbeta partials), one pass writes dy for every element.
+// All reductions are chunked with a fixed fold order (no atomics).  HBM-bound: y is read once per pass.
+#include "ppt_common.h"
+
+namespace {
+
+constexpr int GN_ROWS = 64;       // rows (q, k) per statistics workgroup
+constexpr int GN_Q = 32;          // query points per backward-sum workgroup
+constexpr int GN_MAXC = 1024;
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__ y, int R, int C, int G, double *__restrict__ part)
+{
+    __shared__ float ssum[GN_MAXC], ssq[GN_MAXC];
+    const int b = blockIdx.y, chunk = blockIdx.x, nch = gridDim.x;
+    const int r0 = chunk * GN_ROWS, r1 = min(R, r0 + GN_ROWS);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f, q = 0.f;
+        for (int r = r0; r < r1; ++r) {
+            const float v = y[((size_t)b * R + r) * C + c];
+            s += v;
+            q = fmaf(v, v, q);
+        }
+        ssum[c] = s;
+        ssq[c] = q;
+    }
+    __syncthreads();
+    const int Cg = C / G;
+    if ((int)threadIdx.x < G) {
+        double s = 0.0, q = 0.0;
+        for (int c = threadIdx.x * Cg; c < ((int)threadIdx.x + 1) * Cg; ++c) { s += (double)ssum[c]; q += (double)ssq[c]; }
+        double *o = part + (((size_t)b * nch + chunk) * G + threadIdx.x) * 2;
+        o[0] = s;
+        o[1] = q;
+    }
+}
+
+// out[b,q,c] = max_j lrelu(gamma[c] * (y[b,q,j,c] - mean[b,g]) * rstd[b,g] + beta[c]), arg = first maximising j
+__global__ __launch_bounds__(256) void gn_lrelu_max_kernel(const float *__restrict__ y, const float *__restrict__ mean,
+                                                            const float *__restrict__ rstd, const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, int64_t total, int Q, int K, int C, int G,
+                                                            float slope, float *__restrict__ out, int32_t *__restrict__ arg)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    const int64_t bq = idx / C;
+    const int b = (int)(bq / Q), g = c / (C / G);
+    const float a = rstd[b * G + g] * gamma[c];
+    const float sh = fmaf(-mean[b * G + g], a, beta[c]);
+    float best = -INFINITY;
+    int bi = 0;
+    for (int j = 0; j < K; ++j) {
+        float v = fmaf(y[(bq * K + j) * C + c], a, sh);
+        v = v > 0.f ? v : slope * v;
+        if (v > best) { best = v; bi = j; }
+    }
+    out[idx] = best;
+    arg[idx] = bi;
+}
+
+// per (cloud b, chunk of GN_Q query points): group sums S1 = sum gamma*t, S2 = sum gamma*t*xhat over the arg-max elements,
+// and per-channel partials of dgamma = sum t*xhat, dbeta = sum t;  t = dout * (out > 0 ? 1 : slope)
+__global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const float *__restrict__ y, const float *__restrict__ dout,
+                                                           const float *__restrict__ out, const int32_t *__restrict__ arg,
+                                                           const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                           const float *__restrict__ gamma, int Q, int K, int C, int G, float slope,
+                                                           double *__restrict__ psum, float *__restrict__ pgb)
+{
+    __shared__ float s1[GN_MAXC], s2[GN_MAXC];
+    const int b = blockIdx.y, chunk = blockIdx.x, nch = gridDim.x;
+    const int q0 = chunk * GN_Q, q1 = min(Q, q0 + GN_Q);
+    const int Cg = C / G;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int g = c / Cg;
+        const float m = mean[b * G + g], rs = rstd[b * G + g], ga = gamma[c];
+        float a1 = 0.f, a2 = 0.f, dg = 0.f, db = 0.f;
+        for (int q = q0; q < q1; ++q) {
+            const int64_t o = ((int64_t)b * Q + q) * C + c;
+            const float t = dout[o] * (out[o] > 0.f ? 1.f : slope);
+            const float xh = (y[(((int64_t)b * Q + q) * K + arg[o]) * C + c] - m) * rs;
+            a1 = fmaf(ga, t, a1);
+            a2 = fmaf(ga * t, xh, a2);
+            dg = fmaf(t, xh, dg);
+            db += t;
+        }
+        s1[c] = a1;
+        s2[c] = a2;
+        float *pg = pgb + (((size_t)b * nch + chunk) * C + c) * 2;
+        pg[0] = dg;
+        pg[1] = db;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < G) {
+        double a = 0.0, d = 0.0;
+        for (int c = threadIdx.x * Cg; c < ((int)threadIdx.x + 1) * Cg; ++c) { a += (double)s1[c]; d += (double)s2[c]; }
+        double *o = psum + (((size_t)b * nch + chunk) * G + threadIdx.x) * 2;
+        o[0] = a;
+        o[1] = d;
+    }
+}
+
+// dy[b,q,j,c] = rstd * ((j == arg ? gamma*t : 0) - (S1 + xhat * S2) / n),  S1/S2 already divided by n on the host
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float *__restrict__ y, const float *__restrict__ dout,
+                                                            const float *__restrict__ out, const int32_t *__restrict__ arg,
+                                                            const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                            const float *__restrict__ gamma, const float *__restrict__ s12n,
+                                                            int64_t total, int Q, int K, int C, int G, float slope,
+                                                            float *__restrict__ dy)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    const int64_t bq = idx / C;
+    const int b = (int)(bq / Q), g = c / (C / G);
+    const float m = mean[b * G + g], rs = rstd[b * G + g];
+    const float S1 = s12n[(b * G + g) * 2], S2 = s12n[(b * G + g) * 2 + 1];
+    const float gt = gamma[c] * dout[idx] * (out[idx] > 0.f ? 1.f : slope);
+    const int am = arg[idx];
+    for (int j = 0; j < K; ++j) {
+        const int64_t e = (bq * K + j) * C + c;
+        const float xh = (y[e] - m) * rs;
+        dy[e] = rs * ((j == am ? gt : 0.f) - fmaf(xh, S2, S1));
+    }
+}
+
+}  // namespace
+
+extern "C" int ppt_gn_stats_chunks(int R) { return (R + GN_ROWS - 1) / GN_ROWS; }
+extern "C" int ppt_gn_bwd_chunks(int Q) { return (Q + GN_Q - 1) / GN_Q; }
+
+extern "C" int ppt_gn_stats(const float *y, int B, int R, int C, int G, double *part, void *stream)
+{
+    if (!y || !part || B <= 0 || R <= 0 || C <= 0 || G <= 0 || C % G || C > GN_MAXC || G > 256) return PPT_EINVAL;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(ppt_gn_stats_chunks(R), B), dim3(256), 0, ppt_stream(stream), y, R, C, G, part);
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
+extern "C" int ppt_gn_lrelu_max(const float *y, const float *mean, const float *rstd, const float *gamma, const float *beta, int B,
+                                int Q, int K, int C, int G, float slope, float *out, int32_t *arg, void *stream)
+{
+    if (!y || !mean || !rstd || !gamma || !beta || !out || !arg || B <= 0 || Q <= 0 || K <= 0 || C <= 0 || G <= 0 || C % G)
+        return PPT_EINVAL;
+    const int64_t total = (int64_t)B * Q * C;
+    hipLaunchKernelGGL(gn_lrelu_max_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ppt_stream(stream), y, mean, rstd,
+                       gamma, beta, total, Q, K, C, G, slope, out, arg);
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
+extern "C" int ppt_gn_bwd_sums(const float *y, const float *dout, const float *out, const int32_t *arg, const float *mean,
+                               const float *rstd, const float *gamma, int B, int Q, int K, int C, int G, float slope, double *psum,
+                               float *pgb, void *stream)
+{
+    if (!y || !dout || !out || !arg || !mean || !rstd || !gamma || !psum || !pgb || B <= 0 || Q <= 0 || K <= 0 || C <= 0 ||
+        G <= 0 || C % G || C > GN_MAXC || G > 256)
+        return PPT_EINVAL;
+    hipLaunchKernelGGL(gn_bwd_sums_kernel, dim3(ppt_gn_bwd_chunks(Q), B), dim3(256), 0, ppt_stream(stream), y, dout, out, arg, mean,
+                       rstd, gamma, Q, K, C, G, slope, psum, pgb);
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
+extern "C" int ppt_gn_bwd_apply(const float *y, const float *dout, const float *out, const int32_t *arg, const float *mean,
+                                const float *rstd, const float *gamma, const float *s12n, int B, int Q, int K, int C, int G,
+                                float slope, float *dy, void *stream)
+{
+    if (!y || !dout || !out || !arg || !mean || !rstd || !gamma || !s12n || !dy || B <= 0 || Q <= 0 || K <= 0 || C <= 0 || G <= 0 ||
+        C % G)
+        return PPT_EINVAL;
+    const int64_t total = (int64_t)B * Q * C;
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ppt_stream(stream), y, dout, out, arg,
+                       mean, rstd, gamma, s12n, total, Q, K, C, G, slope, dy);
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}

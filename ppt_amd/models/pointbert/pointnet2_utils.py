@@ -10,7 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import ops
-from ...autograd import batch_norm_relu_rows, linear
+from ...autograd import batch_norm_relu_rows, group_norm_lrelu_max, linear
 from .dvae import knn_point, square_distance          # noqa: F401  (same semantics as pointnet2_utils.py:20-72)
 from .misc import farthest_point_sample, index_points  # noqa: F401
 
@@ -79,9 +79,7 @@ class DGCNN_Propagation(nn.Module):
     def _layer(self, seq, g):
         conv, gn = seq[0], seq[1]
         y = linear(g, conv.weight, None, self.precision)                       # [B,Nq,k,Cout]
-        y = F.group_norm(y.permute(0, 3, 1, 2), gn.num_groups, gn.weight, gn.bias, gn.eps)
-        y = F.leaky_relu(y, 0.2)
-        return y.max(dim=-1)[0].permute(0, 2, 1)                               # [B,Nq,Cout]
+        return group_norm_lrelu_max(y, gn, 0.2)                                # GroupNorm + LeakyReLU(0.2) + max over k: [B,Nq,Cout]
 
     def forward(self, coor, f, coor_q, f_q):
         f_q = self._layer(self.layer1, self.get_graph_feature(coor_q, f_q, coor, f))

@@ -351,6 +351,48 @@ def bn_act_rows(x, scale, shift, y_dtype, mask=None):
     return y
 
 
+def gn_lrelu_max_forward(y, gamma, beta, groups, eps, slope):
+    """y [B,Q,K,C] f32 -> (out [B,Q,C], arg [B,Q,C] i32, mean [B,G], rstd [B,G]): GroupNorm(groups) + LeakyReLU(slope) +
+    max over K (DGCNN_Propagation, pointbert/pointnet2_utils.py:371-467)."""
+    _chk(y, torch.float32, "y")
+    B, Q, K, C = y.shape
+    L = _lib.lib()
+    nch = L.ppt_gn_stats_chunks(Q * K)
+    part = torch.empty((B, nch, groups, 2), dtype=torch.float64, device=y.device)
+    _lib.check(L.ppt_gn_stats(_p(y), B, Q * K, C, groups, _p(part), _stream()), "ppt_gn_stats")
+    s = part.sum(1)                                                   # [B,G,2], fixed order
+    n = float(Q * K * (C // groups))
+    mean = s[..., 0] / n
+    var = (s[..., 1] / n - mean * mean).clamp_min(0.0)                # biased, as nn.GroupNorm
+    rstd = (var + eps).rsqrt()
+    mean, rstd = mean.float().contiguous(), rstd.float().contiguous()
+    out = torch.empty((B, Q, C), dtype=torch.float32, device=y.device)
+    arg = torch.empty((B, Q, C), dtype=torch.int32, device=y.device)
+    _lib.check(L.ppt_gn_lrelu_max(_p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), B, Q, K, C, groups, slope, _p(out), _p(arg),
+                                  _stream()), "ppt_gn_lrelu_max")
+    return out, arg, mean, rstd
+
+
+def gn_lrelu_max_backward(y, dout, out, arg, mean, rstd, gamma, groups, slope):
+    """-> (dy [B,Q,K,C], dgamma [C], dbeta [C])."""
+    _chk(y, torch.float32, "y"); _chk(dout, torch.float32, "dout")
+    B, Q, K, C = y.shape
+    L = _lib.lib()
+    nch = L.ppt_gn_bwd_chunks(Q)
+    psum = torch.empty((B, nch, groups, 2), dtype=torch.float64, device=y.device)
+    pgb = torch.empty((B, nch, C, 2), dtype=torch.float32, device=y.device)
+    _lib.check(L.ppt_gn_bwd_sums(_p(y), _p(dout), _p(out), _p(arg), _p(mean), _p(rstd), _p(gamma), B, Q, K, C, groups, slope,
+                                 _p(psum), _p(pgb), _stream()), "ppt_gn_bwd_sums")
+    n = float(Q * K * (C // groups))
+    s12n = (psum.sum(1) / n).float().contiguous()                     # [B,G,2]
+    gb = reduce_rows(pgb.view(B * nch, 2 * C))                        # [2C] interleaved (dgamma, dbeta)
+    dy = torch.empty_like(y)
+    _lib.check(L.ppt_gn_bwd_apply(_p(y), _p(dout), _p(out), _p(arg), _p(mean), _p(rstd), _p(gamma), _p(s12n), B, Q, K, C, groups,
+                                  slope, _p(dy), _stream()), "ppt_gn_bwd_apply")
+    gb = gb.view(C, 2)
+    return dy, gb[:, 0].contiguous(), gb[:, 1].contiguous()
+
+
 def mini_pointnet_conv12(pts, w1, b1, a_scale, a_shift, w2, bias2):
     """pts [M,3] f32 -> (y2 [M,256] bf16, gmax [M/32,256] bf16): conv1 + folded BN + ReLU + conv2 + bias and the max over
     each group of 32 rows, one kernel (ppt_mini_pointnet_conv12_bf16).  w2 [256,128] bf16."""

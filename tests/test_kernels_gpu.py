@@ -581,3 +581,31 @@ def test_mini_pointnet_conv12_is_the_prologue_gemm(ops, groups):
     ref = a.to(torch.bfloat16).double() @ w2.double().t() + b2.double()
     assert (y2.double() - ref).abs().max().item() < 2e-2 * max(1.0, ref.abs().max().item())
     assert torch.equal(gm, y2.view(groups, 32, 256).float().amax(1).to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("B,Q,K,C", [(2, 100, 4, 512), (3, 257, 4, 384), (1, 33, 16, 64)])
+def test_group_norm_lrelu_max_matches_torch(B, Q, K, C):
+    """csrc/groupnorm.hip (DGCNN_Propagation's GroupNorm(4) + LeakyReLU(0.2) + max over k) against torch autograd of the
+    reference formulation: permute to [B,C,Q,K], F.group_norm, F.leaky_relu, max(dim=-1) -- values and all three gradients."""
+    from ppt_amd.autograd import group_norm_lrelu_max
+    g = torch.Generator(device="cuda").manual_seed(B * Q + C)
+    y0 = torch.randn(B, Q, K, C, device="cuda", generator=g) * 1.5 + 0.3
+    gn = torch.nn.GroupNorm(4, C).cuda()
+    with torch.no_grad():
+        gn.weight.copy_(1.0 + 0.2 * torch.randn(C, device="cuda", generator=g))
+        gn.bias.copy_(0.1 * torch.randn(C, device="cuda", generator=g))
+    dout = torch.randn(B, Q, C, device="cuda", generator=g)
+    res = []
+    for native in (True, False):
+        y = y0.clone().requires_grad_(True)
+        gn.zero_grad()
+        if native:
+            out = group_norm_lrelu_max(y, gn, 0.2)
+        else:
+            z = torch.nn.functional.group_norm(y.double().permute(0, 3, 1, 2), 4, gn.weight.double(), gn.bias.double(), gn.eps)
+            out = torch.nn.functional.leaky_relu(z, 0.2).max(dim=-1)[0].permute(0, 2, 1)
+        out.backward(dout.to(out.dtype))
+        res.append((out.detach().double(), y.grad.double(), gn.weight.grad.double().clone(), gn.bias.grad.double().clone()))
+    for a, b, name in zip(res[0], res[1], ("out", "dy", "dgamma", "dbeta")):
+        scale = max(1.0, b.abs().max().item())
+        assert (a - b).abs().max().item() < 2e-4 * scale, name
