@@ -110,6 +110,38 @@ def group_norm_lrelu_max(y, gn, slope):
     return _GroupNormLReLUMax.apply(y, gn.weight, gn.bias, gn.num_groups, gn.eps, slope)
 
 
+class _GatherAddRows(torch.autograd.Function):
+    """y[b,q,j,:] = P[b, idx[b,q,j], :] + Q[b,q,:] (ppt_gather_add) with gradients for P and Q.  The gradient of P is a
+    scatter-add over idx: index_put_(accumulate=True), the sort-based deterministic kernel advanced indexing also uses."""
+
+    @staticmethod
+    def forward(ctx, P, Q, idx):
+        B, S, C = P.shape
+        y, _ = ops.gather_add(P.reshape(B * S, C).float().contiguous(), Q.reshape(-1, C).float().contiguous(), idx.contiguous(), S,
+                              torch.float32, want_stats=False)
+        ctx.save_for_backward(idx)
+        ctx.S = S
+        return y.view(B, idx.shape[1], idx.shape[2], C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        B, Nq, K, C = dy.shape
+        dQ = dy.sum(2) if ctx.needs_input_grad[1] else None
+        dP = None
+        if ctx.needs_input_grad[0]:
+            flat = (idx + torch.arange(B, device=idx.device).view(B, 1, 1) * ctx.S).reshape(-1)
+            dP = torch.zeros((B * ctx.S, C), dtype=dy.dtype, device=dy.device)
+            dP.index_put_((flat,), dy.reshape(-1, C), accumulate=True)
+            dP = dP.view(B, ctx.S, C)
+        return dP, dQ, None
+
+
+def gather_add_rows(P, Q, idx):
+    """P [B,S,C], Q [B,Nq,C], idx [B,Nq,k] -> [B,Nq,k,C]."""
+    return _GatherAddRows.apply(P, Q, idx)
+
+
 def batch_norm_relu_rows(x, bn, training):
     """F.relu(bn(x)) for x [M,C] and an nn.BatchNorm1d `bn` (momentum must be a number)."""
     return _BatchNormReLURows.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var,

@@ -10,7 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import ops
-from ...autograd import batch_norm_relu_rows, group_norm_lrelu_max, linear
+from ...autograd import batch_norm_relu_rows, gather_add_rows, group_norm_lrelu_max, linear
 from .dvae import knn_point, square_distance          # noqa: F401  (same semantics as pointnet2_utils.py:20-72)
 from .misc import farthest_point_sample, index_points  # noqa: F401
 
@@ -76,12 +76,25 @@ class DGCNN_Propagation(nn.Module):
         xq = x_q.unsqueeze(2).expand(-1, -1, self.k, -1)
         return torch.cat((nb - xq, xq), dim=-1)
 
-    def _layer(self, seq, g):
+    def _layer(self, seq, coor_q, x_q, coor_k, x_k):
+        """conv(cat(x_k[nn] - x_q, x_q)) + GroupNorm + LeakyReLU + max over the k neighbours (:404-440).  The 1x1 conv is
+        linear, W = [Wa | Wb]: Wa.(x_j - x_q) + Wb.x_q = Wa.x_j + (Wb - Wa).x_q -- so it runs once per SOURCE point and once
+        per query point (k times fewer rows, half the channels) and ppt_gather_add forms the [B,Nq,k,Cout] rows; the
+        gathered / concatenated graph feature is never built."""
         conv, gn = seq[0], seq[1]
-        y = linear(g, conv.weight, None, self.precision)                       # [B,Nq,k,Cout]
+        with torch.no_grad():
+            idx, _ = ops.knn_group(coor_k.contiguous(), coor_q.contiguous(), self.k, want_nbhd=False)
+        assert idx.shape[2] == self.k
+        C = x_q.shape[-1]
+        w = conv.weight.reshape(conv.weight.shape[0], -1)
+        wa = w[:, :C].contiguous()
+        wd = (w[:, C:] - w[:, :C]).contiguous()
+        P = linear(x_k, wa, None, self.precision)                              # [B,S,Cout]
+        Q = linear(x_q, wd, None, self.precision)                              # [B,Nq,Cout]
+        y = gather_add_rows(P, Q, idx)                                         # [B,Nq,k,Cout]
         return group_norm_lrelu_max(y, gn, 0.2)                                # GroupNorm + LeakyReLU(0.2) + max over k: [B,Nq,Cout]
 
     def forward(self, coor, f, coor_q, f_q):
-        f_q = self._layer(self.layer1, self.get_graph_feature(coor_q, f_q, coor, f))
-        f_q = self._layer(self.layer2, self.get_graph_feature(coor_q, f_q, coor_q, f_q))
+        f_q = self._layer(self.layer1, coor_q, f_q, coor, f)
+        f_q = self._layer(self.layer2, coor_q, f_q, coor_q, f_q)
         return f_q

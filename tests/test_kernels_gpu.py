@@ -609,3 +609,36 @@ def test_group_norm_lrelu_max_matches_torch(B, Q, K, C):
     for a, b, name in zip(res[0], res[1], ("out", "dy", "dgamma", "dbeta")):
         scale = max(1.0, b.abs().max().item())
         assert (a - b).abs().max().item() < 2e-4 * scale, name
+
+
+def test_dgcnn_layer_matches_the_graph_feature_formulation():
+    """DGCNN_Propagation._layer (conv per source / query point + ppt_gather_add + fused GroupNorm/LeakyReLU/max) against the
+    reference formulation built with torch ops: conv(cat(x_k[nn] - x_q, x_q)) -> GroupNorm -> LeakyReLU -> max; values and the
+    gradients of both inputs and of the conv / norm parameters, fp32 mode."""
+    from ppt_amd.models.pointbert.pointnet2_utils import DGCNN_Propagation
+    torch.manual_seed(11)
+    B, S, Nq, C = 2, 96, 160, 384
+    m = DGCNN_Propagation(k=4).cuda()
+    m.precision = torch.float32
+    coor = torch.randn(B, S, 3, device="cuda")
+    coor_q = torch.randn(B, Nq, 3, device="cuda")
+    f0, fq0 = torch.randn(B, S, C, device="cuda"), torch.randn(B, Nq, C, device="cuda")
+    dout = torch.randn(B, Nq, 512, device="cuda")
+    res = []
+    for native in (True, False):
+        f, fq = f0.clone().requires_grad_(True), fq0.clone().requires_grad_(True)
+        m.zero_grad()
+        if native:
+            out = m._layer(m.layer1, coor_q, fq, coor, f)
+        else:
+            g = m.get_graph_feature(coor_q, fq, coor, f).double()                       # [B,Nq,k,2C]
+            w = m.layer1[0].weight.reshape(512, -1).double()
+            y = (g @ w.t()).permute(0, 3, 1, 2)
+            gn = m.layer1[1]
+            y = torch.nn.functional.leaky_relu(torch.nn.functional.group_norm(y, 4, gn.weight.double(), gn.bias.double(), gn.eps), 0.2)
+            out = y.max(dim=-1)[0].permute(0, 2, 1)
+        out.backward(dout.to(out.dtype))
+        res.append([t.double() for t in (out.detach(), f.grad, fq.grad, m.layer1[0].weight.grad.clone(), m.layer1[1].weight.grad.clone(),
+                                         m.layer1[1].bias.grad.clone())])
+    for a, b, name in zip(res[0], res[1], ("out", "df", "dfq", "dW", "dgamma", "dbeta")):
+        assert (a - b).abs().max().item() < 2e-3 * max(1.0, b.abs().max().item()), name
