@@ -220,6 +220,13 @@ int ppt_mini_pointnet_conv12_bf16(const float *pts, int64_t M, const float *w1, 
                                   const float *a_shift, int C1, const void *W2, const float *bias2, int N, void *y2, void *gmax,
                                   void *stream);
 
+/* The same product with BatchNorm partials of its output instead of the group max -- the first two convs of a PointNet2
+ * set-abstraction branch that sees raw coordinates (models/pointnet2/pointnet2_utils.py:168-199, 217-262): y2 [M,N] bf16,
+ * part_sum / part_m2 [M/32, N] f32 = per 32-row chunk (sum, sum (v - chunk mean)^2), what ppt_bn_finalize_ws takes with
+ * rows_per_partial = 32.  (C1, N) in {(32,32), (64,64), (64,96), (64,128), (128,128)}, M % 32 == 0; bias2 may be NULL. */
+int ppt_conv12_stats_bf16(const float *pts, int64_t M, const float *w1, const float *b1, const float *a_scale, const float *a_shift,
+                          int C1, const void *W2, const float *bias2, int N, void *y2, float *part_sum, float *part_m2, void *stream);
+
 /* ---- PointMLP (models/pointmlp/pointMLP.py) pieces outside the GEMM / BatchNorm / gather kernels above.
  * ppt_group_anchor_stats: LocalGrouper normalize="anchor" (:170-175): out[(b*S+s)*2 + {0,1}] = sum, sum of squares over
  *   j < K, c < D of x[b*Nsrc + idx[b,s,j], c] - x[b*Nsrc + anchor[b,s], c]; x [B*Nsrc, D] f32 or bf16.

@@ -380,8 +380,13 @@ def _sa_level(sd, branches, wc, npoint, xyz, feats, start, train, upd, xyz_first
                 ps, pq, rpp0 = ops.conv1_stats(pts, w03, b0)
                 part0 = (ps, pq)
             sc0, sh0 = _bn_affine(sd, bb + "0.", train, part0, rpp0, M, upd)
-            y1 = ops.gemm(None, wc.get(sd[cb + "1.weight"]), out_dtype=T, a_mode=A_CONV1, pts=pts, w1=w03, b1=b0,
-                          a_scale=sc0, a_shift=sh0, bias=sd[cb + "1.bias"], col_stats=st1)
+            w1c = wc.get(sd[cb + "1.weight"])
+            if (T == torch.bfloat16 and FUSED_CONV12 and train and M % 32 == 0 and w1c.stride(0) == w1c.shape[1]
+                    and (w1c.shape[1], w1c.shape[0]) in ops.CONV12_STATS_SHAPES):
+                y1, st1 = ops.conv12_stats(pts, w03, b0, sc0, sh0, w1c, sd[cb + "1.bias"])     # csrc/mpn1.hip: no tile staging
+            else:
+                y1 = ops.gemm(None, w1c, out_dtype=T, a_mode=A_CONV1, pts=pts, w1=w03, b1=b0,
+                              a_scale=sc0, a_shift=sh0, bias=sd[cb + "1.bias"], col_stats=st1)
         else:
             # layer 0 by linearity of the 1x1 conv: per source point P = W.[feat|xyz], per centre Q = b - W_xyz.c
             D = feats.shape[1]

@@ -410,6 +410,27 @@ def mini_pointnet_conv12(pts, w1, b1, a_scale, a_shift, w2, bias2):
     return y2, gmax
 
 
+CONV12_STATS_SHAPES = {(32, 32), (64, 64), (64, 96), (64, 128), (128, 128)}      # (C1, N) ppt_conv12_stats_bf16 is built for
+
+
+def conv12_stats(pts, w1, b1, a_scale, a_shift, w2, bias2):
+    """pts [M,3] f32 -> (y2 [M,N] bf16, (part_sum, part_m2) [M/32, N]): conv1 + folded BN + ReLU + conv2 (+ bias) with the
+    BatchNorm partials of the output, one barrier-free kernel (ppt_conv12_stats_bf16).  w2 [N,C1] bf16."""
+    _chk(pts, torch.float32, "pts"); _chk(w2, torch.bfloat16, "w2")
+    M = pts.shape[0]
+    N, C1 = w2.shape
+    y2 = torch.empty((M, N), dtype=torch.bfloat16, device=pts.device)
+    ps = torch.empty((M // 32, N), dtype=torch.float32, device=pts.device)
+    pm = torch.empty_like(ps)
+    if profiler is not None:
+        profiler.begin("gemm_bf16", 2.0 * M * N * C1)
+    _lib.check(_lib.lib().ppt_conv12_stats_bf16(_p(pts), M, _p(w1), _p(b1), _p(a_scale), _p(a_shift), C1, _p(w2), _p(bias2), N,
+                                                _p(y2), _p(ps), _p(pm), _stream()), "ppt_conv12_stats_bf16")
+    if profiler is not None:
+        profiler.end()
+    return y2, (ps, pm)
+
+
 def group_anchor_stats(x, idx, anchor, Nsrc):
     """x [B*Nsrc, D] (f32 | bf16), idx [B,S,K], anchor [B,S] -> [B,S,2] f32: (sum, sum of squares) of x[idx] - x[anchor] per
     group (the statistic behind LocalGrouper's per-cloud std, pointMLP.py:170-175)."""

@@ -642,3 +642,31 @@ def test_dgcnn_layer_matches_the_graph_feature_formulation():
                                          m.layer1[1].bias.grad.clone())])
     for a, b, name in zip(res[0], res[1], ("out", "df", "dfq", "dW", "dgamma", "dbeta")):
         assert (a - b).abs().max().item() < 2e-3 * max(1.0, b.abs().max().item()), name
+
+
+@pytest.mark.parametrize("C1,N", [(32, 32), (64, 64), (64, 96), (64, 128), (128, 128)])
+def test_conv12_stats_is_the_prologue_gemm(ops, C1, N):
+    """ppt_conv12_stats_bf16 against ppt_gemm(PPT_A_CONV1 + bias + column statistics): bit-identical y, and BatchNorm
+    partials that finalise to the same scale / shift."""
+    g = torch.Generator(device="cuda").manual_seed(C1 + N)
+    M = 32 * 777
+    pts = torch.randn(M, 3, device="cuda", generator=g) * 0.3
+    w1 = torch.randn(C1, 3, device="cuda", generator=g)
+    b1 = torch.randn(C1, device="cuda", generator=g) * 0.1
+    sc = 1.0 + 0.1 * torch.randn(C1, device="cuda", generator=g)
+    sh = 0.1 * torch.randn(C1, device="cuda", generator=g)
+    w2 = (torch.randn(N, C1, device="cuda", generator=g) / C1 ** 0.5).to(torch.bfloat16)
+    b2 = torch.randn(N, device="cuda", generator=g) * 0.1
+    y, (ps, pm) = ops.conv12_stats(pts, w1, b1, sc, sh, w2, b2)
+    rs = torch.empty((M // 32, N), dtype=torch.float32, device="cuda")
+    rm = torch.empty_like(rs)
+    y_ref = ops.gemm(None, w2, out_dtype=torch.bfloat16, a_mode=ops.A_CONV1, pts=pts, w1=w1, b1=b1, a_scale=sc, a_shift=sh, bias=b2,
+                     col_stats=(rs, rm))
+    assert torch.equal(y, y_ref)
+    assert (ps - rs).abs().max().item() < 1e-4 * max(1.0, rs.abs().max().item())
+    assert (pm - rm).abs().max().item() < 1e-3 * max(1.0, rm.abs().max().item())
+    gamma, beta = torch.ones(N, device="cuda"), torch.zeros(N, device="cuda")
+    a = ops.bn_finalize(gamma, beta, True, partials=(ps, pm), rows_per_partial=32, count=M, update_running=False)
+    b = ops.bn_finalize(gamma, beta, True, partials=(rs, rm), rows_per_partial=32, count=M, update_running=False)
+    for u, v in zip(a, b):
+        assert (u - v).abs().max().item() < 1e-4 * max(1.0, v.abs().max().item())
