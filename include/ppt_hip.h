@@ -227,6 +227,16 @@ int ppt_mini_pointnet_conv12_bf16(const float *pts, int64_t M, const float *w1, 
 int ppt_conv12_stats_bf16(const float *pts, int64_t M, const float *w1, const float *b1, const float *a_scale, const float *a_shift,
                           int C1, const void *W2, const float *bias2, int N, void *y2, float *part_sum, float *part_m2, void *stream);
 
+/* ---- last conv of a PointNet2 set-abstraction branch (models/pointnet2/pointnet2_utils.py:186-206, 236-266) without tile
+ * staging: v = relu(a_scale * A + a_shift) @ W^T + bias over A [M,K] bf16 (row stride lda), W [N,K] bf16; v is not written:
+ * part_sum / part_m2 [M/32, N] = BatchNorm partials per 32-row chunk, pmax / pmin [M/pool_rows, N] f32 = max / min of v
+ * over every pool_rows consecutive rows (ppt_pool_finish folds and finishes).  Same results as ppt_gemm with
+ * PPT_A_AFFINE_RELU + pool_max/pool_min + col_sum.  (K, N, pool_rows) in {(32,64,16), (64,128,32), (96,128,64), (128,256,64)};
+ * anything else: PPT_EUNSUPPORTED. */
+int ppt_affine_conv_pool_bf16(const void *A, int64_t lda, int64_t M, int K, const float *a_scale, const float *a_shift, const void *W,
+                              const float *bias, int N, int pool_rows, float *pmax, float *pmin, float *part_sum, float *part_m2,
+                              void *stream);
+
 /* ---- PointMLP (models/pointmlp/pointMLP.py) pieces outside the GEMM / BatchNorm / gather kernels above.
  * ppt_group_anchor_stats: LocalGrouper normalize="anchor" (:170-175): out[(b*S+s)*2 + {0,1}] = sum, sum of squares over
  *   j < K, c < D of x[b*Nsrc + idx[b,s,j], c] - x[b*Nsrc + anchor[b,s], c]; x [B*Nsrc, D] f32 or bf16.

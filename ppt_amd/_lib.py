@@ -82,6 +82,8 @@ _SIGNATURES = {
                                               c_int, c_void_p, c_void_p, c_void_p]),
     "ppt_conv12_stats_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                       c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ppt_affine_conv_pool_bf16": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ppt_group_anchor_stats": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ppt_bn_res_act_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int, c_void_p]),

@@ -410,8 +410,13 @@ def _sa_level(sd, branches, wc, npoint, xyz, feats, start, train, upd, xyz_first
         pmax = torch.empty((M // pr, C3), dtype=torch.float32, device=dev)
         pmin = torch.empty_like(pmax)
         st2 = _stats_bufs(M, C3, dev, train)
-        ops.gemm(y1, wc.get(sd[cb + "2.weight"]), a_mode=A_AFFINE_RELU, a_scale=sc1, a_shift=sh1, bias=sd[cb + "2.bias"],
-                 want_out=False, pool_max=pmax, pool_min=pmin, pool_rows=pr, col_stats=st2)
+        w2c = wc.get(sd[cb + "2.weight"])
+        if (T == torch.bfloat16 and FUSED_CONV12 and train and M % 64 == 0 and y1.is_contiguous() and w2c.stride(0) == w2c.shape[1]
+                and (w2c.shape[1], C3, pr) in ops.AFFINE_CONV_POOL_SHAPES):
+            ops.affine_conv_pool(y1, sc1, sh1, w2c, sd[cb + "2.bias"], pr, pmax, pmin, st2)      # csrc/affpool.hip: no tile staging
+        else:
+            ops.gemm(y1, w2c, a_mode=A_AFFINE_RELU, a_scale=sc1, a_shift=sh1, bias=sd[cb + "2.bias"],
+                     want_out=False, pool_max=pmax, pool_min=pmin, pool_rows=pr, col_stats=st2)
         sc2, sh2 = _bn_affine(sd, bb + "2.", train, st2, 32, M, upd)
         ops.pool_finish(pmax, pmin, K // pr, sc2, sh2, out[:, col:col + C3])
         col += C3

@@ -431,6 +431,24 @@ def conv12_stats(pts, w1, b1, a_scale, a_shift, w2, bias2):
     return y2, (ps, pm)
 
 
+AFFINE_CONV_POOL_SHAPES = {(32, 64, 16), (64, 128, 32), (96, 128, 64), (128, 256, 64)}     # (K, N, pool_rows)
+
+
+def affine_conv_pool(A, a_scale, a_shift, w, bias, pool_rows, pmax, pmin, col_stats):
+    """relu(a_scale * A + a_shift) @ w^T + bias, not written: BatchNorm partials into col_stats = (sum, M2) [M/32, N] and the
+    max / min over every pool_rows rows into pmax / pmin (ppt_affine_conv_pool_bf16)."""
+    _chk(A, torch.bfloat16, "A"); _chk(w, torch.bfloat16, "w")
+    M, K = A.shape
+    N = w.shape[0]
+    if profiler is not None:
+        profiler.begin("gemm_bf16", 2.0 * M * N * K)
+    _lib.check(_lib.lib().ppt_affine_conv_pool_bf16(_p(A), A.stride(0), M, K, _p(a_scale), _p(a_shift), _p(w), _p(bias), N, pool_rows,
+                                                    _p(pmax), _p(pmin), _p(col_stats[0]), _p(col_stats[1]), _stream()),
+               "ppt_affine_conv_pool_bf16")
+    if profiler is not None:
+        profiler.end()
+
+
 def group_anchor_stats(x, idx, anchor, Nsrc):
     """x [B*Nsrc, D] (f32 | bf16), idx [B,S,K], anchor [B,S] -> [B,S,2] f32: (sum, sum of squares) of x[idx] - x[anchor] per
     group (the statistic behind LocalGrouper's per-cloud std, pointMLP.py:170-175)."""

@@ -670,3 +670,31 @@ def test_conv12_stats_is_the_prologue_gemm(ops, C1, N):
     b = ops.bn_finalize(gamma, beta, True, partials=(rs, rm), rows_per_partial=32, count=M, update_running=False)
     for u, v in zip(a, b):
         assert (u - v).abs().max().item() < 1e-4 * max(1.0, v.abs().max().item())
+
+
+@pytest.mark.parametrize("K,N,pr", [(32, 64, 16), (64, 128, 32), (96, 128, 64), (128, 256, 64)])
+def test_affine_conv_pool_is_the_prologue_gemm(ops, K, N, pr):
+    """ppt_affine_conv_pool_bf16 against ppt_gemm(PPT_A_AFFINE_RELU + bias + pool max/min + column statistics): bit-identical
+    maxima and minima, BatchNorm partials equal to rounding."""
+    g = torch.Generator(device="cuda").manual_seed(K + N)
+    M = 64 * 301
+    A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    sc = 1.0 + 0.2 * torch.randn(K, device="cuda", generator=g)
+    sh = 0.2 * torch.randn(K, device="cuda", generator=g)
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda", generator=g) * 0.1
+
+    def bufs():
+        return (torch.empty((M // pr, N), dtype=torch.float32, device="cuda"), torch.empty((M // pr, N), dtype=torch.float32, device="cuda"),
+                (torch.empty((M // 32, N), dtype=torch.float32, device="cuda"), torch.empty((M // 32, N), dtype=torch.float32, device="cuda")))
+    pmax, pmin, st = bufs()
+    ops.affine_conv_pool(A, sc, sh, w, b, pr, pmax, pmin, st)
+    rmax, rmin, rst = bufs()
+    ops.gemm(A, w, a_mode=ops.A_AFFINE_RELU, a_scale=sc, a_shift=sh, bias=b, want_out=False, pool_max=rmax, pool_min=rmin, pool_rows=pr,
+             col_stats=rst)
+    assert torch.equal(pmax, rmax) and torch.equal(pmin, rmin)
+    assert (st[0] - rst[0]).abs().max().item() < 1e-4 * max(1.0, rst[0].abs().max().item())
+    assert (st[1] - rst[1]).abs().max().item() < 1e-3 * max(1.0, rst[1].abs().max().item())
+    a = torch.relu(A.double() * sc.double() + sh.double()).to(torch.bfloat16).double()
+    v = a @ w.double().t() + b.double()
+    assert (pmax.double() - v.view(M // pr, pr, N).amax(1)).abs().max().item() < 2e-4 * max(1.0, v.abs().max().item())
