@@ -220,6 +220,13 @@ int ppt_mini_pointnet_conv12_bf16(const float *pts, int64_t M, const float *w1, 
                                   const float *a_shift, int C1, const void *W2, const float *bias2, int N, void *y2, void *gmax,
                                   void *stream);
 
+/* The second half's last conv with its group max (Encoder.second_conv[1:] + max, dvae.py:194-199, 213-214):
+ * tok[g, :] = max over the 32 rows of group g of W . relu(a_scale * A + a_shift) + bias, A [M,512] bf16 contiguous, W [256,512]
+ * bf16, tok [M/32, 256] bf16.  Same results as ppt_gemm with PPT_A_AFFINE_RELU + bias + pool_max over 32 rows, with W held in
+ * registers and the group's rows read from HBM once.  K = 512, N = 256, M % 32 == 0; anything else: PPT_EUNSUPPORTED. */
+int ppt_mini_pointnet_conv4_bf16(const void *A, int64_t M, int K, const float *a_scale, const float *a_shift, const void *W,
+                                 const float *bias, int N, void *tok, void *stream);
+
 /* The same product with BatchNorm partials of its output instead of the group max -- the first two convs of a PointNet2
  * set-abstraction branch that sees raw coordinates (models/pointnet2/pointnet2_utils.py:168-199, 217-262): y2 [M,N] bf16,
  * part_sum / part_m2 [M/32, N] f32 = per 32-row chunk (sum, sum (v - chunk mean)^2), what ppt_bn_finalize_ws takes with

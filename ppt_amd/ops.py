@@ -410,6 +410,22 @@ def mini_pointnet_conv12(pts, w1, b1, a_scale, a_shift, w2, bias2):
     return y2, gmax
 
 
+def mini_pointnet_conv4(A, a_scale, a_shift, w, bias):
+    """A [M,512] bf16 -> tok [M/32,256] bf16 = max over each group of 32 rows of relu(a_scale*A + a_shift) @ w^T + bias
+    (ppt_mini_pointnet_conv4_bf16)."""
+    _chk(A, torch.bfloat16, "A"); _chk(w, torch.bfloat16, "w")
+    M, K = A.shape
+    N = w.shape[0]
+    tok = torch.empty((M // 32, N), dtype=torch.bfloat16, device=A.device)
+    if profiler is not None:
+        profiler.begin("gemm_bf16", 2.0 * M * N * K)
+    _lib.check(_lib.lib().ppt_mini_pointnet_conv4_bf16(_p(A), M, K, _p(a_scale), _p(a_shift), _p(w), _p(bias), N, _p(tok), _stream()),
+               "ppt_mini_pointnet_conv4_bf16")
+    if profiler is not None:
+        profiler.end()
+    return tok
+
+
 CONV12_STATS_SHAPES = {(32, 32), (64, 64), (64, 96), (64, 128), (128, 128)}      # (C1, N) ppt_conv12_stats_bf16 is built for
 
 

@@ -698,3 +698,22 @@ def test_affine_conv_pool_is_the_prologue_gemm(ops, K, N, pr):
     a = torch.relu(A.double() * sc.double() + sh.double()).to(torch.bfloat16).double()
     v = a @ w.double().t() + b.double()
     assert (pmax.double() - v.view(M // pr, pr, N).amax(1)).abs().max().item() < 2e-4 * max(1.0, v.abs().max().item())
+
+
+@pytest.mark.parametrize("groups", [1, 5, 2048])
+def test_mini_pointnet_conv4_is_the_prologue_gemm(ops, groups):
+    """ppt_mini_pointnet_conv4_bf16 against ppt_gemm(PPT_A_AFFINE_RELU + bias + pool over 32 rows): bit-identical group maxima."""
+    g = torch.Generator(device="cuda").manual_seed(groups)
+    M = 32 * groups
+    A = torch.randn(M, 512, device="cuda", generator=g).to(torch.bfloat16)
+    sc = 1.0 + 0.2 * torch.randn(512, device="cuda", generator=g)
+    sh = 0.2 * torch.randn(512, device="cuda", generator=g)
+    w = (torch.randn(256, 512, device="cuda", generator=g) / 512 ** 0.5).to(torch.bfloat16)
+    b = torch.randn(256, device="cuda", generator=g) * 0.1
+    tok = ops.mini_pointnet_conv4(A, sc, sh, w, b)
+    ref = torch.empty((groups, 256), dtype=torch.bfloat16, device="cuda")
+    ops.gemm(A, w, a_mode=ops.A_AFFINE_RELU, a_scale=sc, a_shift=sh, bias=b, pool_max=ref, want_out=False)
+    assert torch.equal(tok, ref)
+    a = torch.relu(A.double() * sc.double() + sh.double()).to(torch.bfloat16).double()
+    v = (a @ w.double().t() + b.double()).view(groups, 32, 256).amax(1)
+    assert (tok.double() - v).abs().max().item() < 2e-2 * max(1.0, v.abs().max().item())
