@@ -220,6 +220,14 @@ int ppt_mini_pointnet_conv12_bf16(const float *pts, int64_t M, const float *w1, 
                                   const float *a_shift, int C1, const void *W2, const float *bias2, int N, void *y2, void *gmax,
                                   void *stream);
 
+/* The middle conv (Encoder.second_conv[0] on cat(global, local), dvae.py:194-195, 211-212) in split form:
+ * y[m, :] = W . A[m, :] + gterm[m / 32, :], A [M,256] bf16 contiguous, W [512,256] bf16 (the local half of the weight), gterm
+ * [M/32, 512] f32 (the global half applied to the group maxima, bias included), y [M,512] bf16; part_sum / part_m2 [M/32, 512]
+ * (both or neither) receive the BatchNorm partials per 32-row chunk.  Same results as ppt_gemm with group_add + col_sum.
+ * K = 256, N = 512, M % 32 == 0; anything else: PPT_EUNSUPPORTED. */
+int ppt_mini_pointnet_conv3_bf16(const void *A, int64_t M, int K, const void *W, const float *gterm, int N, void *y, float *part_sum,
+                                 float *part_m2, void *stream);
+
 /* The second half's last conv with its group max (Encoder.second_conv[1:] + max, dvae.py:194-199, 213-214):
  * tok[g, :] = max over the 32 rows of group g of W . relu(a_scale * A + a_shift) + bias, A [M,512] bf16 contiguous, W [256,512]
  * bf16, tok [M/32, 256] bf16.  Same results as ppt_gemm with PPT_A_AFFINE_RELU + bias + pool_max over 32 rows, with W held in

@@ -80,6 +80,8 @@ _SIGNATURES = {
                                  c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "ppt_mini_pointnet_conv12_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                               c_int, c_void_p, c_void_p, c_void_p]),
+    "ppt_mini_pointnet_conv3_bf16": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                             c_void_p]),
     "ppt_mini_pointnet_conv4_bf16": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                              c_void_p]),
     "ppt_conv12_stats_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,

@@ -120,16 +120,22 @@ def mini_pointnet(sd, p, wc, nbhd, bn_train, update_running=True):
     gterm = ops.gemm(gmax, wc.get(w3, cols=(0, 256)), out_dtype=torch.float32, bias=sd[p + "second_conv.0.bias"],
                      algo_k=0)      # its FLOPs are accounted to the 512-wide conv3 (algo_k=512 below)
     g2, be2, rm2, rv2, nb2 = _bn_params(sd, p + "second_conv.1.")
+    w3b = wc.get(w3, cols=(256, 512))
+    fused3 = (T == torch.bfloat16 and FUSED_CONV12 and tuple(w3b.shape) == (512, 256) and w3b.stride(0) == 256
+              and y2.is_contiguous() and gterm.is_contiguous())          # csrc/mpn3.hip: W3b in registers, rows read once
     if bn_train:
         cs = torch.empty((M // 32, 512), dtype=torch.float32, device=dev)
         cq = torch.empty_like(cs)
-        y3 = ops.gemm(y2, wc.get(w3, cols=(256, 512)), out_dtype=T, group_add=gterm, group_rows=32, col_stats=(cs, cq),
-                      algo_k=512)
+        if fused3:
+            y3 = ops.mini_pointnet_conv3(y2, w3b, gterm, (cs, cq))
+        else:
+            y3 = ops.gemm(y2, w3b, out_dtype=T, group_add=gterm, group_rows=32, col_stats=(cs, cq), algo_k=512)
         sc2, sh2 = ops.bn_finalize(g2, be2, True, partials=(cs, cq), rows_per_partial=32, count=M,
                                    running_mean=rm2, running_var=rv2, num_batches_tracked=nb2,
                                    update_running=update_running)
     else:
-        y3 = ops.gemm(y2, wc.get(w3, cols=(256, 512)), out_dtype=T, group_add=gterm, group_rows=32, algo_k=512)
+        y3 = ops.mini_pointnet_conv3(y2, w3b, gterm) if fused3 else \
+            ops.gemm(y2, w3b, out_dtype=T, group_add=gterm, group_rows=32, algo_k=512)
         sc2, sh2 = ops.bn_finalize(g2, be2, False, running_mean=rm2, running_var=rv2)
     # BN2 + ReLU in the A-prologue of conv4; only the pooled maximum is written
     w4 = wc.get(sd[p + "second_conv.3.weight"])

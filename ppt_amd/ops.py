@@ -410,6 +410,23 @@ def mini_pointnet_conv12(pts, w1, b1, a_scale, a_shift, w2, bias2):
     return y2, gmax
 
 
+def mini_pointnet_conv3(A, w, gterm, col_stats=None):
+    """A [M,256] bf16, w [512,256] bf16, gterm [M/32,512] f32 -> y [M,512] bf16 = A @ w^T + gterm[group] (+ BatchNorm partials
+    into col_stats) -- ppt_mini_pointnet_conv3_bf16.  The FLOPs are accounted at the 512-wide conv this is the local half of."""
+    _chk(A, torch.bfloat16, "A"); _chk(w, torch.bfloat16, "w"); _chk(gterm, torch.float32, "gterm")
+    M, K = A.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
+    ps, pm = col_stats if col_stats is not None else (None, None)
+    if profiler is not None:
+        profiler.begin("gemm_bf16", 2.0 * M * N * 2 * K)
+    _lib.check(_lib.lib().ppt_mini_pointnet_conv3_bf16(_p(A), M, K, _p(w), _p(gterm), N, _p(y), _p(ps), _p(pm), _stream()),
+               "ppt_mini_pointnet_conv3_bf16")
+    if profiler is not None:
+        profiler.end()
+    return y
+
+
 def mini_pointnet_conv4(A, a_scale, a_shift, w, bias):
     """A [M,512] bf16 -> tok [M/32,256] bf16 = max over each group of 32 rows of relu(a_scale*A + a_shift) @ w^T + bias
     (ppt_mini_pointnet_conv4_bf16)."""

@@ -717,3 +717,21 @@ def test_mini_pointnet_conv4_is_the_prologue_gemm(ops, groups):
     a = torch.relu(A.double() * sc.double() + sh.double()).to(torch.bfloat16).double()
     v = (a @ w.double().t() + b.double()).view(groups, 32, 256).amax(1)
     assert (tok.double() - v).abs().max().item() < 2e-2 * max(1.0, v.abs().max().item())
+
+
+@pytest.mark.parametrize("groups", [1, 5, 2048])
+def test_mini_pointnet_conv3_is_the_group_add_gemm(ops, groups):
+    """ppt_mini_pointnet_conv3_bf16 against ppt_gemm(group_add + column statistics): bit-identical y3, equal BatchNorm partials."""
+    g = torch.Generator(device="cuda").manual_seed(groups + 3)
+    M = 32 * groups
+    A = torch.randn(M, 256, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(512, 256, device="cuda", generator=g) / 16).to(torch.bfloat16)
+    gt = torch.randn(groups, 512, device="cuda", generator=g)
+    st = (torch.empty((groups, 512), device="cuda"), torch.empty((groups, 512), device="cuda"))
+    y = ops.mini_pointnet_conv3(A, w, gt, st)
+    rst = (torch.empty((groups, 512), device="cuda"), torch.empty((groups, 512), device="cuda"))
+    ref = ops.gemm(A, w, out_dtype=torch.bfloat16, group_add=gt, group_rows=32, col_stats=rst)
+    assert torch.equal(y, ref)
+    assert torch.equal(ops.mini_pointnet_conv3(A, w, gt), ref)                   # eval mode: no partials
+    assert (st[0] - rst[0]).abs().max().item() < 1e-4 * max(1.0, rst[0].abs().max().item())
+    assert (st[1] - rst[1]).abs().max().item() < 1e-3 * max(1.0, rst[1].abs().max().item())
