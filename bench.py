@@ -229,7 +229,7 @@ def main():
         tf = os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")
         if a.config == "C2" and os.path.exists(tf):
             traffic = round(json.load(open(tf))["hbm_bytes_per_launch"])
-        roof = {"bound": "mfma", "kernel": "bf16 GEMM family (ppt_amd/csrc/gemm.hip, mpn1.hip)",
+        roof = {"bound": "mfma", "kernel": "bf16 GEMM family (ppt_amd/csrc/gemm.hip, mpn1/mpn3/mpn4.hip)",
                 "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                 "launches_per_step": g["launches"] // a.steps,

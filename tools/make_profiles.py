@@ -10,7 +10,7 @@ import argparse, glob, json, os, shutil
 import pandas as pd
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-GEMM_BF16 = r"gemm_kernel.*<unsigned short|mpn1_kernel"
+GEMM_BF16 = r"gemm_kernel.*<unsigned short|mpn[134]_kernel"
 
 
 def find(d, pat):
@@ -58,7 +58,7 @@ def main():
         f, nf = pmc(a.fetch, "FETCH_SIZE")
         w, nw = pmc(a.write, "WRITE_SIZE")
         traffic = {
-            "kernel": "bf16 GEMM family (gemm_kernel / gemm_kernel_glds / gemm_kernel_glds_h <unsigned short>, mpn1_kernel)",
+            "kernel": "bf16 GEMM family (gemm_kernel / gemm_kernel_glds / gemm_kernel_glds_h <unsigned short>, mpn1 / mpn3 / mpn4_kernel)",
             "command": "PPT_HIP_GRAPHS=0 rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) --output-format csv -- "
                        "python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline",
             "launches_counted": int(nf), "fetch_size_kb_sum": float(f), "write_size_kb_sum": float(w),
