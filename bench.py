@@ -121,7 +121,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     from ppt_amd import graphs
-    graphs.shared_text_stream()        # before RCCL creates its streams: same hardware-queue position as at N = 1
+    # before RCCL creates its streams: same hardware-queue position as at N = 1.  High priority where only the prompt trains
+    # (the prompt side's backward -> AdamW -> forward chain is then what the head waits for; see graphs.shared_text_stream)
+    c0_ = CONFIGS[a.config]
+    graphs.shared_text_stream(priority=-1 if (c0_["head_type"] == 0 and c0_.get("model", "ULIP_PointBERT") == "ULIP_PointBERT") else 0)
     frozen_too = os.environ.get("PPT_GROUP_AHEAD_FROZEN") == "1"          # experiment: also for a fully frozen PointBERT (C2)
     c_ = CONFIGS[a.config]
     group_ahead = GROUP_AHEAD and (frozen_too or (c_["head_type"] > 0 and c_.get("model", "ULIP_PointBERT") == "ULIP_PointBERT")

@@ -71,7 +71,7 @@ class GraphCache:
 _TEXT_STREAMS = {}
 
 
-def shared_text_stream(device=None):
+def shared_text_stream(device=None, priority=None):
     """The process-wide side stream of `device` (one per GPU, shared by every model): created on first call.
     Which hardware queue a HIP stream gets depends on how many streams the process created before it, and some
     positions execute in order with the caller's stream (4.8 -> 6.2 ... 7.5 ms per C2 step, tools/prio_test.py) -- so the
@@ -81,7 +81,13 @@ def shared_text_stream(device=None):
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
     if dev not in _TEXT_STREAMS:
         with torch.cuda.device(dev):
-            _TEXT_STREAMS[dev] = torch.cuda.Stream()
+            # priority (first call only; PPT_TEXT_STREAM_PRIORITY overrides): -1 lets the prompt side's small kernels ahead of
+            # the point tower's.  Every iteration's text forward waits for the previous iteration's text backward + AdamW,
+            # and once the tower is fast enough that chain -- stretched by contention -- is what the head waits for
+            # (C2: +1 ... 1.6 % at -1 in same-box A/B runs; C3, whose caller stream waits for the optimizer anyway: -1.6 %; PointMLP -0.7 %)
+            prio = os.environ.get("PPT_TEXT_STREAM_PRIORITY")
+            prio = int(prio) if prio is not None else (0 if priority is None else int(priority))
+            _TEXT_STREAMS[dev] = torch.cuda.Stream(priority=prio)
     return _TEXT_STREAMS[dev]
 
 
