@@ -66,7 +66,7 @@ def build_model(dataset="modelnet40", head_type=HEAD_TYPE, precision=torch.bfloa
     import io
     args = SimpleNamespace(classnames=M.dataset_classnames(dataset), template_init='', class_name_position='middle',
                            num_learnable_prompt_tokens=32, gpu=torch.cuda.current_device(), task=task,
-                           head_type=head_type, evaluate_3d=False, ulip2=False)
+                           head_type=head_type, evaluate_3d=False, ulip2=False, synthetic_weights=True)
     with contextlib.redirect_stdout(io.StringIO()):
         m = getattr(M, model)(args)
     sd = {"ULIP_PointBERT": W.ulip_pointbert_state_dict, "ULIP_PN_MSG": W.ulip_pn2_msg_state_dict,

@@ -100,18 +100,32 @@ def name_token_ids(name, bpe_path=None):
     return tok.encode(key)
 
 
-def tokenize_prompts(classnames, n_ctx, template_tokens=None, bpe_path=None):
-    """Token ids of "X X ... X <name>." per class (ULIP_models.py:87-100) -> (ids [C,77] int64, name_lengths)."""
+def tokenize_prompts(classnames, n_ctx, template_tokens=None, bpe_path=None, template_text=None):
+    """Token ids of "X X ... X <name>." per class (ULIP_models.py:87-100) -> (ids [C,77] int64, name_lengths).
+    Names of the reference's datasets come from the committed id table (each is known to tokenize to
+    [sot] + ctx + name + [period, eot]).  Any other name goes through the tokenizer the way the reference does it: the
+    WHOLE string "<prefix> <name>." is encoded at once (a name ending in punctuation merges with the period into one
+    BPE piece), and name_lengths counts the pieces of the name encoded alone."""
     tab = _token_table()
     ids, lens = [], []
     for name in classnames:
-        nt = name_token_ids(name, bpe_path)
+        key = name.replace("_", " ")
         ctx = template_tokens if template_tokens is not None else [tab["placeholder"]] * n_ctx
-        row = [tab["sot"]] + list(ctx) + nt + [tab["period"], tab["eot"]]
+        if key in tab["name_tokens"]:
+            nt = list(tab["name_tokens"][key])
+            row = [tab["sot"]] + list(ctx) + nt + [tab["period"], tab["eot"]]
+            n_name = len(nt)
+        else:
+            tok = _bpe(bpe_path)
+            if tok is None:
+                name_token_ids(name, bpe_path)                  # raises the KeyError that explains what is missing
+            prefix = template_text if template_text is not None else " ".join(["X"] * n_ctx)
+            row = [tab["sot"]] + tok.encode(prefix + " " + key + ".") + [tab["eot"]]
+            n_name = len(tok.encode(key))
         if len(row) > CONTEXT_LENGTH:
             raise RuntimeError(f"prompt for {name!r} exceeds the context length {CONTEXT_LENGTH}")
         ids.append(row + [0] * (CONTEXT_LENGTH - len(row)))
-        lens.append(len(nt))
+        lens.append(n_name)
     return torch.tensor(ids, dtype=torch.long), lens
 
 
@@ -124,9 +138,10 @@ class PromptLearner(nn.Module):
         self.classnames = kwargs.classnames
         self.transformer_width = kwargs.transformer_width
         self.device = kwargs.device
-        template_tokens = None
+        template_tokens = template_text = None
         if kwargs.template_init != '':
-            words = kwargs.template_init.replace("_", " ").split(' ')
+            template_text = kwargs.template_init.replace("_", " ")
+            words = template_text.split(' ')
             template_tokens = []
             for wd in words:
                 template_tokens += name_token_ids(wd)
@@ -138,7 +153,7 @@ class PromptLearner(nn.Module):
             self.num_learnable_prompt_tokens = kwargs.num_learnable_prompt_tokens
         self.learnable_tokens = nn.Parameter(torch.empty(self.num_learnable_prompt_tokens, self.transformer_width))
         self.tokenized_prompts, self.name_lengths = tokenize_prompts(self.classnames, self.num_learnable_prompt_tokens,
-                                                                     template_tokens)
+                                                                     template_tokens, template_text=template_text)
         # the frozen prefix / class-name / suffix embeddings are looked up ONCE at
         # construction (before any weight is initialised or loaded) and are neither parameter nor buffer.
         with torch.no_grad():
@@ -410,16 +425,31 @@ class ULIP_WITH_IMAGE(nn.Module):
             self._sd = (sd, ref, ref.device)
         return self._sd[0]
 
-    def _apply(self, fn, *a, **k):
+    def reset_caches(self):
+        """Drop everything derived from parameter / buffer STORAGE: the state-dict views, the operand copies of the
+        weights and every captured hipGraph (a graph bakes in the device pointers of what it read) -- of this module
+        AND of the point encoder.  nn.Module.load_state_dict loads children through _load_from_state_dict, so the
+        point encoder's own load_state_dict override never runs for a top-level load; train.BufferBroadcast re-binds
+        the BatchNorm buffers to views of a flat tensor.  Both call this."""
         self._sd = None
-        self._eot_pos = None
+        self._wc = None
+        self._te_cache = None
         self._graphs.clear()
+        pe = getattr(self, "point_encoder", None)
+        if pe is not None:
+            for attr in ("_sd", "_wc"):
+                if hasattr(pe, attr):
+                    setattr(pe, attr, None)
+            if hasattr(pe, "_graphs"):
+                pe._graphs.clear()
+
+    def _apply(self, fn, *a, **k):
+        self._eot_pos = None
+        self.reset_caches()
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
-        self._sd = None
-        self._wc = None                     # operand copies of the (frozen) weights and the graphs that read them
-        self._graphs.clear()
+        self.reset_caches()
         return super().load_state_dict(*a, **k)
 
     def _text_len(self):
@@ -542,22 +572,45 @@ def unfreeze_list(head_type):
     return mods
 
 
+SLIP_CKPT = './data/initialize_models/slip_base_100ep.pt'
+
+
+def synthetic_weights_allowed(args):
+    """No ULIP / SLIP checkpoint exists offline (benches, tests): `args.synthetic_weights = True` or
+    PPT_SYNTHETIC_WEIGHTS=1 is the explicit opt-in to build a model WITHOUT loading them (the caller then loads a
+    state dict of its own, ppt_amd/weights.py).  Without it a missing file raises, as the reference's torch.load does."""
+    return bool(getattr(args, "synthetic_weights", False)) or os.environ.get("PPT_SYNTHETIC_WEIGHTS") == "1"
+
+
+def read_pretrained(path):
+    """`torch.load(path)['state_dict']` with the DistributedDataParallel prefix removed (ULIP_models.py:477-485)."""
+    sd = torch.load(path, map_location=torch.device('cpu'))['state_dict']
+    return {k.replace('module.', ''): v for k, v in sd.items()}
+
+
 def _load_and_freeze(model, args, point_ckpt, skip):
-    """ULIP_models.py:472-507: copy pretrained values (when the checkpoint files exist) and freeze
-    everything except `skip`.  Un-frozen parameters are NOT loaded."""
-    point_params = slip_params = None
-    slip_ckpt = './data/initialize_models/slip_base_100ep.pt'
-    if os.path.exists(point_ckpt) and os.path.exists(slip_ckpt):
-        strip = lambda sd: {k.replace('module.', ''): v for k, v in sd.items()}
-        point_params = strip(torch.load(point_ckpt, map_location='cpu')['state_dict'])
-        slip_params = strip(torch.load(slip_ckpt, map_location='cpu')['state_dict'])
+    """ULIP_models.py:472-507: every parameter except the prompt tokens, a `point_encoder.cls_head` and `skip` is
+    frozen and overwritten with the pretrained value -- looked up in the point checkpoint first, else in the SLIP
+    checkpoint (KeyError when neither has it, as in the reference).  Un-frozen parameters are NOT loaded (SURVEY.md
+    App. A Q4).  A missing checkpoint file raises FileNotFoundError like the reference's torch.load, unless the caller
+    opted into synthetic weights (synthetic_weights_allowed); the two files are then looked at independently."""
+    synthetic = synthetic_weights_allowed(args)
+    tables = []
+    for path in (point_ckpt, SLIP_CKPT):
+        if os.path.exists(path) or not synthetic:
+            tables.append(read_pretrained(path))            # FileNotFoundError when absent
     for name, param in model.named_parameters():
         if name == 'prompt_learner.learnable_tokens' or 'point_encoder.cls_head' in name or name in skip:
             continue
         param.requires_grad = False
-        if point_params is not None:
-            src = point_params[name] if name in point_params else slip_params[name]
-            param.data.copy_(src.data if isinstance(src, nn.Parameter) else src)
+        src = next((t[name] for t in tables if name in t), None)
+        if src is None:
+            if not synthetic:
+                raise KeyError(name)
+            continue
+        param.data.copy_(src.data if isinstance(src, nn.Parameter) else src)
+    if hasattr(model, "reset_caches"):
+        model.reset_caches()
 
 
 def ULIP_PointBERT_partseg(args):
@@ -575,7 +628,16 @@ def ULIP_PointBERT_partseg(args):
                             num_learnable_prompt_tokens=args.num_learnable_prompt_tokens, transformer_width=512,
                             transformer_heads=8, transformer_layers=12, pc_feat_dims=128, device=args.gpu, task=args.task)
     if not getattr(args, "evaluate_3d", False):
-        backbone = {"point_encoder." + k for k in PointTransformer(config, args=args).state_dict()}   # keys of the ULIP ckpt
+        proj = os.path.dirname(here)
+        ckpt = os.path.join(proj, 'data/pretrained_models/pointbert_ulip2.pt' if getattr(args, "ulip2", False)
+                            else 'data/pretrained_models/pointbert.pt')
+        if os.path.exists(ckpt) or not synthetic_weights_allowed(args):
+            # the reference reads both files (FileNotFoundError when absent) and uses the point checkpoint for key
+            # membership only: no value is copied (ULIP_models.py:538-565)
+            backbone = set(read_pretrained(ckpt))
+            read_pretrained(os.path.join(proj, SLIP_CKPT[2:]))
+        else:
+            backbone = {"point_encoder." + k for k in PointTransformer(config, args=args).state_dict()}   # keys of the ULIP ckpt
         for name, param in model.named_parameters():
             if name.startswith('prompt_learner'):
                 continue

@@ -78,6 +78,33 @@ TIER_PARAMS = {   # ULIP_models.py:461-470, cumulative
 }
 
 
+def remap_pointbert_checkpoint(base_model):
+    """Key translation of load_model_from_ckpt (point_encoder.py:206-215, 322-331) for a Point-BERT pre-training
+    checkpoint's `base_model` table: the DistributedDataParallel prefix goes, `transformer_q.*` (the dVAE-supervised
+    query encoder; its cls_head excepted) and `base_model.*` entries keep their remainder as the key, every other entry
+    is dropped."""
+    out = {}
+    for k, v in base_model.items():
+        k = k.replace("module.", "")
+        if k.startswith("transformer_q") and not k.startswith("transformer_q.cls_head"):
+            out[k[len("transformer_q."):]] = v
+        elif k.startswith("base_model"):
+            out[k[len("base_model."):]] = v
+    return out
+
+
+def _load_model_from_ckpt(self, bert_ckpt_path):
+    """point_encoder.py:206-232 / :322-345: load a Point-BERT checkpoint non-strictly, reporting what did not match."""
+    ckpt = torch.load(bert_ckpt_path, map_location=torch.device('cpu'))
+    incompatible = self.load_state_dict(remap_pointbert_checkpoint(ckpt['base_model']), strict=False)
+    if incompatible.missing_keys:
+        print('missing_keys\n  ' + '\n  '.join(incompatible.missing_keys))
+    if incompatible.unexpected_keys:
+        print('unexpected_keys\n  ' + '\n  '.join(incompatible.unexpected_keys))
+    print(f'[{type(self).__name__}] Successful Loading the ckpt from {bert_ckpt_path}')
+    return incompatible
+
+
 class _PointEncoderFn(torch.autograd.Function):
     """feat = PointTransformer(pc); gradients only for the un-frozen last-block parameters."""
 
@@ -85,6 +112,12 @@ class _PointEncoderFn(torch.autograd.Function):
     def forward(ctx, module, pc, fps_start, dp, tier, names, *params):
         sd, cache, cfg, train = module._live_state(), module._cache(), module._cfg(), module.training
         ctx.module, ctx.tier, ctx.names = module, tier, names
+        # a hipGraph bakes in the device pointers of everything it reads, including the WeightCache's operand copies,
+        # which are re-made whenever the optimizer changes a parameter: a section that reads a trainable parameter is
+        # never captured.  With an un-frozen last block (head_type >= 1) only the frozen prefix (tokenizer + blocks
+        # 0 .. depth-2) is replayed, also under no_grad (validate() between two training epochs).
+        last_trains, other_trains = module._trainable_split()
+        split = tier > 0 or last_trains
         B, N = pc.shape[0], pc.shape[1]
         drawn = fps_start is None            # the caller injected neither RNG draw: they are made here, inside the graph
 
@@ -92,7 +125,7 @@ class _PointEncoderFn(torch.autograd.Function):
             """the two RNG draws of the path (misc.py:59 FPS start, timm DropPath factors), on the device"""
             return (torch.randint(0, N, (B,), dtype=torch.long, device=pc.device), module._draw_drop_path(B, pc.device))
 
-        use_graph = pc.is_cuda and module.use_hip_graphs and ops.profiler is None
+        use_graph = pc.is_cuda and module.use_hip_graphs and ops.profiler is None and not other_trains
         # tier 0 (everything frozen, nothing kept for a backward): ~140 launches whose arguments depend on shapes only --
         # replayed from a hipGraph after graphs.WARMUP_CALLS eager calls (ppt_amd/graphs.py; 2 us less per launch)
         if tier == 0 and module.param_gate is not None and pc.is_cuda:      # e.g. an evaluation right behind a training step
@@ -101,7 +134,7 @@ class _PointEncoderFn(torch.autograd.Function):
         has_dp = (train and module.drop_path_rate > 0) if drawn else dp is not None
         key = ("point_fwd", tuple(pc.shape), has_dp, drawn, train, cache.dtype)
         ahead = module.group_ahead if (use_graph and module._graphs.ready(("group", tuple(pc.shape), drawn))) else None
-        if tier == 0 and use_graph and module._graphs.ready(key):
+        if not split and use_graph and module._graphs.ready(key):
             if ahead is not None:
                 # FPS + kNN ran (or run right now) on the grouping stream, overlapping the previous iteration's blocks
                 grouped, slot = module._group_ahead(pc, fps_start, drawn, ahead)
@@ -128,7 +161,7 @@ class _PointEncoderFn(torch.autograd.Function):
             (feat,), _ = module._graphs.get(key, build)(*ins)
             ctx.saved = None
             return feat.clone()
-        if tier > 0 and pc.is_cuda:
+        if split and pc.is_cuda:
             # something in the last block trains: everything in front of it is still frozen.  That prefix is replayed
             # from a hipGraph, and only the rest waits for the optimizer of the previous iteration (module.param_gate,
             # set by train.Trainer.step) -- the prefix runs ahead of it like the whole tower does for head_type 0.
@@ -283,6 +316,12 @@ class PointTransformer(nn.Module):
                                f"ULIP_models.py:461-470; got {sorted(actual)}")
         return tier
 
+    def _trainable_split(self):
+        """(something in the last block trains, something in front of it / behind it trains)."""
+        in_last = sum(1 for q in self.blocks.blocks[-1].parameters() if q.requires_grad)
+        total = sum(1 for q in self.parameters() if q.requires_grad)
+        return in_last > 0, total > in_last
+
     def _group_ahead(self, pc, fps_start, drawn, side):
         """Group.forward (dvae.py:159-181) of `pc` on `side`, replayed from one of two hipGraphs with their own output
         buffers (the previous tower may still be reading the other pair).  The caller's stream is made to wait for the
@@ -326,6 +365,8 @@ class PointTransformer(nn.Module):
         return (torch.floor(keep + u) / keep).contiguous()
 
     # ---- reference API ---------------------------------------------------------------------
+    load_model_from_ckpt = _load_model_from_ckpt
+
     def forward(self, pts):
         """pts [B,N,3] -> cat(cls, max) features [B, 2*trans_dim] (point_encoder.py:234-257)."""
         pts = pts.contiguous().float()
@@ -410,6 +451,12 @@ class PointTransformer_partseg(nn.Module):
 
     def _live_state(self):
         return self.state_dict(keep_vars=True)
+
+    def load_state_dict(self, *a, **k):
+        self._wc = None
+        return super().load_state_dict(*a, **k)
+
+    load_model_from_ckpt = _load_model_from_ckpt
 
     def forward(self, pts, cls_label):
         from ...autograd import batch_norm_relu_rows, linear

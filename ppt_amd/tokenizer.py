@@ -125,11 +125,10 @@ class SimpleTokenizer:
 
     def __call__(self, texts, context_length=77):
         import torch
-        single = isinstance(texts, str)
         rows = []
-        for t in ([texts] if single else texts):
+        for t in ([texts] if isinstance(texts, str) else texts):
             ids = [self.encoder[SOT]] + self.encode(t) + [self.encoder[EOT]]
             ids = ids[:context_length]                     # (the reference truncates without re-appending EOT)
             rows.append(ids + [0] * (context_length - len(ids)))
         out = torch.tensor(rows, dtype=torch.long)
-        return out[0] if single else out
+        return out[0] if len(rows) == 1 else out            # utils/tokenizer.py:161-163: one row -> [context_length]

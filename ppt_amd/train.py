@@ -90,7 +90,9 @@ class Trainer:
                  lr_schedule=None, distributed=None, capturable=False):
         self.model = model
         self.criterion = nn.CrossEntropyLoss(label_smoothing=label_smoothing)       # main_cls.py:52
-        # main_cls.py:55-60: AdamW over ALL parameters; frozen ones never get a grad and are skipped
+        # main_cls.py:55-60 builds AdamW over ALL parameters; frozen ones never get a grad and are skipped by step().
+        # Here the frozen ones are left out (380 tensors the optimizer would walk every step); reference_optimizer_state
+        # re-indexes the state dict to the reference's layout for checkpoints.
         self.optimizer = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=lr, betas=betas,
                                            eps=eps, weight_decay=wd, capturable=capturable)
         self.lr_schedule = lr_schedule
@@ -125,10 +127,16 @@ class Trainer:
         self._gated = all(n.startswith("prompt_learner.") or n.startswith("point_encoder.blocks.blocks.") or not p.requires_grad
                           for n, p in model.named_parameters())
         self.bcast = BufferBroadcast(model) if distributed else None
-        if hasattr(model, "_sd"):
-            model._sd = None
-        if hasattr(getattr(model, "point_encoder", None), "_sd"):
-            model.point_encoder._sd = None
+        # BufferBroadcast re-bound the BatchNorm buffers to views of its flat tensor: every state-dict view, operand copy
+        # and captured hipGraph made before that points at the orphaned storage
+        if hasattr(model, "reset_caches"):
+            model.reset_caches()
+        else:
+            for m in (model, getattr(model, "point_encoder", None)):
+                if hasattr(m, "_sd"):
+                    m._sd = None
+                if hasattr(m, "_graphs"):
+                    m._graphs.clear()
 
     def _prompt_stream(self, pc):
         """The side stream the text tower runs on (ULIP_WITH_IMAGE.forward), or None on CPU / when disabled."""
@@ -210,6 +218,23 @@ class Trainer:
             self.bcast.broadcast()
 
 
+def reference_optimizer_state(model, optimizer):
+    """optimizer.state_dict() re-indexed as if the optimizer had been built over model.parameters() (main_cls.py:58):
+    one param group listing every parameter index, state entries keyed by a parameter's position in
+    model.parameters().  Loadable by the reference's `optimizer.load_state_dict`."""
+    sd = optimizer.state_dict()
+    all_params = list(model.parameters())
+    pos = {id(p): i for i, p in enumerate(all_params)}
+    groups, state = [], {}
+    assert len(sd['param_groups']) == len(optimizer.param_groups) == 1, "one param group, as main_cls.py:58"
+    g_sd, g = sd['param_groups'][0], optimizer.param_groups[0]
+    for local, p in zip(g_sd['params'], g['params']):
+        if local in sd['state']:
+            state[pos[id(p)]] = sd['state'][local]
+    groups.append({**{k: v for k, v in g_sd.items() if k != 'params'}, 'params': list(range(len(all_params)))})
+    return {'state': state, 'param_groups': groups}
+
+
 def checkpoint_payload(model, optimizer, epoch, best_acc, args, head_type=0, partseg=False):
     """The dict the reference writes as checkpoint_best.pt: main_cls.py:118-137 saves the
     prompt learner ('state_dict' = {'learnable_tokens'}), the last block when head_type > 0, the optimizer and args;
@@ -217,7 +242,8 @@ def checkpoint_payload(model, optimizer, epoch, best_acc, args, head_type=0, par
     save_recog_feats.py:29-35 / interpret_prompt.py:25-28 style readers work on it."""
     if torch.cuda.is_available():
         torch.cuda.synchronize()           # Trainer.step leaves the optimizer queued on the model's text stream
-    data = {'epoch': epoch + 1, 'state_dict': model.prompt_learner.state_dict(), 'optimizer': optimizer.state_dict(),
+    data = {'epoch': epoch + 1, 'state_dict': model.prompt_learner.state_dict(),
+            'optimizer': reference_optimizer_state(model, optimizer),
             'best_acc': best_acc, 'args': args}
     if partseg:
         data['state_dict_partseg'] = model.point_encoder.state_dict()

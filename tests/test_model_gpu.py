@@ -29,7 +29,7 @@ G = os.path.join(ROOT, "tests", "golden")
 def build(head_type, precision, n_classes_ds="modelnet40"):
     from ppt_amd.models import ULIP_models as M
     args = SimpleNamespace(classnames=M.dataset_classnames(n_classes_ds), template_init='', class_name_position='middle',
-                           num_learnable_prompt_tokens=32, gpu=0, task='cls', head_type=head_type, evaluate_3d=False,
+                           num_learnable_prompt_tokens=32, gpu=0, task='cls', head_type=head_type, evaluate_3d=False, synthetic_weights=True,
                            ulip2=False)
     m = M.ULIP_PointBERT(args)
     sd = W.ulip_pointbert_state_dict(seed=0)
@@ -504,7 +504,7 @@ def test_ulip_pn_mlp_train_step_runs_and_only_prompt_trains():
     from ppt_amd.models import ULIP_models as M
     from ppt_amd.train import Trainer
     args = SimpleNamespace(classnames=M.dataset_classnames("modelnet40"), template_init='', class_name_position='middle',
-                           num_learnable_prompt_tokens=32, gpu=0, task='cls', head_type=0, evaluate_3d=False, ulip2=False)
+                           num_learnable_prompt_tokens=32, gpu=0, task='cls', head_type=0, evaluate_3d=False, ulip2=False, synthetic_weights=True)
     m = M.ULIP_PN_MLP(args)
     m.load_state_dict(W.ulip_pn_mlp_state_dict(seed=0), strict=False)
     m.cuda().train()
@@ -533,7 +533,7 @@ def test_pointnet2_grouping_ahead_is_identical():
     from ppt_amd.models import ULIP_models as M
     from ppt_amd.train import Trainer
     args = SimpleNamespace(classnames=M.dataset_classnames("modelnet40"), template_init='', class_name_position='middle',
-                           num_learnable_prompt_tokens=32, gpu=0, task='cls', head_type=0, evaluate_3d=False, ulip2=False)
+                           num_learnable_prompt_tokens=32, gpu=0, task='cls', head_type=0, evaluate_3d=False, ulip2=False, synthetic_weights=True)
     B = 4
     pc_np, s0 = W.synth_clouds(B, 2048, seed=91)
     _, s1 = W.synth_clouds(B, 512, seed=92)
@@ -570,7 +570,7 @@ def test_ulip_pn_msg_train_step_runs_and_only_prompt_trains():
     from ppt_amd.models import ULIP_models as M
     from ppt_amd.train import Trainer
     args = SimpleNamespace(classnames=M.dataset_classnames("modelnet40"), template_init='', class_name_position='middle',
-                           num_learnable_prompt_tokens=32, gpu=0, task='cls', head_type=0, evaluate_3d=False, ulip2=False)
+                           num_learnable_prompt_tokens=32, gpu=0, task='cls', head_type=0, evaluate_3d=False, ulip2=False, synthetic_weights=True)
     m = M.ULIP_PN_MSG(args)
     m.load_state_dict(W.ulip_pn2_msg_state_dict(seed=0), strict=False)
     m.prompt_learner.embedding = W.synth_prompt_embedding(40, seed=0)
@@ -594,7 +594,7 @@ def test_partseg_train_step_matches_golden(precision):
     from ppt_amd.models import ULIP_models as M
     g = np.load(os.path.join(G, "g_partseg.npz"), allow_pickle=False)
     args = SimpleNamespace(classnames=M.dataset_classnames("shapenetpart"), template_init='', class_name_position='middle',
-                           num_learnable_prompt_tokens=32, gpu=0, task='partseg', head_type=0, evaluate_3d=False, ulip2=False)
+                           num_learnable_prompt_tokens=32, gpu=0, task='partseg', head_type=0, evaluate_3d=False, ulip2=False, synthetic_weights=True)
     m = M.ULIP_PointBERT_partseg(args)
     assert sorted(n for n, p in m.named_parameters() if p.requires_grad) == sorted(g["trainable"].tolist())
     m.load_state_dict(W.ulip_partseg_state_dict(seed=0), strict=False)

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def make(head_type=0, position="middle", ds="modelnet40"):
     import models.ULIP_models as models          # the reference's import line (main_cls.py:25)
     args = SimpleNamespace(classnames=models.dataset_classnames(ds), template_init='', class_name_position=position,
-                           num_learnable_prompt_tokens=32, gpu=0, task='cls', head_type=head_type, evaluate_3d=False,
+                           num_learnable_prompt_tokens=32, gpu=0, task='cls', head_type=head_type, evaluate_3d=False, synthetic_weights=True,
                            ulip2=False, model='ULIP_PointBERT')
     return getattr(models, args.model)(args), models       # main_cls.py:44
 
@@ -107,7 +107,7 @@ def test_other_factories_state_dicts():
     """ULIP_PN_MSG (C4) and ULIP_PointBERT_partseg (C5): reference state-dict layouts and trainable sets."""
     import models.ULIP_models as models
     a = SimpleNamespace(classnames=models.dataset_classnames("shapenetpart"), template_init='', class_name_position='middle',
-                        num_learnable_prompt_tokens=32, gpu=0, task='partseg', head_type=0, evaluate_3d=False, ulip2=False)
+                        num_learnable_prompt_tokens=32, gpu=0, task='partseg', head_type=0, evaluate_3d=False, ulip2=False, synthetic_weights=True)
     m = models.ULIP_PointBERT_partseg(a)
     spec = dict(W.ulip_spec(128, True) + W.pointbert_spec() + W.partseg_decoder_spec())
     assert set(m.state_dict()) == set(spec)
@@ -149,3 +149,134 @@ def test_checkpoint_payload_roundtrip(tmp_path):
     load_prompt_checkpoint(m2, torch.load(f, weights_only=False))
     assert torch.equal(m2.prompt_learner.learnable_tokens, m.prompt_learner.learnable_tokens)
     assert torch.equal(m2.point_encoder.blocks.blocks[-1].mlp.fc2.weight, m.point_encoder.blocks.blocks[-1].mlp.fc2.weight)
+
+
+# ---- N2: the read side of the checkpoint formats (ULIP_models.py:472-507, point_encoder.py:206-232) ----------------
+def _fake_pretrained(tmp_path, head_type=2):
+    """Synthetic pointbert.pt / slip_base_100ep.pt in the reference's on-disk layout: {'state_dict': {'module.<key>': t}}.
+    The point checkpoint holds point_encoder.* and pc_projection; everything else (text tower, logit_scale ...) is only
+    in the SLIP checkpoint, which ALSO holds a (different) pc_projection: the point checkpoint must win."""
+    m, models = make(head_type)
+    g = torch.Generator().manual_seed(7)
+    point, slip = {}, {}
+    for name, p in m.named_parameters():
+        if name == 'prompt_learner.learnable_tokens':
+            continue
+        t = torch.randn(p.shape, generator=g)
+        if name.startswith('point_encoder.') or name == 'pc_projection':
+            point['module.' + name] = torch.nn.Parameter(t) if name.endswith('norm.weight') else t   # both value kinds occur
+        else:
+            slip['module.' + name] = t
+    slip['module.pc_projection'] = torch.full_like(m.pc_projection, 9.0)
+    slip['module.visual.cls_token'] = torch.zeros(1, 1, 768)              # image-tower entries are simply never asked for
+    os.makedirs(tmp_path / "data" / "pretrained_models")
+    os.makedirs(tmp_path / "data" / "initialize_models")
+    torch.save({'state_dict': point, 'epoch': 3}, tmp_path / "data" / "pretrained_models" / "pointbert.pt")
+    torch.save({'state_dict': slip}, tmp_path / "data" / "initialize_models" / "slip_base_100ep.pt")
+    return point, slip
+
+
+def test_ulip_checkpoints_load_and_freeze_as_the_reference(tmp_path, monkeypatch):
+    import models.ULIP_models as models
+    point, slip = _fake_pretrained(tmp_path, head_type=2)
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.delenv("PPT_SYNTHETIC_WEIGHTS", raising=False)
+    args = SimpleNamespace(classnames=models.dataset_classnames("modelnet40"), template_init='', class_name_position='middle',
+                           num_learnable_prompt_tokens=32, gpu=0, task='cls', head_type=2, evaluate_3d=False, ulip2=False)
+    torch.manual_seed(0)
+    m = models.ULIP_PointBERT(args)
+    skip = set(models.unfreeze_list(2))
+    for name, p in m.named_parameters():
+        if name == 'prompt_learner.learnable_tokens':
+            assert p.requires_grad
+        elif name in skip:                                      # SURVEY App. A Q4: un-frozen tier keys keep their random init
+            assert p.requires_grad
+            assert not torch.equal(p.data, point['module.' + name].data), name
+        else:
+            assert not p.requires_grad, name
+            src = point.get('module.' + name, slip.get('module.' + name))
+            assert torch.equal(p.data, src.data), name
+    assert torch.equal(m.pc_projection.data, point['module.pc_projection'])       # point checkpoint first, SLIP second
+
+
+def test_missing_checkpoint_raises_unless_opted_in(tmp_path, monkeypatch):
+    """ULIP_models.py:472-485: torch.load raises on a missing file; a silently random frozen backbone must not happen."""
+    import models.ULIP_models as models
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.delenv("PPT_SYNTHETIC_WEIGHTS", raising=False)
+    base = dict(classnames=models.dataset_classnames("modelnet40"), template_init='', class_name_position='middle',
+                num_learnable_prompt_tokens=32, gpu=0, task='cls', head_type=0, evaluate_3d=False, ulip2=False)
+    with pytest.raises(FileNotFoundError):
+        models.ULIP_PointBERT(SimpleNamespace(**base))
+    with pytest.raises(FileNotFoundError):
+        models.ULIP_PN_MSG(SimpleNamespace(**base))
+    with pytest.raises(FileNotFoundError):
+        models.ULIP_PointBERT_partseg(SimpleNamespace(**{**base, "task": "partseg"}))
+    # one file present, the other absent: still an error (and nothing half-loaded goes unnoticed)
+    _fake_pretrained(tmp_path / "w", head_type=0)
+    os.makedirs(tmp_path / "data" / "pretrained_models")
+    os.replace(tmp_path / "w" / "data" / "pretrained_models" / "pointbert.pt", tmp_path / "data" / "pretrained_models" / "pointbert.pt")
+    with pytest.raises(FileNotFoundError):
+        models.ULIP_PointBERT(SimpleNamespace(**base))
+    # explicit opt-in: the file that IS present is loaded, the missing one is tolerated
+    m = models.ULIP_PointBERT(SimpleNamespace(**base, synthetic_weights=True))
+    pt = torch.load(tmp_path / "data" / "pretrained_models" / "pointbert.pt", weights_only=False)['state_dict']
+    assert torch.equal(m.point_encoder.reduce_dim.weight.data, pt['module.point_encoder.reduce_dim.weight'])
+    assert not m.point_encoder.reduce_dim.weight.requires_grad
+
+
+def test_load_model_from_ckpt_key_translation(tmp_path):
+    """point_encoder.py:206-232: 'base_model' table, module. prefix, transformer_q.* / base_model.* renaming, cls_head and
+    foreign entries dropped, non-strict load."""
+    from models.pointbert.point_encoder import PointTransformer
+    import models.ULIP_models as models
+    pe = PointTransformer(models.POINTBERT_CONFIG)
+    g = torch.Generator().manual_seed(3)
+    want = {k: torch.randn(v.shape, generator=g) if v.dtype.is_floating_point else v.clone() for k, v in pe.state_dict().items()}
+    table = {}
+    for i, (k, v) in enumerate(want.items()):
+        if k.startswith("blocks.blocks.11.mlp"):
+            continue                                           # left out: reported as missing, keeps its value
+        table[("module.transformer_q." if i % 2 else "module.base_model.") + k] = v
+    table["module.transformer_q.cls_head.0.weight"] = torch.zeros(3)      # must be ignored, not reported
+    table["module.dvae.encoder.conv.weight"] = torch.zeros(3)             # neither prefix: dropped
+    torch.save({"base_model": table}, tmp_path / "Point-BERT.pth")
+    before = pe.blocks.blocks[11].mlp.fc1.weight.detach().clone()
+    res = pe.load_model_from_ckpt(str(tmp_path / "Point-BERT.pth"))
+    assert not res.unexpected_keys
+    assert sorted(res.missing_keys) == sorted(k for k in want if k.startswith("blocks.blocks.11.mlp"))
+    assert torch.equal(pe.blocks.blocks[11].mlp.fc1.weight, before)
+    assert torch.equal(pe.encoder.first_conv[0].weight, want["encoder.first_conv.0.weight"])
+    assert torch.equal(pe.blocks.blocks[0].attn.qkv.weight, want["blocks.blocks.0.attn.qkv.weight"])
+
+
+def test_optimizer_state_in_the_checkpoint_uses_the_reference_indexing():
+    """main_cls.py:58 builds AdamW over model.parameters(): the saved state must be loadable by such an optimizer."""
+    from ppt_amd.train import reference_optimizer_state
+    m, _ = make(1)
+    trainable = [p for p in m.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(trainable, lr=1e-3)
+    for p in trainable:
+        p.grad = torch.ones_like(p)
+    opt.step()
+    sd = reference_optimizer_state(m, opt)
+    ref_opt = torch.optim.AdamW(m.parameters(), lr=5.0)
+    ref_opt.load_state_dict(sd)                                         # group sizes match, no error
+    assert ref_opt.param_groups[0]['lr'] == 1e-3
+    allp = list(m.parameters())
+    for p in trainable:
+        i = next(j for j, q in enumerate(allp) if q is p)
+        assert torch.equal(ref_opt.state[allp[i]]['exp_avg'], opt.state[p]['exp_avg'])
+    assert len(ref_opt.state) == len(trainable)
+
+
+def test_top_level_load_state_dict_resets_the_point_encoders_caches():
+    """nn.Module.load_state_dict loads children through _load_from_state_dict -- the point encoder's operand
+    copies and captured graphs must be dropped by the TOP-LEVEL load too."""
+    m, _ = make(1)
+    pe = m.point_encoder
+    pe._wc, pe._sd = object(), (None, None, None)
+    pe._graphs.entries["stale"] = object()
+    m._graphs.entries["stale"] = object()
+    m.load_state_dict({'point_encoder.blocks.blocks.11.mlp.fc2.bias': torch.zeros(384)}, strict=False)
+    assert pe._wc is None and pe._sd is None and not pe._graphs.entries and not m._graphs.entries

@@ -72,3 +72,30 @@ def test_unknown_class_names_fall_back_to_the_tokenizer():
 def tok_path():
     from ppt_amd import tokenizer as T
     return T.find_vocab() or REF_VOCAB
+
+
+def test_single_row_is_squeezed_whatever_the_container():
+    """utils/tokenizer.py:161-163: one row comes back as [context_length], for a str and for a one-element list."""
+    tok = _tokenizer()
+    assert tok("a chair").shape == (77,)
+    assert tok(["a chair"]).shape == (77,)
+    assert tok(["a chair", "a table"]).shape == (2, 77)
+
+
+def test_uncaptured_class_name_is_tokenised_as_a_whole_string(monkeypatch):
+    """A class name outside the committed id table goes through the tokenizer as the reference does it
+    (ULIP_models.py:95-100): the whole "X ... X name." string at once -- a name ending in punctuation merges with the
+    period into ONE piece, so the row is not [name pieces] + [period]."""
+    tok = _tokenizer()
+    from ppt_amd import tokenizer as T
+    from ppt_amd.models import ULIP_models as M
+    if T.find_vocab() is None:
+        monkeypatch.setenv("PPT_BPE_VOCAB", REF_VOCAB)
+    names = ["lamp (floor)", "zebra crossing"]
+    ids, lens = M.tokenize_prompts(names, 4)
+    for row, n_name, name in zip(ids, lens, names):
+        want = tok("X X X X " + name + ".")
+        assert torch.equal(row, want), name
+        assert n_name == len(tok.encode(name))
+    pieces = tok.encode("lamp (floor).")
+    assert pieces[-1] != tok.encode(".")[0], "')' and '.' merge into one BPE piece: the case the fallback must get right"
