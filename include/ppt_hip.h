@@ -126,6 +126,40 @@ typedef struct ppt_gemm_params {
 
 int ppt_gemm(const ppt_gemm_params *p, void *stream);
 
+/* ---- short-K linears with the weight stationary in registers (csrc/rowgemm.hip) --------------------------------
+ * Replaces, for the frozen transformer blocks in the bf16 mode, nn.LayerNorm + nn.Linear pairs and the residual-form
+ * linears: PointBERT norm1 -> attn.qkv, norm2 -> mlp.fc1 + GELU, attn.proj + DropPath + residual
+ * (point_encoder.py:46-58,65-79); CLIP ln_1 -> in_proj, ln_2 -> c_fc + QuickGELU, out_proj + residual
+ * (ULIP_models.py:35-56).   C[M,N] = epilogue( prologue(A)[M,K] . W[N,K]^T ), everything contiguous row-major:
+ *   a_ln == 0: A is bf16 [M,K];  a_ln != 0: A is the f32 residual stream [M,K] and the operand is
+ *              bf16( (A - mean) * rstd * ln_w + ln_b ) per row (two-pass mean / biased variance, eps = ln_eps);
+ *   residual_form == 0: C (bf16) = act(acc + bias); C2 (bf16, optional) = acc + bias (the saved pre-activation);
+ *   residual_form != 0: C (f32)  = residual + row_scale[m / row_scale_rows] * (acc + bias) + residual2; C may alias
+ *              residual; row_scale / residual2 / bias may be NULL.
+ * K must be 384 or 512, N % 4 == 0, pointers 16-byte aligned: anything else PPT_EUNSUPPORTED / PPT_EINVAL.
+ * walkers: workgroups per column group walking the 32-row tiles (0 = as many as fill the chip). */
+typedef struct ppt_rowgemm_params {
+    const void *A;
+    const void *W;                   /* [N,K] bf16 */
+    void *C;
+    void *C2;
+    int M, N, K;
+    int a_ln;
+    const float *ln_w;               /* [K] */
+    const float *ln_b;               /* [K] */
+    float ln_eps;
+    const float *bias;               /* [N] or NULL */
+    int act;                         /* PPT_ACT_NONE / PPT_ACT_GELU / PPT_ACT_QUICKGELU (residual_form == 0 only) */
+    int residual_form;
+    const float *residual;           /* [M,N] f32 */
+    const float *residual2;          /* [M,N] f32 or NULL */
+    const float *row_scale;          /* [ceil(M / row_scale_rows)] f32 or NULL */
+    int row_scale_rows;
+    int walkers;
+} ppt_rowgemm_params;
+
+int ppt_rowgemm_bf16(const ppt_rowgemm_params *p, void *stream);
+
 /* ---- LayerNorm --------------------------------------------------------------------------------
  * Replaces nn.LayerNorm at point_encoder.py:65,69,152 and ULIP_models.py:21-27,39,46,176.
  * fwd: xs = x (+ add); y = LN(xs)*w + b.  x, add, xs f32 [M,D] (xs may alias x, may be NULL);

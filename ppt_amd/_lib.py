@@ -33,6 +33,16 @@ class GemmParams(ctypes.Structure):
     ]
 
 
+class RowGemmParams(ctypes.Structure):
+    """struct ppt_rowgemm_params (include/ppt_hip.h) -- field order must match the header."""
+    _fields_ = [
+        ("A", c_void_p), ("W", c_void_p), ("C", c_void_p), ("C2", c_void_p), ("M", c_int), ("N", c_int), ("K", c_int),
+        ("a_ln", c_int), ("ln_w", c_void_p), ("ln_b", c_void_p), ("ln_eps", c_float), ("bias", c_void_p), ("act", c_int),
+        ("residual_form", c_int), ("residual", c_void_p), ("residual2", c_void_p), ("row_scale", c_void_p),
+        ("row_scale_rows", c_int), ("walkers", c_int),
+    ]
+
+
 _SIGNATURES = {
     "ppt_abi_version": (c_int, []),
     "ppt_fps_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -44,6 +54,7 @@ _SIGNATURES = {
                                 c_void_p]),
     "ppt_bn_act_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ppt_gemm": (c_int, [ctypes.POINTER(GemmParams), c_void_p]),
+    "ppt_rowgemm_bf16": (c_int, [ctypes.POINTER(RowGemmParams), c_void_p]),
     "ppt_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                   c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "ppt_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

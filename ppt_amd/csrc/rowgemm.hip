@@ -1,0 +1,256 @@
+// rowgemm.hip -- C[M,N] = epilogue( prologue(A)[M,K] . W[N,K]^T ) for the SHORT-K linears of the two transformers
+// (K = 384: PointBERT qkv / proj / fc1, point_encoder.py:46-58,76-79; K = 512: the CLIP text tower's in_proj / out_proj /
+// c_fc, ULIP_models.py:35-56), with the weight STATIONARY in registers and the LayerNorm in front of the linear applied
+// while the rows are staged.
+//
+// Why not the tile loop of gemm.hip: with K = 384 a 128 x 128 tile is six 64-wide slabs -- every tile is a pipeline fill,
+// and what bounds the loop is what a CU pulls out of L2 into LDS (both operands, 64 flop per byte at best), not the
+// matrix pipe: qkv 500, fc1 420, proj 350 TFLOP/s.  Here the B operand moves ONCE per workgroup: a workgroup owns NB output
+// columns (384 resp. 256), each of its 8 waves keeps NW = NB / 8 of them -- W[n0 .. n0 + NW) x K, 144 resp. 128 VGPRs --
+// for the whole kernel, and walks 32-row tiles of A.  The only operand that moves is A: 32 rows go to LDS once
+// (double-buffered, one barrier per tile, the next tile's global loads in flight during the MFMAs) and every wave
+// reads its fragments from there.  LDS row pitch 2K + 32 bytes: the four 16-lane groups of a ds_read_b128 of the
+// 16x16x32 operand then hit 64 distinct banks.
+//
+// The product is formed TRANSPOSED, D[n][m] = sum_k W[n][k] A[m][k] (v_mfma_f32_16x16x32_bf16 with W as the first
+// operand): a lane then holds four CONSECUTIVE output columns of one row -- an 8-byte bf16 or 16-byte fp32 store, and a
+// 16-byte read of the fp32 residual stream -- with no transpose through LDS.
+//
+// A prologue (LN = true): A is the fp32 residual stream x [M,K]; 16 lanes share a row, each holding K/16 values; mean and
+// variance are the two-pass forms of nn.LayerNorm reduced over the 16 lanes with four DPP adds (every lane ends with the
+// same bits), and (x - mean) * rstd * gamma + beta goes to LDS as bf16 -- the LayerNorm output never exists in HBM.
+// Column groups recompute it (3x for qkv, 4x for fc1): 1.5 KB per row out of L2 against 23 ... 31 GFLOP per launch.
+//
+// Epilogues: bias; GELU (erf, A&S 7.1.26 as gemm.hip) / QuickGELU with an optional copy of the pre-activation; or the
+// residual form out = residual + row_scale[m / rows] * (acc + bias) (+ residual2), fp32, in place allowed.
+#include "ppt_common.h"
+#include "ppt_act.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+template <int K> struct RG {
+    static constexpr int NCB = (K == 384) ? 3 : 2;      // 16-column blocks per wave
+    static constexpr int NW = 16 * NCB;                  // columns per wave
+    static constexpr int NB = 8 * NW;                    // columns per workgroup
+    static constexpr int KS = K / 32;                    // k-steps of the 16x16x32 MFMA
+    static constexpr int PITCH = 2 * K + 32;             // bytes per LDS row
+    static constexpr int BUF = 32 * PITCH;
+    static constexpr int F4 = K / 64;                    // float4 per thread and row, LayerNorm prologue (16 threads per row)
+    static constexpr int U4 = K / 128;                   // uint4 per thread and row, bf16 A
+    static constexpr int LDS = 2 * BUF + 2 * K * 4;      // two A buffers + gamma + beta
+};
+
+// sum over the 16 lanes of a DPP row; every lane gets the same bits (each step adds a value to its mirror image)
+__device__ __forceinline__ float row16_sum(float v)
+{
+    v += __uint_as_float(dpp_mov<0xB1, 0xf>(__float_as_uint(v)));       // quad_perm [1,0,3,2]
+    v += __uint_as_float(dpp_mov<0x4E, 0xf>(__float_as_uint(v)));       // quad_perm [2,3,0,1]
+    v += __uint_as_float(dpp_mov<0x141, 0xf>(__float_as_uint(v)));      // row_half_mirror
+    v += __uint_as_float(dpp_mov<0x140, 0xf>(__float_as_uint(v)));      // row_mirror
+    return v;
+}
+
+enum { EPI_BF16 = 0, EPI_RESIDUAL = 1 };
+
+template <int K, bool LN, int EPI>
+__global__ __launch_bounds__(512, 2) void rowgemm_kernel(const ppt_rowgemm_params p)
+{
+    using G = RG<K>;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int n0 = blockIdx.y * G::NB + w * G::NW;                       // first column of this wave
+    const int n_tiles = (p.M + 31) >> 5;
+
+    // ---- the stationary operand: W[n0 + 16 nb + l15][32 s + 8 kg .. + 8)
+    bf16x8_t wf[G::NCB][G::KS];
+    const bf16_t *W = (const bf16_t *)p.W;
+#pragma unroll
+    for (int nb = 0; nb < G::NCB; ++nb) {
+        const int n = min(n0 + 16 * nb + l15, p.N - 1);
+#pragma unroll
+        for (int s = 0; s < G::KS; ++s)
+            wf[nb][s] = *reinterpret_cast<const bf16x8_t *>(W + (size_t)n * K + 32 * s + 8 * kg);
+    }
+    // per-lane epilogue constants: columns n0 + 16 nb + 4 kg + i
+    float bias[G::NCB][4];
+#pragma unroll
+    for (int nb = 0; nb < G::NCB; ++nb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + 16 * nb + 4 * kg + i;
+            bias[nb][i] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+        }
+    float *gam = reinterpret_cast<float *>(smem + 2 * G::BUF), *bet = gam + K;
+    if constexpr (LN) {
+        for (int c = threadIdx.x; c < K; c += 512) { gam[c] = p.ln_w[c]; bet[c] = p.ln_b[c]; }
+    }
+
+    // ---- loader: thread -> row r (0..31) of the tile, 16 threads per row
+    const int r = threadIdx.x >> 4, j = threadIdx.x & 15;
+    float4 xf[LN ? G::F4 : 1];
+    uint4 xb0 = {}, xb1 = {}, xb2 = {}, xb3 = {};     // (named values: an array that lives across the barrier is kept in scratch)
+    auto load = [&](int tile) {
+        const size_t row = (size_t)min(tile * 32 + r, p.M - 1);
+        if constexpr (LN) {
+            const float *src = (const float *)p.A + row * K;
+#pragma unroll
+            for (int i = 0; i < G::F4; ++i) xf[i] = *reinterpret_cast<const float4 *>(src + 4 * (j + 16 * i));
+        } else {
+            const bf16_t *src = (const bf16_t *)p.A + row * K + 8 * j;
+            xb0 = *reinterpret_cast<const uint4 *>(src);
+            xb1 = *reinterpret_cast<const uint4 *>(src + 128);
+            xb2 = *reinterpret_cast<const uint4 *>(src + 256);
+            if constexpr (G::U4 > 3) xb3 = *reinterpret_cast<const uint4 *>(src + 384);
+        }
+    };
+    auto stage = [&](int buf) {
+        unsigned char *dst = smem + buf * G::BUF + r * G::PITCH;
+        if constexpr (LN) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < G::F4; ++i) s += (xf[i].x + xf[i].y) + (xf[i].z + xf[i].w);
+            const float mean = row16_sum(s) * (1.0f / (float)K);
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < G::F4; ++i) {
+                const float d0 = xf[i].x - mean, d1 = xf[i].y - mean, d2 = xf[i].z - mean, d3 = xf[i].w - mean;
+                q = fmaf(d0, d0, q); q = fmaf(d1, d1, q); q = fmaf(d2, d2, q); q = fmaf(d3, d3, q);
+            }
+            const float rstd = 1.0f / sqrtf(row16_sum(q) * (1.0f / (float)K) + p.ln_eps);
+#pragma unroll
+            for (int i = 0; i < G::F4; ++i) {
+                const int c = 4 * (j + 16 * i);
+                const float4 g = *reinterpret_cast<const float4 *>(gam + c), b = *reinterpret_cast<const float4 *>(bet + c);
+                const float o0 = (xf[i].x - mean) * rstd * g.x + b.x, o1 = (xf[i].y - mean) * rstd * g.y + b.y;
+                const float o2 = (xf[i].z - mean) * rstd * g.z + b.z, o3 = (xf[i].w - mean) * rstd * g.w + b.w;
+                *reinterpret_cast<uint2 *>(dst + 2 * c) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+            }
+        } else {
+            *reinterpret_cast<uint4 *>(dst + 16 * j) = xb0;
+            *reinterpret_cast<uint4 *>(dst + 16 * j + 256) = xb1;
+            *reinterpret_cast<uint4 *>(dst + 16 * j + 512) = xb2;
+            if constexpr (G::U4 > 3) *reinterpret_cast<uint4 *>(dst + 16 * j + 768) = xb3;
+        }
+    };
+
+    int t = blockIdx.x;
+    if (t >= n_tiles) return;
+    load(t);
+    __syncthreads();                                                     // gamma / beta are in LDS
+    stage(0);
+    __syncthreads();
+    for (int it = 0; t < n_tiles; t += gridDim.x, ++it) {
+        const int cur = it & 1;
+        load(min(t + (int)gridDim.x, n_tiles - 1));                      // unconditional (a branch parks the registers in scratch)
+        const unsigned char *a0 = smem + cur * G::BUF + l15 * G::PITCH + 16 * kg;
+        const unsigned char *a1 = a0 + 16 * G::PITCH;
+        f32x4_t acc[2][G::NCB];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int nb = 0; nb < G::NCB; ++nb) acc[rb][nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < G::KS; ++s) {
+            const bf16x8_t f0 = *reinterpret_cast<const bf16x8_t *>(a0 + 64 * s);
+            const bf16x8_t f1 = *reinterpret_cast<const bf16x8_t *>(a1 + 64 * s);
+#pragma unroll
+            for (int nb = 0; nb < G::NCB; ++nb) {
+                acc[0][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][s], f0, acc[0][nb], 0, 0, 0);
+                acc[1][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][s], f1, acc[1][nb], 0, 0, 0);
+            }
+        }
+        // ---- epilogue: lane holds D[n = n0 + 16 nb + 4 kg + i][m = 32 t + 16 rb + l15]
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const int m = t * 32 + 16 * rb + l15;
+            if (m < p.M) {
+                float rs = 1.0f;
+                if constexpr (EPI == EPI_RESIDUAL) { if (p.row_scale) rs = p.row_scale[m / p.row_scale_rows]; }
+#pragma unroll
+                for (int nb = 0; nb < G::NCB; ++nb) {
+                    const int n = n0 + 16 * nb + 4 * kg;
+                    if (n < p.N) {
+                        float v[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = acc[rb][nb][i] + bias[nb][i];
+                        const size_t o = (size_t)m * p.N + n;
+                        if constexpr (EPI == EPI_RESIDUAL) {
+                            const float4 res = *reinterpret_cast<const float4 *>(p.residual + o);
+                            float4 out = make_float4(v[0] * rs + res.x, v[1] * rs + res.y, v[2] * rs + res.z, v[3] * rs + res.w);
+                            if (p.residual2) {
+                                const float4 r2 = *reinterpret_cast<const float4 *>(p.residual2 + o);
+                                out.x += r2.x; out.y += r2.y; out.z += r2.z; out.w += r2.w;
+                            }
+                            *reinterpret_cast<float4 *>((float *)p.C + o) = out;
+                        } else {
+                            if (p.C2) *reinterpret_cast<uint2 *>((bf16_t *)p.C2 + o) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                            if (p.act == PPT_ACT_GELU) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) v[i] = 0.5f * v[i] * (1.0f + erf_fast(v[i] * 0.70710678118654752f));
+                            } else if (p.act == PPT_ACT_QUICKGELU) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) v[i] = v[i] / (1.0f + __expf(-1.702f * v[i]));
+                            }
+                            *reinterpret_cast<uint2 *>((bf16_t *)p.C + o) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                        }
+                    }
+                }
+            }
+        }
+        stage(cur ^ 1);                                                  // (last read in iteration it - 1, before its barrier)
+        __syncthreads();
+    }
+}
+
+template <int K, bool LN, int EPI>
+int launch(const ppt_rowgemm_params &p, hipStream_t s, int cus)
+{
+    using G = RG<K>;
+    static const int once = [] {
+        (void)hipFuncSetAttribute((const void *)rowgemm_kernel<K, LN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+        return 0;
+    }();
+    (void)once;
+    const int groups = (p.N + G::NB - 1) / G::NB;
+    const int tiles = (p.M + 31) / 32;
+    int walkers = p.walkers > 0 ? p.walkers : cus / groups;
+    if (walkers < 1) walkers = 1;
+    if (walkers > tiles) walkers = tiles;
+    hipLaunchKernelGGL((rowgemm_kernel<K, LN, EPI>), dim3(walkers, groups), dim3(512), G::LDS, s, p);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PPT_OK : PPT_ELAUNCH;
+}
+
+}  // namespace
+
+extern "C" int ppt_rowgemm_bf16(const ppt_rowgemm_params *pp, void *stream)
+{
+    if (!pp) return PPT_EINVAL;
+    const ppt_rowgemm_params &p = *pp;
+    if (!p.A || !p.W || !p.C || p.M <= 0 || p.N <= 0) return PPT_EINVAL;
+    if (p.K != 384 && p.K != 512) return PPT_EUNSUPPORTED;
+    if (p.N % 4) return PPT_EUNSUPPORTED;
+    if (p.a_ln && (!p.ln_w || !p.ln_b)) return PPT_EINVAL;
+    if (p.residual_form && !p.residual) return PPT_EINVAL;
+    if (p.residual_form && (p.act != PPT_ACT_NONE || p.C2)) return PPT_EUNSUPPORTED;
+    if (p.row_scale && p.row_scale_rows <= 0) return PPT_EINVAL;
+    if (p.act != PPT_ACT_NONE && p.act != PPT_ACT_GELU && p.act != PPT_ACT_QUICKGELU) return PPT_EUNSUPPORTED;
+    if (((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.C | (uintptr_t)p.C2 | (uintptr_t)p.residual | (uintptr_t)p.residual2) & 15)
+        return PPT_EINVAL;
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    hipStream_t s = ppt_stream(stream);
+#define PPT_RG(KK)                                                                                       \
+    (p.a_ln ? (p.residual_form ? launch<KK, true, EPI_RESIDUAL>(p, s, cus) : launch<KK, true, EPI_BF16>(p, s, cus)) \
+            : (p.residual_form ? launch<KK, false, EPI_RESIDUAL>(p, s, cus) : launch<KK, false, EPI_BF16>(p, s, cus)))
+    return p.K == 384 ? PPT_RG(384) : PPT_RG(512);
+#undef PPT_RG
+}

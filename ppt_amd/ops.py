@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, A_AFFINE_RELU, A_CONV1, A_PLAIN,
-                   PPT_BF16, PPT_F32, GemmParams)
+                   PPT_BF16, PPT_F32, GemmParams, RowGemmParams)
 
 _DT = {torch.float32: PPT_F32, torch.bfloat16: PPT_BF16}
 _TORCH_DT = {PPT_F32: torch.float32, PPT_BF16: torch.bfloat16}
@@ -176,6 +176,47 @@ def gemm(A, B, *, out=None, out_dtype=None, M=None, bias=None, act=ACT_NONE, dac
         kk = K if algo_k is None else algo_k
         profiler.begin("gemm_" + ("bf16" if p.dtype == PPT_BF16 else "f32"), 2.0 * M * N * kk * max(1, batch))
     _lib.check(_lib.lib().ppt_gemm(ctypes.byref(p), _stream()), "ppt_gemm")
+    if profiler is not None:
+        profiler.end()
+    return out
+
+
+ROWGEMM_K = (384, 512)
+
+
+def rowgemm(A, W, *, ln=None, ln_eps=1e-5, bias=None, act=ACT_NONE, out=None, out2=None, residual=None, residual2=None,
+            row_scale=None, row_scale_rows=0, walkers=0):
+    """ppt_rowgemm_bf16 (csrc/rowgemm.hip): C = epilogue(prologue(A) @ W^T) with W [N,K] bf16 held in registers.
+    A: bf16 [M,K], or -- with ln = (gamma, beta) -- the f32 residual stream, LayerNorm applied while the rows are staged.
+    residual given: the f32 form out = residual + row_scale[m // row_scale_rows] * (acc + bias) + residual2 (out may be
+    residual itself); else out (bf16) = act(acc + bias) and out2 (bf16, optional) receives the pre-activation."""
+    M, K = A.shape
+    N = W.shape[0]
+    assert W.shape[1] == K and W.dtype == torch.bfloat16 and W.is_contiguous() and A.is_contiguous()
+    assert A.dtype == (torch.float32 if ln is not None else torch.bfloat16)
+    p = RowGemmParams()
+    p.A, p.W, p.M, p.N, p.K = _p(A), _p(W), M, N, K
+    if ln is not None:
+        p.a_ln, p.ln_w, p.ln_b, p.ln_eps = 1, _p(ln[0]), _p(ln[1]), ln_eps
+    p.bias, p.act = _p(bias), act
+    if residual is not None:
+        assert residual.dtype == torch.float32 and residual.is_contiguous() and residual.shape == (M, N)
+        if out is None:
+            out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+        assert out.dtype == torch.float32 and out.is_contiguous()
+        p.residual_form, p.residual, p.residual2 = 1, _p(residual), _p(residual2)
+        p.row_scale, p.row_scale_rows = _p(row_scale), row_scale_rows
+    else:
+        if out is None:
+            out = torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
+        assert out.dtype == torch.bfloat16 and out.is_contiguous()
+        if out2 is not None:
+            assert out2.dtype == torch.bfloat16 and out2.is_contiguous()
+            p.C2 = _p(out2)
+    p.C, p.walkers = _p(out), walkers
+    if profiler is not None:
+        profiler.begin("gemm_bf16", 2.0 * M * N * K)
+    _lib.check(_lib.lib().ppt_rowgemm_bf16(ctypes.byref(p), _stream()), "ppt_rowgemm_bf16")
     if profiler is not None:
         profiler.end()
     return out

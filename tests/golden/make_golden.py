@@ -131,7 +131,7 @@ def set_droppath(m, masks):
         blk.drop_path.forward = fwd
 
 
-def gen_encoder_and_step(tok):
+def gen_encoder_and_step(tok, head_types=(0, 1, 2, 3)):
     names = tok["datasets"]["modelnet40"]
     name_lengths = [len(tok["name_tokens"][n.replace("_", " ")]) for n in names]
     sd = W.ulip_pointbert_state_dict(seed=0)
@@ -153,7 +153,7 @@ def gen_encoder_and_step(tok):
     masks[11] = (masks[11][0], torch.tensor([1 / 0.9, 0.0, 1 / 0.9, 1 / 0.9]))
     masks[6] = (torch.tensor([0.0, 1 / (1 - rates[6]), 1 / (1 - rates[6]), 1 / (1 - rates[6])], dtype=torch.float32), masks[6][1])
 
-    for head_type in (0, 3):
+    for head_type in head_types:
         m = R.build_reference_ulip_pointbert(names, head_type=head_type)
         load_into_reference(m, sd, emb)
         eot = m.tokenized_prompts.argmax(-1).numpy()
@@ -507,6 +507,8 @@ if __name__ == "__main__":
         gen_pointnet2_ssg()
     elif sys.argv[1:] == ["pointmlp"]:
         gen_pointmlp()
+    elif sys.argv[1:2] == ["steps"]:            # the train-step fixtures of the given head_types only
+        gen_encoder_and_step(gen_tokens(), tuple(int(h) for h in sys.argv[2:]))
     else:
         tok = gen_tokens()
         gen_index()

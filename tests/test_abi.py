@@ -30,10 +30,9 @@ def test_binding_covers_header():
     assert b"invalid" in _lib.lib().ppt_strerror(-1)
 
 
-def test_gemm_params_struct_matches_header_order():
-    from ppt_amd import _lib
+def _struct_fields(name):
     src = open(os.path.join(ROOT, "include", "ppt_hip.h")).read()
-    body = src[src.index("typedef struct ppt_gemm_params {"):src.index("} ppt_gemm_params;")]
+    body = src[src.index("typedef struct %s {" % name):src.index("} %s;" % name)]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     names = []
     for stmt in body.split("{", 1)[1].split(";"):
@@ -43,7 +42,13 @@ def test_gemm_params_struct_matches_header_order():
         first, *rest = stmt.split(",")
         names.append(re.findall(r"(\w+)\s*$", first.strip())[0])
         names += [r.strip().lstrip("*") for r in rest]
-    assert names == [f[0] for f in _lib.GemmParams._fields_]
+    return names
+
+
+def test_gemm_params_struct_matches_header_order():
+    from ppt_amd import _lib
+    assert _struct_fields("ppt_gemm_params") == [f[0] for f in _lib.GemmParams._fields_]
+    assert _struct_fields("ppt_rowgemm_params") == [f[0] for f in _lib.RowGemmParams._fields_]
 
 
 def test_arg_validation_without_gpu():
@@ -54,3 +59,5 @@ def test_arg_validation_without_gpu():
     assert L.ppt_gemm(None, None) == -1
     p = _lib.GemmParams()
     assert L.ppt_gemm(ctypes.byref(p), None) == -1
+    assert L.ppt_rowgemm_bf16(None, None) == -1
+    assert L.ppt_rowgemm_bf16(ctypes.byref(_lib.RowGemmParams()), None) == -1

@@ -735,3 +735,88 @@ def test_mini_pointnet_conv3_is_the_group_add_gemm(ops, groups):
     assert torch.equal(ops.mini_pointnet_conv3(A, w, gt), ref)                   # eval mode: no partials
     assert (st[0] - rst[0]).abs().max().item() < 1e-4 * max(1.0, rst[0].abs().max().item())
     assert (st[1] - rst[1]).abs().max().item() < 1e-3 * max(1.0, rst[1].abs().max().item())
+
+
+# ------------------------------------------------------------------ rowgemm: weight-stationary short-K linears (csrc/rowgemm.hip)
+def _bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("M,N,K", [(16416, 1152, 384), (513, 384, 384), (100, 1536, 384), (33, 384, 384), (1480, 1536, 512),
+                                    (817, 2048, 512), (40, 512, 512), (1, 256, 512), (2080, 200, 384)])
+@pytest.mark.parametrize("ln", [False, True])
+def test_rowgemm_bf16_forms(ops, M, N, K, ln):
+    """bf16 output forms: plain (+bias), GELU, QuickGELU with the saved pre-activation; A as bf16 rows or as the fp32
+    residual stream with the LayerNorm prologue.  Reference: fp32 torch on the bf16-rounded operands (what the MFMA
+    multiplies), so the only differences are accumulation order and the final bf16 rounding: tolerance 2^-7 relative
+    to the row scale (one bf16 ulp of the result) + the A&S erf's 1.5e-7."""
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    w = torch.randn(N, K, generator=g) * K ** -0.5
+    bias = torch.randn(N, generator=g) * 0.1
+    if ln:
+        x = torch.randn(M, K, generator=g) * 2.0 + torch.randn(M, 1, generator=g)
+        gam, bet = 1.0 + 0.1 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+        a_ref = _bf(torch.nn.functional.layer_norm(x, (K,), gam, bet, 1e-5))
+        A, kw = x.cuda(), dict(ln=(gam.cuda(), bet.cuda()))
+    else:
+        a = torch.randn(M, K, generator=g)
+        a_ref = _bf(a)
+        A, kw = a.cuda().to(torch.bfloat16), {}
+    wd = w.cuda().to(torch.bfloat16)
+    pre = a_ref @ _bf(w).t() + bias
+    for act, fn in ((ops.ACT_NONE, lambda v: v), (ops.ACT_GELU, lambda v: torch.nn.functional.gelu(v)),
+                    (ops.ACT_QUICKGELU, lambda v: v * torch.sigmoid(1.702 * v))):
+        out2 = torch.empty((M, N), dtype=torch.bfloat16, device="cuda") if act != ops.ACT_NONE else None
+        out = ops.rowgemm(A, wd, bias=bias.cuda(), act=act, out2=out2, **kw)
+        want = fn(pre)
+        tol = 2.0 ** -7 * max(1.0, want.abs().max().item()) * (1.5 if ln else 1.0)    # (LN: a bf16 tie of the operand may flip)
+        assert (out.float().cpu() - want).abs().max().item() < tol, act
+        if out2 is not None:
+            assert (out2.float().cpu() - pre).abs().max().item() < tol
+        again = ops.rowgemm(A, wd, bias=bias.cuda(), act=act, **kw)
+        assert torch.equal(out, again), "bit-reproducible"
+    nb = ops.rowgemm(A, wd, **kw)                                          # no bias
+    assert (nb.float().cpu() - (pre - bias)).abs().max().item() < 2.0 ** -7 * max(1.0, pre.abs().max().item()) * 1.5
+
+
+@pytest.mark.parametrize("M,N,K,rows", [(16416, 384, 384, 513), (1026, 384, 384, 513), (1480, 512, 512, 37), (77, 512, 512, 0)])
+def test_rowgemm_residual_form(ops, M, N, K, rows):
+    """out = residual + row_scale[m // rows] * (acc + bias) (+ residual2), fp32, also in place (out is residual): the
+    proj / out_proj epilogue (point_encoder.py:77, ULIP_models.py:53).  fp32 reference on the bf16-rounded operands."""
+    g = torch.Generator().manual_seed(M + N)
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5
+    bias, res, res2 = torch.randn(N, generator=g), torch.randn(M, N, generator=g), torch.randn(M, N, generator=g)
+    rs = (torch.floor(0.7 + torch.rand((M + rows - 1) // rows, generator=g)) / 0.7) if rows else None
+    A, wd = a.cuda().to(torch.bfloat16), w.cuda().to(torch.bfloat16)
+    acc = _bf(a) @ _bf(w).t() + bias
+    scaled = acc * rs.repeat_interleave(rows)[:M, None] if rows else acc
+    kw = dict(row_scale=rs.cuda(), row_scale_rows=rows) if rows else {}
+    out = ops.rowgemm(A, wd, bias=bias.cuda(), residual=res.cuda(), residual2=res2.cuda(), **kw)
+    assert (out.cpu() - (res + scaled + res2)).abs().max().item() < 2e-4 * max(1.0, acc.abs().max().item())
+    x = res.cuda().clone()
+    ops.rowgemm(A, wd, bias=bias.cuda(), residual=x, out=x, **kw)            # in place, no second residual
+    assert (x.cpu() - (res + scaled)).abs().max().item() < 2e-4 * max(1.0, acc.abs().max().item())
+
+
+def test_rowgemm_matches_the_tile_gemm_path(ops):
+    """The fused LayerNorm -> linear equals ppt_layernorm_fwd + ppt_gemm on the same inputs up to the summation order of the
+    LayerNorm statistics (a rare 1-ulp flip of a bf16 operand) and of the K loop: agreement to one bf16 ulp of the output."""
+    g = torch.Generator().manual_seed(5)
+    M, K, N = 4104, 384, 1536
+    x = (torch.randn(M, K, generator=g) * 3).cuda()
+    gam, bet = (1 + 0.2 * torch.randn(K, generator=g)).cuda(), (0.2 * torch.randn(K, generator=g)).cuda()
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).cuda().to(torch.bfloat16)
+    b = torch.randn(N, generator=g).cuda()
+    h, _, _ = ops.layernorm_fwd(x, gam, bet, torch.bfloat16)
+    ref = ops.gemm(h, w, out_dtype=torch.bfloat16, bias=b, act=ops.ACT_GELU)
+    got = ops.rowgemm(x, w, ln=(gam, bet), bias=b, act=ops.ACT_GELU)
+    d = (ref.float() - got.float()).abs()
+    assert d.max().item() <= 2.0 ** -6 * max(1.0, ref.float().abs().max().item())
+    assert (d > 0).float().mean().item() < 0.05, "almost every element is bit-identical"
+
+
+def test_rowgemm_rejects_what_it_does_not_support(ops):
+    a = torch.zeros(64, 256, dtype=torch.bfloat16, device="cuda")
+    w = torch.zeros(64, 256, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.rowgemm(a, w)                                                    # K = 256: PPT_EUNSUPPORTED, no silent fallback
