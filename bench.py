@@ -10,10 +10,17 @@ Workload (BASELINE.json configs[1], "C2"): ModelNet40 class list, 1024-point clo
 AdamW, bf16 MFMA operands / fp32 accumulate.  One step == one iteration of main_cls.py:179-214.
 Synthetic clouds (resident in HBM before the timed region) and deterministic random weights.
 
+Timing: BURN_IN_STEPS (40) untimed steps (clock ramp-up, hipGraph capture; reported as "burn_in"), then --warmup W
+untimed steps, then EXACTLY --steps K steps bracketed by barrier + torch.cuda.synchronize(): `value` = clouds / that
+time; "ms_per_step_median" is the median of the K per-step times taken with HIP events on the caller's stream.
+
 Prints ONE JSON line (rank 0): metric/value/unit..., plus
   "roofline":     the dominant kernel (the bf16 MFMA GEMM family) -- algorithmic FLOPs / its summed launch
                   time measured with HIP events on the launch stream during a second, instrumented pass
                   over the same K steps -- against the 2.5 PFLOP/s dense bf16 peak;
+                  "roofline.kernels" lists EVERY hot kernel of that pass the same way: FPS / kNN / ball query against
+                  8 TB/s with SURVEY §8(d)'s algorithmic bytes, attention and each GEMM kernel against the MFMA peak;
+  "parity_mode":  clouds/s of the same step in the fp32 parity mode (N = 1 only);
   "cpu_baseline": the oracle (CPU restatement of the reference, `kind: "port"`) timed on this host's cores
                   on the reference's CPU-runnable case C1 (batch 8), rank 0, N=1 only.
 """
@@ -55,8 +62,54 @@ METRICS = {"C2": "point-clouds/sec fwd+bwd, PointBERT 1024-pt ModelNet40",
            "MLP": "point-clouds/sec fwd+bwd, PointMLP 1024-pt ModelNet40",
            "C5": "point-clouds/sec fwd+bwd, PointBERT part-seg 2048-pt ShapeNetPart"}
 GROUP_AHEAD = os.environ.get("PPT_GROUP_AHEAD", "1") != "0"
-BURN_IN_STEPS = 40               # untimed, before the --warmup steps (clock ramp, graph capture)
+BURN_IN_STEPS = 40               # untimed, before the --warmup steps (clock ramp, graph capture); reported as "burn_in"
 PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3          # f32-input MFMA == f32 vector rate (same guide)
+PEAK_HBM_GBS = 8000.0            # HBM3E spec (6.3 TB/s is what a copy kernel reaches)
+HBM_KERNELS = ("fps", "knn_group", "ball_query")    # index work: accounted against algorithmic HBM bytes (SURVEY §8(d))
+
+
+def kernel_table(by_kernel, overhead_ms, steps):
+    """roofline.kernels: one entry per hot kernel of the instrumented pass -- time per step, algorithmic work per step
+    (bytes for the index kernels with SURVEY §8(d)'s formulas, FLOPs for the MFMA kernels), achieved rate and its
+    fraction of the roofline that bounds it."""
+    rows = []
+    for k, d in sorted(by_kernel.items(), key=lambda kv: -kv[1]["ms"]):
+        ms = max(d["ms"] - overhead_ms * d["launches"], 1e-6)
+        hbm = d["family"] in HBM_KERNELS
+        f32 = d["family"].endswith("f32")
+        rate = d["work"] / (ms * 1e-3) / (1e9 if hbm else 1e12)
+        peak = PEAK_HBM_GBS if hbm else (PEAK_F32_TFLOPS if f32 else PEAK_BF16_TFLOPS)
+        rows.append({"kernel": k, "bound": "hbm" if hbm else "mfma", "launches_per_step": round(d["launches"] / steps, 2),
+                     "us_per_launch": round(1e3 * ms / d["launches"], 2), "ms_per_step": round(ms / steps, 4),
+                     ("algorithmic_MB_per_step" if hbm else "algorithmic_GFLOP_per_step"):
+                         round(d["work"] / steps / (1e6 if hbm else 1e9), 3),
+                     "achieved": round(rate, 2), "unit": "GB/s" if hbm else "TFLOP/s", "peak": peak, "frac": round(rate / peak, 5)})
+    return rows
+
+
+def parity_mode_rate(cfg, pc, label, extra, steps, burn_in=6):
+    """clouds/s of the SAME step with set_precision(torch.float32): fp32 operands on the fp32 MFMA / fp32 VALU attention,
+    the mode whose results meet the fp32-level tolerances of tests/test_model_gpu.py (VERDICT r1 #6)."""
+    from ppt_amd.train import Trainer
+    m = build_model(cfg["dataset"], cfg["head_type"], precision=torch.float32, model=cfg.get("model", "ULIP_PointBERT"),
+                    task=cfg.get("task", "cls"))
+    m.train()
+    tr = Trainer(m, lr=3e-3, label_smoothing=0.2, distributed=False)
+    tr.extra_inputs = extra
+    for _ in range(burn_in):
+        tr.step(pc, label)
+    tr.finish()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, _ = tr.step(pc, label)
+    tr.finish()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert np.isfinite(loss.item())
+    return {"dtype": "f32", "value": round(pc.shape[0] * steps / dt, 2), "unit": "point-clouds/s",
+            "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "burn_in": burn_in}
 
 
 def build_model(dataset="modelnet40", head_type=HEAD_TYPE, precision=torch.bfloat16, model="ULIP_PointBERT", task="cls"):
@@ -113,6 +166,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-parity-mode", action="store_true")
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
     a = ap.parse_args()
 
@@ -172,12 +226,19 @@ def main():
     for _ in range(a.warmup):
         trainer.step(pc, label)
     barrier()
+    # K steps bracketed by barrier + synchronize (the contract's `value`); a HIP event on the caller's stream after every
+    # step also gives the per-step times (hipEvents, median reported beside the mean)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    marks[0].record()
+    for i in range(a.steps):
         loss, _ = trainer.step(pc, label)
+        marks[i + 1].record()
     trainer.finish()                         # (the deferred BatchNorm-buffer broadcast of a multi-rank run is timed too)
     barrier()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     if world > 1 or force_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -200,8 +261,8 @@ def main():
             for _ in range(a.steps):
                 trainer.step(pc, label)
             torch.cuda.synchronize()
-            passes.append(ops.profiler.summary())
-        summ = sorted(passes, key=lambda d: d["gemm_bf16"]["ms"])[1]
+            passes.append((ops.profiler.summary(), ops.profiler.by_kernel()))
+        summ, detail = sorted(passes, key=lambda d: d[0]["gemm_bf16"]["ms"])[1]
         # an event pair around ANY launch also times the dispatch gaps on both sides of it; calibrate that on a
         # trivial kernel (1-element dtype conversion, ~1.5 us of execution) and take it off every bracket, so that
         # the per-launch figure is comparable with rocprofv3's kernel-only durations (profiles/)
@@ -229,9 +290,11 @@ def main():
         g_ms = g["ms"] - overhead_ms * g["launches"]
         achieved = g["work"] / (g_ms * 1e-3) / 1e12
         traffic = None          # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE), see profiles/
-        tf = os.path.join(ROOT, "profiles", "r01_gemm_hbm_traffic.json")
-        if a.config == "C2" and os.path.exists(tf):
-            traffic = round(json.load(open(tf))["hbm_bytes_per_launch"])
+        for rnd in ("r02", "r01"):
+            tf = os.path.join(ROOT, "profiles", f"{rnd}_gemm_hbm_traffic.json")
+            if a.config == "C2" and os.path.exists(tf):
+                traffic = round(json.load(open(tf))["hbm_bytes_per_launch"])
+                break
         roof = {"bound": "mfma", "kernel": "bf16 GEMM family (ppt_amd/csrc/gemm.hip, mpn1/mpn3/mpn4.hip)",
                 "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
@@ -240,7 +303,8 @@ def main():
                 "avg_bracket_us": round(1e3 * g["ms"] / g["launches"], 2), "event_overhead_us": round(1e3 * overhead_ms, 2),
                 "algorithmic_gflop_per_launch": round(g["work"] / g["launches"] / 1e9, 3),
                 "per_kernel_ms_per_step": {k: round((v["ms"] - overhead_ms * v["launches"]) / a.steps, 4)
-                                           for k, v in summ.items()}}
+                                           for k, v in summ.items()},
+                "kernels": kernel_table(detail, overhead_ms, a.steps)}
     if world > 1 or force_dist:
         dist.barrier()
 
@@ -248,12 +312,15 @@ def main():
         total = PER_GPU_BATCH * world * a.steps
         out = {"metric": METRICS[a.config],
                "value": round(total / elapsed, 2), "unit": "point-clouds/s", "n_gpus": world, "steps": a.steps,
-               "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True,
+               "warmup": a.warmup, "burn_in": BURN_IN_STEPS, "ms_per_step": round(1e3 * elapsed / a.steps, 3),
+               "ms_per_step_median": round(median_ms, 3), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": cfg["name"] + ", train-mode BN + DropPath, fwd + CE(ls 0.2) + bwd + AdamW",
                           "per_gpu_batch": PER_GPU_BATCH, "global_batch": PER_GPU_BATCH * world, "npoints": NPOINTS,
                           "classes": n_classes, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
                "roofline": roof}
+        if world == 1 and not force_dist and not a.no_parity_mode:
+            out["parity_mode"] = parity_mode_rate(cfg, pc, label, trainer.extra_inputs, max(3, a.steps // 2))
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -136,7 +136,8 @@ int ppt_gemm(const ppt_gemm_params *p, void *stream);
  *   residual_form == 0: C (bf16) = act(acc + bias); C2 (bf16, optional) = acc + bias (the saved pre-activation);
  *   residual_form != 0: C (f32)  = residual + row_scale[m / row_scale_rows] * (acc + bias) + residual2; C may alias
  *              residual; row_scale / residual2 / bias may be NULL.
- * K must be 384 or 512, N % 4 == 0, pointers 16-byte aligned: anything else PPT_EUNSUPPORTED / PPT_EINVAL.
+ * K must be 384 or 512, N % 4 == 0, pointers 16-byte aligned, a_ln and residual_form not both set: anything else
+ * PPT_EUNSUPPORTED / PPT_EINVAL.
  * walkers: workgroups per column group walking the 32-row tiles (0 = as many as fill the chip). */
 typedef struct ppt_rowgemm_params {
     const void *A;
@@ -156,6 +157,7 @@ typedef struct ppt_rowgemm_params {
     const float *row_scale;          /* [ceil(M / row_scale_rows)] f32 or NULL */
     int row_scale_rows;
     int walkers;
+    int groups;                      /* set by the library (column groups of the launch); callers leave it 0 */
 } ppt_rowgemm_params;
 
 int ppt_rowgemm_bf16(const ppt_rowgemm_params *p, void *stream);
@@ -226,7 +228,7 @@ int ppt_bn_rows_bwd_reduce(const float *dy, const float *x, const float *scale, 
                            const float *rstd, int relu, int64_t M, int C, float *part_g, float *part_gx, void *stream);
 int ppt_bn_rows_bwd_apply(const float *dy, const float *x, const float *scale, const float *shift, const float *mean,
                           const float *rstd, const float *sum_g, const float *sum_gx, int relu, int batch_stats, int64_t M,
-                          int C, float *dx, void *stream);
+                          int C, float *dx, void *dx_bf16, void *stream);     /* dx f32 and / or a bf16 copy (either may be NULL) */
 int ppt_conv1_stats_max_partials(int64_t M);
 int ppt_conv1_stats_rows_per_partial(void);
 
@@ -321,6 +323,23 @@ int ppt_linear3_gelu(const float *pts, int64_t M, const float *w, const float *b
 /* point_encoder.py:251: out[b] = cat(x[b,0,:], max_t x[b,1:,:]) -> [B, 2D]; argmax [B,D] i32 for bwd. */
 int ppt_cls_max_pool(const void *x, int x_dtype, int B, int T, int D, float *out, int32_t *argmax,
                      void *stream);
+/* ---- part-segmentation decoder glue (models/pointbert/pointnet2_utils.py:297-467; csrc/interp.hip) -------------------
+ * three_nn_interp_fwd: PointNetFeaturePropagation.forward :333-358 after the 3-NN search (ppt_knn_group_f32 with k = 3 and
+ *   distances): weight_j = (1 / (dist_j + 1e-8)) / sum_j (...), out[b*N + n] = [points1[b,n,:D1] | sum_j weight_j *
+ *   points2[b, idx[b,n,j], :D2] | 0 ...] with row stride ld_out (even, >= D1 + D2) in out_dtype -- directly the A operand of
+ *   the first conv (torch.cat + K padding + dtype conversion fused); weight_out [B,N,3] f32 (may be NULL) keeps the
+ *   normalised weights for the backward.  points1 may be NULL when D1 == 0.
+ * scatter_rows_bwd: gradient of a row gather, d_src[b, s, :C] = sum over e in [0, E) with idx[b, e] == s of
+ *   weight[b, e] * d_rows[b * (E / rows_div) + e / rows_div, col_off : col_off + C] (weight NULL = 1), entries taken in
+ *   ascending e: deterministic, no atomics.  Interpolation: E = 3 N, rows_div = 3, weight = weight_out; neighbour gather
+ *   of DGCNN_Propagation (:404-440): E = Nq * k, rows_div = 1, no weight.  S <= 65535, C <= 512.
+ * sum_groups: out[g, :] = sum over j < k of x[g, j, :], x [G, k, C] f32, C % 4 == 0. */
+int ppt_three_nn_interp_fwd(const float *points1, int D1, const float *points2, int D2, const int64_t *idx, const float *dist,
+                            int B, int N, int S, void *out, int out_dtype, int ld_out, float *weight_out, void *stream);
+int ppt_scatter_rows_bwd(const int64_t *idx, const float *weight, const float *d_rows, int64_t ld, int col_off, int B, int E,
+                         int rows_div, int S, int C, float *d_src, void *stream);
+int ppt_sum_groups(const float *x, int64_t G, int k, int C, float *out, void *stream);
+
 /* ---- PointNet2 set-abstraction helpers (models/pointnet2/pointnet2_utils.py:228-266) ------------------------
  * A 1x1 convolution over gathered neighbours is linear, so the first layer of a grouped MLP is evaluated per
  * SOURCE point (P = W.[feat|xyz], a small GEMM) and per centre (Q = b - W_xyz.centre) and then gathered:

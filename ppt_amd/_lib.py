@@ -39,7 +39,7 @@ class RowGemmParams(ctypes.Structure):
         ("A", c_void_p), ("W", c_void_p), ("C", c_void_p), ("C2", c_void_p), ("M", c_int), ("N", c_int), ("K", c_int),
         ("a_ln", c_int), ("ln_w", c_void_p), ("ln_b", c_void_p), ("ln_eps", c_float), ("bias", c_void_p), ("act", c_int),
         ("residual_form", c_int), ("residual", c_void_p), ("residual2", c_void_p), ("row_scale", c_void_p),
-        ("row_scale_rows", c_int), ("walkers", c_int),
+        ("row_scale_rows", c_int), ("walkers", c_int), ("groups", c_int),
     ]
 
 
@@ -54,6 +54,11 @@ _SIGNATURES = {
                                 c_void_p]),
     "ppt_bn_act_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ppt_gemm": (c_int, [ctypes.POINTER(GemmParams), c_void_p]),
+    "ppt_three_nn_interp_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int,
+                                        c_int, c_void_p, c_void_p]),
+    "ppt_scatter_rows_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                     c_void_p]),
+    "ppt_sum_groups": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "ppt_rowgemm_bf16": (c_int, [ctypes.POINTER(RowGemmParams), c_void_p]),
     "ppt_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                   c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
@@ -78,7 +83,7 @@ _SIGNATURES = {
     "ppt_bn_rows_bwd_reduce": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int,
                                        c_void_p, c_void_p, c_void_p]),
     "ppt_bn_rows_bwd_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                      c_int, c_int64, c_int, c_void_p, c_void_p]),
+                                      c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "ppt_bn_finalize_workspace_bytes": (ctypes.c_size_t, [c_int, c_int]),
     "ppt_gn_stats_chunks": (c_int, [c_int]),
     "ppt_gn_bwd_chunks": (c_int, [c_int]),

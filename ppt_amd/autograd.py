@@ -146,3 +146,171 @@ def batch_norm_relu_rows(x, bn, training):
     """F.relu(bn(x)) for x [M,C] and an nn.BatchNorm1d `bn` (momentum must be a number)."""
     return _BatchNormReLURows.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                     bn.num_batches_tracked if training else None, training, bn.momentum, bn.eps)
+
+
+# =================================================================================================
+# Fused modules of the part-segmentation decoder: ONE autograd node per reference module, so the tensors between its
+# layers exist only in the form their consumer wants -- the operand dtype for the next GEMM, never an fp32 tensor that is
+# converted (ppt_convert), padded, concatenated or gathered by ATen kernels on the way.
+# =================================================================================================
+def _mult(prec):
+    return 8 if prec == torch.bfloat16 else 4
+
+
+def _w_operand(w, prec):
+    """Conv / Linear weight [N, K, ...] -> operand copy [N, Kp] in `prec`, K zero-padded to the GEMM's alignment."""
+    return _pad_k(w.detach().reshape(w.shape[0], -1).float(), _mult(prec), prec)
+
+
+def _conv_bn_relu_fwd(xT, w, b, bn, training, prec, out_dtype):
+    """relu(bn(conv(x))) over rows (pointnet2_utils.py:362-366): x [M, Kp] in the operand dtype -> (h [M, N] in out_dtype,
+    what the backward needs).  The conv output is kept in fp32 (the BatchNorm statistics and its backward read it); its
+    chunk statistics come out of the GEMM epilogue."""
+    M = xT.shape[0]
+    wT = _w_operand(w, prec)
+    N = wT.shape[0]
+    st = None
+    if training and M % 32 == 0:
+        st = (torch.empty((M // 32, N), dtype=torch.float32, device=xT.device), torch.empty((M // 32, N), dtype=torch.float32, device=xT.device))
+    y = ops.gemm(xT, wT, out_dtype=torch.float32, bias=b.detach().float().contiguous() if b is not None else None, col_stats=st)
+    g, be = bn.weight.detach().float().contiguous(), bn.bias.detach().float().contiguous()
+    if training:
+        parts, rpp = (st, 32) if st is not None else ops.rows_stats(y)
+        sc, sh, mean, rstd = ops.bn_finalize(g, be, True, partials=parts, rows_per_partial=rpp, count=M, running_mean=bn.running_mean,
+                                             running_var=bn.running_var, num_batches_tracked=bn.num_batches_tracked, eps=bn.eps,
+                                             momentum=bn.momentum, want_moments=True)
+    else:
+        sc, sh, mean, rstd = ops.bn_finalize(g, be, False, running_mean=bn.running_mean, running_var=bn.running_var, eps=bn.eps,
+                                             want_moments=True)
+    h = ops.bn_act_rows(y, sc, sh, out_dtype)
+    return h, (xT, wT, y, sc, sh, mean, rstd)
+
+
+def _conv_bn_relu_bwd(dh, saved, training, prec, w, need_dx):
+    """-> (dx [M, Kp] f32 | None, dW like w, db [N], dgamma, dbeta) for _conv_bn_relu_fwd; dh [M, N] f32."""
+    xT, wT, y, sc, sh, mean, rstd = saved
+    bf = prec == torch.bfloat16
+    res = ops.bn_rows_backward(dh.contiguous().float(), y, sc, sh, mean, rstd, True, training, want_dx=not bf, want_bf16=bf)
+    dgamma, dbeta = res[1], res[2]
+    dyT = res[3] if bf else res[0]
+    K = w[0].numel()
+    dW = ops.gemm_tn_splitk(dyT, xT)
+    dW = (dW if dW.shape[1] == K else dW[:, :K]).reshape(w.shape)
+    db = ops.col_sums(dyT)
+    dx = ops.gemm(dyT, ops.transpose(wT), out_dtype=torch.float32) if need_dx else None
+    return dx, dW, db, dgamma, dbeta
+
+
+class _FeaturePropagation(torch.autograd.Function):
+    """PointNetFeaturePropagation.forward (pointbert/pointnet2_utils.py:310-368) after the 3-NN search: interpolation +
+    concatenation (ppt_three_nn_interp_fwd writes the first conv's operand), two conv + BatchNorm + ReLU layers, and the whole
+    backward (weights, biases, BatchNorm affine, and the interpolated features through ppt_scatter_rows_bwd)."""
+
+    @staticmethod
+    def forward(ctx, points2, w0, b0, g0, be0, w1, b1, g1, be1, mod, idx, dist, points1, prec):
+        training = mod.training
+        B, N, _ = idx.shape
+        p2 = points2.detach().float().contiguous()
+        p1 = points1.detach().float().contiguous() if points1 is not None else None
+        rows, wgt = ops.three_nn_interp(p1, p2, idx, dist, prec, _mult(prec))
+        h0, s0 = _conv_bn_relu_fwd(rows, w0, b0, mod.mlp_bns[0], training, prec, prec)
+        h1, s1 = _conv_bn_relu_fwd(h0, w1, b1, mod.mlp_bns[1], training, prec, torch.float32)
+        ctx.s0, ctx.s1, ctx.idx, ctx.wgt = s0, s1, idx, wgt
+        ctx.training, ctx.prec, ctx.w0, ctx.w1 = training, prec, w0, w1
+        ctx.D1, ctx.S, ctx.D2 = (0 if p1 is None else p1.shape[2]), p2.shape[1], p2.shape[2]
+        return h1.view(B, N, -1)
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, N, C = dout.shape
+        dh0, dW1, db1, dg1, dbe1 = _conv_bn_relu_bwd(dout.reshape(B * N, C), ctx.s1, ctx.training, ctx.prec, ctx.w1, True)
+        d_rows, dW0, db0, dg0, dbe0 = _conv_bn_relu_bwd(dh0, ctx.s0, ctx.training, ctx.prec, ctx.w0, ctx.needs_input_grad[0])
+        dp2 = None
+        if ctx.needs_input_grad[0]:
+            dp2 = ops.scatter_rows_bwd(ctx.idx.view(B, N * 3), ctx.wgt.view(B, N * 3), d_rows, ctx.D1, 3, ctx.S, ctx.D2)
+        return dp2, dW0, db0, dg0, dbe0, dW1, db1, dg1, dbe1, None, None, None, None, None
+
+
+def feature_propagation(mod, points1, points2, idx, dist, prec):
+    """mod: a PointNetFeaturePropagation with two conv + bn layers; idx / dist [B,N,3] from the 3-NN search."""
+    c0, c1, n0, n1 = mod.mlp_convs[0], mod.mlp_convs[1], mod.mlp_bns[0], mod.mlp_bns[1]
+    return _FeaturePropagation.apply(points2, c0.weight, c0.bias, n0.weight, n0.bias, c1.weight, c1.bias, n1.weight, n1.bias,
+                                     mod, idx, dist, points1, prec)
+
+
+class _ConvBNReLURows(torch.autograd.Function):
+    """relu(bn(conv(x))) for fp32 rows x [M,K] (the decoder's conv1 + bn1, point_encoder.py:414-416) as one node."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, g, be, conv_bn, prec):
+        bn, training = conv_bn
+        xT = _pad_k(x.detach().float().contiguous(), _mult(prec), prec)
+        h, s = _conv_bn_relu_fwd(xT, w, b, bn, training, prec, torch.float32)
+        ctx.s, ctx.training, ctx.prec, ctx.w, ctx.K = s, training, prec, w, x.shape[1]
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        dx, dW, db, dg, dbe = _conv_bn_relu_bwd(dh, ctx.s, ctx.training, ctx.prec, ctx.w, ctx.needs_input_grad[0])
+        if dx is not None and dx.shape[1] != ctx.K:
+            dx = dx[:, :ctx.K]
+        return dx, dW, db, dg, dbe, None, None
+
+
+def conv_bn_relu_rows(x, conv, bn, training, prec):
+    return _ConvBNReLURows.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, (bn, training), prec)
+
+
+class _DGCNNLayer(torch.autograd.Function):
+    """One layer of DGCNN_Propagation (pointbert/pointnet2_utils.py:404-440): conv(cat(x_k[nn] - x_q, x_q)) + GroupNorm +
+    LeakyReLU + max over the k neighbours.  By linearity of the 1x1 conv, W = [Wa | Wb]:
+        Wa.(x_j - x_q) + Wb.x_q = Wa.x_j + (Wb - Wa).x_q
+    so the conv runs once per source point (P) and once per query (Q) and ppt_gather_add forms the [B,Nq,k,Cout] rows.
+    Backward: GroupNorm kernels -> dy; dP by the owner-computes scatter (ppt_scatter_rows_bwd), dQ = sum over k
+    (ppt_sum_groups); dWa = dP^T x_k, d(Wb - Wa) = dQ^T x_q on the NT weight-gradient GEMM; input gradients by two GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x_k, x_q, w, gn_w, gn_b, idx, gn, slope, prec):
+        B, S, C = x_k.shape
+        Nq = x_q.shape[1]
+        K = idx.shape[2]
+        w2 = w.detach().reshape(w.shape[0], -1).float()
+        Cout = w2.shape[0]
+        waT = _pad_k(w2[:, :C], _mult(prec), prec)
+        wdT = _pad_k(w2[:, C:] - w2[:, :C], _mult(prec), prec)
+        xkT = _pad_k(x_k.detach().reshape(B * S, C).float(), _mult(prec), prec)
+        xqT = xkT if x_q is x_k else _pad_k(x_q.detach().reshape(B * Nq, C).float(), _mult(prec), prec)
+        P = ops.gemm(xkT, waT, out_dtype=torch.float32)
+        Q = ops.gemm(xqT, wdT, out_dtype=torch.float32)
+        y, _ = ops.gather_add(P, Q, idx.contiguous(), S, torch.float32, want_stats=False)
+        y = y.view(B, Nq, K, Cout)
+        g, b = gn_w.detach().float().contiguous(), gn_b.detach().float().contiguous()
+        out, arg, mean, rstd = ops.gn_lrelu_max_forward(y, g, b, gn.num_groups, gn.eps, slope)
+        ctx.saved = (xkT, xqT, waT, wdT, y, out, arg, mean, rstd, g, idx)
+        ctx.groups, ctx.slope, ctx.prec, ctx.w, ctx.C, ctx.S, ctx.same = gn.num_groups, slope, prec, w, C, S, x_q is x_k
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xkT, xqT, waT, wdT, y, out, arg, mean, rstd, g, idx = ctx.saved
+        B, Nq, K, Cout = y.shape
+        C, prec = ctx.C, ctx.prec
+        dy, dgamma, dbeta = ops.gn_lrelu_max_backward(y, dout.contiguous().float(), out, arg, mean, rstd, g, ctx.groups, ctx.slope)
+        dy2 = dy.view(B * Nq * K, Cout)
+        dP = ops.scatter_rows_bwd(idx.view(B, Nq * K), None, dy2, 0, 1, ctx.S, Cout).view(B * ctx.S, Cout)
+        dQ = ops.sum_groups(dy2, K)
+        dPT, dQT = ops.convert(dP, prec), ops.convert(dQ, prec)
+        dWa = ops.gemm_tn_splitk(dPT, xkT)[:, :C]
+        dWd = ops.gemm_tn_splitk(dQT, xqT)[:, :C]
+        dW = torch.cat([dWa - dWd, dWd], dim=1).reshape(ctx.w.shape)
+        dxk = dxq = None
+        if ctx.needs_input_grad[0]:
+            dxk = ops.gemm(dPT, ops.transpose(waT), out_dtype=torch.float32)[:, :C].reshape(B, ctx.S, C)
+        if ctx.needs_input_grad[1]:
+            dxq = ops.gemm(dQT, ops.transpose(wdT), out_dtype=torch.float32)[:, :C].reshape(B, Nq, C)
+        return dxk, dxq, dW, dgamma, dbeta, None, None, None, None
+
+
+def dgcnn_layer(x_k, x_q, conv, gn, idx, slope, prec):
+    """x_k [B,S,C] sources, x_q [B,Nq,C] queries, idx [B,Nq,k] neighbours of each query among the sources -> [B,Nq,Cout]."""
+    return _DGCNNLayer.apply(x_k, x_q, conv.weight, gn.weight, gn.bias, idx, gn, slope, prec)

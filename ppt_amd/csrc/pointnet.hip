@@ -252,7 +252,8 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_apply_kernel(const float *__r
                                                                 const float *__restrict__ scale, const float *__restrict__ shift,
                                                                 const float *__restrict__ mean, const float *__restrict__ rstd,
                                                                 const float *__restrict__ sum_g, const float *__restrict__ sum_gx,
-                                                                int relu, int batch_stats, int64_t M, int C, float *__restrict__ dx)
+                                                                int relu, int batch_stats, int64_t M, int C, float *__restrict__ dx,
+                                                                bf16_t *__restrict__ dx_bf16)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
@@ -264,7 +265,9 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_apply_kernel(const float *__r
         const float v = x[(r0 + r) * C + c];
         float g = dy[(r0 + r) * C + c];
         if (relu && !(fmaf(v, sc, sh) > 0.f)) g = 0.f;
-        dx[(r0 + r) * C + c] = sc * (g - mg - (v - mu) * rs * mgx);
+        const float o = sc * (g - mg - (v - mu) * rs * mgx);
+        if (dx) dx[(r0 + r) * C + c] = o;
+        if (dx_bf16) dx_bf16[(r0 + r) * C + c] = f32_to_bf16(o);
     }
 }
 
@@ -513,13 +516,14 @@ extern "C" int ppt_bn_rows_bwd_reduce(const float *dy, const float *x, const flo
 
 extern "C" int ppt_bn_rows_bwd_apply(const float *dy, const float *x, const float *scale, const float *shift, const float *mean,
                                      const float *rstd, const float *sum_g, const float *sum_gx, int relu, int batch_stats,
-                                     int64_t M, int C, float *dx, void *stream)
+                                     int64_t M, int C, float *dx, void *dx_bf16, void *stream)
 {
-    if (!dy || !x || !scale || !shift || !mean || !rstd || !dx || M <= 0 || C <= 0 || (M + RS_ROWS - 1) / RS_ROWS > 65535)
+    if (!dy || !x || !scale || !shift || !mean || !rstd || (!dx && !dx_bf16) || M <= 0 || C <= 0 || (M + RS_ROWS - 1) / RS_ROWS > 65535)
         return PPT_EINVAL;
     if (batch_stats && (!sum_g || !sum_gx)) return PPT_EINVAL;
     hipLaunchKernelGGL(bn_rows_bwd_apply_kernel, dim3((C + 255) / 256, (unsigned)((M + RS_ROWS - 1) / RS_ROWS)), dim3(256), 0,
-                       ppt_stream(stream), dy, x, scale, shift, mean, rstd, sum_g, sum_gx, relu, batch_stats, M, C, dx);
+                       ppt_stream(stream), dy, x, scale, shift, mean, rstd, sum_g, sum_gx, relu, batch_stats, M, C, dx,
+                       (bf16_t *)dx_bf16);
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }

@@ -40,7 +40,7 @@ template <int K> struct RG {
     static constexpr int BUF = 32 * PITCH;
     static constexpr int F4 = K / 64;                    // float4 per thread and row, LayerNorm prologue (16 threads per row)
     static constexpr int U4 = K / 128;                   // uint4 per thread and row, bf16 A
-    static constexpr int LDS = 2 * BUF + 2 * K * 4;      // two A buffers + gamma + beta
+    static constexpr int LDS = 2 * BUF + 2 * K * 4 + NB * 4;   // two A buffers + gamma + beta + the bias slice
 };
 
 // sum over the 16 lanes of a DPP row; every lane gets the same bits (each step adds a value to its mirror image)
@@ -63,8 +63,14 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(const ppt_rowgemm_param
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, kg = lane >> 4;
-    const int n0 = blockIdx.y * G::NB + w * G::NW;                       // first column of this wave
+    // Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one): the column groups of one walker -- which
+    // read the same A rows at about the same time -- get linear ids that agree modulo 8, so two of three (three of four)
+    // of those reads are hits in the XCD's L2 instead of trips to the Infinity Cache.
+    const int b_lo = blockIdx.x & 7, b_q = blockIdx.x >> 3;
+    const int group = b_q % p.groups, walker = (b_q / p.groups) * 8 + b_lo;
+    const int n0 = group * G::NB + w * G::NW;                            // first column of this wave
     const int n_tiles = (p.M + 31) >> 5;
+    const int n_walk = p.walkers;
 
     // ---- the stationary operand: W[n0 + 16 nb + l15][32 s + 8 kg .. + 8)
     bf16x8_t wf[G::NCB][G::KS];
@@ -76,18 +82,13 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(const ppt_rowgemm_param
         for (int s = 0; s < G::KS; ++s)
             wf[nb][s] = *reinterpret_cast<const bf16x8_t *>(W + (size_t)n * K + 32 * s + 8 * kg);
     }
-    // per-lane epilogue constants: columns n0 + 16 nb + 4 kg + i
-    float bias[G::NCB][4];
-#pragma unroll
-    for (int nb = 0; nb < G::NCB; ++nb)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = n0 + 16 * nb + 4 * kg + i;
-            bias[nb][i] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
-        }
-    float *gam = reinterpret_cast<float *>(smem + 2 * G::BUF), *bet = gam + K;
+    float *gam = reinterpret_cast<float *>(smem + 2 * G::BUF), *bet = gam + K, *bia = bet + K;
     if constexpr (LN) {
         for (int c = threadIdx.x; c < K; c += 512) { gam[c] = p.ln_w[c]; bet[c] = p.ln_b[c]; }
+    }
+    for (int c = threadIdx.x; c < G::NB; c += 512) {                     // this workgroup's bias slice (0 when there is none)
+        const int n = group * G::NB + c;
+        bia[c] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
     }
 
     // ---- loader: thread -> row r (0..31) of the tile, 16 threads per row
@@ -138,15 +139,41 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(const ppt_rowgemm_param
         }
     };
 
-    int t = blockIdx.x;
+    // residual-form epilogue: the fp32 residual rows of a tile are fetched a whole phase before they are used (a load
+    // consumed where it is issued costs a memory round trip per 16 x 16 block: measured 2x on this epilogue in gemm.hip)
+    float4 res[EPI == EPI_RESIDUAL ? 2 : 1][EPI == EPI_RESIDUAL ? G::NCB : 1];
+    float rsc[2] = {1.0f, 1.0f};
+    auto load_res = [&](int tile) {
+        if constexpr (EPI == EPI_RESIDUAL) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const int m = min(tile * 32 + 16 * rb + l15, p.M - 1);
+                rsc[rb] = p.row_scale ? p.row_scale[m / p.row_scale_rows] : 1.0f;
+#pragma unroll
+                for (int nb = 0; nb < G::NCB; ++nb) {
+                    const int n = min(n0 + 16 * nb + 4 * kg, p.N - 4);
+                    res[rb][nb] = *reinterpret_cast<const float4 *>(p.residual + (size_t)m * p.N + n);
+                }
+            }
+        }
+    };
+
+    int t = walker;
     if (t >= n_tiles) return;
     load(t);
-    __syncthreads();                                                     // gamma / beta are in LDS
+    __syncthreads();                                                     // gamma / beta / bias are in LDS
     stage(0);
+    load(min(t + n_walk, n_tiles - 1));
+    load_res(t);
     __syncthreads();
-    for (int it = 0; t < n_tiles; t += gridDim.x, ++it) {
+    // Order inside an iteration (pinned with scheduling fences; hipcc otherwise sinks the loads behind the MFMAs):
+    //   MFMAs of tile t | stage tile t+1 (its loads were issued a whole iteration ago) | issue the loads of tile t+2 |
+    //   epilogue + stores of tile t | issue the residual loads of tile t+1 | barrier.
+    // Every s_waitcnt vmcnt the compiler places in front of a use of loaded data is conservative across the conditional
+    // stores (vmcnt(0)): with this order whatever it waits for was issued at least one MFMA phase earlier.  (Stores
+    // directly in front of the staging made every tile wait for its own output to drain: 5.4 us per tile.)
+    for (int it = 0; t < n_tiles; t += n_walk, ++it) {
         const int cur = it & 1;
-        load(min(t + (int)gridDim.x, n_tiles - 1));                      // unconditional (a branch parks the registers in scratch)
         const unsigned char *a0 = smem + cur * G::BUF + l15 * G::PITCH + 16 * kg;
         const unsigned char *a1 = a0 + 16 * G::PITCH;
         f32x4_t acc[2][G::NCB];
@@ -164,24 +191,27 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(const ppt_rowgemm_param
                 acc[1][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][s], f1, acc[1][nb], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        stage(cur ^ 1);                                                  // (that buffer was last read in iteration it - 1, before its barrier)
+        __builtin_amdgcn_sched_barrier(0);
+        load(min(t + 2 * n_walk, n_tiles - 1));                          // unconditional (a branch parks the registers in scratch)
+        __builtin_amdgcn_sched_barrier(0);
         // ---- epilogue: lane holds D[n = n0 + 16 nb + 4 kg + i][m = 32 t + 16 rb + l15]
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
             const int m = t * 32 + 16 * rb + l15;
             if (m < p.M) {
-                float rs = 1.0f;
-                if constexpr (EPI == EPI_RESIDUAL) { if (p.row_scale) rs = p.row_scale[m / p.row_scale_rows]; }
 #pragma unroll
                 for (int nb = 0; nb < G::NCB; ++nb) {
                     const int n = n0 + 16 * nb + 4 * kg;
                     if (n < p.N) {
-                        float v[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = acc[rb][nb][i] + bias[nb][i];
+                        const float4 bv = *reinterpret_cast<const float4 *>(bia + w * G::NW + 16 * nb + 4 * kg);
+                        float v[4] = {acc[rb][nb][0] + bv.x, acc[rb][nb][1] + bv.y, acc[rb][nb][2] + bv.z, acc[rb][nb][3] + bv.w};
                         const size_t o = (size_t)m * p.N + n;
                         if constexpr (EPI == EPI_RESIDUAL) {
-                            const float4 res = *reinterpret_cast<const float4 *>(p.residual + o);
-                            float4 out = make_float4(v[0] * rs + res.x, v[1] * rs + res.y, v[2] * rs + res.z, v[3] * rs + res.w);
+                            const float4 r1 = res[rb][nb];
+                            const float rs = rsc[rb];
+                            float4 out = make_float4(v[0] * rs + r1.x, v[1] * rs + r1.y, v[2] * rs + r1.z, v[3] * rs + r1.w);
                             if (p.residual2) {
                                 const float4 r2 = *reinterpret_cast<const float4 *>(p.residual2 + o);
                                 out.x += r2.x; out.y += r2.y; out.z += r2.z; out.w += r2.w;
@@ -202,7 +232,8 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(const ppt_rowgemm_param
                 }
             }
         }
-        stage(cur ^ 1);                                                  // (last read in iteration it - 1, before its barrier)
+        __builtin_amdgcn_sched_barrier(0);
+        load_res(min(t + n_walk, n_tiles - 1));
         __syncthreads();
     }
 }
@@ -216,12 +247,16 @@ int launch(const ppt_rowgemm_params &p, hipStream_t s, int cus)
         return 0;
     }();
     (void)once;
-    const int groups = (p.N + G::NB - 1) / G::NB;
+    ppt_rowgemm_params q = p;
+    q.groups = (p.N + G::NB - 1) / G::NB;
     const int tiles = (p.M + 31) / 32;
-    int walkers = p.walkers > 0 ? p.walkers : cus / groups;
-    if (walkers < 1) walkers = 1;
+    // walkers per column group: a multiple of 8 (the XCD-aware id mapping), as many as fill the chip, no more than tiles
+    int walkers = p.walkers > 0 ? p.walkers : cus / q.groups;
     if (walkers > tiles) walkers = tiles;
-    hipLaunchKernelGGL((rowgemm_kernel<K, LN, EPI>), dim3(walkers, groups), dim3(512), G::LDS, s, p);
+    walkers = (walkers + 7) / 8 * 8;
+    if (walkers * q.groups > cus && walkers > 8 && p.walkers <= 0) walkers -= 8;
+    q.walkers = walkers;
+    hipLaunchKernelGGL((rowgemm_kernel<K, LN, EPI>), dim3(walkers * q.groups), dim3(512), G::LDS, s, q);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PPT_OK : PPT_ELAUNCH;
 }
@@ -237,6 +272,7 @@ extern "C" int ppt_rowgemm_bf16(const ppt_rowgemm_params *pp, void *stream)
     if (p.N % 4) return PPT_EUNSUPPORTED;
     if (p.a_ln && (!p.ln_w || !p.ln_b)) return PPT_EINVAL;
     if (p.residual_form && !p.residual) return PPT_EINVAL;
+    if (p.residual_form && p.a_ln) return PPT_EUNSUPPORTED;          /* (no caller: a LayerNorm is never followed by a residual-form linear) */
     if (p.residual_form && (p.act != PPT_ACT_NONE || p.C2)) return PPT_EUNSUPPORTED;
     if (p.row_scale && p.row_scale_rows <= 0) return PPT_EINVAL;
     if (p.act != PPT_ACT_NONE && p.act != PPT_ACT_GELU && p.act != PPT_ACT_QUICKGELU) return PPT_EUNSUPPORTED;
@@ -249,7 +285,7 @@ extern "C" int ppt_rowgemm_bf16(const ppt_rowgemm_params *pp, void *stream)
     }();
     hipStream_t s = ppt_stream(stream);
 #define PPT_RG(KK)                                                                                       \
-    (p.a_ln ? (p.residual_form ? launch<KK, true, EPI_RESIDUAL>(p, s, cus) : launch<KK, true, EPI_BF16>(p, s, cus)) \
+    (p.a_ln ? launch<KK, true, EPI_BF16>(p, s, cus)                                                       \
             : (p.residual_form ? launch<KK, false, EPI_RESIDUAL>(p, s, cus) : launch<KK, false, EPI_BF16>(p, s, cus)))
     return p.K == 384 ? PPT_RG(384) : PPT_RG(512);
 #undef PPT_RG

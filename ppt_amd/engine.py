@@ -70,6 +70,7 @@ class WeightCache:
 
 
 FUSED_CONV12 = os.environ.get("PPT_FUSED_CONV12", "1") != "0"      # 0: the generic PPT_A_CONV1 GEMM (A/B comparisons)
+ROWGEMM = os.environ.get("PPT_ROWGEMM", "1") != "0"                 # 0: LayerNorm kernel + tile-loop GEMM for the K = 384 / 512 linears
 
 
 def _bn_params(sd, p):
@@ -153,6 +154,24 @@ def vit_block_forward(sd, p, wc, x, pos, B, Tn, heads, dp1, dp2, save=None, pos_
     place unless `save` (a dict) is given: then every intermediate the backward needs is kept.
     pos_in_x: x already holds x + pos (the previous block's fc2 epilogue added it: add_pos_out there), so norm1
     neither reads pos nor rewrites the residual stream; the sums are formed in the same order either way."""
+    T = wc.dtype
+    keep = save is not None
+    if ROWGEMM and T == torch.bfloat16 and not keep and x.shape[1] in ops.ROWGEMM_K:
+        # frozen block, nothing kept: the K = 384 linears with the weight stationary in registers (csrc/rowgemm.hip); both
+        # LayerNorms are applied while the rows are staged, the residual stream is updated in place
+        if pos_in_x:
+            qkv = ops.rowgemm(x, wc.get(sd[p + "attn.qkv.weight"]), ln=(sd[p + "norm1.weight"], sd[p + "norm1.bias"]))
+        else:           # (the first block: x + pos is formed -- and written back -- by the LayerNorm kernel)
+            h, _, _ = ops.layernorm_fwd(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], T, add=pos, write_xs=x)
+            qkv = ops.rowgemm(h, wc.get(sd[p + "attn.qkv.weight"]))
+        a, _ = ops.attention_fwd(qkv, B, Tn, heads, ATTN_SCALE, False, want_lse=False)
+        ops.rowgemm(a, wc.get(sd[p + "attn.proj.weight"]), bias=sd[p + "attn.proj.bias"], residual=x, out=x, row_scale=dp1,
+                    row_scale_rows=Tn)
+        f = ops.rowgemm(x, wc.get(sd[p + "mlp.fc1.weight"]), ln=(sd[p + "norm2.weight"], sd[p + "norm2.bias"]),
+                        bias=sd[p + "mlp.fc1.bias"], act=ACT_GELU)
+        ops.gemm(f, wc.get(sd[p + "mlp.fc2.weight"]), out=x, bias=sd[p + "mlp.fc2.bias"], row_scale=dp2, row_scale_rows=Tn,
+                 residual=x, residual2=pos if add_pos_out else None)
+        return x
     T = wc.dtype
     keep = save is not None
     if pos_in_x:

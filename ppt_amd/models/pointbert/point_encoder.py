@@ -459,7 +459,7 @@ class PointTransformer_partseg(nn.Module):
     load_model_from_ckpt = _load_model_from_ckpt
 
     def forward(self, pts, cls_label):
-        from ...autograd import batch_norm_relu_rows, linear
+        from ...autograd import conv_bn_relu_rows
         pts = pts.contiguous().float()
         B, N, _ = pts.shape
         dev = pts.device
@@ -483,13 +483,12 @@ class PointTransformer_partseg(nn.Module):
             feats, center = engine.point_encoder_forward(self._live_state(), "", self._cache(), None, None, dp, self.training, 0,
                                                          self._cfg(), fetch=(3, 7, 11), grouped=(nbhd, center))
         f0 = torch.cat([cls_label.float().view(B, 1, 16).expand(-1, N, -1), pts], dim=-1)       # [B,N,19]
-        f2 = self.propagation_2(c2, center, c2, feats[1])
-        f1 = self.propagation_1(c1, center, c1, feats[0])
-        f2 = self.dgcnn_pro_2(center, feats[2], c2, f2)
-        f1 = self.dgcnn_pro_1(c2, f2, c1, f1)
-        f0 = self.propagation_0(pts, c1, f0, f1)
-        y = linear(f0.reshape(B * N, -1), self.conv1.weight, self.conv1.bias, self._precision)
-        y = batch_norm_relu_rows(y, self.bn1, self.training)
+        f2 = self.propagation_2.forward_rows(c2, center, c2, feats[1])
+        f1 = self.propagation_1.forward_rows(c1, center, c1, feats[0])
+        f2 = self.dgcnn_pro_2.forward_rows(center, feats[2], c2, f2)
+        f1 = self.dgcnn_pro_1.forward_rows(c2, f2, c1, f1)
+        f0 = self.propagation_0.forward_rows(pts, c1, f0, f1)
+        y = conv_bn_relu_rows(f0.reshape(B * N, -1), self.conv1, self.bn1, self.training, self._precision)
         y = y.view(B, N, -1)
         if self.dropout_mask is not None:
             y = y * self.dropout_mask.to(dev)

@@ -23,17 +23,29 @@ class KernelProfiler:
 
     def __init__(self):
         self.records = []          # (name, start_event, end_event, algorithmic work)
+        self.kernels = []          # the kernel behind each record (a finer name than the family in `name`)
 
-    def begin(self, name, work):
+    def begin(self, name, work, kernel=None):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(torch.cuda.current_stream())
-        self._cur = (name, ev, work)
+        self._cur = (name, ev, work, kernel or name)
 
     def end(self):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(torch.cuda.current_stream())
-        name, st, work = self._cur
+        name, st, work, kernel = self._cur
         self.records.append((name, st, ev, work))
+        self.kernels.append(kernel)
+
+    def by_kernel(self):
+        """-> {kernel: dict(family, launches, ms, work)} (call after a device synchronise)."""
+        out = {}
+        for (name, st, en, work), kernel in zip(self.records, self.kernels):
+            d = out.setdefault(kernel, dict(family=name, launches=0, ms=0.0, work=0.0))
+            d["launches"] += 1
+            d["ms"] += st.elapsed_time(en)
+            d["work"] += work
+        return out
 
     def summary(self):
         """-> {name: dict(launches, ms, work)} (call after a device synchronise)."""
@@ -116,8 +128,12 @@ def ball_query(xyz, center, radius, K, want_grouped=False):
     import numpy as np
     r2 = float(np.float32(radius * radius))
     g = torch.empty((B, S, K, 3), dtype=torch.float32, device=xyz.device) if want_grouped else None
+    if profiler is not None:                    # algorithmic HBM bytes per SA branch: cloud + centres + indices (+ grouped xyz)
+        profiler.begin("ball_query", float(B) * (12 * N + 12 * S + 8 * S * K + (12 * S * K if want_grouped else 0)))
     _lib.check(_lib.lib().ppt_ball_query_f32(_p(xyz), _p(center), B, N, S, r2, K, _p(idx), _p(g), _stream()),
                "ppt_ball_query_f32")
+    if profiler is not None:
+        profiler.end()
     return (idx, g) if want_grouped else idx
 
 
@@ -174,7 +190,8 @@ def gemm(A, B, *, out=None, out_dtype=None, M=None, bias=None, act=ACT_NONE, dac
     p.batch, p.strideA, p.strideB, p.strideC = batch, strideA, strideB, strideC
     if profiler is not None:
         kk = K if algo_k is None else algo_k
-        profiler.begin("gemm_" + ("bf16" if p.dtype == PPT_BF16 else "f32"), 2.0 * M * N * kk * max(1, batch))
+        profiler.begin("gemm_" + ("bf16" if p.dtype == PPT_BF16 else "f32"), 2.0 * M * N * kk * max(1, batch),
+                       "ppt_gemm " + ("bf16" if p.dtype == PPT_BF16 else "f32") + (" (A-prologue)" if a_mode != A_PLAIN else ""))
     _lib.check(_lib.lib().ppt_gemm(ctypes.byref(p), _stream()), "ppt_gemm")
     if profiler is not None:
         profiler.end()
@@ -215,7 +232,8 @@ def rowgemm(A, W, *, ln=None, ln_eps=1e-5, bias=None, act=ACT_NONE, out=None, ou
             p.C2 = _p(out2)
     p.C, p.walkers = _p(out), walkers
     if profiler is not None:
-        profiler.begin("gemm_bf16", 2.0 * M * N * K)
+        profiler.begin("gemm_bf16", 2.0 * M * N * K, "ppt_rowgemm_bf16" + (" (LayerNorm prologue)" if ln is not None else
+                                                                            " (residual form)" if residual is not None else ""))
     _lib.check(_lib.lib().ppt_rowgemm_bf16(ctypes.byref(p), _stream()), "ppt_rowgemm_bf16")
     if profiler is not None:
         profiler.end()
@@ -339,8 +357,8 @@ def rows_stats(x):
     return (ps, pq), rpp
 
 
-def bn_rows_backward(dy, x, scale, shift, mean, rstd, relu, batch_stats):
-    """BatchNorm1d(+ReLU) backward over rows: -> (dx [M,C], d gamma [C], d beta [C])."""
+def bn_rows_backward(dy, x, scale, shift, mean, rstd, relu, batch_stats, want_dx=True, want_bf16=False):
+    """BatchNorm1d(+ReLU) backward over rows: -> (dx [M,C] f32 | None, d gamma [C], d beta [C][, dx as bf16])."""
     _chk(dy, torch.float32, "dy"); _chk(x, torch.float32, "x")
     M, C = x.shape
     rpp = _lib.lib().ppt_rows_stats_rows_per_partial()
@@ -350,10 +368,50 @@ def bn_rows_backward(dy, x, scale, shift, mean, rstd, relu, batch_stats):
     _lib.check(_lib.lib().ppt_bn_rows_bwd_reduce(_p(dy), _p(x), _p(scale), _p(shift), _p(mean), _p(rstd), int(relu), M, C,
                                                  _p(pg), _p(pgx), _stream()), "ppt_bn_rows_bwd_reduce")
     sg, sgx = reduce_rows(pg), reduce_rows(pgx)
-    dx = torch.empty_like(x)
+    dx = torch.empty_like(x) if want_dx else None
+    dxb = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
     _lib.check(_lib.lib().ppt_bn_rows_bwd_apply(_p(dy), _p(x), _p(scale), _p(shift), _p(mean), _p(rstd), _p(sg), _p(sgx),
-                                                int(relu), int(batch_stats), M, C, _p(dx), _stream()), "ppt_bn_rows_bwd_apply")
-    return dx, sgx, sg
+                                                int(relu), int(batch_stats), M, C, _p(dx), _p(dxb), _stream()),
+               "ppt_bn_rows_bwd_apply")
+    return (dx, sgx, sg, dxb) if want_bf16 else (dx, sgx, sg)
+
+
+def three_nn_interp(points1, points2, idx, dist, out_dtype, mult):
+    """ppt_three_nn_interp_fwd: rows [B*N, ld] = [points1 | sum_j w_j points2[idx_j] | 0], ld = D1 + D2 rounded up to `mult`
+    (the K alignment of the GEMM that reads them), in out_dtype; -> (rows, normalised weights [B,N,3] f32)."""
+    _chk(points2, torch.float32, "points2"); _chk(idx, torch.int64, "idx"); _chk(dist, torch.float32, "dist")
+    _chk(points1, torch.float32, "points1")
+    B, N, _ = idx.shape
+    S, D2 = points2.shape[1], points2.shape[2]
+    D1 = 0 if points1 is None else points1.shape[2]
+    ld = (D1 + D2 + mult - 1) // mult * mult
+    rows = torch.empty((B * N, ld), dtype=out_dtype, device=points2.device)
+    w = torch.empty((B, N, 3), dtype=torch.float32, device=points2.device)
+    _lib.check(_lib.lib().ppt_three_nn_interp_fwd(_p(points1), D1, _p(points2), D2, _p(idx), _p(dist), B, N, S, _p(rows),
+                                                  dtype_code(rows), ld, _p(w), _stream()), "ppt_three_nn_interp_fwd")
+    return rows, w
+
+
+def scatter_rows_bwd(idx, weight, d_rows, col_off, rows_div, S, C):
+    """ppt_scatter_rows_bwd: idx [B,E] i64 (E entries per cloud), weight [B,E] f32 | None, d_rows [B * E / rows_div, ld] f32
+    -> d_src [B,S,C] f32 = sum of the (weighted) gradient rows of the entries that gathered source s, ascending entry order."""
+    _chk(idx, torch.int64, "idx"); _chk(weight, torch.float32, "weight"); _chk(d_rows, torch.float32, "d_rows")
+    B = idx.shape[0]
+    E = idx.numel() // B
+    out = torch.empty((B, S, C), dtype=torch.float32, device=d_rows.device)
+    _lib.check(_lib.lib().ppt_scatter_rows_bwd(_p(idx), _p(weight), _p(d_rows), d_rows.shape[1], col_off, B, E, rows_div, S, C,
+                                               _p(out), _stream()), "ppt_scatter_rows_bwd")
+    return out
+
+
+def sum_groups(x, k):
+    """x [G*k, C] f32 -> [G, C]: sums of each k consecutive rows."""
+    _chk(x, torch.float32, "x")
+    C = x.shape[-1]
+    G = x.numel() // (k * C)
+    out = torch.empty((G, C), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().ppt_sum_groups(_p(x), G, k, C, _p(out), _stream()), "ppt_sum_groups")
+    return out
 
 
 def gather_add(P, Q, idx, Nsrc, y_dtype, want_stats=True):
@@ -443,7 +501,7 @@ def mini_pointnet_conv12(pts, w1, b1, a_scale, a_shift, w2, bias2):
     y2 = torch.empty((M, N), dtype=torch.bfloat16, device=pts.device)
     gmax = torch.empty((M // 32, N), dtype=torch.bfloat16, device=pts.device)
     if profiler is not None:
-        profiler.begin("gemm_bf16", 2.0 * M * N * C1)
+        profiler.begin("gemm_bf16", 2.0 * M * N * C1, "ppt_mini_pointnet_conv12_bf16")
     _lib.check(_lib.lib().ppt_mini_pointnet_conv12_bf16(_p(pts), M, _p(w1), _p(b1), _p(a_scale), _p(a_shift), C1, _p(w2), _p(bias2),
                                                         N, _p(y2), _p(gmax), _stream()), "ppt_mini_pointnet_conv12_bf16")
     if profiler is not None:
@@ -460,7 +518,7 @@ def mini_pointnet_conv3(A, w, gterm, col_stats=None):
     y = torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
     ps, pm = col_stats if col_stats is not None else (None, None)
     if profiler is not None:
-        profiler.begin("gemm_bf16", 2.0 * M * N * 2 * K)
+        profiler.begin("gemm_bf16", 2.0 * M * N * 2 * K, "ppt_mini_pointnet_conv3_bf16")
     _lib.check(_lib.lib().ppt_mini_pointnet_conv3_bf16(_p(A), M, K, _p(w), _p(gterm), N, _p(y), _p(ps), _p(pm), _stream()),
                "ppt_mini_pointnet_conv3_bf16")
     if profiler is not None:
@@ -476,7 +534,7 @@ def mini_pointnet_conv4(A, a_scale, a_shift, w, bias):
     N = w.shape[0]
     tok = torch.empty((M // 32, N), dtype=torch.bfloat16, device=A.device)
     if profiler is not None:
-        profiler.begin("gemm_bf16", 2.0 * M * N * K)
+        profiler.begin("gemm_bf16", 2.0 * M * N * K, "ppt_mini_pointnet_conv4_bf16")
     _lib.check(_lib.lib().ppt_mini_pointnet_conv4_bf16(_p(A), M, K, _p(a_scale), _p(a_shift), _p(w), _p(bias), N, _p(tok), _stream()),
                "ppt_mini_pointnet_conv4_bf16")
     if profiler is not None:
@@ -497,7 +555,7 @@ def conv12_stats(pts, w1, b1, a_scale, a_shift, w2, bias2):
     ps = torch.empty((M // 32, N), dtype=torch.float32, device=pts.device)
     pm = torch.empty_like(ps)
     if profiler is not None:
-        profiler.begin("gemm_bf16", 2.0 * M * N * C1)
+        profiler.begin("gemm_bf16", 2.0 * M * N * C1, "ppt_conv12_stats_bf16")
     _lib.check(_lib.lib().ppt_conv12_stats_bf16(_p(pts), M, _p(w1), _p(b1), _p(a_scale), _p(a_shift), C1, _p(w2), _p(bias2), N,
                                                 _p(y2), _p(ps), _p(pm), _stream()), "ppt_conv12_stats_bf16")
     if profiler is not None:
@@ -515,7 +573,7 @@ def affine_conv_pool(A, a_scale, a_shift, w, bias, pool_rows, pmax, pmin, col_st
     M, K = A.shape
     N = w.shape[0]
     if profiler is not None:
-        profiler.begin("gemm_bf16", 2.0 * M * N * K)
+        profiler.begin("gemm_bf16", 2.0 * M * N * K, "ppt_affine_conv_pool_bf16")
     _lib.check(_lib.lib().ppt_affine_conv_pool_bf16(_p(A), A.stride(0), M, K, _p(a_scale), _p(a_shift), _p(w), _p(bias), N, pool_rows,
                                                     _p(pmax), _p(pmin), _p(col_stats[0]), _p(col_stats[1]), _stream()),
                "ppt_affine_conv_pool_bf16")
@@ -645,7 +703,7 @@ def gemm_tn_splitk(x_a, x_b, min_blocks=768, max_splits=16):
         S = max(d for d in range(1, want + 1) if slabs % d == 0)
         part = torch.empty((S, N1 * N2), dtype=torch.float32, device=x_a.device)
         if profiler is not None:
-            profiler.begin("gemm_bf16", 2.0 * M * N1 * N2)
+            profiler.begin("gemm_bf16", 2.0 * M * N1 * N2, "ppt_gemm_tn_bf16")
         _lib.check(_lib.lib().ppt_gemm_tn_bf16(_p(x_a), x_a.stride(0), _p(x_b), x_b.stride(0), M, N1, N2, S, _p(part),
                                                _stream()), "ppt_gemm_tn_bf16")
         if profiler is not None:

@@ -642,6 +642,11 @@ def test_dgcnn_layer_matches_the_graph_feature_formulation():
                                          m.layer1[1].bias.grad.clone())])
     for a, b, name in zip(res[0], res[1], ("out", "df", "dfq", "dW", "dgamma", "dbeta")):
         assert (a - b).abs().max().item() < 2e-3 * max(1.0, b.abs().max().item()), name
+    # forward() takes the reference's channel-first tensors (pointnet2_utils.py:433), forward_rows() the row layout
+    with torch.no_grad():
+        cf = m(coor.permute(0, 2, 1), f0.permute(0, 2, 1), coor_q.permute(0, 2, 1), fq0.permute(0, 2, 1))
+        rows = m.forward_rows(coor, f0, coor_q, fq0)
+    assert cf.shape == (B, 384, Nq) and torch.equal(cf.permute(0, 2, 1), rows)
 
 
 @pytest.mark.parametrize("C1,N", [(32, 32), (64, 64), (64, 96), (64, 128), (128, 128)])
@@ -820,3 +825,112 @@ def test_rowgemm_rejects_what_it_does_not_support(ops):
     w = torch.zeros(64, 256, dtype=torch.bfloat16, device="cuda")
     with pytest.raises(RuntimeError):
         ops.rowgemm(a, w)                                                    # K = 256: PPT_EUNSUPPORTED, no silent fallback
+
+
+# ------------------------------------------------------------------ part-seg decoder glue (csrc/interp.hip)
+@pytest.mark.parametrize("B,N,S,D1,D2,dtype", [(2, 256, 512, 3, 384, torch.float32), (2, 2048, 512, 19, 384, torch.bfloat16),
+                                                (1, 100, 37, 0, 64, torch.float32), (3, 33, 64, 5, 130, torch.bfloat16)])
+def test_three_nn_interp_fwd_matches_the_reference_formulation(ops, B, N, S, D1, D2, dtype):
+    """ppt_three_nn_interp_fwd against pointnet2_utils.py:333-358 written with torch ops on the CPU (and the oracle's 3-NN):
+    weights bit-exact up to the division's rounding, rows = [points1 | interpolated | 0] in the operand dtype."""
+    rng = np.random.default_rng(B * 1000 + N)
+    xyz1 = rng.uniform(-1, 1, (B, N, 3)).astype(np.float32)
+    xyz2 = rng.uniform(-1, 1, (B, S, 3)).astype(np.float32)
+    p1 = torch.from_numpy(rng.standard_normal((B, N, D1)).astype(np.float32)) if D1 else None
+    p2 = torch.from_numpy(rng.standard_normal((B, S, D2)).astype(np.float32))
+    idx, _, d = ops.knn_group(dev(xyz2), dev(xyz1), 3, want_nbhd=False, want_dist=True)
+    oidx, ow = O.three_nn(xyz1, xyz2)
+    assert np.array_equal(idx.cpu().numpy(), oidx)
+    mult = 8 if dtype == torch.bfloat16 else 4
+    rows, w = ops.three_nn_interp(p1.cuda() if D1 else None, p2.cuda(), idx, d, dtype, mult)
+    assert np.abs(w.cpu().numpy() - ow).max() < 2e-6
+    gathered = p2[torch.arange(B)[:, None, None], torch.from_numpy(oidx)]
+    interp = (gathered * torch.from_numpy(ow)[..., None]).sum(dim=2)
+    want = interp if p1 is None else torch.cat([p1, interp], dim=-1)
+    ld = (D1 + D2 + mult - 1) // mult * mult
+    assert rows.shape == (B * N, ld)
+    got = rows.float().cpu().view(B, N, ld)
+    tol = 1e-5 if dtype == torch.float32 else 2.0 ** -8
+    assert (got[..., :D1 + D2] - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
+    assert (got[..., D1 + D2:] == 0).all()
+
+
+@pytest.mark.parametrize("B,E,div,S,C,ld,off,weighted", [(2, 6144, 3, 512, 384, 408, 19, True), (3, 2048, 1, 512, 512, 512, 0, False),
+                                                          (1, 30000, 3, 700, 130, 136, 4, True), (2, 1024, 1, 256, 384, 384, 0, False),
+                                                          (2, 96, 3, 5, 8, 12, 3, True)])
+def test_scatter_rows_bwd_is_the_gather_gradient(ops, B, E, div, S, C, ld, off, weighted):
+    """ppt_scatter_rows_bwd against the definition (fp64 index_add on the CPU), sources nobody gathered get zeros, and two
+    launches give the same bits (owner-computes, fixed order)."""
+    g = torch.Generator().manual_seed(E + S)
+    idx = torch.randint(0, S, (B, E), generator=g)
+    idx[:, : E // 4] = idx[:, : E // 4] % max(1, S // 8)                    # skew: some sources are gathered very often
+    if S > 3:
+        idx[idx == 3] = 2                                                   # ... and source 3 never
+    w = torch.rand(B, E, generator=g) if weighted else None
+    d_rows = torch.randn(B * (E // div), ld, generator=g)
+    want = torch.zeros(B, S, C, dtype=torch.float64)
+    src = d_rows.view(B, E // div, ld)[:, :, off:off + C].double()
+    for b in range(B):
+        rows = src[b][torch.arange(E) // div]
+        if weighted:
+            rows = rows * w[b].double()[:, None]
+        want[b].index_add_(0, idx[b], rows)
+    got = ops.scatter_rows_bwd(idx.cuda(), w.cuda() if weighted else None, d_rows.cuda(), off, div, S, C)
+    assert (got.double().cpu() - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
+    if S > 3:
+        assert (got[:, 3] == 0).all()
+    again = ops.scatter_rows_bwd(idx.cuda(), w.cuda() if weighted else None, d_rows.cuda(), off, div, S, C)
+    assert torch.equal(got, again)
+
+
+def test_sum_groups(ops):
+    x = torch.randn(300 * 4, 384)
+    got = ops.sum_groups(x.cuda(), 4)
+    assert (got.cpu() - x.view(300, 4, 384).sum(1)).abs().max().item() < 1e-5
+
+
+def test_feature_propagation_matches_the_reference_formulation():
+    """PointNetFeaturePropagation (one fused autograd node: interpolation + concat + 2 x (conv, BatchNorm, ReLU) and their
+    backward) against the module written with torch ops in fp64, fp32 mode: output, gradient of the interpolated features and
+    of every parameter; and forward() in the reference's channel-first layout equals forward_rows()."""
+    from ppt_amd.models.pointbert.pointnet2_utils import PointNetFeaturePropagation
+    torch.manual_seed(3)
+    B, N, S, D1, D2 = 2, 320, 96, 19, 64
+    m = PointNetFeaturePropagation(in_channel=D1 + D2, mlp=[128, 48]).cuda()
+    m.precision = torch.float32
+    m.train()
+    xyz1, xyz2 = torch.randn(B, N, 3, device="cuda"), torch.randn(B, S, 3, device="cuda")
+    p1, p2_0 = torch.randn(B, N, D1, device="cuda"), torch.randn(B, S, D2, device="cuda")
+    dout = torch.randn(B, N, 48, device="cuda")
+    res = []
+    for native in (True, False):
+        p2 = p2_0.clone().requires_grad_(True)
+        m.zero_grad()
+        for bn in m.mlp_bns:
+            bn.reset_running_stats()
+        if native:
+            out = m.forward_rows(xyz1, xyz2, p1, p2)
+        else:
+            oidx, ow = O.three_nn(xyz1.cpu().numpy(), xyz2.cpu().numpy())
+            gathered = p2.double()[torch.arange(B, device="cuda")[:, None, None], torch.from_numpy(oidx).cuda()]
+            x = torch.cat([p1.double(), (gathered * torch.from_numpy(ow).cuda().double()[..., None]).sum(2)], -1).reshape(B * N, -1)
+            for conv, bn in zip(m.mlp_convs, m.mlp_bns):
+                x = x @ conv.weight.reshape(conv.weight.shape[0], -1).double().t() + conv.bias.double()
+                mu, var = x.mean(0), x.var(0, unbiased=False)
+                x = torch.relu((x - mu) / torch.sqrt(var + bn.eps) * bn.weight.double() + bn.bias.double())
+            out = x.view(B, N, -1)
+        out.backward(dout.to(out.dtype))
+        grads = [p2.grad] + [q.grad.clone() for q in m.parameters()]
+        res.append([out.detach().double()] + [t.double() for t in grads])
+        if native:
+            rm = m.mlp_bns[0].running_mean.clone()
+    names = ["out", "dp2"] + [n for n, _ in m.named_parameters()]
+    for a, b, name in zip(res[0], res[1], names):
+        if "convs" in name and name.endswith("bias"):
+            continue                                       # bias in front of a BatchNorm: zero gradient up to rounding noise
+        assert (a - b).abs().max().item() < 2e-3 * max(1.0, b.abs().max().item()), name
+    assert rm.abs().max().item() > 0                       # running statistics were updated as nn.BatchNorm1d does
+    with torch.no_grad():
+        cf = m(xyz1.permute(0, 2, 1), xyz2.permute(0, 2, 1), p1.permute(0, 2, 1), p2_0.permute(0, 2, 1))
+        rows = m.forward_rows(xyz1, xyz2, p1, p2_0)
+    assert cf.shape == (B, 48, N) and torch.equal(cf.permute(0, 2, 1), rows)
