@@ -60,6 +60,13 @@ int ppt_knn_group_f32(const float *xyz, const float *center, int B, int N, int G
                       int64_t *nbr_idx, float *neighborhood, float *nbr_dist /* [B,G,k] expanded-form d, or NULL */,
                       void *stream);
 
+/* square_distance (models/pointbert/dvae.py:130-149; twins pointbert/pointnet2_utils.py:51-72, pointnet2/pointnet2_utils.py:
+ * 19-40): out[b, s, n] = ((-2 * <src_s, dst_n>) + |src_s|^2) + |dst_n|^2 with the reference CPU path's rounding sequence
+ * (dot = fma(z, z', fma(y, y', x * x')), |a|^2 = (x^2 + y^2) + z^2): bit-identical to torch on the
+ * CPU for config-sized shapes.  The product path never materialises this matrix (ppt_knn_group_f32 fuses it); the entry
+ * point serves direct callers of the surface function.  src [B,S,3], dst [B,N,3], out [B,S,N] f32. */
+int ppt_square_distance_f32(const float *src, const float *dst, int B, int S, int N, float *out, void *stream);
+
 /* ---- H7: ball query ---------------------------------------------------------------------------
  * Replaces models/pointnet2/pointnet2_utils.py:87-107 query_ball_point: first K indices in
  * ascending order with d <= r^2 (expanded-form distance), padded with the first hit. */
@@ -136,7 +143,7 @@ int ppt_gemm(const ppt_gemm_params *p, void *stream);
  *   residual_form == 0: C (bf16) = act(acc + bias); C2 (bf16, optional) = acc + bias (the saved pre-activation);
  *   residual_form != 0: C (f32)  = residual + row_scale[m / row_scale_rows] * (acc + bias) + residual2; C may alias
  *              residual; row_scale / residual2 / bias may be NULL.
- * K must be 384 or 512, N % 4 == 0, pointers 16-byte aligned, a_ln and residual_form not both set: anything else
+ * K must be 384 or 512, N % 8 == 0 (N % 4 == 0 in the residual form), pointers 16-byte aligned, a_ln and residual_form not both set: anything else
  * PPT_EUNSUPPORTED / PPT_EINVAL.
  * walkers: workgroups per column group walking the 32-row tiles (0 = as many as fill the chip). */
 typedef struct ppt_rowgemm_params {

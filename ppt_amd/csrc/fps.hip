@@ -152,11 +152,10 @@ template <int PPT, int W, bool XYZ_LDS>
 int launch_fps_v(const float *xyz, int B, int N, int M, const int64_t *start, int64_t *out_idx,
                  float *out_xyz, hipStream_t s, size_t lds)
 {
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute((const void *)fps_kernel<PPT, W, XYZ_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return PPT_ELAUNCH;
-    }
+    // opt-in to > 64 KB of dynamic LDS: once per kernel instance (thread-safe static initialisation), to the device limit
+    static const hipError_t optin = hipFuncSetAttribute((const void *)fps_kernel<PPT, W, XYZ_LDS>,
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (lds > 64 * 1024 && optin != hipSuccess) return PPT_ELAUNCH;
     hipLaunchKernelGGL((fps_kernel<PPT, W, XYZ_LDS>), dim3(B), dim3(W * 64), lds, s, xyz, N, M, start, out_idx, out_xyz);
     PPT_CHECK_LAUNCH();
     return PPT_OK;

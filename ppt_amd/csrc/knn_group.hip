@@ -220,7 +220,44 @@ __global__ __launch_bounds__(W * 64) void ball_query_kernel(const float *__restr
     }
 }
 
+// dist[b, s, n] of square_distance (dvae.py:130-149), the reference's expanded form with its rounding sequence; one thread
+// per 4 consecutive n of one (b, s): 16-byte stores along the rows
+__global__ __launch_bounds__(256) void square_distance_kernel(const float *__restrict__ src, const float *__restrict__ dst, int S, int N,
+                                                              int64_t total4, float *__restrict__ out)
+{
+    const int n4 = (N + 3) >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int64_t bs = i / n4;
+        const int n = 4 * (int)(i - bs * n4);
+        const int64_t b = bs / S;
+        const float *a = src + bs * 3;
+        const float ax = a[0], ay = a[1], az = a[2];
+        const float na = sqnorm3_rn(ax, ay, az);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int nn = min(n + e, N - 1);
+            const float *c = dst + (b * N + nn) * 3;
+            const float cx = c[0], cy = c[1], cz = c[2];
+            v[e] = expanded_sqdist_rn(ax, ay, az, na, cx, cy, cz, sqnorm3_rn(cx, cy, cz));
+        }
+        float *o = out + bs * N + n;
+        if (n + 3 < N && (N & 3) == 0) *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        else for (int e = 0; e < 4 && n + e < N; ++e) o[e] = v[e];
+    }
+}
+
 }  // namespace
+
+extern "C" int ppt_square_distance_f32(const float *src, const float *dst, int B, int S, int N, float *out, void *stream)
+{
+    if (!src || !dst || !out || B <= 0 || S <= 0 || N <= 0) return PPT_EINVAL;
+    const int64_t total4 = (int64_t)B * S * ((N + 3) / 4);
+    const int grid = (int)((total4 + 255) / 256 < 16384 ? (total4 + 255) / 256 : 16384);
+    hipLaunchKernelGGL(square_distance_kernel, dim3(grid), dim3(256), 0, ppt_stream(stream), src, dst, S, N, total4, out);
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
 
 extern "C" int ppt_knn_group_f32(const float *xyz, const float *center, int B, int N, int G, int k,
                                  int64_t *nbr_idx, float *neighborhood, float *nbr_dist, void *stream)
@@ -229,11 +266,11 @@ extern "C" int ppt_knn_group_f32(const float *xyz, const float *center, int B, i
         return PPT_EINVAL;
     constexpr int W = 8;
     const size_t lds = (size_t)N * 16 + (size_t)W * KNN_CAP * 8;
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute((const void *)knn_group_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return PPT_ELAUNCH;
-    }
+    // the opt-in to > 64 KB of dynamic LDS is made ONCE per kernel (thread-safe static initialisation), for the
+    // largest cloud the entry point accepts -- not on every launch
+    static const hipError_t optin = hipFuncSetAttribute((const void *)knn_group_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                         8192 * 16 + W * KNN_CAP * 8);
+    if (lds > 64 * 1024 && optin != hipSuccess) return PPT_ELAUNCH;
     const int cpb = 32;
     dim3 grid((G + cpb - 1) / cpb, B);
     hipLaunchKernelGGL((knn_group_kernel<W>), grid, dim3(W * 64), lds, ppt_stream(stream), xyz, center, N, G, k,
@@ -248,11 +285,9 @@ extern "C" int ppt_ball_query_f32(const float *xyz, const float *center, int B, 
     if (!xyz || !center || !idx || B <= 0 || N <= 0 || S <= 0 || K <= 0 || N > 10240) return PPT_EINVAL;
     constexpr int W = 8;
     const size_t lds = (size_t)N * 16;
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute((const void *)ball_query_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return PPT_ELAUNCH;
-    }
+    static const hipError_t optin = hipFuncSetAttribute((const void *)ball_query_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                         10240 * 16);
+    if (lds > 64 * 1024 && optin != hipSuccess) return PPT_ELAUNCH;
     const int cpb = 32;
     dim3 grid((S + cpb - 1) / cpb, B);
     hipLaunchKernelGGL((ball_query_kernel<W>), grid, dim3(W * 64), lds, ppt_stream(stream), xyz, center, N, S,

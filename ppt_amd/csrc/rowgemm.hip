@@ -40,7 +40,9 @@ template <int K> struct RG {
     static constexpr int BUF = 32 * PITCH;
     static constexpr int F4 = K / 64;                    // float4 per thread and row, LayerNorm prologue (16 threads per row)
     static constexpr int U4 = K / 128;                   // uint4 per thread and row, bf16 A
-    static constexpr int LDS = 2 * BUF + 2 * K * 4 + NB * 4;   // two A buffers + gamma + beta + the bias slice
+    static constexpr int CPITCH = 2 * NB + 16;           // bytes per row of the bf16 C tile image
+    static constexpr int CBUF = 32 * CPITCH;
+    static constexpr int LDS = 2 * BUF + 2 * K * 4 + NB * 4 + 2 * CBUF;   // two A buffers, gamma, beta, the bias slice, two C tiles
 };
 
 // sum over the 16 lanes of a DPP row; every lane gets the same bits (each step adds a value to its mirror image)
@@ -54,8 +56,20 @@ __device__ __forceinline__ float row16_sum(float v)
 }
 
 enum { EPI_BF16 = 0, EPI_RESIDUAL = 1 };
+// Diagnostic build only (tools/rowgemm_stamp.py compiles this file with -DPPT_RG_STAMP into its own library): every wave
+// writes s_memtime stamps of its phase boundaries to the buffer passed in `residual2` (unused by the bf16 epilogue) --
+// [workgroup][wave][iteration < 8][8 stamps].  No stamp exists in the shipped kernel.
+#ifdef PPT_RG_STAMP
+#define RG_STAMP(slot) do { if (lane == 0 && it < 8) stamps[((size_t)(blockIdx.x * 8 + w) * 8 + it) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RG_STAMP(slot) do { } while (0)
+#endif
+#ifndef PPT_ROWGEMM_STAGGER
+#define PPT_ROWGEMM_STAGGER 1
+#endif
+constexpr bool STAGGER = PPT_ROWGEMM_STAGGER != 0;
 
-template <int K, bool LN, int EPI>
+template <int K, bool LN, int EPI, int ACT>
 __global__ __launch_bounds__(512, 2) void rowgemm_kernel(const ppt_rowgemm_params p)
 {
     using G = RG<K>;
@@ -71,25 +85,13 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(const ppt_rowgemm_param
     const int n0 = group * G::NB + w * G::NW;                            // first column of this wave
     const int n_tiles = (p.M + 31) >> 5;
     const int n_walk = p.walkers;
-
-    // ---- the stationary operand: W[n0 + 16 nb + l15][32 s + 8 kg .. + 8)
-    bf16x8_t wf[G::NCB][G::KS];
-    const bf16_t *W = (const bf16_t *)p.W;
-#pragma unroll
-    for (int nb = 0; nb < G::NCB; ++nb) {
-        const int n = min(n0 + 16 * nb + l15, p.N - 1);
-#pragma unroll
-        for (int s = 0; s < G::KS; ++s)
-            wf[nb][s] = *reinterpret_cast<const bf16x8_t *>(W + (size_t)n * K + 32 * s + 8 * kg);
-    }
+#ifdef PPT_RG_STAMP
+    if (lane == 0) ((unsigned long long *)p.residual2)[((size_t)(blockIdx.x * 8 + w) * 8 + 7) * 8 + 7] = __builtin_amdgcn_s_memtime();   // kernel entry
+#endif
+    int t = walker;
+    if (t >= n_tiles) return;
     float *gam = reinterpret_cast<float *>(smem + 2 * G::BUF), *bet = gam + K, *bia = bet + K;
-    if constexpr (LN) {
-        for (int c = threadIdx.x; c < K; c += 512) { gam[c] = p.ln_w[c]; bet[c] = p.ln_b[c]; }
-    }
-    for (int c = threadIdx.x; c < G::NB; c += 512) {                     // this workgroup's bias slice (0 when there is none)
-        const int n = group * G::NB + c;
-        bia[c] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
-    }
+    unsigned char *cbuf = reinterpret_cast<unsigned char *>(bia + G::NB);       // two bf16 C tiles (bf16 epilogue only)
 
     // ---- loader: thread -> row r (0..31) of the tile, 16 threads per row
     const int r = threadIdx.x >> 4, j = threadIdx.x & 15;
@@ -138,6 +140,28 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(const ppt_rowgemm_param
             if constexpr (G::U4 > 3) *reinterpret_cast<uint4 *>(dst + 16 * j + 768) = xb3;
         }
     };
+    // the first tile's rows are requested before the 36 (32) weight loads: they are what the first staging waits for
+    load(t);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- the stationary operand: W[n0 + 16 nb + l15][32 s + 8 kg .. + 8)
+    bf16x8_t wf[G::NCB][G::KS];
+    const bf16_t *W = (const bf16_t *)p.W;
+#pragma unroll
+    for (int nb = 0; nb < G::NCB; ++nb) {
+        const int n = min(n0 + 16 * nb + l15, p.N - 1);
+#pragma unroll
+        for (int s = 0; s < G::KS; ++s)
+            wf[nb][s] = *reinterpret_cast<const bf16x8_t *>(W + (size_t)n * K + 32 * s + 8 * kg);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (LN) {
+        for (int c = threadIdx.x; c < K; c += 512) { gam[c] = p.ln_w[c]; bet[c] = p.ln_b[c]; }
+    }
+    for (int c = threadIdx.x; c < G::NB; c += 512) {                     // this workgroup's bias slice (0 when there is none)
+        const int n = group * G::NB + c;
+        bia[c] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    }
 
     // residual-form epilogue: the fp32 residual rows of a tile are fetched a whole phase before they are used (a load
     // consumed where it is issued costs a memory round trip per 16 x 16 block: measured 2x on this epilogue in gemm.hip)
@@ -158,25 +182,10 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(const ppt_rowgemm_param
         }
     };
 
-    int t = walker;
-    if (t >= n_tiles) return;
-    load(t);
-    __syncthreads();                                                     // gamma / beta / bias are in LDS
-    stage(0);
-    load(min(t + n_walk, n_tiles - 1));
-    load_res(t);
-    __syncthreads();
-    // Order inside an iteration (pinned with scheduling fences; hipcc otherwise sinks the loads behind the MFMAs):
-    //   MFMAs of tile t | stage tile t+1 (its loads were issued a whole iteration ago) | issue the loads of tile t+2 |
-    //   epilogue + stores of tile t | issue the residual loads of tile t+1 | barrier.
-    // Every s_waitcnt vmcnt the compiler places in front of a use of loaded data is conservative across the conditional
-    // stores (vmcnt(0)): with this order whatever it waits for was issued at least one MFMA phase earlier.  (Stores
-    // directly in front of the staging made every tile wait for its own output to drain: 5.4 us per tile.)
-    for (int it = 0; t < n_tiles; t += n_walk, ++it) {
-        const int cur = it & 1;
+    f32x4_t acc[2][G::NCB];
+    auto mfma_phase = [&](int cur) {
         const unsigned char *a0 = smem + cur * G::BUF + l15 * G::PITCH + 16 * kg;
         const unsigned char *a1 = a0 + 16 * G::PITCH;
-        f32x4_t acc[2][G::NCB];
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -191,59 +200,129 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(const ppt_rowgemm_param
                 acc[1][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][s], f1, acc[1][nb], 0, 0, 0);
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        stage(cur ^ 1);                                                  // (that buffer was last read in iteration it - 1, before its barrier)
-        __builtin_amdgcn_sched_barrier(0);
-        load(min(t + 2 * n_walk, n_tiles - 1));                          // unconditional (a branch parks the registers in scratch)
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- epilogue: lane holds D[n = n0 + 16 nb + 4 kg + i][m = 32 t + 16 rb + l15]
+    };
+    // lane holds D[n = n0 + 16 nb + 4 kg + i][m = 32 tile + 16 rb + l15].  Residual form: 16-byte fp32 stores straight
+    // from the lane (64-byte row pieces).  bf16 form: a lane's 8 bytes would make 32-byte row pieces -- 16 of them per
+    // store instruction -- and such stores cost ~300 cycles each (in-kernel stamps: 1 850 .. 2 400 cycles of a 5 800-cycle
+    // iteration); the tile therefore goes to an LDS image and leaves at the top of the NEXT iteration (store_tile) as
+    // 16 bytes per lane along the rows.
+    auto epilogue = [&](int tile, int cslot) {
+        float4 bv[G::NCB];                                                // one batch of LDS reads, one wait
+#pragma unroll
+        for (int nb = 0; nb < G::NCB; ++nb) bv[nb] = *reinterpret_cast<const float4 *>(bia + w * G::NW + 16 * nb + 4 * kg);
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
-            const int m = t * 32 + 16 * rb + l15;
-            if (m < p.M) {
+            const int m = tile * 32 + 16 * rb + l15;
 #pragma unroll
-                for (int nb = 0; nb < G::NCB; ++nb) {
-                    const int n = n0 + 16 * nb + 4 * kg;
-                    if (n < p.N) {
-                        const float4 bv = *reinterpret_cast<const float4 *>(bia + w * G::NW + 16 * nb + 4 * kg);
-                        float v[4] = {acc[rb][nb][0] + bv.x, acc[rb][nb][1] + bv.y, acc[rb][nb][2] + bv.z, acc[rb][nb][3] + bv.w};
-                        const size_t o = (size_t)m * p.N + n;
-                        if constexpr (EPI == EPI_RESIDUAL) {
-                            const float4 r1 = res[rb][nb];
-                            const float rs = rsc[rb];
-                            float4 out = make_float4(v[0] * rs + r1.x, v[1] * rs + r1.y, v[2] * rs + r1.z, v[3] * rs + r1.w);
-                            if (p.residual2) {
-                                const float4 r2 = *reinterpret_cast<const float4 *>(p.residual2 + o);
-                                out.x += r2.x; out.y += r2.y; out.z += r2.z; out.w += r2.w;
-                            }
-                            *reinterpret_cast<float4 *>((float *)p.C + o) = out;
-                        } else {
-                            if (p.C2) *reinterpret_cast<uint2 *>((bf16_t *)p.C2 + o) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-                            if (p.act == PPT_ACT_GELU) {
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) v[i] = 0.5f * v[i] * (1.0f + erf_fast(v[i] * 0.70710678118654752f));
-                            } else if (p.act == PPT_ACT_QUICKGELU) {
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) v[i] = v[i] / (1.0f + __expf(-1.702f * v[i]));
-                            }
-                            *reinterpret_cast<uint2 *>((bf16_t *)p.C + o) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+            for (int nb = 0; nb < G::NCB; ++nb) {
+                const int n = n0 + 16 * nb + 4 * kg;
+                float v[4] = {acc[rb][nb][0] + bv[nb].x, acc[rb][nb][1] + bv[nb].y, acc[rb][nb][2] + bv[nb].z, acc[rb][nb][3] + bv[nb].w};
+                const size_t o = (size_t)m * p.N + n;
+                if constexpr (EPI == EPI_RESIDUAL) {
+                    if (m < p.M && n < p.N) {
+                        const float4 r1 = res[rb][nb];
+                        const float rs = rsc[rb];
+                        float4 out = make_float4(v[0] * rs + r1.x, v[1] * rs + r1.y, v[2] * rs + r1.z, v[3] * rs + r1.w);
+                        if (p.residual2) {
+                            const float4 r2 = *reinterpret_cast<const float4 *>(p.residual2 + o);
+                            out.x += r2.x; out.y += r2.y; out.z += r2.z; out.w += r2.w;
                         }
+                        *reinterpret_cast<float4 *>((float *)p.C + o) = out;
                     }
+                } else {
+                    if constexpr (ACT != PPT_ACT_NONE) {
+                        if (p.C2 && m < p.M && n < p.N)    // (the saved pre-activation: rare, stays on the direct path)
+                            *reinterpret_cast<uint2 *>((bf16_t *)p.C2 + o) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                    }
+                    if constexpr (ACT == PPT_ACT_GELU) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = 0.5f * v[i] * (1.0f + erf_fast(v[i] * 0.70710678118654752f));
+                    } else if constexpr (ACT == PPT_ACT_QUICKGELU) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = v[i] / (1.0f + __expf(-1.702f * v[i]));
+                    }
+                    *reinterpret_cast<uint2 *>(cbuf + cslot * G::CBUF + (16 * rb + l15) * G::CPITCH + (w * G::NW + 16 * nb + 4 * kg) * 2) =
+                        make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
                 }
             }
         }
+    };
+    auto store_tile = [&](int tile, int cslot) {
+        if constexpr (EPI == EPI_BF16) {
+            constexpr int CPR = G::NB / 8;                                // 16-byte chunks per row
+#pragma unroll
+            for (int i = 0; i < 32 * CPR / 512; ++i) {
+                const int c = threadIdx.x + 512 * i;
+                const int row = c / CPR, ch = c - row * CPR;
+                const uint4 v = *reinterpret_cast<const uint4 *>(cbuf + cslot * G::CBUF + row * G::CPITCH + 16 * ch);
+                const int m = tile * 32 + row, n = group * G::NB + 8 * ch;
+                if (m < p.M && n < p.N) *reinterpret_cast<uint4 *>((bf16_t *)p.C + (size_t)m * p.N + n) = v;
+            }
+        }
+    };
+
+    __syncthreads();                                                     // gamma / beta / bias are in LDS
+    stage(0);
+    load(min(t + n_walk, n_tiles - 1));
+    load_res(t);
+    __syncthreads();
+    // A workgroup puts two waves on every SIMD (w and w + 4).  Run in lockstep -- MFMAs, then epilogue + LayerNorm staging,
+    // barrier -- the pair leaves the matrix pipe idle through every vector phase and the vector unit idle through every
+    // MFMA phase.  So the second half stages FIRST and multiplies SECOND:
+    //   waves 0-3:  store tile t-1 | MFMAs of tile t | stage tile t+1, issue loads of t+2 | epilogue of tile t | barrier
+    //   waves 4-7:  stage tile t+1, issue loads of t+2 | store tile t-1 | MFMAs of tile t | epilogue of tile t | barrier
+    // Loads are issued a whole phase before anything waits for them, and no store sits directly in front of such a wait
+    // (the compiler's s_waitcnt behind conditional stores is vmcnt(0): the wave would wait for the stores to drain).
+    constexpr bool ST = STAGGER && !LN;                                  // (with the 24 LayerNorm registers the two code paths spill)
+    const bool late = ST && w >= 4;
+#ifdef PPT_RG_STAMP
+    unsigned long long *stamps = (unsigned long long *)p.residual2;
+#endif
+    int t_prev = -1, it = 0;
+    for (; t < n_tiles; t += n_walk, ++it) {
+        const int cur = it & 1;
+        RG_STAMP(0);
+        if (!late) {
+            if (t_prev >= 0) store_tile(t_prev, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_phase(cur);
+            __builtin_amdgcn_sched_barrier(0);
+            RG_STAMP(1);
+            stage(cur ^ 1);                                              // (that buffer was last read in iteration it - 1, before its barrier)
+            __builtin_amdgcn_sched_barrier(0);
+            RG_STAMP(2);
+            load(min(t + 2 * n_walk, n_tiles - 1));                      // unconditional (a branch parks the registers in scratch)
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            stage(cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            RG_STAMP(1);
+            load(min(t + 2 * n_walk, n_tiles - 1));
+            __builtin_amdgcn_sched_barrier(0);
+            if (t_prev >= 0) store_tile(t_prev, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_phase(cur);
+            __builtin_amdgcn_sched_barrier(0);
+            RG_STAMP(2);
+        }
+        RG_STAMP(3);
+        epilogue(t, cur);
         __builtin_amdgcn_sched_barrier(0);
+        RG_STAMP(4);
         load_res(min(t + n_walk, n_tiles - 1));
+        t_prev = t;
         __syncthreads();
+        RG_STAMP(5);
     }
+    if (t_prev >= 0) store_tile(t_prev, (it - 1) & 1);
 }
 
-template <int K, bool LN, int EPI>
+template <int K, bool LN, int EPI, int ACT>
 int launch(const ppt_rowgemm_params &p, hipStream_t s, int cus)
 {
     using G = RG<K>;
     static const int once = [] {
-        (void)hipFuncSetAttribute((const void *)rowgemm_kernel<K, LN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+        (void)hipFuncSetAttribute((const void *)rowgemm_kernel<K, LN, EPI, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
         return 0;
     }();
     (void)once;
@@ -256,7 +335,7 @@ int launch(const ppt_rowgemm_params &p, hipStream_t s, int cus)
     walkers = (walkers + 7) / 8 * 8;
     if (walkers * q.groups > cus && walkers > 8 && p.walkers <= 0) walkers -= 8;
     q.walkers = walkers;
-    hipLaunchKernelGGL((rowgemm_kernel<K, LN, EPI>), dim3(walkers * q.groups), dim3(512), G::LDS, s, q);
+    hipLaunchKernelGGL((rowgemm_kernel<K, LN, EPI, ACT>), dim3(walkers * q.groups), dim3(512), G::LDS, s, q);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PPT_OK : PPT_ELAUNCH;
 }
@@ -269,11 +348,12 @@ extern "C" int ppt_rowgemm_bf16(const ppt_rowgemm_params *pp, void *stream)
     const ppt_rowgemm_params &p = *pp;
     if (!p.A || !p.W || !p.C || p.M <= 0 || p.N <= 0) return PPT_EINVAL;
     if (p.K != 384 && p.K != 512) return PPT_EUNSUPPORTED;
-    if (p.N % 4) return PPT_EUNSUPPORTED;
+    if (p.N % (p.residual_form ? 4 : 8)) return PPT_EUNSUPPORTED;
     if (p.a_ln && (!p.ln_w || !p.ln_b)) return PPT_EINVAL;
     if (p.residual_form && !p.residual) return PPT_EINVAL;
     if (p.residual_form && p.a_ln) return PPT_EUNSUPPORTED;          /* (no caller: a LayerNorm is never followed by a residual-form linear) */
     if (p.residual_form && (p.act != PPT_ACT_NONE || p.C2)) return PPT_EUNSUPPORTED;
+    if (p.C2 && p.act == PPT_ACT_NONE) return PPT_EUNSUPPORTED;     /* the second output is the PRE-activation of an activated launch */
     if (p.row_scale && p.row_scale_rows <= 0) return PPT_EINVAL;
     if (p.act != PPT_ACT_NONE && p.act != PPT_ACT_GELU && p.act != PPT_ACT_QUICKGELU) return PPT_EUNSUPPORTED;
     if (((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.C | (uintptr_t)p.C2 | (uintptr_t)p.residual | (uintptr_t)p.residual2) & 15)
@@ -284,9 +364,13 @@ extern "C" int ppt_rowgemm_bf16(const ppt_rowgemm_params *pp, void *stream)
         return n > 0 ? n : 256;
     }();
     hipStream_t s = ppt_stream(stream);
-#define PPT_RG(KK)                                                                                       \
-    (p.a_ln ? launch<KK, true, EPI_BF16>(p, s, cus)                                                       \
-            : (p.residual_form ? launch<KK, false, EPI_RESIDUAL>(p, s, cus) : launch<KK, false, EPI_BF16>(p, s, cus)))
+#define PPT_RG_ACT(KK, LNV)                                                                                        \
+    (p.act == PPT_ACT_GELU ? launch<KK, LNV, EPI_BF16, PPT_ACT_GELU>(p, s, cus)                                      \
+     : p.act == PPT_ACT_QUICKGELU ? launch<KK, LNV, EPI_BF16, PPT_ACT_QUICKGELU>(p, s, cus)                          \
+                                  : launch<KK, LNV, EPI_BF16, PPT_ACT_NONE>(p, s, cus))
+#define PPT_RG(KK)                                                                                                 \
+    (p.a_ln ? PPT_RG_ACT(KK, true) : (p.residual_form ? launch<KK, false, EPI_RESIDUAL, PPT_ACT_NONE>(p, s, cus) : PPT_RG_ACT(KK, false)))
     return p.K == 384 ? PPT_RG(384) : PPT_RG(512);
+#undef PPT_RG_ACT
 #undef PPT_RG
 }

@@ -70,7 +70,14 @@ class WeightCache:
 
 
 FUSED_CONV12 = os.environ.get("PPT_FUSED_CONV12", "1") != "0"      # 0: the generic PPT_A_CONV1 GEMM (A/B comparisons)
-ROWGEMM = os.environ.get("PPT_ROWGEMM", "1") != "0"                 # 0: LayerNorm kernel + tile-loop GEMM for the K = 384 / 512 linears
+# csrc/rowgemm.hip (weight-stationary K = 384 linears with the LayerNorm applied while the rows are staged) from this many
+# token rows on.  Measured (same box, graph-replayed steps): C3 (32 832 rows) 7.60 -> 7.18 ms per step, the three linears
+# 11-27 % faster each; C2 (16 416 rows) 3.99 -> 4.17 ms although two of the three are ~10 % faster in isolation -- its
+# workgroups take a whole CU each (8 waves x 256 VGPRs), and with only 7 row tiles per workgroup to amortise the weight
+# preload the small win is paid back by the text tower's kernels, which can no longer share those CUs.  PPT_ROWGEMM=0 / 1
+# forces it off / on.
+_RG = os.environ.get("PPT_ROWGEMM", "")
+ROWGEMM_MIN_ROWS = 1 << 30 if _RG == "0" else (0 if _RG == "1" else 24000)
 
 
 def _bn_params(sd, p):
@@ -156,7 +163,7 @@ def vit_block_forward(sd, p, wc, x, pos, B, Tn, heads, dp1, dp2, save=None, pos_
     neither reads pos nor rewrites the residual stream; the sums are formed in the same order either way."""
     T = wc.dtype
     keep = save is not None
-    if ROWGEMM and T == torch.bfloat16 and not keep and x.shape[1] in ops.ROWGEMM_K:
+    if x.shape[0] >= ROWGEMM_MIN_ROWS and T == torch.bfloat16 and not keep and x.shape[1] in ops.ROWGEMM_K:
         # frozen block, nothing kept: the K = 384 linears with the weight stationary in registers (csrc/rowgemm.hip); both
         # LayerNorms are applied while the rows are staged, the residual stream is updated in place
         if pos_in_x:

@@ -8,14 +8,10 @@ from . import misc
 
 
 def square_distance(src, dst):
-    """dvae.py:130-149 -> [B,N,M].  Offered for API completeness only (plain torch ops, same
-    formula); the product path never materialises this matrix (ppt_knn_group_f32)."""
-    B, N, _ = src.shape
-    M = dst.shape[1]
-    dist = -2 * torch.matmul(src, dst.permute(0, 2, 1))
-    dist += torch.sum(src ** 2, -1).view(B, N, 1)
-    dist += torch.sum(dst ** 2, -1).view(B, 1, M)
-    return dist
+    """dvae.py:130-149: src [B,N,3], dst [B,M,3] -> [B,N,M], the expanded form -2 src.dst + |src|^2 + |dst|^2 with the
+    rounding sequence of the reference's CPU path (ppt_square_distance_f32).  The product path never
+    materialises this matrix (ppt_knn_group_f32 fuses it with the selection); this serves direct callers."""
+    return ops.square_distance(src.contiguous().float(), dst.contiguous().float())
 
 
 def knn_point(nsample, xyz, new_xyz):

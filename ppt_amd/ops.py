@@ -119,6 +119,16 @@ def knn_group(xyz, center, k, want_idx=True, want_nbhd=True, want_dist=False):
     return (idx, nb, nd) if want_dist else (idx, nb)
 
 
+def square_distance(src, dst):
+    """dvae.py:130-149: src [B,S,3], dst [B,N,3] f32 -> [B,S,N] f32 with the reference's rounding sequence."""
+    _chk(src, torch.float32, "src"); _chk(dst, torch.float32, "dst")
+    B, S, _ = src.shape
+    N = dst.shape[1]
+    out = torch.empty((B, S, N), dtype=torch.float32, device=src.device)
+    _lib.check(_lib.lib().ppt_square_distance_f32(_p(src), _p(dst), B, S, N, _p(out), _stream()), "ppt_square_distance_f32")
+    return out
+
+
 def ball_query(xyz, center, radius, K, want_grouped=False):
     """H7.  -> idx [B,S,K] i64 (query_ball_point semantics) [, grouped_xyz [B,S,K,3] = xyz[idx] - center]."""
     _chk(xyz, torch.float32, "xyz"); _chk(center, torch.float32, "center")

@@ -1,0 +1,173 @@
+"""GPU: BASELINE.json's configurations at their FULL per-GPU sizes.  The oracle's dense math is too
+slow for these batches, so the checks are the size-independent ones the domain offers:
+  * index work (FPS, kNN, ball query) against the C oracle -- that part of the oracle is fast at any size -- bit for bit;
+  * bf16 performance mode against the fp32 parity mode of the same model (the fp32 mode is pinned to the reference by the
+    golden fixtures at small sizes: tests/test_model_gpu.py);
+  * run-to-run bit reproducibility (no atomics, fixed summation orders);
+  * one real training step per configuration: finite loss, only the expected parameters receive gradients."""
+import contextlib
+import io
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from ppt_amd import weights as W
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(factory, ds, head_type=0, task='cls', sd_fn=None, precision=torch.bfloat16):
+    from ppt_amd.models import ULIP_models as M
+    args = SimpleNamespace(classnames=M.dataset_classnames(ds), template_init='', class_name_position='middle',
+                           num_learnable_prompt_tokens=32, gpu=0, task=task, head_type=head_type, evaluate_3d=False, ulip2=False,
+                           synthetic_weights=True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = getattr(M, factory)(args)
+    m.load_state_dict(sd_fn(seed=0), strict=False)
+    m.prompt_learner.embedding = W.synth_prompt_embedding(len(args.classnames), seed=0)
+    m.cuda().set_precision(precision)
+    return m
+
+
+def test_c2_full_batch_32x1024():
+    """C2: B = 32, N = 1024.  Group.forward (FPS + kNN) against the oracle over the whole batch; tower features bf16 vs fp32;
+    the training step twice from the same state: identical bits."""
+    from ppt_amd.train import Trainer
+    B, N = 32, 1024
+    pc_np, start = W.synth_clouds(B, N, seed=1234)
+    pc = torch.from_numpy(pc_np).cuda()
+    labels = torch.from_numpy(np.random.default_rng(0).integers(0, 40, size=(B,))).cuda()
+    m = _model("ULIP_PointBERT", "modelnet40", sd_fn=W.ulip_pointbert_state_dict)
+    # ---- index work, whole batch, through the module surface
+    nbhd, center = m.point_encoder.group_divider(pc, torch.from_numpy(start).cuda())
+    cidx = O.fps(pc_np, 512, start)
+    _, nb_ref, ce_ref = O.group(pc_np, cidx, 32)
+    assert np.array_equal(center.cpu().numpy(), ce_ref)
+    # both sides order a centre's neighbours by (distance, index): identical arrays (the oracle's tie rule is the kernel's)
+    assert np.array_equal(nbhd.cpu().numpy(), nb_ref)
+    # ---- features: bf16 against the fp32 parity mode, eval BatchNorm, no DropPath
+    m.eval()
+    m.point_encoder.fps_start = torch.from_numpy(start).cuda()
+    feats = {}
+    for prec in (torch.float32, torch.bfloat16):
+        m.set_precision(prec)
+        with torch.no_grad():
+            feats[prec] = m.point_encoder(pc).float().cpu()
+    rel = ((feats[torch.bfloat16] - feats[torch.float32]).norm() / feats[torch.float32].norm()).item()
+    assert rel < 2e-2, rel
+    # ---- the training step is bit-reproducible
+    runs = []
+    for _ in range(2):
+        mm = _model("ULIP_PointBERT", "modelnet40", sd_fn=W.ulip_pointbert_state_dict)
+        mm.train()
+        mm.point_encoder.fps_start = torch.from_numpy(start).cuda()
+        mm.point_encoder.drop_path_factors = torch.ones(12, 2, B)
+        tr = Trainer(mm, distributed=False)
+        for _ in range(4):                                          # eager calls, then hipGraph replays
+            loss, pred = tr.step(pc, labels)
+        tr.finish()
+        torch.cuda.synchronize()
+        runs.append((loss.item(), pred.float().cpu().clone(), mm.prompt_learner.learnable_tokens.detach().cpu().clone()))
+        assert [n for n, p in mm.named_parameters() if p.grad is not None] == ["prompt_learner.learnable_tokens"]
+    assert np.isfinite(runs[0][0]) and runs[0][0] == runs[1][0]
+    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+
+
+def test_c3_full_batch_64x2048_head3():
+    """C3: B = 64, N = 2048 (clouds with duplicate points, as ScanObjectNN resampling gives), head_type 3: FPS indices of the
+    whole batch against the oracle, a finite reproducible step, gradients exactly on the tier's 12 tensors."""
+    from ppt_amd import ops
+    from ppt_amd.train import Trainer
+    B, N = 64, 2048
+    pc_np, start = W.synth_clouds(B, N, seed=77, duplicates=True)
+    pc = torch.from_numpy(pc_np).cuda()
+    idx, _ = ops.fps(pc, 512, torch.from_numpy(start).cuda())
+    assert np.array_equal(idx.cpu().numpy(), O.fps(pc_np, 512, start))
+    labels = torch.from_numpy(np.random.default_rng(1).integers(0, 15, size=(B,))).cuda()
+    losses = []
+    for _ in range(2):
+        m = _model("ULIP_PointBERT", "scanobjectnn", head_type=3, sd_fn=W.ulip_pointbert_state_dict)
+        m.train()
+        m.point_encoder.fps_start = torch.from_numpy(start).cuda()
+        m.point_encoder.drop_path_factors = torch.ones(12, 2, B)
+        tr = Trainer(m, distributed=False)
+        for _ in range(3):
+            loss, _ = tr.step(pc, labels)
+        tr.finish()
+        torch.cuda.synchronize()
+        losses.append(loss.item())
+        assert sum(1 for p in m.parameters() if p.grad is not None) == 12
+    assert np.isfinite(losses[0]) and losses[0] == losses[1]
+
+
+def test_c4_full_batch_32x8192_pointnet2_msg():
+    """C4: B = 32, N = 8192 through Pointnet2_Msg (the multi-scale FPS / ball-query stress): both levels' FPS picks and all six
+    ball queries of the grouping stage against the oracle, bit for bit; bf16 features against fp32; two runs identical."""
+    from ppt_amd import engine
+    from ppt_amd.models.pointnet2.pointnet2 import Pointnet2_Msg
+    B, N = 32, 8192
+    pc_np, s1 = W.synth_clouds(B, N, seed=99)
+    _, s2 = W.synth_clouds(B, 512, seed=98)
+    pc = torch.from_numpy(pc_np).cuda()
+    starts = (torch.from_numpy(s1).cuda(), torch.from_numpy(s2).cuda())
+    g = engine.pointnet2_group(pc, starts, engine.PN2_MSG_LEVELS)
+    l1_idx = O.fps(pc_np, 512, s1)
+    l1_xyz = np.take_along_axis(pc_np, l1_idx[:, :, None], axis=1)
+    assert np.array_equal(g[0].cpu().numpy(), l1_xyz)
+    for i, (r, K) in enumerate(engine.PN2_MSG_LEVELS[0][1]):                     # level 1: grouped, centred coordinates
+        bi = O.ball_query(pc_np, l1_xyz, r, K)
+        want = np.take_along_axis(pc_np[:, None], bi[..., None], axis=2) - l1_xyz[:, :, None]
+        assert np.array_equal(g[1 + i].cpu().numpy(), want.astype(np.float32)), (r, K)
+    l2_idx = O.fps(l1_xyz, 128, s2)
+    l2_xyz = np.take_along_axis(l1_xyz, l2_idx[:, :, None], axis=1)
+    assert np.array_equal(g[4].cpu().numpy(), l2_xyz)
+    for i, (r, K) in enumerate(engine.PN2_MSG_LEVELS[1][1]):                     # level 2: neighbour indices
+        assert np.array_equal(g[5 + i].cpu().numpy(), O.ball_query(l1_xyz, l2_xyz, r, K)), (r, K)
+    m = Pointnet2_Msg()
+    m.load_state_dict(W.synth_state_dict(W.pointnet2_msg_spec(prefix=""), seed=0))
+    m.cuda().eval()
+    m.fps_start = starts
+    outs = {}
+    for prec in (torch.float32, torch.bfloat16, torch.bfloat16):
+        m.precision, m._wc = prec, None
+        with torch.no_grad():
+            outs.setdefault(prec, []).append(m(pc).float().cpu())
+    a, b = outs[torch.float32][0], outs[torch.bfloat16][0]
+    assert torch.isfinite(a).all() and ((a - b).norm() / a.norm()).item() < 3e-2
+    assert torch.equal(outs[torch.bfloat16][0], outs[torch.bfloat16][1])
+
+
+def test_c5_full_batch_16x2048_partseg_step():
+    """C5: B = 16, N = 2048 part segmentation: one training step (forward, per-point CE, backward through the whole decoder),
+    finite, every decoder parameter that takes part in the forward gets a gradient, two runs give identical bits."""
+    from ppt_amd.models import ULIP_models as M
+    B, N = 16, 2048
+    pc_np, s0 = W.synth_clouds(B, N, seed=5, duplicates=True)
+    _, s1 = W.synth_clouds(B, N, seed=6)
+    _, s2 = W.synth_clouds(B, N, seed=7)
+    pc = torch.from_numpy(pc_np).cuda()
+    labels = torch.from_numpy(np.random.default_rng(2).integers(0, 50, size=(B, N))).cuda()
+    onehot = torch.nn.functional.one_hot(torch.arange(B) % 16, 16).float().cuda()
+    res = []
+    for _ in range(2):
+        m = _model("ULIP_PointBERT_partseg", "shapenetpart", task='partseg', sd_fn=W.ulip_partseg_state_dict)
+        m.overlap_text_tower = False
+        m.train()
+        pe = m.point_encoder
+        pe.fps_start = tuple(torch.from_numpy(s).cuda() for s in (s0, s1, s2))
+        pe.drop_path_factors = torch.ones(12, 2, B)
+        pe.dropout_mask = torch.ones(B, N, 128)
+        pred = m(pc, onehot)
+        loss = torch.nn.CrossEntropyLoss(label_smoothing=0.2)(pred.reshape(-1, 50), labels.reshape(-1))
+        loss.backward()
+        torch.cuda.synchronize()
+        missing = [n for n, p in m.named_parameters() if p.requires_grad and p.grad is None]
+        assert missing == ["point_encoder.conv2.weight", "point_encoder.conv2.bias"], missing      # unused by forward, as in the reference
+        res.append((loss.item(), m.point_encoder.propagation_0.mlp_convs[0].weight.grad.cpu().clone(),
+                    m.point_encoder.dgcnn_pro_1.layer1[0].weight.grad.cpu().clone()))
+    assert np.isfinite(res[0][0]) and res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])

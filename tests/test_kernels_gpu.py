@@ -934,3 +934,16 @@ def test_feature_propagation_matches_the_reference_formulation():
         cf = m(xyz1.permute(0, 2, 1), xyz2.permute(0, 2, 1), p1.permute(0, 2, 1), p2_0.permute(0, 2, 1))
         rows = m.forward_rows(xyz1, xyz2, p1, p2_0)
     assert cf.shape == (B, 48, N) and torch.equal(cf.permute(0, 2, 1), rows)
+
+
+@pytest.mark.parametrize("B,S,N,dup", [(2, 512, 1024, False), (1, 512, 8192, False), (2, 128, 512, True), (3, 33, 129, False)])
+def test_square_distance_is_bit_exact(ops, B, S, N, dup):
+    """models.pointbert.dvae.square_distance on the GPU (ppt_square_distance_f32) == the oracle's restatement of the
+    reference CPU arithmetic, bit for bit (it can be slightly negative, as the reference's: SURVEY App. A Q7)."""
+    from ppt_amd.models.pointbert.dvae import square_distance
+    pc, start = W.synth_clouds(B, N, seed=S + N, duplicates=dup)
+    src = np.ascontiguousarray(pc[:, :S])
+    got = square_distance(dev(src), dev(pc))
+    want = O.square_distance(src, pc)
+    assert got.shape == (B, S, N) and np.array_equal(got.cpu().numpy(), want)
+    assert np.array_equal(ops.square_distance(dev(src), dev(pc)).cpu().numpy(), want)
