@@ -125,7 +125,9 @@ def build_model(dataset="modelnet40", head_type=HEAD_TYPE, precision=torch.bfloa
     sd = {"ULIP_PointBERT": W.ulip_pointbert_state_dict, "ULIP_PN_MSG": W.ulip_pn2_msg_state_dict,
           "ULIP_PN_MLP": W.ulip_pn_mlp_state_dict, "ULIP_PointBERT_partseg": W.ulip_partseg_state_dict}[model](seed=0)
     m.load_state_dict(sd, strict=False)
-    m.prompt_learner.embedding = W.synth_prompt_embedding(len(args.classnames), seed=0)
+    # the cached prompt embedding with the structure the reference's has (ULIP_models.py:102: a token_embedding lookup, so the
+    # start token's row is the same in every prompt) -- which is what lets the text tower share the prompts' common prefix
+    m.prompt_learner.embedding = W.synth_prompt_embedding_from_tokens(m.tokenized_prompts, seed=0)
     m.cuda()
     m.set_precision(precision)
     return m

@@ -74,6 +74,18 @@ int ppt_ball_query_f32(const float *xyz, const float *center, int B, int N, int 
                        int K, int64_t *idx, float *grouped_xyz /* [B,S,K,3] = xyz[idx] - center, or NULL */,
                        void *stream);
 
+/* Up to three ball queries around the SAME centres in one pass (PointNetSetAbstractionMsg, pointnet2_utils.py:228-266: one
+ * (radius, nsample) pair per scale): cloud staged once, every distance evaluated once.  Results identical to n calls of
+ * ppt_ball_query_f32.  idx[j] [B,S,K[j]] i64, gxyz[j] [B,S,K[j],3] f32 or NULL. */
+typedef struct ppt_ball_multi {
+    int n;                           /* 1..3 queries */
+    float r2[3];                     /* squared radii */
+    int K[3];
+    int64_t *idx[3];
+    float *gxyz[3];
+} ppt_ball_multi;
+int ppt_ball_query_multi_f32(const float *xyz, const float *center, int B, int N, int S, const ppt_ball_multi *q, void *stream);
+
 /* ---- GEMM with fused prologue / epilogue ----------------------------------------------------
  * C[M,N] = epilogue( prologue(A)[M,K] . B[N,K]^T ).  A and B are K-contiguous (torch Linear /
  * k=1 Conv1d weight layout [out,in]).  Replaces every nn.Linear / Conv1d(k=1) on the path:
@@ -197,6 +209,21 @@ int ppt_attention_fwd(const void *qkv, void *out, float *lse, int Bt, int T, int
 int ppt_attention_bwd(const void *qkv, const void *out, const void *dout, const float *lse,
                       float *delta, void *dqkv, int Bt, int T, int H, int hd, float scale,
                       int causal, int dtype, void *stream);
+
+/* Prefix-shared causal attention for the CLIP text tower under PromptLearner (ULIP_models.py:104-151, 203-230).  With the class
+ * name in the "middle" / "end" position the first P positions of all C prompts are the same tokens (start token + leading
+ * learnable context), and the mask is causal, so their activations are identical in every prompt at every layer: they are
+ * stored -- and every LayerNorm / linear of the tower evaluated -- ONCE.  Row layout of qkv / out / dout / dqkv:
+ *   rows [0, P) = positions 0..P-1 (shared); rows [P + c (T - P), P + (c + 1)(T - P)) = positions P..T-1 of prompt c.
+ * A prompt's queries (positions >= P) see the shared rows as their first P keys; the gradient of the shared keys / values is
+ * the sum over the prompts (+ the prefix's own causal attention): each sequence writes an fp32 partial into `workspace`
+ * [C + 1, P, 2, H * hd] and a last kernel folds them in sequence order (deterministic, no atomics).
+ * lse / delta: [P + C (T - P), H] f32, indexed by ROW.  0 < P < T; hd == 64; same kernels as ppt_attention_fwd / _bwd. */
+size_t ppt_attention_prefix_workspace_bytes(int C, int P, int H, int hd);
+int ppt_attention_prefix_fwd(const void *qkv, void *out, float *lse, int C, int T, int P, int H, int hd, float scale, int dtype,
+                             void *stream);
+int ppt_attention_prefix_bwd(const void *qkv, const void *out, const void *dout, const float *lse, float *delta, void *dqkv,
+                             float *workspace, int C, int T, int P, int H, int hd, float scale, int dtype, void *stream);
 
 /* ---- mini-PointNet helpers -----------------------------------------------------------------------
  * BatchNorm1d in train mode inside dvae.py:188-199.

@@ -33,6 +33,11 @@ class GemmParams(ctypes.Structure):
     ]
 
 
+class BallMulti(ctypes.Structure):
+    """struct ppt_ball_multi (include/ppt_hip.h)."""
+    _fields_ = [("n", c_int), ("r2", c_float * 3), ("K", c_int * 3), ("idx", c_void_p * 3), ("gxyz", c_void_p * 3)]
+
+
 class RowGemmParams(ctypes.Structure):
     """struct ppt_rowgemm_params (include/ppt_hip.h) -- field order must match the header."""
     _fields_ = [
@@ -48,6 +53,7 @@ _SIGNATURES = {
     "ppt_fps_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ppt_knn_group_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ppt_square_distance_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ppt_ball_query_multi_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(BallMulti), c_void_p]),
     "ppt_ball_query_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "ppt_gather_add": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                c_void_p, c_void_p, c_void_p]),
@@ -70,6 +76,10 @@ _SIGNATURES = {
                                   c_int, c_void_p]),
     "ppt_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                   c_int, c_int, c_float, c_int, c_int, c_void_p]),
+    "ppt_attention_prefix_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
+    "ppt_attention_prefix_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "ppt_attention_prefix_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                         c_int, c_int, c_float, c_int, c_void_p]),
     "ppt_conv1_stats": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                 ctypes.POINTER(c_int), c_void_p]),
     "ppt_conv1_stats_max_partials": (c_int, [c_int64]),

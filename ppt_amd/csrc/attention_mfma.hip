@@ -14,9 +14,10 @@
 //   of the key so that the four key rows of a half-wave hit four different 64-byte bank quarters.
 //   Scores never leave registers; softmax scale and log2(e) are folded into one v_exp_f32 argument.
 #include "ppt_common.h"
+#include "attn_rowmap.h"
 
 extern "C" int ppt_attention_fwd_quad_bf16(const void *qkv, void *out, float *lse, int Bt, int T, int H, float scale,
-                                           int causal, hipStream_t s);
+                                           int causal, int P, hipStream_t s);
 
 namespace {
 
@@ -35,7 +36,8 @@ __device__ __forceinline__ float lane_xor32_sum(float v) { return xor32_sum(v); 
 
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out,
-                                                     float *__restrict__ lse, int T, int H, float c /* scale*log2(e) */)
+                                                     float *__restrict__ lse, int Tfull, int H, float c /* scale*log2(e) */,
+                                                     int P, int C)
 {
     __shared__ __align__(16) unsigned char smem[4 * TILE];    // K0 K1 V0 V1
     const int lane = threadIdx.x & 63;
@@ -43,7 +45,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(const bf16_t *__restrict
     const int r = lane & 31, h = lane >> 5;
     const int bh = blockIdx.y, b = bh / H, head = bh % H;
     const int64_t rs = 3 * (int64_t)H * HD;
-    const bf16_t *qb = qkv + (int64_t)b * T * rs + head * HD;
+    const int T = am_len(Tfull, P, C, b), q_lo = am_qlo(P, C, b);     // (attn_rowmap.h: b is a virtual sequence when P > 0)
+    const bf16_t *qb = qkv + head * HD;
     const bf16_t *kb = qb + H * HD, *vb = qb + 2 * H * HD;
     const int q0 = blockIdx.x * QB + w * 32;
     const int qrow = q0 + r;
@@ -52,7 +55,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(const bf16_t *__restrict
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (qrow < T) v = *reinterpret_cast<const uint4 *>(qb + (int64_t)qrow * rs + 16 * kk + 8 * h);
+        if (qrow < T) v = *reinterpret_cast<const uint4 *>(qb + am_row(Tfull, P, b, qrow) * rs + 16 * kk + 8 * h);
         qf[kk] = __builtin_bit_cast(bf16x8_t, v);
     }
 
@@ -69,8 +72,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(const bf16_t *__restrict
             const int key = kt * KVT + (cidx >> 3), ch = cidx & 7;
             sk[i] = sv[i] = make_uint4(0, 0, 0, 0);
             if (key < Tk) {
-                sk[i] = *reinterpret_cast<const uint4 *>(kb + (int64_t)key * rs + ch * 8);
-                sv[i] = *reinterpret_cast<const uint4 *>(vb + (int64_t)key * rs + ch * 8);
+                const int64_t kr = am_row(Tfull, P, b, key) * rs;
+                sk[i] = *reinterpret_cast<const uint4 *>(kb + kr + ch * 8);
+                sv[i] = *reinterpret_cast<const uint4 *>(vb + kr + ch * 8);
             }
         }
     };
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(const bf16_t *__restrict
         for (int e = 0; e < 16; ++e) ot[i][e] = 0.f;
     float m = -INFINITY, l = 0.f;
     if (peel) {
-        const bf16_t *kl = kb + (int64_t)(T - 1) * rs, *vl = vb + (int64_t)(T - 1) * rs;
+        const bf16_t *kl = kb + am_row(Tfull, P, b, T - 1) * rs, *vl = vb + am_row(Tfull, P, b, T - 1) * rs;
         float dot = 0.f;                                  // this lane's 32 of the 64 dimensions; the other half-wave has the rest
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -219,9 +223,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(const bf16_t *__restrict
     }
 
     const float lt = lane_xor32_sum(l);
-    if (qrow < T) {
+    if (qrow < T && qrow >= q_lo) {
         const float inv = 1.0f / lt;
-        bf16_t *ob = out + ((int64_t)b * T + qrow) * (H * HD) + head * HD;
+        bf16_t *ob = out + am_row(Tfull, P, b, qrow) * (H * HD) + head * HD;
 #pragma unroll
         for (int dtile = 0; dtile < 2; ++dtile)
 #pragma unroll
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(const bf16_t *__restrict
                                            pack_bf16x2(ot[dtile][4 * gq + 2] * inv, ot[dtile][4 * gq + 3] * inv));
                 *reinterpret_cast<uint2 *>(ob + 32 * dtile + 8 * gq + 4 * h) = u;
             }
-        if (lse && h == 0) lse[(int64_t)bh * T + qrow] = (m + __log2f(lt)) * 0.6931471805599453f;
+        if (lse && h == 0) lse[am_stat(Tfull, P, H, b, head, qrow)] = (m + __log2f(lt)) * 0.6931471805599453f;
     }
 }
 
@@ -269,7 +273,8 @@ constexpr int QTILE = QT * 128;              // bytes per 32-row image
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dout,
                                                          const float *__restrict__ lse, const float *__restrict__ delta,
-                                                         bf16_t *__restrict__ dqkv, int T, int H, float scale)
+                                                         bf16_t *__restrict__ dqkv, int Tfull, int H, float scale, int P, int C,
+                                                         float *__restrict__ part)
 {
     // per stage: Q row image, Q tr image, dO row image, dO tr image (4 KiB each) + lse2[32] + delta[32]
     __shared__ __align__(16) unsigned char smem[2 * (4 * QTILE + 256)];
@@ -278,9 +283,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma(const bf16_t *__rest
     const int r = lane & 31, h = lane >> 5;
     const int bh = blockIdx.y, b = bh / H, head = bh % H;
     const int64_t rs = 3 * (int64_t)H * HD, os = (int64_t)H * HD;
-    const bf16_t *qb = qkv + (int64_t)b * T * rs + head * HD;
+    const int T = am_len(Tfull, P, C, b), q_lo = am_qlo(P, C, b);
+    const bf16_t *qb = qkv + head * HD;
     const bf16_t *kb = qb + H * HD, *vb = qb + 2 * H * HD;
-    const bf16_t *gb = dout + (int64_t)b * T * os + head * HD;
+    const bf16_t *gb = dout + head * HD;
     const int k0 = blockIdx.x * 128 + w * 32;
     const int key = k0 + r;
     const float c = scale * 1.4426950408889634f;
@@ -290,8 +296,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma(const bf16_t *__rest
     for (int kk = 0; kk < 4; ++kk) {
         uint4 a = make_uint4(0, 0, 0, 0), v = make_uint4(0, 0, 0, 0);
         if (key < T) {
-            a = *reinterpret_cast<const uint4 *>(kb + (int64_t)key * rs + 16 * kk + 8 * h);
-            v = *reinterpret_cast<const uint4 *>(vb + (int64_t)key * rs + 16 * kk + 8 * h);
+            a = *reinterpret_cast<const uint4 *>(kb + am_row(Tfull, P, b, key) * rs + 16 * kk + 8 * h);
+            v = *reinterpret_cast<const uint4 *>(vb + am_row(Tfull, P, b, key) * rs + 16 * kk + 8 * h);
         }
         kf[kk] = __builtin_bit_cast(bf16x8_t, a);
         vf[kk] = __builtin_bit_cast(bf16x8_t, v);
@@ -303,7 +309,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma(const bf16_t *__rest
         for (int e = 0; e < 16; ++e) { dvt[i][e] = 0.f; dkt[i][e] = 0.f; }
 
     const int nqt = (T + QT - 1) / QT;
-    const int qt0 = CAUSAL ? (blockIdx.x * 128) / QT : 0;       // queries before the block's first key see none of it
+    // queries before the block's first key see none of it; queries below q_lo belong to the prefix sequence, not to this one
+    const int qt0 = max(CAUSAL ? (int)(blockIdx.x * 128) / QT : 0, q_lo / QT);
     uint4 sq, sg;
     float sl = 0.f, sd = 0.f;
     const int srow = threadIdx.x >> 3, sch = threadIdx.x & 7;   // staging: one 16-B chunk of Q and of dO per thread
@@ -311,13 +318,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma(const bf16_t *__rest
         const int q = qt * QT + srow;
         sq = sg = make_uint4(0, 0, 0, 0);
         if (q < T) {
-            sq = *reinterpret_cast<const uint4 *>(qb + (int64_t)q * rs + sch * 8);
-            sg = *reinterpret_cast<const uint4 *>(gb + (int64_t)q * os + sch * 8);
+            const int64_t qr = am_row(Tfull, P, b, q);
+            sq = *reinterpret_cast<const uint4 *>(qb + qr * rs + sch * 8);
+            sg = *reinterpret_cast<const uint4 *>(gb + qr * os + sch * 8);
         }
         if (threadIdx.x < QT) {
             const int q2 = qt * QT + threadIdx.x;
-            sl = q2 < T ? lse[(int64_t)bh * T + q2] * 1.4426950408889634f : INFINITY;   // +inf -> p = 0 for padded rows
-            sd = q2 < T ? delta[(int64_t)bh * T + q2] : 0.f;
+            const bool own = q2 < T && q2 >= q_lo;                  // +inf -> p = 0 for padded rows and for rows this sequence does not own
+            sl = own ? lse[am_stat(Tfull, P, H, b, head, q2)] * 1.4426950408889634f : INFINITY;
+            sd = own ? delta[am_stat(Tfull, P, H, b, head, q2)] : 0.f;
         }
     };
     auto write_tile = [&](int buf) {
@@ -388,8 +397,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma(const bf16_t *__rest
         if (qt + 1 < nqt) write_tile(cur ^ 1);
         __syncthreads();
     }
-    if (key < T) {
-        bf16_t *ok = dqkv + ((int64_t)b * T + key) * rs + head * HD + H * HD;
+    if (key < T && P > 0 && key < P) {
+        // a SHARED key: this virtual sequence's contribution goes to its fp32 partial slot [b][key][K | V][H * HD]; the
+        // slots are folded in a fixed order by attn_prefix_reduce (no atomics)
+        float *pk = part + (((int64_t)b * P + key) * 2) * os + head * HD, *pv = pk + os;
+#pragma unroll
+        for (int dtile = 0; dtile < 2; ++dtile)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int d = 32 * dtile + 8 * gq + 4 * h;
+                *reinterpret_cast<float4 *>(pk + d) = make_float4(dkt[dtile][4 * gq], dkt[dtile][4 * gq + 1], dkt[dtile][4 * gq + 2], dkt[dtile][4 * gq + 3]);
+                *reinterpret_cast<float4 *>(pv + d) = make_float4(dvt[dtile][4 * gq], dvt[dtile][4 * gq + 1], dvt[dtile][4 * gq + 2], dvt[dtile][4 * gq + 3]);
+            }
+    } else if (key < T) {
+        bf16_t *ok = dqkv + am_row(Tfull, P, b, key) * rs + head * HD + H * HD;
         bf16_t *ov = ok + H * HD;
 #pragma unroll
         for (int dtile = 0; dtile < 2; ++dtile)
@@ -407,7 +428,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma(const bf16_t *__rest
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dout,
                                                         const float *__restrict__ lse, const float *__restrict__ delta,
-                                                        bf16_t *__restrict__ dqkv, int T, int H, float scale)
+                                                        bf16_t *__restrict__ dqkv, int Tfull, int H, float scale, int P, int C)
 {
     __shared__ __align__(16) unsigned char smem[2 * 3 * TILE];    // per stage: K row image, K tr image, V row image
     const int lane = threadIdx.x & 63;
@@ -415,9 +436,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma(const bf16_t *__restr
     const int r = lane & 31, h = lane >> 5;
     const int bh = blockIdx.y, b = bh / H, head = bh % H;
     const int64_t rs = 3 * (int64_t)H * HD, os = (int64_t)H * HD;
-    const bf16_t *qb = qkv + (int64_t)b * T * rs + head * HD;
+    const int T = am_len(Tfull, P, C, b), q_lo = am_qlo(P, C, b);
+    const bf16_t *qb = qkv + head * HD;
     const bf16_t *kb = qb + H * HD, *vb = qb + 2 * H * HD;
-    const bf16_t *gb = dout + (int64_t)b * T * os + head * HD;
+    const bf16_t *gb = dout + head * HD;
     const int q0 = blockIdx.x * QB + w * 32;
     const int qrow = q0 + r;
     const float c = scale * 1.4426950408889634f;
@@ -427,14 +449,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma(const bf16_t *__restr
     for (int kk = 0; kk < 4; ++kk) {
         uint4 a = make_uint4(0, 0, 0, 0), v = make_uint4(0, 0, 0, 0);
         if (qrow < T) {
-            a = *reinterpret_cast<const uint4 *>(qb + (int64_t)qrow * rs + 16 * kk + 8 * h);
-            v = *reinterpret_cast<const uint4 *>(gb + (int64_t)qrow * os + 16 * kk + 8 * h);
+            a = *reinterpret_cast<const uint4 *>(qb + am_row(Tfull, P, b, qrow) * rs + 16 * kk + 8 * h);
+            v = *reinterpret_cast<const uint4 *>(gb + am_row(Tfull, P, b, qrow) * os + 16 * kk + 8 * h);
         }
         qf[kk] = __builtin_bit_cast(bf16x8_t, a);
         gf[kk] = __builtin_bit_cast(bf16x8_t, v);
     }
-    const float l2 = qrow < T ? lse[(int64_t)bh * T + qrow] * 1.4426950408889634f : INFINITY;
-    const float dl = qrow < T ? delta[(int64_t)bh * T + qrow] : 0.f;
+    const bool own = qrow < T && qrow >= q_lo;
+    const float l2 = own ? lse[am_stat(Tfull, P, H, b, head, qrow)] * 1.4426950408889634f : INFINITY;
+    const float dl = own ? delta[am_stat(Tfull, P, H, b, head, qrow)] : 0.f;
 
     uint4 sk[2], sv[2];
     auto load_tile = [&](int kt) {
@@ -444,8 +467,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma(const bf16_t *__restr
             const int kx = kt * KVT + (cidx >> 3), ch = cidx & 7;
             sk[i] = sv[i] = make_uint4(0, 0, 0, 0);
             if (kx < T) {
-                sk[i] = *reinterpret_cast<const uint4 *>(kb + (int64_t)kx * rs + ch * 8);
-                sv[i] = *reinterpret_cast<const uint4 *>(vb + (int64_t)kx * rs + ch * 8);
+                const int64_t kr = am_row(Tfull, P, b, kx) * rs;
+                sk[i] = *reinterpret_cast<const uint4 *>(kb + kr + ch * 8);
+                sv[i] = *reinterpret_cast<const uint4 *>(vb + kr + ch * 8);
             }
         }
     };
@@ -516,8 +540,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma(const bf16_t *__restr
         if (kt + 1 < nkt) write_tile(cur ^ 1);
         __syncthreads();
     }
-    if (qrow < T) {
-        bf16_t *oq = dqkv + ((int64_t)b * T + qrow) * rs + head * HD;
+    if (own) {
+        bf16_t *oq = dqkv + am_row(Tfull, P, b, qrow) * rs + head * HD;
 #pragma unroll
         for (int dtile = 0; dtile < 2; ++dtile)
 #pragma unroll
@@ -531,31 +555,34 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma(const bf16_t *__restr
 }  // namespace
 
 extern "C" int ppt_attention_fwd_mfma_bf16(const void *qkv, void *out, float *lse, int Bt, int T, int H, float scale,
-                                           int causal, hipStream_t s)
+                                           int causal, int P, hipStream_t s)
 {
-    if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 7)) return ppt_attention_fwd_quad_bf16(qkv, out, lse, Bt, T, H, scale, causal, s);
-    dim3 grid((T + QB - 1) / QB, Bt * H);
+    if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 7)) return ppt_attention_fwd_quad_bf16(qkv, out, lse, Bt, T, H, scale, causal, P, s);
+    dim3 grid((T + QB - 1) / QB, (Bt + (P > 0)) * H);
     const float c = scale * 1.4426950408889634f;
     if (causal)
-        hipLaunchKernelGGL(attn_fwd_mfma<true>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (bf16_t *)out, lse, T, H, c);
+        hipLaunchKernelGGL(attn_fwd_mfma<true>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (bf16_t *)out, lse, T, H, c, P, Bt);
     else
-        hipLaunchKernelGGL(attn_fwd_mfma<false>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (bf16_t *)out, lse, T, H, c);
+        hipLaunchKernelGGL(attn_fwd_mfma<false>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (bf16_t *)out, lse, T, H, c, P, Bt);
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }
 
-// dq / dk / dv of the bf16 path; `delta` must already hold rowsum(dO * O) (attention.hip: attn_delta)
+// dq / dk / dv of the bf16 path; `delta` must already hold rowsum(dO * O) (attention.hip: attn_delta).  P > 0 (prefix-shared
+// layout, attn_rowmap.h): `part` [Bt + 1, P, 2, H * 64] f32 receives the per-sequence dK / dV of the shared rows; the caller
+// folds it (attention.hip: attn_prefix_reduce).
 extern "C" int ppt_attention_bwd_mfma_bf16(const void *qkv, const void *dout, const float *lse, const float *delta,
-                                           void *dqkv, int Bt, int T, int H, float scale, int causal, hipStream_t s)
+                                           void *dqkv, int Bt, int T, int H, float scale, int causal, int P, float *part,
+                                           hipStream_t s)
 {
-    if (((uintptr_t)qkv & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dqkv & 7)) return PPT_EUNSUPPORTED;
-    dim3 grid((T + 127) / 128, Bt * H);
+    if (((uintptr_t)qkv & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dqkv & 7) || ((uintptr_t)part & 15)) return PPT_EUNSUPPORTED;
+    dim3 grid((T + 127) / 128, (Bt + (P > 0)) * H);
     if (causal) {
-        hipLaunchKernelGGL(attn_bwd_dkv_mfma<true>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (const bf16_t *)dout, lse, delta, (bf16_t *)dqkv, T, H, scale);
-        hipLaunchKernelGGL(attn_bwd_dq_mfma<true>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (const bf16_t *)dout, lse, delta, (bf16_t *)dqkv, T, H, scale);
+        hipLaunchKernelGGL(attn_bwd_dkv_mfma<true>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (const bf16_t *)dout, lse, delta, (bf16_t *)dqkv, T, H, scale, P, Bt, part);
+        hipLaunchKernelGGL(attn_bwd_dq_mfma<true>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (const bf16_t *)dout, lse, delta, (bf16_t *)dqkv, T, H, scale, P, Bt);
     } else {
-        hipLaunchKernelGGL(attn_bwd_dkv_mfma<false>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (const bf16_t *)dout, lse, delta, (bf16_t *)dqkv, T, H, scale);
-        hipLaunchKernelGGL(attn_bwd_dq_mfma<false>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (const bf16_t *)dout, lse, delta, (bf16_t *)dqkv, T, H, scale);
+        hipLaunchKernelGGL(attn_bwd_dkv_mfma<false>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (const bf16_t *)dout, lse, delta, (bf16_t *)dqkv, T, H, scale, P, Bt, part);
+        hipLaunchKernelGGL(attn_bwd_dq_mfma<false>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (const bf16_t *)dout, lse, delta, (bf16_t *)dqkv, T, H, scale, P, Bt);
     }
     PPT_CHECK_LAUNCH();
     return PPT_OK;

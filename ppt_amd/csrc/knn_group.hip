@@ -220,6 +220,82 @@ __global__ __launch_bounds__(W * 64) void ball_query_kernel(const float *__restr
     }
 }
 
+// The ball queries of ONE multi-scale set-abstraction level (PointNetSetAbstractionMsg, pointnet2_utils.py:228-266: the same
+// centres, up to three radii) in a single pass: the cloud is staged once, every point's distance is evaluated once and tested
+// against all radii (the reference evaluates square_distance once per radius, :99; three launches of ball_query_kernel staged
+// the 128 KB of an 8192-point cloud three times and walked it three times).  Hits write the index AND the centred
+// coordinates at once (no read-back of the index list); a list is padded from the first hit, which is kept in a register.
+template <int W, int NR>
+__global__ __launch_bounds__(W * 64) void ball_query_multi_kernel(const float *__restrict__ xyz, const float *__restrict__ center, int N,
+                                                                  int S, int cpb, ppt_ball_multi q)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    float4 *cloud = reinterpret_cast<float4 *>(smem);
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    stage_cloud(xyz + (size_t)b * N * 3, N, cloud);
+    __syncthreads();
+    const int c_end = min(S, (int)(blockIdx.x + 1) * cpb);
+    for (int c = blockIdx.x * cpb + w; c < c_end; c += W) {
+        const float *qc = center + ((size_t)b * S + c) * 3;
+        const float qx = qc[0], qy = qc[1], qz = qc[2];
+        const float nq = sqnorm3_rn(qx, qy, qz);
+        int cnt[NR], first[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) { cnt[j] = 0; first[j] = N; }
+        bool more = true;
+        for (int base = 0; base < N && more; base += 64) {
+            const int i = base + lane;
+            float d = INFINITY;
+            float4 pt = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < N) {
+                pt = cloud[i];
+                d = expanded_sqdist_rn(qx, qy, qz, nq, pt.x, pt.y, pt.z, pt.w);
+            }
+            more = false;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                if (j < q.n && cnt[j] < q.K[j]) {                          // (wave-uniform)
+                    const bool hit = i < N && !(d > q.r2[j]);
+                    const unsigned long long mask = __ballot(hit);
+                    if (mask) {
+                        if (cnt[j] == 0) first[j] = base + (int)__builtin_ctzll(mask);
+                        if (hit) {
+                            const int pos = cnt[j] + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+                            if (pos < q.K[j]) {
+                                const size_t o = ((size_t)b * S + c) * q.K[j] + pos;
+                                q.idx[j][o] = (int64_t)i;
+                                if (q.gxyz[j]) {
+                                    float *g = q.gxyz[j] + o * 3;
+                                    g[0] = __fsub_rn(pt.x, qx); g[1] = __fsub_rn(pt.y, qy); g[2] = __fsub_rn(pt.z, qz);
+                                }
+                            }
+                        }
+                        cnt[j] += __popcll(mask);
+                    }
+                    more = more || cnt[j] < q.K[j];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            if (j < q.n) {
+                const float4 pf = cloud[min(first[j], N - 1)];
+                for (int k = min(cnt[j], q.K[j]) + lane; k < q.K[j]; k += 64) {
+                    const size_t o = ((size_t)b * S + c) * q.K[j] + k;
+                    q.idx[j][o] = (int64_t)first[j];
+                    if (q.gxyz[j]) {
+                        float *g = q.gxyz[j] + o * 3;
+                        g[0] = __fsub_rn(pf.x, qx); g[1] = __fsub_rn(pf.y, qy); g[2] = __fsub_rn(pf.z, qz);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // dist[b, s, n] of square_distance (dvae.py:130-149), the reference's expanded form with its rounding sequence; one thread
 // per 4 consecutive n of one (b, s): 16-byte stores along the rows
 __global__ __launch_bounds__(256) void square_distance_kernel(const float *__restrict__ src, const float *__restrict__ dst, int S, int N,
@@ -255,6 +331,23 @@ extern "C" int ppt_square_distance_f32(const float *src, const float *dst, int B
     const int64_t total4 = (int64_t)B * S * ((N + 3) / 4);
     const int grid = (int)((total4 + 255) / 256 < 16384 ? (total4 + 255) / 256 : 16384);
     hipLaunchKernelGGL(square_distance_kernel, dim3(grid), dim3(256), 0, ppt_stream(stream), src, dst, S, N, total4, out);
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
+extern "C" int ppt_ball_query_multi_f32(const float *xyz, const float *center, int B, int N, int S, const ppt_ball_multi *q, void *stream)
+{
+    if (!xyz || !center || !q || B <= 0 || N <= 0 || S <= 0 || N > 10240 || q->n < 1 || q->n > 3) return PPT_EINVAL;
+    for (int j = 0; j < q->n; ++j)
+        if (!q->idx[j] || q->K[j] <= 0) return PPT_EINVAL;
+    constexpr int W = 8;
+    const size_t lds = (size_t)N * 16;
+    static const hipError_t optin = hipFuncSetAttribute((const void *)ball_query_multi_kernel<W, 3>,
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 10240 * 16);
+    if (lds > 64 * 1024 && optin != hipSuccess) return PPT_ELAUNCH;
+    const int cpb = 32;
+    dim3 grid((S + cpb - 1) / cpb, B);
+    hipLaunchKernelGGL((ball_query_multi_kernel<W, 3>), grid, dim3(W * 64), lds, ppt_stream(stream), xyz, center, N, S, cpb, *q);
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }

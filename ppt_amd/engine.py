@@ -366,6 +366,10 @@ def _sa_group(xyz, npoint, branches, start, first):
     -> [new_xyz [B,S,3], per branch: grouped centred xyz [B,S,K,3] (first level) or neighbour indices [B,S,K]]."""
     _, new_xyz = ops.fps(xyz, npoint, start)
     out = [new_xyz]
+    if 1 < len(branches) <= 3:          # the scales of an MSG level share their centres: one pass over the cloud for all radii
+        for idx, gxyz in ops.ball_query_multi(xyz, new_xyz, list(branches), want_grouped=first):
+            out.append(gxyz if first else idx)
+        return out
     for r, K in branches:
         idx, gxyz = ops.ball_query(xyz, new_xyz, r, K, want_grouped=True)
         out.append(gxyz if first else idx)
@@ -659,25 +663,43 @@ def pointmlp_forward(sd, p, wc, pc, fps_starts, train, drop_masks, update_runnin
 # =================================================================================================
 # text branch (CLIP text transformer, ULIP_models.py:35-67, 203-222)
 # =================================================================================================
-def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=None):
+def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=None, prefix=0):
     """encode_text: prompts [C,L,W] fp32 -> text features [C,E] fp32 (before L2 normalisation).
     save=True keeps what the input-gradient backward needs.
 
     eff_len: the attention is causal (ULIP_models.py:224-230) and only the EOT token is pooled
     (:222), so positions after the last EOT of any class can influence neither the output nor any
     gradient; the tower is evaluated on the first eff_len = max(eot)+1 positions only (37 of 77 for
-    the ModelNet40 prompts).  Outputs and gradients are identical to the full-length evaluation."""
+    the ModelNet40 prompts).  Outputs and gradients are identical to the full-length evaluation.
+
+    prefix = P > 0: the caller vouches that positions 0 .. P-1 are the same in every prompt (the start token and the
+    leading learnable context tokens of PromptLearner's "middle" / "end" layouts, ULIP_models.py:112-148).  Causal attention
+    then makes their activations identical in every prompt at every layer, so they are stored and computed ONCE: the tower
+    runs on P + C (L - P) rows instead of C L (817 instead of 1 480 for ModelNet40: every LayerNorm / linear of the tower does
+    45 % less work), with ppt_attention_prefix_fwd reading the shared rows as every prompt's first P keys.  The forward is
+    bit-identical to the unshared evaluation; in the backward the prompts' contributions to the shared rows are summed layer by
+    layer instead of at the very end (same sum, another order)."""
     T = wc.dtype
     C, Lfull, Wd = prompts.shape
     L = Lfull if eff_len is None else min(Lfull, int(eff_len))
-    if L != Lfull:
-        prompts = prompts[:, :L].contiguous()
-    M = C * L
+    P = int(prefix) if (prefix and 0 < int(prefix) < L and C > 1) else 0
     dev = prompts.device
+    if P:
+        M = ops.prefix_rows(C, L, P)
+        xin = torch.cat([prompts[0, :P], prompts[:, P:L].reshape(C * (L - P), Wd)], dim=0)
+        add = wc.derived(("text_pos_prefix", C, L, P), (sd["positional_embedding"],),
+                         lambda: torch.cat([sd["positional_embedding"][:P], sd["positional_embedding"][P:L].repeat(C, 1)], dim=0).contiguous())
+        add_rows = 0
+        rows = P + torch.arange(C, device=dev) * (L - P) + (eot_pos - P)             # EOT pooling (ULIP_models.py:222); eot >= P
+    else:
+        if L != Lfull:
+            prompts = prompts[:, :L].contiguous()
+        M = C * L
+        add, add_rows = sd["positional_embedding"], L             # x = prompts + pos[:L] (ULIP_models.py:210)
+        xin = prompts.reshape(M, Wd)
+        rows = torch.arange(C, device=dev) * L + eot_pos            # EOT pooling (ULIP_models.py:222)
     saved = {"layers": []} if save else None
     x = torch.empty((M, Wd), dtype=torch.float32, device=dev)
-    add, add_rows = sd["positional_embedding"], L                 # x = prompts + pos[:L] (ULIP_models.py:210)
-    xin = prompts.reshape(M, Wd)
     for i in range(layers):
         p = f"transformer.resblocks.{i}."
         h, mean1, rstd1 = ops.layernorm_fwd(xin, sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], T, add=add,
@@ -685,7 +707,10 @@ def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=No
                                             save_stats=save)
         add, add_rows = None, 0
         qkv = ops.gemm(h, wc.get(sd[p + "attn.in_proj_weight"]), out_dtype=T, bias=sd[p + "attn.in_proj_bias"])
-        a, lse = ops.attention_fwd(qkv, C, L, heads, ATTN_SCALE, True, want_lse=save)
+        if P:
+            a, lse = ops.attention_prefix_fwd(qkv, C, L, P, heads, ATTN_SCALE, want_lse=save)
+        else:
+            a, lse = ops.attention_fwd(qkv, C, L, heads, ATTN_SCALE, True, want_lse=save)
         x_mid = torch.empty_like(x)
         ops.gemm(a, wc.get(sd[p + "attn.out_proj.weight"]), out=x_mid, bias=sd[p + "attn.out_proj.bias"], residual=x)
         h2, mean2, rstd2 = ops.layernorm_fwd(x_mid, sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], T, save_stats=save)
@@ -699,14 +724,13 @@ def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=No
                                         rstd2=rstd2, pre=pre))
         x = x_next
         xin = x
-    rows = torch.arange(C, device=dev) * L + eot_pos                # EOT pooling (ULIP_models.py:222)
     x_eot = x.index_select(0, rows)
     hn, meanf, rstdf = ops.layernorm_fwd(x_eot, sd["ln_final.weight"], sd["ln_final.bias"], torch.float32,
                                          save_stats=save)
     wc32 = _f32_cache(wc)
     out = ops.gemm(hn, wc32.get(sd["text_projection"], "wt"), out_dtype=torch.float32)
     if save:
-        saved.update(x_eot=x_eot, meanf=meanf, rstdf=rstdf, rows=rows, C=C, L=L, Lfull=Lfull, W=Wd, heads=heads)
+        saved.update(x_eot=x_eot, meanf=meanf, rstdf=rstdf, rows=rows, C=C, L=L, Lfull=Lfull, W=Wd, heads=heads, P=P, M=M)
     return out, saved
 
 
@@ -725,10 +749,10 @@ def _f32_cache(wc):
 def text_tower_backward(sd, wc, s, dout):
     """Input gradient of encode_text: dout [C,E] -> d prompts [C,L,W] fp32.  The tower is frozen
     (ULIP_models.py:487-507), so no weight gradient is ever formed: 4 dX GEMMs, 2 LayerNorm
-    backwards and one attention backward per layer."""
+    backwards and one attention backward per layer.  With a shared prefix (text_tower_forward) the gradient of the shared
+    rows is handed to prompt 0; the caller (PromptLearner's index_put) sums over the prompts anyway."""
     T = wc.dtype
-    C, L, Wd, heads = s["C"], s["L"], s["W"], s["heads"]
-    M = C * L
+    C, L, Wd, heads, P, M = s["C"], s["L"], s["W"], s["heads"], s["P"], s["M"]
     wc32 = _f32_cache(wc)
     d_hn = ops.gemm(dout.contiguous(), wc32.get(sd["text_projection"], "w"), out_dtype=torch.float32)
     d_eot, _, _ = ops.layernorm_bwd(d_hn, s["x_eot"], sd["ln_final.weight"], s["meanf"], s["rstdf"])
@@ -744,14 +768,21 @@ def text_tower_backward(sd, wc, s, dout):
         _, _, _, g_t = ops.layernorm_bwd(d_h2, ly["x_mid"], sd[p + "ln_2.weight"], ly["mean2"], ly["rstd2"], dx=g,
                                          accumulate=True, copy_dtype=T)
         d_a = ops.gemm(g_t, wc.get(sd[p + "attn.out_proj.weight"], "wt"), out_dtype=T)
-        d_qkv = ops.attention_bwd(ly["qkv"], ly["a"], d_a, ly["lse"], C, L, heads, ATTN_SCALE, True)
+        if P:
+            d_qkv = ops.attention_prefix_bwd(ly["qkv"], ly["a"], d_a, ly["lse"], C, L, P, heads, ATTN_SCALE)
+        else:
+            d_qkv = ops.attention_bwd(ly["qkv"], ly["a"], d_a, ly["lse"], C, L, heads, ATTN_SCALE, True)
         d_h = ops.gemm(d_qkv, wc.get(sd[p + "attn.in_proj_weight"], "wt"), out_dtype=torch.float32)
         _, _, _, g_t = ops.layernorm_bwd(d_h, ly["x"], sd[p + "ln_1.weight"], ly["mean1"], ly["rstd1"], dx=g,
                                          accumulate=True, copy_dtype=T)
-    if L == s["Lfull"]:
+    if not P and L == s["Lfull"]:
         return g.view(C, L, Wd)
     full = torch.zeros((C, s["Lfull"], Wd), dtype=torch.float32, device=dout.device)   # positions past the last EOT: zero gradient
-    full[:, :L] = g.view(C, L, Wd)
+    if P:
+        full[0, :P] = g[:P]
+        full[:, P:L] = g[P:].view(C, L - P, Wd)
+    else:
+        full[:, :L] = g.view(C, L, Wd)
     return full
 
 

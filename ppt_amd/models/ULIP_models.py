@@ -215,6 +215,21 @@ class PromptLearner(nn.Module):
     def eot_positions(self):
         return self.tokenized_prompts.argmax(dim=-1)
 
+    def shared_prefix(self):
+        """Number of leading positions whose prompt rows are the same for EVERY class: the start token (one token id, hence
+        one embedding row: ULIP_models.py:102 looks the prompts up in token_embedding) followed by the learnable context tokens
+        that come before the class name (ULIP_models.py:112-148: all 32 for "end", the first half for "middle", none for
+        "front").  Checked against the cached embedding itself (a caller may have replaced it with per-class rows: then 0)."""
+        emb = self.embedding
+        key = (emb.data_ptr(), str(emb.device), emb._version, self.class_name_position)
+        if getattr(self, "_prefix_cache", (None, 0))[0] != key:
+            n = self.num_learnable_prompt_tokens
+            cand = {"middle": 1 + n // 2, "end": 1 + n}.get(self.class_name_position, 1)
+            same = bool((self.tokenized_prompts[:, 0] == self.tokenized_prompts[0, 0]).all()) and \
+                bool((emb[:, 0] == emb[0:1, 0]).all().item())                       # (one host read per embedding, cached)
+            self._prefix_cache = (key, cand if (same and cand >= 8 and len(self.classnames) > 1) else 0)
+        return self._prefix_cache[1]
+
 
 class _TextTowerFn(torch.autograd.Function):
     """encode_text as one autograd node.  After graphs.WARMUP_CALLS eager calls the forward (and the input-gradient
@@ -228,11 +243,12 @@ class _TextTowerFn(torch.autograd.Function):
         eot = model._eot(prompts.device)
         heads, layers = model.transformer.heads, model.transformer.layers
         eff = model._text_len() if model.truncate_text_to_eot else None
+        pre = model.prompt_learner.shared_prefix() if model.share_text_prefix else 0
 
         def run(pr):
-            return engine.text_tower_forward(sd, cache, pr, eot, heads, layers, save, eff_len=eff)
+            return engine.text_tower_forward(sd, cache, pr, eot, heads, layers, save, eff_len=eff, prefix=pre)
 
-        key = ("text_fwd", tuple(prompts.shape), save, eff, cache.dtype)
+        key = ("text_fwd", tuple(prompts.shape), save, eff, pre, cache.dtype)
         gc = model._graphs
         ctx.model, ctx.graph = model, None
         if prompts.is_cuda and model.use_hip_graphs and ops.profiler is None and gc.ready(key):
@@ -372,6 +388,8 @@ class ULIP_WITH_IMAGE(nn.Module):
         self.use_hip_graphs = True          # replay the text tower from captured hipGraphs after two eager calls
         self.overlap_text_tower = True      # run the (input-independent) text tower on a side stream
         self.truncate_text_to_eot = True    # causal mask + EOT pooling: positions after the last EOT are dead work
+        # positions in front of the class name are the same in every prompt: computed once (PPT_SHARE_TEXT_PREFIX=0: A/B runs)
+        self.share_text_prefix = os.environ.get("PPT_SHARE_TEXT_PREFIX", "1") != "0"
 
     # ---- reference helpers ------------------------------------------------------------------
     def build_attention_mask(self):

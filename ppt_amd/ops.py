@@ -119,6 +119,31 @@ def knn_group(xyz, center, k, want_idx=True, want_nbhd=True, want_dist=False):
     return (idx, nb, nd) if want_dist else (idx, nb)
 
 
+def ball_query_multi(xyz, center, queries, want_grouped=False):
+    """queries = [(radius, K), ...] (1..3) around the same centres, one pass over the cloud (ppt_ball_query_multi_f32)
+    -> [(idx [B,S,K] i64, grouped_xyz [B,S,K,3] | None), ...]; same results as ball_query per pair."""
+    _chk(xyz, torch.float32, "xyz"); _chk(center, torch.float32, "center")
+    import numpy as np
+    B, N, _ = xyz.shape
+    S = center.shape[1]
+    q = _lib.BallMulti()
+    q.n = len(queries)
+    outs, bytes_ = [], 12 * N + 12 * S
+    for j, (r, K) in enumerate(queries):
+        idx = torch.empty((B, S, K), dtype=torch.int64, device=xyz.device)
+        g = torch.empty((B, S, K, 3), dtype=torch.float32, device=xyz.device) if want_grouped else None
+        q.r2[j], q.K[j] = float(np.float32(r * r)), K
+        q.idx[j], q.gxyz[j] = idx.data_ptr(), (g.data_ptr() if g is not None else None)
+        outs.append((idx, g))
+        bytes_ += 8 * S * K + (12 * S * K if want_grouped else 0)
+    if profiler is not None:
+        profiler.begin("ball_query", float(B) * bytes_)
+    _lib.check(_lib.lib().ppt_ball_query_multi_f32(_p(xyz), _p(center), B, N, S, ctypes.byref(q), _stream()), "ppt_ball_query_multi_f32")
+    if profiler is not None:
+        profiler.end()
+    return outs
+
+
 def square_distance(src, dst):
     """dvae.py:130-149: src [B,S,3], dst [B,N,3] f32 -> [B,S,N] f32 with the reference's rounding sequence."""
     _chk(src, torch.float32, "src"); _chk(dst, torch.float32, "dst")
@@ -313,6 +338,43 @@ def attention_bwd(qkv, out, dout, lse, Bt, T, H, scale, causal):
         profiler.begin("attention_bwd", 10.0 * Bt * H * T * T * 64 * (0.5 if causal else 1.0))
     _lib.check(_lib.lib().ppt_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), Bt, T, H, 64,
                                             scale, int(causal), dtype_code(qkv), _stream()), "ppt_attention_bwd")
+    if profiler is not None:
+        profiler.end()
+    return dqkv
+
+
+def prefix_rows(C, T, P):
+    """rows of the prefix-shared layout (include/ppt_hip.h, ppt_attention_prefix_fwd): P shared + C * (T - P)."""
+    return P + C * (T - P)
+
+
+def attention_prefix_fwd(qkv, C, T, P, H, scale, want_lse=True):
+    """causal attention over C prompts of T positions sharing their first P: qkv [P + C(T-P), 3*H*64] ->
+    (out [rows, H*64], lse [rows, H] f32)."""
+    _chk(qkv, None, "qkv")
+    rows = prefix_rows(C, T, P)
+    assert qkv.shape[0] == rows
+    out = torch.empty((rows, H * 64), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((rows, H), dtype=torch.float32, device=qkv.device) if want_lse else None
+    if profiler is not None:
+        profiler.begin("attention_fwd", 2.0 * (C * (T * T - P * P) + P * P) * H * 64)
+    _lib.check(_lib.lib().ppt_attention_prefix_fwd(_p(qkv), _p(out), _p(lse), C, T, P, H, 64, scale, dtype_code(qkv), _stream()),
+               "ppt_attention_prefix_fwd")
+    if profiler is not None:
+        profiler.end()
+    return out, lse
+
+
+def attention_prefix_bwd(qkv, out, dout, lse, C, T, P, H, scale):
+    _chk(qkv, None, "qkv"); _chk(out, qkv.dtype, "out"); _chk(dout, qkv.dtype, "dout")
+    rows = prefix_rows(C, T, P)
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((rows, H), dtype=torch.float32, device=qkv.device)
+    ws = torch.empty((_lib.lib().ppt_attention_prefix_workspace_bytes(C, P, H, 64) // 4,), dtype=torch.float32, device=qkv.device)
+    if profiler is not None:
+        profiler.begin("attention_bwd", 5.0 * (C * (T * T - P * P) + P * P) * H * 64)
+    _lib.check(_lib.lib().ppt_attention_prefix_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), _p(ws), C, T, P, H, 64,
+                                                   scale, dtype_code(qkv), _stream()), "ppt_attention_prefix_bwd")
     if profiler is not None:
         profiler.end()
     return dqkv

@@ -223,7 +223,7 @@ def synth_tensor(key, shape, seed=0):
         return (0.02 * r.standard_normal(shape)).astype(np.float32)
     if key == "positional_embedding":
         return (0.01 * r.standard_normal(shape)).astype(np.float32)
-    if key == "prompt_learner.embedding":      # default nn.Embedding N(0,1) draws
+    if key == "prompt_learner.embedding" or key.startswith("token_embedding.row."):      # default nn.Embedding N(0,1) draws
         return r.standard_normal(shape).astype(np.float32)
     if key in ("text_projection", "pc_projection"):
         return ((512 ** -0.5) * r.standard_normal(shape)).astype(np.float32)
@@ -258,6 +258,21 @@ def synth_prompt_embedding(num_classes, seed=0, as_torch=True):
         import torch
         a = torch.from_numpy(a)
     return a
+
+
+def synth_prompt_embedding_from_tokens(tokenized_prompts, seed=0, as_torch=True):
+    """The same cache with the structure the reference's really has: ULIP_models.py:102 computes it as
+    token_embedding(tokenized_prompts), so two positions holding the SAME token id hold the same row (N(0,1) draws of a
+    never-initialised nn.Embedding) -- in particular the start token's row is identical in every prompt.  One
+    deterministic row per token id."""
+    ids = np.asarray(tokenized_prompts)
+    out = np.empty(ids.shape + (TXT_WIDTH,), dtype=np.float32)
+    for t in np.unique(ids):
+        out[ids == t] = synth_tensor(f"token_embedding.row.{int(t)}", (TXT_WIDTH,), seed)
+    if as_torch:
+        import torch
+        out = torch.from_numpy(out)
+    return out
 
 
 def synth_clouds(B, N, seed=1234, duplicates=False):

@@ -947,3 +947,55 @@ def test_square_distance_is_bit_exact(ops, B, S, N, dup):
     want = O.square_distance(src, pc)
     assert got.shape == (B, S, N) and np.array_equal(got.cpu().numpy(), want)
     assert np.array_equal(ops.square_distance(dev(src), dev(pc)).cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("C,T,P,H", [(5, 37, 17, 8), (3, 77, 33, 2), (40, 37, 17, 8), (2, 130, 70, 1)])
+def test_attention_prefix_matches_the_unshared_kernels(ops, dtype, tol, C, T, P, H):
+    """ppt_attention_prefix_fwd / _bwd (C prompts sharing their first P positions, stored once) against ppt_attention_fwd /
+    _bwd on the EXPANDED tensors (every prompt carrying its own copy of the prefix): outputs bit-identical; dQ of all rows and
+    dK / dV of the prompts' own rows bit-identical; dK / dV of the shared rows = the sum of the copies' gradients."""
+    g = torch.Generator().manual_seed(C * 100 + T)
+    HD = 64
+    rows = P + C * (T - P)
+    qkv_c = torch.randn(rows, 3 * H * HD, generator=g) * 0.5
+    dout_c = torch.randn(rows, H * HD, generator=g)
+    idx = torch.empty(C, T, dtype=torch.long)                       # compact row of (c, pos)
+    for c in range(C):
+        idx[c, :P] = torch.arange(P)
+        idx[c, P:] = P + c * (T - P) + torch.arange(T - P)
+    qkv_f = qkv_c[idx.reshape(-1)].contiguous()
+    dout_f = dout_c[idx.reshape(-1)].clone()
+    dout_f.view(C, T, -1)[1:, :P] = 0                               # the prefix's outputs are consumed once (from copy 0)
+    scale = HD ** -0.5
+    qc, qf = qkv_c.cuda().to(dtype), qkv_f.cuda().to(dtype)
+    out_c, lse_c = ops.attention_prefix_fwd(qc, C, T, P, H, scale)
+    out_f, lse_f = ops.attention_fwd(qf, C, T, H, scale, True)
+    exp = out_f.view(C, T, -1)
+    assert torch.equal(out_c[:P], exp[0, :P]) and torch.equal(out_c[P:].view(C, T - P, -1), exp[:, P:])
+    dq_c = ops.attention_prefix_bwd(qc, out_c, dout_c.cuda().to(dtype), lse_c, C, T, P, H, scale)
+    dq_f = ops.attention_bwd(qf, out_f, dout_f.cuda().to(dtype), lse_f, C, T, H, scale, True).view(C, T, 3, H * HD)
+    dc = dq_c.view(rows, 3, H * HD)
+    assert torch.equal(dc[P:].view(C, T - P, 3, H * HD), dq_f[:, P:])                       # the prompts' own rows, q / k / v
+    assert torch.equal(dc[:P, 0], dq_f[0, :P, 0])                                            # dQ of the shared rows
+    want = dq_f[:, :P, 1:].float().sum(0)                                                    # dK / dV: summed over the copies
+    got = dc[:P, 1:].float()
+    assert (got - want).abs().max().item() < tol * max(1.0, want.abs().max().item())
+    again = ops.attention_prefix_bwd(qc, out_c, dout_c.cuda().to(dtype), lse_c, C, T, P, H, scale)
+    assert torch.equal(dq_c, again)
+
+
+@pytest.mark.parametrize("B,N,S,qs", [(2, 8192, 512, [(0.1, 16), (0.2, 32), (0.4, 128)]), (3, 512, 128, [(0.2, 32), (0.4, 64), (0.8, 128)]),
+                                       (1, 1000, 77, [(0.05, 8), (0.3, 40)]), (2, 300, 64, [(1e-4, 4), (3.0, 128), (0.2, 16)])])
+def test_ball_query_multi_equals_the_single_queries(ops, B, N, S, qs):
+    """ppt_ball_query_multi_f32 (one pass over the cloud for all radii of a set-abstraction level) == ppt_ball_query_f32 per
+    radius == the oracle: indices and centred coordinates bit for bit, including lists with no hit at all and padded lists."""
+    pc, start = W.synth_clouds(B, N, seed=N + S)
+    ctr = np.take_along_axis(pc, O.fps(pc, S, start)[:, :, None], axis=1)
+    outs = ops.ball_query_multi(dev(pc), dev(ctr), qs, want_grouped=True)
+    for (r, K), (idx, g) in zip(qs, outs):
+        i1, g1 = ops.ball_query(dev(pc), dev(ctr), r, K, want_grouped=True)
+        assert torch.equal(idx, i1) and torch.equal(g, g1), (r, K)
+        assert np.array_equal(idx.cpu().numpy(), O.ball_query(pc, ctr, r, K)), (r, K)
+    plain = ops.ball_query_multi(dev(pc), dev(ctr), qs)
+    assert all(g is None for _, g in plain) and all(torch.equal(a[0], b[0]) for a, b in zip(plain, outs))
