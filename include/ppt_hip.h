@@ -168,6 +168,8 @@ typedef struct ppt_rowgemm_params {
     const float *ln_w;               /* [K] */
     const float *ln_b;               /* [K] */
     float ln_eps;
+    float *ln_mean;                  /* [M] f32 or NULL: the rows' mean ... */
+    float *ln_rstd;                  /* ... and 1 / sqrt(var + eps), saved for ppt_layernorm_bwd (both or neither) */
     const float *bias;               /* [N] or NULL */
     int act;                         /* PPT_ACT_NONE / PPT_ACT_GELU / PPT_ACT_QUICKGELU (residual_form == 0 only) */
     int residual_form;
@@ -180,6 +182,37 @@ typedef struct ppt_rowgemm_params {
 } ppt_rowgemm_params;
 
 int ppt_rowgemm_bf16(const ppt_rowgemm_params *p, void *stream);
+
+/* ---- the MLP half of a frozen PointBERT block as one kernel (csrc/mlp_fused.hip) ---------------------------------------
+ * Replaces nn.LayerNorm + Mlp (fc1, GELU, fc2) + DropPath + the residual add of Block.forward (point_encoder.py:14-30, 69,
+ * 78-79) -- and the next block's "+ pos" (:103) -- for the bf16 mode:
+ *   out[m, :] = x[m, :] + row_scale[m / row_scale_rows] * ( GELU( LN(x[m, :]) W1^T + b1 ) W2^T + b2 ) + residual2[m, :]
+ * x, out [M, 384] f32 (out may be x); W1 / W2: the bf16 weights ([1536, 384] / [384, 1536] row-major) RE-TILED once by
+ * ppt_vit_mlp_retile into the order the kernel's waves consume them ([slab 12][wave 8][fragment 12][lane 64][8 bf16]: every
+ * load of a wave is 1 KB of consecutive bytes; same sizes as the originals); ln_w / ln_b [384], b1 [1536], b2 [384] f32
+ * (biases may be NULL), row_scale / residual2 may be NULL.  The [M, 1536] hidden tensor and the LayerNorm output never
+ * exist in memory.  D must be 384 and hidden 1536 (PPT_EUNSUPPORTED otherwise).  workgroups: 0 = one per CU.
+ * n_chunks / rows_per_chunk are set by the library. */
+typedef struct ppt_vit_mlp_params {
+    const float *x;
+    float *out;
+    const void *W1;
+    const void *W2;
+    const float *ln_w;
+    const float *ln_b;
+    float ln_eps;
+    const float *b1;
+    const float *b2;
+    const float *row_scale;
+    int row_scale_rows;
+    const float *residual2;
+    int M, D, hidden;
+    int workgroups;
+    int n_chunks, rows_per_chunk;
+} ppt_vit_mlp_params;
+
+int ppt_vit_mlp_retile(const void *W1, const void *W2, void *W1_tiled, void *W2_tiled, void *stream);
+int ppt_vit_mlp_bf16(const ppt_vit_mlp_params *p, void *stream);
 
 /* ---- LayerNorm --------------------------------------------------------------------------------
  * Replaces nn.LayerNorm at point_encoder.py:65,69,152 and ULIP_models.py:21-27,39,46,176.
@@ -388,6 +421,20 @@ int ppt_pool_finish(const void *pmax, const void *pmin, int p_dtype, int G, int 
                     const float *shift, void *out, int out_dtype, int64_t ld_out, void *stream);
 int ppt_bn_act_rows(const float *x, int M, int C, const float *scale, const float *shift, const float *mask,
                     void *y, int y_dtype, void *stream);
+/* ---- the prompt side's serial steps as single kernels (csrc/optim.hip) ------------------------------------------------
+ * adamw_step: one torch.optim.AdamW update (main_cls.py:58-60, 198; amsgrad off) of a tensor of n f32 values:
+ *   p *= 1 - lr * weight_decay; exp_avg += (g - exp_avg)(1 - beta1); exp_avg_sq = beta2 exp_avg_sq + (1 - beta2) g^2;
+ *   p -= lr / (1 - beta1^step) * exp_avg / (sqrt(exp_avg_sq) / sqrt(1 - beta2^step) + eps).   step >= 1 (this update's number).
+ * prompt_rows: PromptLearner.forward (ULIP_models.py:104-151) + the positional add of encode_text (:210) in the text tower's
+ *   row layout: out[i] = slot[i] >= 0 ? tokens[slot[i]] + pos_rows[i] : base[i]; base [rows, W] = frozen embedding +
+ *   positional embedding per row (a constant), slot [rows] i32, pos_rows [rows, W].  W % 4 == 0.
+ * prompt_rows_bwd: d_tokens[t] = sum of g[row] over rows_of[t * max_rows + k] (ascending, -1 terminated). */
+int ppt_adamw_step(float *p, const float *g, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int step, void *stream);
+int ppt_prompt_rows(const float *base, const int *slot, const float *tokens, const float *pos_rows, int rows, int W, float *out,
+                    void *stream);
+int ppt_prompt_rows_bwd(const float *g, const int *rows_of, int max_rows, int n_tok, int W, float *d_tokens, void *stream);
+
 /* dtype conversion / transposition helpers (weights are converted once, activations never). */
 int ppt_convert(const void *src, int src_dtype, void *dst, int dst_dtype, int64_t n, void *stream);
 /* src [rows, cols] contiguous -> dst [cols, rows] with row stride ld_dst >= rows (padding untouched) */

@@ -33,6 +33,16 @@ class GemmParams(ctypes.Structure):
     ]
 
 
+class VitMlpParams(ctypes.Structure):
+    """struct ppt_vit_mlp_params (include/ppt_hip.h) -- field order must match the header."""
+    _fields_ = [
+        ("x", c_void_p), ("out", c_void_p), ("W1", c_void_p), ("W2", c_void_p), ("ln_w", c_void_p), ("ln_b", c_void_p),
+        ("ln_eps", c_float), ("b1", c_void_p), ("b2", c_void_p), ("row_scale", c_void_p), ("row_scale_rows", c_int),
+        ("residual2", c_void_p), ("M", c_int), ("D", c_int), ("hidden", c_int), ("workgroups", c_int), ("n_chunks", c_int),
+        ("rows_per_chunk", c_int),
+    ]
+
+
 class BallMulti(ctypes.Structure):
     """struct ppt_ball_multi (include/ppt_hip.h)."""
     _fields_ = [("n", c_int), ("r2", c_float * 3), ("K", c_int * 3), ("idx", c_void_p * 3), ("gxyz", c_void_p * 3)]
@@ -42,7 +52,7 @@ class RowGemmParams(ctypes.Structure):
     """struct ppt_rowgemm_params (include/ppt_hip.h) -- field order must match the header."""
     _fields_ = [
         ("A", c_void_p), ("W", c_void_p), ("C", c_void_p), ("C2", c_void_p), ("M", c_int), ("N", c_int), ("K", c_int),
-        ("a_ln", c_int), ("ln_w", c_void_p), ("ln_b", c_void_p), ("ln_eps", c_float), ("bias", c_void_p), ("act", c_int),
+        ("a_ln", c_int), ("ln_w", c_void_p), ("ln_b", c_void_p), ("ln_eps", c_float), ("ln_mean", c_void_p), ("ln_rstd", c_void_p), ("bias", c_void_p), ("act", c_int),
         ("residual_form", c_int), ("residual", c_void_p), ("residual2", c_void_p), ("row_scale", c_void_p),
         ("row_scale_rows", c_int), ("walkers", c_int), ("groups", c_int),
     ]
@@ -66,6 +76,8 @@ _SIGNATURES = {
     "ppt_scatter_rows_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                      c_void_p]),
     "ppt_sum_groups": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "ppt_vit_mlp_retile": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ppt_vit_mlp_bf16": (c_int, [ctypes.POINTER(VitMlpParams), c_void_p]),
     "ppt_rowgemm_bf16": (c_int, [ctypes.POINTER(RowGemmParams), c_void_p]),
     "ppt_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                   c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
@@ -124,6 +136,10 @@ _SIGNATURES = {
                                 c_void_p]),
     "ppt_linear3_gelu": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "ppt_cls_max_pool": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "ppt_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int,
+                               c_void_p]),
+    "ppt_prompt_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "ppt_prompt_rows_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ppt_convert": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
     "ppt_transpose": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_void_p]),
     "ppt_reduce_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),

@@ -1,0 +1,102 @@
+// optim.hip -- the prompt side's small serial steps as single kernels (every node of the prompt chain costs a dispatch
+// round trip: text forward -> head -> text backward -> optimizer -> next text forward is ~250 dependent tiny kernels, and
+// that chain, not the point tower, is half of what bounds the C2 step -- tools/critical_path.py):
+//   * adamw_step: torch.optim.AdamW's update of one tensor (main_cls.py:58-60, 198) in ONE launch instead of the ~10
+//     multi-tensor kernels of the foreach implementation; the same arithmetic in the same order:
+//       p *= 1 - lr wd;  m += (g - m)(1 - b1);  v = v b2 + (1 - b2) g g;  p -= (lr / bc1) m / (sqrt(v) / sqrt(bc2) + eps);
+//   * prompt_rows: PromptLearner.forward (ULIP_models.py:104-151) + the positional add of encode_text (:210) for the row
+//     layout the text tower runs on: row i = base[i] (the frozen embedding + positional embedding, a constant of the
+//     model) or, where slot[i] >= 0, learnable_tokens[slot[i]] + pos[i];
+//   * prompt_rows_bwd: d learnable_tokens[t] = sum over the rows i with slot[i] == t of g[i], rows taken in ascending order
+//     (owner-computes: deterministic, no atomics) -- the backward of the splice.
+#include "ppt_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void adamw_step_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                         float *__restrict__ v, int64_t n, float decay, float omb1, float b2,
+                                                         float omb2, float inv_sqrt_bc2, float eps, float step_size)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    float pi = p[i] * decay;
+    const float mi = m[i] + (gi - m[i]) * omb1;
+    const float vi = v[i] * b2 + omb2 * gi * gi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    pi = pi - step_size * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+}
+
+__global__ __launch_bounds__(256) void prompt_rows_kernel(const float *__restrict__ base, const int *__restrict__ slot,
+                                                          const float *__restrict__ tokens, const float *__restrict__ pos_rows,
+                                                          int rows, int W, float *__restrict__ out)
+{
+    const int w4 = W >> 2;
+    const int64_t total = (int64_t)rows * w4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int row = (int)(i / w4), c = 4 * (int)(i - (int64_t)row * w4);
+        const int s = slot[row];
+        float4 v;
+        if (s >= 0) {
+            const float4 t = *reinterpret_cast<const float4 *>(tokens + (int64_t)s * W + c);
+            const float4 q = *reinterpret_cast<const float4 *>(pos_rows + (int64_t)row * W + c);
+            v = make_float4(t.x + q.x, t.y + q.y, t.z + q.z, t.w + q.w);
+        } else {
+            v = *reinterpret_cast<const float4 *>(base + (int64_t)row * W + c);
+        }
+        *reinterpret_cast<float4 *>(out + (int64_t)row * W + c) = v;
+    }
+}
+
+// one thread per (token, 4 columns); the token's rows are listed (ascending) in rows_of[token * max_rows ...], -1 terminated
+__global__ __launch_bounds__(256) void prompt_rows_bwd_kernel(const float *__restrict__ g, const int *__restrict__ rows_of, int max_rows,
+                                                              int n_tok, int W, float *__restrict__ d_tokens)
+{
+    const int w4 = W >> 2;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_tok * w4) return;
+    const int t = i / w4, c = 4 * (i - t * w4);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < max_rows; ++k) {
+        const int row = rows_of[t * max_rows + k];
+        if (row < 0) break;
+        const float4 v = *reinterpret_cast<const float4 *>(g + (int64_t)row * W + c);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4 *>(d_tokens + (int64_t)t * W + c) = acc;
+}
+
+}  // namespace
+
+extern "C" int ppt_adamw_step(float *p, const float *g, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, int step, void *stream)
+{
+    if (!p || !g || !exp_avg || !exp_avg_sq || n <= 0 || step <= 0) return PPT_EINVAL;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adamw_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ppt_stream(stream), p, g, exp_avg, exp_avg_sq, n,
+                       (float)(1.0 - (double)lr * weight_decay), 1.0f - beta1, beta2, 1.0f - beta2, (float)(1.0 / sqrt(bc2)), eps,
+                       (float)((double)lr / bc1));
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
+extern "C" int ppt_prompt_rows(const float *base, const int *slot, const float *tokens, const float *pos_rows, int rows, int W,
+                               float *out, void *stream)
+{
+    if (!base || !slot || !tokens || !pos_rows || !out || rows <= 0 || W <= 0 || (W & 3)) return PPT_EINVAL;
+    const int64_t total = (int64_t)rows * (W / 4);
+    hipLaunchKernelGGL(prompt_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ppt_stream(stream), base, slot, tokens,
+                       pos_rows, rows, W, out);
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
+extern "C" int ppt_prompt_rows_bwd(const float *g, const int *rows_of, int max_rows, int n_tok, int W, float *d_tokens, void *stream)
+{
+    if (!g || !rows_of || !d_tokens || max_rows <= 0 || n_tok <= 0 || W <= 0 || (W & 3)) return PPT_EINVAL;
+    hipLaunchKernelGGL(prompt_rows_bwd_kernel, dim3((n_tok * (W / 4) + 255) / 256), dim3(256), 0, ppt_stream(stream), g, rows_of, max_rows,
+                       n_tok, W, d_tokens);
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}

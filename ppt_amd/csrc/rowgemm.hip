@@ -111,7 +111,7 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(const ppt_rowgemm_param
             if constexpr (G::U4 > 3) xb3 = *reinterpret_cast<const uint4 *>(src + 384);
         }
     };
-    auto stage = [&](int buf) {
+    auto stage = [&](int buf, int tile) {
         unsigned char *dst = smem + buf * G::BUF + r * G::PITCH;
         if constexpr (LN) {
             float s = 0.f;
@@ -125,6 +125,10 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(const ppt_rowgemm_param
                 q = fmaf(d0, d0, q); q = fmaf(d1, d1, q); q = fmaf(d2, d2, q); q = fmaf(d3, d3, q);
             }
             const float rstd = 1.0f / sqrtf(row16_sum(q) * (1.0f / (float)K) + p.ln_eps);
+            if (p.ln_mean && group == 0 && j == 0 && tile * 32 + r < p.M) {     // the statistics the LayerNorm backward needs
+                p.ln_mean[tile * 32 + r] = mean;
+                p.ln_rstd[tile * 32 + r] = rstd;
+            }
 #pragma unroll
             for (int i = 0; i < G::F4; ++i) {
                 const int c = 4 * (j + 16 * i);
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(const ppt_rowgemm_param
     };
 
     __syncthreads();                                                     // gamma / beta / bias are in LDS
-    stage(0);
+    stage(0, t);
     load(min(t + n_walk, n_tiles - 1));
     load_res(t);
     __syncthreads();
@@ -288,13 +292,13 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(const ppt_rowgemm_param
             mfma_phase(cur);
             __builtin_amdgcn_sched_barrier(0);
             RG_STAMP(1);
-            stage(cur ^ 1);                                              // (that buffer was last read in iteration it - 1, before its barrier)
+            stage(cur ^ 1, min(t + n_walk, n_tiles - 1));                // (that buffer was last read in iteration it - 1, before its barrier)
             __builtin_amdgcn_sched_barrier(0);
             RG_STAMP(2);
             load(min(t + 2 * n_walk, n_tiles - 1));                      // unconditional (a branch parks the registers in scratch)
             __builtin_amdgcn_sched_barrier(0);
         } else {
-            stage(cur ^ 1);
+            stage(cur ^ 1, min(t + n_walk, n_tiles - 1));
             __builtin_amdgcn_sched_barrier(0);
             RG_STAMP(1);
             load(min(t + 2 * n_walk, n_tiles - 1));
@@ -350,6 +354,7 @@ extern "C" int ppt_rowgemm_bf16(const ppt_rowgemm_params *pp, void *stream)
     if (p.K != 384 && p.K != 512) return PPT_EUNSUPPORTED;
     if (p.N % (p.residual_form ? 4 : 8)) return PPT_EUNSUPPORTED;
     if (p.a_ln && (!p.ln_w || !p.ln_b)) return PPT_EINVAL;
+    if ((p.ln_mean == nullptr) != (p.ln_rstd == nullptr)) return PPT_EINVAL;
     if (p.residual_form && !p.residual) return PPT_EINVAL;
     if (p.residual_form && p.a_ln) return PPT_EUNSUPPORTED;          /* (no caller: a LayerNorm is never followed by a residual-form linear) */
     if (p.residual_form && (p.act != PPT_ACT_NONE || p.C2)) return PPT_EUNSUPPORTED;

@@ -76,6 +76,7 @@ FUSED_CONV12 = os.environ.get("PPT_FUSED_CONV12", "1") != "0"      # 0: the gene
 # workgroups take a whole CU each (8 waves x 256 VGPRs), and with only 7 row tiles per workgroup to amortise the weight
 # preload the small win is paid back by the text tower's kernels, which can no longer share those CUs.  PPT_ROWGEMM=0 / 1
 # forces it off / on.
+FUSED_MLP = os.environ.get("PPT_FUSED_MLP", "1") != "0"             # LayerNorm + fc1 + GELU + fc2 + residual of a frozen block: one kernel
 _RG = os.environ.get("PPT_ROWGEMM", "")
 ROWGEMM_MIN_ROWS = 1 << 30 if _RG == "0" else (0 if _RG == "1" else 24000)
 
@@ -156,6 +157,12 @@ def mini_pointnet(sd, p, wc, nbhd, bn_train, update_running=True):
     return tok
 
 
+def _mlp_weights(sd, p, wc):
+    """fc1 / fc2 of block `p` in the fragment order of csrc/mlp_fused.hip (re-made when a weight's version changes)."""
+    w1, w2 = sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc2.weight"]
+    return wc.derived(("vit_mlp_tiled", p), (w1, w2), lambda: ops.vit_mlp_retile(wc.get(w1), wc.get(w2)))
+
+
 def vit_block_forward(sd, p, wc, x, pos, B, Tn, heads, dp1, dp2, save=None, pos_in_x=False, add_pos_out=False):
     """Block.forward on block(x + pos) (point_encoder.py:76-79,103).  x [B*Tn, D] fp32 is updated in
     place unless `save` (a dict) is given: then every intermediate the backward needs is kept.
@@ -174,6 +181,12 @@ def vit_block_forward(sd, p, wc, x, pos, B, Tn, heads, dp1, dp2, save=None, pos_
         a, _ = ops.attention_fwd(qkv, B, Tn, heads, ATTN_SCALE, False, want_lse=False)
         ops.rowgemm(a, wc.get(sd[p + "attn.proj.weight"]), bias=sd[p + "attn.proj.bias"], residual=x, out=x, row_scale=dp1,
                     row_scale_rows=Tn)
+        if FUSED_MLP and sd[p + "mlp.fc1.weight"].shape[0] == 1536:
+            w1t, w2t = _mlp_weights(sd, p, wc)
+            ops.vit_mlp(x, w1t, sd[p + "mlp.fc1.bias"], w2t, sd[p + "mlp.fc2.bias"],
+                        (sd[p + "norm2.weight"], sd[p + "norm2.bias"]), row_scale=dp2, row_scale_rows=Tn,
+                        residual2=pos if add_pos_out else None)
+            return x
         f = ops.rowgemm(x, wc.get(sd[p + "mlp.fc1.weight"]), ln=(sd[p + "norm2.weight"], sd[p + "norm2.bias"]),
                         bias=sd[p + "mlp.fc1.bias"], act=ACT_GELU)
         ops.gemm(f, wc.get(sd[p + "mlp.fc2.weight"]), out=x, bias=sd[p + "mlp.fc2.bias"], row_scale=dp2, row_scale_rows=Tn,
@@ -193,6 +206,13 @@ def vit_block_forward(sd, p, wc, x, pos, B, Tn, heads, dp1, dp2, save=None, pos_
     x_mid = torch.empty_like(x) if keep else xs
     ops.gemm(a, wc.get(sd[p + "attn.proj.weight"]), out=x_mid, bias=sd[p + "attn.proj.bias"], row_scale=dp1,
              row_scale_rows=Tn, residual=xs)
+    if (FUSED_MLP and not keep and T == torch.bfloat16 and x.shape[1] == 384 and sd[p + "mlp.fc1.weight"].shape[0] == 1536
+            and x_mid.is_contiguous()):
+        # frozen block: LayerNorm + fc1 + GELU + fc2 + DropPath + residual (+ the next block's "+ pos") in one kernel
+        w1t, w2t = _mlp_weights(sd, p, wc)
+        return ops.vit_mlp(x_mid, w1t, sd[p + "mlp.fc1.bias"], w2t, sd[p + "mlp.fc2.bias"],
+                           (sd[p + "norm2.weight"], sd[p + "norm2.bias"]), row_scale=dp2, row_scale_rows=Tn,
+                           residual2=pos if add_pos_out else None)
     h2, mean2, rstd2 = ops.layernorm_fwd(x_mid, sd[p + "norm2.weight"], sd[p + "norm2.bias"], T, save_stats=keep)
     pre = torch.empty((x.shape[0], sd[p + "mlp.fc1.weight"].shape[0]), dtype=T, device=x.device) if keep else None
     f = ops.gemm(h2, wc.get(sd[p + "mlp.fc1.weight"]), out_dtype=T, bias=sd[p + "mlp.fc1.bias"], act=ACT_GELU,
@@ -663,7 +683,10 @@ def pointmlp_forward(sd, p, wc, pc, fps_starts, train, drop_masks, update_runnin
 # =================================================================================================
 # text branch (CLIP text transformer, ULIP_models.py:35-67, 203-222)
 # =================================================================================================
-def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=None, prefix=0):
+TEXT_FUSE_LN = os.environ.get("PPT_TEXT_FUSE_LN", "1") != "0"       # LayerNorm -> in_proj / c_fc as ONE kernel (csrc/rowgemm.hip)
+
+
+def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=None, prefix=0, rows_in=None):
     """encode_text: prompts [C,L,W] fp32 -> text features [C,E] fp32 (before L2 normalisation).
     save=True keeps what the input-gradient backward needs.
 
@@ -678,13 +701,26 @@ def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=No
     runs on P + C (L - P) rows instead of C L (817 instead of 1 480 for ModelNet40: every LayerNorm / linear of the tower does
     45 % less work), with ppt_attention_prefix_fwd reading the shared rows as every prompt's first P keys.  The forward is
     bit-identical to the unshared evaluation; in the backward the prompts' contributions to the shared rows are summed layer by
-    layer instead of at the very end (same sum, another order)."""
+    layer instead of at the very end (same sum, another order).
+
+    rows_in = (x0 [M, W] f32, C, Lfull): the first layer's input ALREADY in the tower's row layout with the positional
+    embedding added (ops.prompt_rows builds it from the learnable tokens in one kernel); `prompts` is then None and the
+    backward hands back the gradient of x0 as it is."""
     T = wc.dtype
-    C, Lfull, Wd = prompts.shape
+    if rows_in is not None:
+        x0, C, Lfull = rows_in
+        Wd = x0.shape[1]
+    else:
+        C, Lfull, Wd = prompts.shape
     L = Lfull if eff_len is None else min(Lfull, int(eff_len))
     P = int(prefix) if (prefix and 0 < int(prefix) < L and C > 1) else 0
-    dev = prompts.device
-    if P:
+    dev = x0.device if rows_in is not None else prompts.device
+    if rows_in is not None:
+        M = ops.prefix_rows(C, L, P) if P else C * L
+        assert x0.shape[0] == M
+        xin, add, add_rows = x0, None, 0
+        rows = (P + torch.arange(C, device=dev) * (L - P) + (eot_pos - P)) if P else (torch.arange(C, device=dev) * L + eot_pos)
+    elif P:
         M = ops.prefix_rows(C, L, P)
         xin = torch.cat([prompts[0, :P], prompts[:, P:L].reshape(C * (L - P), Wd)], dim=0)
         add = wc.derived(("text_pos_prefix", C, L, P), (sd["positional_embedding"],),
@@ -699,24 +735,42 @@ def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=No
         xin = prompts.reshape(M, Wd)
         rows = torch.arange(C, device=dev) * L + eot_pos            # EOT pooling (ULIP_models.py:222)
     saved = {"layers": []} if save else None
-    x = torch.empty((M, Wd), dtype=torch.float32, device=dev)
+    x = xin if add is None else torch.empty((M, Wd), dtype=torch.float32, device=dev)
+    fuse = TEXT_FUSE_LN and T == torch.bfloat16 and Wd in ops.ROWGEMM_K
+
+    def stats():
+        return (torch.empty((M,), dtype=torch.float32, device=dev), torch.empty((M,), dtype=torch.float32, device=dev)) if save else None
     for i in range(layers):
         p = f"transformer.resblocks.{i}."
-        h, mean1, rstd1 = ops.layernorm_fwd(xin, sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], T, add=add,
-                                            add_rows=add_rows, write_xs=x if add is not None else None,
-                                            save_stats=save)
+        if fuse and add is None:
+            # LayerNorm applied while the rows are staged (one node of the prompt chain instead of two); its statistics are
+            # kept for the backward
+            st1 = stats()
+            mean1, rstd1 = st1 if save else (None, None)
+            qkv = ops.rowgemm(xin, wc.get(sd[p + "attn.in_proj_weight"]), ln=(sd[p + "ln_1.weight"], sd[p + "ln_1.bias"]), ln_stats=st1,
+                              bias=sd[p + "attn.in_proj_bias"])
+        else:
+            h, mean1, rstd1 = ops.layernorm_fwd(xin, sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], T, add=add,
+                                                add_rows=add_rows, write_xs=x if add is not None else None,
+                                                save_stats=save)
+            qkv = ops.gemm(h, wc.get(sd[p + "attn.in_proj_weight"]), out_dtype=T, bias=sd[p + "attn.in_proj_bias"])
         add, add_rows = None, 0
-        qkv = ops.gemm(h, wc.get(sd[p + "attn.in_proj_weight"]), out_dtype=T, bias=sd[p + "attn.in_proj_bias"])
         if P:
             a, lse = ops.attention_prefix_fwd(qkv, C, L, P, heads, ATTN_SCALE, want_lse=save)
         else:
             a, lse = ops.attention_fwd(qkv, C, L, heads, ATTN_SCALE, True, want_lse=save)
         x_mid = torch.empty_like(x)
         ops.gemm(a, wc.get(sd[p + "attn.out_proj.weight"]), out=x_mid, bias=sd[p + "attn.out_proj.bias"], residual=x)
-        h2, mean2, rstd2 = ops.layernorm_fwd(x_mid, sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], T, save_stats=save)
         pre = torch.empty((M, sd[p + "mlp.c_fc.weight"].shape[0]), dtype=T, device=dev) if save else None
-        f = ops.gemm(h2, wc.get(sd[p + "mlp.c_fc.weight"]), out_dtype=T, bias=sd[p + "mlp.c_fc.bias"],
-                     act=ACT_QUICKGELU, out2=pre, out2_pre=True)
+        if fuse:
+            st2 = stats()
+            mean2, rstd2 = st2 if save else (None, None)
+            f = ops.rowgemm(x_mid, wc.get(sd[p + "mlp.c_fc.weight"]), ln=(sd[p + "ln_2.weight"], sd[p + "ln_2.bias"]), ln_stats=st2,
+                            bias=sd[p + "mlp.c_fc.bias"], act=ACT_QUICKGELU, out2=pre)
+        else:
+            h2, mean2, rstd2 = ops.layernorm_fwd(x_mid, sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], T, save_stats=save)
+            f = ops.gemm(h2, wc.get(sd[p + "mlp.c_fc.weight"]), out_dtype=T, bias=sd[p + "mlp.c_fc.bias"],
+                         act=ACT_QUICKGELU, out2=pre, out2_pre=True)
         x_next = torch.empty_like(x)
         ops.gemm(f, wc.get(sd[p + "mlp.c_proj.weight"]), out=x_next, bias=sd[p + "mlp.c_proj.bias"], residual=x_mid)
         if save:
@@ -730,7 +784,8 @@ def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=No
     wc32 = _f32_cache(wc)
     out = ops.gemm(hn, wc32.get(sd["text_projection"], "wt"), out_dtype=torch.float32)
     if save:
-        saved.update(x_eot=x_eot, meanf=meanf, rstdf=rstdf, rows=rows, C=C, L=L, Lfull=Lfull, W=Wd, heads=heads, P=P, M=M)
+        saved.update(x_eot=x_eot, meanf=meanf, rstdf=rstdf, rows=rows, C=C, L=L, Lfull=Lfull, W=Wd, heads=heads, P=P, M=M,
+                     rows_mode=rows_in is not None)
     return out, saved
 
 
@@ -775,6 +830,8 @@ def text_tower_backward(sd, wc, s, dout):
         d_h = ops.gemm(d_qkv, wc.get(sd[p + "attn.in_proj_weight"], "wt"), out_dtype=torch.float32)
         _, _, _, g_t = ops.layernorm_bwd(d_h, ly["x"], sd[p + "ln_1.weight"], ly["mean1"], ly["rstd1"], dx=g,
                                          accumulate=True, copy_dtype=T)
+    if s["rows_mode"]:
+        return g                                            # gradient of the row-layout input (ops.prompt_rows_bwd folds it)
     if not P and L == s["Lfull"]:
         return g.view(C, L, Wd)
     full = torch.zeros((C, s["Lfull"], Wd), dtype=torch.float32, device=dout.device)   # positions past the last EOT: zero gradient

@@ -215,6 +215,41 @@ class PromptLearner(nn.Module):
     def eot_positions(self):
         return self.tokenized_prompts.argmax(dim=-1)
 
+    def row_layout(self, positional, L, P):
+        """Constants of the text tower's input in its row layout (engine.text_tower_forward: P shared rows + C (L - P) own
+        rows, or C L rows when P == 0) for ops.prompt_rows / prompt_rows_bwd:
+        base [M, W] = frozen embedding + positional embedding per row, slot [M] i32 = index of the learnable token that
+        overwrites the row (-1: none), pos_rows [M, W] = positional embedding per row, rows_of [n_tok, C] i32 = the rows each
+        learnable token appears in (ascending, -1 padded).  Cached per (embedding, positional embedding, L, P)."""
+        emb = self.embedding
+        key = (emb.data_ptr(), emb._version, positional.data_ptr(), positional._version, L, P, self.class_name_position)
+        if getattr(self, "_layout_cache", (None,))[0] != key:
+            dev = self.learnable_tokens.device
+            cls, pos, src = self._scatter_index(torch.device("cpu"))
+            C, n = pos.shape
+            tok_of = torch.full((C, CONTEXT_LENGTH), -1, dtype=torch.int32)
+            tok_of[cls, pos] = torch.arange(n, dtype=torch.int32).view(1, n).expand(C, n)
+            rows = []                                    # (class, position) of every row
+            if P:
+                rows += [(0, q) for q in range(P)]
+                rows += [(c, q) for c in range(C) for q in range(P, L)]
+            else:
+                rows += [(c, q) for c in range(C) for q in range(L)]
+            rc = torch.tensor([r[0] for r in rows]), torch.tensor([r[1] for r in rows])
+            slot = tok_of[rc[0], rc[1]].contiguous()
+            with torch.no_grad():
+                frozen = emb.detach().to("cpu").float()
+                base = frozen[rc[0], src[rc[0], rc[1]]] + positional.detach().to("cpu").float()[rc[1]]
+                pos_rows = positional.detach().to("cpu").float()[rc[1]].contiguous()
+            rows_of = torch.full((n, C), -1, dtype=torch.int32)
+            fill = [0] * n
+            for i, t in enumerate(slot.tolist()):
+                if t >= 0:
+                    rows_of[t, fill[t]] = i
+                    fill[t] += 1
+            self._layout_cache = (key, (base.contiguous().to(dev), slot.to(dev), pos_rows.to(dev), rows_of.to(dev), len(rows)))
+        return self._layout_cache[1]
+
     def shared_prefix(self):
         """Number of leading positions whose prompt rows are the same for EVERY class: the start token (one token id, hence
         one embedding row: ULIP_models.py:102 looks the prompts up in token_embedding) followed by the learnable context tokens
@@ -287,6 +322,77 @@ class _TextTowerFn(torch.autograd.Function):
             return graphs.GraphedCall(fn, [dout.contiguous()], pool=fwd.pool())
         (dp,), _ = m._graphs.get(("text_bwd",) + ctx.key[1:], build)(dout)
         return None, dp.clone()
+
+
+class _TextTowerTokensFn(torch.autograd.Function):
+    """text features as a function of PromptLearner.learnable_tokens directly: the splice (ULIP_models.py:104-151), the
+    positional add (:210) and the row layout of the tower in ONE kernel (ppt_prompt_rows) instead of gather + index_put +
+    cat + the add; the backward folds the tower's input gradient onto the tokens in one kernel (ppt_prompt_rows_bwd)
+    instead of zeros + slice copies + index_put's backward.  Same graphs / saved activations as _TextTowerFn."""
+
+    @staticmethod
+    def forward(ctx, model, tokens):
+        sd, cache = model._live_state(), model._cache()
+        save = bool(ctx.needs_input_grad[1])
+        pl = model.prompt_learner
+        eot = model._eot(tokens.device)
+        heads, layers = model.transformer.heads, model.transformer.layers
+        C, Lfull = len(pl.classnames), model.context_length
+        eff = model._text_len() if model.truncate_text_to_eot else Lfull
+        pre = pl.shared_prefix() if model.share_text_prefix else 0
+        if not (0 < pre < eff and C > 1):
+            pre = 0
+        base, slot, pos_rows, rows_of, M = pl.row_layout(sd["positional_embedding"], eff, pre)
+        tok = tokens.detach().float().contiguous()
+
+        def run(tk):
+            x0 = ops.prompt_rows(base, slot, tk, pos_rows)
+            return engine.text_tower_forward(sd, cache, None, eot, heads, layers, save, eff_len=eff, prefix=pre, rows_in=(x0, C, Lfull))
+
+        key = ("text_fwd_tok", tuple(tok.shape), save, eff, pre, cache.dtype)
+        gc = model._graphs
+        ctx.model, ctx.graph, ctx.rows_of, ctx.n_tok = model, None, rows_of, tok.shape[0]
+        if tok.is_cuda and model.use_hip_graphs and ops.profiler is None and gc.ready(key):
+            def build():
+                def fn(tk):
+                    out, saved = run(tk)
+                    return (out,), saved
+                return graphs.GraphedCall(fn, [tok])
+            g = gc.get(key, build)
+            (out,), saved = g(tok)
+            g.generation = getattr(g, "generation", 0) + 1
+            ctx.graph, ctx.key, ctx.generation = g, key, g.generation
+            out = out.clone()
+        else:
+            out, saved = run(tok)
+        ctx.saved = saved
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        m = ctx.model
+        sd, cache = m._live_state(), m._cache()
+        dout = dout.float()
+        if dout.is_cuda:
+            dout.record_stream(torch.cuda.current_stream())
+        rows_of, n_tok = ctx.rows_of, ctx.n_tok
+
+        def run(d, saved):
+            return ops.prompt_rows_bwd(engine.text_tower_backward(sd, cache, saved, d), rows_of, n_tok)
+
+        if ctx.graph is None:
+            return None, run(dout.contiguous(), ctx.saved)
+        if ctx.graph.generation != ctx.generation:
+            raise RuntimeError("the text tower's captured activations were overwritten by a later forward; set "
+                               "model.use_hip_graphs = False to keep several forwards alive before backward")
+        saved, fwd = ctx.saved, ctx.graph
+
+        def build():
+            def fn(d):
+                return (run(d, saved),), None
+            return graphs.GraphedCall(fn, [dout.contiguous()], pool=fwd.pool())
+        (dt,), _ = m._graphs.get(("text_bwd_tok",) + ctx.key[1:], build)(dout)
+        return None, dt.clone()
 
 
 class _MatmulNT(torch.autograd.Function):
@@ -388,6 +494,7 @@ class ULIP_WITH_IMAGE(nn.Module):
         self.use_hip_graphs = True          # replay the text tower from captured hipGraphs after two eager calls
         self.overlap_text_tower = True      # run the (input-independent) text tower on a side stream
         self.truncate_text_to_eot = True    # causal mask + EOT pooling: positions after the last EOT are dead work
+        self.fused_prompt_rows = os.environ.get("PPT_FUSED_PROMPT_ROWS", "1") != "0"     # PromptLearner splice + pos add: one kernel
         # positions in front of the class name are the same in every prompt: computed once (PPT_SHARE_TEXT_PREFIX=0: A/B runs)
         self.share_text_prefix = os.environ.get("PPT_SHARE_TEXT_PREFIX", "1") != "0"
 
@@ -499,6 +606,13 @@ class ULIP_WITH_IMAGE(nn.Module):
         lead = pc_feat.shape[:-1]
         return matmul_nt(pc_feat.reshape(-1, pc_feat.shape[-1]), wt, self._head_precision()).view(*lead, -1)
 
+    def _text_raw(self):
+        """encode_text(prompt_learner()) -- through the one-kernel prompt assembly (_TextTowerTokensFn) on a GPU."""
+        tok = self.prompt_learner.learnable_tokens
+        if self.fused_prompt_rows and tok.is_cuda and self.prompt_learner.class_name_position in ("front", "middle", "end"):
+            return _TextTowerTokensFn.apply(self, tok)
+        return self.encode_text(self.prompt_learner(), self.tokenized_prompts)
+
     def _text_embed(self):
         # inference fast path (SURVEY.md §8(f) N1): the text features depend only on the prompt tokens, so
         # validate() (main_cls.py:237-299) needs them once per epoch, not once per batch
@@ -506,8 +620,7 @@ class ULIP_WITH_IMAGE(nn.Module):
         if not torch.is_grad_enabled() and self._te_cache is not None and self._te_cache[0] == (tok._version, tok.data_ptr(),
                                                                                                self.precision):
             return self._te_cache[1]
-        prompts = self.prompt_learner()
-        text_embed = self.encode_text(prompts, self.tokenized_prompts)
+        text_embed = self._text_raw()
         text_embed = text_embed / text_embed.norm(dim=-1, keepdim=True)
         if not torch.is_grad_enabled():
             self._te_cache = ((tok._version, tok.data_ptr(), self.precision), text_embed)
@@ -549,7 +662,7 @@ class ULIP_WITH_IMAGE(nn.Module):
         if side is not None:
             side.wait_stream(cur)
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-            text_raw = self.encode_text(self.prompt_learner(), self.tokenized_prompts)
+            text_raw = self._text_raw()
         pc_feat = self.point_encoder(pc)
         if side is not None:
             cur.wait_stream(side)

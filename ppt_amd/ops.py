@@ -12,6 +12,7 @@ import torch
 from . import _lib
 from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, A_AFFINE_RELU, A_CONV1, A_PLAIN,
                    PPT_BF16, PPT_F32, GemmParams, RowGemmParams)
+from . import _lib as _libmod  # noqa: F401
 
 _DT = {torch.float32: PPT_F32, torch.bfloat16: PPT_BF16}
 _TORCH_DT = {PPT_F32: torch.float32, PPT_BF16: torch.bfloat16}
@@ -233,10 +234,37 @@ def gemm(A, B, *, out=None, out_dtype=None, M=None, bias=None, act=ACT_NONE, dac
     return out
 
 
+def vit_mlp_retile(w1, w2):
+    """(w1 [1536,384], w2 [384,1536]) bf16 -> the fragment-ordered copies ppt_vit_mlp_bf16 reads (ppt_vit_mlp_retile)."""
+    _chk(w1, torch.bfloat16, "w1"); _chk(w2, torch.bfloat16, "w2")
+    assert tuple(w1.shape) == (1536, 384) and tuple(w2.shape) == (384, 1536)
+    w1t, w2t = torch.empty_like(w1), torch.empty_like(w2)
+    _lib.check(_lib.lib().ppt_vit_mlp_retile(_p(w1), _p(w2), _p(w1t), _p(w2t), _stream()), "ppt_vit_mlp_retile")
+    return w1t, w2t
+
+
+def vit_mlp(x, w1, b1, w2, b2, ln, *, out=None, ln_eps=1e-5, row_scale=None, row_scale_rows=0, residual2=None, workgroups=0):
+    """ppt_vit_mlp_bf16 (csrc/mlp_fused.hip): out = x + row_scale * (GELU(LN(x) w1^T + b1) w2^T + b2) (+ residual2), x [M,384]
+    f32, w1 / w2: the fragment-ordered bf16 weights of vit_mlp_retile; out defaults to x (in place)."""
+    _chk(x, torch.float32, "x"); _chk(w1, torch.bfloat16, "w1"); _chk(w2, torch.bfloat16, "w2")
+    M, D = x.shape
+    out = x if out is None else out
+    p = _lib.VitMlpParams()
+    p.x, p.out, p.W1, p.W2, p.ln_w, p.ln_b, p.ln_eps = _p(x), _p(out), _p(w1), _p(w2), _p(ln[0]), _p(ln[1]), ln_eps
+    p.b1, p.b2, p.row_scale, p.row_scale_rows, p.residual2 = _p(b1), _p(b2), _p(row_scale), row_scale_rows, _p(residual2)
+    p.M, p.D, p.hidden, p.workgroups = M, D, w1.shape[0], workgroups
+    if profiler is not None:
+        profiler.begin("gemm_bf16", 4.0 * M * D * w1.shape[0], "ppt_vit_mlp_bf16 (LN + fc1 + GELU + fc2 + residual)")
+    _lib.check(_lib.lib().ppt_vit_mlp_bf16(ctypes.byref(p), _stream()), "ppt_vit_mlp_bf16")
+    if profiler is not None:
+        profiler.end()
+    return out
+
+
 ROWGEMM_K = (384, 512)
 
 
-def rowgemm(A, W, *, ln=None, ln_eps=1e-5, bias=None, act=ACT_NONE, out=None, out2=None, residual=None, residual2=None,
+def rowgemm(A, W, *, ln=None, ln_eps=1e-5, ln_stats=None, bias=None, act=ACT_NONE, out=None, out2=None, residual=None, residual2=None,
             row_scale=None, row_scale_rows=0, walkers=0):
     """ppt_rowgemm_bf16 (csrc/rowgemm.hip): C = epilogue(prologue(A) @ W^T) with W [N,K] bf16 held in registers.
     A: bf16 [M,K], or -- with ln = (gamma, beta) -- the f32 residual stream, LayerNorm applied while the rows are staged.
@@ -250,6 +278,8 @@ def rowgemm(A, W, *, ln=None, ln_eps=1e-5, bias=None, act=ACT_NONE, out=None, ou
     p.A, p.W, p.M, p.N, p.K = _p(A), _p(W), M, N, K
     if ln is not None:
         p.a_ln, p.ln_w, p.ln_b, p.ln_eps = 1, _p(ln[0]), _p(ln[1]), ln_eps
+        if ln_stats is not None:                     # (mean [M], rstd [M]) f32: what ppt_layernorm_bwd needs
+            p.ln_mean, p.ln_rstd = _p(ln_stats[0]), _p(ln_stats[1])
     p.bias, p.act = _p(bias), act
     if residual is not None:
         assert residual.dtype == torch.float32 and residual.is_contiguous() and residual.shape == (M, N)
@@ -790,3 +820,30 @@ def gemm_tn_splitk(x_a, x_b, min_blocks=768, max_splits=16):
     part = torch.empty((S * N1, N2), dtype=torch.float32, device=x_a.device)
     gemm(at[:, :Mc], bt[:, :Mc], out=part, batch=S, strideA=Mc, strideB=Mc, strideC=N1 * N2)
     return reduce_rows(part.view(S, N1 * N2)).view(N1, N2)
+
+
+def adamw_step(p, g, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step):
+    """torch.optim.AdamW's update of ONE tensor in one launch (ppt_adamw_step); p, exp_avg, exp_avg_sq updated in place."""
+    for t, nm in ((p, "p"), (g, "g"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        _chk(t, torch.float32, nm)
+    _lib.check(_lib.lib().ppt_adamw_step(_p(p), _p(g), _p(exp_avg), _p(exp_avg_sq), p.numel(), lr, beta1, beta2, eps, weight_decay,
+                                         int(step), _stream()), "ppt_adamw_step")
+
+
+def prompt_rows(base, slot, tokens, pos_rows):
+    """out[i] = tokens[slot[i]] + pos_rows[i] where slot[i] >= 0, else base[i] (ppt_prompt_rows)."""
+    _chk(base, torch.float32, "base"); _chk(slot, torch.int32, "slot"); _chk(tokens, torch.float32, "tokens")
+    _chk(pos_rows, torch.float32, "pos_rows")
+    rows, W = base.shape
+    out = torch.empty_like(base)
+    _lib.check(_lib.lib().ppt_prompt_rows(_p(base), _p(slot), _p(tokens), _p(pos_rows), rows, W, _p(out), _stream()), "ppt_prompt_rows")
+    return out
+
+
+def prompt_rows_bwd(g, rows_of, n_tok):
+    """d tokens [n_tok, W] = sums of the rows of g listed per token in rows_of [n_tok, max_rows] i32 (-1 terminated)."""
+    _chk(g, torch.float32, "g"); _chk(rows_of, torch.int32, "rows_of")
+    W = g.shape[1]
+    out = torch.empty((n_tok, W), dtype=torch.float32, device=g.device)
+    _lib.check(_lib.lib().ppt_prompt_rows_bwd(_p(g), _p(rows_of), rows_of.shape[1], n_tok, W, _p(out), _stream()), "ppt_prompt_rows_bwd")
+    return out

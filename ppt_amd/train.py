@@ -95,6 +95,15 @@ class Trainer:
         # re-indexes the state dict to the reference's layout for checkpoints.
         self.optimizer = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=lr, betas=betas,
                                            eps=eps, weight_decay=wd, capturable=capturable)
+        # One launch per trained tensor (ppt_adamw_step: torch.optim.AdamW's arithmetic; csrc/optim.hip) instead of the ~10
+        # multi-tensor kernels of the foreach implementation, while few tensors train: every kernel of the prompt chain costs a
+        # dispatch round trip.  The torch optimizer object stays the owner of hyper-parameters and state (state_dict()).
+        self.fused_adamw = True
+        # logit_scale is frozen in every PPT configuration (ULIP_models.py:487-507) and its value lies inside the clamp range:
+        # main_cls.py:213's per-step clamp is then idempotent -- applied once here, and per step only if it ever trains
+        if hasattr(model, "logit_scale"):
+            with torch.no_grad():
+                model.logit_scale.data.clamp_(0, 4.6052)
         self.lr_schedule = lr_schedule
         self.it = 0
         self.extra_inputs = ()        # e.g. the one-hot shape category of main_partseg.py:210
@@ -186,8 +195,9 @@ class Trainer:
             loss.backward()                                         # (retain_graph only served Q2)
             if self.distributed:
                 self.sync.all_reduce()
-            self.optimizer.step()
-            model.logit_scale.data.clamp_(0, 4.6052)                # main_cls.py:213
+            self._optimizer_step()
+            if model.logit_scale.requires_grad:
+                model.logit_scale.data.clamp_(0, 4.6052)            # main_cls.py:213 (frozen: clamped once in __init__)
         if side is not None and not self._point_side_frozen:
             pe = getattr(model, "point_encoder", None)
             if self._gated and getattr(pe, "param_gate", False) is None:
@@ -200,6 +210,27 @@ class Trainer:
             raise FloatingPointError(f"Loss is {loss.item()}, stopping training")
         self.it += 1
         return loss, pred
+
+    def _optimizer_step(self):
+        opt = self.optimizer
+        params = [(g, p) for g in opt.param_groups for p in g['params'] if p.grad is not None]
+        if not (self.fused_adamw and params and len(params) <= 8 and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
+                                                                        and p.grad.is_contiguous() for _, p in params)
+                and not any(g.get('amsgrad') or g.get('maximize') for g, _ in params)):
+            opt.step()
+            return
+        from . import ops
+        with torch.no_grad():
+            for g, p in params:
+                st = opt.state[p]
+                if not st:                                   # the layout torch.optim.AdamW._init_group creates
+                    st['step'] = torch.tensor(0.0, dtype=torch.float32)
+                    st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st['step'] += 1
+                b1, b2 = g['betas']
+                ops.adamw_step(p.data, p.grad, st['exp_avg'], st['exp_avg_sq'], float(g['lr']), float(b1), float(b2), float(g['eps']),
+                               float(g['weight_decay']), int(st['step'].item()))
 
     def _drain_gate(self):
         pe = getattr(self.model, "point_encoder", None)

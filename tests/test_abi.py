@@ -49,6 +49,7 @@ def test_gemm_params_struct_matches_header_order():
     from ppt_amd import _lib
     assert _struct_fields("ppt_gemm_params") == [f[0] for f in _lib.GemmParams._fields_]
     assert _struct_fields("ppt_rowgemm_params") == [f[0] for f in _lib.RowGemmParams._fields_]
+    assert _struct_fields("ppt_vit_mlp_params") == [f[0] for f in _lib.VitMlpParams._fields_]
 
 
 def test_arg_validation_without_gpu():

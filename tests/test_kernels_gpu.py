@@ -999,3 +999,87 @@ def test_ball_query_multi_equals_the_single_queries(ops, B, N, S, qs):
         assert np.array_equal(idx.cpu().numpy(), O.ball_query(pc, ctr, r, K)), (r, K)
     plain = ops.ball_query_multi(dev(pc), dev(ctr), qs)
     assert all(g is None for _, g in plain) and all(torch.equal(a[0], b[0]) for a, b in zip(plain, outs))
+
+
+def test_adamw_step_matches_torch(ops):
+    """ppt_adamw_step against torch.optim.AdamW (main_cls.py:58-60 hyper-parameters) over several steps with a changing lr."""
+    g = torch.Generator().manual_seed(0)
+    p0 = torch.randn(32, 512, generator=g) * 0.02
+    p_ref = torch.nn.Parameter(p0.clone().cuda())
+    opt = torch.optim.AdamW([p_ref], lr=3e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.1)
+    p, m, v = p0.clone().cuda(), torch.zeros(32, 512).cuda(), torch.zeros(32, 512).cuda()
+    for step in range(1, 6):
+        grad = (torch.randn(32, 512, generator=g) * (10.0 ** (step - 3))).cuda()
+        lr = 3e-3 / step
+        for gr in opt.param_groups:
+            gr['lr'] = lr
+        p_ref.grad = grad.clone()
+        opt.step()
+        ops.adamw_step(p, grad, m, v, lr, 0.9, 0.98, 1e-8, 0.1, step)
+        assert (p - p_ref.detach()).abs().max().item() < 2e-7 * max(1.0, p_ref.abs().max().item()), step
+        assert (m - opt.state[p_ref]['exp_avg']).abs().max().item() <= 1e-6 * m.abs().max().item()
+        assert (v - opt.state[p_ref]['exp_avg_sq']).abs().max().item() <= 1e-6 * v.abs().max().item()
+
+
+@pytest.mark.parametrize("position", ["front", "middle", "end"])
+def test_prompt_rows_are_the_prompt_learner_splice(ops, position):
+    """ppt_prompt_rows / ppt_prompt_rows_bwd against PromptLearner.forward + positional add written with torch ops and its
+    autograd: rows bit-identical, token gradient = the sum of the rows' gradients."""
+    from types import SimpleNamespace
+    from ppt_amd.models import ULIP_models as M
+    args = SimpleNamespace(classnames=M.dataset_classnames("scanobjectnn"), template_init='', class_name_position=position,
+                           num_learnable_prompt_tokens=32, gpu=0, task='cls', head_type=0, evaluate_3d=False, ulip2=False,
+                           synthetic_weights=True)
+    m = M.ULIP_PointBERT(args)
+    m.prompt_learner.embedding = W.synth_prompt_embedding_from_tokens(m.tokenized_prompts, seed=0)
+    m.cuda()
+    pl = m.prompt_learner
+    C, L, P = len(args.classnames), m._text_len(), pl.shared_prefix()
+    for Puse in sorted({0, P}):
+        base, slot, pos_rows, rows_of, Mr = pl.row_layout(m.positional_embedding, L, Puse)
+        tok = pl.learnable_tokens.detach().clone().requires_grad_(True)
+        pl_out = pl.embedding.gather(1, pl._scatter_index(tok.device)[2].unsqueeze(-1).expand(-1, -1, 512))
+        cls, pos, _ = pl._scatter_index(tok.device)
+        prompts = pl_out.index_put((cls, pos), tok.unsqueeze(0).expand(C, -1, -1)) + m.positional_embedding.detach()
+        want = torch.cat([prompts[0, :Puse], prompts[:, Puse:L].reshape(C * (L - Puse), -1)]) if Puse else prompts[:, :L].reshape(C * L, -1)
+        got = ops.prompt_rows(base, slot, tok.detach().contiguous(), pos_rows)
+        assert got.shape[0] == Mr and torch.equal(got, want.detach())
+        gr = torch.randn(want.shape, device="cuda")
+        (want * gr).sum().backward()
+        dt = ops.prompt_rows_bwd(gr.contiguous(), rows_of, tok.shape[0])
+        assert (dt - tok.grad).abs().max().item() < 1e-4 * max(1.0, tok.grad.abs().max().item())
+
+
+# ------------------------------------------------------------------ fused ViT MLP (csrc/mlp_fused.hip)
+@pytest.mark.parametrize("M,rows,pos", [(16416, 513, True), (32832, 513, False), (513, 513, True), (1000, 0, False), (77, 11, True)])
+def test_vit_mlp_matches_the_unfused_chain(ops, M, rows, pos):
+    """ppt_vit_mlp_bf16 (LayerNorm + fc1 + GELU + fc2 + DropPath + residual (+ pos) in one kernel) against (a) fp32 torch math
+    on the bf16-rounded operands the MFMAs see and (b) the unfused kernels (ppt_layernorm_fwd + 2 x ppt_gemm); in place and
+    out of place; bit-reproducible."""
+    g = torch.Generator().manual_seed(M)
+    D, Hd = 384, 1536
+    x = torch.randn(M, D, generator=g) * 2 + torch.randn(M, 1, generator=g)
+    gam, bet = 1 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    w1, b1 = torch.randn(Hd, D, generator=g) * D ** -0.5, 0.1 * torch.randn(Hd, generator=g)
+    w2, b2 = torch.randn(D, Hd, generator=g) * Hd ** -0.5, 0.1 * torch.randn(D, generator=g)
+    rs = (torch.floor(0.8 + torch.rand((M + rows - 1) // rows, generator=g)) / 0.8) if rows else None
+    r2 = torch.randn(M, D, generator=g) if pos else None
+    h = _bf(torch.nn.functional.layer_norm(x, (D,), gam, bet, 1e-5))
+    u = _bf(torch.nn.functional.gelu(h @ _bf(w1).t() + b1))
+    y = u @ _bf(w2).t() + b2
+    want = x + (y * rs.repeat_interleave(rows)[:M, None] if rows else y) + (r2 if pos else 0)
+    xd, w1d, w2d = x.cuda(), w1.cuda().to(torch.bfloat16), w2.cuda().to(torch.bfloat16)
+    w1t, w2t = ops.vit_mlp_retile(w1d, w2d)
+    kw = dict(row_scale=rs.cuda(), row_scale_rows=rows) if rows else {}
+    out = torch.empty_like(xd)
+    ops.vit_mlp(xd, w1t, b1.cuda(), w2t, b2.cuda(), (gam.cuda(), bet.cuda()), out=out, residual2=r2.cuda() if pos else None, **kw)
+    tol = 2e-2 * max(1.0, (want - x).abs().max().item())          # bf16 slab + bf16 LayerNorm output: ~2^-8 relative per operand
+    assert (out.cpu() - want).abs().max().item() < tol
+    # the unfused kernels on the same inputs
+    hh, _, _ = ops.layernorm_fwd(xd, gam.cuda(), bet.cuda(), torch.bfloat16)
+    f = ops.gemm(hh, w1d, out_dtype=torch.bfloat16, bias=b1.cuda(), act=ops.ACT_GELU)
+    ref = ops.gemm(f, w2d, out=torch.empty_like(xd), bias=b2.cuda(), residual=xd, residual2=r2.cuda() if pos else None, **kw)
+    assert (out - ref).abs().max().item() < 1e-2 * max(1.0, (want - x).abs().max().item())
+    x2 = xd.clone()
+    ops.vit_mlp(x2, w1t, b1.cuda(), w2t, b2.cuda(), (gam.cuda(), bet.cuda()), residual2=r2.cuda() if pos else None, **kw)     # in place
+    assert torch.equal(x2, out)

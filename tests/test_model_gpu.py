@@ -827,3 +827,41 @@ def test_text_prefix_sharing_bf16_and_training_step():
     # which amplify rounding-level gradient differences: only closeness is asked of them
     assert outs[False][0][0] == outs[True][0][0] and torch.equal(outs[False][0][1], outs[True][0][1])
     assert np.isfinite(outs[True][1]) and abs(outs[False][1] - outs[True][1]) < 0.1 * abs(outs[False][1])
+
+
+def test_text_tower_fused_paths_match_the_unfused_tower():
+    """bf16: the prompt chain's fused nodes -- one-kernel prompt assembly (ppt_prompt_rows), LayerNorm inside the in_proj / c_fc
+    linears (ppt_rowgemm_bf16), one-kernel AdamW -- against the same step with all of them off: text features within bf16
+    rounding of the LayerNorm operands, token gradient within 8e-2 (cosine > 0.995)."""
+    from ppt_amd import engine
+    from ppt_amd.train import Trainer
+    pc, start = oracle_inputs()
+    labels = torch.tensor([1, 7, 30, 12]).cuda()
+    res = {}
+    saved = engine.TEXT_FUSE_LN
+    try:
+        for fused in (False, True):
+            engine.TEXT_FUSE_LN = fused
+            m = _token_structured_model(0, torch.bfloat16)
+            m.fused_prompt_rows = fused
+            m.train()
+            m.point_encoder.fps_start = torch.from_numpy(start).cuda()
+            m.point_encoder.drop_path_factors = torch.ones(12, 2, 4)
+            tr = Trainer(m, lr=3e-3, distributed=False)
+            tr.fused_adamw = fused
+            te = m._text_raw().detach().float().cpu()
+            loss, pred = tr.step(pc.cuda(), labels)
+            tr.finish()
+            torch.cuda.synchronize()
+            res[fused] = (te, loss.item(), m.prompt_learner.learnable_tokens.grad.detach().cpu().clone(),
+                          m.prompt_learner.learnable_tokens.detach().cpu().clone())
+    finally:
+        engine.TEXT_FUSE_LN = saved
+    a, b = res[False], res[True]
+    assert ((a[0] - b[0]).norm() / a[0].norm()).item() < 5e-3
+    assert abs(a[1] - b[1]) < 2e-2 * abs(a[1])
+    # (each variant is ~4.5e-2 away from the fp32 oracle's gradient, tools/bf16_error.py; the two differ by a 1-ulp flip of a
+    # few bf16 LayerNorm outputs -- another summation order of the statistics -- that the 12 layers then carry along)
+    assert ((a[2] - b[2]).norm() / a[2].norm()).item() < 8e-2
+    cos = (a[2].flatten() @ b[2].flatten() / (a[2].norm() * b[2].norm())).item()
+    assert cos > 0.995, cos

@@ -59,6 +59,24 @@ def main():
                 t = timeit(fn)
                 line += f" | rowgemm[w={wk}] {t:7.1f} us ({fl / t / 1e6:6.0f} TF)"
             print(line, flush=True)
+    for B in (32, 64):                                             # the fused MLP against LayerNorm + fc1 + fc2
+        M = B * 513
+        x = torch.randn(M, 384, generator=g).cuda()
+        gam, bet = torch.ones(384).cuda(), torch.zeros(384).cuda()
+        w1 = (torch.randn(1536, 384, generator=g) * 0.05).cuda().to(torch.bfloat16)
+        w2 = (torch.randn(384, 1536, generator=g) * 0.02).cuda().to(torch.bfloat16)
+        b1, b2, dp = torch.randn(1536, generator=g).cuda(), torch.randn(384, generator=g).cuda(), torch.ones(B).cuda()
+        xo = x.clone()
+
+        def old():
+            h, _, _ = ops.layernorm_fwd(xo, gam, bet, torch.bfloat16)
+            f = ops.gemm(h, w1, out_dtype=torch.bfloat16, bias=b1, act=ops.ACT_GELU)
+            ops.gemm(f, w2, out=xo, bias=b2, row_scale=dp, row_scale_rows=513, residual=xo)
+        t_old = timeit(old)
+        w1t, w2t = ops.vit_mlp_retile(w1, w2)
+        t_new = timeit(lambda: ops.vit_mlp(xo, w1t, b1, w2t, b2, (gam, bet), row_scale=dp, row_scale_rows=513))
+        fl = 4.0 * M * 384 * 1536
+        print(f"MLP B={B} M={M}: LN + fc1 + fc2 {t_old:7.1f} us ({fl / t_old / 1e6:6.0f} TF) | fused {t_new:7.1f} us ({fl / t_new / 1e6:6.0f} TF)", flush=True)
     for M in (1480, 817):
         x = torch.randn(M, 512, generator=g).cuda()
         gam, bet = torch.ones(512).cuda(), torch.zeros(512).cuda()
