@@ -683,7 +683,11 @@ def pointmlp_forward(sd, p, wc, pc, fps_starts, train, drop_masks, update_runnin
 # =================================================================================================
 # text branch (CLIP text transformer, ULIP_models.py:35-67, 203-222)
 # =================================================================================================
-TEXT_FUSE_LN = os.environ.get("PPT_TEXT_FUSE_LN", "1") != "0"       # LayerNorm -> in_proj / c_fc as ONE kernel (csrc/rowgemm.hip)
+# LayerNorm -> in_proj / c_fc as ONE kernel (csrc/rowgemm.hip): two nodes fewer per layer, but OFF by default -- the
+# weight-stationary kernel's 512-thread / 256-VGPR workgroups take whole CUs for ~15 us where the 817 rows give the 64 x 64 tile
+# GEMM ~8 us of workgroups other kernels share a CU with, and the prompt chain runs BESIDE the point tower: interleaved same-box
+# A/B of the C2 step 3.87 (on) vs 3.79 ms (off) (tools/ab_env.py)
+TEXT_FUSE_LN = os.environ.get("PPT_TEXT_FUSE_LN", "0") != "0"
 
 
 def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=None, prefix=0, rows_in=None):

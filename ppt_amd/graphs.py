@@ -135,6 +135,19 @@ def shared_group_stream(device=None):
     return _GROUP_STREAMS[dev]
 
 
+_TOWER_STREAMS = {}
+
+
+def shared_tower_stream(device=None):
+    """The process-wide stream a fully frozen point tower runs on when the caller vouches for its inputs
+    (train.Trainer.inputs_ready + tower_own_stream): created once per GPU, like the text stream."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    if dev not in _TOWER_STREAMS:
+        with torch.cuda.device(dev):
+            _TOWER_STREAMS[dev] = torch.cuda.Stream()
+    return _TOWER_STREAMS[dev]
+
+
 def _lead_over(ref, cand):
     """Fraction of `ref`'s busy time by which a tiny kernel queued on `cand` AFTER ref's work finishes BEFORE it:
     ~1 when the streams sit on different hardware queues, <= 0 when they share one (in-order execution)."""

@@ -8,6 +8,8 @@ import contextlib
 import math
 
 import numpy as np
+import os
+
 import torch
 import torch.distributed as dist
 from torch import nn
@@ -98,7 +100,7 @@ class Trainer:
         # One launch per trained tensor (ppt_adamw_step: torch.optim.AdamW's arithmetic; csrc/optim.hip) instead of the ~10
         # multi-tensor kernels of the foreach implementation, while few tensors train: every kernel of the prompt chain costs a
         # dispatch round trip.  The torch optimizer object stays the owner of hyper-parameters and state (state_dict()).
-        self.fused_adamw = True
+        self.fused_adamw = os.environ.get("PPT_FUSED_ADAMW", "1") != "0"
         # logit_scale is frozen in every PPT configuration (ULIP_models.py:487-507) and its value lies inside the clamp range:
         # main_cls.py:213's per-step clamp is then idempotent -- applied once here, and per step only if it ever trains
         if hasattr(model, "logit_scale"):
@@ -123,6 +125,10 @@ class Trainer:
         # point tower (FPS + kNN, a function of pc alone) then runs on its own stream as soon as step() is called, i.e.
         # under the previous iteration's transformer blocks (models/pointbert/point_encoder.py: _group_ahead).
         self.inputs_ready = False
+        # head_type 0 with inputs_ready: the frozen point tower of iteration i + 1 does not wait for iteration i's head (which
+        # waits for the prompt chain) -- it runs on its own stream, back to back (ULIP_WITH_IMAGE.forward_loss)
+        self.tower_own_stream = os.environ.get("PPT_TOWER_STREAM", "1") != "0"
+        self._tower_used = None
         # With a fully frozen point side (head_type 0) the tower already runs back to back on its stream with the whole
         # prompt side underneath it, the step is throughput-bound and hiding FPS buys nothing (C2: 4.22 ms without, 4.29
         # with); with a trainable last block the caller's stream has bubbles and it does (C3: 8.85 -> 8.28 ms).
@@ -170,6 +176,11 @@ class Trainer:
             use = self.inputs_ready and pc.is_cuda and side is not None and (
                 self.group_ahead_when_frozen or not self._point_side_frozen or getattr(pe, "group_ahead_pays_when_frozen", False))
             pe.group_ahead = graphs.shared_group_stream() if use else None
+        tower_own = (self.tower_own_stream and self.inputs_ready and pc.is_cuda and side is not None and self._point_side_frozen
+                     and self.fused_head and not self.extra_inputs)
+        if hasattr(model, "forward_loss"):
+            from . import graphs
+            model.tower_stream = self._tower_used = graphs.shared_tower_stream() if tower_own else None
         main = torch.cuda.current_stream() if side is not None else None
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
             self.sync.zero()                                        # optimizer.zero_grad()
@@ -244,6 +255,8 @@ class Trainer:
         to rank 0's (call before reading parameters or buffers: evaluation, checkpointing)."""
         if self._side_used is not None:
             torch.cuda.current_stream().wait_stream(self._side_used)
+        if self._tower_used is not None:
+            torch.cuda.current_stream().wait_stream(self._tower_used)
         self._drain_gate()
         if self.bcast is not None and not self.broadcast_buffers_every_step:
             self.bcast.broadcast()

@@ -16,6 +16,7 @@ graphs.shared_text_stream(priority=-1 if cfg["head_type"] == 0 else 0)
 model = bench.build_model(cfg["dataset"], cfg["head_type"], torch.bfloat16, "ULIP_PointBERT", "cls")
 model.train()
 tr = Trainer(model, lr=3e-3, label_smoothing=0.2, distributed=False)
+tr.inputs_ready = os.environ.get("PPT_INPUTS_READY", "0") == "1"
 B, N = cfg["batch"], cfg["npoints"]
 pc = torch.from_numpy(W.synth_clouds(B, N, seed=1)[0]).cuda()
 label = torch.randint(0, len(model.prompt_learner.classnames), (B,), device="cuda")
