@@ -957,6 +957,14 @@ __device__ __forceinline__ void glds_slab(const T *base, int64_t ld, int rows, i
     }
 }
 
+// Diagnostic build only (tools/gemm_stamp.py compiles this file with -DPPT_GEMM_STAMP into its own library): lane 0 of every
+// wave of the 64x64 LDS-DMA kernel stores s_memtime at entry / loads issued / first slab readable / K loop done / stores done
+// into the buffer p.pool_min points at (unused by these launches).
+#ifdef PPT_GEMM_STAMP
+#define GEMM_STAMP(slot) do { if (lane == 0 && p.pool_min && !p.pool_max) reinterpret_cast<unsigned long long *>(p.pool_min)[((size_t)((blockIdx.y * gridDim.x + blockIdx.x) * 4 + w)) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GEMM_STAMP(slot) do { } while (0)
+#endif
 template <typename T, int BM, int BN>
 __global__ __launch_bounds__(NT, BM == 64 ? 3 : 1) void gemm_kernel_glds(const ppt_gemm_params p)   // (a waves-per-SIMD floor keeps the accumulators out of AGPRs)
 {
@@ -968,6 +976,7 @@ __global__ __launch_bounds__(NT, BM == 64 ? 3 : 1) void gemm_kernel_glds(const p
     constexpr int BK = ROWB / sizeof(T);
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    GEMM_STAMP(0);
     const int wm = w >> 1, wn = w & 1;
     const int nwg = gridDim.x * gridDim.y;
     const int lin0 = blockIdx.y * gridDim.x + blockIdx.x;
@@ -993,12 +1002,14 @@ __global__ __launch_bounds__(NT, BM == 64 ? 3 : 1) void gemm_kernel_glds(const p
     issue(min(1, last), 1);
     EpiPre<TI, TJ> epre;                                  // (behind the first slabs, as in gemm_kernel_glds_h)
     epilogue_prefetch<TI, TJ>(p, epre, lane, m0 + wm * WM, n0 + wn * WN);
+    GEMM_STAMP(1);
     int stage = 0;
     for (int s = 0; s < nslab; ++s) {
         // own copies of slab s have landed (the LOADS_PER_SLAB youngest, slab s+1, may still fly) ...
         if constexpr (LOADS_PER_SLAB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __builtin_amdgcn_s_barrier();                     // ... and so have everybody else's: slab s is readable
+        if (s == 0) GEMM_STAMP(2);
         int nstage = stage + 2; if (nstage >= NSTAGE) nstage -= NSTAGE;
         issue(min(s + 2, last), nstage);                  // stage (s+2)%3 was last read at slab s-1, before this barrier
         mma_slab<T, TI, TJ>(smem + stage * STAGE, smem + stage * STAGE + A_BYTES, wm * WM, wn * WN, lane, acc);
@@ -1006,11 +1017,14 @@ __global__ __launch_bounds__(NT, BM == 64 ? 3 : 1) void gemm_kernel_glds(const p
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // surplus prefetches must not land on the parked accumulators
     __builtin_amdgcn_s_barrier();
+    GEMM_STAMP(3);
 
     const int64_t zc = (int64_t)blockIdx.z * p.strideC;
 #ifndef PPT_DBG_NO_REG_EPILOGUE
     if (reg_epilogue_ok<TI>(p, zc)) {
         epilogue_regs<TI, TJ>(p, acc, epre, smem + w * (WM * WN * 2), lane, m0 + wm * WM, n0 + wn * WN, zc);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GEMM_STAMP(4);
         return;
     }
 #endif
@@ -1030,8 +1044,20 @@ __global__ __launch_bounds__(NT, BM == 64 ? 3 : 1) void gemm_kernel_glds(const p
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (vec_epilogue_ok(p, zc)) epilogue_vec8<WM, WN>(p, ct, lane, m0 + wm * WM, n0 + wn * WN, zc);
     else epilogue_scalar<WM, WN>(p, ct, lane, m0 + wm * WM, n0 + wn * WN, m0, wm, zc);
+#ifdef PPT_GEMM_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GEMM_STAMP(4);
+#endif
 }
 
+// (Tried and removed: a split-K form of this kernel for the prompt chain's skinny linears -- 817 rows, 104 ... 416 tiles --
+// with blockIdx.z cutting K, fp32 partial tiles in a caller-lent workspace and the last workgroup to arrive at the tile's
+// counter summing them in split order.  Correct and repeatable, never faster: with release / acquire fences every workgroup
+// writes back and invalidates its XCD's whole L2 (52 ... 130 us per launch); with fence-free write-through stores and
+// L2-bypassing loads (relaxed agent-scope atomics) the three dependent memory round trips -- partial out, counter, partials
+// in -- cost the 4 ... 6 us the shorter K loop saves: 12.5 -> 12.5 us at two splits of K = 2048, slower beyond.  In-kernel
+// stamps of the unsplit kernel (tools/gemm_stamp.py): ~1.2 us from entry to the first loads issued, 585 clocks per 16 KiB
+// slab = 28 B/clk per CU, the L2 -> LDS rate of one CU.)
 // =================================================================================================
 // Half-slab LDS-DMA kernel for the big plain-operand problems (qkv, fc1, conv3): 128x128 tiles, 64-byte K slabs
 // (32 bf16), 16 KiB stages: two of them (default; FOUR workgroups = 16 waves share a CU) or three (three workgroups).
@@ -1253,7 +1279,9 @@ extern "C" int ppt_gemm(const ppt_gemm_params *pp, void *stream)
     }
     if ((p.col_sum == nullptr) != (p.col_sqsum == nullptr)) return PPT_EINVAL;
     if (p.pool_max && p.pool_rows != 0 && p.pool_rows != 16 && p.pool_rows != 32 && p.pool_rows != 64) return PPT_EINVAL;
+#ifndef PPT_GEMM_STAMP
     if (p.pool_min && !p.pool_max) return PPT_EINVAL;
+#endif
     if ((p.col_sum || p.pool_max) && ((p.N % 8) || ((uintptr_t)p.pool_min & 15) || ((uintptr_t)p.col_sum & 15) || ((uintptr_t)p.col_sqsum & 15) || ((uintptr_t)p.pool_max & 15)))
         return PPT_EUNSUPPORTED;                       // statistics / pooling exist only in the 16-byte epilogue
     if (p.group_add && p.group_rows <= 0) return PPT_EINVAL;

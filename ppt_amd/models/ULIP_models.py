@@ -539,8 +539,9 @@ class ULIP_WITH_IMAGE(nn.Module):
         return self
 
     def _cache(self):
-        if self._wc is None or self._wc.dtype != self.precision:
-            self._wc = engine.WeightCache(self.precision)
+        want = getattr(self, "text_precision", None) or self.precision      # (text_precision: error-budget experiments, tools/bf16_error.py)
+        if self._wc is None or self._wc.dtype != want:
+            self._wc = engine.WeightCache(want)
         return self._wc
 
     def _live_state(self):

@@ -42,12 +42,18 @@ def build(head_type, precision, n_classes_ds="modelnet40"):
     return m, sd
 
 
+def _bound(what, value, bound):
+    """assert value < bound, and print the pair (pytest -s): the stated bf16 tolerances are kept at ~1.5x what is measured"""
+    print(f"PARITY {what}: {value:.4g} (bound {bound:.4g})")
+    assert value < bound, (what, value, bound)
+
+
 def oracle_inputs():
     pc, start = W.synth_clouds(4, 1024, seed=77)
     return torch.from_numpy(pc), start
 
 
-@pytest.mark.parametrize("precision,ltol,gtol", [(torch.float32, 2e-3, 1e-3), (torch.bfloat16, 1.0, 1e-1)])
+@pytest.mark.parametrize("precision,ltol,gtol", [(torch.float32, 2e-3, 1e-3), (torch.bfloat16, 0.5, 9e-2)])
 @pytest.mark.parametrize("head_type", [0, 1, 2, 3])
 def test_train_step_matches_oracle_and_golden(head_type, precision, ltol, gtol):
     from ppt_amd.train import Trainer
@@ -62,8 +68,8 @@ def test_train_step_matches_oracle_and_golden(head_type, precision, ltol, gtol):
     torch.cuda.synchronize()
     # ---- against the golden fixture captured from the reference
     err = np.abs(pred.detach().cpu().numpy() - g["logits"]).max()
-    assert err < ltol, f"logits err {err}"
-    assert abs(loss.item() - float(g["loss"])) < (1e-3 if precision == torch.float32 else 0.3)
+    _bound(f"step h{head_type} {precision} logits abs err", err, ltol)
+    _bound(f"step h{head_type} {precision} loss abs err", abs(loss.item() - float(g["loss"])), 1e-3 if precision == torch.float32 else 0.1)
     # ---- gradients against the oracle (full tensors)
     masks = [(torch.from_numpy(a[0]), torch.from_numpy(a[1])) for a in g["dp_masks"]]
     nl = m.prompt_learner.name_lengths
@@ -74,7 +80,7 @@ def test_train_step_matches_oracle_and_golden(head_type, precision, ltol, gtol):
     for k, go in res["grads"].items():
         gg = live[k].grad.detach().cpu()
         rel = ((gg - go).norm() / go.norm()).item()
-        assert rel < gtol, (k, rel)
+        _bound(f"step h{head_type} {precision} grad {k} rel-L2", rel, gtol)
         # ---- and against the gradient the REFERENCE produced (full tensor, or a strided sample + the norm of big ones)
         if "grad_" + k in g.files:
             gr = torch.from_numpy(g["grad_" + k])
@@ -97,7 +103,7 @@ def test_train_step_matches_oracle_and_golden(head_type, precision, ltol, gtol):
             assert d < 5e-5, (k, d)
 
 
-@pytest.mark.parametrize("precision,tol", [(torch.float32, 2e-3), (torch.bfloat16, 1.0)])
+@pytest.mark.parametrize("precision,tol", [(torch.float32, 2e-3), (torch.bfloat16, 0.55)])
 def test_eval_forward_matches_golden(precision, tol):
     g = np.load(os.path.join(G, "g_eval.npz"))
     f0 = np.load(os.path.join(G, "g_step_h0.npz"))
@@ -108,9 +114,9 @@ def test_eval_forward_matches_golden(precision, tol):
     with torch.no_grad():
         feat = m.point_encoder(pc.cuda())
         logits = m(pc.cuda())
-    ftol = 5e-4 if precision == torch.float32 else 0.15
-    assert np.abs(feat.cpu().numpy() - g["pc_feat"]).max() < ftol
-    assert np.abs(logits.cpu().numpy() - g["logits"]).max() < tol
+    ftol = 5e-4 if precision == torch.float32 else 0.03
+    _bound(f"eval {precision} feature abs err", np.abs(feat.cpu().numpy() - g["pc_feat"]).max(), ftol)
+    _bound(f"eval {precision} logits abs err", np.abs(logits.cpu().numpy() - g["logits"]).max(), tol)
     # argmax agreement is what validate() (main_cls.py:266-270) consumes
     assert (logits.argmax(1).cpu().numpy() == g["logits"].argmax(1)).all()
 
@@ -339,7 +345,7 @@ def test_group_and_encoder_modules():
     enc = Encoder(256)
     enc.load_state_dict(sd)
     enc.cuda()
-    for prec, tol in ((torch.float32, 1e-4), (torch.bfloat16, 0.1)):
+    for prec, tol in ((torch.float32, 1e-4), (torch.bfloat16, 0.01)):
         enc.precision = prec
         for train in (False, True):
             enc.load_state_dict(sd)
@@ -348,7 +354,7 @@ def test_group_and_encoder_modules():
             with torch.no_grad():
                 ref = O.mini_pointnet({"e." + k: v for k, v in sd.items()}, torch.from_numpy(nb_ref), train, prefix="e.")
             err = (out.cpu() - ref).abs().max().item()
-            assert err < tol * max(1.0, ref.abs().max().item()), (prec, train, err)
+            _bound(f"mini-PointNet {prec} train={train} abs err / max(1, |ref|)", err / max(1.0, ref.abs().max().item()), tol)
 
 
 # ------------------------------------------------------------------ PointNet2-MSG (BASELINE config C4)
@@ -359,7 +365,7 @@ def _pn2_inputs():
     return g, torch.from_numpy(pc_np)
 
 
-@pytest.mark.parametrize("precision,tol", [(torch.float32, 2e-3), (torch.bfloat16, 6e-2)])
+@pytest.mark.parametrize("precision,tol", [(torch.float32, 2e-3), (torch.bfloat16, 1e-3)])
 @pytest.mark.parametrize("mode", ["eval", "train"])
 def test_pointnet2_msg_matches_golden(mode, precision, tol):
     """Pointnet2_Msg forward vs the reference output captured in g_pn2msg.npz (tolerance relative to max|ref|;
@@ -397,9 +403,10 @@ def test_pointnet2_msg_matches_golden(mode, precision, tol):
         rel = ((outs[0] - outs[1]).norm() / outs[0].norm()).item()
         err8 = (outs[0] - outs[1]).abs().max().item()
         # three BatchNorm'd set-abstraction levels + two batch-of-8 BatchNorm1d layers on bf16 operands
-        assert rel < 0.12 and err8 < 0.3 * outs[0].abs().max().item(), (rel, err8)
+        _bound("pn2msg bf16 train (batch 8) rel-L2 vs fp32 path", rel, 0.12)
+        _bound("pn2msg bf16 train (batch 8) max err / max|out|", err8 / outs[0].abs().max().item(), 0.25)
         return
-    assert err < tol * max(ref.abs().max().item(), 0.05), err
+    _bound(f"pn2msg {mode} {precision} abs err / max|ref|", err / max(ref.abs().max().item(), 0.05), tol)
     if mode == "train":
         msd = m.state_dict()
         for k in ("sa1.bn_blocks.2.2.running_var", "sa2.bn_blocks.1.0.running_mean", "sa3.mlp_bns.2.running_var"):
@@ -408,7 +415,7 @@ def test_pointnet2_msg_matches_golden(mode, precision, tol):
             assert (msd[k].cpu() - r).abs().max().item() < rtol * max(1.0, r.abs().max().item()), k
 
 
-@pytest.mark.parametrize("precision,tol", [(torch.float32, 2e-3), (torch.bfloat16, 6e-2)])
+@pytest.mark.parametrize("precision,tol", [(torch.float32, 2e-3), (torch.bfloat16, 1e-3)])
 @pytest.mark.parametrize("mode", ["eval", "train"])
 def test_pointnet2_ssg_matches_golden(mode, precision, tol):
     """N4: Pointnet2_Ssg forward vs the reference output captured in g_pn2ssg.npz (same conventions as the MSG test)."""
@@ -440,7 +447,7 @@ def test_pointnet2_ssg_matches_golden(mode, precision, tol):
             m.dropout_masks = dm
             outs.append(m(torch.from_numpy(pc8).cuda()).cpu())
         rel = ((outs[0] - outs[1]).norm() / outs[0].norm()).item()
-        assert rel < 0.2, rel              # three BatchNorm'd levels + two batch-of-8 BatchNorm1d layers on bf16 operands
+        _bound("pn2ssg bf16 train (batch 8) rel-L2 vs fp32 path", rel, 0.2)              # three BatchNorm'd levels + two batch-of-8 BatchNorm1d layers on bf16 operands
         return
     out = m(torch.from_numpy(pc_np).cuda())
     for _ in range(3):                                   # later calls replay the hipGraph: same result
@@ -448,7 +455,7 @@ def test_pointnet2_ssg_matches_golden(mode, precision, tol):
         again = m(torch.from_numpy(pc_np).cuda())
     ref = torch.from_numpy(g[mode])
     err = (out.cpu() - ref).abs().max().item()
-    assert err < tol * max(ref.abs().max().item(), 0.05), err
+    _bound(f"pn2ssg {mode} {precision} abs err / max|ref|", err / max(ref.abs().max().item(), 0.05), tol)
     assert (again.cpu() - ref).abs().max().item() < tol * max(ref.abs().max().item(), 0.05)
     if mode == "train":
         m.load_state_dict(sd)
@@ -460,7 +467,7 @@ def test_pointnet2_ssg_matches_golden(mode, precision, tol):
             assert (msd[k].cpu() - r).abs().max().item() < rtol * max(1.0, r.abs().max().item()), k
 
 
-@pytest.mark.parametrize("precision,tol", [(torch.float32, 2e-3), (torch.bfloat16, 6e-2)])
+@pytest.mark.parametrize("precision,tol", [(torch.float32, 2e-3), (torch.bfloat16, 2e-2)])
 @pytest.mark.parametrize("mode", ["eval", "train"])
 def test_pointmlp_matches_golden(mode, precision, tol):
     """N4: pointMLP() forward vs the reference output captured in g_pointmlp.npz (FPS starts and Dropout masks injected)."""
@@ -505,7 +512,7 @@ def test_pointmlp_matches_golden(mode, precision, tol):
         again = m(torch.from_numpy(pc_np).cuda())
     ref = torch.from_numpy(g[mode])
     err = (out.cpu() - ref).abs().max().item()
-    assert err < tol * max(ref.abs().max().item(), 0.05), err
+    _bound(f"pointmlp {mode} {precision} abs err / max|ref|", err / max(ref.abs().max().item(), 0.05), tol)
     assert (again.cpu() - ref).abs().max().item() < tol * max(ref.abs().max().item(), 0.05)
     if mode == "train":
         m.load_state_dict(sd)
@@ -660,8 +667,8 @@ def test_partseg_train_step_matches_golden(precision):
     f32 = precision == torch.float32
     err = np.abs(pred.detach().cpu().numpy()[:, ::16] - g["logits_sub"]).max()
     # bf16 mode: logits are logit_scale (14.3) x a cosine; operand rounding through 12 blocks + the decoder moves them by
-    # a few % of their range (|logits| <= 47 here), and by how much depends on summation order -- bound it at 5 %
-    assert err < (2e-2 if f32 else 0.05 * float(np.abs(g["logits_sub"]).max())), err
+    # a few % of their range (|logits| <= 47 here), and by how much depends on summation order -- measured 1.3 (2.8 %), bound 4 %
+    _bound(f"partseg {precision} logits abs err", err, 2e-2 if f32 else 0.04 * float(np.abs(g["logits_sub"]).max()))
     assert abs(loss.item() - float(g["loss"])) < (1e-3 if f32 else 0.3)
     live = dict(m.named_parameters())
     top = ("point_encoder.conv1.weight", "point_encoder.bn1.weight", "point_encoder.bn1.bias", "prompt_learner.learnable_tokens")
@@ -680,13 +687,16 @@ def test_partseg_train_step_matches_golden(precision):
             assert rel < (2e-3 if k in top else 6e-2), (k, rel)
             assert abs(live[k].grad.double().norm().item() / ref_n - 1) < 6e-2, k
         elif k in top:
-            assert rel < 0.25, (k, rel)
+            _bound(f"partseg bf16 grad {k} rel-L2", rel, 0.22)
         elif live[k].dim() >= 2:
-            # bf16: an error of ~0.3 on logits of magnitude 47 moves the per-point softmax by tens of percent and flips
-            # max-pool arg-maxima; the weight-matrix gradients must still point the same way.  (1-D norm parameters are
-            # sums with heavy cancellation and are only pinned in fp32 mode.)
+            # bf16: logits = 100 x a cosine, so a feature error of a few 1e-3 moves a logit by ~1 and the per-point softmax by
+            # tens of percent (and flips max-pool arg-maxima): measured rel-L2 0.18 ... 0.38 on the decoder's weight matrices,
+            # while their NORMS agree within 1.2 % and the directions within 1 - cos <= 0.074.  All three are bounded.
+            # (1-D norm parameters are sums with heavy cancellation and are only pinned in fp32 mode.)
             cos = float(np.dot(sub, ref) / (np.linalg.norm(sub) * np.linalg.norm(ref)))
-            assert cos > 0.85, (k, cos)
+            _bound(f"partseg bf16 grad {k} rel-L2", rel, 0.5)
+            _bound(f"partseg bf16 grad {k} |norm ratio - 1|", abs(live[k].grad.double().norm().item() / ref_n - 1), 0.03)
+            _bound(f"partseg bf16 grad {k} 1 - cos", 1 - cos, 0.1)
 
 
 def test_eval_text_cache_fast_path():
@@ -827,6 +837,39 @@ def test_text_prefix_sharing_bf16_and_training_step():
     # which amplify rounding-level gradient differences: only closeness is asked of them
     assert outs[False][0][0] == outs[True][0][0] and torch.equal(outs[False][0][1], outs[True][0][1])
     assert np.isfinite(outs[True][1]) and abs(outs[False][1] - outs[True][1]) < 0.1 * abs(outs[False][1])
+
+
+def test_frozen_tower_on_its_own_stream_is_bit_identical():
+    """Trainer.inputs_ready with a fully frozen point side (head_type 0): the point tower runs on a stream of its own that
+    does not wait for the caller's stream (train.Trainer.tower_own_stream, ULIP_WITH_IMAGE.forward_loss).  Ten steps --
+    eager calls, then hipGraph replays -- give the same losses, logits and learnable tokens, bit for bit, as the in-order
+    schedule: the streams change when the work runs, not what it computes."""
+    from ppt_amd.train import Trainer
+    pc, start = oracle_inputs()
+    labels = torch.tensor([1, 7, 30, 12]).cuda()
+    outs = {}
+    for own in (False, True):
+        m = _token_structured_model(0, torch.bfloat16)
+        m.overlap_text_tower = True
+        m.train()
+        m.point_encoder.fps_start = torch.from_numpy(start).cuda()
+        m.point_encoder.drop_path_factors = torch.ones(12, 2, 4)
+        tr = Trainer(m, lr=3e-3, distributed=False)
+        tr.inputs_ready, tr.tower_own_stream = own, own
+        pcs = [pc.cuda() + 0.001 * i for i in range(10)]          # a different cloud per step: a stale feature would show
+        torch.cuda.synchronize()
+        losses, preds = [], []
+        for i in range(10):
+            loss, pred = tr.step(pcs[i], labels)
+            losses.append(loss)
+            preds.append(pred)
+        tr.finish()
+        torch.cuda.synchronize()
+        assert (tr._tower_used is not None) == own
+        outs[own] = ([l.item() for l in losses], torch.stack([q.float() for q in preds]).cpu(),
+                     m.prompt_learner.learnable_tokens.detach().cpu().clone())
+    assert outs[False][0] == outs[True][0]
+    assert torch.equal(outs[False][1], outs[True][1]) and torch.equal(outs[False][2], outs[True][2])
 
 
 def test_text_tower_fused_paths_match_the_unfused_tower():

@@ -15,7 +15,7 @@ from ppt_amd.train import Trainer
 
 prec = torch.float32 if "f32" in sys.argv[1:] else torch.bfloat16
 G = os.path.join(ROOT, "tests", "golden")
-for h in (0, 1, 2, 3):
+for h in ((0, 3) if len(sys.argv) > 1 else (0, 1, 2, 3)):
     g = np.load(os.path.join(G, f"g_step_h{h}.npz"))
     args = SimpleNamespace(classnames=M.dataset_classnames("modelnet40"), template_init='', class_name_position='middle',
                            num_learnable_prompt_tokens=32, gpu=0, task='cls', head_type=h, evaluate_3d=False, ulip2=False,
@@ -26,6 +26,11 @@ for h in (0, 1, 2, 3):
     m.load_state_dict(sd, strict=False)
     m.prompt_learner.embedding = W.synth_prompt_embedding(40, seed=0)
     m.cuda().set_precision(prec)
+    if "text=f32" in sys.argv[1:]:
+        m.text_precision = torch.float32
+    if "point=f32" in sys.argv[1:]:
+        m.set_precision(torch.float32)
+        m.text_precision = torch.bfloat16
     m.overlap_text_tower = False
     m.train()
     pc, start = W.synth_clouds(4, 1024, seed=77)
