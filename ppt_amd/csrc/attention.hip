@@ -343,6 +343,8 @@ extern "C" int ppt_attention_fwd(const void *qkv, void *out, float *lse, int Bt,
 }
 
 // used by attention_mfma.hip until every shape has an MFMA kernel
+extern "C" int ppt_attention_bwd_short_mfma_bf16(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv, int Bt, int T,
+                                                 int H, float scale, int causal, int P, float *part, hipStream_t s);
 extern "C" int ppt_attention_fwd_quad_bf16(const void *qkv, void *out, float *lse, int Bt, int T, int H, float scale,
                                            int causal, int P, hipStream_t s)
 {
@@ -358,6 +360,11 @@ static int attn_bwd_any(const void *qkv, const void *out, const void *dout, cons
         return attn_bwd_t<float>(qkv, out, dout, lse, delta, dqkv, Bt, T, H, scale, causal, P, part, true, ppt_stream(stream));
     if (dtype == PPT_BF16) {
         hipStream_t s = ppt_stream(stream);
+        if (T <= 128) {                                    // short sequences (the text tower): delta + dK/dV + dQ in ONE launch
+            const int rc = ppt_attention_bwd_short_mfma_bf16(qkv, out, dout, lse, dqkv, Bt, T, H, scale, causal, P, part, s);
+            if (rc == PPT_OK) return attn_reduce_t<bf16_t>(part, dqkv, Bt, P, H, s);
+            if (rc != PPT_EUNSUPPORTED) return rc;
+        }
         const int64_t rows = attn_rows(Bt, T, P) * H;
         hipLaunchKernelGGL(attn_delta<bf16_t>, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, s, (const bf16_t *)out,
                            (const bf16_t *)dout, delta, T, H, rows, P);

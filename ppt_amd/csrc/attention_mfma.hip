@@ -267,27 +267,49 @@ __device__ __forceinline__ bf16x8_t tr_frag(const unsigned char *img, int row0, 
     return __builtin_bit_cast(bf16x8_t, f);
 }
 
+// sum over the eight bf16 pairs of two 16-byte chunks (fp32)
+__device__ __forceinline__ float dot8_bf16(uint4 a, uint4 b)
+{
+    const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        acc = fmaf(__uint_as_float(aw[i] << 16), __uint_as_float(bw[i] << 16), acc);
+        acc = fmaf(__uint_as_float(aw[i] & 0xffff0000u), __uint_as_float(bw[i] & 0xffff0000u), acc);
+    }
+    return acc;
+}
+
 constexpr int QT = 32;                       // query rows per staged tile in the dK/dV kernel
 constexpr int QTILE = QT * 128;              // bytes per 32-row image
 
-template <bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dout,
-                                                         const float *__restrict__ lse, const float *__restrict__ delta,
-                                                         bf16_t *__restrict__ dqkv, int Tfull, int H, float scale, int P, int C,
-                                                         float *__restrict__ part)
+constexpr int DKV_SMEM = 2 * (4 * QTILE + 256);   // per stage: Q row image, Q tr image, dO row image, dO tr image (4 KiB each) + lse2[32] + delta[32]
+
+// INLINE_DELTA: delta[q] = sum_d out[q, d] * dout[q, d] is computed while the q tile is staged (the eight threads that stage a
+// row hold its eight 16-byte chunks) instead of being read from the array a separate kernel filled: one node less in the
+// prompt chain per layer.
+template <bool CAUSAL, bool INLINE_DELTA, bool WHOLE_PREFIX = false>
+__device__ __forceinline__ void attn_bwd_dkv_body(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ out, const bf16_t *__restrict__ dout,
+                                                  const float *__restrict__ lse, const float *__restrict__ delta,
+                                                  bf16_t *__restrict__ dqkv, int Tfull, int H, float scale, int P, int C,
+                                                  float *__restrict__ part, unsigned char *smem, const int bx, const int by)
 {
-    // per stage: Q row image, Q tr image, dO row image, dO tr image (4 KiB each) + lse2[32] + delta[32]
-    __shared__ __align__(16) unsigned char smem[2 * (4 * QTILE + 256)];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int bh = blockIdx.y, b = bh / H, head = bh % H;
+    const int bh = by, b = bh / H, head = bh % H;
     const int64_t rs = 3 * (int64_t)H * HD, os = (int64_t)H * HD;
     const int T = am_len(Tfull, P, C, b), q_lo = am_qlo(P, C, b);
+    // WHOLE_PREFIX: the prefix sequence's workgroup (b == C) walks ALL physical rows as queries -- every prompt's own rows attend
+    // to every shared key, the shared rows causally among themselves (key <= row covers both: own rows sit at >= P) -- and
+    // writes dK / dV of the shared keys itself, in one fixed order; the prompts' workgroups then skip their shared keys.  No
+    // fp32 partials, no reduction kernel behind this one.
+    const bool pfx = WHOLE_PREFIX && P > 0 && b == C;
+    const int Tq = pfx ? P + C * (Tfull - P) : T;
     const bf16_t *qb = qkv + head * HD;
     const bf16_t *kb = qb + H * HD, *vb = qb + 2 * H * HD;
     const bf16_t *gb = dout + head * HD;
-    const int k0 = blockIdx.x * 128 + w * 32;
+    const int k0 = bx * 128 + w * 32;
     const int key = k0 + r;
     const float c = scale * 1.4426950408889634f;
 
@@ -308,21 +330,33 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma(const bf16_t *__rest
 #pragma unroll
         for (int e = 0; e < 16; ++e) { dvt[i][e] = 0.f; dkt[i][e] = 0.f; }
 
-    const int nqt = (T + QT - 1) / QT;
+    const int nqt = (Tq + QT - 1) / QT;
     // queries before the block's first key see none of it; queries below q_lo belong to the prefix sequence, not to this one
-    const int qt0 = max(CAUSAL ? (int)(blockIdx.x * 128) / QT : 0, q_lo / QT);
-    uint4 sq, sg;
-    float sl = 0.f, sd = 0.f;
+    const int qt0 = max(CAUSAL ? (int)(bx * 128) / QT : 0, q_lo / QT);
+    uint4 sq, sg, so = make_uint4(0, 0, 0, 0);
+    float sl = 0.f, sd = 0.f, sdr = 0.f;
     const int srow = threadIdx.x >> 3, sch = threadIdx.x & 7;   // staging: one 16-B chunk of Q and of dO per thread
     auto load_tile = [&](int qt) {
         const int q = qt * QT + srow;
-        sq = sg = make_uint4(0, 0, 0, 0);
-        if (q < T) {
-            const int64_t qr = am_row(Tfull, P, b, q);
+        sq = sg = so = make_uint4(0, 0, 0, 0);
+        if (q < Tq) {
+            const int64_t qr = pfx ? (int64_t)q : am_row(Tfull, P, b, q);
             sq = *reinterpret_cast<const uint4 *>(qb + qr * rs + sch * 8);
             sg = *reinterpret_cast<const uint4 *>(gb + qr * os + sch * 8);
+            if constexpr (INLINE_DELTA) so = *reinterpret_cast<const uint4 *>(out + head * HD + qr * os + sch * 8);
         }
-        if (threadIdx.x < QT) {
+        if constexpr (INLINE_DELTA) {
+            // the row's eight chunks sit in eight consecutive lanes: three xor steps leave the row sum in all of them
+            float d = dot8_bf16(sg, so);
+            d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4);
+            const bool own = q < Tq && q >= q_lo;
+            sdr = own ? d : 0.f;
+            if (threadIdx.x < QT) {
+                const int q2 = qt * QT + threadIdx.x;
+                const bool own2 = q2 < Tq && q2 >= q_lo;
+                sl = own2 ? lse[pfx ? (int64_t)q2 * H + head : am_stat(Tfull, P, H, b, head, q2)] * 1.4426950408889634f : INFINITY;
+            }
+        } else if (threadIdx.x < QT) {
             const int q2 = qt * QT + threadIdx.x;
             const bool own = q2 < T && q2 >= q_lo;                  // +inf -> p = 0 for padded rows and for rows this sequence does not own
             sl = own ? lse[am_stat(Tfull, P, H, b, head, q2)] * 1.4426950408889634f : INFINITY;
@@ -335,8 +369,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma(const bf16_t *__rest
         *reinterpret_cast<uint4 *>(base + 1 * QTILE + v_off(srow, sch * 16)) = sq;
         *reinterpret_cast<uint4 *>(base + 2 * QTILE + k_off(srow, sch)) = sg;
         *reinterpret_cast<uint4 *>(base + 3 * QTILE + v_off(srow, sch * 16)) = sg;
-        if (threadIdx.x < QT) {
-            reinterpret_cast<float *>(base + 4 * QTILE)[threadIdx.x] = sl;
+        if (threadIdx.x < QT) reinterpret_cast<float *>(base + 4 * QTILE)[threadIdx.x] = sl;
+        if constexpr (INLINE_DELTA) {
+            if (sch == 0) reinterpret_cast<float *>(base + 4 * QTILE + 128)[srow] = sdr;
+        } else if (threadIdx.x < QT) {
             reinterpret_cast<float *>(base + 4 * QTILE + 128)[threadIdx.x] = sd;
         }
     };
@@ -397,7 +433,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma(const bf16_t *__rest
         if (qt + 1 < nqt) write_tile(cur ^ 1);
         __syncthreads();
     }
-    if (key < T && P > 0 && key < P) {
+    if (WHOLE_PREFIX && P > 0 && key < P && !pfx) {
+        // (a shared key seen from a prompt: the prefix workgroup owns it)
+    } else if (!WHOLE_PREFIX && key < T && P > 0 && key < P) {
         // a SHARED key: this virtual sequence's contribution goes to its fp32 partial slot [b][key][K | V][H * HD]; the
         // slots are folded in a fixed order by attn_prefix_reduce (no atomics)
         float *pk = part + (((int64_t)b * P + key) * 2) * os + head * HD, *pv = pk + os;
@@ -426,38 +464,57 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma(const bf16_t *__rest
 }
 
 template <bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dout,
-                                                        const float *__restrict__ lse, const float *__restrict__ delta,
-                                                        bf16_t *__restrict__ dqkv, int Tfull, int H, float scale, int P, int C)
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dout,
+                                                         const float *__restrict__ lse, const float *__restrict__ delta,
+                                                         bf16_t *__restrict__ dqkv, int Tfull, int H, float scale, int P, int C,
+                                                         float *__restrict__ part)
 {
-    __shared__ __align__(16) unsigned char smem[2 * 3 * TILE];    // per stage: K row image, K tr image, V row image
+    __shared__ __align__(16) unsigned char smem[DKV_SMEM];
+    attn_bwd_dkv_body<CAUSAL, false>(qkv, nullptr, dout, lse, delta, dqkv, Tfull, H, scale, P, C, part, smem, blockIdx.x, blockIdx.y);
+}
+
+constexpr int DQ_SMEM = 2 * 3 * TILE;            // per stage: K row image, K tr image, V row image
+
+template <bool CAUSAL, bool INLINE_DELTA>
+__device__ __forceinline__ void attn_bwd_dq_body(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ out, const bf16_t *__restrict__ dout,
+                                                 const float *__restrict__ lse, const float *__restrict__ delta,
+                                                 bf16_t *__restrict__ dqkv, int Tfull, int H, float scale, int P, int C,
+                                                 unsigned char *smem, const int bx, const int by)
+{
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int bh = blockIdx.y, b = bh / H, head = bh % H;
+    const int bh = by, b = bh / H, head = bh % H;
     const int64_t rs = 3 * (int64_t)H * HD, os = (int64_t)H * HD;
     const int T = am_len(Tfull, P, C, b), q_lo = am_qlo(P, C, b);
     const bf16_t *qb = qkv + head * HD;
     const bf16_t *kb = qb + H * HD, *vb = qb + 2 * H * HD;
     const bf16_t *gb = dout + head * HD;
-    const int q0 = blockIdx.x * QB + w * 32;
+    const int q0 = bx * QB + w * 32;
     const int qrow = q0 + r;
     const float c = scale * 1.4426950408889634f;
 
     bf16x8_t qf[4], gf[4];
+    float dsum = 0.f;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
         uint4 a = make_uint4(0, 0, 0, 0), v = make_uint4(0, 0, 0, 0);
         if (qrow < T) {
             a = *reinterpret_cast<const uint4 *>(qb + am_row(Tfull, P, b, qrow) * rs + 16 * kk + 8 * h);
             v = *reinterpret_cast<const uint4 *>(gb + am_row(Tfull, P, b, qrow) * os + 16 * kk + 8 * h);
+            if constexpr (INLINE_DELTA)      // this lane's half of the row (the other half sits in lane ^ 32)
+                dsum += dot8_bf16(v, *reinterpret_cast<const uint4 *>(out + head * HD + am_row(Tfull, P, b, qrow) * os + 16 * kk + 8 * h));
         }
         qf[kk] = __builtin_bit_cast(bf16x8_t, a);
         gf[kk] = __builtin_bit_cast(bf16x8_t, v);
     }
     const bool own = qrow < T && qrow >= q_lo;
     const float l2 = own ? lse[am_stat(Tfull, P, H, b, head, qrow)] * 1.4426950408889634f : INFINITY;
-    const float dl = own ? delta[am_stat(Tfull, P, H, b, head, qrow)] : 0.f;
+    float dl;
+    if constexpr (INLINE_DELTA) {
+        const float ds = lane_xor32_sum(dsum);            // (both halves of the pair run it: same row, same `own`)
+        dl = own ? ds : 0.f;
+    } else dl = own ? delta[am_stat(Tfull, P, H, b, head, qrow)] : 0.f;
 
     uint4 sk[2], sv[2];
     auto load_tile = [&](int kt) {
@@ -484,7 +541,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma(const bf16_t *__restr
             *reinterpret_cast<uint4 *>(base + 2 * TILE + k_off(row, ch)) = sv[i];
         }
     };
-    const int q_hi = min(T, (int)(blockIdx.x + 1) * QB) - 1;
+    const int q_hi = min(T, (int)(bx + 1) * QB) - 1;
     const int nkt = CAUSAL ? min((T + KVT - 1) / KVT, q_hi / KVT + 1) : (T + KVT - 1) / KVT;
     f32x16_t dqt[2];
 #pragma unroll
@@ -552,6 +609,32 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma(const bf16_t *__restr
     }
 }
 
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dout,
+                                                        const float *__restrict__ lse, const float *__restrict__ delta,
+                                                        bf16_t *__restrict__ dqkv, int Tfull, int H, float scale, int P, int C)
+{
+    __shared__ __align__(16) unsigned char smem[DQ_SMEM];
+    attn_bwd_dq_body<CAUSAL, false>(qkv, nullptr, dout, lse, delta, dqkv, Tfull, H, scale, P, C, smem, blockIdx.x, blockIdx.y);
+}
+
+// One launch for the whole backward of a SHORT sequence (T <= 128: one key block and one query block per (sequence, head);
+// the CLIP text tower, 37 positions): blockIdx.x == 0 computes dK / dV, blockIdx.x == 1 computes dQ, both form delta
+// themselves -- attn_delta + dkv + dq (three nodes of the prompt chain per layer) become one.  (WHOLE_PREFIX, which would also
+// absorb attn_prefix_reduce, is compiled out: the prefix workgroup's walk over all 817 rows is 26 dependent tile iterations
+// of ~1.1 us each -- the next tile's loads are only one iteration ahead -- and made the launch ~29 us instead of ~3 + a 4.5 us
+// reduction: prompt chain alone 1.97 -> 2.33 ms.)
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_bwd_short_mfma(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ out,
+                                                           const bf16_t *__restrict__ dout, const float *__restrict__ lse,
+                                                           bf16_t *__restrict__ dqkv, int Tfull, int H, float scale, int P, int C,
+                                                           float *__restrict__ part)
+{
+    __shared__ __align__(16) unsigned char smem[DQ_SMEM > DKV_SMEM ? DQ_SMEM : DKV_SMEM];
+    if (blockIdx.x == 0) attn_bwd_dkv_body<CAUSAL, true, false>(qkv, out, dout, lse, nullptr, dqkv, Tfull, H, scale, P, C, part, smem, 0, blockIdx.y);
+    else attn_bwd_dq_body<CAUSAL, true>(qkv, out, dout, lse, nullptr, dqkv, Tfull, H, scale, P, C, smem, 0, blockIdx.y);
+}
+
 }  // namespace
 
 extern "C" int ppt_attention_fwd_mfma_bf16(const void *qkv, void *out, float *lse, int Bt, int T, int H, float scale,
@@ -571,6 +654,20 @@ extern "C" int ppt_attention_fwd_mfma_bf16(const void *qkv, void *out, float *ls
 // dq / dk / dv of the bf16 path; `delta` must already hold rowsum(dO * O) (attention.hip: attn_delta).  P > 0 (prefix-shared
 // layout, attn_rowmap.h): `part` [Bt + 1, P, 2, H * 64] f32 receives the per-sequence dK / dV of the shared rows; the caller
 // folds it (attention.hip: attn_prefix_reduce).
+extern "C" int ppt_attention_bwd_short_mfma_bf16(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv, int Bt, int T,
+                                                 int H, float scale, int causal, int P, float *part, hipStream_t s)
+{
+    if (T > 128) return PPT_EUNSUPPORTED;
+    if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dqkv & 7) || ((uintptr_t)part & 15)) return PPT_EUNSUPPORTED;
+    dim3 grid(2, (Bt + (P > 0)) * H);
+    if (causal)
+        hipLaunchKernelGGL(attn_bwd_short_mfma<true>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, T, H, scale, P, Bt, part);
+    else
+        hipLaunchKernelGGL(attn_bwd_short_mfma<false>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, T, H, scale, P, Bt, part);
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
 extern "C" int ppt_attention_bwd_mfma_bf16(const void *qkv, const void *dout, const float *lse, const float *delta,
                                            void *dqkv, int Bt, int T, int H, float scale, int causal, int P, float *part,
                                            hipStream_t s)

@@ -126,8 +126,11 @@ class Trainer:
         # under the previous iteration's transformer blocks (models/pointbert/point_encoder.py: _group_ahead).
         self.inputs_ready = False
         # head_type 0 with inputs_ready: the frozen point tower of iteration i + 1 does not wait for iteration i's head (which
-        # waits for the prompt chain) -- it runs on its own stream, back to back (ULIP_WITH_IMAGE.forward_loss)
-        self.tower_own_stream = os.environ.get("PPT_TOWER_STREAM", "1") != "0"
+        # waits for the prompt chain) -- it runs on its own stream, back to back (ULIP_WITH_IMAGE.forward_loss).  Opt-in: it
+        # does not shorten the C2 step (3.83 vs 3.80 ms, tools/ab_env.py) -- the step timeline (tools/step_timeline.py) shows
+        # the caller's stream does not idle at the head for long; what bounds the step is the prompt chain's kernels getting
+        # 2.3x slower beside the tower (tools/chain_under_load.py), on whatever stream the tower runs.
+        self.tower_own_stream = os.environ.get("PPT_TOWER_STREAM", "0") != "0"
         self._tower_used = None
         # With a fully frozen point side (head_type 0) the tower already runs back to back on its stream with the whole
         # prompt side underneath it, the step is throughput-bound and hiding FPS buys nothing (C2: 4.22 ms without, 4.29
