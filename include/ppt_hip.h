@@ -373,6 +373,10 @@ int ppt_bn_res_act_rows(const void *x, int x_dtype, const void *res, int res_dty
 int ppt_gemm_tn_bf16(const void *A, int64_t lda, const void *B, int64_t ldb, int64_t M, int N1, int N2, int n_slices, float *part,
                      void *stream);
 
+/* out[M,N] = A[M,K] . W[K,N], fp32, few rows (K <= 1536, K % 32 == 0): the EOT projection `x @ self.text_projection`
+ * (ULIP_models.py:222) and its backward.  W row-major as stored ([K,N]). */
+int ppt_rows_matmul_f32(const float *A, const float *W, int M, int K, int N, float *out, void *stream);
+
 /* ---- the step between the towers when only the prompt trains (head_type 0) --------------------------
  * head_logits: spc[B,E] = exp(logit_scale) * feat[B,F] @ w[F,E] (w = pc_projection as stored, ULIP_models.py:257), logits[B,C] =
  *   spc @ (text / |text|)^T with text[C,E] the un-normalised text features (:279-281).

@@ -60,6 +60,7 @@ class RowGemmParams(ctypes.Structure):
 
 _SIGNATURES = {
     "ppt_abi_version": (c_int, []),
+    "ppt_rows_matmul_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ppt_fps_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ppt_knn_group_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ppt_square_distance_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -56,6 +56,57 @@ __global__ __launch_bounds__(HT) void head_project_kernel(const float *__restric
         spc[(size_t)b * E + e] = __expf(logit_scale[0]) * ((part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]));
 }
 
+// The same projection for F <= 1536 with EIGHT samples per workgroup: grid (E / 64, ceil(B / 8)), 8 waves each walk an eighth of F
+// with the lane on the output column; every W element loaded feeds eight FMAs (one per sample, feat rows in LDS), so W is read
+// B / 8 times instead of B times and a wave's walk is F / 8 = 96 steps instead of 192: 24.7 -> ~4 us for 32 x 768 x 512 -- this
+// kernel sits between two point towers AND at the head of the prompt chain.  Partials fold in wave order (fixed).
+constexpr int HS = 8;
+__global__ __launch_bounds__(512) void head_project8_kernel(const float *__restrict__ feat, const float *__restrict__ w,
+                                                            const float *__restrict__ logit_scale, int B, int F, int E,
+                                                            float *__restrict__ spc)
+{
+    extern __shared__ float sm[];                         // [HS][F] feat rows, then [8 waves][HS][64] partials
+    float *part = sm + HS * F;
+    const int b0 = blockIdx.y * HS, lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    for (int i = threadIdx.x; i < HS * F; i += 512) {
+        const int s_ = i / F;
+        sm[i] = b0 + s_ < B ? feat[(size_t)(b0 + s_) * F + (i - s_ * F)] : 0.f;
+    }
+    __syncthreads();
+    const int fq = (F + 7) / 8, f0 = q * fq, f1 = min(F, f0 + fq);
+    float acc[HS];
+#pragma unroll
+    for (int s_ = 0; s_ < HS; ++s_) acc[s_] = 0.f;
+    if (e < E) {
+        int i = f0;
+        for (; i + 4 <= f1; i += 4) {
+            const float w0 = w[(size_t)(i + 0) * E + e], w1 = w[(size_t)(i + 1) * E + e], w2 = w[(size_t)(i + 2) * E + e],
+                        w3 = w[(size_t)(i + 3) * E + e];
+#pragma unroll
+            for (int s_ = 0; s_ < HS; ++s_) {
+                const float4 f = *reinterpret_cast<const float4 *>(sm + s_ * F + i);      // (F % 4 == 0 and fq % 4 == 0 checked on the host)
+                acc[s_] = fmaf(f.w, w3, fmaf(f.z, w2, fmaf(f.y, w1, fmaf(f.x, w0, acc[s_]))));
+            }
+        }
+        for (; i < f1; ++i) {
+            const float wv = w[(size_t)i * E + e];
+#pragma unroll
+            for (int s_ = 0; s_ < HS; ++s_) acc[s_] = fmaf(sm[s_ * F + i], wv, acc[s_]);
+        }
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < HS; ++s_) part[(q * HS + s_) * 64 + lane] = acc[s_];
+    __syncthreads();
+    const int s_ = q;                                     // wave q finishes sample b0 + q
+    if (e < E && b0 + s_ < B) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += part[(k * HS + s_) * 64 + lane];
+        spc[(size_t)(b0 + s_) * E + e] = logit_scale ? __expf(logit_scale[0]) * t : t;
+    }
+}
+
 // logits[b,c] = spc[b,:] . text[c,:] / |text[c,:]|: one wave per (b, c) pair, 16 waves per workgroup
 __global__ __launch_bounds__(1024) void head_logits_kernel(const float *__restrict__ spc, const float *__restrict__ text, int B,
                                                            int E, int C, float *__restrict__ logits)
@@ -136,10 +187,27 @@ extern "C" int ppt_head_logits(const float *feat, const float *w, const float *t
 {
     if (!feat || !w || !text || !logit_scale || !spc || !logits || B <= 0 || F <= 0 || E <= 0 || C <= 0) return PPT_EINVAL;
     if (F > 8192 || B > 65535) return PPT_EUNSUPPORTED;
-    hipLaunchKernelGGL(head_project_kernel, dim3((E + 63) / 64, B), dim3(HT), sizeof(float) * (size_t)(F + 256), ppt_stream(stream),
-                       feat, w, logit_scale, F, E, spc);
+    if (F <= 1536 && F % 32 == 0 && (((uintptr_t)feat) & 15) == 0)
+        hipLaunchKernelGGL(head_project8_kernel, dim3((E + 63) / 64, (B + HS - 1) / HS), dim3(512), sizeof(float) * (size_t)(HS * F + 8 * HS * 64),
+                           ppt_stream(stream), feat, w, logit_scale, B, F, E, spc);
+    else
+        hipLaunchKernelGGL(head_project_kernel, dim3((E + 63) / 64, B), dim3(HT), sizeof(float) * (size_t)(F + 256), ppt_stream(stream),
+                           feat, w, logit_scale, F, E, spc);
     PPT_CHECK_LAUNCH();
     hipLaunchKernelGGL(head_logits_kernel, dim3((B * C + 15) / 16), dim3(1024), 0, ppt_stream(stream), spc, text, B, E, C, logits);
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
+// out[M,N] = A[M,K] . W[K,N] in fp32 for a FEW rows (the text tower's EOT projection x @ text_projection, ULIP_models.py:222, and
+// its backward: 40 rows): head_project8_kernel without the scale.  The fp32 MFMA tile loop ran these 10 MFLOP in 18.9 us (eight
+// workgroups walking K serially); here ~4 us.
+extern "C" int ppt_rows_matmul_f32(const float *A, const float *W, int M, int K, int N, float *out, void *stream)
+{
+    if (!A || !W || !out || M <= 0 || K <= 0 || N <= 0) return PPT_EINVAL;
+    if (K > 1536 || (K % 32) != 0 || M > 65535 * HS || (((uintptr_t)A) & 15)) return PPT_EUNSUPPORTED;
+    hipLaunchKernelGGL(head_project8_kernel, dim3((N + 63) / 64, (M + HS - 1) / HS), dim3(512), sizeof(float) * (size_t)(HS * K + 8 * HS * 64),
+                       ppt_stream(stream), A, W, (const float *)nullptr, M, K, N, out);
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }

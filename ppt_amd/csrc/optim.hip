@@ -58,11 +58,19 @@ __global__ __launch_bounds__(256) void prompt_rows_bwd_kernel(const float *__res
     if (i >= n_tok * w4) return;
     const int t = i / w4, c = 4 * (i - t * w4);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = 0; k < max_rows; ++k) {
-        const int row = rows_of[t * max_rows + k];
-        if (row < 0) break;
-        const float4 v = *reinterpret_cast<const float4 *>(g + (int64_t)row * W + c);
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    // eight rows in flight, added in list order (one dependent index -> row walk per element was 40 round trips: 21.6 us)
+    for (int k = 0; k < max_rows; k += 8) {
+        int row[8];
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) row[u] = k + u < max_rows ? rows_of[t * max_rows + k + u] : -1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            v[u] = row[u] >= 0 ? *reinterpret_cast<const float4 *>(g + (int64_t)row[u] * W + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (row[u] >= 0) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+        if (row[7] < 0) break;
     }
     *reinterpret_cast<float4 *>(d_tokens + (int64_t)t * W + c) = acc;
 }

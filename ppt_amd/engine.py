@@ -723,7 +723,9 @@ def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=No
         M = ops.prefix_rows(C, L, P) if P else C * L
         assert x0.shape[0] == M
         xin, add, add_rows = x0, None, 0
-        rows = (P + torch.arange(C, device=dev) * (L - P) + (eot_pos - P)) if P else (torch.arange(C, device=dev) * L + eot_pos)
+        # rows of the EOT tokens (ULIP_models.py:222): a function of the token ids alone -- cached, not four tiny kernels per forward
+        rows = wc.derived(("text_eot_rows", C, L, P), (eot_pos,), lambda: ((P + torch.arange(C, device=dev) * (L - P) + (eot_pos - P)) if P
+                                                                           else (torch.arange(C, device=dev) * L + eot_pos)))
     elif P:
         M = ops.prefix_rows(C, L, P)
         xin = torch.cat([prompts[0, :P], prompts[:, P:L].reshape(C * (L - P), Wd)], dim=0)
@@ -786,7 +788,9 @@ def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=No
     hn, meanf, rstdf = ops.layernorm_fwd(x_eot, sd["ln_final.weight"], sd["ln_final.bias"], torch.float32,
                                          save_stats=save)
     wc32 = _f32_cache(wc)
-    out = ops.gemm(hn, wc32.get(sd["text_projection"], "wt"), out_dtype=torch.float32)
+    out = ops.rows_matmul(hn, wc32.get(sd["text_projection"], "f32")) if hn.shape[0] <= 256 else None      # x @ text_projection (ULIP_models.py:222)
+    if out is None:
+        out = ops.gemm(hn, wc32.get(sd["text_projection"], "wt"), out_dtype=torch.float32)
     if save:
         saved.update(x_eot=x_eot, meanf=meanf, rstdf=rstdf, rows=rows, C=C, L=L, Lfull=Lfull, W=Wd, heads=heads, P=P, M=M,
                      rows_mode=rows_in is not None)
@@ -813,7 +817,9 @@ def text_tower_backward(sd, wc, s, dout):
     T = wc.dtype
     C, L, Wd, heads, P, M = s["C"], s["L"], s["W"], s["heads"], s["P"], s["M"]
     wc32 = _f32_cache(wc)
-    d_hn = ops.gemm(dout.contiguous(), wc32.get(sd["text_projection"], "w"), out_dtype=torch.float32)
+    d_hn = ops.rows_matmul(dout.contiguous(), wc32.get(sd["text_projection"], "wt")) if dout.shape[0] <= 256 else None
+    if d_hn is None:
+        d_hn = ops.gemm(dout.contiguous(), wc32.get(sd["text_projection"], "w"), out_dtype=torch.float32)
     d_eot, _, _ = ops.layernorm_bwd(d_hn, s["x_eot"], sd["ln_final.weight"], s["meanf"], s["rstdf"])
     g = torch.zeros((M, Wd), dtype=torch.float32, device=dout.device)
     g.index_copy_(0, s["rows"], d_eot)

@@ -296,7 +296,8 @@ class _TextTowerFn(torch.autograd.Function):
             (out,), saved = g(prompts)
             g.generation = getattr(g, "generation", 0) + 1
             ctx.graph, ctx.key, ctx.generation = g, key, g.generation
-            out = out.clone()
+            if not model._handoff:
+                out = out.clone()
         else:
             out, saved = run(prompts)
         ctx.saved = saved
@@ -362,7 +363,8 @@ class _TextTowerTokensFn(torch.autograd.Function):
             (out,), saved = g(tok)
             g.generation = getattr(g, "generation", 0) + 1
             ctx.graph, ctx.key, ctx.generation = g, key, g.generation
-            out = out.clone()
+            if not model._handoff:                       # (forward_loss copies it into the head graph's input at once)
+                out = out.clone()
         else:
             out, saved = run(tok)
         ctx.saved = saved
@@ -392,7 +394,10 @@ class _TextTowerTokensFn(torch.autograd.Function):
                 return (run(d, saved),), None
             return graphs.GraphedCall(fn, [dout.contiguous()], pool=fwd.pool())
         (dt,), _ = m._graphs.get(("text_bwd_tok",) + ctx.key[1:], build)(dout)
-        return None, dt.clone()
+        # learnable_tokens is a leaf whose .grad exists (a view of the Trainer's flat buffer): autograd ADDS dt into it on this
+        # stream before anything can replay the graph again -- no copy needed then
+        tok_grad = m.prompt_learner.learnable_tokens.grad
+        return None, (dt if (m._handoff_grad and tok_grad is not None) else dt.clone())
 
 
 class _MatmulNT(torch.autograd.Function):
@@ -444,18 +449,24 @@ class _HeadLossFn(torch.autograd.Function):
         key = ("head", tuple(feat.shape), tuple(traw.shape), float(smoothing))
         gc = model._graphs
         if feat.is_cuda and model.use_hip_graphs and ops.profiler is None and gc.ready(key):
-            (loss, logits, d_raw), _ = gc.get(key, lambda: graphs.GraphedCall(run, [feat, traw, lab]))(feat, traw, lab)
-            loss, logits, d_raw = loss.clone(), logits.clone(), d_raw.clone()
+            g = gc.get(key, lambda: graphs.GraphedCall(run, [feat, traw, lab]))
+            (loss, logits, d_raw), _ = g(feat, traw, lab)
+            g.generation = getattr(g, "generation", 0) + 1
+            ctx.graph, ctx.generation = g, g.generation
+            loss, logits = loss.clone(), logits.clone()  # (d_raw stays in the graph's buffer: read by backward before the next replay)
         else:
             (loss, logits, d_raw), _ = run(feat, traw, lab)
-        ctx.save_for_backward(d_raw)
+            ctx.graph = None
+        ctx.d_raw = d_raw
         ctx.mark_non_differentiable(logits)
         return loss, logits
 
     @staticmethod
     def backward(ctx, dloss, _dlogits):
-        (d_raw,) = ctx.saved_tensors
-        return None, None, d_raw * dloss, None, None
+        if ctx.graph is not None and ctx.graph.generation != ctx.generation:
+            raise RuntimeError("the head's captured text-feature gradient was overwritten by a later forward_loss; set "
+                               "model.use_hip_graphs = False to keep several forwards alive before backward")
+        return None, None, ctx.d_raw * dloss, None, None
 
 
 def matmul_nt(a, b, prec=torch.float32):
@@ -497,6 +508,8 @@ class ULIP_WITH_IMAGE(nn.Module):
         self.fused_prompt_rows = os.environ.get("PPT_FUSED_PROMPT_ROWS", "1") != "0"     # PromptLearner splice + pos add: one kernel
         # positions in front of the class name are the same in every prompt: computed once (PPT_SHARE_TEXT_PREFIX=0: A/B runs)
         self.share_text_prefix = os.environ.get("PPT_SHARE_TEXT_PREFIX", "1") != "0"
+        self._handoff = False               # inside forward_loss: graph outputs go straight into the next graph's input (no clone)
+        self._handoff_grad = os.environ.get("PPT_HANDOFF", "1") != "0"
 
     # ---- reference helpers ------------------------------------------------------------------
     def build_attention_mask(self):
@@ -663,7 +676,11 @@ class ULIP_WITH_IMAGE(nn.Module):
         if side is not None:
             side.wait_stream(cur)
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-            text_raw = self._text_raw()
+            self._handoff = self._handoff_grad and self.use_hip_graphs
+            try:
+                text_raw = self._text_raw()
+            finally:
+                self._handoff = False
         tw = getattr(self, "tower_stream", None) if side is not None else None
         if tw is not None:
             # the caller vouched that `pc` is complete in memory (train.Trainer.inputs_ready): the frozen point tower runs on

@@ -234,6 +234,22 @@ def gemm(A, B, *, out=None, out_dtype=None, M=None, bias=None, act=ACT_NONE, dac
     return out
 
 
+def rows_matmul(a, w_kn):
+    """out [M,N] = a [M,K] @ w_kn [K,N], fp32, for a few rows (ppt_rows_matmul_f32) -- None when the shape is not covered."""
+    _chk(a, torch.float32, "a"); _chk(w_kn, torch.float32, "w_kn")
+    M, K = a.shape
+    N = w_kn.shape[1]
+    if K > 1536 or K % 32 or w_kn.shape[0] != K:
+        return None
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    if profiler is not None:
+        profiler.begin("gemm_f32", 2.0 * M * N * K, "ppt_rows_matmul_f32")
+    _lib.check(_lib.lib().ppt_rows_matmul_f32(_p(a), _p(w_kn), M, K, N, _p(out), _stream()), "ppt_rows_matmul_f32")
+    if profiler is not None:
+        profiler.end()
+    return out
+
+
 def vit_mlp_retile(w1, w2):
     """(w1 [1536,384], w2 [384,1536]) bf16 -> the fragment-ordered copies ppt_vit_mlp_bf16 reads (ppt_vit_mlp_retile)."""
     _chk(w1, torch.bfloat16, "w1"); _chk(w2, torch.bfloat16, "w2")
