@@ -4,7 +4,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libppt_hip.so")
+LIB_PATH = os.environ.get("PPT_HIP_LIB") or os.path.join(_HERE, "csrc", "libppt_hip.so")      # (PPT_HIP_LIB: a variant build, A/B runs)
 _lib = None
 
 PPT_F32, PPT_BF16 = 0, 1

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void mpn1_kernel(const float *__restrict__ pts
             const int row = RPI * q2 + lane / LPR, ch = lane % LPR;
             if (row < 32 && lane < RPI * LPR) {
                 const uint4 v = *reinterpret_cast<const uint4 *>(tr + row * PITCH + ch * 16);
-                *reinterpret_cast<uint4 *>(y2 + ((size_t)t * 32 + row) * N + n_w + ch * 8) = v;
+                ppt_store16_stream(y2 + ((size_t)t * 32 + row) * N + n_w + ch * 8, v);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

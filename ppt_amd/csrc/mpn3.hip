@@ -104,7 +104,7 @@ __global__ __launch_bounds__(512, 2) void mpn3_kernel(const bf16_t *__restrict__
         for (int q2 = 0; q2 < 4; ++q2) {
             const int row = 8 * q2 + (lane >> 3), ch = lane & 7;
             const uint4 o = *reinterpret_cast<const uint4 *>(tr + row * M3_TP + ch * 16);
-            *reinterpret_cast<uint4 *>(y + ((size_t)t * 32 + row) * M3_N + 64 * w + ch * 8) = o;
+            ppt_store16_stream(y + ((size_t)t * 32 + row) * M3_N + 64 * w + ch * 8, o);
         }
         M3_STAGE(cur ^ 1);                                          // last read in iteration it - 1, before its barrier
         __syncthreads();

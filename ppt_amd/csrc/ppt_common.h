@@ -131,3 +131,13 @@ __device__ __forceinline__ uint32_t float_order_key(float f)
 }
 
 static inline hipStream_t ppt_stream(void *s) { return (hipStream_t)s; }
+
+// 16-byte NON-TEMPORAL store of a kernel's bulk output (the mini-PointNet activations: hundreds of MB per step, read back by
+// the next kernel from HBM anyway): the lines do not linger dirty in L2, so the end-of-kernel write-back of the small kernels
+// running beside this one (the prompt chain) has less to flush.  Same-box A/B against plain stores: C2 3.718 -> 3.702 ms,
+// C3 6.787 -> 6.749 ms per step (tools/build_variant.sh + tools/ab_env.py).
+__device__ __forceinline__ void ppt_store16_stream(void *p, uint4 v)
+{
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+    __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, v), reinterpret_cast<u32x4_t *>(p));
+}
