@@ -132,6 +132,7 @@ typedef struct ppt_gemm_params {
     void *pool_min;                  /* optional [M/pool_rows, N] minimum (BatchNorm with a negative scale flips the max) */
     /* batching (blockIdx.z): pointer offsets in ELEMENTS per batch */
     int batch; int64_t strideA, strideB, strideC;
+    int wave_prio;                   /* != 0: the kernel raises its waves' issue priority (0: what ppt_set_wave_priority set) */
 } ppt_gemm_params;
 
 #define PPT_A_PLAIN 0
@@ -144,6 +145,12 @@ typedef struct ppt_gemm_params {
 #define PPT_ACT_QUICKGELU 3  /* x*sigmoid(1.702x), ULIP_models.py:30-32 */
 
 int ppt_gemm(const ppt_gemm_params *p, void *stream);
+
+/* Wave (issue) priority of the launches this host thread makes from now on: != 0 raises it (s_setprio 3) in the kernels of the
+ * prompt chain -- ppt_gemm's 64x64 tile loop, LayerNorm forward / backward, the causal / short attention kernels, the head,
+ * AdamW and prompt-row kernels.  For callers whose critical path is the text side (only the prompt trains); default 0. */
+void ppt_set_wave_priority(int prio);
+int ppt_get_wave_priority(void);
 
 /* ---- short-K linears with the weight stationary in registers (csrc/rowgemm.hip) --------------------------------
  * Replaces, for the frozen transformer blocks in the bf16 mode, nn.LayerNorm + nn.Linear pairs and the residual-form

@@ -29,7 +29,7 @@ class GemmParams(ctypes.Structure):
         ("residual", c_void_p), ("ld_res", c_int64), ("residual2", c_void_p), ("ld_res2", c_int64),
         ("C2", c_void_p), ("ldc2", c_int64), ("c2_dtype", c_int), ("c2_pre", c_int),
         ("col_sum", c_void_p), ("col_sqsum", c_void_p), ("pool_max", c_void_p), ("pool_dtype", c_int), ("pool_rows", c_int), ("pool_min", c_void_p),
-        ("batch", c_int), ("strideA", c_int64), ("strideB", c_int64), ("strideC", c_int64),
+        ("batch", c_int), ("strideA", c_int64), ("strideB", c_int64), ("strideC", c_int64), ("wave_prio", c_int),
     ]
 
 
@@ -60,6 +60,8 @@ class RowGemmParams(ctypes.Structure):
 
 _SIGNATURES = {
     "ppt_abi_version": (c_int, []),
+    "ppt_set_wave_priority": (None, [c_int]),
+    "ppt_get_wave_priority": (c_int, []),
     "ppt_rows_matmul_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ppt_fps_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ppt_knn_group_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

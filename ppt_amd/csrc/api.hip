@@ -13,3 +13,7 @@ extern "C" const char *ppt_strerror(int code)
 }
 
 extern "C" int ppt_abi_version(void) { return 2; }   // 2: + ppt_bn_finalize_ws, ppt_rows_stats_f32, ppt_bn_rows_bwd_*
+
+static thread_local int g_wave_priority = 0;
+extern "C" void ppt_set_wave_priority(int prio) { g_wave_priority = prio > 0 ? 1 : 0; }
+extern "C" int ppt_get_wave_priority(void) { return g_wave_priority; }

@@ -264,8 +264,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv(const T *__restrict__ qkv, c
 // dK / dV of the shared prefix rows = sum over the C + 1 virtual sequences of their partials, in sequence order (fixed:
 // deterministic, no atomics); one thread per (position, K | V, column)
 template <typename T>
-__global__ __launch_bounds__(256) void attn_prefix_reduce(const float *__restrict__ part, int nseq, int P, int HHD, T *__restrict__ dqkv)
+__global__ __launch_bounds__(256) void attn_prefix_reduce(const float *__restrict__ part, int nseq, int P, int HHD, T *__restrict__ dqkv, int prio)
 {
+    PPT_PRIO(prio);
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P * 2 * HHD) return;
     float acc = 0.f;
@@ -300,7 +301,7 @@ int attn_reduce_t(const float *part, void *dqkv, int Bt, int P, int H, hipStream
 {
     if (P <= 0) return PPT_OK;
     const int n = P * 2 * H * HD;
-    hipLaunchKernelGGL(attn_prefix_reduce<T>, dim3((n + 255) / 256), dim3(256), 0, s, part, Bt + 1, P, H * HD, (T *)dqkv);
+    hipLaunchKernelGGL(attn_prefix_reduce<T>, dim3((n + 255) / 256), dim3(256), 0, s, part, Bt + 1, P, H * HD, (T *)dqkv, ppt_get_wave_priority());
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }

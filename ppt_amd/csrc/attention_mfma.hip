@@ -37,9 +37,10 @@ __device__ __forceinline__ float lane_xor32_sum(float v) { return xor32_sum(v); 
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out,
                                                      float *__restrict__ lse, int Tfull, int H, float c /* scale*log2(e) */,
-                                                     int P, int C)
+                                                     int P, int C, int prio)
 {
     __shared__ __align__(16) unsigned char smem[4 * TILE];    // K0 K1 V0 V1
+    PPT_PRIO(prio);
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -628,8 +629,9 @@ template <bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_short_mfma(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ out,
                                                            const bf16_t *__restrict__ dout, const float *__restrict__ lse,
                                                            bf16_t *__restrict__ dqkv, int Tfull, int H, float scale, int P, int C,
-                                                           float *__restrict__ part)
+                                                           float *__restrict__ part, int prio)
 {
+    PPT_PRIO(prio);
     __shared__ __align__(16) unsigned char smem[DQ_SMEM > DKV_SMEM ? DQ_SMEM : DKV_SMEM];
     if (blockIdx.x == 0) attn_bwd_dkv_body<CAUSAL, true, false>(qkv, out, dout, lse, nullptr, dqkv, Tfull, H, scale, P, C, part, smem, 0, blockIdx.y);
     else attn_bwd_dq_body<CAUSAL, true>(qkv, out, dout, lse, nullptr, dqkv, Tfull, H, scale, P, C, smem, 0, blockIdx.y);
@@ -644,9 +646,9 @@ extern "C" int ppt_attention_fwd_mfma_bf16(const void *qkv, void *out, float *ls
     dim3 grid((T + QB - 1) / QB, (Bt + (P > 0)) * H);
     const float c = scale * 1.4426950408889634f;
     if (causal)
-        hipLaunchKernelGGL(attn_fwd_mfma<true>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (bf16_t *)out, lse, T, H, c, P, Bt);
+        hipLaunchKernelGGL(attn_fwd_mfma<true>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (bf16_t *)out, lse, T, H, c, P, Bt, ppt_get_wave_priority());
     else
-        hipLaunchKernelGGL(attn_fwd_mfma<false>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (bf16_t *)out, lse, T, H, c, P, Bt);
+        hipLaunchKernelGGL(attn_fwd_mfma<false>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (bf16_t *)out, lse, T, H, c, P, Bt, ppt_get_wave_priority());
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }
@@ -661,9 +663,9 @@ extern "C" int ppt_attention_bwd_short_mfma_bf16(const void *qkv, const void *ou
     if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dqkv & 7) || ((uintptr_t)part & 15)) return PPT_EUNSUPPORTED;
     dim3 grid(2, (Bt + (P > 0)) * H);
     if (causal)
-        hipLaunchKernelGGL(attn_bwd_short_mfma<true>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, T, H, scale, P, Bt, part);
+        hipLaunchKernelGGL(attn_bwd_short_mfma<true>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, T, H, scale, P, Bt, part, ppt_get_wave_priority());
     else
-        hipLaunchKernelGGL(attn_bwd_short_mfma<false>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, T, H, scale, P, Bt, part);
+        hipLaunchKernelGGL(attn_bwd_short_mfma<false>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, T, H, scale, P, Bt, part, ppt_get_wave_priority());
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }

@@ -977,6 +977,7 @@ __global__ __launch_bounds__(NT, BM == 64 ? 3 : 1) void gemm_kernel_glds(const p
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     GEMM_STAMP(0);
+    PPT_PRIO(p.wave_prio);
     const int wm = w >> 1, wn = w & 1;
     const int nwg = gridDim.x * gridDim.y;
     const int lin0 = blockIdx.y * gridDim.x + blockIdx.x;
@@ -1265,7 +1266,9 @@ int launch_gemm(const ppt_gemm_params &p, hipStream_t s)
 extern "C" int ppt_gemm(const ppt_gemm_params *pp, void *stream)
 {
     if (!pp) return PPT_EINVAL;
-    const ppt_gemm_params &p = *pp;
+    ppt_gemm_params q = *pp;
+    if (!q.wave_prio) q.wave_prio = ppt_get_wave_priority();
+    const ppt_gemm_params &p = q;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || !p.B) return PPT_EINVAL;
     if (p.dtype != PPT_F32 && p.dtype != PPT_BF16) return PPT_EINVAL;
     const int epc = p.dtype == PPT_BF16 ? 8 : 4;

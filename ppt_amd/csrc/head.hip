@@ -63,8 +63,9 @@ __global__ __launch_bounds__(HT) void head_project_kernel(const float *__restric
 constexpr int HS = 8;
 __global__ __launch_bounds__(512) void head_project8_kernel(const float *__restrict__ feat, const float *__restrict__ w,
                                                             const float *__restrict__ logit_scale, int B, int F, int E,
-                                                            float *__restrict__ spc)
+                                                            float *__restrict__ spc, int prio)
 {
+    PPT_PRIO(prio);
     extern __shared__ float sm[];                         // [HS][F] feat rows, then [8 waves][HS][64] partials
     float *part = sm + HS * F;
     const int b0 = blockIdx.y * HS, lane = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -109,8 +110,9 @@ __global__ __launch_bounds__(512) void head_project8_kernel(const float *__restr
 
 // logits[b,c] = spc[b,:] . text[c,:] / |text[c,:]|: one wave per (b, c) pair, 16 waves per workgroup
 __global__ __launch_bounds__(1024) void head_logits_kernel(const float *__restrict__ spc, const float *__restrict__ text, int B,
-                                                           int E, int C, float *__restrict__ logits)
+                                                           int E, int C, float *__restrict__ logits, int prio)
 {
+    PPT_PRIO(prio);
     const int lane = threadIdx.x & 63;
     const int pair = blockIdx.x * 16 + (threadIdx.x >> 6);
     if (pair >= B * C) return;
@@ -128,8 +130,9 @@ __global__ __launch_bounds__(1024) void head_logits_kernel(const float *__restri
 __global__ __launch_bounds__(CT) void head_ce_bwd_kernel(const float *__restrict__ logits, const int64_t *__restrict__ labels,
                                                          const float *__restrict__ spc, const float *__restrict__ text,
                                                          float smoothing, int B, int E, int C, float *__restrict__ loss,
-                                                         float *__restrict__ d_raw)
+                                                         float *__restrict__ d_raw, int prio)
 {
+    PPT_PRIO(prio);
     extern __shared__ float sm[];
     float *dl = sm;                                      // dlogits[:, c] for this class, [B]
     float *rowloss = sm + B;                             // [B] (workgroup 0)
@@ -189,12 +192,12 @@ extern "C" int ppt_head_logits(const float *feat, const float *w, const float *t
     if (F > 8192 || B > 65535) return PPT_EUNSUPPORTED;
     if (F <= 1536 && F % 32 == 0 && (((uintptr_t)feat) & 15) == 0)
         hipLaunchKernelGGL(head_project8_kernel, dim3((E + 63) / 64, (B + HS - 1) / HS), dim3(512), sizeof(float) * (size_t)(HS * F + 8 * HS * 64),
-                           ppt_stream(stream), feat, w, logit_scale, B, F, E, spc);
+                           ppt_stream(stream), feat, w, logit_scale, B, F, E, spc, ppt_get_wave_priority());
     else
         hipLaunchKernelGGL(head_project_kernel, dim3((E + 63) / 64, B), dim3(HT), sizeof(float) * (size_t)(F + 256), ppt_stream(stream),
                            feat, w, logit_scale, F, E, spc);
     PPT_CHECK_LAUNCH();
-    hipLaunchKernelGGL(head_logits_kernel, dim3((B * C + 15) / 16), dim3(1024), 0, ppt_stream(stream), spc, text, B, E, C, logits);
+    hipLaunchKernelGGL(head_logits_kernel, dim3((B * C + 15) / 16), dim3(1024), 0, ppt_stream(stream), spc, text, B, E, C, logits, ppt_get_wave_priority());
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }
@@ -207,7 +210,7 @@ extern "C" int ppt_rows_matmul_f32(const float *A, const float *W, int M, int K,
     if (!A || !W || !out || M <= 0 || K <= 0 || N <= 0) return PPT_EINVAL;
     if (K > 1536 || (K % 32) != 0 || M > 65535 * HS || (((uintptr_t)A) & 15)) return PPT_EUNSUPPORTED;
     hipLaunchKernelGGL(head_project8_kernel, dim3((N + 63) / 64, (M + HS - 1) / HS), dim3(512), sizeof(float) * (size_t)(HS * K + 8 * HS * 64),
-                       ppt_stream(stream), A, W, (const float *)nullptr, M, K, N, out);
+                       ppt_stream(stream), A, W, (const float *)nullptr, M, K, N, out, ppt_get_wave_priority());
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }
@@ -218,7 +221,7 @@ extern "C" int ppt_head_ce_bwd(const float *logits, const int64_t *labels, const
     if (!logits || !labels || !spc || !text || !loss || !d_text || B <= 0 || E <= 0 || C <= 0) return PPT_EINVAL;
     if (B > 4096) return PPT_EUNSUPPORTED;
     hipLaunchKernelGGL(head_ce_bwd_kernel, dim3(C), dim3(CT), sizeof(float) * (size_t)(2 * B), ppt_stream(stream), logits, labels,
-                       spc, text, smoothing, B, E, C, loss, d_text);
+                       spc, text, smoothing, B, E, C, loss, d_text, ppt_get_wave_priority());
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }

@@ -62,8 +62,9 @@ __global__ __launch_bounds__(256) void ln_fwd_vec8_kernel(const float *__restric
                                                           int add_rows, float *__restrict__ xs,
                                                           const float *__restrict__ w, const float *__restrict__ b,
                                                           TY *__restrict__ y, float *__restrict__ mean_out,
-                                                          float *__restrict__ rstd_out, int M, int D, float eps)
+                                                          float *__restrict__ rstd_out, int M, int D, float eps, int prio)
 {
+    PPT_PRIO(prio);
     const int lane = threadIdx.x & 63;
     const int nw = gridDim.x * 4;
     const bool on = lane * 8 < D;
@@ -122,8 +123,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ d
                                                      const float *__restrict__ rstd, float *__restrict__ dx,
                                                      int accumulate, void *__restrict__ dx_copy, int copy_dtype,
                                                      float *__restrict__ dw_part,
-                                                     float *__restrict__ db_part, int rpw, int M, int D)
+                                                     float *__restrict__ db_part, int rpw, int M, int D, int prio)
 {
+    PPT_PRIO(prio);
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int r0 = g * rpw, r1 = min(M, r0 + rpw);
@@ -187,10 +189,10 @@ extern "C" int ppt_layernorm_fwd(const float *x, const float *add, int add_rows,
         dim3 vgrid(min((M + 3) / 4, 256 * 8));         // 8 workgroups per CU; each wave walks rows with that stride
         if (y_dtype == PPT_BF16)
             hipLaunchKernelGGL(ln_fwd_vec8_kernel<bf16_t>, vgrid, dim3(256), 0, ppt_stream(stream), x, add, add_rows, xs, w, b,
-                               (bf16_t *)y, mean, rstd, M, D, eps);
+                               (bf16_t *)y, mean, rstd, M, D, eps, ppt_get_wave_priority());
         else
             hipLaunchKernelGGL(ln_fwd_vec8_kernel<float>, vgrid, dim3(256), 0, ppt_stream(stream), x, add, add_rows, xs, w, b,
-                               (float *)y, mean, rstd, M, D, eps);
+                               (float *)y, mean, rstd, M, D, eps, ppt_get_wave_priority());
         PPT_CHECK_LAUNCH();
         return PPT_OK;
     }
@@ -224,7 +226,7 @@ extern "C" int ppt_layernorm_bwd(const float *dy, const float *xs, const float *
         (void)hipMemsetAsync(db_partial + (size_t)used * D, 0, sizeof(float) * (size_t)(partial_rows - used) * D, ppt_stream(stream));
     }
     hipLaunchKernelGGL(ln_bwd_kernel, dim3((used + 3) / 4), dim3(256), 0, ppt_stream(stream), dy, xs, w, mean, rstd, dx,
-                       accumulate_dx, dx_copy, dx_copy_dtype, dw_partial, db_partial, rpw, M, D);
+                       accumulate_dx, dx_copy, dx_copy_dtype, dw_partial, db_partial, rpw, M, D, ppt_get_wave_priority());
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }

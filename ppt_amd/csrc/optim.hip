@@ -15,8 +15,9 @@ namespace {
 
 __global__ __launch_bounds__(256) void adamw_step_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
                                                          float *__restrict__ v, int64_t n, float decay, float omb1, float b2,
-                                                         float omb2, float inv_sqrt_bc2, float eps, float step_size)
+                                                         float omb2, float inv_sqrt_bc2, float eps, float step_size, int prio)
 {
+    PPT_PRIO(prio);
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float gi = g[i];
@@ -30,8 +31,9 @@ __global__ __launch_bounds__(256) void adamw_step_kernel(float *__restrict__ p, 
 
 __global__ __launch_bounds__(256) void prompt_rows_kernel(const float *__restrict__ base, const int *__restrict__ slot,
                                                           const float *__restrict__ tokens, const float *__restrict__ pos_rows,
-                                                          int rows, int W, float *__restrict__ out)
+                                                          int rows, int W, float *__restrict__ out, int prio)
 {
+    PPT_PRIO(prio);
     const int w4 = W >> 2;
     const int64_t total = (int64_t)rows * w4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -51,8 +53,9 @@ __global__ __launch_bounds__(256) void prompt_rows_kernel(const float *__restric
 
 // one thread per (token, 4 columns); the token's rows are listed (ascending) in rows_of[token * max_rows ...], -1 terminated
 __global__ __launch_bounds__(256) void prompt_rows_bwd_kernel(const float *__restrict__ g, const int *__restrict__ rows_of, int max_rows,
-                                                              int n_tok, int W, float *__restrict__ d_tokens)
+                                                              int n_tok, int W, float *__restrict__ d_tokens, int prio)
 {
+    PPT_PRIO(prio);
     const int w4 = W >> 2;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_tok * w4) return;
@@ -84,7 +87,7 @@ extern "C" int ppt_adamw_step(float *p, const float *g, float *exp_avg, float *e
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     hipLaunchKernelGGL(adamw_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ppt_stream(stream), p, g, exp_avg, exp_avg_sq, n,
                        (float)(1.0 - (double)lr * weight_decay), 1.0f - beta1, beta2, 1.0f - beta2, (float)(1.0 / sqrt(bc2)), eps,
-                       (float)((double)lr / bc1));
+                       (float)((double)lr / bc1), ppt_get_wave_priority());
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }
@@ -95,7 +98,7 @@ extern "C" int ppt_prompt_rows(const float *base, const int *slot, const float *
     if (!base || !slot || !tokens || !pos_rows || !out || rows <= 0 || W <= 0 || (W & 3)) return PPT_EINVAL;
     const int64_t total = (int64_t)rows * (W / 4);
     hipLaunchKernelGGL(prompt_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ppt_stream(stream), base, slot, tokens,
-                       pos_rows, rows, W, out);
+                       pos_rows, rows, W, out, ppt_get_wave_priority());
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }
@@ -104,7 +107,7 @@ extern "C" int ppt_prompt_rows_bwd(const float *g, const int *rows_of, int max_r
 {
     if (!g || !rows_of || !d_tokens || max_rows <= 0 || n_tok <= 0 || W <= 0 || (W & 3)) return PPT_EINVAL;
     hipLaunchKernelGGL(prompt_rows_bwd_kernel, dim3((n_tok * (W / 4) + 255) / 256), dim3(256), 0, ppt_stream(stream), g, rows_of, max_rows,
-                       n_tok, W, d_tokens);
+                       n_tok, W, d_tokens, ppt_get_wave_priority());
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }

@@ -141,3 +141,13 @@ __device__ __forceinline__ void ppt_store16_stream(void *p, uint4 v)
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
     __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, v), reinterpret_cast<u32x4_t *>(p));
 }
+
+// Wave priority of the prompt chain's kernels (s_setprio: issue arbitration among the waves of a SIMD; 0 is the default).  When
+// only the prompt trains, the chain -- text backward, AdamW, text forward, head: ~200 small dependent kernels -- is the critical
+// path of the step and its waves share SIMDs with the point tower's; with priority 3 they are issued first.  Same-box A/B
+// (tools/build_variant.sh + tools/ab_env.py): C2 3.716 -> 3.676 ms, C4 2.989 -> 2.821 ms per step; where the point side trains
+// (C3, C5) the tower is the critical path and the same setting costs 0.2-0.5 %, so it is a RUN-TIME property of the launch:
+// ppt_set_wave_priority(n) (per host thread) applies to every launch that follows, the kernels take it as an argument.
+// (HIP STREAM priority, by contrast, changed nothing: it orders kernel dispatch, not the waves already resident.)
+extern "C" int ppt_get_wave_priority(void);
+#define PPT_PRIO(prio) do { if (prio) __builtin_amdgcn_s_setprio(3); } while (0)

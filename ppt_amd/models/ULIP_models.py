@@ -280,10 +280,13 @@ class _TextTowerFn(torch.autograd.Function):
         eff = model._text_len() if model.truncate_text_to_eot else None
         pre = model.prompt_learner.shared_prefix() if model.share_text_prefix else 0
 
-        def run(pr):
-            return engine.text_tower_forward(sd, cache, pr, eot, heads, layers, save, eff_len=eff, prefix=pre)
+        prio = model.chain_priority()
 
-        key = ("text_fwd", tuple(prompts.shape), save, eff, pre, cache.dtype)
+        def run(pr):
+            with ops.wave_priority(prio):
+                return engine.text_tower_forward(sd, cache, pr, eot, heads, layers, save, eff_len=eff, prefix=pre)
+
+        key = ("text_fwd", tuple(prompts.shape), save, eff, pre, cache.dtype, prio)
         gc = model._graphs
         ctx.model, ctx.graph = model, None
         if prompts.is_cuda and model.use_hip_graphs and ops.profiler is None and gc.ready(key):
@@ -310,8 +313,10 @@ class _TextTowerFn(torch.autograd.Function):
         dout = dout.float()
         if dout.is_cuda:
             dout.record_stream(torch.cuda.current_stream())     # produced on the caller's stream, read on the text stream
+        prio = m.chain_priority()
         if ctx.graph is None:
-            return None, engine.text_tower_backward(sd, cache, ctx.saved, dout)
+            with ops.wave_priority(prio):
+                return None, engine.text_tower_backward(sd, cache, ctx.saved, dout)
         if ctx.graph.generation != ctx.generation:
             raise RuntimeError("the text tower's captured activations were overwritten by a later forward; set "
                                "model.use_hip_graphs = False to keep several forwards alive before backward")
@@ -319,7 +324,8 @@ class _TextTowerFn(torch.autograd.Function):
 
         def build():
             def fn(d):
-                return (engine.text_tower_backward(sd, cache, saved, d),), None
+                with ops.wave_priority(prio):
+                    return (engine.text_tower_backward(sd, cache, saved, d),), None
             return graphs.GraphedCall(fn, [dout.contiguous()], pool=fwd.pool())
         (dp,), _ = m._graphs.get(("text_bwd",) + ctx.key[1:], build)(dout)
         return None, dp.clone()
@@ -346,11 +352,14 @@ class _TextTowerTokensFn(torch.autograd.Function):
         base, slot, pos_rows, rows_of, M = pl.row_layout(sd["positional_embedding"], eff, pre)
         tok = tokens.detach().float().contiguous()
 
-        def run(tk):
-            x0 = ops.prompt_rows(base, slot, tk, pos_rows)
-            return engine.text_tower_forward(sd, cache, None, eot, heads, layers, save, eff_len=eff, prefix=pre, rows_in=(x0, C, Lfull))
+        prio = model.chain_priority()
 
-        key = ("text_fwd_tok", tuple(tok.shape), save, eff, pre, cache.dtype)
+        def run(tk):
+            with ops.wave_priority(prio):
+                x0 = ops.prompt_rows(base, slot, tk, pos_rows)
+                return engine.text_tower_forward(sd, cache, None, eot, heads, layers, save, eff_len=eff, prefix=pre, rows_in=(x0, C, Lfull))
+
+        key = ("text_fwd_tok", tuple(tok.shape), save, eff, pre, cache.dtype, prio)
         gc = model._graphs
         ctx.model, ctx.graph, ctx.rows_of, ctx.n_tok = model, None, rows_of, tok.shape[0]
         if tok.is_cuda and model.use_hip_graphs and ops.profiler is None and gc.ready(key):
@@ -379,8 +388,11 @@ class _TextTowerTokensFn(torch.autograd.Function):
             dout.record_stream(torch.cuda.current_stream())
         rows_of, n_tok = ctx.rows_of, ctx.n_tok
 
+        prio = m.chain_priority()
+
         def run(d, saved):
-            return ops.prompt_rows_bwd(engine.text_tower_backward(sd, cache, saved, d), rows_of, n_tok)
+            with ops.wave_priority(prio):
+                return ops.prompt_rows_bwd(engine.text_tower_backward(sd, cache, saved, d), rows_of, n_tok)
 
         if ctx.graph is None:
             return None, run(dout.contiguous(), ctx.saved)
@@ -443,10 +455,13 @@ class _HeadLossFn(torch.autograd.Function):
         proj = model.pc_projection.detach()
         feat, traw, lab = pc_feat.detach().float().contiguous(), text_raw.detach().float().contiguous(), labels.contiguous()
 
-        def run(f, t, l):
-            return engine.head_loss_forward_backward(f, wt, t, scale, l, smoothing, w=proj), None
+        prio = model.chain_priority()
 
-        key = ("head", tuple(feat.shape), tuple(traw.shape), float(smoothing))
+        def run(f, t, l):
+            with ops.wave_priority(prio):
+                return engine.head_loss_forward_backward(f, wt, t, scale, l, smoothing, w=proj), None
+
+        key = ("head", tuple(feat.shape), tuple(traw.shape), float(smoothing), prio)
         gc = model._graphs
         if feat.is_cuda and model.use_hip_graphs and ops.profiler is None and gc.ready(key):
             g = gc.get(key, lambda: graphs.GraphedCall(run, [feat, traw, lab]))
@@ -508,6 +523,7 @@ class ULIP_WITH_IMAGE(nn.Module):
         self.fused_prompt_rows = os.environ.get("PPT_FUSED_PROMPT_ROWS", "1") != "0"     # PromptLearner splice + pos add: one kernel
         # positions in front of the class name are the same in every prompt: computed once (PPT_SHARE_TEXT_PREFIX=0: A/B runs)
         self.share_text_prefix = os.environ.get("PPT_SHARE_TEXT_PREFIX", "1") != "0"
+        self._chain_prio = None
         self._handoff = False               # inside forward_loss: graph outputs go straight into the next graph's input (no clone)
         self._handoff_grad = os.environ.get("PPT_HANDOFF", "1") != "0"
 
@@ -564,6 +580,22 @@ class ULIP_WITH_IMAGE(nn.Module):
             self._sd = (sd, ref, ref.device)
         return self._sd[0]
 
+    def chain_priority(self):
+        """1 when the prompt chain is the step's critical path -- nothing but the PromptLearner trains, so the point tower
+        never waits for the optimizer -- else 0 (a training point side makes the tower critical: measured +0.2-0.5 % step
+        time with the chain prioritised on C3 / C5).  PPT_CHAIN_PRIO=0|1 overrides.  See csrc/ppt_common.h PPT_PRIO."""
+        if self._chain_prio is None:
+            env = os.environ.get("PPT_CHAIN_PRIO")
+            if env in ("0", "1"):
+                self._chain_prio = int(env)
+            else:
+                # (a frozen encoder whose tower is much longer than the chain -- PointMLP: 4.6 ms -- is the critical path itself:
+                # 4.655 -> 4.686 ms with the chain prioritised; such encoders carry chain_priority_hint = 0)
+                hint = getattr(self.point_encoder, "chain_priority_hint", 1)
+                self._chain_prio = int(bool(hint) and all(n.startswith("prompt_learner.") or not q.requires_grad
+                                                          for n, q in self.named_parameters()))
+        return self._chain_prio
+
     def reset_caches(self):
         """Drop everything derived from parameter / buffer STORAGE: the state-dict views, the operand copies of the
         weights and every captured hipGraph (a graph bakes in the device pointers of what it read) -- of this module
@@ -573,6 +605,7 @@ class ULIP_WITH_IMAGE(nn.Module):
         self._sd = None
         self._wc = None
         self._te_cache = None
+        self._chain_prio = None
         self._graphs.clear()
         pe = getattr(self, "point_encoder", None)
         if pe is not None:

@@ -80,6 +80,8 @@ class Model(nn.Module):
     Build-specific knobs: `precision` (bf16 / fp32 parity), `fps_start` = one start vector [B] per stage and
     `dropout_masks` = (m1 [B,512], m2 [B,256]) to inject the RNG draws of the path in parity tests."""
 
+    chain_priority_hint = 0     # ULIP_WITH_IMAGE.chain_priority: this tower (4.6 ms) is the step's critical path, not the prompt chain
+
     def __init__(self, points=1024, embed_dim=64, groups=1, res_expansion=1.0, activation="relu", bias=True, use_xyz=True,
                  normalize="center", dim_expansion=[2, 2, 2, 2], pre_blocks=[2, 2, 2, 2], pos_blocks=[2, 2, 2, 2],
                  k_neighbors=[32, 32, 32, 32], reducers=[2, 2, 2, 2], **kwargs):

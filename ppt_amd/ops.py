@@ -234,6 +234,21 @@ def gemm(A, B, *, out=None, out_dtype=None, M=None, bias=None, act=ACT_NONE, dac
     return out
 
 
+class wave_priority:
+    """with ops.wave_priority(1): every launch made inside raises its waves' issue priority (ppt_set_wave_priority; the
+    kernels of the prompt chain take it as an argument, so a hipGraph captured inside keeps it)."""
+
+    def __init__(self, prio):
+        self.prio = int(bool(prio))
+
+    def __enter__(self):
+        self.old = _lib.lib().ppt_get_wave_priority()
+        _lib.lib().ppt_set_wave_priority(self.prio)
+
+    def __exit__(self, *exc):
+        _lib.lib().ppt_set_wave_priority(self.old)
+
+
 def rows_matmul(a, w_kn):
     """out [M,N] = a [M,K] @ w_kn [K,N], fp32, for a few rows (ppt_rows_matmul_f32) -- None when the shape is not covered."""
     _chk(a, torch.float32, "a"); _chk(w_kn, torch.float32, "w_kn")

@@ -234,7 +234,8 @@ class Trainer:
             opt.step()
             return
         from . import ops
-        with torch.no_grad():
+        prio = self.model.chain_priority() if hasattr(self.model, "chain_priority") else 0
+        with torch.no_grad(), ops.wave_priority(prio):
             for g, p in params:
                 st = opt.state[p]
                 if not st:                                   # the layout torch.optim.AdamW._init_group creates

@@ -1001,6 +1001,33 @@ def test_ball_query_multi_equals_the_single_queries(ops, B, N, S, qs):
     assert all(g is None for _, g in plain) and all(torch.equal(a[0], b[0]) for a, b in zip(plain, outs))
 
 
+def test_wave_priority_changes_no_result(ops):
+    """ppt_set_wave_priority only raises the issue priority of the waves (s_setprio): GEMM, LayerNorm forward / backward and
+    the short-sequence attention backward give bit-identical results with it on."""
+    g = torch.Generator().manual_seed(0)
+    a = torch.randn(817, 512, generator=g).cuda().to(torch.bfloat16)
+    w = (torch.randn(1536, 512, generator=g) * 0.05).cuda().to(torch.bfloat16)
+    x = torch.randn(817, 512, generator=g).cuda()
+    gam, bet = (1 + 0.1 * torch.randn(512, generator=g)).cuda(), (0.1 * torch.randn(512, generator=g)).cuda()
+    qkv = torch.randn(817, 1536, generator=g).cuda().to(torch.bfloat16)
+
+    def run():
+        c = ops.gemm(a, w, out_dtype=torch.float32)
+        y, mean, rstd = ops.layernorm_fwd(x, gam, bet, torch.bfloat16, save_stats=True)
+        dx = ops.layernorm_bwd(c[:, :512].contiguous(), x, gam, mean, rstd)[0]
+        o, lse = ops.attention_prefix_fwd(qkv, 40, 37, 17, 8, 0.125)
+        dq = ops.attention_prefix_bwd(qkv, o, o, lse, 40, 37, 17, 8, 0.125)
+        return c, y, dx, o, dq
+    plain = run()
+    assert ops._lib.lib().ppt_get_wave_priority() == 0
+    with ops.wave_priority(1):
+        assert ops._lib.lib().ppt_get_wave_priority() == 1
+        hi = run()
+    assert ops._lib.lib().ppt_get_wave_priority() == 0
+    for p_, h_ in zip(plain, hi):
+        assert torch.equal(p_, h_)
+
+
 def test_adamw_step_matches_torch(ops):
     """ppt_adamw_step against torch.optim.AdamW (main_cls.py:58-60 hyper-parameters) over several steps with a changing lr."""
     g = torch.Generator().manual_seed(0)

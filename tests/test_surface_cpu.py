@@ -40,6 +40,18 @@ def test_trainable_sets(head_type, count):
     assert m.point_encoder._tier() == head_type
 
 
+@pytest.mark.parametrize("head_type,prio", [(0, 1), (1, 0), (3, 0)])
+def test_chain_priority_follows_the_trainable_set(head_type, prio, monkeypatch):
+    """The prompt chain's kernels raise their wave priority only when nothing but the PromptLearner trains (the chain is then the
+    step's critical path; with a training point side the tower is).  PPT_CHAIN_PRIO overrides."""
+    monkeypatch.delenv("PPT_CHAIN_PRIO", raising=False)
+    m, _ = make(head_type)
+    assert m.chain_priority() == prio
+    monkeypatch.setenv("PPT_CHAIN_PRIO", str(1 - prio))
+    m.reset_caches()
+    assert m.chain_priority() == 1 - prio
+
+
 def test_surface_attributes():
     m, models = make(3)
     assert models.get_metric_names() == ['loss', 'acc']
