@@ -150,6 +150,13 @@ int ppt_gemm(const ppt_gemm_params *p, void *stream);
  * prompt chain -- ppt_gemm's 64x64 tile loop, LayerNorm forward / backward, the causal / short attention kernels, the head,
  * AdamW and prompt-row kernels.  For callers whose critical path is the text side (only the prompt trains); default 0. */
 void ppt_set_wave_priority(int prio);
+/* Percent (10..100, default 100) of the CUs the persistent point-tower kernels of this host thread's following launches take
+ * (ppt_mini_pointnet_conv12 / conv3 / conv4_bf16: one long-lived workgroup per CU, HBM-bound -- alone they are as fast on 60 %
+ * of the CUs' wave slots as on all).  A workgroup that lives for the whole kernel frees its CU only when the kernel ends, so
+ * while such a kernel covers the chip, the small kernels of the prompt chain on the other stream wait: when that chain is the
+ * step's critical path (only the prompt trains), leaving it CUs shortens the step (C2: 3.67 -> 3.50 ms at 60 %). */
+void ppt_set_persistent_occupancy(int percent);
+int ppt_get_persistent_occupancy(void);
 int ppt_get_wave_priority(void);
 
 /* ---- short-K linears with the weight stationary in registers (csrc/rowgemm.hip) --------------------------------

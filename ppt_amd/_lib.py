@@ -62,6 +62,8 @@ _SIGNATURES = {
     "ppt_abi_version": (c_int, []),
     "ppt_set_wave_priority": (None, [c_int]),
     "ppt_get_wave_priority": (c_int, []),
+    "ppt_set_persistent_occupancy": (None, [c_int]),
+    "ppt_get_persistent_occupancy": (c_int, []),
     "ppt_rows_matmul_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ppt_fps_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ppt_knn_group_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -17,3 +17,7 @@ extern "C" int ppt_abi_version(void) { return 2; }   // 2: + ppt_bn_finalize_ws,
 static thread_local int g_wave_priority = 0;
 extern "C" void ppt_set_wave_priority(int prio) { g_wave_priority = prio > 0 ? 1 : 0; }
 extern "C" int ppt_get_wave_priority(void) { return g_wave_priority; }
+
+static thread_local int g_persistent_percent = 100;
+extern "C" void ppt_set_persistent_occupancy(int percent) { g_persistent_percent = percent < 10 ? 10 : (percent > 100 ? 100 : percent); }
+extern "C" int ppt_get_persistent_occupancy(void) { return g_persistent_percent; }

@@ -143,7 +143,9 @@ int mpn1_grid(int64_t tiles, int nwm)
         return n > 0 ? n : 256;
     }();
     const int64_t blocks = (tiles + nwm - 1) / nwm;
-    return (int)(blocks < (int64_t)cus * 3 ? blocks : (int64_t)cus * 3);
+    int64_t want = (int64_t)cus * 3 * ppt_get_persistent_occupancy() / 100;        // (ppt_set_persistent_occupancy)
+    want = want < 8 ? 8 : want;
+    return (int)(blocks < want ? blocks : want);
 }
 
 }  // namespace

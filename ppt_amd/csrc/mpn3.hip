@@ -8,6 +8,7 @@
 // 32 x 64 bf16 block out through a wave-private LDS transpose as 128-byte row pieces.  Same k order as the generic path:
 // y3 is bit-identical.
 #include "ppt_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -130,7 +131,11 @@ extern "C" int ppt_mini_pointnet_conv3_bf16(const void *A, int64_t M, int K, con
         return n > 0 ? n : 256;
     }();
     const int64_t tiles = M / 32;
-    const int grid = (int)(tiles < (int64_t)cus * 2 ? tiles : (int64_t)cus * 2);
+    // ONE persistent workgroup per CU (alone the kernel is HBM-bound and as fast as with two: C2 tower 2.765 vs 2.776 ms), fewer
+    // when the caller leaves room for the other stream (ppt_set_persistent_occupancy)
+    int64_t want = (int64_t)cus * ppt_get_persistent_occupancy() / 100;
+    want = want < 8 ? 8 : want;
+    const int grid = (int)(tiles < want ? tiles : want);
     if (part_sum)
         hipLaunchKernelGGL(mpn3_kernel<true>, dim3(grid), dim3(512), lds, ppt_stream(stream), (const bf16_t *)A, (int)tiles,
                            (const bf16_t *)W, gterm, (bf16_t *)y, part_sum, part_m2);

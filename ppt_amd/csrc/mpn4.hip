@@ -10,6 +10,7 @@
 // the max over the rows out of its accumulator.  Two LDS buffers, one barrier per group; the next group's global loads are
 // issued before the MFMA loop.  Same affine expression and k order as the generic path: bit-identical maxima.
 #include "ppt_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -97,7 +98,11 @@ extern "C" int ppt_mini_pointnet_conv4_bf16(const void *A, int64_t M, int K, con
         return n > 0 ? n : 256;
     }();
     const int64_t tiles = M / 32;
-    const int grid = (int)(tiles < (int64_t)cus * 2 ? tiles : (int64_t)cus * 2);
+    // ONE persistent workgroup per CU (alone the kernel is HBM-bound and as fast as with two: C2 tower 2.765 vs 2.776 ms), fewer
+    // when the caller leaves room for the other stream (ppt_set_persistent_occupancy)
+    int64_t want = (int64_t)cus * ppt_get_persistent_occupancy() / 100;
+    want = want < 8 ? 8 : want;
+    const int grid = (int)(tiles < want ? tiles : want);
     hipLaunchKernelGGL(mpn4_kernel, dim3(grid), dim3(512), lds, ppt_stream(stream), (const bf16_t *)A, (int)tiles, a_scale, a_shift,
                        (const bf16_t *)W, bias, (bf16_t *)tok);
     PPT_CHECK_LAUNCH();

@@ -151,3 +151,7 @@ __device__ __forceinline__ void ppt_store16_stream(void *p, uint4 v)
 // (HIP STREAM priority, by contrast, changed nothing: it orders kernel dispatch, not the waves already resident.)
 extern "C" int ppt_get_wave_priority(void);
 #define PPT_PRIO(prio) do { if (prio) __builtin_amdgcn_s_setprio(3); } while (0)
+
+// Share of the chip the PERSISTENT point-tower kernels (one long-lived workgroup per CU: the mini-PointNet kernels) size their
+// grids for, in percent; see ppt_set_persistent_occupancy in include/ppt_hip.h.
+extern "C" int ppt_get_persistent_occupancy(void);

@@ -596,6 +596,14 @@ class ULIP_WITH_IMAGE(nn.Module):
                                                           for n, q in self.named_parameters()))
         return self._chain_prio
 
+    def _tower_room(self):
+        """Context for the point tower's launches of a TRAINING step whose critical path is the prompt chain (chain_priority):
+        its persistent kernels leave CUs to the text stream (ops.persistent_occupancy; PPT_TOWER_OCCUPANCY percent, default 60:
+        C2 3.67 -> 3.50 ms per step, the optimum of 200 / 150 / 100 / 75 / 60 / 50 / 40 / 30 % of a workgroup per CU)."""
+        if self.training and torch.is_grad_enabled() and self.chain_priority():
+            return ops.persistent_occupancy(int(os.environ.get("PPT_TOWER_OCCUPANCY", "60")))
+        return contextlib.nullcontext()
+
     def reset_caches(self):
         """Drop everything derived from parameter / buffer STORAGE: the state-dict views, the operand copies of the
         weights and every captured hipGraph (a graph bakes in the device pointers of what it read) -- of this module
@@ -689,7 +697,8 @@ class ULIP_WITH_IMAGE(nn.Module):
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 text_embed = self._text_embed()
-        pc_embed = self.encode_pc(pc, cls_label) if self.task == 'partseg' else self.encode_pc(pc)
+        with self._tower_room():
+            pc_embed = self.encode_pc(pc, cls_label) if self.task == 'partseg' else self.encode_pc(pc)
         if side is not None:
             cur.wait_stream(side)
             text_embed.record_stream(cur)
@@ -719,12 +728,13 @@ class ULIP_WITH_IMAGE(nn.Module):
             # the caller vouched that `pc` is complete in memory (train.Trainer.inputs_ready): the frozen point tower runs on
             # a stream of its own that waits for nothing -- the caller's stream, which stalls at the head until the prompt
             # chain of the previous iteration has finished, then no longer holds the NEXT iteration's tower back
-            with torch.cuda.stream(tw):
+            with torch.cuda.stream(tw), self._tower_room():
                 pc_feat = self.point_encoder(pc)
             cur.wait_stream(tw)
             pc_feat.record_stream(cur)
         else:
-            pc_feat = self.point_encoder(pc)
+            with self._tower_room():
+                pc_feat = self.point_encoder(pc)
         if side is not None:
             cur.wait_stream(side)
             text_raw.record_stream(cur)

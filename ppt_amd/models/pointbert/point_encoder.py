@@ -132,7 +132,7 @@ class _PointEncoderFn(torch.autograd.Function):
             torch.cuda.current_stream().wait_event(module.param_gate)
             module.param_gate = None
         has_dp = (train and module.drop_path_rate > 0) if drawn else dp is not None
-        key = ("point_fwd", tuple(pc.shape), has_dp, drawn, train, cache.dtype)
+        key = ("point_fwd", tuple(pc.shape), has_dp, drawn, train, cache.dtype, ops.get_persistent_occupancy() if pc.is_cuda else 100)
         ahead = module.group_ahead if (use_graph and module._graphs.ready(("group", tuple(pc.shape), drawn))) else None
         if not split and use_graph and module._graphs.ready(key):
             if ahead is not None:
@@ -165,7 +165,7 @@ class _PointEncoderFn(torch.autograd.Function):
             # something in the last block trains: everything in front of it is still frozen.  That prefix is replayed
             # from a hipGraph, and only the rest waits for the optimizer of the previous iteration (module.param_gate,
             # set by train.Trainer.step) -- the prefix runs ahead of it like the whole tower does for head_type 0.
-            key = ("point_prefix", tuple(pc.shape), has_dp, drawn, train, cache.dtype)
+            key = ("point_prefix", tuple(pc.shape), has_dp, drawn, train, cache.dtype, ops.get_persistent_occupancy() if pc.is_cuda else 100)
             if use_graph and module._graphs.ready(key):
                 slot = None
                 if ahead is not None:

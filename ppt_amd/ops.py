@@ -249,6 +249,25 @@ class wave_priority:
         _lib.lib().ppt_set_wave_priority(self.old)
 
 
+class persistent_occupancy:
+    """with ops.persistent_occupancy(60): the persistent point-tower kernels launched inside size their grids for 60 % of the
+    CUs (ppt_set_persistent_occupancy) -- room for the prompt chain on the other stream."""
+
+    def __init__(self, percent):
+        self.percent = int(percent)
+
+    def __enter__(self):
+        self.old = _lib.lib().ppt_get_persistent_occupancy()
+        _lib.lib().ppt_set_persistent_occupancy(self.percent)
+
+    def __exit__(self, *exc):
+        _lib.lib().ppt_set_persistent_occupancy(self.old)
+
+
+def get_persistent_occupancy():
+    return _lib.lib().ppt_get_persistent_occupancy()
+
+
 def rows_matmul(a, w_kn):
     """out [M,N] = a [M,K] @ w_kn [K,N], fp32, for a few rows (ppt_rows_matmul_f32) -- None when the shape is not covered."""
     _chk(a, torch.float32, "a"); _chk(w_kn, torch.float32, "w_kn")
