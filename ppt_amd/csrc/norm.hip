@@ -176,6 +176,57 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ d
     }
 }
 
+// The input-gradient-only backward (no dw / db: the text tower's LayerNorms are frozen) for D % 8 == 0, D <= 512: one wave per
+// row, a lane owns EIGHT consecutive columns -- two 16-byte loads per tensor, and the row of dx that the result is added to is
+// requested together with dy and xs instead of after the reduction (the scalar kernel's third dependent round trip); the bf16
+// operand copy leaves as one 16-byte store per lane.  8.5 -> ~5 us for 817 x 512 (24 launches per step of the prompt chain).
+__global__ __launch_bounds__(256) void ln_bwd_dx8_kernel(const float *__restrict__ dy, const float *__restrict__ xs,
+                                                         const float *__restrict__ w, const float *__restrict__ mean,
+                                                         const float *__restrict__ rstd, float *__restrict__ dx, int accumulate,
+                                                         void *__restrict__ dx_copy, int copy_dtype, int M, int D, int prio)
+{
+    PPT_PRIO(prio);
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const bool act = lane * 8 < D;
+    const size_t off = (size_t)row * D + lane * 8;
+    float4 d0 = make_float4(0.f, 0.f, 0.f, 0.f), d1 = d0, x0 = d0, x1 = d0, a0 = d0, a1 = d0, w0 = d0, w1 = d0;
+    if (act) {
+        d0 = *reinterpret_cast<const float4 *>(dy + off); d1 = *reinterpret_cast<const float4 *>(dy + off + 4);
+        x0 = *reinterpret_cast<const float4 *>(xs + off); x1 = *reinterpret_cast<const float4 *>(xs + off + 4);
+        w0 = *reinterpret_cast<const float4 *>(w + lane * 8); w1 = *reinterpret_cast<const float4 *>(w + lane * 8 + 4);
+        if (accumulate) { a0 = *reinterpret_cast<const float4 *>(dx + off); a1 = *reinterpret_cast<const float4 *>(dx + off + 4); }
+    }
+    const float mu = mean[row], rs = rstd[row];
+    const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w}, xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w}, av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    float gv[8], xh[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        xh[j] = act ? (xv[j] - mu) * rs : 0.f;
+        gv[j] = dv[j] * wv[j];
+        s1 += gv[j]; s2 += gv[j] * xh[j];
+    }
+    s1 = wave_reduce_sum(s1) / (float)D;
+    s2 = wave_reduce_sum(s2) / (float)D;
+    if (!act) return;
+    float t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = av[j] + rs * (gv[j] - s1 - xh[j] * s2);
+    *reinterpret_cast<float4 *>(dx + off) = make_float4(t[0], t[1], t[2], t[3]);
+    *reinterpret_cast<float4 *>(dx + off + 4) = make_float4(t[4], t[5], t[6], t[7]);
+    if (dx_copy) {
+        if (copy_dtype == PPT_BF16) {
+            *reinterpret_cast<uint4 *>((bf16_t *)dx_copy + off) = make_uint4(pack_bf16x2(t[0], t[1]), pack_bf16x2(t[2], t[3]),
+                                                                              pack_bf16x2(t[4], t[5]), pack_bf16x2(t[6], t[7]));
+        } else {
+            *reinterpret_cast<float4 *>((float *)dx_copy + off) = make_float4(t[0], t[1], t[2], t[3]);
+            *reinterpret_cast<float4 *>((float *)dx_copy + off + 4) = make_float4(t[4], t[5], t[6], t[7]);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int ppt_layernorm_fwd(const float *x, const float *add, int add_rows, float *xs, const float *w,
@@ -216,6 +267,12 @@ extern "C" int ppt_layernorm_bwd(const float *dy, const float *xs, const float *
     if (!dy || !xs || !w || !mean || !rstd || !dx || M <= 0 || D <= 0 || D > 64 * MAX_EPL) return PPT_EINVAL;
     if ((dw_partial == nullptr) != (db_partial == nullptr)) return PPT_EINVAL;
     if (dw_partial && partial_rows <= 0) return PPT_EINVAL;
+    if (!dw_partial && D % 8 == 0 && D <= 512 && ((((uintptr_t)dy | (uintptr_t)xs | (uintptr_t)w | (uintptr_t)dx | (uintptr_t)dx_copy) & 15) == 0)) {
+        hipLaunchKernelGGL(ln_bwd_dx8_kernel, dim3((M + 3) / 4), dim3(256), 0, ppt_stream(stream), dy, xs, w, mean, rstd, dx, accumulate_dx,
+                           dx_copy, dx_copy_dtype, M, D, ppt_get_wave_priority());
+        PPT_CHECK_LAUNCH();
+        return PPT_OK;
+    }
     const int waves = dw_partial ? partial_rows : M;
     const int rpw = (M + waves - 1) / waves;
     // every partial row must be written (rows past the data get zeros from an empty range): the
