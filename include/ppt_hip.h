@@ -321,6 +321,9 @@ int ppt_conv1_stats_rows_per_partial(void);
  * ppt_gn_bwd_apply writes dy [B][Q][K][C] given s12n [B][G][2] = the folded sums divided by n = Q*K*C/G. */
 int ppt_gn_stats_chunks(int R);
 int ppt_gn_bwd_chunks(int Q);
+/* (cloud, group) statistics out of ppt_gn_stats' / ppt_gn_bwd_sums' fp64 chunk partials [B, nch, G, 2], n = elements per group:
+ * mode 0 -> out0 = mean [B,G], out1 = rstd [B,G] (biased variance + eps, nn.GroupNorm); mode 1 -> out0 [B,G,2] = sums / n. */
+int ppt_gn_finish(const double *part, int B, int nch, int G, double n, double eps, int mode, float *out0, float *out1, void *stream);
 int ppt_gn_stats(const float *y, int B, int R, int C, int G, double *part, void *stream);
 int ppt_gn_lrelu_max(const float *y, const float *mean, const float *rstd, const float *gamma, const float *beta, int B, int Q, int K,
                      int C, int G, float slope, float *out, int32_t *arg, void *stream);
@@ -386,6 +389,11 @@ int ppt_bn_res_act_rows(const void *x, int x_dtype, const void *res, int res_dty
  * Needs M % (32 * n_slices) == 0 and N1, N2, lda, ldb multiples of 8. */
 int ppt_gemm_tn_bf16(const void *A, int64_t lda, const void *B, int64_t ldb, int64_t M, int N1, int N2, int n_slices, float *part,
                      void *stream);
+
+/* nn.CrossEntropyLoss(label_smoothing, reduction='mean') over R rows of C <= 96 classes and its gradient (main_partseg.py:213;
+ * main_cls.py:52,196): loss[0], dlogits [R,C] = d loss / d logits; partial: scratch of ceil(R / 128) floats.  Fixed summation order. */
+int ppt_cross_entropy_rows(const float *logits, const int64_t *labels, float smoothing, int64_t R, int C, float *loss, float *dlogits,
+                           float *partial, void *stream);
 
 /* out[M,N] = A[M,K] . W[K,N], fp32, few rows (K <= 1536, K % 32 == 0): the EOT projection `x @ self.text_projection`
  * (ULIP_models.py:222) and its backward.  W row-major as stored ([K,N]). */

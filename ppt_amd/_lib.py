@@ -60,6 +60,8 @@ class RowGemmParams(ctypes.Structure):
 
 _SIGNATURES = {
     "ppt_abi_version": (c_int, []),
+    "ppt_cross_entropy_rows": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ppt_gn_finish": (c_int, [c_void_p, c_int, c_int, c_int, ctypes.c_double, ctypes.c_double, c_int, c_void_p, c_void_p, c_void_p]),
     "ppt_set_wave_priority": (None, [c_int]),
     "ppt_get_wave_priority": (c_int, []),
     "ppt_set_persistent_occupancy": (None, [c_int]),

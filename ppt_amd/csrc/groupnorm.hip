@@ -130,7 +130,43 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float *__restri
     }
 }
 
+// the (cloud, group) statistics out of the chunk partials, one thread each: mode 0 -> mean = S0 / n, rstd = 1 / sqrt(max(S1 / n -
+// mean^2, 0) + eps) (biased variance, as nn.GroupNorm); mode 1 -> (S0 / n, S1 / n) (the two group sums of the backward).  Sums in
+// chunk order, fp64.  Replaces ~9 (forward) / 3 (backward) tiny ATen kernels per GroupNorm layer.
+__global__ __launch_bounds__(256) void gn_finish_kernel(const double *__restrict__ part, int BG, int nch, int G, double n, double eps,
+                                                        int mode, float *__restrict__ o0, float *__restrict__ o1)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= BG) return;
+    const int b = i / G, g = i - b * G;
+    double s0 = 0.0, s1 = 0.0;
+    for (int c = 0; c < nch; ++c) {
+        const double *q = part + (((size_t)b * nch + c) * G + g) * 2;
+        s0 += q[0]; s1 += q[1];
+    }
+    if (mode == 0) {
+        const double mean = s0 / n;
+        double var = s1 / n - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        o0[i] = (float)mean;
+        o1[i] = (float)(1.0 / sqrt(var + eps));
+    } else {
+        o0[2 * i] = (float)(s0 / n);
+        o0[2 * i + 1] = (float)(s1 / n);
+    }
+}
+
 }  // namespace
+
+extern "C" int ppt_gn_finish(const double *part, int B, int nch, int G, double n, double eps, int mode, float *out0, float *out1,
+                             void *stream)
+{
+    if (!part || !out0 || B <= 0 || nch <= 0 || G <= 0 || n <= 0 || (mode == 0 && !out1) || mode < 0 || mode > 1) return PPT_EINVAL;
+    hipLaunchKernelGGL(gn_finish_kernel, dim3((B * G + 255) / 256), dim3(256), 0, ppt_stream(stream), part, B * G, nch, G, n, eps, mode,
+                       out0, out1);
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
 
 extern "C" int ppt_gn_stats_chunks(int R) { return (R + GN_ROWS - 1) / GN_ROWS; }
 extern "C" int ppt_gn_bwd_chunks(int Q) { return (Q + GN_Q - 1) / GN_Q; }

@@ -202,6 +202,67 @@ extern "C" int ppt_head_logits(const float *feat, const float *w, const float *t
     return PPT_OK;
 }
 
+// CrossEntropyLoss(label_smoothing = eps, mean reduction) over R rows of C classes (main_partseg.py:213: R = B x 2048 points,
+// C = 50 parts; main_cls.py:52,196 when the point side trains) AND its gradient in one pass over the logits:
+//   loss_r = (1 - eps) (lse_r - x_r[y_r]) + eps (lse_r - mean_c x_rc);  dlogits_rc = (softmax_rc - ((1 - eps) [c == y_r] + eps / C)) / R.
+// 128 rows per workgroup go through LDS (coalesced both ways), a thread owns a row; per-workgroup loss partials are folded by
+// ce_rows_finish in workgroup order (fixed).  Replaces log_softmax + nll_loss forward / backward + the smoothing ops.
+constexpr int CE_ROWS = 128;
+__global__ __launch_bounds__(CE_ROWS) void ce_rows_kernel(const float *__restrict__ logits, const int64_t *__restrict__ labels, float eps,
+                                                          int64_t R, int C, float *__restrict__ dlogits, float *__restrict__ partial)
+{
+    extern __shared__ float sm[];                         // [CE_ROWS][C + 1] (odd pitch for C even: no bank conflicts on the row walk)
+    __shared__ float red[CE_ROWS];
+    const int pitch = C | 1;
+    const int64_t r0 = (int64_t)blockIdx.x * CE_ROWS;
+    const int nrow = (int)min((int64_t)CE_ROWS, R - r0);
+    for (int i = threadIdx.x; i < nrow * C; i += CE_ROWS) sm[(i / C) * pitch + i % C] = logits[r0 * C + i];
+    __syncthreads();
+    float lr = 0.f;
+    if ((int)threadIdx.x < nrow) {
+        float *x = sm + threadIdx.x * pitch;
+        const int y = (int)labels[r0 + threadIdx.x];
+        float m = x[0], sx = 0.f;
+        for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
+        float z = 0.f;
+        for (int c = 0; c < C; ++c) { z += expf(x[c] - m); sx += x[c]; }
+        const float lse = m + logf(z);
+        lr = (1.0f - eps) * (lse - x[y]) + eps * (lse - sx / (float)C);
+        const float inv_r = 1.0f / (float)R, base = eps / (float)C;
+        for (int c = 0; c < C; ++c) x[c] = (expf(x[c] - lse) - (base + (c == y ? 1.0f - eps : 0.f))) * inv_r;
+    }
+    red[threadIdx.x] = lr;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nrow * C; i += CE_ROWS) dlogits[r0 * C + i] = sm[(i / C) * pitch + i % C];
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < CE_ROWS; ++i) t += red[i];
+        partial[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(64) void ce_rows_finish(const float *__restrict__ partial, int n, float inv_r, float *__restrict__ loss)
+{
+    if (threadIdx.x) return;
+    double t = 0.0;
+    for (int i = 0; i < n; ++i) t += (double)partial[i];
+    loss[0] = (float)(t * (double)inv_r);
+}
+
+extern "C" int ppt_cross_entropy_rows(const float *logits, const int64_t *labels, float smoothing, int64_t R, int C, float *loss,
+                                      float *dlogits, float *partial, void *stream)
+{
+    if (!logits || !labels || !loss || !dlogits || !partial || R <= 0 || C <= 0) return PPT_EINVAL;
+    if (C > 96) return PPT_EUNSUPPORTED;                  // (rows stay in LDS: CE_ROWS x (C | 1) floats)
+    const int nwg = (int)((R + CE_ROWS - 1) / CE_ROWS);
+    hipLaunchKernelGGL(ce_rows_kernel, dim3(nwg), dim3(CE_ROWS), sizeof(float) * (size_t)CE_ROWS * (C | 1), ppt_stream(stream), logits, labels,
+                       smoothing, R, C, dlogits, partial);
+    PPT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ce_rows_finish, dim3(1), dim3(64), 0, ppt_stream(stream), partial, nwg, 1.0f / (float)R, loss);
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
 // out[M,N] = A[M,K] . W[K,N] in fp32 for a FEW rows (the text tower's EOT projection x @ text_projection, ULIP_models.py:222, and
 // its backward: 40 rows): head_project8_kernel without the scale.  The fp32 MFMA tile loop ran these 10 MFLOP in 18.9 us (eight
 // workgroups walking K serially); here ~4 us.

@@ -249,6 +249,18 @@ class wave_priority:
         _lib.lib().ppt_set_wave_priority(self.old)
 
 
+def cross_entropy_rows(logits, labels, smoothing):
+    """(loss 0-d, dlogits [R,C]) of nn.CrossEntropyLoss(label_smoothing=smoothing) with mean reduction (ppt_cross_entropy_rows)."""
+    _chk(logits, torch.float32, "logits"); _chk(labels, torch.int64, "labels")
+    R, C = logits.shape
+    loss = torch.empty((), dtype=torch.float32, device=logits.device)
+    dlogits = torch.empty_like(logits)
+    partial = torch.empty(((R + 127) // 128,), dtype=torch.float32, device=logits.device)
+    _lib.check(_lib.lib().ppt_cross_entropy_rows(_p(logits), _p(labels), float(smoothing), R, C, _p(loss), _p(dlogits), _p(partial),
+                                                 _stream()), "ppt_cross_entropy_rows")
+    return loss, dlogits
+
+
 class persistent_occupancy:
     """with ops.persistent_occupancy(60): the persistent point-tower kernels launched inside size their grids for 60 % of the
     CUs (ppt_set_persistent_occupancy) -- room for the prompt chain on the other stream."""
@@ -611,12 +623,10 @@ def gn_lrelu_max_forward(y, gamma, beta, groups, eps, slope):
     nch = L.ppt_gn_stats_chunks(Q * K)
     part = torch.empty((B, nch, groups, 2), dtype=torch.float64, device=y.device)
     _lib.check(L.ppt_gn_stats(_p(y), B, Q * K, C, groups, _p(part), _stream()), "ppt_gn_stats")
-    s = part.sum(1)                                                   # [B,G,2], fixed order
     n = float(Q * K * (C // groups))
-    mean = s[..., 0] / n
-    var = (s[..., 1] / n - mean * mean).clamp_min(0.0)                # biased, as nn.GroupNorm
-    rstd = (var + eps).rsqrt()
-    mean, rstd = mean.float().contiguous(), rstd.float().contiguous()
+    mean = torch.empty((B, groups), dtype=torch.float32, device=y.device)
+    rstd = torch.empty((B, groups), dtype=torch.float32, device=y.device)
+    _lib.check(L.ppt_gn_finish(_p(part), B, nch, groups, n, float(eps), 0, _p(mean), _p(rstd), _stream()), "ppt_gn_finish")   # biased, as nn.GroupNorm
     out = torch.empty((B, Q, C), dtype=torch.float32, device=y.device)
     arg = torch.empty((B, Q, C), dtype=torch.int32, device=y.device)
     _lib.check(L.ppt_gn_lrelu_max(_p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), B, Q, K, C, groups, slope, _p(out), _p(arg),
@@ -635,7 +645,8 @@ def gn_lrelu_max_backward(y, dout, out, arg, mean, rstd, gamma, groups, slope):
     _lib.check(L.ppt_gn_bwd_sums(_p(y), _p(dout), _p(out), _p(arg), _p(mean), _p(rstd), _p(gamma), B, Q, K, C, groups, slope,
                                  _p(psum), _p(pgb), _stream()), "ppt_gn_bwd_sums")
     n = float(Q * K * (C // groups))
-    s12n = (psum.sum(1) / n).float().contiguous()                     # [B,G,2]
+    s12n = torch.empty((B, groups, 2), dtype=torch.float32, device=y.device)
+    _lib.check(L.ppt_gn_finish(_p(psum), B, nch, groups, n, 0.0, 1, _p(s12n), None, _stream()), "ppt_gn_finish")
     gb = reduce_rows(pgb.view(B * nch, 2 * C))                        # [2C] interleaved (dgamma, dbeta)
     dy = torch.empty_like(y)
     _lib.check(L.ppt_gn_bwd_apply(_p(y), _p(dout), _p(out), _p(arg), _p(mean), _p(rstd), _p(gamma), _p(s12n), B, Q, K, C, groups,

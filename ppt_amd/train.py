@@ -32,31 +32,64 @@ class FlatGradSync:
     gradients.  64 KiB (head_type 0) ... 7.2 MB (head_type 3) per step -- latency-bound on xGMI, so
     one call beats any bucketing."""
 
-    def __init__(self, params, process_group=None):
+    def __init__(self, params, process_group=None, lazy=False):
+        """lazy=False: .grad of every trainable parameter IS a view of the flat buffer (autograd accumulates into it).
+        lazy=True (train.Trainer): zero() only drops the .grad references -- autograd then ASSIGNS each gradient instead of
+        adding it into a zeroed view (one ATen add per parameter per step: 46 of them in the part-seg step) -- and
+        all_reduce() packs the gradients into the flat buffer with one multi-tensor copy, reduces it, and re-binds .grad to
+        the views.  Without a process group nothing is packed at all: the optimizer reads the gradients where they are."""
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
+        self.lazy = lazy
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.views = []
         off = 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            if not lazy:
+                p.grad = self.views[-1]
             off += p.numel()
 
     def zero(self):
+        if self.lazy:
+            # the gradients were allocated on whatever stream their backward node ran on and last read on the CURRENT stream
+            # (optimizer / packing): tell the caching allocator, or dropping the reference here -- the host runs ahead of the
+            # GPU -- would let their memory be reused before that read has happened
+            cur = torch.cuda.current_stream() if self.flat.is_cuda else None
+            for p in self.params:
+                if p.grad is not None and cur is not None and p.grad.is_cuda:
+                    p.grad.record_stream(cur)
+                p.grad = None
+            return
         self.flat.zero_()
-        off = 0
-        for p in self.params:          # re-attach views if an optimizer / zero_grad(set_to_none) dropped them
-            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * off:
-                p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+        for p, v in zip(self.params, self.views):          # re-attach views if an optimizer / zero_grad(set_to_none) dropped them
+            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                p.grad = v
 
     def all_reduce(self):
-        if dist.is_available() and dist.is_initialized():
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-            w = dist.get_world_size(self.group)
-            if w > 1:
-                self.flat.div_(w)
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        if self.lazy:
+            with torch.no_grad():
+                have = [(v, p.grad) for p, v in zip(self.params, self.views) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+                for p, v in zip(self.params, self.views):
+                    if p.grad is None:
+                        v.zero_()
+                if have:
+                    torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+                    if self.flat.is_cuda:            # (read here, on this stream; allocated on their backward node's: see zero())
+                        cur = torch.cuda.current_stream()
+                        for _, g in have:
+                            g.record_stream(cur)
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        w = dist.get_world_size(self.group)
+        if w > 1:
+            self.flat.div_(w)
+        if self.lazy:
+            for p, v in zip(self.params, self.views):
+                p.grad = v
 
 
 class BufferBroadcast:
@@ -83,6 +116,22 @@ class BufferBroadcast:
     def broadcast(self):
         if self.flat is not None and dist.is_available() and dist.is_initialized():
             dist.broadcast(self.flat, src=0, group=self.group)
+
+
+class _CrossEntropyRows(torch.autograd.Function):
+    """nn.CrossEntropyLoss(label_smoothing) as one node: the forward pass over the logits also forms d loss / d logits."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, smoothing):
+        from . import ops
+        loss, dlogits = ops.cross_entropy_rows(logits, labels, smoothing)
+        ctx.save_for_backward(dlogits)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * dloss, None, None
 
 
 class Trainer:
@@ -112,7 +161,7 @@ class Trainer:
         if distributed is None:
             distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         self.distributed = distributed
-        self.sync = FlatGradSync(model.parameters())
+        self.sync = FlatGradSync(model.parameters(), lazy=os.environ.get("PPT_LAZY_GRADS", "1") != "0")
         self.run_ahead = True
         # DDP re-broadcasts rank 0's buffers before every forward.  The only float buffers here are BatchNorm running
         # statistics, which a train-mode forward never reads and which rank 0 updates from its own batches alone, so one
@@ -199,7 +248,7 @@ class Trainer:
                 loss, pred = model.forward_loss(pc, label, self.criterion.label_smoothing)
             else:
                 pred = model(pc, *self.extra_inputs)                # main_cls.py:194 / main_partseg.py:210
-                loss = self.criterion(pred.reshape(-1, pred.shape[-1]), label.reshape(-1))     # main_partseg.py:213
+                loss = self._loss(pred.reshape(-1, pred.shape[-1]), label.reshape(-1))         # main_partseg.py:213
         finally:
             if hasattr(pe, "group_ahead"):
                 pe.group_ahead = None       # the vouching covers this call's `pc` only: a forward outside step() stays in order
@@ -224,6 +273,14 @@ class Trainer:
             raise FloatingPointError(f"Loss is {loss.item()}, stopping training")
         self.it += 1
         return loss, pred
+
+    def _loss(self, logits, labels):
+        """self.criterion (main_cls.py:52: CrossEntropyLoss with label smoothing, mean reduction); on a GPU with <= 96 classes the
+        loss and its gradient come from one pass over the logits (ops.cross_entropy_rows) instead of ~10 ATen kernels."""
+        if logits.is_cuda and logits.dtype == torch.float32 and logits.shape[1] <= 96 and labels.dtype == torch.int64 \
+                and self.criterion.weight is None and self.criterion.reduction == 'mean':
+            return _CrossEntropyRows.apply(logits.contiguous(), labels.contiguous(), float(self.criterion.label_smoothing))
+        return self.criterion(logits, labels)
 
     def _optimizer_step(self):
         opt = self.optimizer

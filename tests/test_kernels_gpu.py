@@ -1001,6 +1001,22 @@ def test_ball_query_multi_equals_the_single_queries(ops, B, N, S, qs):
     assert all(g is None for _, g in plain) and all(torch.equal(a[0], b[0]) for a, b in zip(plain, outs))
 
 
+@pytest.mark.parametrize("R,C,eps", [(4 * 2048, 50, 0.2), (64, 15, 0.2), (1000, 40, 0.0), (129, 96, 0.1)])
+def test_cross_entropy_rows_matches_torch(ops, R, C, eps):
+    """ppt_cross_entropy_rows against nn.CrossEntropyLoss(label_smoothing) and its autograd gradient (main_partseg.py:213,
+    main_cls.py:52): loss to 1e-6 relative, gradient to 1e-7 absolute (values are O(1 / R)); repeatable bit for bit."""
+    g = torch.Generator().manual_seed(R + C)
+    logits = (torch.randn(R, C, generator=g) * 8).cuda().requires_grad_(True)
+    labels = torch.randint(0, C, (R,), generator=g).cuda()
+    ref = torch.nn.CrossEntropyLoss(label_smoothing=eps)(logits.double(), labels)
+    (gref,) = torch.autograd.grad(ref, logits)
+    loss, dl = ops.cross_entropy_rows(logits.detach(), labels, eps)
+    loss2, dl2 = ops.cross_entropy_rows(logits.detach(), labels, eps)
+    assert torch.equal(loss, loss2) and torch.equal(dl, dl2)
+    assert abs(loss.item() - ref.item()) < 2e-6 * max(1.0, abs(ref.item()))
+    assert (dl - gref).abs().max().item() < 2e-6 / R * 10 + 1e-7
+
+
 def test_wave_priority_changes_no_result(ops):
     """ppt_set_wave_priority only raises the issue priority of the waves (s_setprio): GEMM, LayerNorm forward / backward and
     the short-sequence attention backward give bit-identical results with it on."""
