@@ -85,6 +85,45 @@ __global__ __launch_bounds__(256) void col_sums_kernel(const TX *__restrict__ x,
     part[(size_t)blockIdx.y * D + d] = s;
 }
 
+// bf16, D % 8 == 0: a workgroup owns 256 rows x 128 columns as 16 row groups x 16 column octets (16-byte loads, 256-byte row
+// pieces), fp32 sums, the 16 group sums folded through LDS in a fixed order.  (The one-thread-per-column walk: 64 us for a
+// 32768 x 256 bias gradient, 0.26 TB/s; 7 per part-seg step.)
+__global__ __launch_bounds__(256) void col_sums_vec8_bf16_kernel(const bf16_t *__restrict__ x, int M, int D, int64_t ldx,
+                                                                 float *__restrict__ part)
+{
+    __shared__ float red[16][16][9];
+    const int q = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int d = blockIdx.x * 128 + q * 8;
+    const int r0 = blockIdx.y * 256 + g * 16;
+    float s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = 0.f;
+    if (d < D) {
+#pragma unroll 8
+        for (int i = 0; i < 16; ++i) {
+            const int r = r0 + i;
+            if (r < M) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(x + (int64_t)r * ldx + d);
+                const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s[2 * j] += __uint_as_float(wv[j] << 16);
+                    s[2 * j + 1] += __uint_as_float(wv[j] & 0xffff0000u);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[g][q][j] = s[j];
+    __syncthreads();
+    if (g < 8 && d < D) {                                 // thread (g, q) finishes column d + g
+        float t = red[0][q][g];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += red[k][q][g];
+        if (d + g < D) part[(size_t)blockIdx.y * D + d + g] = t;
+    }
+}
+
 // fp32, D % 4 == 0: a workgroup owns 256 rows x 64 columns as 16 row groups x 16 column quads (float4 loads, 256-byte row
 // pieces), the 16 group sums folded through LDS in a fixed order.  The one-thread-per-column walk above took 74 us for a
 // 32768 x 256 bias gradient (0.45 TB/s; 7 per part-seg step).
@@ -213,6 +252,9 @@ extern "C" int ppt_col_sums(const void *x, int x_dtype, int M, int D, int64_t ld
                            (const float *)x, M, D, ldx, partial);
     else if (x_dtype == PPT_F32)
         hipLaunchKernelGGL(col_sums_kernel<float>, grid, dim3(256), 0, ppt_stream(stream), (const float *)x, M, D, ldx, partial);
+    else if (x_dtype == PPT_BF16 && D % 8 == 0 && ldx % 8 == 0 && !((uintptr_t)x & 15))
+        hipLaunchKernelGGL(col_sums_vec8_bf16_kernel, dim3((D + 127) / 128, (M + 255) / 256), dim3(256), 0, ppt_stream(stream),
+                           (const bf16_t *)x, M, D, ldx, partial);
     else if (x_dtype == PPT_BF16)
         hipLaunchKernelGGL(col_sums_kernel<bf16_t>, grid, dim3(256), 0, ppt_stream(stream), (const bf16_t *)x, M, D, ldx, partial);
     else

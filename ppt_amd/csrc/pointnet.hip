@@ -248,6 +248,49 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_reduce_kernel(const float *__
     pgx[(size_t)blockIdx.y * C + c] = sgx;
 }
 
+// C % 4 == 0: the same partial sums with float4 loads -- a workgroup owns RS_ROWS rows x 64 columns as 16 row groups x 16 column
+// quads (256-byte row pieces), rows of a group taken in ascending order, the 16 group sums folded through LDS in group order.
+// (The one-thread-per-column walk above: 42 us for 32768 x 256, 1.6 TB/s; 7 per part-seg step.)
+__global__ __launch_bounds__(256) void bn_rows_bwd_reduce_vec_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                                     const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                     const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                                     int relu, int64_t M, int C, float *__restrict__ pg,
+                                                                     float *__restrict__ pgx)
+{
+    __shared__ float4 red[2][16][17];
+    const int q = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + q * 4;
+    const int64_t r0 = (int64_t)blockIdx.y * RS_ROWS;
+    const int nrow = (int)min((int64_t)RS_ROWS, M - r0);
+    float4 sg = make_float4(0.f, 0.f, 0.f, 0.f), sgx = sg;
+    if (c < C) {
+        const float4 sc = *reinterpret_cast<const float4 *>(scale + c), sh = *reinterpret_cast<const float4 *>(shift + c);
+        const float4 mu = *reinterpret_cast<const float4 *>(mean + c), rs = *reinterpret_cast<const float4 *>(rstd + c);
+#pragma unroll 4
+        for (int r = g; r < nrow; r += 16) {
+            const float4 v = *reinterpret_cast<const float4 *>(x + (r0 + r) * C + c);
+            float4 gd = *reinterpret_cast<const float4 *>(dy + (r0 + r) * C + c);
+            if (relu) {
+                if (!(fmaf(v.x, sc.x, sh.x) > 0.f)) gd.x = 0.f;
+                if (!(fmaf(v.y, sc.y, sh.y) > 0.f)) gd.y = 0.f;
+                if (!(fmaf(v.z, sc.z, sh.z) > 0.f)) gd.z = 0.f;
+                if (!(fmaf(v.w, sc.w, sh.w) > 0.f)) gd.w = 0.f;
+            }
+            sg.x += gd.x; sg.y += gd.y; sg.z += gd.z; sg.w += gd.w;
+            sgx.x = fmaf(gd.x, (v.x - mu.x) * rs.x, sgx.x); sgx.y = fmaf(gd.y, (v.y - mu.y) * rs.y, sgx.y);
+            sgx.z = fmaf(gd.z, (v.z - mu.z) * rs.z, sgx.z); sgx.w = fmaf(gd.w, (v.w - mu.w) * rs.w, sgx.w);
+        }
+    }
+    red[0][g][q] = sg; red[1][g][q] = sgx;
+    __syncthreads();
+    if (g < 2 && c < C) {                                  // group 0 finishes sum g, group 1 finishes sum g x
+        float4 t = red[g][0][q];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) { const float4 v = red[g][k][q]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        *reinterpret_cast<float4 *>((g == 0 ? pg : pgx) + (size_t)blockIdx.y * C + c) = t;
+    }
+}
+
 __global__ __launch_bounds__(256) void bn_rows_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                                 const float *__restrict__ scale, const float *__restrict__ shift,
                                                                 const float *__restrict__ mean, const float *__restrict__ rstd,
@@ -508,8 +551,13 @@ extern "C" int ppt_bn_rows_bwd_reduce(const float *dy, const float *x, const flo
     if (!dy || !x || !scale || !shift || !mean || !rstd || !part_g || !part_gx || M <= 0 || C <= 0 ||
         (M + RS_ROWS - 1) / RS_ROWS > 65535)
         return PPT_EINVAL;
-    hipLaunchKernelGGL(bn_rows_bwd_reduce_kernel, dim3((C + 255) / 256, (unsigned)((M + RS_ROWS - 1) / RS_ROWS)), dim3(256), 0,
-                       ppt_stream(stream), dy, x, scale, shift, mean, rstd, relu, M, C, part_g, part_gx);
+    if (C % 4 == 0 && !(((uintptr_t)dy | (uintptr_t)x | (uintptr_t)scale | (uintptr_t)shift | (uintptr_t)mean | (uintptr_t)rstd |
+                          (uintptr_t)part_g | (uintptr_t)part_gx) & 15))
+        hipLaunchKernelGGL(bn_rows_bwd_reduce_vec_kernel, dim3((C + 63) / 64, (unsigned)((M + RS_ROWS - 1) / RS_ROWS)), dim3(256), 0,
+                           ppt_stream(stream), dy, x, scale, shift, mean, rstd, relu, M, C, part_g, part_gx);
+    else
+        hipLaunchKernelGGL(bn_rows_bwd_reduce_kernel, dim3((C + 255) / 256, (unsigned)((M + RS_ROWS - 1) / RS_ROWS)), dim3(256), 0,
+                           ppt_stream(stream), dy, x, scale, shift, mean, rstd, relu, M, C, part_g, part_gx);
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }
