@@ -14,6 +14,7 @@
 //   of the key so that the four key rows of a half-wave hit four different 64-byte bank quarters.
 //   Scores never leave registers; softmax scale and log2(e) are folded into one v_exp_f32 argument.
 #include "ppt_common.h"
+#include <stdlib.h>
 #include "attn_rowmap.h"
 
 extern "C" int ppt_attention_fwd_quad_bf16(const void *qkv, void *out, float *lse, int Bt, int T, int H, float scale,
@@ -633,8 +634,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_short_mfma(const bf16_t *__re
 {
     PPT_PRIO(prio);
     __shared__ __align__(16) unsigned char smem[DQ_SMEM > DKV_SMEM ? DQ_SMEM : DKV_SMEM];
-    if (blockIdx.x == 0) attn_bwd_dkv_body<CAUSAL, true, false>(qkv, out, dout, lse, nullptr, dqkv, Tfull, H, scale, P, C, part, smem, 0, blockIdx.y);
-    else attn_bwd_dq_body<CAUSAL, true>(qkv, out, dout, lse, nullptr, dqkv, Tfull, H, scale, P, C, smem, 0, blockIdx.y);
+    // gridDim.x == 2: one workgroup per role; == 1: ONE workgroup runs both roles back to back (half the workgroups: with two
+    // 208-VGPR workgroups per CU, 656 role workgroups of the 41 x 8 (sequence, head) pairs were two rounds on 512 slots)
+    if (gridDim.x == 1 || blockIdx.x == 0)
+        attn_bwd_dkv_body<CAUSAL, true, false>(qkv, out, dout, lse, nullptr, dqkv, Tfull, H, scale, P, C, part, smem, 0, blockIdx.y);
+    if (gridDim.x == 1) __syncthreads();
+    if (gridDim.x == 1 || blockIdx.x == 1)
+        attn_bwd_dq_body<CAUSAL, true>(qkv, out, dout, lse, nullptr, dqkv, Tfull, H, scale, P, C, smem, 0, blockIdx.y);
 }
 
 }  // namespace
@@ -661,7 +667,9 @@ extern "C" int ppt_attention_bwd_short_mfma_bf16(const void *qkv, const void *ou
 {
     if (T > 128) return PPT_EUNSUPPORTED;
     if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dqkv & 7) || ((uintptr_t)part & 15)) return PPT_EUNSUPPORTED;
-    dim3 grid(2, (Bt + (P > 0)) * H);
+    static const int both = [] { const char *e = getenv("PPT_ATTN_SHORT_BOTH"); return e ? atoi(e) : 1; }();
+    const int pairs = (Bt + (P > 0)) * H;
+    dim3 grid(both && 2 * pairs > 512 ? 1 : 2, pairs);    // (two roles per workgroup once the role workgroups would not fit in one round)
     if (causal)
         hipLaunchKernelGGL(attn_bwd_short_mfma<true>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, T, H, scale, P, Bt, part, ppt_get_wave_priority());
     else
