@@ -39,7 +39,7 @@ __device__ __forceinline__ float act_fwd(float v, int act)
 {
     switch (act) {
     case PPT_ACT_RELU: return fmaxf(v, 0.0f);
-    case PPT_ACT_GELU: return 0.5f * v * (1.0f + (FAST ? erf_fast(v * 0.70710678118654752f) : erff(v * 0.70710678118654752f)));
+    case PPT_ACT_GELU: return FAST ? gelu_poly(v) : 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
     case PPT_ACT_QUICKGELU: return v / (1.0f + __expf(-1.702f * v));
     default: return v;
     }

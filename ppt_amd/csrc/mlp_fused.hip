@@ -158,7 +158,7 @@ __global__ __launch_bounds__(512, 2) void vit_mlp_kernel(const ppt_vit_mlp_param
             for (int rb = 0; rb < RB; ++rb) {
                 float v[4] = {a1[rb][0] + bv.x, a1[rb][1] + bv.y, a1[rb][2] + bv.z, a1[rb][3] + bv.w};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = 0.5f * v[i] * (1.0f + erf_fast(v[i] * 0.70710678118654752f));
+                for (int i = 0; i < 4; ++i) v[i] = gelu_poly(v[i]);
                 *reinterpret_cast<uint2 *>(ud + rb * 16 * UP) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
             }
         };

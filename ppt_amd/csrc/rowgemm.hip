@@ -240,7 +240,7 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(const ppt_rowgemm_param
                     }
                     if constexpr (ACT == PPT_ACT_GELU) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = 0.5f * v[i] * (1.0f + erf_fast(v[i] * 0.70710678118654752f));
+                        for (int i = 0; i < 4; ++i) v[i] = gelu_poly(v[i]);
                     } else if constexpr (ACT == PPT_ACT_QUICKGELU) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = v[i] / (1.0f + __expf(-1.702f * v[i]));
