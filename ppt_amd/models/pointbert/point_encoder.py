@@ -434,6 +434,16 @@ class PointTransformer_partseg(nn.Module):
         self.dropout_mask = None         # [B,N,128] multiplicative Dropout(0.5) factors
         self._wc = None
         self._sd = None
+        # The frozen backbone's part of the forward (three FPS, kNN, tokenizer, 12 blocks: ~200 launches) is replayed from a
+        # hipGraph after graphs.WARMUP_CALLS eager calls per shape: the part-seg step is ~690 launches of small kernels and
+        # was HOST-bound -- 7.5 ... 16 ms of enqueue time per step depending on the host's load for ~6 ms of GPU work
+        # (tools/host_time.py).  Only with the RNG draws made on the device (nothing injected).  (The decoder's forward +
+        # backward as graphs through torch.cuda.make_graphed_callables was tried: hipStreamEndCapture of the BACKWARD capture
+        # segfaults in this ROCm / PyTorch build whenever any eager GPU work preceded it in the process, also for a
+        # two-line pure-ATen module.)
+        self.use_hip_graphs = True
+        self._graphs = graphs.GraphCache()
+        self._graph_injected = False      # tests: allow the graph with injected (static) RNG tensors
 
     @property
     def precision(self):
@@ -442,6 +452,7 @@ class PointTransformer_partseg(nn.Module):
     @precision.setter
     def precision(self, dtype):
         self._precision = dtype
+        self._graphs.clear()
         for m in (self.propagation_0, self.propagation_1, self.propagation_2, self.dgcnn_pro_1, self.dgcnn_pro_2):
             m.precision = dtype
 
@@ -454,34 +465,52 @@ class PointTransformer_partseg(nn.Module):
 
     def load_state_dict(self, *a, **k):
         self._wc = None
+        self._graphs.clear()
         return super().load_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):
+        self._graphs.clear()
+        return super()._apply(fn, *a, **k)
 
     load_model_from_ckpt = _load_model_from_ckpt
 
     def forward(self, pts, cls_label):
+
         from ...autograd import conv_bn_relu_rows
         pts = pts.contiguous().float()
         B, N, _ = pts.shape
         dev = pts.device
-        if self.fps_start is not None:
-            s0, s1, s2 = (t.to(dev).contiguous() for t in self.fps_start)
-        else:                                        # three independent random starts
-            s0, s1, s2 = (torch.randint(0, N, (B,), dtype=torch.long, device=dev) for _ in range(3))
-        dp = self._draw_drop_path(B, dev)
-        with torch.no_grad():                        # frozen backbone: features after blocks 3, 7, 11 (+ final LN, cls dropped)
-            # the three farthest-point samplings of the step (group centres, 512 and 256 decoder anchors: point_encoder.py
-            # :360-364) are independent walks over the same clouds and each is one serial workgroup per cloud: run as ONE
-            # launch over 3B clouds; the 256-point sampling is the first 256 picks of a 512-point one from the same start
-            if self.num_group == 512:
-                _, ctr = ops.fps(pts.repeat(3, 1, 1), 512, torch.cat([s0, s1, s2]))
-                center, c1, c2 = ctr[:B], ctr[B:2 * B], ctr[2 * B:, :256].contiguous()
-            else:
-                _, center = ops.fps(pts, self.num_group, s0)
-                _, c1 = ops.fps(pts, 512, s1)
-                _, c2 = ops.fps(pts, 256, s2)
-            _, nbhd = ops.knn_group(pts, center, self.group_size, want_idx=False)
-            feats, center = engine.point_encoder_forward(self._live_state(), "", self._cache(), None, None, dp, self.training, 0,
-                                                         self._cfg(), fetch=(3, 7, 11), grouped=(nbhd, center))
+        def backbone(p):
+            if self.fps_start is not None:
+                s0, s1, s2 = (t.to(dev).contiguous() for t in self.fps_start)
+            else:                                        # three independent random starts
+                s0, s1, s2 = (torch.randint(0, N, (B,), dtype=torch.long, device=dev) for _ in range(3))
+            dp = self._draw_drop_path(B, dev)
+            with torch.no_grad():                        # frozen backbone: features after blocks 3, 7, 11 (+ final LN, cls dropped)
+                # the three farthest-point samplings of the step (group centres, 512 and 256 decoder anchors: point_encoder.py
+                # :360-364) are independent walks over the same clouds and each is one serial workgroup per cloud: run as ONE
+                # launch over 3B clouds; the 256-point sampling is the first 256 picks of a 512-point one from the same start
+                if self.num_group == 512:
+                    _, ctr = ops.fps(p.repeat(3, 1, 1), 512, torch.cat([s0, s1, s2]))
+                    center, c1, c2 = ctr[:B], ctr[B:2 * B], ctr[2 * B:, :256].contiguous()
+                else:
+                    _, center = ops.fps(p, self.num_group, s0)
+                    _, c1 = ops.fps(p, 512, s1)
+                    _, c2 = ops.fps(p, 256, s2)
+                _, nbhd = ops.knn_group(p, center, self.group_size, want_idx=False)
+                feats, center = engine.point_encoder_forward(self._live_state(), "", self._cache(), None, None, dp, self.training, 0,
+                                                             self._cfg(), fetch=(3, 7, 11), grouped=(nbhd, center))
+            return (feats[0], feats[1], feats[2], center.contiguous(), c1.contiguous(), c2.contiguous()), None
+
+        injected = self.fps_start is not None or self.drop_path_factors is not None or self.dropout_mask is not None
+        key = ("partseg_backbone", (B, N), self.training, self._precision)
+        if (pts.is_cuda and self.use_hip_graphs and graphs.enabled and ops.profiler is None and (not injected or self._graph_injected)
+                and not torch.cuda.is_current_stream_capturing() and self._graphs.ready(key)):
+            outs, _ = self._graphs.get(key, lambda: graphs.GraphedCall(backbone, [pts]))(pts)
+            f_a, f_b, f_c, center, c1, c2 = (o.clone() for o in outs)          # (the decoder's autograd nodes keep them)
+        else:
+            (f_a, f_b, f_c, center, c1, c2), _ = backbone(pts)
+        feats = (f_a, f_b, f_c)
         f0 = torch.cat([cls_label.float().view(B, 1, 16).expand(-1, N, -1), pts], dim=-1)       # [B,N,19]
         f2 = self.propagation_2.forward_rows(c2, center, c2, feats[1])
         f1 = self.propagation_1.forward_rows(c1, center, c1, feats[0])

@@ -699,6 +699,46 @@ def test_partseg_train_step_matches_golden(precision):
             _bound(f"partseg bf16 grad {k} 1 - cos", 1 - cos, 0.1)
 
 
+def test_partseg_graphed_step_is_bit_identical_to_eager():
+    """PointTransformer_partseg replays the frozen backbone's part of its forward (three FPS, kNN, tokenizer, 12 blocks) from a
+    hipGraph once a shape has been seen graphs.WARMUP_CALLS times.  Six training steps (Trainer: CE + backward + AdamW) with the
+    RNG draws injected as static tensors: losses, trained parameters and BatchNorm running statistics are the same bits as with
+    use_hip_graphs = False."""
+    from ppt_amd.models import ULIP_models as M
+    from ppt_amd.train import Trainer
+    g = np.load(os.path.join(G, "g_partseg.npz"), allow_pickle=False)
+    pc_np, _ = W.synth_clouds(2, 2048, seed=55, duplicates=True)
+    pc = torch.from_numpy(pc_np).cuda()
+    labels = torch.from_numpy(g["labels"].astype(np.int64)).cuda()
+    onehot = torch.from_numpy(g["onehot"]).cuda()
+    outs = {}
+    for graphed in (False, True):
+        args = SimpleNamespace(classnames=M.dataset_classnames("shapenetpart"), template_init='', class_name_position='middle',
+                               num_learnable_prompt_tokens=32, gpu=0, task='partseg', head_type=0, evaluate_3d=False, ulip2=False,
+                               synthetic_weights=True)
+        m = M.ULIP_PointBERT_partseg(args)
+        m.load_state_dict(W.ulip_partseg_state_dict(seed=0), strict=False)
+        m.prompt_learner.embedding = W.synth_prompt_embedding(50, seed=0)
+        m.cuda().set_precision(torch.bfloat16)
+        m.train()
+        pe = m.point_encoder
+        pe.fps_start = tuple(torch.from_numpy(g[k]).cuda() for k in ("s0", "s1", "s2"))
+        pe.drop_path_factors = torch.from_numpy(g["dp_masks"]).cuda()
+        pe.dropout_mask = (torch.from_numpy(np.unpackbits(g["drop"]).reshape(2, 2048, 128).astype(np.float32)) * 2.0).cuda()
+        pe.use_hip_graphs, pe._graph_injected = graphed, True
+        tr = Trainer(m, lr=1e-3, label_smoothing=0.2, distributed=False)
+        tr.extra_inputs = (onehot,)
+        losses = [tr.step(pc, labels)[0] for _ in range(6)]
+        tr.finish()
+        torch.cuda.synchronize()
+        assert (len(pe._graphs.entries) == 1) == graphed
+        outs[graphed] = ([l.item() for l in losses], {n: q.detach().cpu().clone() for n, q in m.named_parameters() if q.requires_grad},
+                         {n: b.detach().cpu().clone() for n, b in pe.named_buffers()})
+    assert outs[False][0] == outs[True][0], (outs[False][0], outs[True][0])
+    assert all(torch.equal(outs[False][1][k], outs[True][1][k]) for k in outs[False][1])
+    assert all(torch.equal(outs[False][2][k], outs[True][2][k]) for k in outs[False][2])
+
+
 def test_eval_text_cache_fast_path():
     """validate()-style inference: text features are computed once and reused until the prompt tokens change."""
     m, _ = build(0, torch.bfloat16)
