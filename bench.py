@@ -231,6 +231,9 @@ def main():
     # K steps bracketed by barrier + synchronize (the contract's `value`); a HIP event on the caller's stream after every
     # step also gives the per-step times (hipEvents, median reported beside the mean)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+    if os.environ.get("PPT_BENCH_GC", "1") == "0":
+        import gc
+        gc.collect(); gc.disable()
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(a.steps):
@@ -240,6 +243,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
+    if os.environ.get("PPT_BENCH_VERBOSE") == "1":
+        print("per-step ms (sorted, top 5):", [round(x, 2) for x in step_ms[-5:]], file=sys.stderr)
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     if world > 1 or force_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
