@@ -314,3 +314,128 @@ class _DGCNNLayer(torch.autograd.Function):
 def dgcnn_layer(x_k, x_q, conv, gn, idx, slope, prec):
     """x_k [B,S,C] sources, x_q [B,Nq,C] queries, idx [B,Nq,k] neighbours of each query among the sources -> [B,Nq,Cout]."""
     return _DGCNNLayer.apply(x_k, x_q, conv.weight, gn.weight, gn.bias, idx, gn, slope, prec)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The whole part-segmentation decoder as ONE autograd node whose forward and backward are hipGraph replays.
+#
+# The decoder's step is ~450 launches of small kernels issued from Python autograd nodes, and enqueueing them is what bounds the
+# part-seg step (tools/host_time.py).  torch.cuda.make_graphed_callables cannot be used (capturing an autograd backward
+# segfaults in hipStreamEndCapture in this build), so the backward is hand-scheduled here: the per-module nodes above already
+# ARE explicit forward / backward pairs, and this node calls their static methods with stand-in contexts in topological /
+# reverse order and routes the gradients between them itself -- plain functions of tensors that graphs.GraphedCall captures.
+# Same kernels in the same order as the per-module path: bit-identical results (tests/test_model_gpu.py).
+class _Ctx:
+    """Stand-in for the autograd context of the per-module nodes: attributes + needs_input_grad."""
+
+    def __init__(self, needs):
+        self.needs_input_grad = needs
+
+
+def partseg_decoder_params(pe):
+    """The trainable tensors the decoder node returns gradients for, in its fixed order."""
+    ps = []
+    for fp in (pe.propagation_0, pe.propagation_1, pe.propagation_2):
+        for conv, bn in zip(fp.mlp_convs, fp.mlp_bns):
+            ps += [conv.weight, conv.bias, bn.weight, bn.bias]
+    for dg in (pe.dgcnn_pro_1, pe.dgcnn_pro_2):
+        for layer in (dg.layer1, dg.layer2):
+            ps += [layer[0].weight, layer[1].weight, layer[1].bias]
+    return ps + [pe.conv1.weight, pe.conv1.bias, pe.bn1.weight, pe.bn1.bias]
+
+
+def _fp_forward(mod, xyz1, xyz2, points1, points2, need_dp2):
+    idx, _, d = ops.knn_group(xyz2.contiguous().float(), xyz1.contiguous().float(), 3, want_nbhd=False, want_dist=True)
+    c = _Ctx((need_dp2,))
+    c0, c1, n0, n1 = mod.mlp_convs[0], mod.mlp_convs[1], mod.mlp_bns[0], mod.mlp_bns[1]
+    out = _FeaturePropagation.forward(c, points2, c0.weight, c0.bias, n0.weight, n0.bias, c1.weight, c1.bias, n1.weight, n1.bias,
+                                      mod, idx, d, points1, mod.precision)
+    return out, c
+
+
+def _dg_forward(mod, seq, coor_q, x_q, coor_k, x_k, need_k, need_q):
+    idx, _ = ops.knn_group(coor_k.contiguous(), coor_q.contiguous(), mod.k, want_nbhd=False)
+    c = _Ctx((need_k, need_q))
+    out = _DGCNNLayer.forward(c, x_k, x_q, seq[0].weight, seq[1].weight, seq[1].bias, idx, seq[1], 0.2, mod.precision)
+    return out, c
+
+
+def partseg_decoder_forward(pe, f_a, f_b, f_c, center, c1, c2, pts, cls_label, drop):
+    """point_encoder.py:396-416 on rows -> (y [B,N,128], contexts for partseg_decoder_backward).  drop: multiplicative Dropout
+    factors [B,N,128] or None."""
+    B, N, _ = pts.shape
+    f0 = torch.cat([cls_label.float().view(B, 1, 16).expand(-1, N, -1), pts], dim=-1)
+    F2, k1 = _fp_forward(pe.propagation_2, c2, center, c2, f_b, False)
+    F1, k2 = _fp_forward(pe.propagation_1, c1, center, c1, f_a, False)
+    L1, k3a = _dg_forward(pe.dgcnn_pro_2, pe.dgcnn_pro_2.layer1, c2, F2, center, f_c, False, True)
+    L2, k3b = _dg_forward(pe.dgcnn_pro_2, pe.dgcnn_pro_2.layer2, c2, L1, c2, L1, True, True)
+    L3, k4a = _dg_forward(pe.dgcnn_pro_1, pe.dgcnn_pro_1.layer1, c1, F1, c2, L2, True, True)
+    L4, k4b = _dg_forward(pe.dgcnn_pro_1, pe.dgcnn_pro_1.layer2, c1, L3, c1, L3, True, True)
+    F0, k5 = _fp_forward(pe.propagation_0, pts, c1, f0, L4, True)
+    k6 = _Ctx((True,))
+    y = _ConvBNReLURows.forward(k6, F0.reshape(B * N, -1), pe.conv1.weight, pe.conv1.bias, pe.bn1.weight, pe.bn1.bias,
+                                (pe.bn1, pe.training), pe._precision).view(B, N, -1)
+    if drop is not None:
+        y = y * drop
+    return y, (k1, k2, k3a, k3b, k4a, k4b, k5, k6, drop, (B, N))
+
+
+def partseg_decoder_backward(ctxs, dy):
+    """dy [B,N,128] -> the gradients of partseg_decoder_params(pe), in that order."""
+    k1, k2, k3a, k3b, k4a, k4b, k5, k6, drop, (B, N) = ctxs
+    dy = dy.float()
+    if drop is not None:
+        dy = dy * drop
+    g6 = _ConvBNReLURows.backward(k6, dy.reshape(B * N, -1).contiguous())
+    g5 = _FeaturePropagation.backward(k5, g6[0].reshape(B, N, -1))                       # -> d L4 (points2 of propagation_0)
+    g4b = _DGCNNLayer.backward(k4b, g5[0])
+    g4a = _DGCNNLayer.backward(k4a, g4b[0] + g4b[1])                                      # L3 is both operands of layer 2
+    g2 = _FeaturePropagation.backward(k2, g4a[1])                                         # F1 = propagation_1's output
+    g3b = _DGCNNLayer.backward(k3b, g4a[0])                                               # L2 = dgcnn_pro_2's output
+    g3a = _DGCNNLayer.backward(k3a, g3b[0] + g3b[1])
+    g1 = _FeaturePropagation.backward(k1, g3a[1])                                         # F2 = propagation_2's output
+    out = list(g5[1:9]) + list(g2[1:9]) + list(g1[1:9])
+    for gd in (g4a, g4b, g3a, g3b):
+        out += [gd[2], gd[3], gd[4]]
+    return out + [g6[1], g6[2], g6[3], g6[4]]
+
+
+class _PartsegDecoder(torch.autograd.Function):
+    """forward(pe, f_a, f_b, f_c, center, c1, c2, pts, cls_label, drop, *partseg_decoder_params(pe)) -> y [B,N,128]; forward and
+    backward are replayed from hipGraphs (captured at the first call per shape; activations live in the forward graph's pool)."""
+
+    @staticmethod
+    def forward(ctx, pe, f_a, f_b, f_c, center, c1, c2, pts, cls_label, drop, *params):
+        from . import graphs
+        ins = [f_a, f_b, f_c, center, c1, c2, pts.contiguous().float(), cls_label.contiguous().float()]
+        key = ("partseg_decoder", tuple(pts.shape), pe.training, pe._precision, drop is not None)
+
+        def build():
+            def fn(*t):
+                d = drop if drop is not None else ((torch.rand((t[6].shape[0], t[6].shape[1], 128), device=t[6].device) >= 0.5).float() * 2.0
+                                                   if pe.training else None)                 # nn.Dropout(0.5), point_encoder.py:417
+                y, ctxs = partseg_decoder_forward(pe, *t, d)
+                return (y,), ctxs
+            return graphs.GraphedCall(fn, ins)
+        g = pe._graphs.get(key, build)
+        (y,), ctxs = g(*ins)
+        g.generation = getattr(g, "generation", 0) + 1
+        ctx.pe, ctx.g, ctx.key, ctx.generation, ctx.ctxs = pe, g, key, g.generation, ctxs
+        return y.clone()
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import graphs
+        if ctx.g.generation != ctx.generation:
+            raise RuntimeError("the part-seg decoder's captured activations were overwritten by a later forward; set "
+                               "point_encoder.use_hip_graphs = False to keep several forwards alive before backward")
+        ctxs, fwd = ctx.ctxs, ctx.g
+
+        def build():
+            def fn(d):
+                return tuple(partseg_decoder_backward(ctxs, d)), None
+            return graphs.GraphedCall(fn, [dy.contiguous()], pool=fwd.pool())
+        grads, _ = ctx.pe._graphs.get(("partseg_decoder_bwd",) + ctx.key[1:], build)(dy.contiguous())
+        # (detached: fresh tensor objects over the graph's static buffers, which autograd may adopt as .grad without a copy --
+        # they are read by the optimizer before the next replay overwrites them)
+        return (None,) * 10 + tuple(gr.detach() for gr in grads)

@@ -1,6 +1,8 @@
 """Mirror of models/pointbert/point_encoder.py:14-257 (Mlp, Attention, Block, TransformerEncoder,
 PointTransformer): identical constructor signatures, attribute names and state-dict keys; the
 forward of PointTransformer is ONE autograd node running ppt_amd.engine's kernel pipeline."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -444,6 +446,7 @@ class PointTransformer_partseg(nn.Module):
         self.use_hip_graphs = True
         self._graphs = graphs.GraphCache()
         self._graph_injected = False      # tests: allow the graph with injected (static) RNG tensors
+        self.graph_decoder = os.environ.get("PPT_PARTSEG_GRAPH_DECODER", "1") != "0"
 
     @property
     def precision(self):
@@ -511,6 +514,14 @@ class PointTransformer_partseg(nn.Module):
         else:
             (f_a, f_b, f_c, center, c1, c2), _ = backbone(pts)
         feats = (f_a, f_b, f_c)
+        dkey = ("partseg_decoder_warm", (B, N), self.training, self._precision)
+        if (pts.is_cuda and self.training and torch.is_grad_enabled() and self.use_hip_graphs and self.graph_decoder and graphs.enabled
+                and ops.profiler is None and (not injected or self._graph_injected) and not torch.cuda.is_current_stream_capturing()
+                and self._graphs.ready(dkey)):
+            # the decoder's forward AND backward from hipGraphs, as one autograd node (ppt_amd.autograd._PartsegDecoder)
+            from ...autograd import _PartsegDecoder, partseg_decoder_params
+            drop = self.dropout_mask.to(dev) if self.dropout_mask is not None else None
+            return _PartsegDecoder.apply(self, f_a, f_b, f_c, center, c1, c2, pts, cls_label, drop, *partseg_decoder_params(self))
         f0 = torch.cat([cls_label.float().view(B, 1, 16).expand(-1, N, -1), pts], dim=-1)       # [B,N,19]
         f2 = self.propagation_2.forward_rows(c2, center, c2, feats[1])
         f1 = self.propagation_1.forward_rows(c1, center, c1, feats[0])

@@ -700,8 +700,9 @@ def test_partseg_train_step_matches_golden(precision):
 
 
 def test_partseg_graphed_step_is_bit_identical_to_eager():
-    """PointTransformer_partseg replays the frozen backbone's part of its forward (three FPS, kNN, tokenizer, 12 blocks) from a
-    hipGraph once a shape has been seen graphs.WARMUP_CALLS times.  Six training steps (Trainer: CE + backward + AdamW) with the
+    """PointTransformer_partseg replays the frozen backbone's part of its forward (three FPS, kNN, tokenizer, 12 blocks), the
+    decoder's forward and the decoder's hand-scheduled backward (ppt_amd.autograd._PartsegDecoder) from hipGraphs once a shape
+    has been seen graphs.WARMUP_CALLS times.  Six training steps (Trainer: CE + backward + AdamW) with the
     RNG draws injected as static tensors: losses, trained parameters and BatchNorm running statistics are the same bits as with
     use_hip_graphs = False."""
     from ppt_amd.models import ULIP_models as M
@@ -731,7 +732,7 @@ def test_partseg_graphed_step_is_bit_identical_to_eager():
         losses = [tr.step(pc, labels)[0] for _ in range(6)]
         tr.finish()
         torch.cuda.synchronize()
-        assert (len(pe._graphs.entries) == 1) == graphed
+        assert (len(pe._graphs.entries) == 3) == graphed and (graphed or not pe._graphs.entries)      # backbone, decoder forward, decoder backward
         outs[graphed] = ([l.item() for l in losses], {n: q.detach().cpu().clone() for n, q in m.named_parameters() if q.requires_grad},
                          {n: b.detach().cpu().clone() for n, b in pe.named_buffers()})
     assert outs[False][0] == outs[True][0], (outs[False][0], outs[True][0])
