@@ -277,9 +277,12 @@ extern "C" int ppt_vit_mlp_bf16(const ppt_vit_mlp_params *pp, void *stream)
         return n > 0 ? n : 256;
     }();
     // chunks of at most R rows, a whole number of rounds over the CUs, every chunk as full as the division allows
-    const int wgs = p.workgroups > 0 ? p.workgroups : cus;
+    int wgs = p.workgroups > 0 ? p.workgroups : cus;
     int rounds = 1;
     while ((int64_t)rounds * wgs * R < p.M) ++rounds;
+    // the caller leaves room for the other stream (ppt_set_persistent_occupancy < 100): as FEW workgroups as the same number of
+    // rounds allows, i.e. full R-row chunks (C2: 206 workgroups of 80 rows instead of 253 of 65 -- same time, 47 CUs free)
+    if (p.workgroups <= 0 && ppt_get_persistent_occupancy() < 100) wgs = (int)((p.M + (int64_t)rounds * R - 1) / ((int64_t)rounds * R));
     p.n_chunks = rounds * wgs;
     p.rows_per_chunk = (p.M + p.n_chunks - 1) / p.n_chunks;
     p.n_chunks = (p.M + p.rows_per_chunk - 1) / p.rows_per_chunk;
