@@ -71,6 +71,16 @@ class FlatGradSync:
     def all_reduce(self):
         if not (dist.is_available() and dist.is_initialized()):
             return
+        if self.lazy and len(self.params) == 1 and self.params[0].grad is not None and self.params[0].grad.is_contiguous():
+            # one trained tensor (head_type 0: the prompt tokens): reduce its gradient where it is -- no packing copy on the
+            # prompt chain, which is the step's critical path; `flat` is re-pointed at it so that readers see the reduced values
+            g = self.params[0].grad
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+            w = dist.get_world_size(self.group)
+            if w > 1:
+                g.div_(w)
+            self.flat = g.detach().view(-1)
+            return
         if self.lazy:
             with torch.no_grad():
                 have = [(v, p.grad) for p, v in zip(self.params, self.views) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
