@@ -447,6 +447,7 @@ class PointTransformer_partseg(nn.Module):
         self._graphs = graphs.GraphCache()
         self._graph_injected = False      # tests: allow the graph with injected (static) RNG tensors
         self.graph_decoder = os.environ.get("PPT_PARTSEG_GRAPH_DECODER", "1") != "0"
+        self.decoder_gate = None          # event after which this iteration may read the decoder's parameters (train.Trainer)
 
     @property
     def precision(self):
@@ -514,6 +515,10 @@ class PointTransformer_partseg(nn.Module):
         else:
             (f_a, f_b, f_c, center, c1, c2), _ = backbone(pts)
         feats = (f_a, f_b, f_c)
+        if self.decoder_gate is not None:        # the optimizer of the previous iteration (on the text stream) has written the decoder
+            if pts.is_cuda:
+                torch.cuda.current_stream().wait_event(self.decoder_gate)
+            self.decoder_gate = None
         dkey = ("partseg_decoder_warm", (B, N), self.training, self._precision)
         if (pts.is_cuda and self.training and torch.is_grad_enabled() and self.use_hip_graphs and self.graph_decoder and graphs.enabled
                 and ops.profiler is None and (not injected or self._graph_injected) and not torch.cuda.is_current_stream_capturing()

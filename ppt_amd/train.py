@@ -203,6 +203,11 @@ class Trainer:
         # part-seg decoder ...) are read wherever forward() likes: no gating then
         self._gated = all(n.startswith("prompt_learner.") or n.startswith("point_encoder.blocks.blocks.") or not p.requires_grad
                           for n, p in model.named_parameters())
+        pe_ = getattr(model, "point_encoder", None)
+        dec = ("propagation_", "dgcnn_pro_", "conv1.", "bn1.", "conv2.")
+        self._decoder_gated = hasattr(pe_, "decoder_gate") and all(
+            (not p.requires_grad) or n.startswith("prompt_learner.") or
+            (n.startswith("point_encoder.") and n[len("point_encoder."):].startswith(dec)) for n, p in model.named_parameters())
         self.bcast = BufferBroadcast(model) if distributed else None
         # BufferBroadcast re-bound the BatchNorm buffers to views of its flat tensor: every state-dict view, operand copy
         # and captured hipGraph made before that points at the orphaned storage
@@ -277,6 +282,10 @@ class Trainer:
                 # PointBERT with an un-frozen last block: only that block (and what follows) must see this update; the
                 # frozen prefix of the next iteration runs ahead (point_encoder._PointEncoderFn waits on the event)
                 pe.param_gate = side.record_event()
+            elif self._decoder_gated and getattr(pe, "decoder_gate", False) is None:
+                # part segmentation: everything that trains on the point side is the DECODER; the frozen backbone of the next
+                # iteration does not wait for the optimizer (PointTransformer_partseg.forward waits in front of the decoder)
+                pe.decoder_gate = side.record_event()
             else:
                 main.wait_stream(side)                              # the point tower reads updated parameters
         if check_finite and not math.isfinite(loss.item()):         # main_cls.py:205-207
@@ -316,6 +325,10 @@ class Trainer:
 
     def _drain_gate(self):
         pe = getattr(self.model, "point_encoder", None)
+        dgate = getattr(pe, "decoder_gate", None)
+        if dgate is not None:
+            torch.cuda.current_stream().wait_event(dgate)
+            pe.decoder_gate = None
         gate = getattr(pe, "param_gate", None)
         if gate is not None:
             torch.cuda.current_stream().wait_event(gate)
