@@ -92,16 +92,43 @@ __global__ __launch_bounds__(256) void scatter_rows_bwd_kernel(const int64_t *__
                 for (int e0 = 0; e0 < n_e; e0 += 64) {
                     const int e = e0 + lane;
                     uint64_t hit = __ballot(e < n_e && s_idx[e] == (uint16_t)s);
-                    while (hit) {                                         // ascending entry order: a fixed summation order
-                        const int l = __builtin_ctzll(hit);
-                        hit &= hit - 1;
-                        const int ee = e0 + l;
-                        const float wv = HAS_W ? s_w[ee] : 1.0f;
-                        const float *src = db + (int64_t)((e_base + ee) / rows_div) * ld;
+                    // ascending entry order: a fixed summation order.  FOUR matching rows are requested before any is added --
+                    // one row at a time, every hit was a dependent global round trip (169 us for the 2048 x 3 -> 512 gather of
+                    // the part-seg decoder); the additions keep their order, so the sums are the same bits
+                    while (hit) {
+                        int ee[4];
+                        float wv[4], v[4][CPL];
+                        int nh = 0;
 #pragma unroll
-                        for (int k = 0; k < CPL; ++k) {
-                            const int c = lane + 64 * k;
-                            if (c < C) acc[k] = HAS_W ? fmaf(wv, src[c], acc[k]) : acc[k] + src[c];
+                        for (int u = 0; u < 4; ++u) {
+                            ee[u] = -1;
+                            if (hit) {
+                                ee[u] = e0 + __builtin_ctzll(hit);
+                                hit &= hit - 1;
+                                nh = u + 1;
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (u < nh) {
+                                wv[u] = HAS_W ? s_w[ee[u]] : 1.0f;
+                                const float *src = db + (int64_t)((e_base + ee[u]) / rows_div) * ld;
+#pragma unroll
+                                for (int k = 0; k < CPL; ++k) {
+                                    const int c = lane + 64 * k;
+                                    v[u][k] = c < C ? src[c] : 0.f;
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (u < nh) {
+#pragma unroll
+                                for (int k = 0; k < CPL; ++k) {
+                                    const int c = lane + 64 * k;
+                                    if (c < C) acc[k] = HAS_W ? fmaf(wv[u], v[u][k], acc[k]) : acc[k] + v[u][k];
+                                }
+                            }
                         }
                     }
                 }
