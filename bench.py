@@ -184,7 +184,7 @@ def main():
     frozen_too = os.environ.get("PPT_GROUP_AHEAD_FROZEN") == "1"          # experiment: also for a fully frozen PointBERT (C2)
     c_ = CONFIGS[a.config]
     group_ahead = GROUP_AHEAD and (frozen_too or (c_["head_type"] > 0 and c_.get("model", "ULIP_PointBERT") == "ULIP_PointBERT")
-                                   or c_.get("model") in ("ULIP_PN_MSG", "ULIP_PN_MLP"))
+                                   or c_.get("model") in ("ULIP_PN_MSG", "ULIP_PN_MLP", "ULIP_PointBERT_partseg"))
     if group_ahead:                    # (only where Trainer uses it: an extra stream shifts the others' queue positions)
         graphs.shared_group_stream()
     force_dist = os.environ.get("PPT_FORCE_DIST") == "1"      # exercise the RCCL path with a single rank (dev aid)

@@ -448,6 +448,8 @@ class PointTransformer_partseg(nn.Module):
         self._graph_injected = False      # tests: allow the graph with injected (static) RNG tensors
         self.graph_decoder = os.environ.get("PPT_PARTSEG_GRAPH_DECODER", "1") != "0"
         self.decoder_gate = None          # event after which this iteration may read the decoder's parameters (train.Trainer)
+        self.group_ahead = None           # stream for the grouping stage of a step whose inputs the caller vouches for (Trainer)
+        self._ahead = graphs.AheadStage()
 
     @property
     def precision(self):
@@ -484,34 +486,56 @@ class PointTransformer_partseg(nn.Module):
         pts = pts.contiguous().float()
         B, N, _ = pts.shape
         dev = pts.device
-        def backbone(p):
+        def grouping(p):
+            """The part of the step that depends on the input cloud alone: three FPS + the kNN grouping."""
             if self.fps_start is not None:
                 s0, s1, s2 = (t.to(dev).contiguous() for t in self.fps_start)
             else:                                        # three independent random starts (SURVEY App. A Q10)
                 s0, s1, s2 = (torch.randint(0, N, (B,), dtype=torch.long, device=dev) for _ in range(3))
-            dp = self._draw_drop_path(B, dev)
-            with torch.no_grad():                        # frozen backbone: features after blocks 3, 7, 11 (+ final LN, cls dropped)
+            with torch.no_grad():
                 # the three farthest-point samplings of the step (group centres, 512 and 256 decoder anchors: point_encoder.py
                 # :360-364) are independent walks over the same clouds and each is one serial workgroup per cloud: run as ONE
                 # launch over 3B clouds; the 256-point sampling is the first 256 picks of a 512-point one from the same start
                 if self.num_group == 512:
                     _, ctr = ops.fps(p.repeat(3, 1, 1), 512, torch.cat([s0, s1, s2]))
-                    center, c1, c2 = ctr[:B], ctr[B:2 * B], ctr[2 * B:, :256].contiguous()
+                    center, c1, c2 = ctr[:B].contiguous(), ctr[B:2 * B].contiguous(), ctr[2 * B:, :256].contiguous()
                 else:
                     _, center = ops.fps(p, self.num_group, s0)
                     _, c1 = ops.fps(p, 512, s1)
                     _, c2 = ops.fps(p, 256, s2)
                 _, nbhd = ops.knn_group(p, center, self.group_size, want_idx=False)
-                feats, center = engine.point_encoder_forward(self._live_state(), "", self._cache(), None, None, dp, self.training, 0,
-                                                             self._cfg(), fetch=(3, 7, 11), grouped=(nbhd, center))
-            return (feats[0], feats[1], feats[2], center.contiguous(), c1.contiguous(), c2.contiguous()), None
+            return (center, c1, c2, nbhd), None
+
+        def blocks(nbhd, center):
+            dp = self._draw_drop_path(B, dev)
+            with torch.no_grad():                        # frozen backbone: features after blocks 3, 7, 11 (+ final LN, cls dropped)
+                feats, ctr = engine.point_encoder_forward(self._live_state(), "", self._cache(), None, None, dp, self.training, 0,
+                                                          self._cfg(), fetch=(3, 7, 11), grouped=(nbhd, center))
+            return (feats[0], feats[1], feats[2], ctr.contiguous()), None
+
+        def backbone(p):
+            (center, c1, c2, nbhd), _ = grouping(p)
+            (f0_, f1_, f2_, ctr), _ = blocks(nbhd, center)
+            return (f0_, f1_, f2_, ctr, c1, c2), None
 
         injected = self.fps_start is not None or self.drop_path_factors is not None or self.dropout_mask is not None
         key = ("partseg_backbone", (B, N), self.training, self._precision)
+        slot = None
         if (pts.is_cuda and self.use_hip_graphs and graphs.enabled and ops.profiler is None and (not injected or self._graph_injected)
                 and not torch.cuda.is_current_stream_capturing() and self._graphs.ready(key)):
-            outs, _ = self._graphs.get(key, lambda: graphs.GraphedCall(backbone, [pts]))(pts)
-            f_a, f_b, f_c, center, c1, c2 = (o.clone() for o in outs)          # (the decoder's autograd nodes keep them)
+            if self.group_ahead is not None:
+                # the caller vouches that `pts` is complete in memory (train.Trainer.inputs_ready): the grouping stage runs on its
+                # own stream as soon as the step is called -- under the previous iteration's decoder backward (0.3 ms of serial
+                # FPS walks off the head of the caller's stream) -- and only the blocks wait for it (graphs.AheadStage)
+                (center, c1, c2, nbhd), slot = self._ahead.run(self._graphs, ("partseg_group", (B, N)), grouping, [pts], self.group_ahead)
+                bkey = ("partseg_blocks", (B, N), self.training, self._precision)
+                outs, _ = self._graphs.get(bkey, lambda: graphs.GraphedCall(blocks, [nbhd, center]))(nbhd, center)
+                f_a, f_b, f_c, center = (o.clone() for o in outs)
+                c1, c2 = c1.clone(), c2.clone()
+                self._ahead.consumed(slot)
+            else:
+                outs, _ = self._graphs.get(key, lambda: graphs.GraphedCall(backbone, [pts]))(pts)
+                f_a, f_b, f_c, center, c1, c2 = (o.clone() for o in outs)          # (the decoder's autograd nodes keep them)
         else:
             (f_a, f_b, f_c, center, c1, c2), _ = backbone(pts)
         feats = (f_a, f_b, f_c)
