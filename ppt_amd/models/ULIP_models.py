@@ -602,6 +602,8 @@ class ULIP_WITH_IMAGE(nn.Module):
         C2 3.67 -> 3.50 ms per step, the optimum of 200 / 150 / 100 / 75 / 60 / 50 / 40 / 30 % of a workgroup per CU)."""
         if self.training and torch.is_grad_enabled() and self.chain_priority():
             return ops.persistent_occupancy(int(os.environ.get("PPT_TOWER_OCCUPANCY", "60")))
+        if self.training and torch.is_grad_enabled() and os.environ.get("PPT_TOWER_OCCUPANCY_ALWAYS"):
+            return ops.persistent_occupancy(int(os.environ["PPT_TOWER_OCCUPANCY_ALWAYS"]))       # (experiments)
         if self.training and torch.is_grad_enabled() and os.environ.get("PPT_TOWER_PRIO", "1") == "1":
             # the TOWER is the critical path (a training point side, or a long frozen encoder): its kernels that take the
             # priority argument are issued ahead of the chain's where they share a SIMD (C3 6.56 -> 6.53 ms, C5 7.69 -> 7.65 ms)
