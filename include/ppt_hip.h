@@ -391,7 +391,10 @@ int ppt_gemm_tn_bf16(const void *A, int64_t lda, const void *B, int64_t ldb, int
                      void *stream);
 
 /* nn.CrossEntropyLoss(label_smoothing, reduction='mean') over R rows of C <= 96 classes and its gradient (main_partseg.py:213;
- * main_cls.py:52,196): loss[0], dlogits [R,C] = d loss / d logits; partial: scratch of ceil(R / 128) floats.  Fixed summation order. */
+ * main_cls.py:52,196).  A label outside [0, C) (ignore_index = -100) is an ignored row, as in ATen: no loss, zero gradient, not
+ * counted in the mean.  loss: TWO floats -- loss[0] = the mean over the counted rows, loss[1] = R / counted rows (exactly 1 when
+ * none is ignored); dlogits [R,C] = d loss / d logits scaled by 1 / R: multiply by loss[1] for the exact gradient.
+ * partial: scratch of 2 * ceil(R / 128) floats.  Fixed summation order. */
 int ppt_cross_entropy_rows(const float *logits, const int64_t *labels, float smoothing, int64_t R, int C, float *loss, float *dlogits,
                            float *partial, void *stream);
 

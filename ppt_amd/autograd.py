@@ -404,6 +404,9 @@ def partseg_decoder_backward(ctxs, dy):
     return out + [g6[1], g6[2], g6[3], g6[4]]
 
 
+STATIC_GRADS_OK = False          # set by train.Trainer.step around loss.backward(): see _PartsegDecoder.backward
+
+
 class _PartsegDecoder(torch.autograd.Function):
     """forward(pe, f_a, f_b, f_c, center, c1, c2, pts, cls_label, drop, *partseg_decoder_params(pe)) -> y [B,N,128]; forward and
     backward are replayed from hipGraphs (captured at the first call per shape; activations live in the forward graph's pool)."""
@@ -440,6 +443,10 @@ class _PartsegDecoder(torch.autograd.Function):
                 return tuple(partseg_decoder_backward(ctxs, d)), None
             return graphs.GraphedCall(fn, [dy.contiguous()], pool=fwd.pool())
         grads, _ = ctx.pe._graphs.get(("partseg_decoder_bwd",) + ctx.key[1:], build)(dy.contiguous())
-        # (detached: fresh tensor objects over the graph's static buffers, which autograd may adopt as .grad without a copy --
-        # they are read by the optimizer before the next replay overwrites them)
-        return (None,) * 10 + tuple(gr.detach() for gr in grads)
+        # Inside train.Trainer.step (STATIC_GRADS_OK): fresh tensor objects over the graph's static buffers, which autograd adopts
+        # as .grad without a copy -- the step drops every .grad before each backward and its optimizer reads them before the next
+        # replay overwrites them.  Any other caller (gradient accumulation, a custom loop holding p.grad) gets copies: an adopted
+        # alias would be overwritten by the next replay and then added to itself.
+        if STATIC_GRADS_OK:
+            return (None,) * 10 + tuple(gr.detach() for gr in grads)
+        return (None,) * 10 + tuple(gr.clone() for gr in grads)

@@ -7,6 +7,8 @@ with the gpurun snapshot).  FPS / kNN are built with -ffp-contract=off on top of
 _rn intrinsics: their results must be bit-exact.
 """
 import concurrent.futures
+import hashlib
+import json
 import os
 import subprocess
 import sys
@@ -27,25 +29,46 @@ def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _digest(paths, extra=()):
+    """sha256 over the CONTENT of the files (and the flags): the prebuilt objects travel with the gpurun snapshot, where
+    modification times mean nothing -- an object is reused only if the bytes it was compiled from are the bytes in the tree."""
+    h = hashlib.sha256()
+    for x in extra:
+        h.update(x.encode() + b"\0")
+    for p in paths:
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+LAST_BUILD = {"compiled": [], "reused": [], "linked": False}       # what the last build() call did (__graft_entry__.build reports it)
 
 
 def build(force=False, verbose=True):
     bdir = os.path.join(CSRC, "_build")
     os.makedirs(bdir, exist_ok=True)
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
     headers.append(os.path.join(os.path.dirname(os.path.dirname(CSRC)), "include", "ppt_hip.h"))
-    jobs, objs = [], []
+    stamp_path = os.path.join(bdir, "stamps.json")
+    try:
+        with open(stamp_path) as fh:
+            stamps = json.load(fh)
+    except (OSError, ValueError):
+        stamps = {}
+    jobs, objs, new_stamps = [], [], {}
+    LAST_BUILD.update(compiled=[], reused=[], linked=False)
     for f in sources():
         src = os.path.join(CSRC, f)
         obj = os.path.join(bdir, f[:-4] + ".o")
         objs.append(obj)
-        if force or _stale(obj, [src] + headers):
-            jobs.append([HIPCC] + COMMON + PER_FILE.get(f, []) + ["-c", src, "-o", obj])
+        flags = COMMON + PER_FILE.get(f, [])
+        new_stamps[f] = _digest([src] + headers, flags)
+        if force or not os.path.exists(obj) or stamps.get(f) != new_stamps[f]:
+            jobs.append([HIPCC] + flags + ["-c", src, "-o", obj])
+            LAST_BUILD["compiled"].append(f)
+        else:
+            LAST_BUILD["reused"].append(f)
 
     def run(cmd):
         if verbose:
@@ -58,8 +81,12 @@ def build(force=False, verbose=True):
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
-    if jobs or force or _stale(OUT, objs):
+    new_stamps["__link__"] = hashlib.sha256("".join(new_stamps[f] for f in sorted(new_stamps)).encode()).hexdigest()
+    if jobs or force or not os.path.exists(OUT) or stamps.get("__link__") != new_stamps["__link__"]:
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+        LAST_BUILD["linked"] = True
+    with open(stamp_path, "w") as fh:
+        json.dump(new_stamps, fh, indent=0, sort_keys=True)
     return OUT
 
 

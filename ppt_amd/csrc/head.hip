@@ -212,41 +212,51 @@ __global__ __launch_bounds__(CE_ROWS) void ce_rows_kernel(const float *__restric
                                                           int64_t R, int C, float *__restrict__ dlogits, float *__restrict__ partial)
 {
     extern __shared__ float sm[];                         // [CE_ROWS][C + 1] (odd pitch for C even: no bank conflicts on the row walk)
-    __shared__ float red[CE_ROWS];
+    __shared__ float red[CE_ROWS], redc[CE_ROWS];
     const int pitch = C | 1;
     const int64_t r0 = (int64_t)blockIdx.x * CE_ROWS;
     const int nrow = (int)min((int64_t)CE_ROWS, R - r0);
     for (int i = threadIdx.x; i < nrow * C; i += CE_ROWS) sm[(i / C) * pitch + i % C] = logits[r0 * C + i];
     __syncthreads();
-    float lr = 0.f;
+    float lr = 0.f, cnt = 0.f;
     if ((int)threadIdx.x < nrow) {
         float *x = sm + threadIdx.x * pitch;
-        const int y = (int)labels[r0 + threadIdx.x];
+        const int64_t y64 = labels[r0 + threadIdx.x];
+        // a label outside [0, C) -- nn.CrossEntropyLoss's ignore_index (-100 by default) -- is an IGNORED row, as in ATen: no
+        // loss, zero gradient, not counted in the mean (ce_rows_finish divides by the number of counted rows)
+        const bool valid = y64 >= 0 && y64 < (int64_t)C;
+        const int y = valid ? (int)y64 : 0;
         float m = x[0], sx = 0.f;
         for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
         float z = 0.f;
         for (int c = 0; c < C; ++c) { z += expf(x[c] - m); sx += x[c]; }
         const float lse = m + logf(z);
-        lr = (1.0f - eps) * (lse - x[y]) + eps * (lse - sx / (float)C);
-        const float inv_r = 1.0f / (float)R, base = eps / (float)C;
+        lr = valid ? (1.0f - eps) * (lse - x[y]) + eps * (lse - sx / (float)C) : 0.f;
+        const float inv_r = valid ? 1.0f / (float)R : 0.f, base = eps / (float)C;
         for (int c = 0; c < C; ++c) x[c] = (expf(x[c] - lse) - (base + (c == y ? 1.0f - eps : 0.f))) * inv_r;
+        cnt = valid ? 1.f : 0.f;
     }
     red[threadIdx.x] = lr;
+    redc[threadIdx.x] = cnt;
     __syncthreads();
     for (int i = threadIdx.x; i < nrow * C; i += CE_ROWS) dlogits[r0 * C + i] = sm[(i / C) * pitch + i % C];
     if (threadIdx.x == 0) {
-        float t = 0.f;
-        for (int i = 0; i < CE_ROWS; ++i) t += red[i];
+        float t = 0.f, n = 0.f;
+        for (int i = 0; i < CE_ROWS; ++i) { t += red[i]; n += redc[i]; }
         partial[blockIdx.x] = t;
+        partial[gridDim.x + blockIdx.x] = n;
     }
 }
 
-__global__ __launch_bounds__(64) void ce_rows_finish(const float *__restrict__ partial, int n, float inv_r, float *__restrict__ loss)
+// loss[0] = sum / counted rows; loss[1] = R / counted rows: dlogits was scaled by 1 / R, the caller multiplies the incoming
+// gradient by loss[1] (exactly 1.0f when no row is ignored, so that case is bit for bit what it was)
+__global__ __launch_bounds__(64) void ce_rows_finish(const float *__restrict__ partial, int n, float r, float *__restrict__ loss)
 {
     if (threadIdx.x) return;
-    double t = 0.0;
-    for (int i = 0; i < n; ++i) t += (double)partial[i];
-    loss[0] = (float)(t * (double)inv_r);
+    double t = 0.0, cnt = 0.0;
+    for (int i = 0; i < n; ++i) { t += (double)partial[i]; cnt += (double)partial[n + i]; }
+    loss[0] = cnt > 0.0 ? (float)(t / cnt) : __uint_as_float(0x7fc00000u);      // (no counted row: NaN, as ATen)
+    loss[1] = cnt > 0.0 ? (float)((double)r / cnt) : 0.f;
 }
 
 extern "C" int ppt_cross_entropy_rows(const float *logits, const int64_t *labels, float smoothing, int64_t R, int C, float *loss,
@@ -258,7 +268,7 @@ extern "C" int ppt_cross_entropy_rows(const float *logits, const int64_t *labels
     hipLaunchKernelGGL(ce_rows_kernel, dim3(nwg), dim3(CE_ROWS), sizeof(float) * (size_t)CE_ROWS * (C | 1), ppt_stream(stream), logits, labels,
                        smoothing, R, C, dlogits, partial);
     PPT_CHECK_LAUNCH();
-    hipLaunchKernelGGL(ce_rows_finish, dim3(1), dim3(64), 0, ppt_stream(stream), partial, nwg, 1.0f / (float)R, loss);
+    hipLaunchKernelGGL(ce_rows_finish, dim3(1), dim3(64), 0, ppt_stream(stream), partial, nwg, (float)R, loss);
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }

@@ -74,7 +74,7 @@ _TEXT_STREAMS = {}
 def shared_text_stream(device=None, priority=None):
     """The process-wide side stream of `device` (one per GPU, shared by every model): created on first call.
     Which hardware queue a HIP stream gets depends on how many streams the process created before it, and some
-    positions execute in order with the caller's stream (4.8 -> 6.2 ... 7.5 ms per C2 step, tools/prio_test.py) -- so the
+    positions execute in order with the caller's stream (4.8 -> 6.2 ... 7.5 ms per C2 step, tools/prio_probe.py) -- so the
     stream is created ONCE, and callers that know better create it early: bench.py calls this right after
     set_device, before init_process_group lets RCCL create its own streams, which puts it in the same position as in
     the single-GPU run."""

@@ -271,14 +271,19 @@ class _TextTowerFn(torch.autograd.Function):
     backward) of a given shape are replayed from a captured hipGraph (ppt_amd/graphs.py)."""
 
     @staticmethod
-    def forward(ctx, model, prompts):
+    def forward(ctx, model, prompts, trusted_prefix=False):
         sd, cache = model._live_state(), model._cache()
         save = bool(ctx.needs_input_grad[1])
         prompts = prompts.contiguous().float()
         eot = model._eot(prompts.device)
         heads, layers = model.transformer.heads, model.transformer.layers
         eff = model._text_len() if model.truncate_text_to_eot else None
+        # prefix sharing is a property of the PROMPTS: PromptLearner's own output has it by construction (trusted_prefix, from
+        # _text_raw); any other tensor handed to the public encode_text is checked (ULIP_WITH_IMAGE._prefix_of) and falls back
+        # to the general evaluation when its leading positions differ between classes (ADVICE r2, medium)
         pre = model.prompt_learner.shared_prefix() if model.share_text_prefix else 0
+        if pre and not trusted_prefix:
+            pre = model._prefix_of(prompts, pre)
 
         prio = model.chain_priority()
 
@@ -316,7 +321,7 @@ class _TextTowerFn(torch.autograd.Function):
         prio = m.chain_priority()
         if ctx.graph is None:
             with ops.wave_priority(prio):
-                return None, engine.text_tower_backward(sd, cache, ctx.saved, dout)
+                return None, engine.text_tower_backward(sd, cache, ctx.saved, dout), None
         if ctx.graph.generation != ctx.generation:
             raise RuntimeError("the text tower's captured activations were overwritten by a later forward; set "
                                "model.use_hip_graphs = False to keep several forwards alive before backward")
@@ -328,7 +333,7 @@ class _TextTowerFn(torch.autograd.Function):
                     return (engine.text_tower_backward(sd, cache, saved, d),), None
             return graphs.GraphedCall(fn, [dout.contiguous()], pool=fwd.pool())
         (dp,), _ = m._graphs.get(("text_bwd",) + ctx.key[1:], build)(dout)
-        return None, dp.clone()
+        return None, dp.clone(), None
 
 
 class _TextTowerTokensFn(torch.autograd.Function):
@@ -654,8 +659,16 @@ class ULIP_WITH_IMAGE(nn.Module):
         return self.precision if (self.task == 'partseg' and self.precision == torch.bfloat16) else torch.float32
 
     def encode_text(self, prompts, tokenized_prompts=None):
-        """ULIP_models.py:203-222: prompts [C,77,W] -> [C,embed_dim]."""
-        return _TextTowerFn.apply(self, prompts)
+        """ULIP_models.py:203-222: prompts [C,77,W] -> [C,embed_dim].  General in `prompts`, as the reference: the shared-prefix
+        evaluation is used only when the tensor's leading positions really are the same for every class."""
+        return _TextTowerFn.apply(self, prompts, False)
+
+    def _prefix_of(self, prompts, cand):
+        """`cand` if positions 0 .. cand-1 of `prompts` [C,L,W] are identical in every class, else 0.  One host read per call:
+        the public encode_text is not the training path (train.Trainer goes through _text_raw, whose prompts are PromptLearner's)."""
+        if prompts.shape[1] < cand:
+            return 0
+        return cand if bool((prompts[:, :cand] == prompts[:1, :cand]).all().item()) else 0
 
     def encode_pc(self, pc, cls_label=None):
         """ULIP_models.py:250-258."""
@@ -672,7 +685,7 @@ class ULIP_WITH_IMAGE(nn.Module):
         tok = self.prompt_learner.learnable_tokens
         if self.fused_prompt_rows and tok.is_cuda and self.prompt_learner.class_name_position in ("front", "middle", "end"):
             return _TextTowerTokensFn.apply(self, tok)
-        return self.encode_text(self.prompt_learner(), self.tokenized_prompts)
+        return _TextTowerFn.apply(self, self.prompt_learner(), True)        # PromptLearner's output: the prefix is shared by construction
 
     def _text_embed(self):
         # inference fast path: the text features depend only on the prompt tokens, so

@@ -250,15 +250,17 @@ class wave_priority:
 
 
 def cross_entropy_rows(logits, labels, smoothing):
-    """(loss 0-d, dlogits [R,C]) of nn.CrossEntropyLoss(label_smoothing=smoothing) with mean reduction (ppt_cross_entropy_rows)."""
+    """(loss 0-d, dlogits [R,C], scale 0-d) of nn.CrossEntropyLoss(label_smoothing=smoothing) with mean reduction
+    (ppt_cross_entropy_rows).  Rows whose label lies outside [0, C) are ignored as ATen ignores ignore_index; dlogits is scaled
+    by 1 / R and `scale` = R / counted rows (1.0 when none is ignored) completes it."""
     _chk(logits, torch.float32, "logits"); _chk(labels, torch.int64, "labels")
     R, C = logits.shape
-    loss = torch.empty((), dtype=torch.float32, device=logits.device)
+    out = torch.empty((2,), dtype=torch.float32, device=logits.device)
     dlogits = torch.empty_like(logits)
-    partial = torch.empty(((R + 127) // 128,), dtype=torch.float32, device=logits.device)
-    _lib.check(_lib.lib().ppt_cross_entropy_rows(_p(logits), _p(labels), float(smoothing), R, C, _p(loss), _p(dlogits), _p(partial),
+    partial = torch.empty((2 * ((R + 127) // 128),), dtype=torch.float32, device=logits.device)
+    _lib.check(_lib.lib().ppt_cross_entropy_rows(_p(logits), _p(labels), float(smoothing), R, C, _p(out), _p(dlogits), _p(partial),
                                                  _stream()), "ppt_cross_entropy_rows")
-    return loss, dlogits
+    return out[0], dlogits, out[1]
 
 
 class persistent_occupancy:

@@ -80,6 +80,7 @@ class FlatGradSync:
             if w > 1:
                 g.div_(w)
             self.flat = g.detach().view(-1)
+            self.views = [self.flat.view_as(self.params[0])]        # (readers of either see the reduced gradient)
             return
         if self.lazy:
             with torch.no_grad():
@@ -128,20 +129,67 @@ class BufferBroadcast:
             dist.broadcast(self.flat, src=0, group=self.group)
 
 
+def broadcast_module_states(model, process_group=None, src=0, chunk_bytes=256 << 20):
+    """What DistributedDataParallel's constructor does before the first forward (main_cls.py:47-49; torch's
+    `_sync_module_states`): rank `src`'s parameters AND buffers overwrite every other rank's, in flat chunks of at most
+    `chunk_bytes` (DDP's 250 MB buckets) -- ONE collective for the trainable set of every PPT configuration.  With the
+    reference's per-rank seeding (`seed = args.seed + rank`, main_cls.py:39) this broadcast is the only thing that makes
+    `learnable_tokens` and the randomly initialised un-frozen last block equal across ranks.  Tensors that are
+    neither parameter nor buffer -- PromptLearner.embedding (App. A Q1) -- stay per-rank, as under DDP.
+    Trainable parameters go first (their own chunk), then the frozen ones, then the buffers.  Returns the number of collectives."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0
+    seen, groups = set(), [[], [], []]
+    for p in model.parameters():
+        if id(p) not in seen:
+            seen.add(id(p))
+            groups[0 if p.requires_grad else 1].append(p.data)
+    for b in model.buffers():
+        if b is not None and id(b) not in seen:
+            seen.add(id(b))
+            groups[2].append(b.data)
+    calls = 0
+    with torch.no_grad():
+        for tensors in groups:
+            by_type = {}
+            for t in tensors:
+                by_type.setdefault((t.dtype, t.device), []).append(t)
+            for (dtype, dev), ts in by_type.items():
+                i = 0
+                while i < len(ts):
+                    j, n = i, 0
+                    while j < len(ts) and (j == i or (n + ts[j].numel()) * ts[j].element_size() <= chunk_bytes):
+                        n += ts[j].numel()
+                        j += 1
+                    flat = torch.empty(n, dtype=dtype, device=dev)
+                    off = 0
+                    for t in ts[i:j]:
+                        flat[off:off + t.numel()].copy_(t.reshape(-1))
+                        off += t.numel()
+                    dist.broadcast(flat, src=src, group=process_group)
+                    calls += 1
+                    off = 0
+                    for t in ts[i:j]:
+                        t.copy_(flat[off:off + t.numel()].view_as(t))
+                        off += t.numel()
+                    i = j
+    return calls
+
+
 class _CrossEntropyRows(torch.autograd.Function):
     """nn.CrossEntropyLoss(label_smoothing) as one node: the forward pass over the logits also forms d loss / d logits."""
 
     @staticmethod
     def forward(ctx, logits, labels, smoothing):
         from . import ops
-        loss, dlogits = ops.cross_entropy_rows(logits, labels, smoothing)
-        ctx.save_for_backward(dlogits)
+        loss, dlogits, scale = ops.cross_entropy_rows(logits, labels, smoothing)
+        ctx.save_for_backward(dlogits, scale)
         return loss
 
     @staticmethod
     def backward(ctx, dloss):
-        (dlogits,) = ctx.saved_tensors
-        return dlogits * dloss, None, None
+        dlogits, scale = ctx.saved_tensors
+        return dlogits * (dloss * scale), None, None
 
 
 class Trainer:
@@ -209,6 +257,9 @@ class Trainer:
             (not p.requires_grad) or n.startswith("prompt_learner.") or
             (n.startswith("point_encoder.") and n[len("point_encoder."):].startswith(dec)) for n, p in model.named_parameters())
         self.bcast = BufferBroadcast(model) if distributed else None
+        if distributed:
+            # DDP's constructor: rank 0's parameters and buffers everywhere before the first step (see the function)
+            self.init_broadcasts = broadcast_module_states(model)
         # BufferBroadcast re-bound the BatchNorm buffers to views of its flat tensor: every state-dict view, operand copy
         # and captured hipGraph made before that points at the orphaned storage
         if hasattr(model, "reset_caches"):
@@ -270,7 +321,12 @@ class Trainer:
         if side is not None:
             side.wait_stream(main)
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-            loss.backward()                                         # (retain_graph only served Q2)
+            from . import autograd as _ag
+            _ag.STATIC_GRADS_OK = self.sync.lazy                    # .grad dropped before every backward, read before the next replay
+            try:
+                loss.backward()                                     # (retain_graph only served Q2)
+            finally:
+                _ag.STATIC_GRADS_OK = False
             if self.distributed:
                 self.sync.all_reduce()
             self._optimizer_step()
@@ -296,8 +352,11 @@ class Trainer:
     def _loss(self, logits, labels):
         """self.criterion (main_cls.py:52: CrossEntropyLoss with label smoothing, mean reduction); on a GPU with <= 96 classes the
         loss and its gradient come from one pass over the logits (ops.cross_entropy_rows) instead of ~10 ATen kernels."""
+        # (ppt_cross_entropy_rows treats a label outside [0, C) -- nn.CrossEntropyLoss's ignore_index = -100 -- as an ignored row:
+        # zero loss and gradient, left out of the mean, as ATen does)
+        ign = self.criterion.ignore_index
         if logits.is_cuda and logits.dtype == torch.float32 and logits.shape[1] <= 96 and labels.dtype == torch.int64 \
-                and self.criterion.weight is None and self.criterion.reduction == 'mean':
+                and self.criterion.weight is None and self.criterion.reduction == 'mean' and not (0 <= ign < logits.shape[1]):
             return _CrossEntropyRows.apply(logits.contiguous(), labels.contiguous(), float(self.criterion.label_smoothing))
         return self.criterion(logits, labels)
 
@@ -322,6 +381,11 @@ class Trainer:
                 b1, b2 = g['betas']
                 ops.adamw_step(p.data, p.grad, st['exp_avg'], st['exp_avg_sq'], float(g['lr']), float(b1), float(b2), float(g['eps']),
                                float(g['weight_decay']), int(st['step'].item()))
+                # the kernel wrote through a raw pointer: tell autograd's version counter, as torch.optim.AdamW's in-place ops
+                # would.  Two caches key on it -- ULIP_WITH_IMAGE._te_cache (validate()'s text features) and
+                # engine.WeightCache (the bf16 / transposed operand copies of a trained last-block weight) -- and would otherwise
+                # keep serving the values of the FIRST step
+                torch.autograd.graph.increment_version(p)
 
     def _drain_gate(self):
         pe = getattr(self.model, "point_encoder", None)
@@ -363,26 +427,31 @@ def reference_optimizer_state(model, optimizer):
     return {'state': state, 'param_groups': groups}
 
 
-def checkpoint_payload(model, optimizer, epoch, best_acc, args, head_type=0, partseg=False):
-    """The dict the reference writes as checkpoint_best.pt: main_cls.py:118-137 saves the
-    prompt learner ('state_dict' = {'learnable_tokens'}), the last block when head_type > 0, the optimizer and args;
-    main_partseg.py:127-143 saves the whole point encoder under 'state_dict_partseg'.  Keys are the reference's, so
-    save_recog_feats.py:29-35 / interpret_prompt.py:25-28 style readers work on it."""
+def checkpoint_payload(model, optimizer, epoch, best_acc, args, head_type=0, partseg=False, best_mean_class_iou=None,
+                       best_mean_inst_iou=None):
+    """The dict the reference writes as checkpoint_best.pt, with the reference's keys so that its readers
+    work on the file (save_recog_feats.py:29-35, interpret_prompt.py:25-28, notebook/show_balls.py:219):
+      recognition (main_cls.py:118-137): 'epoch', 'state_dict' (= {'learnable_tokens'}), 'last_block' (block 11 when
+        head_type > 0, else None), 'optimizer', 'best_acc', 'args';
+      part segmentation (main_partseg.py:127-143): 'epoch', 'state_dict_prompt', 'state_dict_partseg' (the whole point
+        encoder), 'optimizer', 'best_test_acc', 'best_mean_class_iou', 'best_mean_inst_iou', 'args' (`best_acc` is the test
+        accuracy there)."""
     if torch.cuda.is_available():
         torch.cuda.synchronize()           # Trainer.step leaves the optimizer queued on the model's text stream
-    data = {'epoch': epoch + 1, 'state_dict': model.prompt_learner.state_dict(),
-            'optimizer': reference_optimizer_state(model, optimizer),
-            'best_acc': best_acc, 'args': args}
+    opt = reference_optimizer_state(model, optimizer)
     if partseg:
-        data['state_dict_partseg'] = model.point_encoder.state_dict()
-    else:
-        data['last_block'] = model.point_encoder.blocks.blocks[-1].state_dict() if head_type > 0 else None
-    return data
+        return {'epoch': epoch + 1, 'state_dict_prompt': model.prompt_learner.state_dict(),
+                'state_dict_partseg': model.point_encoder.state_dict(), 'optimizer': opt, 'best_test_acc': best_acc,
+                'best_mean_class_iou': best_mean_class_iou, 'best_mean_inst_iou': best_mean_inst_iou, 'args': args}
+    return {'epoch': epoch + 1, 'state_dict': model.prompt_learner.state_dict(),
+            'last_block': model.point_encoder.blocks.blocks[-1].state_dict() if head_type > 0 else None,
+            'optimizer': opt, 'best_acc': best_acc, 'args': args}
 
 
 def load_prompt_checkpoint(model, ckpt):
     """Inverse of checkpoint_payload for evaluation (save_recog_feats.py:29-35): prompt tokens + optional last block."""
-    model.prompt_learner.load_state_dict(ckpt['state_dict'])
+    prompt = ckpt['state_dict'] if 'state_dict' in ckpt else ckpt['state_dict_prompt']      # main_cls.py:132 / main_partseg.py:135
+    model.prompt_learner.load_state_dict(prompt)
     if ckpt.get('last_block'):
         blk = {'point_encoder.blocks.blocks.11.' + k: v for k, v in ckpt['last_block'].items()}
         model.load_state_dict(blk, strict=False)

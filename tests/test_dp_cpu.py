@@ -49,7 +49,11 @@ def _worker(rank, world, port, ret):
     m = TinyModel()
     if rank == 1:                       # rank 1 starts with different BN buffers: the broadcast must fix that
         m.bn.running_mean.fill_(3.0)
+        with torch.no_grad():           # ... and with different TRAINABLE values (main_cls.py:39 seeds seed + rank): DDP's
+            m.prompt.add_(1.0)          # constructor broadcast (train.broadcast_module_states) must overwrite them
     tr = Trainer(m, lr=1e-2, distributed=True)
+    if rank == 1:
+        m.bn.running_mean.fill_(3.0)    # (diverge again AFTER the constructor broadcast: finish() must still fix it)
     g = torch.Generator().manual_seed(123)
     x = torch.randn(8, 4, generator=g)
     y = torch.randint(0, 5, (8,), generator=g)
@@ -136,10 +140,11 @@ def _real_worker(rank, world, port, head_type, ret):
     args = SimpleNamespace(classnames=M.dataset_classnames("modelnet40"), template_init='', class_name_position='middle',
                            num_learnable_prompt_tokens=32, gpu=0, task='cls', head_type=head_type, evaluate_3d=False,
                            ulip2=False, synthetic_weights=True)
-    torch.manual_seed(0)
+    torch.manual_seed(0 + rank)          # main_cls.py:39: seed = args.seed + rank -> every rank draws its own initial values
     with contextlib.redirect_stdout(io.StringIO()):
         m = M.ULIP_PointBERT(args)
     trainable = [(n, p) for n, p in m.named_parameters() if p.requires_grad]
+    init_own = {n: p.detach().clone() for n, p in trainable}
     g = torch.Generator().manual_seed(99)
     coef = {n: torch.randn(p.shape, generator=g) * 1e-2 for n, p in trainable}
     w = torch.randn(40, generator=g)
@@ -164,6 +169,11 @@ def _real_worker(rank, world, port, head_type, ret):
         return real_bc(t, *a, **k)
     dist.all_reduce, dist.broadcast = counting_ar, counting_bc
     tr = Trainer(m, lr=1e-3, distributed=True)
+    bc_init = calls["broadcast"]
+    calls["broadcast"] = 0
+    if rank == 1:
+        bn.running_mean.fill_(3.0)       # (the constructor broadcast equalised it: diverge again for the finish() check)
+    after_ctor = {n: p.detach().clone() for n, p in trainable}
     n_flat = tr.sync.flat.numel()
     views_ok = bn.running_mean.data_ptr() >= tr.bcast.flat.data_ptr() and \
         bn.running_mean.data_ptr() < tr.bcast.flat.data_ptr() + 4 * tr.bcast.flat.numel()
@@ -172,8 +182,11 @@ def _real_worker(rank, world, port, head_type, ret):
     y = torch.randint(0, 40, (8,), generator=gx)
     p0 = {n: p.detach().clone() for n, p in trainable}
     steps = 3
-    for _ in range(steps):
+    after_first = None
+    for it in range(steps):
         tr.step(x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4])
+        if it == 0:
+            after_first = {n: p.detach().numpy().copy() for n, p in trainable}
         if rank == 0:
             bn.running_mean.add_(0.25)          # what a train-mode forward does to rank 0's running statistics
     grad_last = tr.sync.flat.clone()
@@ -184,7 +197,9 @@ def _real_worker(rank, world, port, head_type, ret):
     # after the update, so the first step is checked instead by the parent (from p0); here: hand back what it needs
     ret[rank] = dict(n_flat=n_flat, ar=ar_during, bc_during=bc_during, bc_total=calls["broadcast"], numel=calls["numel"],
                      views_ok=views_ok, grad=grad_last.numpy(), rm_mid=rm_mid.numpy(), rm=bn.running_mean.numpy().copy(),
-                     params={n: p.detach().numpy().copy() for n, p in trainable}, steps=steps,
+                     params={n: p.detach().numpy().copy() for n, p in trainable}, steps=steps, bc_init=bc_init,
+                     init_differs=any(not torch.equal(init_own[n], after_ctor[n]) for n in init_own),
+                     after_ctor={n: v.numpy() for n, v in after_ctor.items()}, after_first=after_first,
                      still_view=bn.running_mean.data_ptr() == m.state_dict()["point_encoder.encoder.first_conv.1.running_mean"].data_ptr())
     dist.all_reduce, dist.broadcast = real_ar, real_bc
     dist.destroy_process_group()
@@ -202,6 +217,13 @@ def test_real_trainable_sets_one_allreduce_per_step(head_type):
     # exactly ONE all-reduce per step, over the whole flat buffer, and no broadcast inside the steps
     assert r0["ar"] == r1["ar"] == r0["steps"] and set(r0["numel"]) == {REAL_SIZES[head_type]}
     assert r0["bc_during"] == r1["bc_during"] == 0 and r0["bc_total"] == r1["bc_total"] == 1
+    # DDP's constructor broadcast (main_cls.py:47-49): the ranks were seeded seed + rank (main_cls.py:39), so rank 1 drew its
+    # own learnable tokens / last block; after Trainer() it holds rank 0's, which kept its own
+    assert r0["bc_init"] == r1["bc_init"] and 1 <= r0["bc_init"] <= 8
+    assert r1["init_differs"] and not r0["init_differs"]
+    for n in r0["after_ctor"]:
+        assert np.array_equal(r0["after_ctor"][n], r1["after_ctor"][n]), n
+        assert np.array_equal(r0["after_first"][n], r1["after_first"][n]), n
     # same averaged gradient, same parameters on both ranks after three steps
     assert np.array_equal(r0["grad"], r1["grad"]) and np.abs(r0["grad"]).max() > 0
     for n in r0["params"]:

@@ -1010,11 +1010,34 @@ def test_cross_entropy_rows_matches_torch(ops, R, C, eps):
     labels = torch.randint(0, C, (R,), generator=g).cuda()
     ref = torch.nn.CrossEntropyLoss(label_smoothing=eps)(logits.double(), labels)
     (gref,) = torch.autograd.grad(ref, logits)
-    loss, dl = ops.cross_entropy_rows(logits.detach(), labels, eps)
-    loss2, dl2 = ops.cross_entropy_rows(logits.detach(), labels, eps)
-    assert torch.equal(loss, loss2) and torch.equal(dl, dl2)
+    loss, dl, scale = ops.cross_entropy_rows(logits.detach(), labels, eps)
+    loss2, dl2, _ = ops.cross_entropy_rows(logits.detach(), labels, eps)
+    assert torch.equal(loss, loss2) and torch.equal(dl, dl2) and scale.item() == 1.0
     assert abs(loss.item() - ref.item()) < 2e-6 * max(1.0, abs(ref.item()))
     assert (dl - gref).abs().max().item() < 2e-6 / R * 10 + 1e-7
+
+
+@pytest.mark.parametrize("R,C,eps", [(700, 50, 0.2), (64, 15, 0.0)])
+def test_cross_entropy_rows_ignores_out_of_range_labels(ops, R, C, eps):
+    """a label of -100 (nn.CrossEntropyLoss's ignore_index) or >= C is an ignored row, as in ATen -- no loss,
+    zero gradient, left out of the mean -- instead of an out-of-range LDS read."""
+    g = torch.Generator().manual_seed(R)
+    logits = (torch.randn(R, C, generator=g) * 4).cuda().requires_grad_(True)
+    labels = torch.randint(0, C, (R,), generator=g)
+    labels[::7] = -100
+    labels = labels.cuda()
+    ref = torch.nn.CrossEntropyLoss(label_smoothing=eps)(logits.double(), labels)
+    (gref,) = torch.autograd.grad(ref, logits)
+    loss, dl, scale = ops.cross_entropy_rows(logits.detach(), labels, eps)
+    n_valid = int((labels >= 0).sum())
+    assert abs(scale.item() - R / n_valid) < 1e-6 * R / n_valid
+    assert abs(loss.item() - ref.item()) < 2e-6 * max(1.0, abs(ref.item()))
+    assert (dl * scale - gref).abs().max().item() < 2e-5 / n_valid + 1e-7
+    assert dl[::7].abs().max().item() == 0.0
+    from ppt_amd.train import _CrossEntropyRows
+    lg = logits.detach().clone().requires_grad_(True)
+    _CrossEntropyRows.apply(lg, labels, eps).backward()
+    assert (lg.grad - gref).abs().max().item() < 2e-5 / n_valid + 1e-7
 
 
 def test_wave_priority_changes_no_result(ops):

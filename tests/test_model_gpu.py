@@ -259,6 +259,41 @@ def test_validation_between_training_epochs_reads_current_weights(head_type):
     assert not torch.equal(outs[True][0], outs[True][2]), "training changed the logits between the two validations"
 
 
+@pytest.mark.parametrize("head_type", [0, 1])
+def test_fused_adamw_keeps_eval_caches_current(head_type):
+    """ppt_adamw_step writes parameters through a raw pointer; without a version bump the eval text-feature
+    cache (_te_cache) and the operand copies of a trained last-block weight (engine.WeightCache) would keep the values of the
+    first step.  train -> eval -> train -> eval with the fused AdamW against torch.optim.AdamW: same logits at every validation
+    (the two optimizers are bit-identical per step, test_adamw_step_matches_torch), and the validations differ from each other."""
+    from ppt_amd.train import Trainer
+    pc, start = oracle_inputs()
+    pc = pc.cuda()
+    labels = torch.tensor([1, 7, 30, 12]).cuda()
+    outs = {}
+    for fused in (False, True):
+        m, _ = build(head_type, torch.bfloat16)
+        m.point_encoder.fps_start = torch.from_numpy(start).cuda()
+        m.point_encoder.drop_path_factors = torch.ones(12, 2, 4)
+        tr = Trainer(m, lr=3e-2, distributed=False)
+        tr.fused_adamw = fused
+        seq = []
+        for epoch in range(3):
+            m.train()
+            for _ in range(3):
+                tr.step(pc, labels)
+            tr.finish()
+            m.eval()
+            with torch.no_grad():
+                for _ in range(2):
+                    lg = m(pc)
+            seq.append(lg.float().cpu().clone())
+        outs[fused] = seq
+    moved = min((outs[False][0] - outs[False][1]).abs().max().item(), (outs[False][1] - outs[False][2]).abs().max().item())
+    assert moved > 0.5, moved                                 # training moves the validation logits (|logits| ~ 45)
+    for a, b in zip(outs[False], outs[True]):                 # ... and the fused optimizer's validations follow, every epoch
+        assert (a - b).abs().max().item() < 0.05 * moved, ((a - b).abs().max().item(), moved)
+
+
 def test_replayed_activations_are_guarded_against_a_second_forward():
     """head_type 3 keeps the prefix's activations in the graph's buffers: a backward through a forward that a later
     forward has overwritten must fail loudly (and work with use_hip_graphs = False)."""
@@ -841,6 +876,25 @@ def test_text_prefix_sharing_is_exact(position, want_p):
     assert torch.equal(res[False][0], res[True][0])
     rel = ((res[False][1] - res[True][1]).norm() / res[False][1].norm()).item()
     assert rel < 1e-5, rel
+
+
+def test_encode_text_with_per_class_prefixes_is_not_prefix_shared():
+    """the public encode_text is general in `prompts`.  Prompts whose leading positions differ per class must
+    not take the shared-prefix evaluation (which reads positions 0 .. P-1 from prompt 0 only): features and input gradient equal
+    the evaluation with sharing switched off, bit for bit."""
+    m = _token_structured_model(0, torch.float32, "middle")
+    assert m.prompt_learner.shared_prefix() == 17
+    g = torch.Generator().manual_seed(3)
+    base = m.prompt_learner().detach()
+    prompts = (base + 0.05 * torch.randn(base.shape, generator=g).cuda()).requires_grad_(True)     # per-class contexts
+    res = {}
+    for share in (False, True):
+        m.share_text_prefix = share
+        prompts.grad = None
+        te = m.encode_text(prompts, m.tokenized_prompts)
+        (te * torch.randn(te.shape, generator=torch.Generator().manual_seed(1)).cuda()).sum().backward()
+        res[share] = (te.detach().clone(), prompts.grad.detach().clone())
+    assert torch.equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
 
 
 def test_text_prefix_sharing_bf16_and_training_step():

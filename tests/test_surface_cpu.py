@@ -163,6 +163,30 @@ def test_checkpoint_payload_roundtrip(tmp_path):
     assert torch.equal(m2.point_encoder.blocks.blocks[-1].mlp.fc2.weight, m.point_encoder.blocks.blocks[-1].mlp.fc2.weight)
 
 
+def test_partseg_checkpoint_payload_uses_the_reference_keys(tmp_path):
+    """main_partseg.py:134-143 writes 'state_dict_prompt' / 'state_dict_partseg' / 'best_test_acc' / 'best_mean_class_iou' /
+    'best_mean_inst_iou'; notebook/show_balls.py:219 reads saved_data['state_dict_prompt']."""
+    from types import SimpleNamespace
+    from ppt_amd.models import ULIP_models as models
+    from ppt_amd.train import checkpoint_payload, load_prompt_checkpoint
+    a = SimpleNamespace(classnames=models.dataset_classnames("shapenetpart"), template_init='', class_name_position='middle',
+                        num_learnable_prompt_tokens=32, gpu=0, task='partseg', head_type=0, evaluate_3d=False, ulip2=False,
+                        synthetic_weights=True)
+    m = models.ULIP_PointBERT_partseg(a)
+    opt = torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-3)
+    payload = checkpoint_payload(m, opt, epoch=2, best_acc=93.0, args={}, partseg=True, best_mean_class_iou=81.0,
+                                 best_mean_inst_iou=84.5)
+    assert set(payload) == {'epoch', 'state_dict_prompt', 'state_dict_partseg', 'optimizer', 'best_test_acc',
+                            'best_mean_class_iou', 'best_mean_inst_iou', 'args'}
+    assert list(payload['state_dict_prompt']) == ['learnable_tokens'] and payload['best_test_acc'] == 93.0
+    f = tmp_path / "checkpoint_best.pt"
+    torch.save(payload, f)
+    m2 = models.ULIP_PointBERT_partseg(a)
+    load_prompt_checkpoint(m2, torch.load(f, weights_only=False))
+    assert torch.equal(m2.prompt_learner.learnable_tokens, m.prompt_learner.learnable_tokens)
+    assert torch.equal(m2.point_encoder.conv1.weight, m.point_encoder.conv1.weight)
+
+
 # ---- N2: the read side of the checkpoint formats (ULIP_models.py:472-507, point_encoder.py:206-232) ----------------
 def _fake_pretrained(tmp_path, head_type=2):
     """Synthetic pointbert.pt / slip_base_100ep.pt in the reference's on-disk layout: {'state_dict': {'module.<key>': t}}.
