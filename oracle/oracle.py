@@ -59,6 +59,27 @@ def fps(xyz, M, start):
     return out
 
 
+def dataset_farthest_point_sample(point, npoint, start):
+    """data/dataset_3d.py:40-61 farthest_point_sample(point [N,D], npoint) -> point[centroids] [npoint,D], with the random
+    start (np.random.randint, :51) injected.  Restated as the loop it is: float32 coordinates, `dist` in the array's dtype
+    ((dx^2 + dy^2) + dz^2, numpy's 3-term sum), the running `distance` in float64 starting at 1e10, strict `<` update, first
+    arg-max.  Returns (rows, indices)."""
+    point = np.asarray(point)
+    xyz = point[:, :3]
+    N = xyz.shape[0]
+    idx = np.zeros((npoint,), np.int64)
+    distance = np.ones((N,)) * 1e10
+    far = int(start)
+    for i in range(npoint):
+        idx[i] = far
+        d = xyz - xyz[far]
+        dist = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        mask = dist < distance
+        distance[mask] = dist[mask]
+        far = int(np.argmax(distance))
+    return point[idx], idx
+
+
 def square_distance(src, dst):
     """dvae.py:130-149.  src [B,S,3], dst [B,N,3] -> [B,S,N]."""
     src = np.ascontiguousarray(src, np.float32)

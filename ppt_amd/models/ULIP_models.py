@@ -14,6 +14,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from .. import blocks as _blk
 from .. import engine, graphs, ops
 
 _DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data")
@@ -21,7 +22,12 @@ CONTEXT_LENGTH = 77
 
 
 class LayerNorm(nn.LayerNorm):
-    """ULIP_models.py:21-27 (parameter container; fp32 statistics are what the kernel computes)."""
+    """ULIP_models.py:21-27: fp32 statistics whatever the input dtype.  On the device forward() is ppt_layernorm_fwd / _bwd."""
+
+    def forward(self, x):
+        if x.is_cuda:
+            return _blk.layer_norm(x, self.weight, self.bias, self.eps)
+        return super().forward(x.type(torch.float32)).type(x.dtype)
 
 
 class QuickGELU(nn.Module):
@@ -43,6 +49,36 @@ class ResidualAttentionBlock(nn.Module):
         self.ln_2 = LayerNorm(d_model)
         self.attn_mask = attn_mask
 
+    def _is_causal(self, L):
+        """The only mask the reference ever builds is the causal one (ULIP_models.py:224-230); the attention kernel applies
+        it itself.  Any other additive mask is not supported by the kernels."""
+        m = self.attn_mask
+        if m is None:
+            return False
+        want = torch.full((L, L), float("-inf")).triu_(1)
+        if m.shape[0] < L or not torch.equal(m[:L, :L].detach().float().cpu(), want):
+            raise NotImplementedError("ResidualAttentionBlock: only attn_mask = None or the causal mask of build_attention_mask")
+        return True
+
+    def attention(self, x):
+        """ULIP_models.py:49-51: nn.MultiheadAttention(x, x, x, attn_mask)[0]; x [L, N, D] (sequence first)."""
+        L, N, D = x.shape
+        a = self.attn
+        heads = a.num_heads
+        y = _blk.self_attention(x.transpose(0, 1), a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias, heads,
+                                float(D // heads) ** -0.5, self._is_causal(L), getattr(self, "precision", None))
+        return y.transpose(0, 1)
+
+    def forward(self, x):
+        """ULIP_models.py:53-56; x [L, N, D]."""
+        if not x.is_cuda:
+            raise RuntimeError("ppt_amd modules run on the HIP device only (no CPU fallback)")
+        x = x + self.attention(self.ln_1(x))
+        h = self.ln_2(x)
+        x = x + _blk.mlp(h, self.mlp.c_fc.weight, self.mlp.c_fc.bias, self.mlp.c_proj.weight, self.mlp.c_proj.bias,
+                         ops.ACT_QUICKGELU, getattr(self, "precision", None))
+        return x
+
 
 class Transformer(nn.Module):
     """ULIP_models.py:59-67."""
@@ -53,6 +89,10 @@ class Transformer(nn.Module):
         self.layers = layers
         self.heads = heads
         self.resblocks = nn.Sequential(*[ResidualAttentionBlock(width, heads, attn_mask) for _ in range(layers)])
+
+    def forward(self, x):
+        """ULIP_models.py:66-67; x [L, N, D]."""
+        return self.resblocks(x)
 
 
 # ---- prompt tokenisation (SURVEY.md §8(f) N3: token-id table captured from the reference tokenizer)
@@ -570,6 +610,9 @@ class ULIP_WITH_IMAGE(nn.Module):
             self.point_encoder._graphs.clear()
         if hasattr(self.point_encoder, "encoder"):
             self.point_encoder.encoder.precision = dtype
+        for m in self.modules():                     # the callable sub-modules (ppt_amd/blocks.py) follow the model's mode
+            if type(m).__name__ in ("Mlp", "Attention", "Block", "ResidualAttentionBlock"):
+                m.precision = dtype
         return self
 
     def _cache(self):

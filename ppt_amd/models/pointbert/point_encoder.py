@@ -6,12 +6,19 @@ import os
 import torch
 import torch.nn as nn
 
+from ... import blocks as _blk
 from ... import engine, graphs, ops
 from .dvae import Encoder, Group
 
 
+def _prec(m):
+    return getattr(m, "precision", None) or _blk.DEFAULT_PRECISION
+
+
 class Mlp(nn.Module):
-    """point_encoder.py:14-30 (parameter container; computed inside engine.vit_block_forward)."""
+    """point_encoder.py:14-30.  Inside PointTransformer the block is computed by engine.vit_block_forward (one autograd node
+    per tower); called on its own, forward() runs the same kernels through ppt_amd.blocks (GEMMs with the GELU and its
+    derivative in their epilogues, weight gradients included)."""
 
     def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
         super().__init__()
@@ -21,6 +28,17 @@ class Mlp(nn.Module):
         self.act = act_layer()
         self.fc2 = nn.Linear(hidden_features, out_features)
         self.drop = nn.Dropout(drop)
+
+    def forward(self, x):
+        """point_encoder.py:24-30 (x [..., in_features])."""
+        if not x.is_cuda:
+            raise RuntimeError("ppt_amd modules run on the HIP device only (no CPU fallback)")
+        if self.drop.p:
+            raise NotImplementedError("Mlp with drop > 0: every PPT configuration builds it with drop = 0 (point_encoder.py:147)")
+        act = {nn.GELU: ops.ACT_GELU}.get(type(self.act))
+        if act is None:
+            raise NotImplementedError(f"Mlp activation {type(self.act).__name__}: the GEMM epilogues implement nn.GELU")
+        return _blk.mlp(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, act, _prec(self))
 
 
 class Attention(nn.Module):
@@ -36,6 +54,15 @@ class Attention(nn.Module):
         self.proj = nn.Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
 
+    def forward(self, x):
+        """point_encoder.py:46-58 (x [B, N, C]; heads of 64)."""
+        if not x.is_cuda:
+            raise RuntimeError("ppt_amd modules run on the HIP device only (no CPU fallback)")
+        if self.attn_drop.p or self.proj_drop.p:
+            raise NotImplementedError("Attention with dropout: every PPT configuration builds it with p = 0")
+        return _blk.self_attention(x, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias, self.num_heads,
+                                   float(self.scale), False, _prec(self))
+
 
 class DropPath(nn.Module):
     """timm 0.4.12 DropPath semantics: per-sample factor floor(keep + U[0,1)) / keep in train()."""
@@ -43,6 +70,9 @@ class DropPath(nn.Module):
     def __init__(self, drop_prob=None):
         super().__init__()
         self.drop_prob = drop_prob
+
+    def forward(self, x):
+        return _blk.drop_path(x, self.drop_prob, self.training)
 
 
 class Block(nn.Module):
@@ -59,6 +89,15 @@ class Block(nn.Module):
         self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop,
                               proj_drop=drop)
 
+    def _norm(self, ln, x):
+        return _blk.layer_norm(x, ln.weight, ln.bias, ln.eps) if isinstance(ln, nn.LayerNorm) else ln(x)
+
+    def forward(self, x):
+        """point_encoder.py:76-79."""
+        x = x + self.drop_path(self.attn(self._norm(self.norm1, x)))
+        x = x + self.drop_path(self.mlp(self._norm(self.norm2, x)))
+        return x
+
 
 class TransformerEncoder(nn.Module):
     """point_encoder.py:82-110."""
@@ -71,6 +110,16 @@ class TransformerEncoder(nn.Module):
                   drop=drop_rate, attn_drop=attn_drop_rate,
                   drop_path=drop_path_rate[i] if isinstance(drop_path_rate, list) else drop_path_rate)
             for i in range(depth)])
+
+    def forward(self, x, pos, task='cls'):
+        """point_encoder.py:99-110: `block(x + pos)` for every block; task='partseg' returns the outputs of
+        blocks 3, 7 and 11."""
+        feature_list = []
+        for i, block in enumerate(self.blocks):
+            x = block(x + pos)
+            if task == 'partseg' and i in (3, 7, 11):
+                feature_list.append(x)
+        return feature_list if task == 'partseg' else x
 
 
 TIER_PARAMS = {   # ULIP_models.py:461-470, cumulative

@@ -106,6 +106,25 @@ def gen_index():
                     ob = O.ball_query(pc, center.numpy(), r, K)
                     assert np.array_equal(rb, ob), f"ball query mismatch {tag} r={r}"
                     out[f"ball_{tag}_r{r}_K{K}"] = rb.astype(np.int16)
+        # dataset-side FPS (data/dataset_3d.py:40-61): numpy loop, random start injected; cloud with duplicates and 6 columns
+        from data import dataset_3d as D3
+        for tag, N, M, dup, cols in (("d", 8192, 1024, False, 3), ("e", 2048, 512, True, 6)):
+            pc, start = W.synth_clouds(1, N, seed=4321, duplicates=dup)
+            pts = pc[0].astype(np.float32)
+            if cols == 6:
+                pts = np.concatenate([pts, pts[:, ::-1] * 0.5], axis=1)
+            orig_ri = np.random.randint
+            np.random.randint = lambda *a, **k: int(start[0])
+            try:
+                ref = D3.farthest_point_sample(pts.copy(), M)
+            finally:
+                np.random.randint = orig_ri
+            rows, idx = O.dataset_farthest_point_sample(pts, M, int(start[0]))
+            assert np.array_equal(ref, rows), f"dataset FPS oracle mismatch case {tag}"
+            # ... and the same walk as the tokenizer's FPS restatement (C oracle) on the fp32 coordinates
+            assert np.array_equal(idx, O.fps(pts[None, :, :3], M, start[:1])[0]), tag
+            out[f"dsfps_{tag}_idx"] = idx.astype(np.int16)
+            out[f"dsfps_{tag}_start"] = np.int64(start[0])
     np.savez_compressed(os.path.join(HERE, "g_index.npz"), **out)
     print("g_index.npz:", {k: v.shape for k, v in out.items()})
 
@@ -265,6 +284,82 @@ def gen_encoder_and_step(tok, head_types=(0, 1, 2, 3)):
             assert (te - to).abs().max().item() < 1e-4
             np.savez_compressed(os.path.join(HERE, "g_eval.npz"), pc_feat=pe_feat.numpy(),
                                 text_feat=te.numpy(), logits=lg.numpy(), prompts_sub=prompts[:, ::4, ::8].numpy())
+
+
+def block_inputs():
+    """Seeded inputs of the G5 / G6 fixtures (regenerated by the tests, not stored)."""
+    g = torch.Generator().manual_seed(2024)
+    x = torch.randn(2, 513, 384, generator=g) * 0.5
+    pos = torch.randn(2, 513, 384, generator=g) * 0.1
+    cot = torch.randn(2, 513, 384, generator=g)
+    tcot = torch.randn(40, 512, generator=g)
+    xt = torch.randn(37, 3, 512, generator=g) * 0.3            # [L, N, D] for one ResidualAttentionBlock call
+    xtcot = torch.randn(37, 3, 512, generator=g)
+    return x, pos, cot, tcot, xt, xtcot
+
+
+def _sub(t, n=4099):
+    """a strided sample (prime stride) + norm of a big tensor"""
+    f = t.detach().flatten()
+    step = max(1, f.numel() // n) | 1
+    return f[::step].numpy(), np.float64(f.double().norm().item())
+
+
+def gen_blocks(tok):
+    """G5: one PointBERT Block forward / backward on [2,513,384] (point_encoder.py:76-79) plus its Mlp and Attention alone and
+    the 12-block TransformerEncoder(x, pos) (:99-110);  G6: the text tower on the ModelNet40 prompts -> [40,512] with the gradient
+    w.r.t. learnable_tokens (ULIP_models.py:203-222), and one ResidualAttentionBlock on [37,3,512] (:49-56)."""
+    names = tok["datasets"]["modelnet40"]
+    sd = W.ulip_pointbert_state_dict(seed=0)
+    emb = W.synth_prompt_embedding(len(names), seed=0)
+    m = R.build_reference_ulip_pointbert(names, head_type=3)
+    load_into_reference(m, sd, emb)
+    m.eval()                                         # DropPath off, no Dropout anywhere on these paths
+    for p in m.parameters():
+        p.requires_grad_(True)
+    x, pos, cot, tcot, xt, xtcot = block_inputs()
+    fx = {}
+    blk = m.point_encoder.blocks.blocks[11]
+    for name, fn in (("block", lambda t: blk(t)), ("mlp", lambda t: blk.mlp(t)), ("attn", lambda t: blk.attn(t)),
+                     ("encoder", lambda t: m.point_encoder.blocks(t, pos))):
+        m.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        y = fn(xi)
+        (y * cot).sum().backward()
+        fx[f"{name}_y"], fx[f"{name}_ynorm"] = _sub(y)
+        fx[f"{name}_dx"], fx[f"{name}_dxnorm"] = _sub(xi.grad)
+        if name != "encoder":
+            for k, p_ in blk.named_parameters():
+                if p_.grad is not None and p_.grad.abs().sum() > 0:
+                    fx[f"{name}_g_{k}"], fx[f"{name}_gn_{k}"] = _sub(p_.grad)
+    part = m.point_encoder.blocks(x, pos, task='partseg')
+    assert len(part) == 3
+    fx["encoder_partseg_y3"], _ = _sub(part[0])
+    # ---- G6
+    m.zero_grad()
+    prompts = m.prompt_learner()
+    te = m.encode_text(prompts, m.tokenized_prompts)
+    (te * tcot).sum().backward()
+    fx["text_feat"] = te.detach().numpy()
+    fx["text_gtok"] = m.prompt_learner.learnable_tokens.grad.numpy().copy()
+    eot = m.tokenized_prompts.argmax(-1).numpy()
+    with torch.no_grad():
+        to = O.text_tower(sd, O.splice_prompts(emb, sd["prompt_learner.learnable_tokens"], m.prompt_learner.name_lengths), eot)
+    e = (te.detach() - to).abs().max().item()
+    print("G6 text tower: max|ref-oracle|", e)
+    assert e < 1e-4
+    rb = m.transformer.resblocks[0]
+    m.zero_grad()
+    xi = xt.clone().requires_grad_(True)
+    rb.attn_mask = m.build_attention_mask()[:37, :37]
+    y = rb(xi)
+    (y * xtcot).sum().backward()
+    fx["resblock_y"], fx["resblock_ynorm"] = _sub(y)
+    fx["resblock_dx"], fx["resblock_dxnorm"] = _sub(xi.grad)
+    for k, p_ in rb.named_parameters():
+        fx[f"resblock_g_{k}"], fx[f"resblock_gn_{k}"] = _sub(p_.grad)
+    np.savez_compressed(os.path.join(HERE, "g_blocks.npz"), **fx)
+    print("g_blocks.npz:", len(fx), "arrays,", sum(v.nbytes for v in fx.values()) // 1024, "KiB")
 
 
 def gen_pointnet2_msg():
@@ -507,6 +602,10 @@ if __name__ == "__main__":
         gen_pointnet2_ssg()
     elif sys.argv[1:] == ["pointmlp"]:
         gen_pointmlp()
+    elif sys.argv[1:] == ["index"]:
+        gen_index()
+    elif sys.argv[1:] == ["blocks"]:
+        gen_blocks(gen_tokens())
     elif sys.argv[1:2] == ["steps"]:            # the train-step fixtures of the given head_types only
         gen_encoder_and_step(gen_tokens(), tuple(int(h) for h in sys.argv[2:]))
     else:
@@ -517,4 +616,5 @@ if __name__ == "__main__":
         gen_pointnet2_ssg()
         gen_pointmlp()
         gen_partseg(tok)
+        gen_blocks(tok)
     print("done")

@@ -1149,3 +1149,34 @@ def test_vit_mlp_matches_the_unfused_chain(ops, M, rows, pos):
     x2 = xd.clone()
     ops.vit_mlp(x2, w1t, b1.cuda(), w2t, b2.cuda(), (gam.cuda(), bet.cuda()), residual2=r2.cuda() if pos else None, **kw)     # in place
     assert torch.equal(x2, out)
+
+
+@pytest.mark.parametrize("tag,N,M,dup,cols", [("d", 8192, 1024, False, 3), ("e", 2048, 512, True, 6)])
+def test_dataset_fps_is_bit_exact(tag, N, M, dup, cols):
+    """ppt_amd.data.farthest_point_sample(point, npoint) (data/dataset_3d.py:40-61 on the FPS kernel): the rows the reference
+    selected (golden) and the oracle's restated loop select, on the committed cases and on random clouds / starts / widths;
+    np.random.randint is drawn exactly once when no start is given; float64 input is rejected."""
+    from ppt_amd import data as PD
+    gidx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g_index.npz"))
+    pc, start = W.synth_clouds(1, N, seed=4321, duplicates=dup)
+    pts = pc[0].astype(np.float32)
+    if cols == 6:
+        pts = np.concatenate([pts, pts[:, ::-1] * 0.5], axis=1)
+    rows, idx = PD.farthest_point_sample(pts, M, start=int(start[0]), return_index=True)
+    assert np.array_equal(idx, gidx[f"dsfps_{tag}_idx"].astype(np.int64))
+    assert rows.dtype == np.float32 and np.array_equal(rows, pts[idx])
+    rng = np.random.default_rng(N)
+    for n, m in ((1500, 1024), (33, 7), (4096, 2048)):
+        cloud = rng.standard_normal((n, 3)).astype(np.float32)
+        cloud[n // 2:n // 2 + 5] = cloud[0]                        # duplicates
+        st = int(rng.integers(0, n))
+        want_rows, want_idx = O.dataset_farthest_point_sample(cloud, m, st)
+        got_rows, got_idx = PD.farthest_point_sample(cloud, m, start=st, return_index=True)
+        assert np.array_equal(got_idx, want_idx) and np.array_equal(got_rows, want_rows)
+    r = np.random.RandomState(11)
+    want_start, want_next = r.randint(0, N), r.randint(0, 1 << 30)
+    np.random.seed(11)
+    _, idx2 = PD.farthest_point_sample(pts, 16, return_index=True)
+    assert idx2[0] == want_start and np.random.randint(0, 1 << 30) == want_next      # ONE draw, where the reference draws (:51)
+    with pytest.raises(TypeError):
+        PD.farthest_point_sample(pts.astype(np.float64), 8)

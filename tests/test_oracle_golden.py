@@ -195,3 +195,69 @@ def test_partseg_oracle_forward_vs_golden():
         loss = O.cross_entropy_ls(lo.reshape(-1, 50), torch.from_numpy(g["labels"].astype(np.int64)).reshape(-1), 0.2)
     assert np.abs(lo[:, ::16].numpy() - g["logits_sub"]).max() < 2e-3
     assert abs(loss.item() - float(g["loss"])) < 1e-4
+
+
+def _block_inputs():
+    """the seeded inputs of tests/golden/make_golden.py: block_inputs"""
+    g = torch.Generator().manual_seed(2024)
+    x = torch.randn(2, 513, 384, generator=g) * 0.5
+    pos = torch.randn(2, 513, 384, generator=g) * 0.1
+    cot = torch.randn(2, 513, 384, generator=g)
+    tcot = torch.randn(40, 512, generator=g)
+    return x, pos, cot, tcot
+
+
+def _sub(t, n=4099):
+    f = t.detach().flatten()
+    step = max(1, f.numel() // n) | 1
+    return f[::step].numpy()
+
+
+def test_vit_block_oracle_vs_golden_g5():
+    """G5: O.vit_block forward / input gradient / weight gradients on [2,513,384] against the reference Block
+    (point_encoder.py:76-79) captured in g_blocks.npz."""
+    gb = np.load(os.path.join(G, "g_blocks.npz"))
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in W.ulip_pointbert_state_dict(seed=0).items()}
+    x, pos, cot, _ = _block_inputs()
+    xi = x.clone().requires_grad_(True)
+    p = "point_encoder.blocks.blocks.11."
+    y = O.vit_block(sd, p, xi, 6)
+    (y * cot).sum().backward()
+    assert np.abs(_sub(y) - gb["block_y"]).max() < 2e-5
+    assert np.abs(_sub(xi.grad) - gb["block_dx"]).max() < 2e-4
+    for k in ("mlp.fc2.weight", "attn.qkv.weight", "norm1.weight"):
+        g = _sub(sd[p + k].grad)
+        assert np.linalg.norm(g - gb["block_g_" + k]) / np.linalg.norm(gb["block_g_" + k]) < 1e-4, k
+
+
+def test_text_tower_oracle_vs_golden_g6():
+    """G6: O.text_tower on the spliced ModelNet40 prompts -> [40,512], and the gradient w.r.t. learnable_tokens, against the
+    reference's encode_text (ULIP_models.py:203-222)."""
+    gb = np.load(os.path.join(G, "g_blocks.npz"))
+    sd = W.ulip_pointbert_state_dict(seed=0)
+    tab = json.load(open(os.path.join(ROOT, "ppt_amd", "data", "classnames.json")))
+    names = tab["datasets"]["modelnet40"]
+    lens = [len(tab["name_tokens"][n.replace("_", " ")]) for n in names]
+    eot = np.array([1 + 32 + l + 1 for l in lens])
+    emb = W.synth_prompt_embedding(len(names), seed=0)
+    tok = sd["prompt_learner.learnable_tokens"].clone().requires_grad_(True)
+    _, _, _, tcot = _block_inputs()
+    te = O.text_tower(sd, O.splice_prompts(emb, tok, lens), eot)
+    (te * tcot).sum().backward()
+    assert np.abs(te.detach().numpy() - gb["text_feat"]).max() < 1e-4
+    rel = np.linalg.norm(tok.grad.numpy() - gb["text_gtok"]) / np.linalg.norm(gb["text_gtok"])
+    assert rel < 1e-4, rel
+
+
+@pytest.mark.parametrize("tag,N,M,dup,cols", [("d", 8192, 1024, False, 3), ("e", 2048, 512, True, 6)])
+def test_dataset_fps_oracle_vs_golden(gidx, tag, N, M, dup, cols):
+    """data/dataset_3d.py:40-61 (numpy farthest_point_sample of the datasets): the restated loop selects the indices the
+    reference function selected (captured with its np.random.randint start injected)."""
+    pc, start = W.synth_clouds(1, N, seed=4321, duplicates=dup)
+    pts = pc[0].astype(np.float32)
+    if cols == 6:
+        pts = np.concatenate([pts, pts[:, ::-1] * 0.5], axis=1)
+    assert int(gidx[f"dsfps_{tag}_start"]) == int(start[0])
+    rows, idx = O.dataset_farthest_point_sample(pts, M, int(start[0]))
+    assert np.array_equal(idx, gidx[f"dsfps_{tag}_idx"].astype(np.int64))
+    assert rows.shape == (M, cols) and np.array_equal(rows, pts[idx])
