@@ -25,37 +25,44 @@ class KernelProfiler:
     def __init__(self):
         self.records = []          # (name, start_event, end_event, algorithmic work)
         self.kernels = []          # the kernel behind each record (a finer name than the family in `name`)
+        self.executed = []         # FLOPs / bytes the launch really performs (differs from the model's where work is shared
+                                   # -- the broadcast half of conv3 evaluated once per group -- or recomputed)
 
-    def begin(self, name, work, kernel=None):
+    def begin(self, name, work, kernel=None, executed=None):
+        """work: the MODEL's algorithmic FLOPs (or bytes) of the layer(s) the launch stands for (SURVEY §8(d) / App. B);
+        executed: what the launch itself computes (default: the same)."""
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(torch.cuda.current_stream())
-        self._cur = (name, ev, work, kernel or name)
+        self._cur = (name, ev, work, kernel or name, work if executed is None else executed)
 
     def end(self):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(torch.cuda.current_stream())
-        name, st, work, kernel = self._cur
+        name, st, work, kernel, executed = self._cur
         self.records.append((name, st, ev, work))
         self.kernels.append(kernel)
+        self.executed.append(executed)
 
     def by_kernel(self):
-        """-> {kernel: dict(family, launches, ms, work)} (call after a device synchronise)."""
+        """-> {kernel: dict(family, launches, ms, work, executed)} (call after a device synchronise)."""
         out = {}
-        for (name, st, en, work), kernel in zip(self.records, self.kernels):
-            d = out.setdefault(kernel, dict(family=name, launches=0, ms=0.0, work=0.0))
+        for (name, st, en, work), kernel, ex in zip(self.records, self.kernels, self.executed):
+            d = out.setdefault(kernel, dict(family=name, launches=0, ms=0.0, work=0.0, executed=0.0))
             d["launches"] += 1
             d["ms"] += st.elapsed_time(en)
             d["work"] += work
+            d["executed"] += ex
         return out
 
     def summary(self):
-        """-> {name: dict(launches, ms, work)} (call after a device synchronise)."""
+        """-> {name: dict(launches, ms, work, executed)} (call after a device synchronise)."""
         out = {}
-        for name, st, en, work in self.records:
-            d = out.setdefault(name, dict(launches=0, ms=0.0, work=0.0))
+        for (name, st, en, work), ex in zip(self.records, self.executed):
+            d = out.setdefault(name, dict(launches=0, ms=0.0, work=0.0, executed=0.0))
             d["launches"] += 1
             d["ms"] += st.elapsed_time(en)
             d["work"] += work
+            d["executed"] += ex
         return out
 
 
@@ -227,7 +234,8 @@ def gemm(A, B, *, out=None, out_dtype=None, M=None, bias=None, act=ACT_NONE, dac
     if profiler is not None:
         kk = K if algo_k is None else algo_k
         profiler.begin("gemm_" + ("bf16" if p.dtype == PPT_BF16 else "f32"), 2.0 * M * N * kk * max(1, batch),
-                       "ppt_gemm " + ("bf16" if p.dtype == PPT_BF16 else "f32") + (" (A-prologue)" if a_mode != A_PLAIN else ""))
+                       "ppt_gemm " + ("bf16" if p.dtype == PPT_BF16 else "f32") + (" (A-prologue)" if a_mode != A_PLAIN else ""),
+                       executed=2.0 * M * N * K * max(1, batch))
     _lib.check(_lib.lib().ppt_gemm(ctypes.byref(p), _stream()), "ppt_gemm")
     if profiler is not None:
         profiler.end()
@@ -683,7 +691,9 @@ def mini_pointnet_conv3(A, w, gterm, col_stats=None):
     y = torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
     ps, pm = col_stats if col_stats is not None else (None, None)
     if profiler is not None:
-        profiler.begin("gemm_bf16", 2.0 * M * N * 2 * K, "ppt_mini_pointnet_conv3_bf16")
+        # model: the 512-wide Conv1d on cat(global, local) (dvae.py:194); executed: the local half (the global half is one row
+        # per group, a separate small GEMM booked with algo_k = 0 / its own executed FLOPs)
+        profiler.begin("gemm_bf16", 2.0 * M * N * 2 * K, "ppt_mini_pointnet_conv3_bf16", executed=2.0 * M * N * K)
     _lib.check(_lib.lib().ppt_mini_pointnet_conv3_bf16(_p(A), M, K, _p(w), _p(gterm), N, _p(y), _p(ps), _p(pm), _stream()),
                "ppt_mini_pointnet_conv3_bf16")
     if profiler is not None:
