@@ -255,40 +255,62 @@ class PromptLearner(nn.Module):
     def eot_positions(self):
         return self.tokenized_prompts.argmax(dim=-1)
 
-    def row_layout(self, positional, L, P):
-        """Constants of the text tower's input in its row layout (engine.text_tower_forward: P shared rows + C (L - P) own
-        rows, or C L rows when P == 0) for ops.prompt_rows / prompt_rows_bwd:
+    def row_layout(self, positional, L, P, group=0):
+        """Constants of the text tower's input in its row layout for ops.prompt_rows / prompt_rows_bwd:
         base [M, W] = frozen embedding + positional embedding per row, slot [M] i32 = index of the learnable token that
         overwrites the row (-1: none), pos_rows [M, W] = positional embedding per row, rows_of [n_tok, C] i32 = the rows each
-        learnable token appears in (ascending, -1 padded).  Cached per (embedding, positional embedding, L, P)."""
+        learnable token appears in (ascending, -1 padded), M, eot_rows [C] i64 = the row of every class's EOT token.
+        group == 0: engine.text_tower_forward's layout -- P shared rows + C (L - P) own rows, or C L rows when P == 0.
+        group == NP > 0: the fused tower's GROUPED layout (csrc/text_tower.hip) -- workgroup g owns prompts g NP .. g NP + NP - 1
+        and its own copy of the P shared rows: rows [g RW, g RW + P) = positions 0 .. P-1, then prompt g NP + n at rows
+        g RW + P + n (L - P) ...; RW = P + NP (L - P); rows of a short last group stay unused.
+        Cached per (embedding, positional embedding, L, P, group)."""
         emb = self.embedding
-        key = (emb.data_ptr(), emb._version, positional.data_ptr(), positional._version, L, P, self.class_name_position)
-        if getattr(self, "_layout_cache", (None,))[0] != key:
+        key = (emb.data_ptr(), emb._version, positional.data_ptr(), positional._version, L, P, self.class_name_position, group)
+        cache = self.__dict__.setdefault("_layout_caches", {})
+        if key not in cache:
             dev = self.learnable_tokens.device
             cls, pos, src = self._scatter_index(torch.device("cpu"))
             C, n = pos.shape
             tok_of = torch.full((C, CONTEXT_LENGTH), -1, dtype=torch.int32)
             tok_of[cls, pos] = torch.arange(n, dtype=torch.int32).view(1, n).expand(C, n)
-            rows = []                                    # (class, position) of every row
-            if P:
+            eot = self.tokenized_prompts.argmax(dim=-1).tolist()
+            rows, eot_rows = [], [0] * C                 # rows: (class, position) or None for an unused row
+            if group:
+                RW = P + group * (L - P)
+                for g0 in range(0, C, group):
+                    blk = [(g0, q) for q in range(P)]
+                    for c in range(g0, min(C, g0 + group)):
+                        eot_rows[c] = len(rows) + len(blk) + (eot[c] - P)
+                        blk += [(c, q) for q in range(P, L)]
+                    rows += blk + [None] * (RW - len(blk))
+            elif P:
                 rows += [(0, q) for q in range(P)]
-                rows += [(c, q) for c in range(C) for q in range(P, L)]
+                for c in range(C):
+                    eot_rows[c] = len(rows) + (eot[c] - P)
+                    rows += [(c, q) for q in range(P, L)]
             else:
-                rows += [(c, q) for c in range(C) for q in range(L)]
-            rc = torch.tensor([r[0] for r in rows]), torch.tensor([r[1] for r in rows])
-            slot = tok_of[rc[0], rc[1]].contiguous()
+                for c in range(C):
+                    eot_rows[c] = len(rows) + eot[c]
+                    rows += [(c, q) for q in range(L)]
+            used = torch.tensor([r is not None for r in rows])
+            rc = torch.tensor([r[0] if r is not None else 0 for r in rows]), torch.tensor([r[1] if r is not None else 0 for r in rows])
+            slot = torch.where(used, tok_of[rc[0], rc[1]], torch.full((len(rows),), -1, dtype=torch.int32)).contiguous()
             with torch.no_grad():
                 frozen = emb.detach().to("cpu").float()
-                base = frozen[rc[0], src[rc[0], rc[1]]] + positional.detach().to("cpu").float()[rc[1]]
-                pos_rows = positional.detach().to("cpu").float()[rc[1]].contiguous()
+                pos_rows = (positional.detach().to("cpu").float()[rc[1]] * used.view(-1, 1)).contiguous()
+                base = (frozen[rc[0], src[rc[0], rc[1]]] * used.view(-1, 1) + pos_rows).contiguous()
             rows_of = torch.full((n, C), -1, dtype=torch.int32)
             fill = [0] * n
             for i, t in enumerate(slot.tolist()):
                 if t >= 0:
                     rows_of[t, fill[t]] = i
                     fill[t] += 1
-            self._layout_cache = (key, (base.contiguous().to(dev), slot.to(dev), pos_rows.to(dev), rows_of.to(dev), len(rows)))
-        return self._layout_cache[1]
+            if len(cache) > 8:
+                cache.clear()
+            cache[key] = (base.to(dev), slot.to(dev), pos_rows.to(dev), rows_of.to(dev), len(rows),
+                          torch.tensor(eot_rows, dtype=torch.long).to(dev))
+        return cache[key]
 
     def shared_prefix(self):
         """Number of leading positions whose prompt rows are the same for EVERY class: the start token (one token id, hence
@@ -394,7 +416,10 @@ class _TextTowerTokensFn(torch.autograd.Function):
         pre = pl.shared_prefix() if model.share_text_prefix else 0
         if not (0 < pre < eff and C > 1):
             pre = 0
-        base, slot, pos_rows, rows_of, M = pl.row_layout(sd["positional_embedding"], eff, pre)
+        # bf16 mode: the whole tower as ONE persistent kernel per direction (csrc/text_tower.hip) on the grouped row layout
+        fused = tokens.is_cuda and model.fused_text_tower and engine.text_tower_fusable(sd, cache, heads, layers, C, eff, pre)
+        grp = engine.text_group_size(C, eff, pre) if fused else 0
+        base, slot, pos_rows, rows_of, M, eot_rows = pl.row_layout(sd["positional_embedding"], eff, pre, group=grp)
         tok = tokens.detach().float().contiguous()
 
         prio = model.chain_priority()
@@ -402,9 +427,11 @@ class _TextTowerTokensFn(torch.autograd.Function):
         def run(tk):
             with ops.wave_priority(prio):
                 x0 = ops.prompt_rows(base, slot, tk, pos_rows)
+                if fused:
+                    return engine.text_tower_forward_fused(sd, cache, x0, C, eff, pre, heads, layers, save, eot_rows)
                 return engine.text_tower_forward(sd, cache, None, eot, heads, layers, save, eff_len=eff, prefix=pre, rows_in=(x0, C, Lfull))
 
-        key = ("text_fwd_tok", tuple(tok.shape), save, eff, pre, cache.dtype, prio)
+        key = ("text_fwd_tok", tuple(tok.shape), save, eff, pre, cache.dtype, prio, grp)
         gc = model._graphs
         ctx.model, ctx.graph, ctx.rows_of, ctx.n_tok = model, None, rows_of, tok.shape[0]
         if tok.is_cuda and model.use_hip_graphs and ops.profiler is None and gc.ready(key):
@@ -437,6 +464,8 @@ class _TextTowerTokensFn(torch.autograd.Function):
 
         def run(d, saved):
             with ops.wave_priority(prio):
+                if saved.get("fused"):
+                    return ops.prompt_rows_bwd(engine.text_tower_backward_fused(sd, cache, saved, d), rows_of, n_tok)
                 return ops.prompt_rows_bwd(engine.text_tower_backward(sd, cache, saved, d), rows_of, n_tok)
 
         if ctx.graph is None:
@@ -568,6 +597,8 @@ class ULIP_WITH_IMAGE(nn.Module):
         self.fused_prompt_rows = os.environ.get("PPT_FUSED_PROMPT_ROWS", "1") != "0"     # PromptLearner splice + pos add: one kernel
         # positions in front of the class name are the same in every prompt: computed once (PPT_SHARE_TEXT_PREFIX=0: A/B runs)
         self.share_text_prefix = os.environ.get("PPT_SHARE_TEXT_PREFIX", "1") != "0"
+        # bf16 mode: the text tower forward / backward as one persistent kernel each (csrc/text_tower.hip; engine.TEXT_FUSED)
+        self.fused_text_tower = True
         self._chain_prio = None
         self._handoff = False               # inside forward_loss: graph outputs go straight into the next graph's input (no clone)
         self._handoff_grad = os.environ.get("PPT_HANDOFF", "1") != "0"
