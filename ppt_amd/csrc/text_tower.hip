@@ -41,8 +41,9 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 constexpr int WD = 512, HID = 2048, NH = 8, MT = 64;          // width, MLP hidden, heads (of 64), rows per workgroup tile
 constexpr int HP = 2 * WD + 32;                               // LDS row pitch of a [64 x 512] bf16 image (1056 = 32 mod 256)
 constexpr int IMG = MT * HP;                                  // 67 584 bytes
-constexpr int DEPTH = 16;                                     // weight ring: 1 KiB pieces in flight per wave
+constexpr int DEPTH = 8;                                      // weight ring: 1 KiB pieces in flight per wave
 constexpr int PIECES = 64;                                    // pieces per unit per wave (16 k-steps x 4 column tiles)
+static_assert(32 % DEPTH == 0, "a half unit (32 pieces) must keep the ring position");
 constexpr int VIMG = 64 * 128;                                // wave-private V image (64 keys x 64 dims bf16)
 constexpr float LOG2E = 1.4426950408889634f;
 
@@ -98,15 +99,19 @@ __device__ __forceinline__ bf16x8_t pack8(const f32x16_t &x, int s)
     return __builtin_bit_cast(bf16x8_t, u);
 }
 
-struct Acc { f32x4_t v[4][4]; };          // [row block of 16][column tile of 16]: D[n = 16 t + 4 kg + i][m = 16 rb + l15]
+template <int NT> struct AccT { f32x4_t v[4][NT]; };      // [row block of 16][column tile of 16]: D[n = 16 t + 4 kg + i][m = 16 rb + l15]
+typedef AccT<4> Acc;
 
-__device__ __forceinline__ void acc_zero(Acc &a)
+template <int NT> __device__ __forceinline__ void acc_zero(AccT<NT> &a)
 {
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) a.v[rb][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NT; ++t) a.v[rb][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 }
+// a per-phase copy of a lane constant that hipcc cannot see through: everything derived from it is computed where it is used
+// instead of being hoisted out of the layer loop and kept (or spilled) for the whole kernel
+#define OPAQUE(x) asm volatile("" : "+v"(x))
 
 // The wave's weight stream: piece i of the wave at byte offset (wave base + 1024 i) of the fragment-ordered buffer; a ring of
 // DEPTH pieces in registers, every consumed slot refilled with the piece DEPTH ahead.
@@ -122,9 +127,12 @@ __device__ __forceinline__ bf16x8_t ws_next(WStream &ws)
     return v;
 }
 
-// One unit: acc[64 rows x 64 columns of this wave] += A[64 x 512] (LDS image) . W_unit^T, the wave's 64 weight pieces coming
-// out of the ring in order.
-__device__ __forceinline__ void gemm_unit(Acc &acc, const unsigned char *img, bf16x8_t (&ring)[DEPTH], WStream &ws, const int l15,
+// One PASS of a unit over NT of the wave's four 16-column tiles: acc[64 rows x 16 NT columns] += A[64 x 512] (LDS image) . W^T,
+// the 16 NT weight pieces of the pass coming out of the ring in order ([k-step][tile]).  A unit is one pass with NT = 4 (64
+// pieces), or two passes with NT = 2 (tiles 0-1, then 2-3) where a second 64-register accumulator would not fit.  16 NT is a
+// multiple of DEPTH either way, so every pass starts at ring position 0.
+template <int NT, int NA>
+__device__ __forceinline__ void gemm_pass(AccT<NA> &acc, const unsigned char *img, bf16x8_t (&ring)[DEPTH], WStream &ws, const int l15,
                                           const int kg)
 {
     const unsigned char *a0 = img + l15 * HP + 16 * kg;
@@ -134,13 +142,19 @@ __device__ __forceinline__ void gemm_unit(Acc &acc, const unsigned char *img, bf
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) fa[rb] = *reinterpret_cast<const bf16x8_t *>(a0 + rb * 16 * HP + 64 * s);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const bf16x8_t b = ring[(4 * s + t) % DEPTH];
+        for (int t = 0; t < NT; ++t) {
+            const bf16x8_t b = ring[(NT * s + t) % DEPTH];
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb) acc.v[rb][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, fa[rb], acc.v[rb][t], 0, 0, 0);
-            ring[(4 * s + t) % DEPTH] = ws_next(ws);
+            for (int rb = 0; rb < 4; ++rb)
+                acc.v[rb][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, fa[rb], acc.v[rb][t], 0, 0, 0);
+            ring[(NT * s + t) % DEPTH] = ws_next(ws);
         }
     }
+}
+__device__ __forceinline__ void gemm_unit(Acc &acc, const unsigned char *img, bf16x8_t (&ring)[DEPTH], WStream &ws, const int l15,
+                                          const int kg)
+{
+    gemm_pass<4, 4>(acc, img, ring, ws, l15, kg);
 }
 
 // LayerNorm of the workgroup's rows (fp32, row pitch WD; buffer r at SGPR offset soff) -> bf16 image in LDS; wave w takes rows
@@ -206,11 +220,15 @@ __global__ __launch_bounds__(512, 2) void text_tower_fwd_kernel(const ppt_text_t
 {
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char *img1 = smem, *img2 = smem + IMG;           // img1: h -> V images -> u slab;  img2: attention out -> h2
+    // the layer's biases and LayerNorm parameters in LDS (refreshed per layer): an epilogue that fetched them from memory would
+    // wait for its own YOUNGEST load, i.e. vmcnt(0) -- the whole weight ring drained at every epilogue
+    float *prm = reinterpret_cast<float *>(smem + 2 * IMG);
+    float *pb_in = prm, *pb_out = prm + 3 * WD, *pb_fc = prm + 4 * WD, *pb_proj = prm + 4 * WD + HID;
+    float *pl1w = prm + 5 * WD + HID, *pl1b = pl1w + WD, *pl2w = pl1b + WD, *pl2b = pl2w + WD;
     PPT_PRIO(p.prio);
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, kg = lane >> 4;
-    const int r31 = lane & 31, hh = lane >> 5;
     const int P = p.P, own = p.L - p.P;
     const int RW = P + p.NP * own;
     const int ng = min(p.NP, p.C - (int)blockIdx.x * p.NP);
@@ -235,24 +253,17 @@ __global__ __launch_bounds__(512, 2) void text_tower_fwd_kernel(const ppt_text_t
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         unsigned m = 0;
-        const int qi = 32 * qt + r31;
+        const int qi = 32 * qt + (lane & 31);
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int kj = 32 * sub + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                const int kj = 32 * sub + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
                 if (visible(qi, kj, P, own)) m |= 1u << (16 * sub + e);
             }
         amask[qt] = m;
     }
-    const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
-    const int tr_key = 4 * (tg >> 1) + tq;
-    const int tr_dbyte = (16 * (tg & 1) + 4 * tp) * 2;
     const float c = p.scale * LOG2E;
-    // per-lane row validity of the four 16-row blocks of an accumulator (m = 16 rb + l15)
-    bool mval[4];
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb) mval[rb] = 16 * rb + l15 < nrow;
 
 #pragma unroll 1
     for (int l = 0; l < p.layers; ++l) {
@@ -264,9 +275,25 @@ __global__ __launch_bounds__(512, 2) void text_tower_fwd_kernel(const ppt_text_t
         const unsigned st_soff = (unsigned)(l * p.stats_stride * 4) + row0 * 4;
         const rsrc_t rXin = l == 0 ? rX0 : rX;
 
+        // ---- this layer's parameters -> LDS (the previous layer's last readers passed the barrier that ended it)
+        {
+            auto ldp = [&](const float *src, int n, float *dst) {
+                for (int i = threadIdx.x; i < n / 4; i += 512) reinterpret_cast<float4 *>(dst)[i] = reinterpret_cast<const float4 *>(src)[i];
+            };
+            ldp(p.b_in + (size_t)l * 3 * WD, 3 * WD, pb_in);
+            ldp(p.b_out + (size_t)l * WD, WD, pb_out);
+            ldp(p.b_fc + (size_t)l * HID, HID, pb_fc);
+            ldp(p.b_proj + (size_t)l * WD, WD, pb_proj);
+            ldp(p.ln1_w + (size_t)l * WD, WD, pl1w);
+            ldp(p.ln1_b + (size_t)l * WD, WD, pl1b);
+            ldp(p.ln2_w + (size_t)l * WD, WD, pl2w);
+            ldp(p.ln2_b + (size_t)l * WD, WD, pl2b);
+        }
+        lds_barrier();
+
         // ---- LN1 -> h (img1)
-        if (l == 0) ln_rows<0>(rXin, xin_soff, p.ln1_w, p.ln1_b, img1, p.stats != nullptr, rST, st_soff, p.rows * 4, nrow, w, lane);
-        else ln_rows<AUX_NT>(rXin, xin_soff, p.ln1_w + l * WD, p.ln1_b + l * WD, img1, p.stats != nullptr, rST, st_soff, p.rows * 4, nrow, w, lane);
+        if (l == 0) ln_rows<0>(rXin, xin_soff, pl1w, pl1b, img1, p.stats != nullptr, rST, st_soff, p.rows * 4, nrow, w, lane);
+        else ln_rows<AUX_NT>(rXin, xin_soff, pl1w, pl1b, img1, p.stats != nullptr, rST, st_soff, p.rows * 4, nrow, w, lane);
         lds_barrier();
 
         // ---- in_proj: three units (q, k, v); wave w computes head w's 64 columns of each
@@ -275,23 +302,33 @@ __global__ __launch_bounds__(512, 2) void text_tower_fwd_kernel(const ppt_text_t
             Acc acc;
             acc_zero(acc);
             gemm_unit(acc, img1, ring, ws, l15, kg);
-            const float *bias = p.b_in + (size_t)l * 3 * WD + u * WD + 64 * w;
-            const unsigned cb = (u * WD + 64 * w + 4 * kg) * 2;
+            int l15e = l15, kge = kg;
+            OPAQUE(l15e); OPAQUE(kge);
+            const float *bias = pb_in + u * WD + 64 * w;
+            const unsigned cb = (u * WD + 64 * w + 4 * kge) * 2;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const float4 bv = *reinterpret_cast<const float4 *>(bias + 16 * t + 4 * kg);
+                const float4 bv = *reinterpret_cast<const float4 *>(bias + 16 * t + 4 * kge);
 #pragma unroll
                 for (int rb = 0; rb < 4; ++rb) {
                     const f32x4_t a = acc.v[rb][t];
-                    const unsigned off = mval[rb] ? (unsigned)((16 * rb + l15) * (3 * WD * 2)) + cb + 32 * t : OOB;
+                    const unsigned off = 16 * rb + l15e < nrow ? (unsigned)((16 * rb + l15e) * (3 * WD * 2)) + cb + 32 * t : OOB;
                     bst8(rQKV, off, qkv_soff, make_uint2(pack_bf16x2(a[0] + bv.x, a[1] + bv.y), pack_bf16x2(a[2] + bv.z, a[3] + bv.w)));
                 }
             }
         }
         vm_barrier();                                          // qkv complete in memory; h (img1) dead
 
-        // ---- attention of head w over the workgroup's rows (scores never leave registers)
+        // ---- attention of head w over the workgroup's rows (scores never leave registers).  The weight ring is given up for
+        // the phase -- its DEPTH pieces are requested again behind it -- so that its registers are free here: the attention's
+        // fragments and the ring together spilled, and every scratch reload is a vmcnt(0)
+        ws.soff -= DEPTH * 1024;
         {
+            int r31 = lane & 31, hh = lane >> 5, lane_ = lane;
+            OPAQUE(r31); OPAQUE(hh); OPAQUE(lane_);
+            const int tg = lane_ >> 4, tq = (lane_ >> 2) & 3, tp = lane_ & 3;
+            const int tr_key = 4 * (tg >> 1) + tq;
+            const int tr_dbyte = (16 * (tg & 1) + 4 * tp) * 2;
             unsigned char *vimg = img1 + w * VIMG;
             bf16x8_t kf[2][4];
 #pragma unroll
@@ -304,7 +341,7 @@ __global__ __launch_bounds__(512, 2) void text_tower_fwd_kernel(const ppt_text_t
                 }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int cidx = lane + 64 * i, key = cidx >> 3, ch = cidx & 7;
+                const int cidx = lane_ + 64 * i, key = cidx >> 3, ch = cidx & 7;
                 const unsigned off = key < nrow ? (unsigned)(key * (3 * WD * 2) + (2 * WD + 64 * w + ch * 8) * 2) : OOB;
                 *reinterpret_cast<uint4 *>(vimg + v_off(key, ch * 16)) = bld16<AUX_NT>(rQKV, off, qkv_soff);
             }
@@ -389,6 +426,8 @@ __global__ __launch_bounds__(512, 2) void text_tower_fwd_kernel(const ppt_text_t
                 if (save) bst4(rLSE, (qok && hh == 0) ? (unsigned)(qrow * (NH * 4) + w * 4) : OOB, lse_soff, (mn + __log2f(lt)) * 0.6931471805599453f);
             }
         }
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) ring[i] = ws_next(ws);
         lds_barrier();                                         // attention output image complete; V images dead
 
         // ---- out_proj + residual -> x_mid
@@ -396,16 +435,18 @@ __global__ __launch_bounds__(512, 2) void text_tower_fwd_kernel(const ppt_text_t
             Acc acc;
             acc_zero(acc);
             gemm_unit(acc, img2, ring, ws, l15, kg);
-            const float *bias = p.b_out + (size_t)l * WD + 64 * w;
+            int l15e = l15, kge = kg;
+            OPAQUE(l15e); OPAQUE(kge);
+            const float *bias = pb_out + 64 * w;
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb) {
-                const unsigned ro = mval[rb] ? (unsigned)((16 * rb + l15) * (WD * 4) + (64 * w + 4 * kg) * 4) : OOB;
+                const unsigned ro = 16 * rb + l15e < nrow ? (unsigned)((16 * rb + l15e) * (WD * 4) + (64 * w + 4 * kge) * 4) : OOB;
                 float4 rv[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) rv[t] = l == 0 ? bldf4<0>(rXin, ro + 64 * t, xin_soff) : bldf4<AUX_NT>(rXin, ro + 64 * t, xin_soff);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const float4 bv = *reinterpret_cast<const float4 *>(bias + 16 * t + 4 * kg);
+                    const float4 bv = *reinterpret_cast<const float4 *>(bias + 16 * t + 4 * kge);
                     const f32x4_t a = acc.v[rb][t];
                     bstf4(rXM, ro + 64 * t, xm_soff, make_float4(a[0] + bv.x + rv[t].x, a[1] + bv.y + rv[t].y, a[2] + bv.z + rv[t].z, a[3] + bv.w + rv[t].w));
                 }
@@ -414,7 +455,7 @@ __global__ __launch_bounds__(512, 2) void text_tower_fwd_kernel(const ppt_text_t
         vm_barrier();                                          // x_mid complete in memory; attention image dead
 
         // ---- LN2 -> h2 (img2)
-        ln_rows<AUX_NT>(rXM, xm_soff, p.ln2_w + l * WD, p.ln2_b + l * WD, img2, p.stats != nullptr, rST, st_soff + 2 * p.rows * 4, p.rows * 4, nrow, w, lane);
+        ln_rows<AUX_NT>(rXM, xm_soff, pl2w, pl2b, img2, p.stats != nullptr, rST, st_soff + 2 * p.rows * 4, p.rows * 4, nrow, w, lane);
         lds_barrier();
 
         // ---- MLP: four hidden slabs of 512; c_fc + QuickGELU -> u (img1), c_proj accumulates over the slabs
@@ -423,26 +464,30 @@ __global__ __launch_bounds__(512, 2) void text_tower_fwd_kernel(const ppt_text_t
         const unsigned pre_soff = (unsigned)(l * p.pre_stride * 2) + row0 * (HID * 2);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            {
-                Acc acc;
-                acc_zero(acc);
-                gemm_unit(acc, img2, ring, ws, l15, kg);
-                const float *bias = p.b_fc + (size_t)l * HID + j * WD + 64 * w;
-                const unsigned cb = (j * WD + 64 * w + 4 * kg) * 2;
+            // c_fc of the slab in two passes of two column tiles (a second 64-register accumulator beside accp does not fit)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float4 bv = *reinterpret_cast<const float4 *>(bias + 16 * t + 4 * kg);
+            for (int ps = 0; ps < 2; ++ps) {
+                AccT<2> acc;
+                acc_zero(acc);
+                gemm_pass<2, 2>(acc, img2, ring, ws, l15, kg);
+                int l15e = l15, kge = kg;
+                OPAQUE(l15e); OPAQUE(kge);
+                const float *bias = pb_fc + j * WD + 64 * w + 32 * ps;
+                const unsigned cb = (j * WD + 64 * w + 32 * ps + 4 * kge) * 2;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const float4 bv = *reinterpret_cast<const float4 *>(bias + 16 * t + 4 * kge);
 #pragma unroll
                     for (int rb = 0; rb < 4; ++rb) {
-                        const int m = 16 * rb + l15;
+                        const int m = 16 * rb + l15e;
                         const f32x4_t a = acc.v[rb][t];
                         float v[4] = {a[0] + bv.x, a[1] + bv.y, a[2] + bv.z, a[3] + bv.w};
                         if (save)
-                            bst8(rPRE, mval[rb] ? (unsigned)(m * (HID * 2)) + cb + 32 * t : OOB, pre_soff,
+                            bst8(rPRE, m < nrow ? (unsigned)(m * (HID * 2)) + cb + 32 * t : OOB, pre_soff,
                                  make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])));
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = v[i] / (1.0f + __expf(-1.702f * v[i]));      // QuickGELU (ULIP_models.py:30-32)
-                        *reinterpret_cast<uint2 *>(img1 + m * HP + (64 * w + 16 * t + 4 * kg) * 2) =
+                        *reinterpret_cast<uint2 *>(img1 + m * HP + (64 * w + 32 * ps + 16 * t + 4 * kge) * 2) =
                             make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
                     }
                 }
@@ -452,16 +497,18 @@ __global__ __launch_bounds__(512, 2) void text_tower_fwd_kernel(const ppt_text_t
             lds_barrier();                                     // slab consumed
         }
         {
-            const float *bias = p.b_proj + (size_t)l * WD + 64 * w;
+            int l15e = l15, kge = kg;
+            OPAQUE(l15e); OPAQUE(kge);
+            const float *bias = pb_proj + 64 * w;
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb) {
-                const unsigned ro = mval[rb] ? (unsigned)((16 * rb + l15) * (WD * 4) + (64 * w + 4 * kg) * 4) : OOB;
+                const unsigned ro = 16 * rb + l15e < nrow ? (unsigned)((16 * rb + l15e) * (WD * 4) + (64 * w + 4 * kge) * 4) : OOB;
                 float4 rv[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) rv[t] = bldf4<AUX_NT>(rXM, ro + 64 * t, xm_soff);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const float4 bv = *reinterpret_cast<const float4 *>(bias + 16 * t + 4 * kg);
+                    const float4 bv = *reinterpret_cast<const float4 *>(bias + 16 * t + 4 * kge);
                     const f32x4_t a = accp.v[rb][t];
                     bstf4(rX, ro + 64 * t, xout_soff, make_float4(a[0] + bv.x + rv[t].x, a[1] + bv.y + rv[t].y, a[2] + bv.z + rv[t].z, a[3] + bv.w + rv[t].w));
                 }
@@ -574,13 +621,13 @@ __global__ __launch_bounds__(512, 2) void text_tower_bwd_kernel(const ppt_text_t
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l15 = lane & 15, kg = lane >> 4;
-    const int r31 = lane & 31, hh = lane >> 5;
     const int P = p.P, own = p.L - p.P;
     const int RW = P + p.NP * own;
     const int ng = min(p.NP, p.C - (int)blockIdx.x * p.NP);
     const int nrow = P + ng * own;
     const unsigned row0 = blockIdx.x * RW;
     float *l2s = reinterpret_cast<float *>(smem + AUXLDS) + w * 128, *dls = l2s + 64;      // wave-private lse * log2(e), delta
+    float *pg1 = reinterpret_cast<float *>(smem + AUXLDS) + 8 * 128, *pg2 = pg1 + WD;      // the layer's ln_1 / ln_2 weights
 
     const rsrc_t rX0 = mk_rsrc(p.x0), rX = mk_rsrc(p.x), rXM = mk_rsrc(p.xmid), rQKV = mk_rsrc(p.qkv);
     const rsrc_t rA = mk_rsrc(p.a), rLSE = mk_rsrc(p.lse), rPRE = mk_rsrc(p.pre), rST = mk_rsrc(p.stats);
@@ -606,7 +653,7 @@ __global__ __launch_bounds__(512, 2) void text_tower_bwd_kernel(const ppt_text_t
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-                if (visible(32 * qt + r31, 32 * sub + (e & 3) + 8 * (e >> 2) + 4 * hh, P, own)) m |= 1u << (16 * sub + e);
+                if (visible(32 * qt + (lane & 31), 32 * sub + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5), P, own)) m |= 1u << (16 * sub + e);
         amask[qt] = m;
     }
     unsigned long long bmask = 0;
@@ -615,15 +662,9 @@ __global__ __launch_bounds__(512, 2) void text_tower_bwd_kernel(const ppt_text_t
         const int qt = pr == 0 ? 0 : 1, kt = pr == 2 ? 1 : 0;
 #pragma unroll
         for (int e = 0; e < 16; ++e)
-            if (visible(32 * qt + (e & 3) + 8 * (e >> 2) + 4 * hh, 32 * kt + r31, P, own)) bmask |= 1ull << (16 * pr + e);
+            if (visible(32 * qt + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5), 32 * kt + (lane & 31), P, own)) bmask |= 1ull << (16 * pr + e);
     }
-    const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
-    const int tr_row = 4 * (tg >> 1) + tq;
-    const int tr_dbyte = (16 * (tg & 1) + 4 * tp) * 2;
     const float c = p.scale * LOG2E;
-    bool mval[4];
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb) mval[rb] = 16 * rb + l15 < nrow;
 
     // ---- the incoming gradient's bf16 image (img1): rows of g, zeros past nrow
     {
@@ -649,28 +690,37 @@ __global__ __launch_bounds__(512, 2) void text_tower_bwd_kernel(const ppt_text_t
         const unsigned pre_soff = (unsigned)(l * p.pre_stride * 2) + row0 * (HID * 2);
         const unsigned st_soff = (unsigned)(l * p.stats_stride * 4) + row0 * 4;
         const rsrc_t rXin = l == 0 ? rX0 : rX;
+        if (threadIdx.x < 256) {          // this layer's LayerNorm weights -> LDS (first read two barriers further down)
+            const float *src = threadIdx.x < 128 ? p.ln1_w + (size_t)l * WD : p.ln2_w + (size_t)l * WD;
+            reinterpret_cast<float4 *>(threadIdx.x < 128 ? pg1 : pg2)[threadIdx.x & 127] = reinterpret_cast<const float4 *>(src)[threadIdx.x & 127];
+        }
 
         // ---- MLP backward: d_pre = (g W_proj) * QuickGELU'(pre) per hidden slab -> img2; d_h2 += d_pre W_fc
         Acc acch;
         acc_zero(acch);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            {
-                Acc acc;
+            // (g W_proj) of the slab in two passes of two column tiles: a second 64-register accumulator beside acch does not fit
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                AccT<2> acc;
                 acc_zero(acc);
-                // the slab's saved pre-activations, requested before the unit (consumed in its epilogue)
-                uint2 pv[4][4];
+                int l15e = l15, kge = kg;
+                OPAQUE(l15e); OPAQUE(kge);
+                // the slab's saved pre-activations, requested BEFORE the pass (older than its ring refills: no drain when used)
+                uint2 pv[4][2];
 #pragma unroll
                 for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
+                    for (int t = 0; t < 2; ++t)
                         pv[rb][t] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(
-                            rPRE, (int)(mval[rb] ? (unsigned)((16 * rb + l15) * (HID * 2) + (j * WD + 64 * w + 16 * t + 4 * kg) * 2) : OOB), (int)pre_soff, 0));
-                gemm_unit(acc, img1, ring, ws, l15, kg);
+                            rPRE, (int)(16 * rb + l15e < nrow ? (unsigned)((16 * rb + l15e) * (HID * 2) + (j * WD + 64 * w + 32 * ps + 16 * t + 4 * kge) * 2) : OOB),
+                            (int)pre_soff, 0));
+                gemm_pass<2, 2>(acc, img1, ring, ws, l15, kg);
 #pragma unroll
                 for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
+                    for (int t = 0; t < 2; ++t) {
                         const f32x4_t a = acc.v[rb][t];
                         const float x[4] = {__uint_as_float(pv[rb][t].x << 16), __uint_as_float(pv[rb][t].x & 0xffff0000u),
                                             __uint_as_float(pv[rb][t].y << 16), __uint_as_float(pv[rb][t].y & 0xffff0000u)};
@@ -680,7 +730,7 @@ __global__ __launch_bounds__(512, 2) void text_tower_bwd_kernel(const ppt_text_t
                             const float sg = 1.0f / (1.0f + __expf(-1.702f * x[i]));
                             v[i] = a[i] * (sg * (1.0f + 1.702f * x[i] * (1.0f - sg)));
                         }
-                        *reinterpret_cast<uint2 *>(img2 + (16 * rb + l15) * HP + (64 * w + 16 * t + 4 * kg) * 2) =
+                        *reinterpret_cast<uint2 *>(img2 + (16 * rb + l15e) * HP + (64 * w + 32 * ps + 16 * t + 4 * kge) * 2) =
                             make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
                     }
             }
@@ -693,7 +743,7 @@ __global__ __launch_bounds__(512, 2) void text_tower_bwd_kernel(const ppt_text_t
             acc_to_lds(acch, smem, w, l15, kg);
             lds_barrier();
             uint4 nb[8];
-            ln_bwd_rows(smem, rXM, xm_soff, p.ln2_w + l * WD, rST, st_soff + 2 * p.rows * 4, p.rows * 4, rG, g_soff, nb, nrow, w, lane);
+            ln_bwd_rows(smem, rXM, xm_soff, pg2, rST, st_soff + 2 * p.rows * 4, p.rows * 4, rG, g_soff, nb, nrow, w, lane);
             lds_barrier();
 #pragma unroll
             for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4 *>(img1 + (w + 8 * i) * HP + 16 * lane) = nb[i];
@@ -706,24 +756,33 @@ __global__ __launch_bounds__(512, 2) void text_tower_bwd_kernel(const ppt_text_t
             Acc acc;
             acc_zero(acc);
             gemm_unit(acc, img1, ring, ws, l15, kg);
+            int l15e = l15, kge = kg;
+            OPAQUE(l15e); OPAQUE(kge);
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const f32x4_t a = acc.v[rb][t];
-                    *reinterpret_cast<uint2 *>(imD + v_off(16 * rb + l15, (16 * t + 4 * kg) * 2)) =
+                    *reinterpret_cast<uint2 *>(imD + v_off(16 * rb + l15e, (16 * t + 4 * kge) * 2)) =
                         make_uint2(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]));
                 }
         }
         lds_barrier();                                         // every wave is done with img1
 
-        // ---- attention backward of head w (wave-private): dV, dK per key tile, then dQ per query tile -> DQKV scratch
+        // ---- attention backward of head w (wave-private): dV, dK per key tile, then dQ per query tile -> DQKV scratch.
+        // (the weight ring is given up for the phase and requested again behind it: see the forward kernel)
+        ws.soff -= DEPTH * 1024;
         {
+            int r31 = lane & 31, hh = lane >> 5, lane_ = lane;
+            OPAQUE(r31); OPAQUE(hh); OPAQUE(lane_);
+            const int tg = lane_ >> 4, tq = (lane_ >> 2) & 3, tp = lane_ & 3;
+            const int tr_row = 4 * (tg >> 1) + tq;
+            const int tr_dbyte = (16 * (tg & 1) + 4 * tp) * 2;
             const unsigned qcol = (64 * w) * 2, kcol = (WD + 64 * w) * 2, vcol = (2 * WD + 64 * w) * 2;
             // Q rows -> imQ; lse2 / delta of the 64 queries
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int cidx = lane + 64 * i, row = cidx >> 3, ch = cidx & 7;
+                const int cidx = lane_ + 64 * i, row = cidx >> 3, ch = cidx & 7;
                 const unsigned off = row < nrow ? (unsigned)(row * (3 * WD * 2)) + qcol + ch * 16 : OOB;
                 *reinterpret_cast<uint4 *>(imQ + v_off(row, ch * 16)) = bld16<0>(rQKV, off, qkv_soff);
             }
@@ -815,7 +874,7 @@ __global__ __launch_bounds__(512, 2) void text_tower_bwd_kernel(const ppt_text_t
             wave_fence();
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int cidx = lane + 64 * i, row = cidx >> 3, ch = cidx & 7;
+                const int cidx = lane_ + 64 * i, row = cidx >> 3, ch = cidx & 7;
                 const unsigned off = row < nrow ? (unsigned)(row * (3 * WD * 2)) + kcol + ch * 16 : OOB;
                 *reinterpret_cast<uint4 *>(imQ + v_off(row, ch * 16)) = bld16<0>(rQKV, off, qkv_soff);
             }
@@ -869,6 +928,8 @@ __global__ __launch_bounds__(512, 2) void text_tower_bwd_kernel(const ppt_text_t
                              make_uint2(pack_bf16x2(dqt[dtile][4 * gq], dqt[dtile][4 * gq + 1]), pack_bf16x2(dqt[dtile][4 * gq + 2], dqt[dtile][4 * gq + 3])));
             }
         }
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) ring[i] = ws_next(ws);
         vm_barrier();                                          // d_qkv complete in memory; the private images are dead
 
         // ---- in_proj backward: d_h = dq W_q + dk W_k + dv W_v (three units); the parts are staged from DQKV into the images
@@ -898,7 +959,7 @@ __global__ __launch_bounds__(512, 2) void text_tower_bwd_kernel(const ppt_text_t
             acc_to_lds(accd, smem, w, l15, kg);
             lds_barrier();
             uint4 nb[8];
-            ln_bwd_rows(smem, rXin, xin_soff, p.ln1_w + l * WD, rST, st_soff, p.rows * 4, rG, g_soff, nb, nrow, w, lane);
+            ln_bwd_rows(smem, rXin, xin_soff, pg1, rST, st_soff, p.rows * 4, rG, g_soff, nb, nrow, w, lane);
             lds_barrier();
 #pragma unroll
             for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4 *>(img1 + (w + 8 * i) * HP + 16 * lane) = nb[i];
@@ -908,6 +969,8 @@ __global__ __launch_bounds__(512, 2) void text_tower_bwd_kernel(const ppt_text_t
 }
 
 }  // namespace
+
+constexpr int FWD_LDS = 2 * 67584 + (9 * 512 + 2048) * 4;      // two images + the layer's biases and LayerNorm parameters
 
 extern "C" int ppt_text_tower_fwd_bf16(const ppt_text_tower_params *pp, void *stream)
 {
@@ -922,11 +985,11 @@ extern "C" int ppt_text_tower_fwd_bf16(const ppt_text_tower_params *pp, void *st
         return PPT_EINVAL;
     p.prio = ppt_get_wave_priority();
     static const int once = [] {
-        return (int)hipFuncSetAttribute((const void *)text_tower_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * IMG);
+        return (int)hipFuncSetAttribute((const void *)text_tower_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS);
     }();
     (void)once;
     const int groups = (p.C + p.NP - 1) / p.NP;
-    hipLaunchKernelGGL(text_tower_fwd_kernel, dim3(groups), dim3(512), 2 * IMG, ppt_stream(stream), p);
+    hipLaunchKernelGGL(text_tower_fwd_kernel, dim3(groups), dim3(512), FWD_LDS, ppt_stream(stream), p);
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }
@@ -943,7 +1006,7 @@ extern "C" int ppt_text_tower_bwd_bf16(const ppt_text_tower_params *pp, void *st
          (uintptr_t)p.g | (uintptr_t)p.dqkv) & 15)
         return PPT_EINVAL;
     p.prio = ppt_get_wave_priority();
-    constexpr int LDS = 2 * IMG + 8 * 128 * 4;
+    constexpr int LDS = 2 * IMG + 8 * 128 * 4 + 2 * WD * 4;
     static const int once = [] {
         return (int)hipFuncSetAttribute((const void *)text_tower_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     }();
