@@ -247,7 +247,7 @@ typedef struct ppt_vit_mlp_params {
  * Backward: g [rows,512] f32 holds d loss / d x(last layer) on entry (zero except the pooled EOT rows) and d loss / d x0 on
  * exit -- for the shared rows each workgroup's PARTIAL (sum them: ppt_prompt_rows_bwd does, given every copy's row); dqkv
  * [rows,1536] bf16, da [rows,512] bf16, dscr [rows,512] f32: scratch.  Nothing is exchanged between workgroups.
- * prio is set by the library. */
+ * prio is set by the library; dbg: diagnostic, normally NULL. */
 typedef struct ppt_text_tower_params {
     const float *x0;
     const void *wfrag;
@@ -272,6 +272,8 @@ typedef struct ppt_text_tower_params {
     int C, L, P, NP, layers, rows;
     float scale;                                     /* softmax scale, 64^-0.5 */
     int prio;
+    unsigned long long *dbg;                         /* NULL, or >= 64 words: shader-clock stamps of workgroup 0 / wave 0 at the
+                                                        phase boundaries of layer 1 (tools/text_tower_stamps.py; diagnostic) */
 } ppt_text_tower_params;
 
 int ppt_text_tower_fwd_bf16(const ppt_text_tower_params *p, void *stream);

@@ -53,6 +53,7 @@ class TextTowerParams(ctypes.Structure):
         ("a_stride", ctypes.c_longlong), ("lse_stride", ctypes.c_longlong), ("pre_stride", ctypes.c_longlong),
         ("stats_stride", ctypes.c_longlong), ("g", c_void_p), ("dqkv", c_void_p), ("da", c_void_p), ("dscr", c_void_p),
         ("C", c_int), ("L", c_int), ("P", c_int), ("NP", c_int), ("layers", c_int), ("rows", c_int), ("scale", c_float), ("prio", c_int),
+        ("dbg", c_void_p),
     ]
 
 

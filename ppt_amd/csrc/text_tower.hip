@@ -112,6 +112,9 @@ template <int NT> __device__ __forceinline__ void acc_zero(AccT<NT> &a)
 // a per-phase copy of a lane constant that hipcc cannot see through: everything derived from it is computed where it is used
 // instead of being hoisted out of the layer loop and kept (or spilled) for the whole kernel
 #define OPAQUE(x) asm volatile("" : "+v"(x))
+// diagnostic stamps (p.dbg != NULL only): shader clock of workgroup 0 / wave 0 at the phase boundaries of layer LSTAMP
+#define STAMP(i) do { if (p.dbg && blockIdx.x == 0 && w == 0 && l == LSTAMP && lane == 0) p.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+constexpr int LSTAMP = 1;
 
 // The wave's weight stream: piece i of the wave at byte offset (wave base + 1024 i) of the fragment-ordered buffer; a ring of
 // DEPTH pieces in registers, every consumed slot refilled with the piece DEPTH ahead.
@@ -275,6 +278,7 @@ __global__ __launch_bounds__(512, 2) void text_tower_fwd_kernel(const ppt_text_t
         const unsigned st_soff = (unsigned)(l * p.stats_stride * 4) + row0 * 4;
         const rsrc_t rXin = l == 0 ? rX0 : rX;
 
+        STAMP(0);
         // ---- this layer's parameters -> LDS (the previous layer's last readers passed the barrier that ended it)
         {
             auto ldp = [&](const float *src, int n, float *dst) {
@@ -291,11 +295,13 @@ __global__ __launch_bounds__(512, 2) void text_tower_fwd_kernel(const ppt_text_t
         }
         lds_barrier();
 
+        STAMP(1);
         // ---- LN1 -> h (img1)
         if (l == 0) ln_rows<0>(rXin, xin_soff, pl1w, pl1b, img1, p.stats != nullptr, rST, st_soff, p.rows * 4, nrow, w, lane);
         else ln_rows<AUX_NT>(rXin, xin_soff, pl1w, pl1b, img1, p.stats != nullptr, rST, st_soff, p.rows * 4, nrow, w, lane);
         lds_barrier();
 
+        STAMP(2);
         // ---- in_proj: three units (q, k, v); wave w computes head w's 64 columns of each
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
@@ -317,7 +323,9 @@ __global__ __launch_bounds__(512, 2) void text_tower_fwd_kernel(const ppt_text_t
                 }
             }
         }
+        STAMP(3);
         vm_barrier();                                          // qkv complete in memory; h (img1) dead
+        STAMP(4);
 
         // ---- attention of head w over the workgroup's rows (scores never leave registers).  The weight ring is given up for
         // the phase -- its DEPTH pieces are requested again behind it -- so that its registers are free here: the attention's
@@ -428,7 +436,9 @@ __global__ __launch_bounds__(512, 2) void text_tower_fwd_kernel(const ppt_text_t
         }
 #pragma unroll
         for (int i = 0; i < DEPTH; ++i) ring[i] = ws_next(ws);
+        STAMP(5);
         lds_barrier();                                         // attention output image complete; V images dead
+        STAMP(6);
 
         // ---- out_proj + residual -> x_mid
         {
@@ -452,12 +462,15 @@ __global__ __launch_bounds__(512, 2) void text_tower_fwd_kernel(const ppt_text_t
                 }
             }
         }
+        STAMP(7);
         vm_barrier();                                          // x_mid complete in memory; attention image dead
+        STAMP(8);
 
         // ---- LN2 -> h2 (img2)
         ln_rows<AUX_NT>(rXM, xm_soff, pl2w, pl2b, img2, p.stats != nullptr, rST, st_soff + 2 * p.rows * 4, p.rows * 4, nrow, w, lane);
         lds_barrier();
 
+        STAMP(9);
         // ---- MLP: four hidden slabs of 512; c_fc + QuickGELU -> u (img1), c_proj accumulates over the slabs
         Acc accp;
         acc_zero(accp);
@@ -492,8 +505,11 @@ __global__ __launch_bounds__(512, 2) void text_tower_fwd_kernel(const ppt_text_t
                     }
                 }
             }
+            STAMP(10 + 3 * j);
             lds_barrier();                                     // slab complete
+            STAMP(11 + 3 * j);
             gemm_unit(accp, img1, ring, ws, l15, kg);
+            STAMP(12 + 3 * j);
             lds_barrier();                                     // slab consumed
         }
         {
@@ -514,7 +530,9 @@ __global__ __launch_bounds__(512, 2) void text_tower_fwd_kernel(const ppt_text_t
                 }
             }
         }
+        STAMP(22);
         vm_barrier();                                          // x_out complete in memory
+        STAMP(23);
     }
 }
 
@@ -695,6 +713,7 @@ __global__ __launch_bounds__(512, 2) void text_tower_bwd_kernel(const ppt_text_t
             reinterpret_cast<float4 *>(threadIdx.x < 128 ? pg1 : pg2)[threadIdx.x & 127] = reinterpret_cast<const float4 *>(src)[threadIdx.x & 127];
         }
 
+        STAMP(0);
         // ---- MLP backward: d_pre = (g W_proj) * QuickGELU'(pre) per hidden slab -> img2; d_h2 += d_pre W_fc
         Acc acch;
         acc_zero(acch);
@@ -738,6 +757,7 @@ __global__ __launch_bounds__(512, 2) void text_tower_bwd_kernel(const ppt_text_t
             gemm_unit(acch, img2, ring, ws, l15, kg);
             lds_barrier();
         }
+        STAMP(1);
         // ---- LayerNorm-2 backward: g <- g + LN2'(d_h2); the new g's bf16 image -> img1
         {
             acc_to_lds(acch, smem, w, l15, kg);
@@ -750,6 +770,7 @@ __global__ __launch_bounds__(512, 2) void text_tower_bwd_kernel(const ppt_text_t
         }
         lds_barrier();
 
+        STAMP(2);
         // ---- out_proj backward: d_a = g W_out; wave w's 64 columns are head w's dO -> its private dO image (img2 + 8 KiB w)
         unsigned char *imD = img2 + w * VIMG, *imQ = img1 + w * VIMG;
         {
@@ -767,7 +788,9 @@ __global__ __launch_bounds__(512, 2) void text_tower_bwd_kernel(const ppt_text_t
                         make_uint2(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]));
                 }
         }
+        STAMP(3);
         lds_barrier();                                         // every wave is done with img1
+        STAMP(4);
 
         // ---- attention backward of head w (wave-private): dV, dK per key tile, then dQ per query tile -> DQKV scratch.
         // (the weight ring is given up for the phase and requested again behind it: see the forward kernel)
@@ -930,7 +953,9 @@ __global__ __launch_bounds__(512, 2) void text_tower_bwd_kernel(const ppt_text_t
         }
 #pragma unroll
         for (int i = 0; i < DEPTH; ++i) ring[i] = ws_next(ws);
+        STAMP(5);
         vm_barrier();                                          // d_qkv complete in memory; the private images are dead
+        STAMP(6);
 
         // ---- in_proj backward: d_h = dq W_q + dk W_k + dv W_v (three units); the parts are staged from DQKV into the images
         Acc accd;
@@ -954,6 +979,7 @@ __global__ __launch_bounds__(512, 2) void text_tower_bwd_kernel(const ppt_text_t
         gemm_unit(accd, img1, ring, ws, l15, kg);
         lds_barrier();
 
+        STAMP(7);
         // ---- LayerNorm-1 backward: g <- g + LN1'(d_h); the bf16 image of the new g -> img1 for the next layer down
         {
             acc_to_lds(accd, smem, w, l15, kg);
@@ -965,6 +991,7 @@ __global__ __launch_bounds__(512, 2) void text_tower_bwd_kernel(const ppt_text_t
             for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4 *>(img1 + (w + 8 * i) * HP + 16 * lane) = nb[i];
         }
         lds_barrier();
+        STAMP(8);
     }
 }
 

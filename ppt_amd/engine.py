@@ -798,8 +798,14 @@ def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=No
 
 
 # ---- the text tower as ONE persistent kernel per direction (csrc/text_tower.hip; bf16 mode) -----------------------------------
-# PPT_TEXT_FUSED=0 keeps the per-layer launches (A/B runs; the fp32 parity mode always uses them).
-TEXT_FUSED = os.environ.get("PPT_TEXT_FUSED", "1") != "0"
+# OFF by default (PPT_TEXT_FUSED=1 / model.fused_text_tower = True turn it on): measured on C2 (round 3, same box, interleaved):
+# the per-layer launches 3.40 ms per step, the fused kernels 4.93 ms.  The kernel holds only 20 CUs and is hardly stretched by the
+# point tower (4.0 ms alone for forward + backward, 4.9 beside it, where the per-layer chain goes 1.54 -> ~3.4 ms), but a workgroup
+# that owns whole prompts must pull ALL of a layer's weights (6.3 MB) through ONE CU's L2 -> register path: 75-80 GB/s measured,
+# i.e. >= 75 us per layer and direction before any LayerNorm / attention / barrier time (in-kernel stamps, tools/
+# text_tower_stamps.py: 170 us per layer now) -- against 64 us for the per-layer launches, which spread every GEMM's weight
+# columns over ~100 CUs.  Kept as a tested alternative (tests/test_model_gpu.py); DESIGN.md §7 has the numbers.
+TEXT_FUSED = os.environ.get("PPT_TEXT_FUSED", "0") != "0"
 TEXT_TILE_ROWS = 64               # rows of a workgroup's tile (csrc/text_tower.hip: MT)
 
 
@@ -812,16 +818,23 @@ def text_group_size(C, L, P):
 
 def text_tower_fusable(sd, wc, heads, layers, C, L, P):
     w = sd["transformer.resblocks.0.attn.in_proj_weight"]
-    return (TEXT_FUSED and wc.dtype == torch.bfloat16 and w.is_cuda and tuple(w.shape) == (1536, 512) and heads == 8
+    return (wc.dtype == torch.bfloat16 and w.is_cuda and tuple(w.shape) == (1536, 512) and heads == 8
             and tuple(sd["transformer.resblocks.0.mlp.c_fc.weight"].shape) == (2048, 512) and text_group_size(C, L, P) >= 1)
 
 
-def _tile_units(blocks):
-    """[U, 512 (out), 512 (in)] bf16 -> [8 wave, U, 16 k-step, 4 column tile, 64 lane, 8]: piece[lane = 16 kg + i] =
-    W[64 wave + 16 tile + i][32 kstep + 8 kg .. + 8) (include/ppt_hip.h: ppt_text_tower_params.wfrag)."""
+def _tile_units(blocks, halves):
+    """[U, 512 (out), 512 (in)] bf16 -> [8 wave, U, 64 pieces, 64 lane, 8]: piece[lane = 16 kg + i] =
+    W[64 wave + 16 tile + i][32 kstep + 8 kg .. + 8) (include/ppt_hip.h: ppt_text_tower_params.wfrag).  Piece order inside a unit:
+    [k-step 16][tile 4]; for the units listed in `halves` (run as two passes of two column tiles): [pass 2][k-step 16][tile 2],
+    tile = 2 pass + t."""
     U = blocks.shape[0]
     x = blocks.reshape(U, 8, 4, 16, 16, 4, 8)                    # n -> (wave, tile, i); k -> (kstep, kg, e)
-    return x.permute(1, 0, 4, 2, 5, 3, 6).contiguous()           # (wave, U, kstep, tile, kg, i, e)
+    x = x.permute(1, 0, 4, 2, 5, 3, 6).contiguous()              # (wave, U, kstep, tile, kg, i, e)
+    if halves:
+        idx = torch.tensor(sorted(halves), device=x.device)
+        h = x[:, idx].reshape(8, len(halves), 16, 2, 2, 4, 16, 8)        # tile -> (pass, t)
+        x[:, idx] = h.permute(0, 1, 3, 2, 4, 5, 6, 7).reshape(8, len(halves), 16, 4, 4, 16, 8)   # (pass, kstep, t) flattened back
+    return x
 
 
 def text_tower_weights(sd, wc, layers):
@@ -849,12 +862,14 @@ def text_tower_weights(sd, wc, layers):
             bwd.append(torch.stack([t.contiguous() for t in b]))
         dev = fwd[0].device
 
-        def stream(per_layer):
-            t = _tile_units(torch.cat(per_layer, 0))             # [8, layers * 12, ...]
+        def stream(per_layer, half_units):
+            halves = [12 * i + u for i in range(len(per_layer)) for u in half_units]
+            t = _tile_units(torch.cat(per_layer, 0), halves)     # [8, layers * 12, ...]
             flat = t.reshape(-1)
             pad = torch.zeros(32 * 1024, dtype=flat.dtype, device=dev)     # (the ring requests DEPTH pieces past the end)
             return torch.cat([flat, pad])
-        out = dict(wfrag=stream(fwd), wfrag_bwd=stream(bwd[::-1]))
+        # two-pass units: forward c_fc slabs (units 4, 6, 8, 10); backward (g W_proj) slabs (units 0, 2, 4, 6)
+        out = dict(wfrag=stream(fwd, (4, 6, 8, 10)), wfrag_bwd=stream(bwd[::-1], (0, 2, 4, 6)))
         for k, nm in (("ln1_w", "ln_1.weight"), ("ln1_b", "ln_1.bias"), ("ln2_w", "ln_2.weight"), ("ln2_b", "ln_2.bias"),
                       ("b_in", "attn.in_proj_bias"), ("b_out", "attn.out_proj.bias"), ("b_fc", "mlp.c_fc.bias"), ("b_proj", "mlp.c_proj.bias")):
             out[k] = torch.stack([sd[p + nm].detach().float() for p in names]).contiguous()

@@ -597,8 +597,9 @@ class ULIP_WITH_IMAGE(nn.Module):
         self.fused_prompt_rows = os.environ.get("PPT_FUSED_PROMPT_ROWS", "1") != "0"     # PromptLearner splice + pos add: one kernel
         # positions in front of the class name are the same in every prompt: computed once (PPT_SHARE_TEXT_PREFIX=0: A/B runs)
         self.share_text_prefix = os.environ.get("PPT_SHARE_TEXT_PREFIX", "1") != "0"
-        # bf16 mode: the text tower forward / backward as one persistent kernel each (csrc/text_tower.hip; engine.TEXT_FUSED)
-        self.fused_text_tower = True
+        # bf16 mode: the text tower forward / backward as one persistent kernel each (csrc/text_tower.hip).  Off by default:
+        # slower than the per-layer launches on every configuration measured (engine.TEXT_FUSED has the numbers)
+        self.fused_text_tower = engine.TEXT_FUSED
         self._chain_prio = None
         self._handoff = False               # inside forward_loss: graph outputs go straight into the next graph's input (no clone)
         self._handoff_grad = os.environ.get("PPT_HANDOFF", "1") != "0"
