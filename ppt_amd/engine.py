@@ -69,6 +69,23 @@ class WeightCache:
         return out
 
 
+# Diagnostic (tools/bf16_error.py): operand precision of ONE stage of the point tower overridden -- {"tokenizer" | "blocks" (0 ..
+# depth-2) | "last_block": torch.float32 / torch.bfloat16} -- to attribute the bf16 mode's error to stages.  Eager execution only
+# (the hipGraph keys do not carry it); empty in production.
+STAGE_DTYPE = {}
+
+
+def _stage_wc(wc, stage):
+    """The WeightCache a stage runs with: `wc`, or a sibling of the overridden precision (kept on `wc`)."""
+    dt = STAGE_DTYPE.get(stage)
+    if dt is None or dt == wc.dtype:
+        return wc
+    alts = wc.__dict__.setdefault("_alts", {})
+    if dt not in alts:
+        alts[dt] = WeightCache(dt)
+    return alts[dt]
+
+
 FUSED_CONV12 = os.environ.get("PPT_FUSED_CONV12", "1") != "0"      # 0: the generic PPT_A_CONV1 GEMM (A/B comparisons)
 # csrc/rowgemm.hip (weight-stationary K = 384 linears with the LayerNorm applied while the rows are staged) from this many
 # token rows on.  Measured (same box, graph-replayed steps): C3 (32 832 rows) 7.60 -> 7.18 ms per step, the three linears
@@ -244,17 +261,18 @@ def point_encoder_forward(sd, p, wc, pc, fps_start, dp, bn_train, save_tier, cfg
         nbhd, center = grouped if grouped is not None else group_points(pc, G, cfg["group_size"], fps_start)
         B = center.shape[0]
         dev = center.device
-        tok = mini_pointnet(sd, p + "encoder.", wc, nbhd, bn_train, update_running)
+        wct = _stage_wc(wc, "tokenizer")
+        tok = mini_pointnet(sd, p + "encoder.", wct, nbhd, bn_train, update_running)
         x = torch.empty((B, Tn, D), dtype=torch.float32, device=dev)
         pos = torch.empty((B, Tn, D), dtype=torch.float32, device=dev)
         x[:, 0] = sd[p + "cls_token"].view(D)
         pos[:, 0] = sd[p + "cls_pos"].view(D)
         x2, pos2 = x.view(B * Tn, D), pos.view(B * Tn, D)
         # reduce_dim and pos_embed write straight into rows 1.. of every sample (batched GEMM)
-        ops.gemm(tok, wc.get(sd[p + "reduce_dim.weight"]), out=x2[1:], M=G, bias=sd[p + "reduce_dim.bias"], batch=B,
+        ops.gemm(tok, wct.get(sd[p + "reduce_dim.weight"]), out=x2[1:], M=G, bias=sd[p + "reduce_dim.bias"], batch=B,
                  strideA=G * tok.shape[1], strideC=Tn * D)
-        pe = ops.linear3_gelu(center.view(B * G, 3), sd[p + "pos_embed.0.weight"], sd[p + "pos_embed.0.bias"], T)
-        ops.gemm(pe, wc.get(sd[p + "pos_embed.2.weight"]), out=pos2[1:], M=G, bias=sd[p + "pos_embed.2.bias"], batch=B,
+        pe = ops.linear3_gelu(center.view(B * G, 3), sd[p + "pos_embed.0.weight"], sd[p + "pos_embed.0.bias"], wct.dtype)
+        ops.gemm(pe, wct.get(sd[p + "pos_embed.2.weight"]), out=pos2[1:], M=G, bias=sd[p + "pos_embed.2.bias"], batch=B,
                  strideA=G * pe.shape[1], strideC=Tn * D)
         first, pos_in_x = 0, False
     else:
@@ -269,12 +287,13 @@ def point_encoder_forward(sd, p, wc, pc, fps_start, dp, bn_train, save_tier, cfg
         d2 = dp[l, 1] if dp is not None else None
         # the next block's "+ pos" rides in this block's fc2 epilogue (unless the block output itself is wanted)
         add_pos_out = l + 1 < depth and not (fetch is not None and l in fetch)
+        wcl = _stage_wc(wc, "last_block" if l == depth - 1 else "blocks")
         if save_tier > 0 and l == depth - 1:
-            saved = {}
-            x2 = vit_block_forward(sd, bp, wc, x2, pos2, B, Tn, heads, d1, d2, save=saved, pos_in_x=pos_in_x,
+            saved = {"wc": wcl}
+            x2 = vit_block_forward(sd, bp, wcl, x2, pos2, B, Tn, heads, d1, d2, save=saved, pos_in_x=pos_in_x,
                                    add_pos_out=add_pos_out)
         else:
-            x2 = vit_block_forward(sd, bp, wc, x2, pos2, B, Tn, heads, d1, d2, pos_in_x=pos_in_x, add_pos_out=add_pos_out)
+            x2 = vit_block_forward(sd, bp, wcl, x2, pos2, B, Tn, heads, d1, d2, pos_in_x=pos_in_x, add_pos_out=add_pos_out)
         pos_in_x = add_pos_out
         if fetch is not None and l in fetch:        # part-seg: norm(x)[:, 1:] after blocks 3, 7, 11 (point_encoder.py:100-108,377)
             fn, _, _ = ops.layernorm_fwd(x2, sd[p + "norm.weight"], sd[p + "norm.bias"], torch.float32)
@@ -301,6 +320,7 @@ def _wgrad(dy_t, x_t):
 def point_encoder_backward(sd, wc, s, dfeat, tier):
     """Backward of the un-frozen part (ULIP_models.py:461-470): final LN -> block depth-1.
     Returns {param name: grad} for the tier's parameters."""
+    wc = s.get("wc", wc)                       # (the cache block depth-1 ran its forward with: STAGE_DTYPE diagnostics)
     T = wc.dtype
     B, Tn, D, heads, p = s["B"], s["Tn"], s["D"], s["heads"], s["prefix"]
     M = B * Tn
