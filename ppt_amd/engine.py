@@ -763,6 +763,12 @@ def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=No
     saved = {"layers": []} if save else None
     x = xin if add is None else torch.empty((M, Wd), dtype=torch.float32, device=dev)
     fuse = TEXT_FUSE_LN and T == torch.bfloat16 and Wd in ops.ROWGEMM_K
+    # (diagnostics, tools/bf16_error.py: the attention half and the MLP half of every layer may run at another operand precision;
+    # both start from and end in the fp32 residual stream)
+    wca, wcm = _stage_wc(wc, "text_attn"), _stage_wc(wc, "text_mlp")
+    Ta, Tm = wca.dtype, wcm.dtype
+    if Ta != T or Tm != T:
+        fuse = False
 
     def stats():
         return (torch.empty((M,), dtype=torch.float32, device=dev), torch.empty((M,), dtype=torch.float32, device=dev)) if save else None
@@ -776,29 +782,29 @@ def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=No
             qkv = ops.rowgemm(xin, wc.get(sd[p + "attn.in_proj_weight"]), ln=(sd[p + "ln_1.weight"], sd[p + "ln_1.bias"]), ln_stats=st1,
                               bias=sd[p + "attn.in_proj_bias"])
         else:
-            h, mean1, rstd1 = ops.layernorm_fwd(xin, sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], T, add=add,
+            h, mean1, rstd1 = ops.layernorm_fwd(xin, sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], Ta, add=add,
                                                 add_rows=add_rows, write_xs=x if add is not None else None,
                                                 save_stats=save)
-            qkv = ops.gemm(h, wc.get(sd[p + "attn.in_proj_weight"]), out_dtype=T, bias=sd[p + "attn.in_proj_bias"])
+            qkv = ops.gemm(h, wca.get(sd[p + "attn.in_proj_weight"]), out_dtype=Ta, bias=sd[p + "attn.in_proj_bias"])
         add, add_rows = None, 0
         if P:
             a, lse = ops.attention_prefix_fwd(qkv, C, L, P, heads, ATTN_SCALE, want_lse=save)
         else:
             a, lse = ops.attention_fwd(qkv, C, L, heads, ATTN_SCALE, True, want_lse=save)
         x_mid = torch.empty_like(x)
-        ops.gemm(a, wc.get(sd[p + "attn.out_proj.weight"]), out=x_mid, bias=sd[p + "attn.out_proj.bias"], residual=x)
-        pre = torch.empty((M, sd[p + "mlp.c_fc.weight"].shape[0]), dtype=T, device=dev) if save else None
+        ops.gemm(a, wca.get(sd[p + "attn.out_proj.weight"]), out=x_mid, bias=sd[p + "attn.out_proj.bias"], residual=x)
+        pre = torch.empty((M, sd[p + "mlp.c_fc.weight"].shape[0]), dtype=Tm, device=dev) if save else None
         if fuse:
             st2 = stats()
             mean2, rstd2 = st2 if save else (None, None)
             f = ops.rowgemm(x_mid, wc.get(sd[p + "mlp.c_fc.weight"]), ln=(sd[p + "ln_2.weight"], sd[p + "ln_2.bias"]), ln_stats=st2,
                             bias=sd[p + "mlp.c_fc.bias"], act=ACT_QUICKGELU, out2=pre)
         else:
-            h2, mean2, rstd2 = ops.layernorm_fwd(x_mid, sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], T, save_stats=save)
-            f = ops.gemm(h2, wc.get(sd[p + "mlp.c_fc.weight"]), out_dtype=T, bias=sd[p + "mlp.c_fc.bias"],
+            h2, mean2, rstd2 = ops.layernorm_fwd(x_mid, sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], Tm, save_stats=save)
+            f = ops.gemm(h2, wcm.get(sd[p + "mlp.c_fc.weight"]), out_dtype=Tm, bias=sd[p + "mlp.c_fc.bias"],
                          act=ACT_QUICKGELU, out2=pre, out2_pre=True)
         x_next = torch.empty_like(x)
-        ops.gemm(f, wc.get(sd[p + "mlp.c_proj.weight"]), out=x_next, bias=sd[p + "mlp.c_proj.bias"], residual=x_mid)
+        ops.gemm(f, wcm.get(sd[p + "mlp.c_proj.weight"]), out=x_next, bias=sd[p + "mlp.c_proj.bias"], residual=x_mid)
         if save:
             saved["layers"].append(dict(x=x, mean1=mean1, rstd1=rstd1, qkv=qkv, a=a, lse=lse, x_mid=x_mid, mean2=mean2,
                                         rstd2=rstd2, pre=pre))
@@ -813,7 +819,7 @@ def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=No
         out = ops.gemm(hn, wc32.get(sd["text_projection"], "wt"), out_dtype=torch.float32)
     if save:
         saved.update(x_eot=x_eot, meanf=meanf, rstdf=rstdf, rows=rows, C=C, L=L, Lfull=Lfull, W=Wd, heads=heads, P=P, M=M,
-                     rows_mode=rows_in is not None)
+                     rows_mode=rows_in is not None, wca=wca, wcm=wcm)
     return out, saved
 
 
@@ -999,23 +1005,25 @@ def text_tower_backward(sd, wc, s, dout):
     d_eot, _, _ = ops.layernorm_bwd(d_hn, s["x_eot"], sd["ln_final.weight"], s["meanf"], s["rstdf"])
     g = torch.zeros((M, Wd), dtype=torch.float32, device=dout.device)
     g.index_copy_(0, s["rows"], d_eot)
-    g_t = ops.convert(g, T)
+    wca, wcm = s.get("wca", wc), s.get("wcm", wc)              # (per-half operand precision: diagnostics, see the forward)
+    Ta, Tm = wca.dtype, wcm.dtype
+    g_t = ops.convert(g, Tm)
     for i in reversed(range(len(s["layers"]))):
         p = f"transformer.resblocks.{i}."
         ly = s["layers"][i]
-        d_pre = ops.gemm(g_t, wc.get(sd[p + "mlp.c_proj.weight"], "wt"), out_dtype=T, act=ACT_QUICKGELU,
+        d_pre = ops.gemm(g_t, wcm.get(sd[p + "mlp.c_proj.weight"], "wt"), out_dtype=Tm, act=ACT_QUICKGELU,
                          dact_pre=ly["pre"])
-        d_h2 = ops.gemm(d_pre, wc.get(sd[p + "mlp.c_fc.weight"], "wt"), out_dtype=torch.float32)
+        d_h2 = ops.gemm(d_pre, wcm.get(sd[p + "mlp.c_fc.weight"], "wt"), out_dtype=torch.float32)
         _, _, _, g_t = ops.layernorm_bwd(d_h2, ly["x_mid"], sd[p + "ln_2.weight"], ly["mean2"], ly["rstd2"], dx=g,
-                                         accumulate=True, copy_dtype=T)
-        d_a = ops.gemm(g_t, wc.get(sd[p + "attn.out_proj.weight"], "wt"), out_dtype=T)
+                                         accumulate=True, copy_dtype=Ta)
+        d_a = ops.gemm(g_t, wca.get(sd[p + "attn.out_proj.weight"], "wt"), out_dtype=Ta)
         if P:
             d_qkv = ops.attention_prefix_bwd(ly["qkv"], ly["a"], d_a, ly["lse"], C, L, P, heads, ATTN_SCALE)
         else:
             d_qkv = ops.attention_bwd(ly["qkv"], ly["a"], d_a, ly["lse"], C, L, heads, ATTN_SCALE, True)
-        d_h = ops.gemm(d_qkv, wc.get(sd[p + "attn.in_proj_weight"], "wt"), out_dtype=torch.float32)
+        d_h = ops.gemm(d_qkv, wca.get(sd[p + "attn.in_proj_weight"], "wt"), out_dtype=torch.float32)
         _, _, _, g_t = ops.layernorm_bwd(d_h, ly["x"], sd[p + "ln_1.weight"], ly["mean1"], ly["rstd1"], dx=g,
-                                         accumulate=True, copy_dtype=T)
+                                         accumulate=True, copy_dtype=Tm)
     if s["rows_mode"]:
         return g                                            # gradient of the row-layout input (ops.prompt_rows_bwd folds it)
     if not P and L == s["Lfull"]:

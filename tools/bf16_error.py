@@ -24,6 +24,7 @@ from ppt_amd.train import Trainer                     # noqa: E402
 
 G = os.path.join(ROOT, "tests", "golden")
 STAGES = ("tokenizer", "blocks", "last_block", "text")
+TEXT_PARTS = ("text_attn", "text_mlp")          # finer: one half of every text layer in fp32 (engine.STAGE_DTYPE)
 extra = [a for a in sys.argv[1:] if "=" in a]                      # e.g. PPT-style experiment switches: key=value -> engine attr
 
 
@@ -70,7 +71,7 @@ for h in heads:
     ref_logits = res["logits"]
     gkeys = ["prompt_learner.learnable_tokens"] + (["point_encoder.blocks.blocks.11.mlp.fc2.weight", "point_encoder.blocks.blocks.11.attn.qkv.weight"] if h >= 3 else [])
     rows = {}
-    configs = [("all bf16", ())] + [(f"{st} in fp32", (st,)) for st in STAGES] + [("all fp32", STAGES)]
+    configs = [("all bf16", ())] + [(f"{st} in fp32", (st,)) for st in STAGES + TEXT_PARTS] + [("all fp32", STAGES)]
     for name, f32 in configs:
         loss, lg, grads = run(h, g, f32)
         e = (lg - ref_logits)
