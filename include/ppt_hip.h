@@ -33,6 +33,9 @@ extern "C" {
 
 #define PPT_F32 0
 #define PPT_BF16 1
+#define PPT_F16 2   /* IEEE half operands / fp32 accumulate: the MFMA rate of bf16 with 11 significand bits instead of 8 -- the
+                     * operand format of the transformer-side GEMMs / attention (activations bounded by LayerNorm, residual stream
+                     * in fp32, gradients scaled); bf16 stays the format of the tokenizer's un-normalised activations */
 
 const char *ppt_strerror(int code);
 /* ABI version of this header (currently 2); bumped on any signature change or added entry point. */

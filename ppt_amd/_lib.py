@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PPT_HIP_LIB") or os.path.join(_HERE, "csrc", "libppt_hip.so")      # (PPT_HIP_LIB: a variant build, A/B runs)
 _lib = None
 
-PPT_F32, PPT_BF16 = 0, 1
+PPT_F32, PPT_BF16, PPT_F16 = 0, 1, 2
 A_PLAIN, A_AFFINE_RELU, A_CONV1 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_QUICKGELU = 0, 1, 2, 3
 

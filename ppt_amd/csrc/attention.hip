@@ -13,11 +13,12 @@
 #include "ppt_common.h"
 #include "attn_rowmap.h"
 
+// (fmt: PPT_BF16 or PPT_F16, the 16-bit operand format)
 extern "C" int ppt_attention_fwd_mfma_bf16(const void *qkv, void *out, float *lse, int Bt, int T, int H,
-                                           float scale, int causal, int P, hipStream_t s);
+                                           float scale, int causal, int P, int fmt, hipStream_t s);
 extern "C" int ppt_attention_bwd_mfma_bf16(const void *qkv, const void *dout, const float *lse, const float *delta,
                                            void *dqkv, int Bt, int T, int H, float scale, int causal, int P, float *part,
-                                           hipStream_t s);
+                                           int fmt, hipStream_t s);
 
 namespace {
 
@@ -333,7 +334,7 @@ static int attn_fwd_any(const void *qkv, void *out, float *lse, int Bt, int T, i
 {
     if (!qkv || !out || Bt <= 0 || T <= 0 || H <= 0 || hd != HD) return PPT_EINVAL;
     if (dtype == PPT_F32) return attn_fwd_t<float>(qkv, out, lse, Bt, T, H, scale, causal, P, ppt_stream(stream));
-    if (dtype == PPT_BF16) return ppt_attention_fwd_mfma_bf16(qkv, out, lse, Bt, T, H, scale, causal, P, ppt_stream(stream));
+    if (dtype == PPT_BF16 || dtype == PPT_F16) return ppt_attention_fwd_mfma_bf16(qkv, out, lse, Bt, T, H, scale, causal, P, dtype, ppt_stream(stream));
     return PPT_EINVAL;
 }
 
@@ -345,11 +346,11 @@ extern "C" int ppt_attention_fwd(const void *qkv, void *out, float *lse, int Bt,
 
 // used by attention_mfma.hip until every shape has an MFMA kernel
 extern "C" int ppt_attention_bwd_short_mfma_bf16(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv, int Bt, int T,
-                                                 int H, float scale, int causal, int P, float *part, hipStream_t s);
+                                                 int H, float scale, int causal, int P, float *part, int fmt, hipStream_t s);
 extern "C" int ppt_attention_fwd_quad_bf16(const void *qkv, void *out, float *lse, int Bt, int T, int H, float scale,
-                                           int causal, int P, hipStream_t s)
+                                           int causal, int P, int fmt, hipStream_t s)
 {
-    return attn_fwd_t<bf16_t>(qkv, out, lse, Bt, T, H, scale, causal, P, s);
+    return fmt == PPT_F16 ? attn_fwd_t<f16_t>(qkv, out, lse, Bt, T, H, scale, causal, P, s) : attn_fwd_t<bf16_t>(qkv, out, lse, Bt, T, H, scale, causal, P, s);
 }
 
 static int attn_bwd_any(const void *qkv, const void *out, const void *dout, const float *lse, float *delta, void *dqkv, float *part,
@@ -359,21 +360,28 @@ static int attn_bwd_any(const void *qkv, const void *out, const void *dout, cons
     if (P > 0 && !part) return PPT_EINVAL;
     if (dtype == PPT_F32)
         return attn_bwd_t<float>(qkv, out, dout, lse, delta, dqkv, Bt, T, H, scale, causal, P, part, true, ppt_stream(stream));
-    if (dtype == PPT_BF16) {
+    if (dtype == PPT_BF16 || dtype == PPT_F16) {
         hipStream_t s = ppt_stream(stream);
+        const bool f16 = dtype == PPT_F16;
+        auto reduce = [&]() { return f16 ? attn_reduce_t<f16_t>(part, dqkv, Bt, P, H, s) : attn_reduce_t<bf16_t>(part, dqkv, Bt, P, H, s); };
         if (T <= 128) {                                    // short sequences (the text tower): delta + dK/dV + dQ in ONE launch
-            const int rc = ppt_attention_bwd_short_mfma_bf16(qkv, out, dout, lse, dqkv, Bt, T, H, scale, causal, P, part, s);
-            if (rc == PPT_OK) return attn_reduce_t<bf16_t>(part, dqkv, Bt, P, H, s);
+            const int rc = ppt_attention_bwd_short_mfma_bf16(qkv, out, dout, lse, dqkv, Bt, T, H, scale, causal, P, part, dtype, s);
+            if (rc == PPT_OK) return reduce();
             if (rc != PPT_EUNSUPPORTED) return rc;
         }
         const int64_t rows = attn_rows(Bt, T, P) * H;
-        hipLaunchKernelGGL(attn_delta<bf16_t>, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, s, (const bf16_t *)out,
-                           (const bf16_t *)dout, delta, T, H, rows, P);
+        if (f16)
+            hipLaunchKernelGGL(attn_delta<f16_t>, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, s, (const f16_t *)out,
+                               (const f16_t *)dout, delta, T, H, rows, P);
+        else
+            hipLaunchKernelGGL(attn_delta<bf16_t>, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, s, (const bf16_t *)out,
+                               (const bf16_t *)dout, delta, T, H, rows, P);
         PPT_CHECK_LAUNCH();
-        const int rc = ppt_attention_bwd_mfma_bf16(qkv, dout, lse, delta, dqkv, Bt, T, H, scale, causal, P, part, s);
-        if (rc == PPT_OK) return attn_reduce_t<bf16_t>(part, dqkv, Bt, P, H, s);
+        const int rc = ppt_attention_bwd_mfma_bf16(qkv, dout, lse, delta, dqkv, Bt, T, H, scale, causal, P, part, dtype, s);
+        if (rc == PPT_OK) return reduce();
         if (rc != PPT_EUNSUPPORTED) return rc;
-        return attn_bwd_t<bf16_t>(qkv, out, dout, lse, delta, dqkv, Bt, T, H, scale, causal, P, part, false, s);
+        return f16 ? attn_bwd_t<f16_t>(qkv, out, dout, lse, delta, dqkv, Bt, T, H, scale, causal, P, part, false, s)
+                   : attn_bwd_t<bf16_t>(qkv, out, dout, lse, delta, dqkv, Bt, T, H, scale, causal, P, part, false, s);
     }
     return PPT_EINVAL;
 }

@@ -18,11 +18,10 @@
 #include "attn_rowmap.h"
 
 extern "C" int ppt_attention_fwd_quad_bf16(const void *qkv, void *out, float *lse, int Bt, int T, int H, float scale,
-                                           int causal, int P, hipStream_t s);
+                                           int causal, int P, int fmt, hipStream_t s);
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
@@ -35,7 +34,7 @@ __device__ __forceinline__ int v_off(int key, int dbyte) { return key * 128 + (d
 __device__ __forceinline__ float lane_xor32_max(float v) { return xor32_max(v); }
 __device__ __forceinline__ float lane_xor32_sum(float v) { return xor32_sum(v); }
 
-template <bool CAUSAL>
+template <bool CAUSAL, typename F>
 __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out,
                                                      float *__restrict__ lse, int Tfull, int H, float c /* scale*log2(e) */,
                                                      int P, int C, int prio)
@@ -53,12 +52,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(const bf16_t *__restrict
     const int q0 = blockIdx.x * QB + w * 32;
     const int qrow = q0 + r;
 
-    bf16x8_t qf[4];
+    uint4 qf[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
         uint4 v = make_uint4(0, 0, 0, 0);
         if (qrow < T) v = *reinterpret_cast<const uint4 *>(qb + am_row(Tfull, P, b, qrow) * rs + 16 * kk + 8 * h);
-        qf[kk] = __builtin_bit_cast(bf16x8_t, v);
+        qf[kk] = (v);
     }
 
     // T = 64 n + 1 (the ViT's class token: 513): the last key would cost a ninth 64-key tile for ONE key.  It is peeled:
@@ -105,12 +104,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(const bf16_t *__restrict
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const uint4 kv = *reinterpret_cast<const uint4 *>(kl + 16 * kk + 8 * h);
-            const uint4 qv = __builtin_bit_cast(uint4, qf[kk]);
+            const uint4 qv = (qf[kk]);
             const uint32_t kw[4] = {kv.x, kv.y, kv.z, kv.w}, qw[4] = {qv.x, qv.y, qv.z, qv.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                dot = fmaf(__uint_as_float(kw[e] << 16), __uint_as_float(qw[e] << 16), dot);
-                dot = fmaf(__uint_as_float(kw[e] & 0xFFFF0000u), __uint_as_float(qw[e] & 0xFFFF0000u), dot);
+                dot = fmaf(h16<F>::lo(kw[e]), h16<F>::lo(qw[e]), dot);
+                dot = fmaf(h16<F>::hi(kw[e]), h16<F>::hi(qw[e]), dot);
             }
         }
         m = lane_xor32_sum(dot) * c;
@@ -120,8 +119,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(const bf16_t *__restrict
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const uint2 vv = *reinterpret_cast<const uint2 *>(vl + 32 * dtile + 8 * gq + 4 * h);
-                ot[dtile][4 * gq + 0] = __uint_as_float(vv.x << 16); ot[dtile][4 * gq + 1] = __uint_as_float(vv.x & 0xFFFF0000u);
-                ot[dtile][4 * gq + 2] = __uint_as_float(vv.y << 16); ot[dtile][4 * gq + 3] = __uint_as_float(vv.y & 0xFFFF0000u);
+                ot[dtile][4 * gq + 0] = h16<F>::lo(vv.x); ot[dtile][4 * gq + 1] = h16<F>::hi(vv.x);
+                ot[dtile][4 * gq + 2] = h16<F>::lo(vv.y); ot[dtile][4 * gq + 3] = h16<F>::hi(vv.y);
             }
     }
 
@@ -147,18 +146,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(const bf16_t *__restrict
                 for (int e = 0; e < 16; ++e) st[i][e] = 0.f;
             // all eight K fragments first (independent ds_read_b128, one wait), then the MFMAs: loaded one by one, each
             // MFMA waited for its own LDS round trip
-            bf16x8_t kf[4][2];
+            uint4 kf[4][2];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                 for (int sub = 0; sub < 2; ++sub)
                     kf[kk][sub] = __builtin_bit_cast(
-                        bf16x8_t, *reinterpret_cast<const uint4 *>(Kc + k_off(32 * sub + r, 2 * kk + h)));
+                        uint4, *reinterpret_cast<const uint4 *>(Kc + k_off(32 * sub + r, 2 * kk + h)));
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                 for (int sub = 0; sub < 2; ++sub)
-                    st[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk][sub], qf[kk], st[sub], 0, 0, 0);
+                    st[sub] = h16<F>::mfma32(kf[kk][sub], qf[kk], st[sub]);
             const bool need_mask = (kt * KVT + KVT > Tk) || (CAUSAL && kt * KVT + KVT - 1 > q0);
             if (need_mask) {
 #pragma unroll
@@ -193,16 +192,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(const bf16_t *__restrict
 #pragma unroll
                 for (int e = 0; e < 16; ++e) ot[i][e] *= alpha;
             // P (still in the S^T accumulator layout) -> bf16 B fragments of the 16-key k-steps
-            bf16x8_t pf[2][2];
+            uint4 pf[2][2];
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const uint4 u = make_uint4(pack_bf16x2(st[sub][8 * s + 0], st[sub][8 * s + 1]),
-                                               pack_bf16x2(st[sub][8 * s + 2], st[sub][8 * s + 3]),
-                                               pack_bf16x2(st[sub][8 * s + 4], st[sub][8 * s + 5]),
-                                               pack_bf16x2(st[sub][8 * s + 6], st[sub][8 * s + 7]));
-                    pf[sub][s] = __builtin_bit_cast(bf16x8_t, u);
+                    const uint4 u = make_uint4(h16<F>::pack2(st[sub][8 * s + 0], st[sub][8 * s + 1]),
+                                               h16<F>::pack2(st[sub][8 * s + 2], st[sub][8 * s + 3]),
+                                               h16<F>::pack2(st[sub][8 * s + 4], st[sub][8 * s + 5]),
+                                               h16<F>::pack2(st[sub][8 * s + 6], st[sub][8 * s + 7]));
+                    pf[sub][s] = (u);
                 }
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
@@ -216,8 +215,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(const bf16_t *__restrict
                             (__attribute__((address_space(3))) s4_t *)(Vc + v_off(key0, tr_dbyte + 64 * dtile)));
                         vf.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                             (__attribute__((address_space(3))) s4_t *)(Vc + v_off(key0 + 8, tr_dbyte + 64 * dtile)));
-                        ot[dtile] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf), pf[sub][s],
-                                                                             ot[dtile], 0, 0, 0);
+                        ot[dtile] = h16<F>::mfma32(__builtin_bit_cast(uint4, vf), pf[sub][s],
+                                                                             ot[dtile]);
                     }
         }
         if (kt + 1 < nkt) write_tile(cur ^ 1);
@@ -232,8 +231,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(const bf16_t *__restrict
         for (int dtile = 0; dtile < 2; ++dtile)
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                const uint2 u = make_uint2(pack_bf16x2(ot[dtile][4 * gq + 0] * inv, ot[dtile][4 * gq + 1] * inv),
-                                           pack_bf16x2(ot[dtile][4 * gq + 2] * inv, ot[dtile][4 * gq + 3] * inv));
+                const uint2 u = make_uint2(h16<F>::pack2(ot[dtile][4 * gq + 0] * inv, ot[dtile][4 * gq + 1] * inv),
+                                           h16<F>::pack2(ot[dtile][4 * gq + 2] * inv, ot[dtile][4 * gq + 3] * inv));
                 *reinterpret_cast<uint2 *>(ob + 32 * dtile + 8 * gq + 4 * h) = u;
             }
         if (lse && h == 0) lse[am_stat(Tfull, P, H, b, head, qrow)] = (m + __log2f(lt)) * 0.6931471805599453f;
@@ -254,30 +253,32 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(const bf16_t *__restrict
 // Tiles that are read both row-wise (ds_read_b128) and transposed (ds_read_b64_tr_b16) are kept as
 // two LDS images, each with the swizzle that makes its read conflict-free.
 // =================================================================================================
-__device__ __forceinline__ bf16x8_t pack8(const f32x16_t &x, int s)
+template <typename F>
+__device__ __forceinline__ uint4 pack8(const f32x16_t &x, int s)
 {
-    const uint4 u = make_uint4(pack_bf16x2(x[8 * s + 0], x[8 * s + 1]), pack_bf16x2(x[8 * s + 2], x[8 * s + 3]),
-                               pack_bf16x2(x[8 * s + 4], x[8 * s + 5]), pack_bf16x2(x[8 * s + 6], x[8 * s + 7]));
-    return __builtin_bit_cast(bf16x8_t, u);
+    const uint4 u = make_uint4(h16<F>::pack2(x[8 * s + 0], x[8 * s + 1]), h16<F>::pack2(x[8 * s + 2], x[8 * s + 3]),
+                               h16<F>::pack2(x[8 * s + 4], x[8 * s + 5]), h16<F>::pack2(x[8 * s + 6], x[8 * s + 7]));
+    return (u);
 }
 
-__device__ __forceinline__ bf16x8_t tr_frag(const unsigned char *img, int row0, int dbyte)
+__device__ __forceinline__ uint4 tr_frag(const unsigned char *img, int row0, int dbyte)
 {
     struct { s4_t a, b; } f;
     f.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t *)(img + v_off(row0, dbyte)));
     f.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t *)(img + v_off(row0 + 8, dbyte)));
-    return __builtin_bit_cast(bf16x8_t, f);
+    return __builtin_bit_cast(uint4, f);
 }
 
 // sum over the eight bf16 pairs of two 16-byte chunks (fp32)
+template <typename F>
 __device__ __forceinline__ float dot8_bf16(uint4 a, uint4 b)
 {
     const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
     float acc = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        acc = fmaf(__uint_as_float(aw[i] << 16), __uint_as_float(bw[i] << 16), acc);
-        acc = fmaf(__uint_as_float(aw[i] & 0xffff0000u), __uint_as_float(bw[i] & 0xffff0000u), acc);
+        acc = fmaf(h16<F>::lo(aw[i]), h16<F>::lo(bw[i]), acc);
+        acc = fmaf(h16<F>::hi(aw[i]), h16<F>::hi(bw[i]), acc);
     }
     return acc;
 }
@@ -290,7 +291,7 @@ constexpr int DKV_SMEM = 2 * (4 * QTILE + 256);   // per stage: Q row image, Q t
 // INLINE_DELTA: delta[q] = sum_d out[q, d] * dout[q, d] is computed while the q tile is staged (the eight threads that stage a
 // row hold its eight 16-byte chunks) instead of being read from the array a separate kernel filled: one node less in the
 // prompt chain per layer.
-template <bool CAUSAL, bool INLINE_DELTA, bool WHOLE_PREFIX = false>
+template <typename F, bool CAUSAL, bool INLINE_DELTA, bool WHOLE_PREFIX = false>
 __device__ __forceinline__ void attn_bwd_dkv_body(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ out, const bf16_t *__restrict__ dout,
                                                   const float *__restrict__ lse, const float *__restrict__ delta,
                                                   bf16_t *__restrict__ dqkv, int Tfull, int H, float scale, int P, int C,
@@ -315,7 +316,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const bf16_t *__restrict__ qkv
     const int key = k0 + r;
     const float c = scale * 1.4426950408889634f;
 
-    bf16x8_t kf[4], vf[4];
+    uint4 kf[4], vf[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
         uint4 a = make_uint4(0, 0, 0, 0), v = make_uint4(0, 0, 0, 0);
@@ -323,8 +324,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const bf16_t *__restrict__ qkv
             a = *reinterpret_cast<const uint4 *>(kb + am_row(Tfull, P, b, key) * rs + 16 * kk + 8 * h);
             v = *reinterpret_cast<const uint4 *>(vb + am_row(Tfull, P, b, key) * rs + 16 * kk + 8 * h);
         }
-        kf[kk] = __builtin_bit_cast(bf16x8_t, a);
-        vf[kk] = __builtin_bit_cast(bf16x8_t, v);
+        kf[kk] = (a);
+        vf[kk] = (v);
     }
     f32x16_t dvt[2], dkt[2];
 #pragma unroll
@@ -349,7 +350,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const bf16_t *__restrict__ qkv
         }
         if constexpr (INLINE_DELTA) {
             // the row's eight chunks sit in eight consecutive lanes: three xor steps leave the row sum in all of them
-            float d = dot8_bf16(sg, so);
+            float d = dot8_bf16<F>(sg, so);
             d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4);
             const bool own = q < Tq && q >= q_lo;
             sdr = own ? d : 0.f;
@@ -400,10 +401,10 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const bf16_t *__restrict__ qkv
             for (int e = 0; e < 16; ++e) { sa[e] = 0.f; dp[e] = 0.f; }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                const bf16x8_t qa = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(base + 0 * QTILE + k_off(r, 2 * kk + h)));
-                const bf16x8_t ga = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(base + 2 * QTILE + k_off(r, 2 * kk + h)));
-                sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[kk], sa, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, vf[kk], dp, 0, 0, 0);
+                const uint4 qa = (*reinterpret_cast<const uint4 *>(base + 0 * QTILE + k_off(r, 2 * kk + h)));
+                const uint4 ga = (*reinterpret_cast<const uint4 *>(base + 2 * QTILE + k_off(r, 2 * kk + h)));
+                sa = h16<F>::mfma32(qa, kf[kk], sa);
+                dp = h16<F>::mfma32(ga, vf[kk], dp);
             }
             const bool diag = CAUSAL && qt * QT < k0 + 32;        // some (q, key) pairs of this tile are masked
 #pragma unroll
@@ -422,13 +423,13 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const bf16_t *__restrict__ qkv
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const bf16x8_t pf = pack8(sa, s), df = pack8(dp, s);
+                const uint4 pf = pack8<F>(sa, s), df = pack8<F>(dp, s);
 #pragma unroll
                 for (int dtile = 0; dtile < 2; ++dtile) {
-                    const bf16x8_t gt = tr_frag(base + 3 * QTILE, 16 * s + tr_row, tr_dbyte + 64 * dtile);   // dO^T
-                    dvt[dtile] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gt, pf, dvt[dtile], 0, 0, 0);
-                    const bf16x8_t qt_ = tr_frag(base + 1 * QTILE, 16 * s + tr_row, tr_dbyte + 64 * dtile);  // Q^T
-                    dkt[dtile] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt_, df, dkt[dtile], 0, 0, 0);
+                    const uint4 gt = tr_frag(base + 3 * QTILE, 16 * s + tr_row, tr_dbyte + 64 * dtile);   // dO^T
+                    dvt[dtile] = h16<F>::mfma32(gt, pf, dvt[dtile]);
+                    const uint4 qt_ = tr_frag(base + 1 * QTILE, 16 * s + tr_row, tr_dbyte + 64 * dtile);  // Q^T
+                    dkt[dtile] = h16<F>::mfma32(qt_, df, dkt[dtile]);
                 }
             }
         }
@@ -457,27 +458,27 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const bf16_t *__restrict__ qkv
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const int d = 32 * dtile + 8 * gq + 4 * h;
-                *reinterpret_cast<uint2 *>(ok + d) = make_uint2(pack_bf16x2(dkt[dtile][4 * gq], dkt[dtile][4 * gq + 1]),
-                                                                 pack_bf16x2(dkt[dtile][4 * gq + 2], dkt[dtile][4 * gq + 3]));
-                *reinterpret_cast<uint2 *>(ov + d) = make_uint2(pack_bf16x2(dvt[dtile][4 * gq], dvt[dtile][4 * gq + 1]),
-                                                                 pack_bf16x2(dvt[dtile][4 * gq + 2], dvt[dtile][4 * gq + 3]));
+                *reinterpret_cast<uint2 *>(ok + d) = make_uint2(h16<F>::pack2(dkt[dtile][4 * gq], dkt[dtile][4 * gq + 1]),
+                                                                 h16<F>::pack2(dkt[dtile][4 * gq + 2], dkt[dtile][4 * gq + 3]));
+                *reinterpret_cast<uint2 *>(ov + d) = make_uint2(h16<F>::pack2(dvt[dtile][4 * gq], dvt[dtile][4 * gq + 1]),
+                                                                 h16<F>::pack2(dvt[dtile][4 * gq + 2], dvt[dtile][4 * gq + 3]));
             }
     }
 }
 
-template <bool CAUSAL>
+template <bool CAUSAL, typename F>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_mfma(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dout,
                                                          const float *__restrict__ lse, const float *__restrict__ delta,
                                                          bf16_t *__restrict__ dqkv, int Tfull, int H, float scale, int P, int C,
                                                          float *__restrict__ part)
 {
     __shared__ __align__(16) unsigned char smem[DKV_SMEM];
-    attn_bwd_dkv_body<CAUSAL, false>(qkv, nullptr, dout, lse, delta, dqkv, Tfull, H, scale, P, C, part, smem, blockIdx.x, blockIdx.y);
+    attn_bwd_dkv_body<F, CAUSAL, false>(qkv, nullptr, dout, lse, delta, dqkv, Tfull, H, scale, P, C, part, smem, blockIdx.x, blockIdx.y);
 }
 
 constexpr int DQ_SMEM = 2 * 3 * TILE;            // per stage: K row image, K tr image, V row image
 
-template <bool CAUSAL, bool INLINE_DELTA>
+template <typename F, bool CAUSAL, bool INLINE_DELTA>
 __device__ __forceinline__ void attn_bwd_dq_body(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ out, const bf16_t *__restrict__ dout,
                                                  const float *__restrict__ lse, const float *__restrict__ delta,
                                                  bf16_t *__restrict__ dqkv, int Tfull, int H, float scale, int P, int C,
@@ -496,7 +497,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const bf16_t *__restrict__ qkv,
     const int qrow = q0 + r;
     const float c = scale * 1.4426950408889634f;
 
-    bf16x8_t qf[4], gf[4];
+    uint4 qf[4], gf[4];
     float dsum = 0.f;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -505,10 +506,10 @@ __device__ __forceinline__ void attn_bwd_dq_body(const bf16_t *__restrict__ qkv,
             a = *reinterpret_cast<const uint4 *>(qb + am_row(Tfull, P, b, qrow) * rs + 16 * kk + 8 * h);
             v = *reinterpret_cast<const uint4 *>(gb + am_row(Tfull, P, b, qrow) * os + 16 * kk + 8 * h);
             if constexpr (INLINE_DELTA)      // this lane's half of the row (the other half sits in lane ^ 32)
-                dsum += dot8_bf16(v, *reinterpret_cast<const uint4 *>(out + head * HD + am_row(Tfull, P, b, qrow) * os + 16 * kk + 8 * h));
+                dsum += dot8_bf16<F>(v, *reinterpret_cast<const uint4 *>(out + head * HD + am_row(Tfull, P, b, qrow) * os + 16 * kk + 8 * h));
         }
-        qf[kk] = __builtin_bit_cast(bf16x8_t, a);
-        gf[kk] = __builtin_bit_cast(bf16x8_t, v);
+        qf[kk] = (a);
+        gf[kk] = (v);
     }
     const bool own = qrow < T && qrow >= q_lo;
     const float l2 = own ? lse[am_stat(Tfull, P, H, b, head, qrow)] * 1.4426950408889634f : INFINITY;
@@ -571,10 +572,10 @@ __device__ __forceinline__ void attn_bwd_dq_body(const bf16_t *__restrict__ qkv,
                 for (int e = 0; e < 16; ++e) { sa[e] = 0.f; dp[e] = 0.f; }
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    const bf16x8_t ka = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(base + 0 * TILE + k_off(32 * sub + r, 2 * kk + h)));
-                    const bf16x8_t va = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(base + 2 * TILE + k_off(32 * sub + r, 2 * kk + h)));
-                    sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[kk], sa, 0, 0, 0);     // S^T  [key][q]
-                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, gf[kk], dp, 0, 0, 0);     // dP^T [key][q]
+                    const uint4 ka = (*reinterpret_cast<const uint4 *>(base + 0 * TILE + k_off(32 * sub + r, 2 * kk + h)));
+                    const uint4 va = (*reinterpret_cast<const uint4 *>(base + 2 * TILE + k_off(32 * sub + r, 2 * kk + h)));
+                    sa = h16<F>::mfma32(ka, qf[kk], sa);     // S^T  [key][q]
+                    dp = h16<F>::mfma32(va, gf[kk], dp);     // dP^T [key][q]
                 }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
@@ -587,11 +588,11 @@ __device__ __forceinline__ void attn_bwd_dq_body(const bf16_t *__restrict__ qkv,
                 }
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const bf16x8_t df = pack8(dp, s);
+                    const uint4 df = pack8<F>(dp, s);
 #pragma unroll
                     for (int dtile = 0; dtile < 2; ++dtile) {
-                        const bf16x8_t kt_ = tr_frag(base + 1 * TILE, 32 * sub + 16 * s + tr_row, tr_dbyte + 64 * dtile);   // K^T
-                        dqt[dtile] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt_, df, dqt[dtile], 0, 0, 0);
+                        const uint4 kt_ = tr_frag(base + 1 * TILE, 32 * sub + 16 * s + tr_row, tr_dbyte + 64 * dtile);   // K^T
+                        dqt[dtile] = h16<F>::mfma32(kt_, df, dqt[dtile]);
                     }
                 }
             }
@@ -606,18 +607,18 @@ __device__ __forceinline__ void attn_bwd_dq_body(const bf16_t *__restrict__ qkv,
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq)
                 *reinterpret_cast<uint2 *>(oq + 32 * dtile + 8 * gq + 4 * h) =
-                    make_uint2(pack_bf16x2(dqt[dtile][4 * gq], dqt[dtile][4 * gq + 1]),
-                               pack_bf16x2(dqt[dtile][4 * gq + 2], dqt[dtile][4 * gq + 3]));
+                    make_uint2(h16<F>::pack2(dqt[dtile][4 * gq], dqt[dtile][4 * gq + 1]),
+                               h16<F>::pack2(dqt[dtile][4 * gq + 2], dqt[dtile][4 * gq + 3]));
     }
 }
 
-template <bool CAUSAL>
+template <bool CAUSAL, typename F>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ dout,
                                                         const float *__restrict__ lse, const float *__restrict__ delta,
                                                         bf16_t *__restrict__ dqkv, int Tfull, int H, float scale, int P, int C)
 {
     __shared__ __align__(16) unsigned char smem[DQ_SMEM];
-    attn_bwd_dq_body<CAUSAL, false>(qkv, nullptr, dout, lse, delta, dqkv, Tfull, H, scale, P, C, smem, blockIdx.x, blockIdx.y);
+    attn_bwd_dq_body<F, CAUSAL, false>(qkv, nullptr, dout, lse, delta, dqkv, Tfull, H, scale, P, C, smem, blockIdx.x, blockIdx.y);
 }
 
 // One launch for the whole backward of a SHORT sequence (T <= 128: one key block and one query block per (sequence, head);
@@ -626,7 +627,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma(const bf16_t *__restr
 // absorb attn_prefix_reduce, is compiled out: the prefix workgroup's walk over all 817 rows is 26 dependent tile iterations
 // of ~1.1 us each -- the next tile's loads are only one iteration ahead -- and made the launch ~29 us instead of ~3 + a 4.5 us
 // reduction: prompt chain alone 1.97 -> 2.33 ms.)
-template <bool CAUSAL>
+template <bool CAUSAL, typename F>
 __global__ __launch_bounds__(256, 2) void attn_bwd_short_mfma(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ out,
                                                            const bf16_t *__restrict__ dout, const float *__restrict__ lse,
                                                            bf16_t *__restrict__ dqkv, int Tfull, int H, float scale, int P, int C,
@@ -637,24 +638,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_short_mfma(const bf16_t *__re
     // gridDim.x == 2: one workgroup per role; == 1: ONE workgroup runs both roles back to back (half the workgroups: with two
     // 208-VGPR workgroups per CU, 656 role workgroups of the 41 x 8 (sequence, head) pairs were two rounds on 512 slots)
     if (gridDim.x == 1 || blockIdx.x == 0)
-        attn_bwd_dkv_body<CAUSAL, true, false>(qkv, out, dout, lse, nullptr, dqkv, Tfull, H, scale, P, C, part, smem, 0, blockIdx.y);
+        attn_bwd_dkv_body<F, CAUSAL, true, false>(qkv, out, dout, lse, nullptr, dqkv, Tfull, H, scale, P, C, part, smem, 0, blockIdx.y);
     if (gridDim.x == 1) __syncthreads();
     if (gridDim.x == 1 || blockIdx.x == 1)
-        attn_bwd_dq_body<CAUSAL, true>(qkv, out, dout, lse, nullptr, dqkv, Tfull, H, scale, P, C, smem, 0, blockIdx.y);
+        attn_bwd_dq_body<F, CAUSAL, true>(qkv, out, dout, lse, nullptr, dqkv, Tfull, H, scale, P, C, smem, 0, blockIdx.y);
 }
 
 }  // namespace
 
+// fmt = PPT_BF16 or PPT_F16 (the 16-bit operand format of qkv / out / dout / dqkv) for the functions below
 extern "C" int ppt_attention_fwd_mfma_bf16(const void *qkv, void *out, float *lse, int Bt, int T, int H, float scale,
-                                           int causal, int P, hipStream_t s)
+                                           int causal, int P, int fmt, hipStream_t s)
 {
-    if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 7)) return ppt_attention_fwd_quad_bf16(qkv, out, lse, Bt, T, H, scale, causal, P, s);
+    if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 7)) return ppt_attention_fwd_quad_bf16(qkv, out, lse, Bt, T, H, scale, causal, P, fmt, s);
     dim3 grid((T + QB - 1) / QB, (Bt + (P > 0)) * H);
     const float c = scale * 1.4426950408889634f;
-    if (causal)
-        hipLaunchKernelGGL(attn_fwd_mfma<true>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (bf16_t *)out, lse, T, H, c, P, Bt, ppt_get_wave_priority());
-    else
-        hipLaunchKernelGGL(attn_fwd_mfma<false>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (bf16_t *)out, lse, T, H, c, P, Bt, ppt_get_wave_priority());
+    const int prio = ppt_get_wave_priority();
+    if (fmt == PPT_F16) {
+        if (causal) hipLaunchKernelGGL((attn_fwd_mfma<true, f16_t>), grid, dim3(256), 0, s, (const bf16_t *)qkv, (bf16_t *)out, lse, T, H, c, P, Bt, prio);
+        else hipLaunchKernelGGL((attn_fwd_mfma<false, f16_t>), grid, dim3(256), 0, s, (const bf16_t *)qkv, (bf16_t *)out, lse, T, H, c, P, Bt, prio);
+    } else {
+        if (causal) hipLaunchKernelGGL((attn_fwd_mfma<true, bf16_t>), grid, dim3(256), 0, s, (const bf16_t *)qkv, (bf16_t *)out, lse, T, H, c, P, Bt, prio);
+        else hipLaunchKernelGGL((attn_fwd_mfma<false, bf16_t>), grid, dim3(256), 0, s, (const bf16_t *)qkv, (bf16_t *)out, lse, T, H, c, P, Bt, prio);
+    }
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }
@@ -663,34 +669,34 @@ extern "C" int ppt_attention_fwd_mfma_bf16(const void *qkv, void *out, float *ls
 // layout, attn_rowmap.h): `part` [Bt + 1, P, 2, H * 64] f32 receives the per-sequence dK / dV of the shared rows; the caller
 // folds it (attention.hip: attn_prefix_reduce).
 extern "C" int ppt_attention_bwd_short_mfma_bf16(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv, int Bt, int T,
-                                                 int H, float scale, int causal, int P, float *part, hipStream_t s)
+                                                 int H, float scale, int causal, int P, float *part, int fmt, hipStream_t s)
 {
     if (T > 128) return PPT_EUNSUPPORTED;
     if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dqkv & 7) || ((uintptr_t)part & 15)) return PPT_EUNSUPPORTED;
     static const int both = [] { const char *e = getenv("PPT_ATTN_SHORT_BOTH"); return e ? atoi(e) : 1; }();
     const int pairs = (Bt + (P > 0)) * H;
     dim3 grid(both && 2 * pairs > 512 ? 1 : 2, pairs);    // (two roles per workgroup once the role workgroups would not fit in one round)
-    if (causal)
-        hipLaunchKernelGGL(attn_bwd_short_mfma<true>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, T, H, scale, P, Bt, part, ppt_get_wave_priority());
-    else
-        hipLaunchKernelGGL(attn_bwd_short_mfma<false>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, T, H, scale, P, Bt, part, ppt_get_wave_priority());
+    const int prio = ppt_get_wave_priority();
+#define PPT_LAUNCH_SHORT(CA, TT) hipLaunchKernelGGL((attn_bwd_short_mfma<CA, TT>), grid, dim3(256), 0, s, (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, T, H, scale, P, Bt, part, prio)
+    if (fmt == PPT_F16) { if (causal) PPT_LAUNCH_SHORT(true, f16_t); else PPT_LAUNCH_SHORT(false, f16_t); }
+    else { if (causal) PPT_LAUNCH_SHORT(true, bf16_t); else PPT_LAUNCH_SHORT(false, bf16_t); }
+#undef PPT_LAUNCH_SHORT
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }
 
 extern "C" int ppt_attention_bwd_mfma_bf16(const void *qkv, const void *dout, const float *lse, const float *delta,
                                            void *dqkv, int Bt, int T, int H, float scale, int causal, int P, float *part,
-                                           hipStream_t s)
+                                           int fmt, hipStream_t s)
 {
     if (((uintptr_t)qkv & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dqkv & 7) || ((uintptr_t)part & 15)) return PPT_EUNSUPPORTED;
     dim3 grid((T + 127) / 128, (Bt + (P > 0)) * H);
-    if (causal) {
-        hipLaunchKernelGGL(attn_bwd_dkv_mfma<true>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (const bf16_t *)dout, lse, delta, (bf16_t *)dqkv, T, H, scale, P, Bt, part);
-        hipLaunchKernelGGL(attn_bwd_dq_mfma<true>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (const bf16_t *)dout, lse, delta, (bf16_t *)dqkv, T, H, scale, P, Bt);
-    } else {
-        hipLaunchKernelGGL(attn_bwd_dkv_mfma<false>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (const bf16_t *)dout, lse, delta, (bf16_t *)dqkv, T, H, scale, P, Bt, part);
-        hipLaunchKernelGGL(attn_bwd_dq_mfma<false>, grid, dim3(256), 0, s, (const bf16_t *)qkv, (const bf16_t *)dout, lse, delta, (bf16_t *)dqkv, T, H, scale, P, Bt);
-    }
+#define PPT_LAUNCH_BWD(CA, TT) do { \
+        hipLaunchKernelGGL((attn_bwd_dkv_mfma<CA, TT>), grid, dim3(256), 0, s, (const bf16_t *)qkv, (const bf16_t *)dout, lse, delta, (bf16_t *)dqkv, T, H, scale, P, Bt, part); \
+        hipLaunchKernelGGL((attn_bwd_dq_mfma<CA, TT>), grid, dim3(256), 0, s, (const bf16_t *)qkv, (const bf16_t *)dout, lse, delta, (bf16_t *)dqkv, T, H, scale, P, Bt); } while (0)
+    if (fmt == PPT_F16) { if (causal) PPT_LAUNCH_BWD(true, f16_t); else PPT_LAUNCH_BWD(false, f16_t); }
+    else { if (causal) PPT_LAUNCH_BWD(true, bf16_t); else PPT_LAUNCH_BWD(false, bf16_t); }
+#undef PPT_LAUNCH_BWD
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }

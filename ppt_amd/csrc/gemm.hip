@@ -95,10 +95,16 @@ __device__ __forceinline__ void act_bwd_n(float (&v)[N], const float (&x)[N], in
 template <typename T> __device__ __forceinline__ float load_as_f32(const void *p, int64_t i);
 template <> __device__ __forceinline__ float load_as_f32<float>(const void *p, int64_t i) { return ((const float *)p)[i]; }
 template <> __device__ __forceinline__ float load_as_f32<bf16_t>(const void *p, int64_t i) { return bf16_to_f32(((const bf16_t *)p)[i]); }
+template <> __device__ __forceinline__ float load_as_f32<f16_t>(const void *p, int64_t i) { return f16_to_f32(((const uint16_t *)p)[i]); }
+// element i of a tensor whose dtype is a run-time code
+__device__ __forceinline__ float load_dt(const void *p, int dtype, int64_t i)
+{
+    return dtype == PPT_F32 ? ((const float *)p)[i] : to_f32_dt(dtype, ((const uint16_t *)p)[i]);
+}
 
 __device__ __forceinline__ void store_dt(void *p, int dtype, int64_t i, float v)
 {
-    if (dtype == PPT_BF16) ((bf16_t *)p)[i] = f32_to_bf16(v);
+    if (dtype != PPT_F32) ((uint16_t *)p)[i] = from_f32_dt(dtype, v);
     else ((float *)p)[i] = v;
 }
 
@@ -137,18 +143,20 @@ __device__ __forceinline__ void mask_plain(Stage<NR> &st, int rows, int K, int r
 }
 
 template <typename T> __device__ __forceinline__ void affine_relu_chunk(uint4 &v, const float *sc, const float *sh);
-template <>
-__device__ __forceinline__ void affine_relu_chunk<bf16_t>(uint4 &v, const float *sc, const float *sh)
+template <typename T>
+__device__ __forceinline__ void affine_relu_chunk16(uint4 &v, const float *sc, const float *sh)
 {
     uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const float lo = fmaxf(fmaf(__uint_as_float(w[e] << 16), sc[2 * e], sh[2 * e]), 0.0f);
-        const float hi = fmaxf(fmaf(__uint_as_float(w[e] & 0xFFFF0000u), sc[2 * e + 1], sh[2 * e + 1]), 0.0f);
-        w[e] = pack_bf16x2(lo, hi);
+        const float lo = fmaxf(fmaf(h16<T>::lo(w[e]), sc[2 * e], sh[2 * e]), 0.0f);
+        const float hi = fmaxf(fmaf(h16<T>::hi(w[e]), sc[2 * e + 1], sh[2 * e + 1]), 0.0f);
+        w[e] = h16<T>::pack2(lo, hi);
     }
     v = make_uint4(w[0], w[1], w[2], w[3]);
 }
+template <> __device__ __forceinline__ void affine_relu_chunk<bf16_t>(uint4 &v, const float *sc, const float *sh) { affine_relu_chunk16<bf16_t>(v, sc, sh); }
+template <> __device__ __forceinline__ void affine_relu_chunk<f16_t>(uint4 &v, const float *sc, const float *sh) { affine_relu_chunk16<f16_t>(v, sc, sh); }
 template <>
 __device__ __forceinline__ void affine_relu_chunk<float>(uint4 &v, const float *sc, const float *sh)
 {
@@ -236,8 +244,8 @@ __device__ __forceinline__ void finish_A(Stage<NR> &st, const ppt_gemm_params &p
             for (int e = 0; e < EPC; ++e)
                 f[e] = r < p.M ? fmaxf(fmaf(wz[e], z, fmaf(wy[e], y, fmaf(wx[e], x, wb[e]))), 0.0f) : 0.0f;
             if constexpr (sizeof(T) == 2)
-                st.v[i] = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]),
-                                     pack_bf16x2(f[6], f[7]));
+                st.v[i] = make_uint4(h16<T>::pack2(f[0], f[1]), h16<T>::pack2(f[2], f[3]), h16<T>::pack2(f[4], f[5]),
+                                     h16<T>::pack2(f[6], f[7]));
             else
                 st.v[i] = make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]),
                                      __float_as_uint(f[3]));
@@ -265,18 +273,18 @@ __device__ __forceinline__ void mma_slab(const unsigned char *As, const unsigned
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            bf16x8_t a[TI], b[TJ];
+            uint4 a[TI], b[TJ];
 #pragma unroll
             for (int i = 0; i < TI; ++i)
-                a[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(As + lds_off(arow0 + i * 32 + r, kk * 2 + h)));
+                a[i] = *reinterpret_cast<const uint4 *>(As + lds_off(arow0 + i * 32 + r, kk * 2 + h));
 #pragma unroll
             for (int j = 0; j < TJ; ++j)
-                b[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(Bs + lds_off(brow0 + j * 32 + r, kk * 2 + h)));
+                b[j] = *reinterpret_cast<const uint4 *>(Bs + lds_off(brow0 + j * 32 + r, kk * 2 + h));
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int j = 0; j < TJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = h16<T>::mfma32(a[i], b[j], acc[i][j]);
         }
     } else {
 #pragma unroll
@@ -317,8 +325,7 @@ __device__ __forceinline__ void epilogue_scalar(const ppt_gemm_params &p, float 
             if (p.group_add) v += p.group_add[(int64_t)(m / p.group_rows) * p.N + n];
             if (p.C2 && p.c2_pre) store_dt(p.C2, p.c2_dtype, (int64_t)m * p.ldc2 + n, v);
             if (p.dact_pre) {
-                const float x = p.dtype == PPT_BF16 ? load_as_f32<bf16_t>(p.dact_pre, (int64_t)m * p.ld_dact + n)
-                                                     : load_as_f32<float>(p.dact_pre, (int64_t)m * p.ld_dact + n);
+                const float x = load_dt(p.dact_pre, p.dtype, (int64_t)m * p.ld_dact + n);
                 v *= act_bwd<false>(x, p.act);
             } else {
                 v = act_fwd<false>(v, p.act);
@@ -350,21 +357,21 @@ __device__ __forceinline__ void st8_f32(float *p, const f8 &x)
 }
 __device__ __forceinline__ f8 ld8_dt(const void *p, int dtype, int64_t i)
 {
-    if (dtype == PPT_BF16) {
-        const uint4 u = *reinterpret_cast<const uint4 *>((const bf16_t *)p + i);
+    if (dtype != PPT_F32) {
+        const uint4 u = *reinterpret_cast<const uint4 *>((const uint16_t *)p + i);
         const uint32_t w[4] = {u.x, u.y, u.z, u.w};
         f8 r;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { r.v[2 * e] = __uint_as_float(w[e] << 16); r.v[2 * e + 1] = __uint_as_float(w[e] & 0xFFFF0000u); }
+        for (int e = 0; e < 4; ++e) { r.v[2 * e] = lo_dt(dtype, w[e]); r.v[2 * e + 1] = hi_dt(dtype, w[e]); }
         return r;
     }
     return ld8_f32((const float *)p + i);
 }
 __device__ __forceinline__ void st8_dt(void *p, int dtype, int64_t i, const f8 &x)
 {
-    if (dtype == PPT_BF16)
-        *reinterpret_cast<uint4 *>((bf16_t *)p + i) = make_uint4(pack_bf16x2(x.v[0], x.v[1]), pack_bf16x2(x.v[2], x.v[3]),
-                                                                 pack_bf16x2(x.v[4], x.v[5]), pack_bf16x2(x.v[6], x.v[7]));
+    if (dtype != PPT_F32)
+        *reinterpret_cast<uint4 *>((uint16_t *)p + i) = make_uint4(pack2_dt(dtype, x.v[0], x.v[1]), pack2_dt(dtype, x.v[2], x.v[3]),
+                                                                   pack2_dt(dtype, x.v[4], x.v[5]), pack2_dt(dtype, x.v[6], x.v[7]));
     else
         st8_f32((float *)p + i, x);
 }
@@ -401,8 +408,8 @@ __device__ __forceinline__ void epilogue_vec8(const ppt_gemm_params &p, float *c
             } else if (kind == 2) {
                 const float *q = p.residual + (int64_t)m * p.ld_res + nc;
                 pre[pass][0] = *reinterpret_cast<const uint4 *>(q); pre[pass][1] = *reinterpret_cast<const uint4 *>(q + 4);
-            } else if (p.dtype == PPT_BF16) {
-                pre[pass][0] = *reinterpret_cast<const uint4 *>((const bf16_t *)p.dact_pre + (int64_t)m * p.ld_dact + nc);
+            } else if (p.dtype != PPT_F32) {
+                pre[pass][0] = *reinterpret_cast<const uint4 *>((const uint16_t *)p.dact_pre + (int64_t)m * p.ld_dact + nc);
                 pre[pass][1] = make_uint4(0, 0, 0, 0);
             } else {
                 const float *q = (const float *)p.dact_pre + (int64_t)m * p.ld_dact + nc;
@@ -419,13 +426,13 @@ __device__ __forceinline__ void epilogue_vec8(const ppt_gemm_params &p, float *c
             pre2[pass][0] = *reinterpret_cast<const uint4 *>(q); pre2[pass][1] = *reinterpret_cast<const uint4 *>(q + 4);
         }
     }
-    auto pre_f8 = [&](int pass, bool packed_bf16) {
+    auto pre_f8 = [&](int pass, bool packed16) {
         f8 r;
         const uint4 a = pre[pass][0], b = pre[pass][1];
-        if (packed_bf16) {
+        if (packed16) {
             const uint32_t w[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { r.v[2 * e] = __uint_as_float(w[e] << 16); r.v[2 * e + 1] = __uint_as_float(w[e] & 0xFFFF0000u); }
+            for (int e = 0; e < 4; ++e) { r.v[2 * e] = lo_dt(p.dtype, w[e]); r.v[2 * e + 1] = hi_dt(p.dtype, w[e]); }
         } else {
             r = f8{{__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w),
                     __uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w)}};
@@ -453,11 +460,11 @@ __device__ __forceinline__ void epilogue_vec8(const ppt_gemm_params &p, float *c
             }
             if (p.C2 && p.c2_pre) st8_dt(p.C2, p.c2_dtype, (int64_t)m * p.ldc2 + n, v);
             if ((FEAT & 1) && p.dact_pre) {
-                const f8 x = kind == 3 ? pre_f8(pass, p.dtype == PPT_BF16) : ld8_dt(p.dact_pre, p.dtype, (int64_t)m * p.ld_dact + n);
-                if (p.dtype == PPT_BF16) act_bwd_n<true, 8>(v.v, x.v, p.act);
+                const f8 x = kind == 3 ? pre_f8(pass, p.dtype != PPT_F32) : ld8_dt(p.dact_pre, p.dtype, (int64_t)m * p.ld_dact + n);
+                if (p.dtype != PPT_F32) act_bwd_n<true, 8>(v.v, x.v, p.act);
                 else act_bwd_n<false, 8>(v.v, x.v, p.act);
             } else if (p.act != PPT_ACT_NONE) {
-                if (p.dtype == PPT_BF16) act_fwd_n<true, 8>(v.v, p.act);
+                if (p.dtype != PPT_F32) act_fwd_n<true, 8>(v.v, p.act);
                 else act_fwd_n<false, 8>(v.v, p.act);
             }
             if (p.row_scale) {
@@ -588,7 +595,7 @@ __host__ __device__ __forceinline__ bool reg_epilogue_ok(const ppt_gemm_params &
 {
     if (p.residual || p.residual2 || p.dact_pre || p.row_scale || p.C2) return false;
     if ((p.N % 8) != 0) return false;
-    if (p.C && (p.c_dtype != PPT_BF16 || (p.ldc % 8) != 0 || (zc % 8) != 0 || !al16(p.C))) return false;
+    if (p.C && (p.c_dtype == PPT_F32 || (p.ldc % 8) != 0 || (zc % 8) != 0 || !al16(p.C))) return false;
     if (p.group_add && !(p.group_rows == 16 || (p.group_rows > 0 && (p.group_rows % 32) == 0))) return false;
     if (p.pool_max) {
         const int pr = p.pool_rows > 0 ? p.pool_rows : 32;
@@ -599,7 +606,7 @@ __host__ __device__ __forceinline__ bool reg_epilogue_ok(const ppt_gemm_params &
 
 __device__ __forceinline__ void st_pool(void *base, int dtype, int64_t i, float v)
 {
-    if (dtype == PPT_BF16) reinterpret_cast<bf16_t *>(base)[i] = f32_to_bf16(v);
+    if (dtype != PPT_F32) reinterpret_cast<uint16_t *>(base)[i] = from_f32_dt(dtype, v);
     else reinterpret_cast<float *>(base)[i] = v;
 }
 
@@ -654,7 +661,7 @@ __device__ __forceinline__ void epilogue_regs(const ppt_gemm_params &p, f32x16_t
     const bool has_pool = EPI < 0 ? p.pool_max != nullptr : (EPI & EPI_POOL) != 0;
     constexpr int WM = TI * 32, WN = TJ * 32, ROWBYTES = WN * 2;
     const int cl = lane & 31, h = lane >> 5, odd = cl & 1;
-    const bool fast = FAST < 0 ? p.dtype == PPT_BF16 : FAST != 0;
+    const bool fast = FAST < 0 ? p.dtype != PPT_F32 : FAST != 0;
     const int pool_rows = p.pool_rows > 0 ? p.pool_rows : 32;
     // parked dword of this lane inside a (row pair, column tile): row + odd, columns (cl & ~1, cl | 1); for 64-column
     // wave tiles odd rows keep their two 64-byte halves swapped, which puts the even-lane row and the odd-lane row of
@@ -770,7 +777,7 @@ __device__ __forceinline__ void epilogue_regs(const ppt_gemm_params &p, f32x16_t
                     // even lane keeps row(r): (own, neighbour's); odd lane keeps row(r+1): (neighbour's, own)
                     const float give = odd ? v[r] : v[r + 1];
                     const float got = __uint_as_float(dpp_mov<0xB1, 0xf>(__float_as_uint(give)));   // quad_perm [1,0,3,2]
-                    const uint32_t w = pack_bf16x2(odd ? got : v[r], odd ? v[r + 1] : got);
+                    const uint32_t w = pack2_dt(p.c_dtype, odd ? got : v[r], odd ? v[r + 1] : got);
                     const int jb = TJ == 2 ? ((j ^ odd) << 6) : 0;     // the written row (r + odd) is odd exactly on odd lanes
                     *reinterpret_cast<uint32_t *>(park + (i * 32 + (r & 3) + 8 * (r >> 2)) * ROWBYTES + jb + lane_byte) = w;
                 }
@@ -784,7 +791,7 @@ __device__ __forceinline__ void epilogue_regs(const ppt_gemm_params &p, f32x16_t
     constexpr int CPR = WN / 8, RP = 64 / CPR;                        // 16-byte chunks per row, rows per pass
     const int ch = lane % CPR, rl = lane / CPR;
     const int n = nw + ch * 8;
-    bf16_t *C = reinterpret_cast<bf16_t *>(p.C) + zc;
+    uint16_t *C = reinterpret_cast<uint16_t *>(p.C) + zc;
 #pragma unroll
     for (int pass = 0; pass < WM / RP; ++pass) {
         const int row = pass * RP + rl;
@@ -1098,18 +1105,18 @@ __device__ __forceinline__ void mma_half(const unsigned char *As, const unsigned
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8_t a[TI], b[TJ];
+            uint4 a[TI], b[TJ];
 #pragma unroll
             for (int i = 0; i < TI; ++i)
-                a[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(As + lds_off_h(arow0 + i * 32 + r, kk * 2 + h)));
+                a[i] = *reinterpret_cast<const uint4 *>(As + lds_off_h(arow0 + i * 32 + r, kk * 2 + h));
 #pragma unroll
             for (int j = 0; j < TJ; ++j)
-                b[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(Bs + lds_off_h(brow0 + j * 32 + r, kk * 2 + h)));
+                b[j] = *reinterpret_cast<const uint4 *>(Bs + lds_off_h(brow0 + j * 32 + r, kk * 2 + h));
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int j = 0; j < TJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = h16<T>::mfma32(a[i], b[j], acc[i][j]);
         }
     } else {
 #pragma unroll
@@ -1270,8 +1277,14 @@ extern "C" int ppt_gemm(const ppt_gemm_params *pp, void *stream)
     if (!q.wave_prio) q.wave_prio = ppt_get_wave_priority();
     const ppt_gemm_params &p = q;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || !p.B) return PPT_EINVAL;
-    if (p.dtype != PPT_F32 && p.dtype != PPT_BF16) return PPT_EINVAL;
-    const int epc = p.dtype == PPT_BF16 ? 8 : 4;
+    if (p.dtype != PPT_F32 && p.dtype != PPT_BF16 && p.dtype != PPT_F16) return PPT_EINVAL;
+    // one 16-bit format per GEMM: outputs / saved pre-activations / pooled rows are fp32 or the operands' format
+    if (p.dtype != PPT_F32) {
+        if ((p.C && p.c_dtype != PPT_F32 && p.c_dtype != p.dtype) || (p.C2 && p.c2_dtype != PPT_F32 && p.c2_dtype != p.dtype) ||
+            (p.pool_max && p.pool_dtype != PPT_F32 && p.pool_dtype != p.dtype))
+            return PPT_EINVAL;
+    }
+    const int epc = p.dtype != PPT_F32 ? 8 : 4;
     if (p.K % epc || p.ldb % epc || ((uintptr_t)p.B & 15)) return PPT_EINVAL;
     if (p.a_mode != PPT_A_PLAIN && p.K > 1024) return PPT_EUNSUPPORTED;      // prologue constants live in an LDS table
     if (p.a_mode == PPT_A_CONV1) {
@@ -1292,5 +1305,5 @@ extern "C" int ppt_gemm(const ppt_gemm_params *pp, void *stream)
     if (p.batch > 1 && (p.C2 || p.col_sum || p.pool_max || p.residual || p.residual2 || p.dact_pre || p.group_add))
         return PPT_EUNSUPPORTED;
     hipStream_t s = ppt_stream(stream);
-    return p.dtype == PPT_BF16 ? launch_gemm<bf16_t>(p, s) : launch_gemm<float>(p, s);
+    return p.dtype == PPT_BF16 ? launch_gemm<bf16_t>(p, s) : p.dtype == PPT_F16 ? launch_gemm<f16_t>(p, s) : launch_gemm<float>(p, s);
 }

@@ -194,6 +194,7 @@ int convert_from(const void *src, void *dst, int dd, int64_t n, hipStream_t s)
 {
     const unsigned grid = (unsigned)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
     if (dd == PPT_BF16) hipLaunchKernelGGL((convert_kernel<TS, bf16_t>), dim3(grid), dim3(256), 0, s, (const TS *)src, (bf16_t *)dst, n);
+    else if (dd == PPT_F16) hipLaunchKernelGGL((convert_kernel<TS, f16_t>), dim3(grid), dim3(256), 0, s, (const TS *)src, (f16_t *)dst, n);
     else if (dd == PPT_F32) hipLaunchKernelGGL((convert_kernel<TS, float>), dim3(grid), dim3(256), 0, s, (const TS *)src, (float *)dst, n);
     else return PPT_EINVAL;
     PPT_CHECK_LAUNCH();
@@ -205,6 +206,7 @@ int transpose_from(const void *src, void *dst, int dd, int rows, int cols, int64
 {
     dim3 grid((cols + 31) / 32, (rows + 31) / 32);
     if (dd == PPT_BF16) hipLaunchKernelGGL((transpose_kernel<TS, bf16_t>), grid, dim3(256), 0, s, (const TS *)src, (bf16_t *)dst, rows, cols, ldd);
+    else if (dd == PPT_F16) hipLaunchKernelGGL((transpose_kernel<TS, f16_t>), grid, dim3(256), 0, s, (const TS *)src, (f16_t *)dst, rows, cols, ldd);
     else if (dd == PPT_F32) hipLaunchKernelGGL((transpose_kernel<TS, float>), grid, dim3(256), 0, s, (const TS *)src, (float *)dst, rows, cols, ldd);
     else return PPT_EINVAL;
     PPT_CHECK_LAUNCH();
@@ -220,6 +222,8 @@ extern "C" int ppt_cls_max_pool(const void *x, int x_dtype, int B, int T, int D,
         hipLaunchKernelGGL(cls_max_pool_kernel<float>, dim3((D + 63) / 64, B), dim3(CMP_W * 64), 0, ppt_stream(stream), (const float *)x, T, D, out, argmax);
     else if (x_dtype == PPT_BF16)
         hipLaunchKernelGGL(cls_max_pool_kernel<bf16_t>, dim3((D + 63) / 64, B), dim3(CMP_W * 64), 0, ppt_stream(stream), (const bf16_t *)x, T, D, out, argmax);
+    else if (x_dtype == PPT_F16)
+        hipLaunchKernelGGL(cls_max_pool_kernel<f16_t>, dim3((D + 63) / 64, B), dim3(CMP_W * 64), 0, ppt_stream(stream), (const f16_t *)x, T, D, out, argmax);
     else
         return PPT_EINVAL;
     PPT_CHECK_LAUNCH();
@@ -231,6 +235,7 @@ extern "C" int ppt_convert(const void *src, int src_dtype, void *dst, int dst_dt
     if (!src || !dst || n <= 0) return PPT_EINVAL;
     if (src_dtype == PPT_F32) return convert_from<float>(src, dst, dst_dtype, n, ppt_stream(stream));
     if (src_dtype == PPT_BF16) return convert_from<bf16_t>(src, dst, dst_dtype, n, ppt_stream(stream));
+    if (src_dtype == PPT_F16) return convert_from<f16_t>(src, dst, dst_dtype, n, ppt_stream(stream));
     return PPT_EINVAL;
 }
 
@@ -240,6 +245,7 @@ extern "C" int ppt_transpose(const void *src, int src_dtype, void *dst, int dst_
     if (!src || !dst || rows <= 0 || cols <= 0 || ld_dst < rows) return PPT_EINVAL;
     if (src_dtype == PPT_F32) return transpose_from<float>(src, dst, dst_dtype, rows, cols, ld_dst, ppt_stream(stream));
     if (src_dtype == PPT_BF16) return transpose_from<bf16_t>(src, dst, dst_dtype, rows, cols, ld_dst, ppt_stream(stream));
+    if (src_dtype == PPT_F16) return transpose_from<f16_t>(src, dst, dst_dtype, rows, cols, ld_dst, ppt_stream(stream));
     return PPT_EINVAL;
 }
 
@@ -257,6 +263,8 @@ extern "C" int ppt_col_sums(const void *x, int x_dtype, int M, int D, int64_t ld
                            (const bf16_t *)x, M, D, ldx, partial);
     else if (x_dtype == PPT_BF16)
         hipLaunchKernelGGL(col_sums_kernel<bf16_t>, grid, dim3(256), 0, ppt_stream(stream), (const bf16_t *)x, M, D, ldx, partial);
+    else if (x_dtype == PPT_F16)
+        hipLaunchKernelGGL(col_sums_kernel<f16_t>, grid, dim3(256), 0, ppt_stream(stream), (const f16_t *)x, M, D, ldx, partial);
     else
         return PPT_EINVAL;
     PPT_CHECK_LAUNCH();

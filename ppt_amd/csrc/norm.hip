@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void ln_fwd_vec8_kernel(const float *__restric
             for (int j = 0; j < 8; ++j) o[j] = (v[j] - mean) * rstd * g[j] + be[j];
             if constexpr (sizeof(TY) == 2) {
                 *reinterpret_cast<uint4 *>(y + (size_t)row * D + c) =
-                    make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+                    make_uint4(h16<TY>::pack2(o[0], o[1]), h16<TY>::pack2(o[2], o[3]), h16<TY>::pack2(o[4], o[5]), h16<TY>::pack2(o[6], o[7]));
             } else {
                 *reinterpret_cast<float4 *>(y + (size_t)row * D + c) = make_float4(o[0], o[1], o[2], o[3]);
                 *reinterpret_cast<float4 *>(y + (size_t)row * D + c + 4) = make_float4(o[4], o[5], o[6], o[7]);
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ d
                 const float t = accumulate ? *o + r : r;
                 *o = t;
                 if (dx_copy) {
-                    if (copy_dtype == PPT_BF16) ((bf16_t *)dx_copy)[(size_t)row * D + e] = f32_to_bf16(t);
+                    if (copy_dtype != PPT_F32) ((uint16_t *)dx_copy)[(size_t)row * D + e] = from_f32_dt(copy_dtype, t);
                     else ((float *)dx_copy)[(size_t)row * D + e] = t;
                 }
             }
@@ -217,9 +217,9 @@ __global__ __launch_bounds__(256) void ln_bwd_dx8_kernel(const float *__restrict
     *reinterpret_cast<float4 *>(dx + off) = make_float4(t[0], t[1], t[2], t[3]);
     *reinterpret_cast<float4 *>(dx + off + 4) = make_float4(t[4], t[5], t[6], t[7]);
     if (dx_copy) {
-        if (copy_dtype == PPT_BF16) {
-            *reinterpret_cast<uint4 *>((bf16_t *)dx_copy + off) = make_uint4(pack_bf16x2(t[0], t[1]), pack_bf16x2(t[2], t[3]),
-                                                                              pack_bf16x2(t[4], t[5]), pack_bf16x2(t[6], t[7]));
+        if (copy_dtype != PPT_F32) {
+            *reinterpret_cast<uint4 *>((uint16_t *)dx_copy + off) = make_uint4(pack2_dt(copy_dtype, t[0], t[1]), pack2_dt(copy_dtype, t[2], t[3]),
+                                                                               pack2_dt(copy_dtype, t[4], t[5]), pack2_dt(copy_dtype, t[6], t[7]));
         } else {
             *reinterpret_cast<float4 *>((float *)dx_copy + off) = make_float4(t[0], t[1], t[2], t[3]);
             *reinterpret_cast<float4 *>((float *)dx_copy + off + 4) = make_float4(t[4], t[5], t[6], t[7]);
@@ -234,13 +234,16 @@ extern "C" int ppt_layernorm_fwd(const float *x, const float *add, int add_rows,
                                  float eps, void *stream)
 {
     if (!x || !w || !b || !y || M <= 0 || D <= 0 || D > 64 * MAX_EPL) return PPT_EINVAL;
-    if (y_dtype != PPT_BF16 && y_dtype != PPT_F32) return PPT_EINVAL;
+    if (y_dtype != PPT_BF16 && y_dtype != PPT_F32 && y_dtype != PPT_F16) return PPT_EINVAL;
     const bool al = (((uintptr_t)x | (uintptr_t)w | (uintptr_t)b | (uintptr_t)y | (uintptr_t)add | (uintptr_t)xs) & 15) == 0;
     if ((D % 8) == 0 && D <= 512 && al) {
         dim3 vgrid(min((M + 3) / 4, 256 * 8));         // 8 workgroups per CU; each wave walks rows with that stride
         if (y_dtype == PPT_BF16)
             hipLaunchKernelGGL(ln_fwd_vec8_kernel<bf16_t>, vgrid, dim3(256), 0, ppt_stream(stream), x, add, add_rows, xs, w, b,
                                (bf16_t *)y, mean, rstd, M, D, eps, ppt_get_wave_priority());
+        else if (y_dtype == PPT_F16)
+            hipLaunchKernelGGL(ln_fwd_vec8_kernel<f16_t>, vgrid, dim3(256), 0, ppt_stream(stream), x, add, add_rows, xs, w, b,
+                               (f16_t *)y, mean, rstd, M, D, eps, ppt_get_wave_priority());
         else
             hipLaunchKernelGGL(ln_fwd_vec8_kernel<float>, vgrid, dim3(256), 0, ppt_stream(stream), x, add, add_rows, xs, w, b,
                                (float *)y, mean, rstd, M, D, eps, ppt_get_wave_priority());
@@ -251,6 +254,9 @@ extern "C" int ppt_layernorm_fwd(const float *x, const float *add, int add_rows,
     if (y_dtype == PPT_BF16)
         hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, dim3(256), 0, ppt_stream(stream), x, add, add_rows, xs, w, b,
                            (bf16_t *)y, mean, rstd, M, D, eps);
+    else if (y_dtype == PPT_F16)
+        hipLaunchKernelGGL(ln_fwd_kernel<f16_t>, grid, dim3(256), 0, ppt_stream(stream), x, add, add_rows, xs, w, b,
+                           (f16_t *)y, mean, rstd, M, D, eps);
     else if (y_dtype == PPT_F32)
         hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, dim3(256), 0, ppt_stream(stream), x, add, add_rows, xs, w, b,
                            (float *)y, mean, rstd, M, D, eps);

@@ -34,6 +34,17 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi)
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, ppt_bf16x2));
 }
 
+// ---- IEEE half (PPT_F16): raw bits in a type of its own so that kernels can be instantiated per 16-bit format -------------------
+struct f16_t { uint16_t b; };
+typedef _Float16 ppt_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float f16_to_f32(uint16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ uint16_t f32_to_f16(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }      // round-to-nearest-even
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi)                                                  // one v_cvt_pk_f16_f32
+{
+    const ppt_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, ppt_f16x2));
+}
+
 template <typename T> struct dt;
 template <> struct dt<float> {
     static __device__ __forceinline__ float load(const float *p) { return *p; }
@@ -45,6 +56,58 @@ template <> struct dt<bf16_t> {
     static __device__ __forceinline__ void store(bf16_t *p, float v) { *p = f32_to_bf16(v); }
     static constexpr int code = PPT_BF16;
 };
+
+template <> struct dt<f16_t> {
+    static __device__ __forceinline__ float load(const f16_t *p) { return f16_to_f32(p->b); }
+    static __device__ __forceinline__ void store(f16_t *p, float v) { p->b = f32_to_f16(v); }
+    static constexpr int code = PPT_F16;
+};
+
+// The two 16-bit operand formats behind one interface (T = bf16_t or f16_t): conversions of a packed pair and the MFMA forms.
+// Fragments travel as uint4 (8 values); the matrix instructions of both formats run at the same rate.
+typedef __attribute__((ext_vector_type(8))) __bf16 ppt_bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 ppt_f16x8;
+typedef __attribute__((ext_vector_type(16))) float ppt_f32x16;
+typedef __attribute__((ext_vector_type(4))) float ppt_f32x4;
+template <typename T> struct h16;
+template <> struct h16<bf16_t> {
+    static constexpr int code = PPT_BF16;
+    static __device__ __forceinline__ float lo(uint32_t w) { return __uint_as_float(w << 16); }
+    static __device__ __forceinline__ float hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+    static __device__ __forceinline__ uint32_t pack2(float a, float b) { return pack_bf16x2(a, b); }
+    static __device__ __forceinline__ float to_f32(uint16_t v) { return bf16_to_f32(v); }
+    static __device__ __forceinline__ uint16_t from_f32(float v) { return f32_to_bf16(v); }
+    static __device__ __forceinline__ ppt_f32x16 mfma32(uint4 a, uint4 b, ppt_f32x16 c)
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ppt_bf16x8, a), __builtin_bit_cast(ppt_bf16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ ppt_f32x4 mfma16(uint4 a, uint4 b, ppt_f32x4 c)
+    {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(ppt_bf16x8, a), __builtin_bit_cast(ppt_bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct h16<f16_t> {
+    static constexpr int code = PPT_F16;
+    static __device__ __forceinline__ float lo(uint32_t w) { return f16_to_f32((uint16_t)(w & 0xffffu)); }
+    static __device__ __forceinline__ float hi(uint32_t w) { return f16_to_f32((uint16_t)(w >> 16)); }
+    static __device__ __forceinline__ uint32_t pack2(float a, float b) { return pack_f16x2(a, b); }
+    static __device__ __forceinline__ float to_f32(uint16_t v) { return f16_to_f32(v); }
+    static __device__ __forceinline__ uint16_t from_f32(float v) { return f32_to_f16(v); }
+    static __device__ __forceinline__ ppt_f32x16 mfma32(uint4 a, uint4 b, ppt_f32x16 c)
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ppt_f16x8, a), __builtin_bit_cast(ppt_f16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ ppt_f32x4 mfma16(uint4 a, uint4 b, ppt_f32x4 c)
+    {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(ppt_f16x8, a), __builtin_bit_cast(ppt_f16x8, b), c, 0, 0, 0);
+    }
+};
+// run-time forms for code that carries a dtype code instead of a template parameter (code != PPT_F32)
+__device__ __forceinline__ uint32_t pack2_dt(int code, float a, float b) { return code == PPT_F16 ? pack_f16x2(a, b) : pack_bf16x2(a, b); }
+__device__ __forceinline__ float lo_dt(int code, uint32_t w) { return code == PPT_F16 ? h16<f16_t>::lo(w) : h16<bf16_t>::lo(w); }
+__device__ __forceinline__ float hi_dt(int code, uint32_t w) { return code == PPT_F16 ? h16<f16_t>::hi(w) : h16<bf16_t>::hi(w); }
+__device__ __forceinline__ uint16_t from_f32_dt(int code, float v) { return code == PPT_F16 ? f32_to_f16(v) : f32_to_bf16(v); }
+__device__ __forceinline__ float to_f32_dt(int code, uint16_t v) { return code == PPT_F16 ? f16_to_f32(v) : bf16_to_f32(v); }
 
 // ---- wave64 reductions over DPP (no LDS, no ds_bpermute) -----------------------------------
 // butterfly inside each row of 16 lanes, then row_bcast15 / row_bcast31 fold the four rows;

@@ -441,7 +441,7 @@ def _sa_level(sd, branches, wc, npoint, xyz, feats, start, train, upd, xyz_first
     c_out = [sd[cb + "2.weight"].shape[0] for _, _, cb, _ in branches]
     out = torch.empty((B * S, sum(c_out)), dtype=T, device=dev)
     col = 0
-    mult = 8 if T == torch.bfloat16 else 4
+    mult = 8 if T in ops.HALF else 4
     for i, (r, K, cb, bb) in enumerate(branches):
         if pre is not None:
             idx = gxyz = pre[1 + i]
@@ -524,7 +524,7 @@ def _pn2_tail(sd, p, wc, l2_xyz, l2, train, drop_masks, update_running):
     T = wc.dtype
     B = l2_xyz.shape[0]
     dev = l2_xyz.device
-    mult = 8 if T == torch.bfloat16 else 4
+    mult = 8 if T in ops.HALF else 4
     # sa3: group_all over the 128 remaining points, channels = [xyz | features] (pointnet2_utils.py:152-157)
     S2 = l2_xyz.shape[1]
     M = B * S2

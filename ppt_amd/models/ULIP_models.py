@@ -597,6 +597,7 @@ class ULIP_WITH_IMAGE(nn.Module):
         self.fused_prompt_rows = os.environ.get("PPT_FUSED_PROMPT_ROWS", "1") != "0"     # PromptLearner splice + pos add: one kernel
         # positions in front of the class name are the same in every prompt: computed once (PPT_SHARE_TEXT_PREFIX=0: A/B runs)
         self.share_text_prefix = os.environ.get("PPT_SHARE_TEXT_PREFIX", "1") != "0"
+        self.text_f16 = os.environ.get("PPT_TEXT_F16", "1") != "0"
         # bf16 mode: the text tower forward / backward as one persistent kernel each (csrc/text_tower.hip).  Off by default:
         # slower than the per-layer launches on every configuration measured (engine.TEXT_FUSED has the numbers)
         self.fused_text_tower = engine.TEXT_FUSED
@@ -648,7 +649,14 @@ class ULIP_WITH_IMAGE(nn.Module):
         return self
 
     def _cache(self):
-        want = getattr(self, "text_precision", None) or self.precision      # (text_precision: error-budget experiments, tools/bf16_error.py)
+        # The text tower's operand format in the performance mode is IEEE half, not bf16 (PPT_TEXT_F16=0: bf16): same MFMA rate,
+        # 11 significand bits instead of 8.  tools/bf16_error.py attributes 69 % of the bf16 mode's squared logits error and 89 %
+        # of its token-gradient error to the bf16 text tower -- almost all of it to the attention half of its layers, where the
+        # rounding of q and k is amplified by the softmax.  Its activations are LayerNorm outputs, projections of them and
+        # softmax weights (the residual stream is fp32), far inside fp16's range; gradients are O(1e-2 .. 1).
+        want = getattr(self, "text_precision", None)                        # (explicit override: error-budget experiments)
+        if want is None:
+            want = torch.float16 if (self.precision == torch.bfloat16 and self.text_f16) else self.precision
         if self._wc is None or self._wc.dtype != want:
             self._wc = engine.WeightCache(want)
         return self._wc

@@ -11,11 +11,12 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GELU, ACT_NONE, ACT_QUICKGELU, ACT_RELU, A_AFFINE_RELU, A_CONV1, A_PLAIN,
-                   PPT_BF16, PPT_F32, GemmParams, RowGemmParams)
+                   PPT_BF16, PPT_F16, PPT_F32, GemmParams, RowGemmParams)
 from . import _lib as _libmod  # noqa: F401
 
-_DT = {torch.float32: PPT_F32, torch.bfloat16: PPT_BF16}
-_TORCH_DT = {PPT_F32: torch.float32, PPT_BF16: torch.bfloat16}
+_DT = {torch.float32: PPT_F32, torch.bfloat16: PPT_BF16, torch.float16: PPT_F16}
+_TORCH_DT = {PPT_F32: torch.float32, PPT_BF16: torch.bfloat16, PPT_F16: torch.float16}
+HALF = (torch.bfloat16, torch.float16)        # the two 16-bit operand formats (same MFMA rate)
 
 
 class KernelProfiler:
@@ -233,8 +234,9 @@ def gemm(A, B, *, out=None, out_dtype=None, M=None, bias=None, act=ACT_NONE, dac
     p.batch, p.strideA, p.strideB, p.strideC = batch, strideA, strideB, strideC
     if profiler is not None:
         kk = K if algo_k is None else algo_k
-        profiler.begin("gemm_" + ("bf16" if p.dtype == PPT_BF16 else "f32"), 2.0 * M * N * kk * max(1, batch),
-                       "ppt_gemm " + ("bf16" if p.dtype == PPT_BF16 else "f32") + (" (A-prologue)" if a_mode != A_PLAIN else ""),
+        # ("bf16" names the 16-bit MFMA family of the roofline table: bf16 and fp16 operands run at the same rate)
+        profiler.begin("gemm_" + ("bf16" if p.dtype != PPT_F32 else "f32"), 2.0 * M * N * kk * max(1, batch),
+                       "ppt_gemm " + ({PPT_BF16: "bf16", PPT_F16: "f16"}.get(p.dtype, "f32")) + (" (A-prologue)" if a_mode != A_PLAIN else ""),
                        executed=2.0 * M * N * K * max(1, batch))
     _lib.check(_lib.lib().ppt_gemm(ctypes.byref(p), _stream()), "ppt_gemm")
     if profiler is not None:

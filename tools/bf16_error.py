@@ -44,6 +44,8 @@ def run(h, g, f32_stages):
     for st in f32_stages:
         if st == "text":
             m.text_precision = torch.float32
+        elif st == "text_bf16":
+            m.text_precision = torch.bfloat16
         else:
             engine.STAGE_DTYPE[st] = torch.float32
     m.train()
@@ -71,7 +73,7 @@ for h in heads:
     ref_logits = res["logits"]
     gkeys = ["prompt_learner.learnable_tokens"] + (["point_encoder.blocks.blocks.11.mlp.fc2.weight", "point_encoder.blocks.blocks.11.attn.qkv.weight"] if h >= 3 else [])
     rows = {}
-    configs = [("all bf16", ())] + [(f"{st} in fp32", (st,)) for st in STAGES + TEXT_PARTS] + [("all fp32", STAGES)]
+    configs = [("all bf16", ("text_bf16",)), ("default (text f16)", ())] + [(f"{st} in fp32", (st,)) for st in STAGES + TEXT_PARTS] + [("all fp32", STAGES)]
     for name, f32 in configs:
         loss, lg, grads = run(h, g, f32)
         e = (lg - ref_logits)
