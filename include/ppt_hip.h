@@ -196,6 +196,7 @@ typedef struct ppt_rowgemm_params {
     int row_scale_rows;
     int walkers;
     int groups;                      /* set by the library (column groups of the launch); callers leave it 0 */
+    int dtype;                       /* PPT_BF16 (also 0) or PPT_F16: the 16-bit format of A (or of the LayerNorm output), W, C, C2 */
 } ppt_rowgemm_params;
 
 int ppt_rowgemm_bf16(const ppt_rowgemm_params *p, void *stream);
@@ -226,6 +227,7 @@ typedef struct ppt_vit_mlp_params {
     int M, D, hidden;
     int workgroups;
     int n_chunks, rows_per_chunk;
+    int dtype;                       /* PPT_BF16 (also 0) or PPT_F16: the 16-bit format of W1 / W2 and of the in-kernel operands */
 } ppt_vit_mlp_params;
 
 /* ---- the CLIP text tower under PromptLearner as ONE persistent kernel per direction (csrc/text_tower.hip) ------------------
@@ -446,6 +448,9 @@ int ppt_bn_res_act_rows(const void *x, int x_dtype, const void *res, int res_dty
  * Needs M % (32 * n_slices) == 0 and N1, N2, lda, ldb multiples of 8. */
 int ppt_gemm_tn_bf16(const void *A, int64_t lda, const void *B, int64_t ldb, int64_t M, int N1, int N2, int n_slices, float *part,
                      void *stream);
+/* the same kernel for operands of either 16-bit format: dtype = PPT_BF16 or PPT_F16 */
+int ppt_gemm_tn_half(const void *A, int64_t lda, const void *B, int64_t ldb, int64_t M, int N1, int N2, int n_slices, float *part,
+                     int dtype, void *stream);
 
 /* nn.CrossEntropyLoss(label_smoothing, reduction='mean') over R rows of C <= 96 classes and its gradient (main_partseg.py:213;
  * main_cls.py:52,196).  A label outside [0, C) (ignore_index = -100) is an ignored row, as in ATen: no loss, zero gradient, not

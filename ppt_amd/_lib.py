@@ -39,7 +39,7 @@ class VitMlpParams(ctypes.Structure):
         ("x", c_void_p), ("out", c_void_p), ("W1", c_void_p), ("W2", c_void_p), ("ln_w", c_void_p), ("ln_b", c_void_p),
         ("ln_eps", c_float), ("b1", c_void_p), ("b2", c_void_p), ("row_scale", c_void_p), ("row_scale_rows", c_int),
         ("residual2", c_void_p), ("M", c_int), ("D", c_int), ("hidden", c_int), ("workgroups", c_int), ("n_chunks", c_int),
-        ("rows_per_chunk", c_int),
+        ("rows_per_chunk", c_int), ("dtype", c_int),
     ]
 
 
@@ -68,7 +68,7 @@ class RowGemmParams(ctypes.Structure):
         ("A", c_void_p), ("W", c_void_p), ("C", c_void_p), ("C2", c_void_p), ("M", c_int), ("N", c_int), ("K", c_int),
         ("a_ln", c_int), ("ln_w", c_void_p), ("ln_b", c_void_p), ("ln_eps", c_float), ("ln_mean", c_void_p), ("ln_rstd", c_void_p), ("bias", c_void_p), ("act", c_int),
         ("residual_form", c_int), ("residual", c_void_p), ("residual2", c_void_p), ("row_scale", c_void_p),
-        ("row_scale_rows", c_int), ("walkers", c_int), ("groups", c_int),
+        ("row_scale_rows", c_int), ("walkers", c_int), ("groups", c_int), ("dtype", c_int),
     ]
 
 
@@ -154,6 +154,7 @@ _SIGNATURES = {
     "ppt_bn_res_act_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int, c_void_p]),
     "ppt_gemm_tn_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ppt_gemm_tn_half": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "ppt_head_logits": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ppt_head_ce_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p, c_void_p,
                                 c_void_p]),

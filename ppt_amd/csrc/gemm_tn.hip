@@ -9,7 +9,6 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) short s4_t;
 
@@ -18,17 +17,17 @@ constexpr int TN_IMG = TN_KS * 128;      // one LDS image: 32 rows x 64 bf16 col
 
 __device__ __forceinline__ int tn_off(int row, int dbyte) { return row * 128 + (dbyte ^ (((row >> 1) & 1) << 6)); }
 
-__device__ __forceinline__ bf16x8_t tn_frag(const unsigned char *img, int row0, int dbyte)
+__device__ __forceinline__ uint4 tn_frag(const unsigned char *img, int row0, int dbyte)
 {
     struct { s4_t a, b; } f;
     f.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t *)(img + tn_off(row0, dbyte)));
     f.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4_t *)(img + tn_off(row0 + 8, dbyte)));
-    return __builtin_bit_cast(bf16x8_t, f);
+    return __builtin_bit_cast(uint4, f);
 }
 
 // 2 x 2 waves, each TI x TJ MFMA tiles of 32 x 32: the workgroup owns 64 TI x 64 TJ outputs.  Operand columns are kept in
 // TI (TJ) images of 64 columns so that every transposed read sees the 128-byte rows the swizzle was made for.
-template <int TI, int TJ>
+template <typename F, int TI, int TJ>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t *__restrict__ A, int64_t lda, const bf16_t *__restrict__ B,
                                                          int64_t ldb, int N1, int N2, int rows_per_slice,
                                                          float *__restrict__ part)
@@ -95,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t *__restric
         const unsigned char *At = smem + cur * STAGE + a_img * TN_IMG, *Bt = smem + cur * STAGE + b_img * TN_IMG;
 #pragma unroll
         for (int k = 0; k < TN_KS / 16; ++k) {
-            bf16x8_t af[TI], bf[TJ];
+            uint4 af[TI], bf[TJ];
 #pragma unroll
             for (int i = 0; i < TI; ++i) af[i] = tn_frag(At, 16 * k + tr_row, tr_dbyte + a_db + 64 * i);
 #pragma unroll
@@ -103,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t *__restric
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TJ; ++j) acc[i][j] = h16<F>::mfma32(af[i], bf[j], acc[i][j]);
         }
         TN_STORE(cur ^ 1);
         __syncthreads();
@@ -125,8 +124,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const bf16_t *__restric
 
 }  // namespace
 
-extern "C" int ppt_gemm_tn_bf16(const void *A, int64_t lda, const void *B, int64_t ldb, int64_t M, int N1, int N2, int n_slices,
-                                float *part, void *stream)
+static int gemm_tn_any(const void *A, int64_t lda, const void *B, int64_t ldb, int64_t M, int N1, int N2, int n_slices,
+                       float *part, int dtype, void *stream)
 {
     if (!A || !B || !part || M <= 0 || N1 <= 0 || N2 <= 0 || n_slices <= 0) return PPT_EINVAL;
     if ((N1 % 8) || (N2 % 8) || (lda % 8) || (ldb % 8) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return PPT_EINVAL;
@@ -135,12 +134,31 @@ extern "C" int ppt_gemm_tn_bf16(const void *A, int64_t lda, const void *B, int64
     // 128 x 128 tiles when they (times the slices) fill the chip, 64 x 64 otherwise
     const int64_t big = (int64_t)((N1 + 127) / 128) * ((N2 + 127) / 128) * n_slices;
     if (n_slices > 65535 || (N1 + 63) / 64 > 65535) return PPT_EUNSUPPORTED;
-    if (big >= 256)
-        hipLaunchKernelGGL((gemm_tn_kernel<2, 2>), dim3((N2 + 127) / 128, (N1 + 127) / 128, n_slices), dim3(256), 0,
-                           ppt_stream(stream), (const bf16_t *)A, lda, (const bf16_t *)B, ldb, N1, N2, rows, part);
-    else
-        hipLaunchKernelGGL((gemm_tn_kernel<1, 1>), dim3((N2 + 63) / 64, (N1 + 63) / 64, n_slices), dim3(256), 0,
-                           ppt_stream(stream), (const bf16_t *)A, lda, (const bf16_t *)B, ldb, N1, N2, rows, part);
+#define PPT_TN(FF)                                                                                                                     \
+    do {                                                                                                                               \
+        if (big >= 256)                                                                                                                \
+            hipLaunchKernelGGL((gemm_tn_kernel<FF, 2, 2>), dim3((N2 + 127) / 128, (N1 + 127) / 128, n_slices), dim3(256), 0,            \
+                               ppt_stream(stream), (const bf16_t *)A, lda, (const bf16_t *)B, ldb, N1, N2, rows, part);                  \
+        else                                                                                                                           \
+            hipLaunchKernelGGL((gemm_tn_kernel<FF, 1, 1>), dim3((N2 + 63) / 64, (N1 + 63) / 64, n_slices), dim3(256), 0,                \
+                               ppt_stream(stream), (const bf16_t *)A, lda, (const bf16_t *)B, ldb, N1, N2, rows, part);                  \
+    } while (0)
+    if (dtype == PPT_F16) PPT_TN(f16_t); else PPT_TN(bf16_t);
+#undef PPT_TN
     PPT_CHECK_LAUNCH();
     return PPT_OK;
+}
+
+extern "C" int ppt_gemm_tn_bf16(const void *A, int64_t lda, const void *B, int64_t ldb, int64_t M, int N1, int N2, int n_slices,
+                                float *part, void *stream)
+{
+    return gemm_tn_any(A, lda, B, ldb, M, N1, N2, n_slices, part, PPT_BF16, stream);
+}
+
+/* the same for operands of either 16-bit format (dtype = PPT_BF16 or PPT_F16) */
+extern "C" int ppt_gemm_tn_half(const void *A, int64_t lda, const void *B, int64_t ldb, int64_t M, int N1, int N2, int n_slices,
+                                float *part, int dtype, void *stream)
+{
+    if (dtype != PPT_BF16 && dtype != PPT_F16) return PPT_EINVAL;
+    return gemm_tn_any(A, lda, B, ldb, M, N1, N2, n_slices, part, dtype, stream);
 }

@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256) void col_sums_kernel(const TX *__restrict__ x,
 // bf16, D % 8 == 0: a workgroup owns 256 rows x 128 columns as 16 row groups x 16 column octets (16-byte loads, 256-byte row
 // pieces), fp32 sums, the 16 group sums folded through LDS in a fixed order.  (The one-thread-per-column walk: 64 us for a
 // 32768 x 256 bias gradient, 0.26 TB/s; 7 per part-seg step.)
+template <typename F>
 __global__ __launch_bounds__(256) void col_sums_vec8_bf16_kernel(const bf16_t *__restrict__ x, int M, int D, int64_t ldx,
                                                                  float *__restrict__ part)
 {
@@ -107,8 +108,8 @@ __global__ __launch_bounds__(256) void col_sums_vec8_bf16_kernel(const bf16_t *_
                 const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    s[2 * j] += __uint_as_float(wv[j] << 16);
-                    s[2 * j + 1] += __uint_as_float(wv[j] & 0xffff0000u);
+                    s[2 * j] += h16<F>::lo(wv[j]);
+                    s[2 * j + 1] += h16<F>::hi(wv[j]);
                 }
             }
         }
@@ -259,7 +260,10 @@ extern "C" int ppt_col_sums(const void *x, int x_dtype, int M, int D, int64_t ld
     else if (x_dtype == PPT_F32)
         hipLaunchKernelGGL(col_sums_kernel<float>, grid, dim3(256), 0, ppt_stream(stream), (const float *)x, M, D, ldx, partial);
     else if (x_dtype == PPT_BF16 && D % 8 == 0 && ldx % 8 == 0 && !((uintptr_t)x & 15))
-        hipLaunchKernelGGL(col_sums_vec8_bf16_kernel, dim3((D + 127) / 128, (M + 255) / 256), dim3(256), 0, ppt_stream(stream),
+        hipLaunchKernelGGL(col_sums_vec8_bf16_kernel<bf16_t>, dim3((D + 127) / 128, (M + 255) / 256), dim3(256), 0, ppt_stream(stream),
+                           (const bf16_t *)x, M, D, ldx, partial);
+    else if (x_dtype == PPT_F16 && D % 8 == 0 && ldx % 8 == 0 && !((uintptr_t)x & 15))
+        hipLaunchKernelGGL(col_sums_vec8_bf16_kernel<f16_t>, dim3((D + 127) / 128, (M + 255) / 256), dim3(256), 0, ppt_stream(stream),
                            (const bf16_t *)x, M, D, ldx, partial);
     else if (x_dtype == PPT_BF16)
         hipLaunchKernelGGL(col_sums_kernel<bf16_t>, grid, dim3(256), 0, ppt_stream(stream), (const bf16_t *)x, M, D, ldx, partial);

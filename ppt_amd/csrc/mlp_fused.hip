@@ -23,7 +23,6 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 constexpr int D = 384, HID = 1536, HC = 128, NJ = HID / HC;       // model dims, hidden slab
@@ -49,6 +48,7 @@ __device__ __forceinline__ float row16_sum(float v)
 #define MLP_STAMP(j, slot) do { } while (0)
 #endif
 
+template <typename F>
 __global__ __launch_bounds__(512, 2) void vit_mlp_kernel(const ppt_vit_mlp_params p)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -67,10 +67,10 @@ __global__ __launch_bounds__(512, 2) void vit_mlp_kernel(const ppt_vit_mlp_param
     // fragment is sixteen 64-byte row pieces (half lines): measured 14 B/clk/CU out of L2 instead of ~30 (in-kernel stamps:
     // 14 300 cycles per slab for 196 KB against 9 300 in fragment order).
     auto frag = [&](const bf16_t *Wt, int j, int f) {
-        return *reinterpret_cast<const bf16x8_t *>(Wt + ((size_t)((j * 8 + w) * 12 + f) * 64 + lane) * 8);
+        return *reinterpret_cast<const uint4 *>(Wt + ((size_t)((j * 8 + w) * 12 + f) * 64 + lane) * 8);
     };
     // this wave's weight fragments: B1 = W1 rows (hidden units) 16 w .. + 15 of the slab, B2 = W2 rows (outputs) 48 w .. + 47
-    bf16x8_t b1f[D / 32], b2f[3][HC / 32];
+    uint4 b1f[D / 32], b2f[3][HC / 32];
     auto load_b1 = [&](int j) {
 #pragma unroll
         for (int s = 0; s < D / 32; ++s) b1f[s] = frag(W1, j, s);
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(512, 2) void vit_mlp_kernel(const ppt_vit_mlp_param
                             const float4 g = *reinterpret_cast<const float4 *>(gam + cc), b = *reinterpret_cast<const float4 *>(bet + cc);
                             const float o0 = (xf[i].x - mean) * rstd * g.x + b.x, o1 = (xf[i].y - mean) * rstd * g.y + b.y;
                             const float o2 = (xf[i].z - mean) * rstd * g.z + b.z, o3 = (xf[i].w - mean) * rstd * g.w + b.w;
-                            *reinterpret_cast<uint2 *>(dst + 2 * cc) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+                            *reinterpret_cast<uint2 *>(dst + 2 * cc) = make_uint2(h16<F>::pack2(o0, o1), h16<F>::pack2(o2, o3));
                         }
                     } else {
                         // (row16_sum needs the whole DPP row: rows are per 16 lanes, so a missing row skips it as a unit)
@@ -147,8 +147,8 @@ __global__ __launch_bounds__(512, 2) void vit_mlp_kernel(const ppt_vit_mlp_param
                 if (jb >= 0) b2f[s / 4][s % 4] = frag(W2, jb, s);       // 12 k-steps <-> the 12 fragments of B2: (nb, ks) = (s / 4, s % 4)
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) {
-                    const bf16x8_t f = *reinterpret_cast<const bf16x8_t *>(ha + rb * 16 * HP + 64 * s);
-                    a1[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1f[s], f, a1[rb], 0, 0, 0);
+                    const uint4 f = *reinterpret_cast<const uint4 *>(ha + rb * 16 * HP + 64 * s);
+                    a1[rb] = h16<F>::mfma16(b1f[s], f, a1[rb]);
                 }
             }
             MLP_STAMP(j - 1, 4);                                         // (diagnostic build: end of the MFMA loop, start of the GELU)
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(512, 2) void vit_mlp_kernel(const ppt_vit_mlp_param
                 float v[4] = {a1[rb][0] + bv.x, a1[rb][1] + bv.y, a1[rb][2] + bv.z, a1[rb][3] + bv.w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = gelu_poly(v[i]);
-                *reinterpret_cast<uint2 *>(ud + rb * 16 * UP) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                *reinterpret_cast<uint2 *>(ud + rb * 16 * UP) = make_uint2(h16<F>::pack2(v[0], v[1]), h16<F>::pack2(v[2], v[3]));
             }
         };
         auto gemm2 = [&](int j, int jb) {                               // acc2 += slab j . W2[:, slab]^T
@@ -170,9 +170,9 @@ __global__ __launch_bounds__(512, 2) void vit_mlp_kernel(const ppt_vit_mlp_param
                 for (int rb = 0; rb < RB; ++rb) {
                     // 4 x 5 MFMA groups <-> the 12 fragments of B1 (the first three row blocks of every k-step carry one)
                     if (jb >= 0 && rb < 3) b1f[3 * s + rb] = frag(W1, jb, 3 * s + rb);
-                    const bf16x8_t f = *reinterpret_cast<const bf16x8_t *>(ua + rb * 16 * UP + 64 * s);
+                    const uint4 f = *reinterpret_cast<const uint4 *>(ua + rb * 16 * UP + 64 * s);
 #pragma unroll
-                    for (int nb = 0; nb < 3; ++nb) acc2[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2f[nb][s], f, acc2[rb][nb], 0, 0, 0);
+                    for (int nb = 0; nb < 3; ++nb) acc2[rb][nb] = h16<F>::mfma16(b2f[nb][s], f, acc2[rb][nb]);
                 }
         };
 
@@ -268,12 +268,14 @@ extern "C" int ppt_vit_mlp_bf16(const ppt_vit_mlp_params *pp, void *stream)
     ppt_vit_mlp_params p = *pp;
     if (!p.x || !p.out || !p.W1 || !p.W2 || !p.ln_w || !p.ln_b || p.M <= 0) return PPT_EINVAL;
     if (p.D != D || p.hidden != HID) return PPT_EUNSUPPORTED;
+    if (p.dtype != PPT_BF16 && p.dtype != PPT_F16 && p.dtype != 0) return PPT_EINVAL;          // (0: callers of ABI 2 -- bf16)
     if (p.row_scale && p.row_scale_rows <= 0) return PPT_EINVAL;
     if (((uintptr_t)p.x | (uintptr_t)p.out | (uintptr_t)p.W1 | (uintptr_t)p.W2 | (uintptr_t)p.residual2) & 15) return PPT_EINVAL;
     static const int cus = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        (void)hipFuncSetAttribute((const void *)vit_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)vit_mlp_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)vit_mlp_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         return n > 0 ? n : 256;
     }();
     // chunks of at most R rows, a whole number of rounds over the CUs, every chunk as full as the division allows
@@ -287,7 +289,8 @@ extern "C" int ppt_vit_mlp_bf16(const ppt_vit_mlp_params *pp, void *stream)
     p.rows_per_chunk = (p.M + p.n_chunks - 1) / p.n_chunks;
     p.n_chunks = (p.M + p.rows_per_chunk - 1) / p.rows_per_chunk;
     const int grid = p.n_chunks < wgs ? p.n_chunks : wgs;
-    hipLaunchKernelGGL(vit_mlp_kernel, dim3(grid), dim3(512), LDS_BYTES, ppt_stream(stream), p);
+    if (p.dtype == PPT_F16) hipLaunchKernelGGL(vit_mlp_kernel<f16_t>, dim3(grid), dim3(512), LDS_BYTES, ppt_stream(stream), p);
+    else hipLaunchKernelGGL(vit_mlp_kernel<bf16_t>, dim3(grid), dim3(512), LDS_BYTES, ppt_stream(stream), p);
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }

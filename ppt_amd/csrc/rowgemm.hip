@@ -28,7 +28,6 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 template <int K> struct RG {
@@ -69,7 +68,7 @@ enum { EPI_BF16 = 0, EPI_RESIDUAL = 1 };
 #endif
 constexpr bool STAGGER = PPT_ROWGEMM_STAGGER != 0;
 
-template <int K, bool LN, int EPI, int ACT>
+template <typename F, int K, bool LN, int EPI, int ACT>
 __global__ __launch_bounds__(512, 2) void rowgemm_kernel(const ppt_rowgemm_params p)
 {
     using G = RG<K>;
@@ -135,7 +134,7 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(const ppt_rowgemm_param
                 const float4 g = *reinterpret_cast<const float4 *>(gam + c), b = *reinterpret_cast<const float4 *>(bet + c);
                 const float o0 = (xf[i].x - mean) * rstd * g.x + b.x, o1 = (xf[i].y - mean) * rstd * g.y + b.y;
                 const float o2 = (xf[i].z - mean) * rstd * g.z + b.z, o3 = (xf[i].w - mean) * rstd * g.w + b.w;
-                *reinterpret_cast<uint2 *>(dst + 2 * c) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+                *reinterpret_cast<uint2 *>(dst + 2 * c) = make_uint2(h16<F>::pack2(o0, o1), h16<F>::pack2(o2, o3));
             }
         } else {
             *reinterpret_cast<uint4 *>(dst + 16 * j) = xb0;
@@ -149,14 +148,14 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(const ppt_rowgemm_param
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- the stationary operand: W[n0 + 16 nb + l15][32 s + 8 kg .. + 8)
-    bf16x8_t wf[G::NCB][G::KS];
+    uint4 wf[G::NCB][G::KS];
     const bf16_t *W = (const bf16_t *)p.W;
 #pragma unroll
     for (int nb = 0; nb < G::NCB; ++nb) {
         const int n = min(n0 + 16 * nb + l15, p.N - 1);
 #pragma unroll
         for (int s = 0; s < G::KS; ++s)
-            wf[nb][s] = *reinterpret_cast<const bf16x8_t *>(W + (size_t)n * K + 32 * s + 8 * kg);
+            wf[nb][s] = *reinterpret_cast<const uint4 *>(W + (size_t)n * K + 32 * s + 8 * kg);
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (LN) {
@@ -196,12 +195,12 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(const ppt_rowgemm_param
             for (int nb = 0; nb < G::NCB; ++nb) acc[rb][nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < G::KS; ++s) {
-            const bf16x8_t f0 = *reinterpret_cast<const bf16x8_t *>(a0 + 64 * s);
-            const bf16x8_t f1 = *reinterpret_cast<const bf16x8_t *>(a1 + 64 * s);
+            const uint4 f0 = *reinterpret_cast<const uint4 *>(a0 + 64 * s);
+            const uint4 f1 = *reinterpret_cast<const uint4 *>(a1 + 64 * s);
 #pragma unroll
             for (int nb = 0; nb < G::NCB; ++nb) {
-                acc[0][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][s], f0, acc[0][nb], 0, 0, 0);
-                acc[1][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][s], f1, acc[1][nb], 0, 0, 0);
+                acc[0][nb] = h16<F>::mfma16(wf[nb][s], f0, acc[0][nb]);
+                acc[1][nb] = h16<F>::mfma16(wf[nb][s], f1, acc[1][nb]);
             }
         }
     };
@@ -236,7 +235,7 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(const ppt_rowgemm_param
                 } else {
                     if constexpr (ACT != PPT_ACT_NONE) {
                         if (p.C2 && m < p.M && n < p.N)    // (the saved pre-activation: rare, stays on the direct path)
-                            *reinterpret_cast<uint2 *>((bf16_t *)p.C2 + o) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                            *reinterpret_cast<uint2 *>((bf16_t *)p.C2 + o) = make_uint2(h16<F>::pack2(v[0], v[1]), h16<F>::pack2(v[2], v[3]));
                     }
                     if constexpr (ACT == PPT_ACT_GELU) {
 #pragma unroll
@@ -246,7 +245,7 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(const ppt_rowgemm_param
                         for (int i = 0; i < 4; ++i) v[i] = v[i] / (1.0f + __expf(-1.702f * v[i]));
                     }
                     *reinterpret_cast<uint2 *>(cbuf + cslot * G::CBUF + (16 * rb + l15) * G::CPITCH + (w * G::NW + 16 * nb + 4 * kg) * 2) =
-                        make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                        make_uint2(h16<F>::pack2(v[0], v[1]), h16<F>::pack2(v[2], v[3]));
                 }
             }
         }
@@ -321,12 +320,12 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(const ppt_rowgemm_param
     if (t_prev >= 0) store_tile(t_prev, (it - 1) & 1);
 }
 
-template <int K, bool LN, int EPI, int ACT>
+template <typename F, int K, bool LN, int EPI, int ACT>
 int launch(const ppt_rowgemm_params &p, hipStream_t s, int cus)
 {
     using G = RG<K>;
     static const int once = [] {
-        (void)hipFuncSetAttribute((const void *)rowgemm_kernel<K, LN, EPI, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+        (void)hipFuncSetAttribute((const void *)rowgemm_kernel<F, K, LN, EPI, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
         return 0;
     }();
     (void)once;
@@ -339,7 +338,7 @@ int launch(const ppt_rowgemm_params &p, hipStream_t s, int cus)
     walkers = (walkers + 7) / 8 * 8;
     if (walkers * q.groups > cus && walkers > 8 && p.walkers <= 0) walkers -= 8;
     q.walkers = walkers;
-    hipLaunchKernelGGL((rowgemm_kernel<K, LN, EPI, ACT>), dim3(walkers * q.groups), dim3(512), G::LDS, s, q);
+    hipLaunchKernelGGL((rowgemm_kernel<F, K, LN, EPI, ACT>), dim3(walkers * q.groups), dim3(512), G::LDS, s, q);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PPT_OK : PPT_ELAUNCH;
 }
@@ -352,6 +351,7 @@ extern "C" int ppt_rowgemm_bf16(const ppt_rowgemm_params *pp, void *stream)
     const ppt_rowgemm_params &p = *pp;
     if (!p.A || !p.W || !p.C || p.M <= 0 || p.N <= 0) return PPT_EINVAL;
     if (p.K != 384 && p.K != 512) return PPT_EUNSUPPORTED;
+    if (p.dtype != 0 && p.dtype != PPT_BF16 && p.dtype != PPT_F16) return PPT_EINVAL;          /* (0: ABI-2 callers, bf16) */
     if (p.N % (p.residual_form ? 4 : 8)) return PPT_EUNSUPPORTED;
     if (p.a_ln && (!p.ln_w || !p.ln_b)) return PPT_EINVAL;
     if ((p.ln_mean == nullptr) != (p.ln_rstd == nullptr)) return PPT_EINVAL;
@@ -369,13 +369,14 @@ extern "C" int ppt_rowgemm_bf16(const ppt_rowgemm_params *pp, void *stream)
         return n > 0 ? n : 256;
     }();
     hipStream_t s = ppt_stream(stream);
-#define PPT_RG_ACT(KK, LNV)                                                                                        \
-    (p.act == PPT_ACT_GELU ? launch<KK, LNV, EPI_BF16, PPT_ACT_GELU>(p, s, cus)                                      \
-     : p.act == PPT_ACT_QUICKGELU ? launch<KK, LNV, EPI_BF16, PPT_ACT_QUICKGELU>(p, s, cus)                          \
-                                  : launch<KK, LNV, EPI_BF16, PPT_ACT_NONE>(p, s, cus))
-#define PPT_RG(KK)                                                                                                 \
-    (p.a_ln ? PPT_RG_ACT(KK, true) : (p.residual_form ? launch<KK, false, EPI_RESIDUAL, PPT_ACT_NONE>(p, s, cus) : PPT_RG_ACT(KK, false)))
-    return p.K == 384 ? PPT_RG(384) : PPT_RG(512);
+#define PPT_RG_ACT(FF, KK, LNV)                                                                                        \
+    (p.act == PPT_ACT_GELU ? launch<FF, KK, LNV, EPI_BF16, PPT_ACT_GELU>(p, s, cus)                                      \
+     : p.act == PPT_ACT_QUICKGELU ? launch<FF, KK, LNV, EPI_BF16, PPT_ACT_QUICKGELU>(p, s, cus)                          \
+                                  : launch<FF, KK, LNV, EPI_BF16, PPT_ACT_NONE>(p, s, cus))
+#define PPT_RG(FF, KK)                                                                                               \
+    (p.a_ln ? PPT_RG_ACT(FF, KK, true) : (p.residual_form ? launch<FF, KK, false, EPI_RESIDUAL, PPT_ACT_NONE>(p, s, cus) : PPT_RG_ACT(FF, KK, false)))
+    if (p.dtype == PPT_F16) return p.K == 384 ? PPT_RG(f16_t, 384) : PPT_RG(f16_t, 512);
+    return p.K == 384 ? PPT_RG(bf16_t, 384) : PPT_RG(bf16_t, 512);
 #undef PPT_RG_ACT
 #undef PPT_RG
 }

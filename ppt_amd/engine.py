@@ -75,9 +75,18 @@ class WeightCache:
 STAGE_DTYPE = {}
 
 
+# The transformer blocks' operand format in the performance mode is IEEE half (PPT_BLOCKS_F16=0: bf16, as the tokenizer keeps):
+# the same MFMA rate with 11 significand bits instead of 8.  Their activations are LayerNorm outputs, projections of them,
+# softmax weights and GELU outputs (the residual stream is fp32) -- far inside fp16's range -- and tools/bf16_error.py puts what
+# is left of the logits / gradient error after the text tower moved to fp16 (ULIP_WITH_IMAGE._cache) in blocks 0-10.
+BLOCKS_F16 = os.environ.get("PPT_BLOCKS_F16", "1") != "0"
+
+
 def _stage_wc(wc, stage):
-    """The WeightCache a stage runs with: `wc`, or a sibling of the overridden precision (kept on `wc`)."""
+    """The WeightCache a stage runs with: `wc`, or a sibling of another operand precision (kept on `wc`)."""
     dt = STAGE_DTYPE.get(stage)
+    if dt is None and BLOCKS_F16 and wc.dtype == torch.bfloat16 and stage in ("blocks", "last_block"):
+        dt = torch.float16
     if dt is None or dt == wc.dtype:
         return wc
     alts = wc.__dict__.setdefault("_alts", {})
@@ -187,7 +196,7 @@ def vit_block_forward(sd, p, wc, x, pos, B, Tn, heads, dp1, dp2, save=None, pos_
     neither reads pos nor rewrites the residual stream; the sums are formed in the same order either way."""
     T = wc.dtype
     keep = save is not None
-    if x.shape[0] >= ROWGEMM_MIN_ROWS and T == torch.bfloat16 and not keep and x.shape[1] in ops.ROWGEMM_K:
+    if x.shape[0] >= ROWGEMM_MIN_ROWS and T in ops.HALF and not keep and x.shape[1] in ops.ROWGEMM_K:
         # frozen block, nothing kept: the K = 384 linears with the weight stationary in registers (csrc/rowgemm.hip); both
         # LayerNorms are applied while the rows are staged, the residual stream is updated in place
         if pos_in_x:
@@ -223,7 +232,7 @@ def vit_block_forward(sd, p, wc, x, pos, B, Tn, heads, dp1, dp2, save=None, pos_
     x_mid = torch.empty_like(x) if keep else xs
     ops.gemm(a, wc.get(sd[p + "attn.proj.weight"]), out=x_mid, bias=sd[p + "attn.proj.bias"], row_scale=dp1,
              row_scale_rows=Tn, residual=xs)
-    if (FUSED_MLP and not keep and T == torch.bfloat16 and x.shape[1] == 384 and sd[p + "mlp.fc1.weight"].shape[0] == 1536
+    if (FUSED_MLP and not keep and T in ops.HALF and x.shape[1] == 384 and sd[p + "mlp.fc1.weight"].shape[0] == 1536
             and x_mid.is_contiguous()):
         # frozen block: LayerNorm + fc1 + GELU + fc2 + DropPath + residual (+ the next block's "+ pos") in one kernel
         w1t, w2t = _mlp_weights(sd, p, wc)
@@ -762,7 +771,7 @@ def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=No
         rows = torch.arange(C, device=dev) * L + eot_pos            # EOT pooling (ULIP_models.py:222)
     saved = {"layers": []} if save else None
     x = xin if add is None else torch.empty((M, Wd), dtype=torch.float32, device=dev)
-    fuse = TEXT_FUSE_LN and T == torch.bfloat16 and Wd in ops.ROWGEMM_K
+    fuse = TEXT_FUSE_LN and T in ops.HALF and Wd in ops.ROWGEMM_K
     # (diagnostics, tools/bf16_error.py: the attention half and the MLP half of every layer may run at another operand precision;
     # both start from and end in the fp32 residual stream)
     wca, wcm = _stage_wc(wc, "text_attn"), _stage_wc(wc, "text_mlp")

@@ -310,7 +310,8 @@ def rows_matmul(a, w_kn):
 
 def vit_mlp_retile(w1, w2):
     """(w1 [1536,384], w2 [384,1536]) bf16 -> the fragment-ordered copies ppt_vit_mlp_bf16 reads (ppt_vit_mlp_retile)."""
-    _chk(w1, torch.bfloat16, "w1"); _chk(w2, torch.bfloat16, "w2")
+    assert w1.dtype in HALF and w2.dtype == w1.dtype
+    _chk(w1, w1.dtype, "w1"); _chk(w2, w1.dtype, "w2")
     assert tuple(w1.shape) == (1536, 384) and tuple(w2.shape) == (384, 1536)
     w1t, w2t = torch.empty_like(w1), torch.empty_like(w2)
     _lib.check(_lib.lib().ppt_vit_mlp_retile(_p(w1), _p(w2), _p(w1t), _p(w2t), _stream()), "ppt_vit_mlp_retile")
@@ -320,10 +321,12 @@ def vit_mlp_retile(w1, w2):
 def vit_mlp(x, w1, b1, w2, b2, ln, *, out=None, ln_eps=1e-5, row_scale=None, row_scale_rows=0, residual2=None, workgroups=0):
     """ppt_vit_mlp_bf16 (csrc/mlp_fused.hip): out = x + row_scale * (GELU(LN(x) w1^T + b1) w2^T + b2) (+ residual2), x [M,384]
     f32, w1 / w2: the fragment-ordered bf16 weights of vit_mlp_retile; out defaults to x (in place)."""
-    _chk(x, torch.float32, "x"); _chk(w1, torch.bfloat16, "w1"); _chk(w2, torch.bfloat16, "w2")
+    assert w1.dtype in HALF and w2.dtype == w1.dtype
+    _chk(x, torch.float32, "x"); _chk(w1, w1.dtype, "w1"); _chk(w2, w1.dtype, "w2")
     M, D = x.shape
     out = x if out is None else out
     p = _lib.VitMlpParams()
+    p.dtype = dtype_code(w1)
     p.x, p.out, p.W1, p.W2, p.ln_w, p.ln_b, p.ln_eps = _p(x), _p(out), _p(w1), _p(w2), _p(ln[0]), _p(ln[1]), ln_eps
     p.b1, p.b2, p.row_scale, p.row_scale_rows, p.residual2 = _p(b1), _p(b2), _p(row_scale), row_scale_rows, _p(residual2)
     p.M, p.D, p.hidden, p.workgroups = M, D, w1.shape[0], workgroups
@@ -346,10 +349,12 @@ def rowgemm(A, W, *, ln=None, ln_eps=1e-5, ln_stats=None, bias=None, act=ACT_NON
     residual itself); else out (bf16) = act(acc + bias) and out2 (bf16, optional) receives the pre-activation."""
     M, K = A.shape
     N = W.shape[0]
-    assert W.shape[1] == K and W.dtype == torch.bfloat16 and W.is_contiguous() and A.is_contiguous()
-    assert A.dtype == (torch.float32 if ln is not None else torch.bfloat16)
+    T = W.dtype
+    assert W.shape[1] == K and T in HALF and W.is_contiguous() and A.is_contiguous()
+    assert A.dtype == (torch.float32 if ln is not None else T)
     p = RowGemmParams()
     p.A, p.W, p.M, p.N, p.K = _p(A), _p(W), M, N, K
+    p.dtype = dtype_code(W)
     if ln is not None:
         p.a_ln, p.ln_w, p.ln_b, p.ln_eps = 1, _p(ln[0]), _p(ln[1]), ln_eps
         if ln_stats is not None:                     # (mean [M], rstd [M]) f32: what ppt_layernorm_bwd needs
@@ -364,10 +369,10 @@ def rowgemm(A, W, *, ln=None, ln_eps=1e-5, ln_stats=None, bias=None, act=ACT_NON
         p.row_scale, p.row_scale_rows = _p(row_scale), row_scale_rows
     else:
         if out is None:
-            out = torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
-        assert out.dtype == torch.bfloat16 and out.is_contiguous()
+            out = torch.empty((M, N), dtype=T, device=A.device)
+        assert out.dtype == T and out.is_contiguous()
         if out2 is not None:
-            assert out2.dtype == torch.bfloat16 and out2.is_contiguous()
+            assert out2.dtype == T and out2.is_contiguous()
             p.C2 = _p(out2)
     p.C, p.walkers = _p(out), walkers
     if profiler is not None:
@@ -870,7 +875,7 @@ def gemm_tn_splitk(x_a, x_b, min_blocks=768, max_splits=16):
     M, N1 = x_a.shape
     N2 = x_b.shape[1]
     tiles = ((N1 + 63) // 64) * ((N2 + 63) // 64)
-    if (x_a.dtype == torch.bfloat16 and x_b.dtype == torch.bfloat16 and M % 32 == 0 and N1 % 8 == 0 and N2 % 8 == 0
+    if (x_a.dtype in HALF and x_b.dtype == x_a.dtype and M % 32 == 0 and N1 % 8 == 0 and N2 % 8 == 0
             and x_a.stride(1) == 1 and x_b.stride(1) == 1 and x_a.stride(0) % 8 == 0 and x_b.stride(0) % 8 == 0):
         # operands as stored (ppt_gemm_tn_bf16: transposing LDS reads), no transposed copies; the number of slices must
         # divide the number of 32-row slabs
@@ -881,8 +886,8 @@ def gemm_tn_splitk(x_a, x_b, min_blocks=768, max_splits=16):
         part = torch.empty((S, N1 * N2), dtype=torch.float32, device=x_a.device)
         if profiler is not None:
             profiler.begin("gemm_bf16", 2.0 * M * N1 * N2, "ppt_gemm_tn_bf16")
-        _lib.check(_lib.lib().ppt_gemm_tn_bf16(_p(x_a), x_a.stride(0), _p(x_b), x_b.stride(0), M, N1, N2, S, _p(part),
-                                               _stream()), "ppt_gemm_tn_bf16")
+        _lib.check(_lib.lib().ppt_gemm_tn_half(_p(x_a), x_a.stride(0), _p(x_b), x_b.stride(0), M, N1, N2, S, _p(part),
+                                               dtype_code(x_a), _stream()), "ppt_gemm_tn_half")
         if profiler is not None:
             profiler.end()
         return (reduce_rows(part) if S > 1 else part[0]).view(N1, N2)
