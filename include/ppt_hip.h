@@ -414,6 +414,16 @@ int ppt_mini_pointnet_conv3_bf16(const void *A, int64_t M, int K, const void *W,
 int ppt_mini_pointnet_conv4_bf16(const void *A, int64_t M, int K, const float *a_scale, const float *a_shift, const void *W,
                                  const float *bias, int N, void *tok, void *stream);
 
+/* The three kernels above for either 16-bit operand format: dtype = PPT_BF16 or PPT_F16 (W, the bf16-typed activations and
+ * outputs are then all in that format). */
+int ppt_mini_pointnet_conv12_half(const float *pts, int64_t M, const float *w1, const float *b1, const float *a_scale,
+                                  const float *a_shift, int C1, const void *W2, const float *bias2, int N, void *y2, void *gmax,
+                                  int dtype, void *stream);
+int ppt_mini_pointnet_conv3_half(const void *A, int64_t M, int K, const void *W, const float *gterm, int N, void *y, float *part_sum,
+                                 float *part_m2, int dtype, void *stream);
+int ppt_mini_pointnet_conv4_half(const void *A, int64_t M, int K, const float *a_scale, const float *a_shift, const void *W,
+                                 const float *bias, int N, void *tok, int dtype, void *stream);
+
 /* The same product with BatchNorm partials of its output instead of the group max -- the first two convs of a PointNet2
  * set-abstraction branch that sees raw coordinates (models/pointnet2/pointnet2_utils.py:168-199, 217-262): y2 [M,N] bf16,
  * part_sum / part_m2 [M/32, N] f32 = per 32-row chunk (sum, sum (v - chunk mean)^2), what ppt_bn_finalize_ws takes with

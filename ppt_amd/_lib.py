@@ -146,6 +146,12 @@ _SIGNATURES = {
                                              c_void_p]),
     "ppt_mini_pointnet_conv4_bf16": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                              c_void_p]),
+    "ppt_mini_pointnet_conv12_half": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                              c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "ppt_mini_pointnet_conv3_half": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                             c_int, c_void_p]),
+    "ppt_mini_pointnet_conv4_half": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                             c_int, c_void_p]),
     "ppt_conv12_stats_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                       c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ppt_affine_conv_pool_bf16": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,

@@ -16,14 +16,13 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 // C1: channels of the K=3 conv (= K of the MFMA product); a wave owns TJ column tiles of 32; NWN waves side by side cover
 // N = 32 * TJ * NWN columns, the 4 / NWN wave rows of a workgroup take different groups of 32 points.
 // POOL: gmax[g, :] = max over the 32 rows of the group.  STATS: BatchNorm partials of the output per 32-row chunk,
 // (sum, M2 = sum (v - chunk mean)^2), the layout ppt_bn_finalize_ws takes with rows_per_partial = 32.
-template <int C1, int TJ, int NWN, bool POOL, bool STATS>
+template <typename F, int C1, int TJ, int NWN, bool POOL, bool STATS>
 __global__ __launch_bounds__(256) void mpn1_kernel(const float *__restrict__ pts, int n_tiles, const float *__restrict__ w1,
                                                     const float *__restrict__ b1, const float *__restrict__ a_scale,
                                                     const float *__restrict__ a_shift, const bf16_t *__restrict__ W2,
@@ -44,13 +43,13 @@ __global__ __launch_bounds__(256) void mpn1_kernel(const float *__restrict__ pts
     }
     const int col = lane & 31, h = lane >> 5;
     const int n_w = 32 * TJ * wn;                                      // first column of this wave
-    bf16x8_t bfrag[TJ][KS];
+    uint4 bfrag[TJ][KS];
     float bias[TJ];
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
 #pragma unroll
         for (int s = 0; s < KS; ++s)
-            bfrag[j][s] = *reinterpret_cast<const bf16x8_t *>(W2 + (size_t)(n_w + 32 * j + col) * C1 + 16 * s + 8 * h);
+            bfrag[j][s] = *reinterpret_cast<const uint4 *>(W2 + (size_t)(n_w + 32 * j + col) * C1 + 16 * s + 8 * h);
         bias[j] = bias2 ? bias2[n_w + 32 * j + col] : 0.f;
     }
     unsigned char *tr = tr_all[w];
@@ -72,11 +71,11 @@ __global__ __launch_bounds__(256) void mpn1_kernel(const float *__restrict__ pts
                 const float4 v0 = tab[16 * s + 8 * h + 2 * i], v1 = tab[16 * s + 8 * h + 2 * i + 1];
                 const float f0 = fmaxf(fmaf(v0.z, z, fmaf(v0.y, y, fmaf(v0.x, x, v0.w))), 0.0f);
                 const float f1 = fmaxf(fmaf(v1.z, z, fmaf(v1.y, y, fmaf(v1.x, x, v1.w))), 0.0f);
-                pk[i] = pack_bf16x2(f0, f1);
+                pk[i] = h16<F>::pack2(f0, f1);
             }
-            const bf16x8_t a = __builtin_bit_cast(bf16x8_t, make_uint4(pk[0], pk[1], pk[2], pk[3]));
+            const uint4 a = (make_uint4(pk[0], pk[1], pk[2], pk[3]));
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag[j][s], acc[j], 0, 0, 0);
+            for (int j = 0; j < TJ; ++j) acc[j] = h16<F>::mfma32(a, bfrag[j][s], acc[j]);
         }
         // C layout: column (lane & 31), rows (e & 3) + 8 (e >> 2) + 4 h
 #pragma unroll
@@ -90,7 +89,7 @@ __global__ __launch_bounds__(256) void mpn1_kernel(const float *__restrict__ pts
             }
             if constexpr (POOL) {
                 mx = xor32_max(mx);
-                if (h == 0) gmax[(size_t)t * N + n_w + 32 * j + col] = f32_to_bf16(mx);
+                if (h == 0) gmax[(size_t)t * N + n_w + 32 * j + col] = h16<F>::from_f32(mx);
             }
             if constexpr (STATS) {
                 sm = xor32_sum(sm);
@@ -111,7 +110,7 @@ __global__ __launch_bounds__(256) void mpn1_kernel(const float *__restrict__ pts
                 const int e0 = 2 * q2, e1 = 2 * q2 + 1;
                 const float send = (lane & 1) ? acc[j][e0] : acc[j][e1];
                 const float recv = __uint_as_float(dpp_mov<0xB1, 0xf>(__float_as_uint(send)));     // quad_perm [1,0,3,2]
-                const uint32_t packed = (lane & 1) ? pack_bf16x2(recv, acc[j][e1]) : pack_bf16x2(acc[j][e0], recv);
+                const uint32_t packed = (lane & 1) ? h16<F>::pack2(recv, acc[j][e1]) : h16<F>::pack2(acc[j][e0], recv);
                 const int e = (lane & 1) ? e1 : e0;
                 const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
                 *reinterpret_cast<uint32_t *>(tr + row * PITCH + (32 * j + (col & ~1)) * 2) = packed;
@@ -150,18 +149,30 @@ int mpn1_grid(int64_t tiles, int nwm)
 
 }  // namespace
 
-extern "C" int ppt_mini_pointnet_conv12_bf16(const float *pts, int64_t M, const float *w1, const float *b1, const float *a_scale,
+extern "C" int ppt_mini_pointnet_conv12_half(const float *pts, int64_t M, const float *w1, const float *b1, const float *a_scale,
                                              const float *a_shift, int C1, const void *W2, const float *bias2, int N, void *y2,
-                                             void *gmax, void *stream)
+                                             void *gmax, int dtype, void *stream)
 {
+    if (dtype != PPT_BF16 && dtype != PPT_F16) return PPT_EINVAL;
     if (!pts || !w1 || !b1 || !a_scale || !a_shift || !W2 || !bias2 || !y2 || !gmax || M <= 0) return PPT_EINVAL;
     if (C1 != 128 || N != 256 || M % 32) return PPT_EUNSUPPORTED;
     if (((uintptr_t)W2 | (uintptr_t)y2) & 15) return PPT_EINVAL;
     const int64_t tiles = M / 32;
-    hipLaunchKernelGGL((mpn1_kernel<128, 2, 4, true, false>), dim3(mpn1_grid(tiles, 1)), dim3(256), 0, ppt_stream(stream), pts,
-                       (int)tiles, w1, b1, a_scale, a_shift, (const bf16_t *)W2, bias2, (bf16_t *)y2, (bf16_t *)gmax, nullptr, nullptr);
+    if (dtype == PPT_F16)
+        hipLaunchKernelGGL((mpn1_kernel<f16_t, 128, 2, 4, true, false>), dim3(mpn1_grid(tiles, 1)), dim3(256), 0, ppt_stream(stream), pts,
+                           (int)tiles, w1, b1, a_scale, a_shift, (const bf16_t *)W2, bias2, (bf16_t *)y2, (bf16_t *)gmax, nullptr, nullptr);
+    else
+        hipLaunchKernelGGL((mpn1_kernel<bf16_t, 128, 2, 4, true, false>), dim3(mpn1_grid(tiles, 1)), dim3(256), 0, ppt_stream(stream), pts,
+                           (int)tiles, w1, b1, a_scale, a_shift, (const bf16_t *)W2, bias2, (bf16_t *)y2, (bf16_t *)gmax, nullptr, nullptr);
     PPT_CHECK_LAUNCH();
     return PPT_OK;
+}
+
+extern "C" int ppt_mini_pointnet_conv12_bf16(const float *pts, int64_t M, const float *w1, const float *b1, const float *a_scale,
+                                             const float *a_shift, int C1, const void *W2, const float *bias2, int N, void *y2,
+                                             void *gmax, void *stream)
+{
+    return ppt_mini_pointnet_conv12_half(pts, M, w1, b1, a_scale, a_shift, C1, W2, bias2, N, y2, gmax, PPT_BF16, stream);
 }
 
 // the same product with BatchNorm partials of the output instead of the group max: the first two convs of a PointNet2
@@ -176,7 +187,7 @@ extern "C" int ppt_conv12_stats_bf16(const float *pts, int64_t M, const float *w
     const int64_t tiles = M / 32;
     hipStream_t s = ppt_stream(stream);
 #define MPN_LAUNCH(C, TJ_)                                                                                                 \
-    hipLaunchKernelGGL((mpn1_kernel<C, TJ_, 1, false, true>), dim3(mpn1_grid(tiles, 4)), dim3(256), 0, s, pts, (int)tiles, w1, b1, \
+    hipLaunchKernelGGL((mpn1_kernel<bf16_t, C, TJ_, 1, false, true>), dim3(mpn1_grid(tiles, 4)), dim3(256), 0, s, pts, (int)tiles, w1, b1, \
                        a_scale, a_shift, (const bf16_t *)W2, bias2, (bf16_t *)y2, nullptr, part_sum, part_m2)
     if (C1 == 32 && N == 32) MPN_LAUNCH(32, 1);
     else if (C1 == 64 && N == 64) MPN_LAUNCH(64, 2);

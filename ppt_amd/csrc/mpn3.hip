@@ -12,13 +12,12 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 constexpr int M3_K = 256, M3_N = 512, M3_KS = M3_K / 16, M3_PITCH = 2 * M3_K + 16, M3_BUF = 32 * M3_PITCH;
 constexpr int M3_TP = 64 * 2 + 16, M3_TR = 32 * M3_TP;             // a wave's 32 x 64 bf16 transpose tile
 
-template <bool STATS>
+template <typename F, bool STATS>
 __global__ __launch_bounds__(512, 2) void mpn3_kernel(const bf16_t *__restrict__ A, int n_tiles, const bf16_t *__restrict__ W,
                                                        const float *__restrict__ gterm, bf16_t *__restrict__ y,
                                                        float *__restrict__ part_sum, float *__restrict__ part_m2)
@@ -27,12 +26,12 @@ __global__ __launch_bounds__(512, 2) void mpn3_kernel(const bf16_t *__restrict__
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = lane & 31, h = lane >> 5;
-    bf16x8_t bfrag[2][M3_KS];
+    uint4 bfrag[2][M3_KS];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int s = 0; s < M3_KS; ++s)
-            bfrag[j][s] = *reinterpret_cast<const bf16x8_t *>(W + (size_t)(64 * w + 32 * j + col) * M3_K + 16 * s + 8 * h);
+            bfrag[j][s] = *reinterpret_cast<const uint4 *>(W + (size_t)(64 * w + 32 * j + col) * M3_K + 16 * s + 8 * h);
     unsigned char *tr = smem + 2 * M3_BUF + w * M3_TR;
     const int cc = threadIdx.x & 31, rb = threadIdx.x >> 5;         // loader: 16-byte chunk cc of rows rb and rb + 16
     uint4 v0, v1;                                                    // (named values, not an array: an array that lives across
@@ -60,9 +59,9 @@ __global__ __launch_bounds__(512, 2) void mpn3_kernel(const bf16_t *__restrict__
             for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 #pragma unroll
         for (int s = 0; s < M3_KS; ++s) {
-            const bf16x8_t a = *reinterpret_cast<const bf16x8_t *>(at + 32 * s);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag[0][s], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag[1][s], acc[1], 0, 0, 0);
+            const uint4 a = *reinterpret_cast<const uint4 *>(at + 32 * s);
+            acc[0] = h16<F>::mfma32(a, bfrag[0][s], acc[0]);
+            acc[1] = h16<F>::mfma32(a, bfrag[1][s], acc[1]);
         }
         // C layout: column (lane & 31), rows (e & 3) + 8 (e >> 2) + 4 h
 #pragma unroll
@@ -92,7 +91,7 @@ __global__ __launch_bounds__(512, 2) void mpn3_kernel(const bf16_t *__restrict__
                 const int e0 = 2 * q2, e1 = 2 * q2 + 1;
                 const float send = (lane & 1) ? acc[j][e0] : acc[j][e1];
                 const float recv = __uint_as_float(dpp_mov<0xB1, 0xf>(__float_as_uint(send)));
-                const uint32_t packed = (lane & 1) ? pack_bf16x2(recv, acc[j][e1]) : pack_bf16x2(acc[j][e0], recv);
+                const uint32_t packed = (lane & 1) ? h16<F>::pack2(recv, acc[j][e1]) : h16<F>::pack2(acc[j][e0], recv);
                 const int e = (lane & 1) ? e1 : e0;
                 const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
                 *reinterpret_cast<uint32_t *>(tr + row * M3_TP + (32 * j + (col & ~1)) * 2) = packed;
@@ -116,9 +115,10 @@ __global__ __launch_bounds__(512, 2) void mpn3_kernel(const bf16_t *__restrict__
 
 }  // namespace
 
-extern "C" int ppt_mini_pointnet_conv3_bf16(const void *A, int64_t M, int K, const void *W, const float *gterm, int N, void *y,
-                                            float *part_sum, float *part_m2, void *stream)
+extern "C" int ppt_mini_pointnet_conv3_half(const void *A, int64_t M, int K, const void *W, const float *gterm, int N, void *y,
+                                            float *part_sum, float *part_m2, int dtype, void *stream)
 {
+    if (dtype != PPT_BF16 && dtype != PPT_F16) return PPT_EINVAL;
     if (!A || !W || !gterm || !y || M <= 0 || ((part_sum == nullptr) != (part_m2 == nullptr))) return PPT_EINVAL;
     if (K != M3_K || N != M3_N || M % 32) return PPT_EUNSUPPORTED;
     if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)y) & 15) return PPT_EINVAL;
@@ -126,8 +126,10 @@ extern "C" int ppt_mini_pointnet_conv3_bf16(const void *A, int64_t M, int K, con
     static const int cus = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        (void)hipFuncSetAttribute((const void *)mpn3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void *)mpn3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void *)mpn3_kernel<bf16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void *)mpn3_kernel<bf16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void *)mpn3_kernel<f16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void *)mpn3_kernel<f16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         return n > 0 ? n : 256;
     }();
     const int64_t tiles = M / 32;
@@ -136,12 +138,17 @@ extern "C" int ppt_mini_pointnet_conv3_bf16(const void *A, int64_t M, int K, con
     int64_t want = (int64_t)cus * ppt_get_persistent_occupancy() / 100;
     want = want < 8 ? 8 : want;
     const int grid = (int)(tiles < want ? tiles : want);
-    if (part_sum)
-        hipLaunchKernelGGL(mpn3_kernel<true>, dim3(grid), dim3(512), lds, ppt_stream(stream), (const bf16_t *)A, (int)tiles,
-                           (const bf16_t *)W, gterm, (bf16_t *)y, part_sum, part_m2);
-    else
-        hipLaunchKernelGGL(mpn3_kernel<false>, dim3(grid), dim3(512), lds, ppt_stream(stream), (const bf16_t *)A, (int)tiles,
-                           (const bf16_t *)W, gterm, (bf16_t *)y, part_sum, part_m2);
+#define PPT_M3(FF, ST) hipLaunchKernelGGL((mpn3_kernel<FF, ST>), dim3(grid), dim3(512), lds, ppt_stream(stream), (const bf16_t *)A, (int)tiles, \
+                                          (const bf16_t *)W, gterm, (bf16_t *)y, part_sum, part_m2)
+    if (dtype == PPT_F16) { if (part_sum) PPT_M3(f16_t, true); else PPT_M3(f16_t, false); }
+    else { if (part_sum) PPT_M3(bf16_t, true); else PPT_M3(bf16_t, false); }
+#undef PPT_M3
     PPT_CHECK_LAUNCH();
     return PPT_OK;
+}
+
+extern "C" int ppt_mini_pointnet_conv3_bf16(const void *A, int64_t M, int K, const void *W, const float *gterm, int N, void *y,
+                                            float *part_sum, float *part_m2, void *stream)
+{
+    return ppt_mini_pointnet_conv3_half(A, M, K, W, gterm, N, y, part_sum, part_m2, PPT_BF16, stream);
 }

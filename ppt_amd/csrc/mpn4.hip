@@ -14,11 +14,11 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 constexpr int M4_K = 512, M4_N = 256, M4_KS = M4_K / 16, M4_PITCH = 2 * M4_K + 16, M4_BUF = 32 * M4_PITCH;
 
+template <typename F>
 __global__ __launch_bounds__(512, 2) void mpn4_kernel(const bf16_t *__restrict__ A, int n_tiles, const float *__restrict__ a_scale,
                                                        const float *__restrict__ a_shift, const bf16_t *__restrict__ W,
                                                        const float *__restrict__ bias, bf16_t *__restrict__ tok)
@@ -27,10 +27,10 @@ __global__ __launch_bounds__(512, 2) void mpn4_kernel(const bf16_t *__restrict__
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = lane & 31, h = lane >> 5;
-    bf16x8_t bfrag[M4_KS];
+    uint4 bfrag[M4_KS];
 #pragma unroll
     for (int s = 0; s < M4_KS; ++s)
-        bfrag[s] = *reinterpret_cast<const bf16x8_t *>(W + (size_t)(32 * w + col) * M4_K + 16 * s + 8 * h);
+        bfrag[s] = *reinterpret_cast<const uint4 *>(W + (size_t)(32 * w + col) * M4_K + 16 * s + 8 * h);
     const float bias_v = bias ? bias[32 * w + col] : 0.f;
     // loader: thread -> 16-byte chunk cc of rows rb, rb + 8, rb + 16, rb + 24
     const int cc = threadIdx.x & 63, rb = threadIdx.x >> 6;
@@ -46,9 +46,9 @@ __global__ __launch_bounds__(512, 2) void mpn4_kernel(const bf16_t *__restrict__
         const uint32_t wv[4] = {v[i].x, v[i].y, v[i].z, v[i].w};                                                        \
         uint32_t pk[4];                                                                                                 \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                                 \
-            const float lo = fmaxf(fmaf(__uint_as_float(wv[e] << 16), sc[2 * e], sh[2 * e]), 0.0f);                     \
-            const float hi = fmaxf(fmaf(__uint_as_float(wv[e] & 0xFFFF0000u), sc[2 * e + 1], sh[2 * e + 1]), 0.0f);     \
-            pk[e] = pack_bf16x2(lo, hi);                                                                                \
+            const float lo = fmaxf(fmaf(h16<F>::lo(wv[e]), sc[2 * e], sh[2 * e]), 0.0f);                     \
+            const float hi = fmaxf(fmaf(h16<F>::hi(wv[e]), sc[2 * e + 1], sh[2 * e + 1]), 0.0f);     \
+            pk[e] = h16<F>::pack2(lo, hi);                                                                                \
         }                                                                                                               \
         *reinterpret_cast<uint4 *>(smem + (buf) * M4_BUF + (rb + 8 * i) * M4_PITCH + cc * 16) = make_uint4(pk[0], pk[1], pk[2], pk[3]); \
     }
@@ -67,14 +67,14 @@ __global__ __launch_bounds__(512, 2) void mpn4_kernel(const bf16_t *__restrict__
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
         for (int s = 0; s < M4_KS; ++s) {
-            const bf16x8_t a = *reinterpret_cast<const bf16x8_t *>(at + 32 * s);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag[s], acc, 0, 0, 0);
+            const uint4 a = *reinterpret_cast<const uint4 *>(at + 32 * s);
+            acc = h16<F>::mfma32(a, bfrag[s], acc);
         }
         float mx = -INFINITY;
 #pragma unroll
         for (int e = 0; e < 16; ++e) mx = fmaxf(mx, acc[e] + bias_v);
         mx = xor32_max(mx);
-        if (h == 0) tok[(size_t)t * M4_N + 32 * w + col] = f32_to_bf16(mx);
+        if (h == 0) tok[(size_t)t * M4_N + 32 * w + col] = h16<F>::from_f32(mx);
         M4_STAGE(cur ^ 1);                                            // last read in iteration it - 1, before its barrier
         __syncthreads();
     }
@@ -84,9 +84,10 @@ __global__ __launch_bounds__(512, 2) void mpn4_kernel(const bf16_t *__restrict__
 
 }  // namespace
 
-extern "C" int ppt_mini_pointnet_conv4_bf16(const void *A, int64_t M, int K, const float *a_scale, const float *a_shift, const void *W,
-                                            const float *bias, int N, void *tok, void *stream)
+extern "C" int ppt_mini_pointnet_conv4_half(const void *A, int64_t M, int K, const float *a_scale, const float *a_shift, const void *W,
+                                            const float *bias, int N, void *tok, int dtype, void *stream)
 {
+    if (dtype != PPT_BF16 && dtype != PPT_F16) return PPT_EINVAL;
     if (!A || !a_scale || !a_shift || !W || !tok || M <= 0) return PPT_EINVAL;
     if (K != M4_K || N != M4_N || M % 32) return PPT_EUNSUPPORTED;
     if (((uintptr_t)A | (uintptr_t)W) & 15) return PPT_EINVAL;
@@ -94,7 +95,8 @@ extern "C" int ppt_mini_pointnet_conv4_bf16(const void *A, int64_t M, int K, con
     static const int cus = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        (void)hipFuncSetAttribute((const void *)mpn4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void *)mpn4_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void *)mpn4_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         return n > 0 ? n : 256;
     }();
     const int64_t tiles = M / 32;
@@ -103,8 +105,18 @@ extern "C" int ppt_mini_pointnet_conv4_bf16(const void *A, int64_t M, int K, con
     int64_t want = (int64_t)cus * ppt_get_persistent_occupancy() / 100;
     want = want < 8 ? 8 : want;
     const int grid = (int)(tiles < want ? tiles : want);
-    hipLaunchKernelGGL(mpn4_kernel, dim3(grid), dim3(512), lds, ppt_stream(stream), (const bf16_t *)A, (int)tiles, a_scale, a_shift,
-                       (const bf16_t *)W, bias, (bf16_t *)tok);
+    if (dtype == PPT_F16)
+        hipLaunchKernelGGL(mpn4_kernel<f16_t>, dim3(grid), dim3(512), lds, ppt_stream(stream), (const bf16_t *)A, (int)tiles, a_scale, a_shift,
+                           (const bf16_t *)W, bias, (bf16_t *)tok);
+    else
+        hipLaunchKernelGGL(mpn4_kernel<bf16_t>, dim3(grid), dim3(512), lds, ppt_stream(stream), (const bf16_t *)A, (int)tiles, a_scale, a_shift,
+                           (const bf16_t *)W, bias, (bf16_t *)tok);
     PPT_CHECK_LAUNCH();
     return PPT_OK;
+}
+
+extern "C" int ppt_mini_pointnet_conv4_bf16(const void *A, int64_t M, int K, const float *a_scale, const float *a_shift, const void *W,
+                                            const float *bias, int N, void *tok, void *stream)
+{
+    return ppt_mini_pointnet_conv4_half(A, M, K, a_scale, a_shift, W, bias, N, tok, PPT_BF16, stream);
 }

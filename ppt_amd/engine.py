@@ -80,13 +80,19 @@ STAGE_DTYPE = {}
 # softmax weights and GELU outputs (the residual stream is fp32) -- far inside fp16's range -- and tools/bf16_error.py puts what
 # is left of the logits / gradient error after the text tower moved to fp16 (ULIP_WITH_IMAGE._cache) in blocks 0-10.
 BLOCKS_F16 = os.environ.get("PPT_BLOCKS_F16", "1") != "0"
+# ... and the PointBERT tokenizer (mini-PointNet + reduce_dim + pos_embed; PPT_TOKENIZER_F16=0: bf16): with text tower and blocks
+# on fp16 it is what remains (logits 0.10 -> 0.04 max, last-block weight gradients 2 % -> 0.4 % with it in fp32).  Its stored
+# activations are raw Conv1d outputs in front of a BatchNorm (y2, y3) and group maxima: |values| of order 1-100, fp16's range is
+# 65 504; the conv1 output is rebuilt in fp32 from the coordinates and never stored.
+TOKENIZER_F16 = os.environ.get("PPT_TOKENIZER_F16", "1") != "0"
 
 
 def _stage_wc(wc, stage):
     """The WeightCache a stage runs with: `wc`, or a sibling of another operand precision (kept on `wc`)."""
     dt = STAGE_DTYPE.get(stage)
-    if dt is None and BLOCKS_F16 and wc.dtype == torch.bfloat16 and stage in ("blocks", "last_block"):
-        dt = torch.float16
+    if dt is None and wc.dtype == torch.bfloat16:
+        if (BLOCKS_F16 and stage in ("blocks", "last_block")) or (TOKENIZER_F16 and stage == "tokenizer"):
+            dt = torch.float16
     if dt is None or dt == wc.dtype:
         return wc
     alts = wc.__dict__.setdefault("_alts", {})
@@ -143,7 +149,7 @@ def mini_pointnet(sd, p, wc, nbhd, bn_train, update_running=True):
         sc1, sh1 = ops.bn_finalize(g1, be1, False, running_mean=rm1, running_var=rv1)
     # conv1 + BN1 + ReLU live in the A-prologue of the conv2 GEMM; epilogue: +bias, group max
     w2 = wc.get(sd[p + "first_conv.3.weight"])
-    if T == torch.bfloat16 and FUSED_CONV12 and tuple(w2.shape) == (256, 128) and w2.stride(0) == 128:
+    if T in ops.HALF and FUSED_CONV12 and tuple(w2.shape) == (256, 128) and w2.stride(0) == 128:
         # the dedicated kernel (csrc/mpn1.hip): same arithmetic, no tile staging (326 -> ~100 us for 524 288 points)
         y2, gmax = ops.mini_pointnet_conv12(pts, w1, b1, sc1, sh1, w2, sd[p + "first_conv.3.bias"])
     else:
@@ -156,7 +162,7 @@ def mini_pointnet(sd, p, wc, nbhd, bn_train, update_running=True):
                      algo_k=0)      # its FLOPs are accounted to the 512-wide conv3 (algo_k=512 below)
     g2, be2, rm2, rv2, nb2 = _bn_params(sd, p + "second_conv.1.")
     w3b = wc.get(w3, cols=(256, 512))
-    fused3 = (T == torch.bfloat16 and FUSED_CONV12 and tuple(w3b.shape) == (512, 256) and w3b.stride(0) == 256
+    fused3 = (T in ops.HALF and FUSED_CONV12 and tuple(w3b.shape) == (512, 256) and w3b.stride(0) == 256
               and y2.is_contiguous() and gterm.is_contiguous())          # csrc/mpn3.hip: W3b in registers, rows read once
     if bn_train:
         cs = torch.empty((M // 32, 512), dtype=torch.float32, device=dev)
@@ -174,7 +180,7 @@ def mini_pointnet(sd, p, wc, nbhd, bn_train, update_running=True):
         sc2, sh2 = ops.bn_finalize(g2, be2, False, running_mean=rm2, running_var=rv2)
     # BN2 + ReLU in the A-prologue of conv4; only the pooled maximum is written
     w4 = wc.get(sd[p + "second_conv.3.weight"])
-    if (T == torch.bfloat16 and FUSED_CONV12 and tuple(w4.shape) == (256, 512) and w4.stride(0) == 512 and y3.is_contiguous()
+    if (T in ops.HALF and FUSED_CONV12 and tuple(w4.shape) == (256, 512) and w4.stride(0) == 512 and y3.is_contiguous()
             and y3.shape[1] == 512):
         # csrc/mpn4.hip: W4 stays in registers, every group's rows are read once (305 -> ~150 us for 524 288 points)
         return ops.mini_pointnet_conv4(y3, sc2, sh2, w4, sd[p + "second_conv.3.bias"])

@@ -675,15 +675,16 @@ def gn_lrelu_max_backward(y, dout, out, arg, mean, rstd, gamma, groups, slope):
 def mini_pointnet_conv12(pts, w1, b1, a_scale, a_shift, w2, bias2):
     """pts [M,3] f32 -> (y2 [M,256] bf16, gmax [M/32,256] bf16): conv1 + folded BN + ReLU + conv2 + bias and the max over
     each group of 32 rows, one kernel (ppt_mini_pointnet_conv12_bf16).  w2 [256,128] bf16."""
-    _chk(pts, torch.float32, "pts"); _chk(w2, torch.bfloat16, "w2")
+    assert w2.dtype in HALF
+    _chk(pts, torch.float32, "pts"); _chk(w2, w2.dtype, "w2")
     M = pts.shape[0]
     N, C1 = w2.shape
-    y2 = torch.empty((M, N), dtype=torch.bfloat16, device=pts.device)
-    gmax = torch.empty((M // 32, N), dtype=torch.bfloat16, device=pts.device)
+    y2 = torch.empty((M, N), dtype=w2.dtype, device=pts.device)
+    gmax = torch.empty((M // 32, N), dtype=w2.dtype, device=pts.device)
     if profiler is not None:
         profiler.begin("gemm_bf16", 2.0 * M * N * C1, "ppt_mini_pointnet_conv12_bf16")
-    _lib.check(_lib.lib().ppt_mini_pointnet_conv12_bf16(_p(pts), M, _p(w1), _p(b1), _p(a_scale), _p(a_shift), C1, _p(w2), _p(bias2),
-                                                        N, _p(y2), _p(gmax), _stream()), "ppt_mini_pointnet_conv12_bf16")
+    _lib.check(_lib.lib().ppt_mini_pointnet_conv12_half(_p(pts), M, _p(w1), _p(b1), _p(a_scale), _p(a_shift), C1, _p(w2), _p(bias2),
+                                                        N, _p(y2), _p(gmax), dtype_code(w2), _stream()), "ppt_mini_pointnet_conv12_half")
     if profiler is not None:
         profiler.end()
     return y2, gmax
@@ -692,17 +693,18 @@ def mini_pointnet_conv12(pts, w1, b1, a_scale, a_shift, w2, bias2):
 def mini_pointnet_conv3(A, w, gterm, col_stats=None):
     """A [M,256] bf16, w [512,256] bf16, gterm [M/32,512] f32 -> y [M,512] bf16 = A @ w^T + gterm[group] (+ BatchNorm partials
     into col_stats) -- ppt_mini_pointnet_conv3_bf16.  The FLOPs are accounted at the 512-wide conv this is the local half of."""
-    _chk(A, torch.bfloat16, "A"); _chk(w, torch.bfloat16, "w"); _chk(gterm, torch.float32, "gterm")
+    assert w.dtype in HALF
+    _chk(A, w.dtype, "A"); _chk(w, w.dtype, "w"); _chk(gterm, torch.float32, "gterm")
     M, K = A.shape
     N = w.shape[0]
-    y = torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
+    y = torch.empty((M, N), dtype=w.dtype, device=A.device)
     ps, pm = col_stats if col_stats is not None else (None, None)
     if profiler is not None:
         # model: the 512-wide Conv1d on cat(global, local) (dvae.py:194); executed: the local half (the global half is one row
         # per group, a separate small GEMM booked with algo_k = 0 / its own executed FLOPs)
         profiler.begin("gemm_bf16", 2.0 * M * N * 2 * K, "ppt_mini_pointnet_conv3_bf16", executed=2.0 * M * N * K)
-    _lib.check(_lib.lib().ppt_mini_pointnet_conv3_bf16(_p(A), M, K, _p(w), _p(gterm), N, _p(y), _p(ps), _p(pm), _stream()),
-               "ppt_mini_pointnet_conv3_bf16")
+    _lib.check(_lib.lib().ppt_mini_pointnet_conv3_half(_p(A), M, K, _p(w), _p(gterm), N, _p(y), _p(ps), _p(pm), dtype_code(w), _stream()),
+               "ppt_mini_pointnet_conv3_half")
     if profiler is not None:
         profiler.end()
     return y
@@ -711,14 +713,15 @@ def mini_pointnet_conv3(A, w, gterm, col_stats=None):
 def mini_pointnet_conv4(A, a_scale, a_shift, w, bias):
     """A [M,512] bf16 -> tok [M/32,256] bf16 = max over each group of 32 rows of relu(a_scale*A + a_shift) @ w^T + bias
     (ppt_mini_pointnet_conv4_bf16)."""
-    _chk(A, torch.bfloat16, "A"); _chk(w, torch.bfloat16, "w")
+    assert w.dtype in HALF
+    _chk(A, w.dtype, "A"); _chk(w, w.dtype, "w")
     M, K = A.shape
     N = w.shape[0]
-    tok = torch.empty((M // 32, N), dtype=torch.bfloat16, device=A.device)
+    tok = torch.empty((M // 32, N), dtype=w.dtype, device=A.device)
     if profiler is not None:
         profiler.begin("gemm_bf16", 2.0 * M * N * K, "ppt_mini_pointnet_conv4_bf16")
-    _lib.check(_lib.lib().ppt_mini_pointnet_conv4_bf16(_p(A), M, K, _p(a_scale), _p(a_shift), _p(w), _p(bias), N, _p(tok), _stream()),
-               "ppt_mini_pointnet_conv4_bf16")
+    _lib.check(_lib.lib().ppt_mini_pointnet_conv4_half(_p(A), M, K, _p(a_scale), _p(a_shift), _p(w), _p(bias), N, _p(tok), dtype_code(w),
+                                                       _stream()), "ppt_mini_pointnet_conv4_half")
     if profiler is not None:
         profiler.end()
     return tok

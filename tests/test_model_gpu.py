@@ -1024,6 +1024,8 @@ def test_fused_text_tower_matches_the_per_layer_tower(ds, position):
         m.load_state_dict(W.ulip_pointbert_state_dict(seed=0), strict=False)
         m.prompt_learner.embedding = W.synth_prompt_embedding_from_tokens(m.tokenized_prompts, seed=0)
         m.cuda().set_precision(torch.float32 if mode == "f32" else torch.bfloat16)
+        if mode != "f32":
+            m.text_precision = torch.bfloat16        # the fused kernels are bf16: compare like with like (the default text tower is fp16)
         m.overlap_text_tower = False
         m.use_hip_graphs = False
         m.fused_text_tower = mode == "fused"
@@ -1055,6 +1057,7 @@ def test_fused_text_tower_eval_and_graph_replay():
     from ppt_amd.train import Trainer
     m = _token_structured_model(0, torch.bfloat16)
     m.use_hip_graphs = False
+    m.text_precision, m.fused_text_tower = torch.bfloat16, True
     te_train = m._text_raw().detach().clone()
     with torch.no_grad():
         te_eval = m._text_raw().detach().clone()
@@ -1065,6 +1068,7 @@ def test_fused_text_tower_eval_and_graph_replay():
     for graphs_on in (False, True):
         mm = _token_structured_model(0, torch.bfloat16)
         mm.use_hip_graphs = mm.point_encoder.use_hip_graphs = graphs_on
+        mm.text_precision, mm.fused_text_tower = torch.bfloat16, True
         mm.train()
         mm.point_encoder.fps_start = torch.from_numpy(start).cuda()
         mm.point_encoder.drop_path_factors = torch.ones(12, 2, 4)

@@ -46,6 +46,8 @@ def run(h, g, f32_stages):
             m.text_precision = torch.float32
         elif st == "text_bf16":
             m.text_precision = torch.bfloat16
+        elif st == "tokenizer_bf16":
+            engine.STAGE_DTYPE["tokenizer"] = torch.bfloat16
         elif st == "blocks_bf16":
             engine.STAGE_DTYPE["blocks"] = engine.STAGE_DTYPE["last_block"] = torch.bfloat16
         else:
@@ -75,7 +77,8 @@ for h in heads:
     ref_logits = res["logits"]
     gkeys = ["prompt_learner.learnable_tokens"] + (["point_encoder.blocks.blocks.11.mlp.fc2.weight", "point_encoder.blocks.blocks.11.attn.qkv.weight"] if h >= 3 else [])
     rows = {}
-    configs = [("all bf16", ("text_bf16", "blocks_bf16")), ("text f16, blocks bf16", ("blocks_bf16",)), ("default: both f16", ())] + \
+    configs = [("all bf16", ("text_bf16", "blocks_bf16", "tokenizer_bf16")), ("text f16 only", ("blocks_bf16", "tokenizer_bf16")),
+               ("text + blocks f16", ("tokenizer_bf16",)), ("default: all f16", ())] + \
         [(f"{st} in fp32", (st,)) for st in STAGES] + [("all fp32", STAGES)]
     for name, f32 in configs:
         loss, lg, grads = run(h, g, f32)
