@@ -584,6 +584,8 @@ extern "C" int ppt_linear3_gelu(const float *pts, int64_t M, const float *w, con
     dim3 grid((unsigned)((n + 255) / 256));
     if (y_dtype == PPT_BF16)
         hipLaunchKernelGGL(linear3_gelu_kernel<bf16_t>, grid, dim3(256), 0, ppt_stream(stream), pts, M, w, b, C, (bf16_t *)y);
+    else if (y_dtype == PPT_F16)
+        hipLaunchKernelGGL(linear3_gelu_kernel<f16_t>, grid, dim3(256), 0, ppt_stream(stream), pts, M, w, b, C, (f16_t *)y);
     else if (y_dtype == PPT_F32)
         hipLaunchKernelGGL(linear3_gelu_kernel<float>, grid, dim3(256), 0, ppt_stream(stream), pts, M, w, b, C, (float *)y);
     else
