@@ -230,60 +230,6 @@ typedef struct ppt_vit_mlp_params {
     int dtype;                       /* PPT_BF16 (also 0) or PPT_F16: the 16-bit format of W1 / W2 and of the in-kernel operands */
 } ppt_vit_mlp_params;
 
-/* ---- the CLIP text tower under PromptLearner as ONE persistent kernel per direction (csrc/text_tower.hip) ------------------
- * Replaces encode_text's transformer (ULIP_models.py:203-222; Transformer / ResidualAttentionBlock :35-67: 12 x [ln_1,
- * nn.MultiheadAttention(512, 8) with the causal mask of :224-230, ln_2, c_fc, QuickGELU, c_proj]) and its input-gradient
- * backward (the tower is frozen, ULIP_models.py:487-507) for the bf16 mode: width 512, 8 heads of 64, hidden 2048.
- *
- * Row layout ("grouped"): workgroup g owns prompts g*NP .. g*NP + NP - 1 and a private copy of the P positions all prompts
- * share (P = 0: none): rows [g*RW, g*RW + P) = positions 0 .. P-1, then prompt g*NP + n at rows g*RW + P + n (L - P) ...;
- * RW = P + NP (L - P) <= 64; rows = ceil(C / NP) * RW.  L = the evaluated length (positions after the last EOT are dead).
- * x0 [rows, 512] f32: the tower's input with the positional embedding added (ppt_prompt_rows builds it).
- * wfrag: the 12 GEMM "units" of every layer (in_proj q / k / v, out_proj, then c_fc slab j, c_proj slab j for j = 0 .. 3; slab
- * = 512 hidden units) re-tiled into [wave 8][layer][unit 12][k-step 16][column tile 4][lane 64][8 bf16] with
- *   piece[lane = 16 kg + i] = Wunit[64 wave + 16 tile + i][32 kstep + 8 kg .. + 8)  (Wunit: the unit's [512 out, 512 in] block)
- * plus at least 16 KiB of readable padding behind it (the ring prefetches past the end); wfrag_bwd: the same for the
- * backward's units, layers LAST to first, unit order per layer [c_proj^T slab j, c_fc^T slab j] j = 0 .. 3, out_proj^T,
- * in_proj^T q / k / v (ppt_amd/engine.py: text_tower_weights builds both).
- * Per-layer activations: layer l at base + l * stride (elements); stride 0 = one buffer reused (no backward wanted):
- *   x [rows,512] f32 (output of layer l; the last layer's is the tower's output), xmid [rows,512] f32, qkv [rows,1536] bf16,
- *   a [rows,512] bf16 (attention output; may be NULL when stride 0), lse [rows,8] f32 (NULL ok), pre [rows,2048] bf16 (c_fc
- *   output before QuickGELU; NULL ok), stats [4,rows] f32 = mean1 | rstd1 | mean2 | rstd2 (NULL ok).
- * Backward: g [rows,512] f32 holds d loss / d x(last layer) on entry (zero except the pooled EOT rows) and d loss / d x0 on
- * exit -- for the shared rows each workgroup's PARTIAL (sum them: ppt_prompt_rows_bwd does, given every copy's row); dqkv
- * [rows,1536] bf16, da [rows,512] bf16, dscr [rows,512] f32: scratch.  Nothing is exchanged between workgroups.
- * prio is set by the library; dbg: diagnostic, normally NULL. */
-typedef struct ppt_text_tower_params {
-    const float *x0;
-    const void *wfrag;
-    const void *wfrag_bwd;
-    const float *ln1_w, *ln1_b, *ln2_w, *ln2_b;      /* [layers, 512] */
-    const float *b_in;                               /* [layers, 1536] */
-    const float *b_out;                              /* [layers, 512] */
-    const float *b_fc;                               /* [layers, 2048] */
-    const float *b_proj;                             /* [layers, 512] */
-    float *x;
-    float *xmid;
-    void *qkv;
-    void *a;
-    float *lse;
-    void *pre;
-    float *stats;
-    long long x_stride, xm_stride, qkv_stride, a_stride, lse_stride, pre_stride, stats_stride;
-    float *g;
-    void *dqkv;
-    void *da;
-    float *dscr;
-    int C, L, P, NP, layers, rows;
-    float scale;                                     /* softmax scale, 64^-0.5 */
-    int prio;
-    unsigned long long *dbg;                         /* NULL, or >= 64 words: shader-clock stamps of workgroup 0 / wave 0 at the
-                                                        phase boundaries of layer 1 (tools/text_tower_stamps.py; diagnostic) */
-} ppt_text_tower_params;
-
-int ppt_text_tower_fwd_bf16(const ppt_text_tower_params *p, void *stream);
-int ppt_text_tower_bwd_bf16(const ppt_text_tower_params *p, void *stream);
-
 int ppt_vit_mlp_retile(const void *W1, const void *W2, void *W1_tiled, void *W2_tiled, void *stream);
 int ppt_vit_mlp_bf16(const ppt_vit_mlp_params *p, void *stream);
 

@@ -43,20 +43,6 @@ class VitMlpParams(ctypes.Structure):
     ]
 
 
-class TextTowerParams(ctypes.Structure):
-    """struct ppt_text_tower_params (include/ppt_hip.h) -- field order must match the header."""
-    _fields_ = [
-        ("x0", c_void_p), ("wfrag", c_void_p), ("wfrag_bwd", c_void_p), ("ln1_w", c_void_p), ("ln1_b", c_void_p), ("ln2_w", c_void_p),
-        ("ln2_b", c_void_p), ("b_in", c_void_p), ("b_out", c_void_p), ("b_fc", c_void_p), ("b_proj", c_void_p), ("x", c_void_p),
-        ("xmid", c_void_p), ("qkv", c_void_p), ("a", c_void_p), ("lse", c_void_p), ("pre", c_void_p), ("stats", c_void_p),
-        ("x_stride", ctypes.c_longlong), ("xm_stride", ctypes.c_longlong), ("qkv_stride", ctypes.c_longlong),
-        ("a_stride", ctypes.c_longlong), ("lse_stride", ctypes.c_longlong), ("pre_stride", ctypes.c_longlong),
-        ("stats_stride", ctypes.c_longlong), ("g", c_void_p), ("dqkv", c_void_p), ("da", c_void_p), ("dscr", c_void_p),
-        ("C", c_int), ("L", c_int), ("P", c_int), ("NP", c_int), ("layers", c_int), ("rows", c_int), ("scale", c_float), ("prio", c_int),
-        ("dbg", c_void_p),
-    ]
-
-
 class BallMulti(ctypes.Structure):
     """struct ppt_ball_multi (include/ppt_hip.h)."""
     _fields_ = [("n", c_int), ("r2", c_float * 3), ("K", c_int * 3), ("idx", c_void_p * 3), ("gxyz", c_void_p * 3)]
@@ -100,8 +86,6 @@ _SIGNATURES = {
     "ppt_vit_mlp_retile": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ppt_vit_mlp_bf16": (c_int, [ctypes.POINTER(VitMlpParams), c_void_p]),
     "ppt_rowgemm_bf16": (c_int, [ctypes.POINTER(RowGemmParams), c_void_p]),
-    "ppt_text_tower_fwd_bf16": (c_int, [ctypes.POINTER(TextTowerParams), c_void_p]),
-    "ppt_text_tower_bwd_bf16": (c_int, [ctypes.POINTER(TextTowerParams), c_void_p]),
     "ppt_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                   c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "ppt_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

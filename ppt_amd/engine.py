@@ -838,162 +838,6 @@ def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=No
     return out, saved
 
 
-# ---- the text tower as ONE persistent kernel per direction (csrc/text_tower.hip; bf16 mode) -----------------------------------
-# OFF by default (PPT_TEXT_FUSED=1 / model.fused_text_tower = True turn it on): measured on C2 (round 3, same box, interleaved):
-# the per-layer launches 3.40 ms per step, the fused kernels 4.93 ms.  The kernel holds only 20 CUs and is hardly stretched by the
-# point tower (4.0 ms alone for forward + backward, 4.9 beside it, where the per-layer chain goes 1.54 -> ~3.4 ms), but a workgroup
-# that owns whole prompts must pull ALL of a layer's weights (6.3 MB) through ONE CU's L2 -> register path: 75-80 GB/s measured,
-# i.e. >= 75 us per layer and direction before any LayerNorm / attention / barrier time (in-kernel stamps, tools/
-# text_tower_stamps.py: 170 us per layer now) -- against 64 us for the per-layer launches, which spread every GEMM's weight
-# columns over ~100 CUs.  Kept as a tested alternative (tests/test_model_gpu.py); DESIGN.md §7 has the numbers.
-TEXT_FUSED = os.environ.get("PPT_TEXT_FUSED", "0") != "0"
-TEXT_TILE_ROWS = 64               # rows of a workgroup's tile (csrc/text_tower.hip: MT)
-
-
-def text_group_size(C, L, P):
-    """Prompts per workgroup of the fused tower: as many whole prompts as fit in a 64-row tile beside the private copy of the
-    P shared rows (0 when not even one fits)."""
-    own = L - P
-    return max(0, min(C, (TEXT_TILE_ROWS - P) // own)) if own > 0 else 0
-
-
-def text_tower_fusable(sd, wc, heads, layers, C, L, P):
-    w = sd["transformer.resblocks.0.attn.in_proj_weight"]
-    return (wc.dtype == torch.bfloat16 and w.is_cuda and tuple(w.shape) == (1536, 512) and heads == 8
-            and tuple(sd["transformer.resblocks.0.mlp.c_fc.weight"].shape) == (2048, 512) and text_group_size(C, L, P) >= 1)
-
-
-def _tile_units(blocks, halves):
-    """[U, 512 (out), 512 (in)] bf16 -> [8 wave, U, 64 pieces, 64 lane, 8]: piece[lane = 16 kg + i] =
-    W[64 wave + 16 tile + i][32 kstep + 8 kg .. + 8) (include/ppt_hip.h: ppt_text_tower_params.wfrag).  Piece order inside a unit:
-    [k-step 16][tile 4]; for the units listed in `halves` (run as two passes of two column tiles): [pass 2][k-step 16][tile 2],
-    tile = 2 pass + t."""
-    U = blocks.shape[0]
-    x = blocks.reshape(U, 8, 4, 16, 16, 4, 8)                    # n -> (wave, tile, i); k -> (kstep, kg, e)
-    x = x.permute(1, 0, 4, 2, 5, 3, 6).contiguous()              # (wave, U, kstep, tile, kg, i, e)
-    if halves:
-        idx = torch.tensor(sorted(halves), device=x.device)
-        h = x[:, idx].reshape(8, len(halves), 16, 2, 2, 4, 16, 8)        # tile -> (pass, t)
-        x[:, idx] = h.permute(0, 1, 3, 2, 4, 5, 6, 7).reshape(8, len(halves), 16, 4, 4, 16, 8)   # (pass, kstep, t) flattened back
-    return x
-
-
-def text_tower_weights(sd, wc, layers):
-    """The frozen tower's weights in the order the fused kernels' waves consume them (made once; re-made if a weight's version
-    changes), plus the stacked LayerNorm parameters and biases."""
-    names = [f"transformer.resblocks.{i}." for i in range(layers)]
-    keys = ("attn.in_proj_weight", "attn.out_proj.weight", "mlp.c_fc.weight", "mlp.c_proj.weight", "attn.in_proj_bias",
-            "attn.out_proj.bias", "mlp.c_fc.bias", "mlp.c_proj.bias", "ln_1.weight", "ln_1.bias", "ln_2.weight", "ln_2.bias")
-    tensors = tuple(sd[p + k] for p in names for k in keys)
-
-    def make():
-        fwd, bwd = [], []
-        for p in names:
-            w_in, w_out = wc.get(sd[p + "attn.in_proj_weight"]), wc.get(sd[p + "attn.out_proj.weight"])
-            w_fc, w_pr = wc.get(sd[p + "mlp.c_fc.weight"]), wc.get(sd[p + "mlp.c_proj.weight"])
-            f = [w_in[512 * u:512 * (u + 1)] for u in range(3)] + [w_out]
-            for j in range(4):
-                f += [w_fc[512 * j:512 * (j + 1)], w_pr[:, 512 * j:512 * (j + 1)]]
-            fwd.append(torch.stack([t.contiguous() for t in f]))
-            # dX = dY @ W: the unit's [out, in] block is W^T's
-            b = []
-            for j in range(4):
-                b += [w_pr[:, 512 * j:512 * (j + 1)].t(), w_fc[512 * j:512 * (j + 1)].t()]
-            b += [w_out.t()] + [w_in[512 * u:512 * (u + 1)].t() for u in range(3)]
-            bwd.append(torch.stack([t.contiguous() for t in b]))
-        dev = fwd[0].device
-
-        def stream(per_layer, half_units):
-            halves = [12 * i + u for i in range(len(per_layer)) for u in half_units]
-            t = _tile_units(torch.cat(per_layer, 0), halves)     # [8, layers * 12, ...]
-            flat = t.reshape(-1)
-            pad = torch.zeros(32 * 1024, dtype=flat.dtype, device=dev)     # (the ring requests DEPTH pieces past the end)
-            return torch.cat([flat, pad])
-        # two-pass units: forward c_fc slabs (units 4, 6, 8, 10); backward (g W_proj) slabs (units 0, 2, 4, 6)
-        out = dict(wfrag=stream(fwd, (4, 6, 8, 10)), wfrag_bwd=stream(bwd[::-1], (0, 2, 4, 6)))
-        for k, nm in (("ln1_w", "ln_1.weight"), ("ln1_b", "ln_1.bias"), ("ln2_w", "ln_2.weight"), ("ln2_b", "ln_2.bias"),
-                      ("b_in", "attn.in_proj_bias"), ("b_out", "attn.out_proj.bias"), ("b_fc", "mlp.c_fc.bias"), ("b_proj", "mlp.c_proj.bias")):
-            out[k] = torch.stack([sd[p + nm].detach().float() for p in names]).contiguous()
-        return out
-    return wc.derived(("text_tower_fused", layers), tensors, make)
-
-
-def text_tower_forward_fused(sd, wc, x0, C, L, P, heads, layers, save, eot_rows):
-    """encode_text on the fused kernel: x0 [G * RW, 512] f32 in the GROUPED row layout (PromptLearner.row_layout(group=NP)),
-    eot_rows [C] the rows of the EOT tokens in it -> (text features [C, E] f32, saved | None)."""
-    NP = text_group_size(C, L, P)
-    RW = P + NP * (L - P)
-    G = (C + NP - 1) // NP
-    rows = G * RW
-    assert x0.shape == (rows, 512) and x0.dtype == torch.float32 and x0.is_contiguous()
-    dev = x0.device
-    W = text_tower_weights(sd, wc, layers)
-    T = torch.bfloat16
-    n = layers if save else 1
-    X = torch.empty((n, rows, 512), dtype=torch.float32, device=dev)
-    XM = torch.empty((n, rows, 512), dtype=torch.float32, device=dev)
-    QKV = torch.empty((n, rows, 1536), dtype=T, device=dev)
-    A = LSE = PRE = ST = None
-    if save:
-        A = torch.empty((n, rows, 512), dtype=T, device=dev)
-        LSE = torch.empty((n, rows, 8), dtype=torch.float32, device=dev)
-        PRE = torch.empty((n, rows, 2048), dtype=T, device=dev)
-        ST = torch.empty((n, 4, rows), dtype=torch.float32, device=dev)
-    s_ = (lambda t: t.stride(0)) if save else (lambda t: 0)
-    prm = ops.text_tower_params(
-        x0=x0, wfrag=W["wfrag"], wfrag_bwd=W["wfrag_bwd"], ln1_w=W["ln1_w"], ln1_b=W["ln1_b"], ln2_w=W["ln2_w"], ln2_b=W["ln2_b"],
-        b_in=W["b_in"], b_out=W["b_out"], b_fc=W["b_fc"], b_proj=W["b_proj"], x=X, xmid=XM, qkv=QKV, a=A, lse=LSE, pre=PRE, stats=ST,
-        x_stride=s_(X), xm_stride=s_(XM), qkv_stride=s_(QKV), a_stride=s_(A) if A is not None else 0,
-        lse_stride=s_(LSE) if LSE is not None else 0, pre_stride=s_(PRE) if PRE is not None else 0,
-        stats_stride=s_(ST) if ST is not None else 0, g=None, dqkv=None, da=None, dscr=None,
-        C=C, L=L, P=P, NP=NP, layers=layers, rows=rows, scale=ATTN_SCALE, prio=0)
-    # executed FLOPs: every row of every tile is computed (G * 64 rows), 12 units of 64 x 512 x 512 + the attention
-    flops = layers * G * (12 * 2.0 * 64 * 512 * 512 + 8 * 3 * 2.0 * 2 * 32 * 32 * 64)
-    ops.text_tower_fused("fwd", prm, flops)
-    x_last = X[n - 1]
-    x_eot = x_last.index_select(0, eot_rows)
-    hn, meanf, rstdf = ops.layernorm_fwd(x_eot, sd["ln_final.weight"], sd["ln_final.bias"], torch.float32, save_stats=save)
-    wc32 = _f32_cache(wc)
-    out = ops.rows_matmul(hn, wc32.get(sd["text_projection"], "f32")) if hn.shape[0] <= 256 else None
-    if out is None:
-        out = ops.gemm(hn, wc32.get(sd["text_projection"], "wt"), out_dtype=torch.float32)
-    saved = None
-    if save:
-        saved = dict(fused=True, x0=x0, X=X, XM=XM, QKV=QKV, A=A, LSE=LSE, PRE=PRE, ST=ST, x_eot=x_eot, meanf=meanf, rstdf=rstdf,
-                     rows=eot_rows, C=C, L=L, P=P, NP=NP, M=rows, layers=layers, W=512, rows_mode=True)
-    return out, saved
-
-
-def text_tower_backward_fused(sd, wc, s, dout):
-    """Input gradient of the fused tower: dout [C, E] -> d x0 [G * RW, 512] f32 in the grouped row layout; every workgroup's copy
-    of the shared rows holds ITS partial (ops.prompt_rows_bwd sums them onto the tokens)."""
-    layers, rows = s["layers"], s["M"]
-    dev = dout.device
-    W = text_tower_weights(sd, wc, layers)
-    wc32 = _f32_cache(wc)
-    d_hn = ops.rows_matmul(dout.contiguous(), wc32.get(sd["text_projection"], "wt")) if dout.shape[0] <= 256 else None
-    if d_hn is None:
-        d_hn = ops.gemm(dout.contiguous(), wc32.get(sd["text_projection"], "w"), out_dtype=torch.float32)
-    d_eot, _, _ = ops.layernorm_bwd(d_hn, s["x_eot"], sd["ln_final.weight"], s["meanf"], s["rstdf"])
-    g = torch.zeros((rows, 512), dtype=torch.float32, device=dev)
-    g.index_copy_(0, s["rows"], d_eot)
-    T = torch.bfloat16
-    DQKV = torch.empty((rows, 1536), dtype=T, device=dev)
-    DA = torch.empty((rows, 512), dtype=T, device=dev)
-    DS = torch.empty((rows, 512), dtype=torch.float32, device=dev)
-    X, XM, QKV, A, LSE, PRE, ST = s["X"], s["XM"], s["QKV"], s["A"], s["LSE"], s["PRE"], s["ST"]
-    prm = ops.text_tower_params(
-        x0=s["x0"], wfrag=W["wfrag"], wfrag_bwd=W["wfrag_bwd"], ln1_w=W["ln1_w"], ln1_b=W["ln1_b"], ln2_w=W["ln2_w"], ln2_b=W["ln2_b"],
-        b_in=W["b_in"], b_out=W["b_out"], b_fc=W["b_fc"], b_proj=W["b_proj"], x=X, xmid=XM, qkv=QKV, a=A, lse=LSE, pre=PRE, stats=ST,
-        x_stride=X.stride(0), xm_stride=XM.stride(0), qkv_stride=QKV.stride(0), a_stride=A.stride(0), lse_stride=LSE.stride(0),
-        pre_stride=PRE.stride(0), stats_stride=ST.stride(0), g=g, dqkv=DQKV, da=DA, dscr=DS,
-        C=s["C"], L=s["L"], P=s["P"], NP=s["NP"], layers=layers, rows=rows, scale=ATTN_SCALE, prio=0)
-    G = rows // (s["P"] + s["NP"] * (s["L"] - s["P"]))
-    flops = layers * G * (12 * 2.0 * 64 * 512 * 512 + 8 * 3 * 5.0 * 2 * 32 * 32 * 64)
-    ops.text_tower_fused("bwd", prm, flops)
-    return g
-
-
 _F32_CACHES = {}
 
 

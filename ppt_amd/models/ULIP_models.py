@@ -255,18 +255,15 @@ class PromptLearner(nn.Module):
     def eot_positions(self):
         return self.tokenized_prompts.argmax(dim=-1)
 
-    def row_layout(self, positional, L, P, group=0):
+    def row_layout(self, positional, L, P):
         """Constants of the text tower's input in its row layout for ops.prompt_rows / prompt_rows_bwd:
         base [M, W] = frozen embedding + positional embedding per row, slot [M] i32 = index of the learnable token that
         overwrites the row (-1: none), pos_rows [M, W] = positional embedding per row, rows_of [n_tok, C] i32 = the rows each
         learnable token appears in (ascending, -1 padded), M, eot_rows [C] i64 = the row of every class's EOT token.
-        group == 0: engine.text_tower_forward's layout -- P shared rows + C (L - P) own rows, or C L rows when P == 0.
-        group == NP > 0: the fused tower's GROUPED layout (csrc/text_tower.hip) -- workgroup g owns prompts g NP .. g NP + NP - 1
-        and its own copy of the P shared rows: rows [g RW, g RW + P) = positions 0 .. P-1, then prompt g NP + n at rows
-        g RW + P + n (L - P) ...; RW = P + NP (L - P); rows of a short last group stay unused.
-        Cached per (embedding, positional embedding, L, P, group)."""
+        Layout (engine.text_tower_forward): P shared rows + C (L - P) own rows, or C L rows when P == 0.
+        Cached per (embedding, positional embedding, L, P)."""
         emb = self.embedding
-        key = (emb.data_ptr(), emb._version, positional.data_ptr(), positional._version, L, P, self.class_name_position, group)
+        key = (emb.data_ptr(), emb._version, positional.data_ptr(), positional._version, L, P, self.class_name_position)
         cache = self.__dict__.setdefault("_layout_caches", {})
         if key not in cache:
             dev = self.learnable_tokens.device
@@ -276,15 +273,7 @@ class PromptLearner(nn.Module):
             tok_of[cls, pos] = torch.arange(n, dtype=torch.int32).view(1, n).expand(C, n)
             eot = self.tokenized_prompts.argmax(dim=-1).tolist()
             rows, eot_rows = [], [0] * C                 # rows: (class, position) or None for an unused row
-            if group:
-                RW = P + group * (L - P)
-                for g0 in range(0, C, group):
-                    blk = [(g0, q) for q in range(P)]
-                    for c in range(g0, min(C, g0 + group)):
-                        eot_rows[c] = len(rows) + len(blk) + (eot[c] - P)
-                        blk += [(c, q) for q in range(P, L)]
-                    rows += blk + [None] * (RW - len(blk))
-            elif P:
+            if P:
                 rows += [(0, q) for q in range(P)]
                 for c in range(C):
                     eot_rows[c] = len(rows) + (eot[c] - P)
@@ -416,10 +405,7 @@ class _TextTowerTokensFn(torch.autograd.Function):
         pre = pl.shared_prefix() if model.share_text_prefix else 0
         if not (0 < pre < eff and C > 1):
             pre = 0
-        # bf16 mode: the whole tower as ONE persistent kernel per direction (csrc/text_tower.hip) on the grouped row layout
-        fused = tokens.is_cuda and model.fused_text_tower and engine.text_tower_fusable(sd, cache, heads, layers, C, eff, pre)
-        grp = engine.text_group_size(C, eff, pre) if fused else 0
-        base, slot, pos_rows, rows_of, M, eot_rows = pl.row_layout(sd["positional_embedding"], eff, pre, group=grp)
+        base, slot, pos_rows, rows_of, M, eot_rows = pl.row_layout(sd["positional_embedding"], eff, pre)
         tok = tokens.detach().float().contiguous()
 
         prio = model.chain_priority()
@@ -427,11 +413,9 @@ class _TextTowerTokensFn(torch.autograd.Function):
         def run(tk):
             with ops.wave_priority(prio):
                 x0 = ops.prompt_rows(base, slot, tk, pos_rows)
-                if fused:
-                    return engine.text_tower_forward_fused(sd, cache, x0, C, eff, pre, heads, layers, save, eot_rows)
                 return engine.text_tower_forward(sd, cache, None, eot, heads, layers, save, eff_len=eff, prefix=pre, rows_in=(x0, C, Lfull))
 
-        key = ("text_fwd_tok", tuple(tok.shape), save, eff, pre, cache.dtype, prio, grp)
+        key = ("text_fwd_tok", tuple(tok.shape), save, eff, pre, cache.dtype, prio)
         gc = model._graphs
         ctx.model, ctx.graph, ctx.rows_of, ctx.n_tok = model, None, rows_of, tok.shape[0]
         if tok.is_cuda and model.use_hip_graphs and ops.profiler is None and gc.ready(key):
@@ -464,8 +448,6 @@ class _TextTowerTokensFn(torch.autograd.Function):
 
         def run(d, saved):
             with ops.wave_priority(prio):
-                if saved.get("fused"):
-                    return ops.prompt_rows_bwd(engine.text_tower_backward_fused(sd, cache, saved, d), rows_of, n_tok)
                 return ops.prompt_rows_bwd(engine.text_tower_backward(sd, cache, saved, d), rows_of, n_tok)
 
         if ctx.graph is None:
@@ -598,9 +580,6 @@ class ULIP_WITH_IMAGE(nn.Module):
         # positions in front of the class name are the same in every prompt: computed once (PPT_SHARE_TEXT_PREFIX=0: A/B runs)
         self.share_text_prefix = os.environ.get("PPT_SHARE_TEXT_PREFIX", "1") != "0"
         self.text_f16 = os.environ.get("PPT_TEXT_F16", "1") != "0"
-        # bf16 mode: the text tower forward / backward as one persistent kernel each (csrc/text_tower.hip).  Off by default:
-        # slower than the per-layer launches on every configuration measured (engine.TEXT_FUSED has the numbers)
-        self.fused_text_tower = engine.TEXT_FUSED
         self._chain_prio = None
         self._handoff = False               # inside forward_loss: graph outputs go straight into the next graph's input (no clone)
         self._handoff_grad = os.environ.get("PPT_HANDOFF", "1") != "0"

@@ -913,26 +913,6 @@ def adamw_step(p, g, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, s
                                          int(step), _stream()), "ppt_adamw_step")
 
 
-def text_tower_params(**kw):
-    """struct ppt_text_tower_params from keyword arguments (tensors become device pointers, None a null pointer)."""
-    from ._lib import TextTowerParams
-    p = TextTowerParams()
-    for k, v in kw.items():
-        setattr(p, k, _p(v) if (isinstance(v, torch.Tensor) or v is None) else v)
-    return p
-
-
-def text_tower_fused(direction, params, flops=0.0):
-    """ppt_text_tower_fwd_bf16 / ppt_text_tower_bwd_bf16: the whole CLIP text tower (or its input-gradient backward) as one
-    persistent launch (csrc/text_tower.hip)."""
-    fn = _lib.lib().ppt_text_tower_fwd_bf16 if direction == "fwd" else _lib.lib().ppt_text_tower_bwd_bf16
-    if profiler is not None:
-        profiler.begin("gemm_bf16", flops, "ppt_text_tower_%s_bf16" % direction)
-    _lib.check(fn(ctypes.byref(params), _stream()), "ppt_text_tower_%s_bf16" % direction)
-    if profiler is not None:
-        profiler.end()
-
-
 def prompt_rows(base, slot, tokens, pos_rows):
     """out[i] = tokens[slot[i]] + pos_rows[i] where slot[i] >= 0, else base[i] (ppt_prompt_rows)."""
     _chk(base, torch.float32, "base"); _chk(slot, torch.int32, "slot"); _chk(tokens, torch.float32, "tokens")

@@ -1116,35 +1116,6 @@ def test_prompt_rows_are_the_prompt_learner_splice(ops, position):
         assert (dt - tok.grad).abs().max().item() < 1e-4 * max(1.0, tok.grad.abs().max().item())
         eot = m.tokenized_prompts.argmax(-1).cuda()
         assert torch.equal(got[eot_rows], prompts.detach()[torch.arange(C, device="cuda"), eot])
-        # the GROUPED layout of the fused text tower (csrc/text_tower.hip): every workgroup's rows = its copy of the shared
-        # positions + its prompts' own positions; unused rows of a short last group are zeros
-        from ppt_amd import engine
-        NP = engine.text_group_size(C, L, Puse)
-        baseg, slotg, posg, rows_ofg, Mg, eotg = pl.row_layout(m.positional_embedding, L, Puse, group=NP)
-        RW = Puse + NP * (L - Puse)
-        assert Mg == ((C + NP - 1) // NP) * RW
-        gotg = ops.prompt_rows(baseg, slotg, tok.detach().contiguous(), posg)
-        pd = prompts.detach()
-        for g0 in range(0, C, NP):
-            r0 = (g0 // NP) * RW
-            assert torch.equal(gotg[r0:r0 + Puse], pd[g0, :Puse])
-            for n_, c_ in enumerate(range(g0, min(C, g0 + NP))):
-                assert torch.equal(gotg[r0 + Puse + n_ * (L - Puse):r0 + Puse + (n_ + 1) * (L - Puse)], pd[c_, Puse:L])
-            used = Puse + (min(C, g0 + NP) - g0) * (L - Puse)
-            assert gotg[r0 + used:r0 + RW].abs().sum().item() == 0
-        assert torch.equal(gotg[eotg], pd[torch.arange(C, device="cuda"), eot])
-        # gradient: a row gradient that is the SAME for every copy of a shared position divided by the number of copies sums
-        # back to the plain layout's token gradient
-        grg = torch.zeros((Mg, 512), device="cuda")
-        for g0 in range(0, C, NP):
-            r0 = (g0 // NP) * RW
-            for n_, c_ in enumerate(range(g0, min(C, g0 + NP))):
-                src = (Puse + c_ * (L - Puse)) if Puse else c_ * L
-                grg[r0 + Puse + n_ * (L - Puse):r0 + Puse + (n_ + 1) * (L - Puse)] = gr[src:src + (L - Puse)] if Puse else gr[src + Puse:src + L]
-            if Puse:
-                grg[r0:r0 + Puse] = gr[:Puse] / ((C + NP - 1) // NP)
-        dtg = ops.prompt_rows_bwd(grg.contiguous(), rows_ofg, tok.shape[0])
-        assert (dtg - tok.grad).abs().max().item() < 1e-4 * max(1.0, tok.grad.abs().max().item())
 
 
 # ------------------------------------------------------------------ fused ViT MLP (csrc/mlp_fused.hip)

@@ -56,7 +56,10 @@ __device__ __forceinline__ int v_off(int key, int dbyte) { return key * 128 + (d
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 constexpr int NUM_RECORDS = 0x40000000;                       // 1 GiB window per descriptor (the SGPR offset is not range-checked)
 constexpr unsigned OOB = 0x7ffffff0u;
-constexpr int AUX_NT = 2;                                     // re-reads of this workgroup's own earlier stores: served by L2
+#ifndef PPT_TT_AUX
+#define PPT_TT_AUX 2
+#endif
+constexpr int AUX_NT = PPT_TT_AUX;                            // re-reads of this workgroup's own earlier stores: served by L2
 __device__ __forceinline__ rsrc_t mk_rsrc(const void *p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, NUM_RECORDS, 0x00020000); }
 template <int AUX> __device__ __forceinline__ uint4 bld16(rsrc_t r, unsigned voff, unsigned soff)
 {
@@ -85,7 +88,11 @@ __device__ __forceinline__ void bst4(rsrc_t r, unsigned voff, unsigned soff, flo
 
 // LDS-only synchronisation: wait for this wave's LDS traffic, then the barrier -- NOT __syncthreads(), whose vmcnt(0) would
 // drain the weight ring at every phase boundary
+#ifdef PPT_TT_FULLBAR
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#else
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 // the three points per layer where other waves' GLOBAL stores are read back (qkv, x_mid, x_out): stores complete, then barrier
 // wave-private LDS hand-over (a wave's own writes read back by itself): the LDS executes one wave's instructions in order, so no
 // wait is needed -- only the COMPILER must not move the reads above the writes (the accesses go through differently typed pointers)
@@ -112,6 +119,16 @@ template <int NT> __device__ __forceinline__ void acc_zero(AccT<NT> &a)
 // a per-phase copy of a lane constant that hipcc cannot see through: everything derived from it is computed where it is used
 // instead of being hoisted out of the layer loop and kept (or spilled) for the whole kernel
 #define OPAQUE(x) asm volatile("" : "+v"(x))
+// Wait states behind the LAST matrix instruction of an accumulation chain, fenced against the scheduler.  Found the hard way
+// (tools/text_fused_eval_check.py: run-to-run differences in element 0 of four lanes of ONE 16 x 16 tile, any layer): where
+// hipcc (ROCm 7.2) lets the final v_mfma_f32_16x16x32_bf16 of a chain write a NEW destination (D != C), it may reuse the old
+// accumulator register two instructions later -- here a v_mov of an epilogue index into C's first register behind one more MFMA,
+// a buffer_load and `s_nop 0` -- while the matrix pipe has not yet read SrcC for its last pass (columns 12-15: exactly the lanes
+// that came out wrong, and only when the pipe was busy with the SIMD's other wave).  16 wait states cover the four passes.
+#ifndef PPT_TT_TAIL_ASM
+#define PPT_TT_TAIL_ASM "s_nop 7\n\ts_nop 7"
+#endif
+#define MFMA_TAIL() do { __builtin_amdgcn_sched_barrier(0); asm volatile(PPT_TT_TAIL_ASM); __builtin_amdgcn_sched_barrier(0); } while (0)
 // diagnostic stamps (p.dbg != NULL only): shader clock of workgroup 0 / wave 0 at the phase boundaries of layer LSTAMP
 #define STAMP(i) do { if (p.dbg && blockIdx.x == 0 && w == 0 && l == LSTAMP && lane == 0) p.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
 constexpr int LSTAMP = 1;
@@ -153,6 +170,7 @@ __device__ __forceinline__ void gemm_pass(AccT<NA> &acc, const unsigned char *im
             ring[(NT * s + t) % DEPTH] = ws_next(ws);
         }
     }
+    MFMA_TAIL();
 }
 __device__ __forceinline__ void gemm_unit(Acc &acc, const unsigned char *img, bf16x8_t (&ring)[DEPTH], WStream &ws, const int l15,
                                           const int kg)
@@ -330,7 +348,9 @@ __global__ __launch_bounds__(512, 2) void text_tower_fwd_kernel(const ppt_text_t
         // ---- attention of head w over the workgroup's rows (scores never leave registers).  The weight ring is given up for
         // the phase -- its DEPTH pieces are requested again behind it -- so that its registers are free here: the attention's
         // fragments and the ring together spilled, and every scratch reload is a vmcnt(0)
+#ifndef PPT_TT_NOGIVEUP
         ws.soff -= DEPTH * 1024;
+#endif
         {
             int r31 = lane & 31, hh = lane >> 5, lane_ = lane;
             OPAQUE(r31); OPAQUE(hh); OPAQUE(lane_);
@@ -376,6 +396,7 @@ __global__ __launch_bounds__(512, 2) void text_tower_fwd_kernel(const ppt_text_t
 #pragma unroll
                         for (int kk = 0; kk < 4; ++kk) sc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[sub][kk], qf[kk], sc[sub], 0, 0, 0);
                     }
+                MFMA_TAIL();
                 unsigned am = amask[qt];
                 asm volatile("" : "+v"(am));          // (opaque: keeps hipcc from hoisting 64 loop-invariant compares into SGPR pairs)
                 float mx = -INFINITY;
@@ -419,6 +440,7 @@ __global__ __launch_bounds__(512, 2) void text_tower_fwd_kernel(const ppt_text_t
                             }
                         }
                     }
+                MFMA_TAIL();
                 const float inv = 1.0f / lt;
                 const bool qok = qrow < nrow;
 #pragma unroll
@@ -434,8 +456,10 @@ __global__ __launch_bounds__(512, 2) void text_tower_fwd_kernel(const ppt_text_t
                 if (save) bst4(rLSE, (qok && hh == 0) ? (unsigned)(qrow * (NH * 4) + w * 4) : OOB, lse_soff, (mn + __log2f(lt)) * 0.6931471805599453f);
             }
         }
+#ifndef PPT_TT_NOGIVEUP
 #pragma unroll
         for (int i = 0; i < DEPTH; ++i) ring[i] = ws_next(ws);
+#endif
         STAMP(5);
         lds_barrier();                                         // attention output image complete; V images dead
         STAMP(6);
@@ -853,6 +877,7 @@ __global__ __launch_bounds__(512, 2) void text_tower_bwd_kernel(const ppt_text_t
                             sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(imQ, 32 * qt + r31, 2 * kk + hh), kf[kk], sa, 0, 0, 0);
                             dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(imD, 32 * qt + r31, 2 * kk + hh), vf[kk], dp, 0, 0, 0);
                         }
+                        MFMA_TAIL();
                         unsigned bm = (unsigned)(bmask >> (16 * pr)) & 0xffffu;
                         asm volatile("" : "+v"(bm));
 #pragma unroll
@@ -878,6 +903,7 @@ __global__ __launch_bounds__(512, 2) void text_tower_bwd_kernel(const ppt_text_t
                             }
                         }
                     }
+                MFMA_TAIL();
                 const unsigned ro = key < nrow ? (unsigned)(key * (3 * WD * 2)) : OOB;
 #pragma unroll
                 for (int dtile = 0; dtile < 2; ++dtile)
@@ -929,6 +955,7 @@ __global__ __launch_bounds__(512, 2) void text_tower_bwd_kernel(const ppt_text_t
                             sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(imQ, key, 2 * kk + hh), qfb[qt][kk], sa, 0, 0, 0);
                             dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, gfb[kk], dp, 0, 0, 0);
                         }
+                        MFMA_TAIL();
 #pragma unroll
                         for (int e = 0; e < 16; ++e) {
                             const float pv = ((am >> (16 * kt + e)) & 1u) ? __builtin_amdgcn_exp2f(fmaf(sa[e], c, -l2)) : 0.f;
@@ -942,6 +969,7 @@ __global__ __launch_bounds__(512, 2) void text_tower_bwd_kernel(const ppt_text_t
                                 dqt[dtile] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(imQ, 32 * kt + 16 * s + tr_row, tr_dbyte + 64 * dtile), df, dqt[dtile], 0, 0, 0);
                         }
                     }
+                MFMA_TAIL();
                 const unsigned ro = q < nrow ? (unsigned)(q * (3 * WD * 2)) + qcol : OOB;
 #pragma unroll
                 for (int dtile = 0; dtile < 2; ++dtile)
