@@ -27,7 +27,11 @@ class GraphedCall:
     def __init__(self, fn, inputs, pool=None):
         self.static_in = [t.clone() for t in inputs]
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, pool=pool):
+        # thread_local: only THIS thread's calls are checked against the capture.  Under a process group RCCL's watchdog thread
+        # polls the events of earlier collectives (the DDP-constructor broadcast, the previous step's all-reduce); in the default
+        # "global" mode such a query during a capture aborts the process with hipErrorStreamCaptureUnsupported (seen once the
+        # constructor broadcast existed: tests/dist_single_rank.py, head_type 3)
+        with torch.cuda.graph(self.graph, pool=pool, capture_error_mode="thread_local"):
             self.outputs, self.keepalive = fn(*self.static_in)
 
     def pool(self):

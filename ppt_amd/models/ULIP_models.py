@@ -470,16 +470,16 @@ class _TextTowerTokensFn(torch.autograd.Function):
 
 class _MatmulNT(torch.autograd.Function):
     """a [M,K] @ b[N,K]^T with fp32 results.  prec = torch.float32: fp32 operands on the fp32 MFMA (the classification
-    heads: projection and logits of a few dozen rows); prec = torch.bfloat16: bf16 operands, fp32 accumulation -- the
-    per-POINT head of part segmentation (32 768 rows x 50 parts) in the bf16 performance mode, where the fp32 MFMA
-    (1/16 of the bf16 rate) cost 1.06 ms of a 14 ms step."""
+    heads: projection and logits of a few dozen rows); prec = torch.float16 / torch.bfloat16: 16-bit operands, fp32
+    accumulation -- the per-POINT head of part segmentation (32 768 rows x 50 parts) in the performance mode, where the fp32
+    MFMA (1/16 of the 16-bit rate) cost 1.06 ms of a 14 ms step."""
 
     @staticmethod
     def forward(ctx, a, b, prec):
         a, b = a.contiguous().float(), b.contiguous().float()
         ctx.save_for_backward(a, b)
-        ctx.prec = prec if (prec == torch.bfloat16 and a.shape[1] % 8 == 0) else torch.float32
-        if ctx.prec == torch.bfloat16:
+        ctx.prec = prec if (prec in ops.HALF and a.shape[1] % 8 == 0) else torch.float32
+        if ctx.prec in ops.HALF:
             return ops.gemm(ops.convert(a, prec), ops.convert(b, prec), out_dtype=torch.float32)
         return ops.gemm(a, b, out_dtype=torch.float32)
 
@@ -488,8 +488,8 @@ class _MatmulNT(torch.autograd.Function):
         a, b = ctx.saved_tensors
         dc = dc.contiguous().float()
         da = db = None
-        T = ctx.prec if ctx.prec == torch.bfloat16 else torch.float32
-        mult = 8 if T == torch.bfloat16 else 4
+        T = ctx.prec if ctx.prec in ops.HALF else torch.float32
+        mult = 8 if T in ops.HALF else 4
         if ctx.needs_input_grad[0]:                      # dA[M,K] = dC[M,N] @ B[N,K]; N padded to the chunk size
             n = dc.shape[1]
             dcp = dc if n % mult == 0 else torch.nn.functional.pad(dc, (0, mult - n % mult))
@@ -717,8 +717,9 @@ class ULIP_WITH_IMAGE(nn.Module):
 
     # ---- reference API ------------------------------------------------------------------------
     def _head_precision(self):
-        """fp32 head products, except the per-point head of part segmentation in the bf16 performance mode (_MatmulNT)."""
-        return self.precision if (self.task == 'partseg' and self.precision == torch.bfloat16) else torch.float32
+        """fp32 head products, except the per-point head of part segmentation in the performance mode: fp16 operands (_MatmulNT;
+        the logit scale is then applied to the PRODUCT, so that the operands stay far inside fp16's range)."""
+        return torch.float16 if (self.task == 'partseg' and self.precision == torch.bfloat16) else torch.float32
 
     def encode_text(self, prompts, tokenized_prompts=None):
         """ULIP_models.py:203-222: prompts [C,77,W] -> [C,embed_dim].  General in `prompts`, as the reference: the shared-prefix
@@ -787,7 +788,11 @@ class ULIP_WITH_IMAGE(nn.Module):
             text_embed = self._text_embed()
         logit_scale = self.logit_scale.exp()
         lead = pc_embed.shape[:-1]
-        logits = matmul_nt((logit_scale * pc_embed).reshape(-1, pc_embed.shape[-1]), text_embed, self._head_precision())
+        hp = self._head_precision()
+        if hp == torch.float16:       # ULIP_models.py:281 with the scale moved behind the product (same value, fp16-safe operands)
+            logits = logit_scale * matmul_nt(pc_embed.reshape(-1, pc_embed.shape[-1]), text_embed, hp)
+        else:
+            logits = matmul_nt((logit_scale * pc_embed).reshape(-1, pc_embed.shape[-1]), text_embed, hp)
         return logits.view(*lead, -1)
 
     def forward_loss(self, pc, labels, smoothing):

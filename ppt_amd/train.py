@@ -173,6 +173,8 @@ def broadcast_module_states(model, process_group=None, src=0, chunk_bytes=256 <<
                         t.copy_(flat[off:off + t.numel()].view_as(t))
                         off += t.numel()
                     i = j
+    if calls and torch.cuda.is_available():
+        torch.cuda.synchronize()             # (the collectives are complete before any hipGraph capture can begin)
     return calls
 
 

@@ -3,12 +3,12 @@
 Tolerances (stated, per north_star "logits and gradients within a stated fp32 tolerance"):
   parity mode (fp32 MFMA):  logits |err| <= 2e-3 absolute on |logits| <= ~45 (4e-5 relative),
                             loss 1e-4, gradients 1e-3 relative (L2), BN running stats 1e-5;
-  performance mode (bf16 operands, fp32 accumulate): logits 1.0 absolute on |logits| <= ~45 (2e-2 of the
-                            range; measured 0.2-0.4), gradients 1e-1 relative (L2; measured 1-5e-2).  bf16 has
-                            8 significand bits and the synthetic logits are large, so a logits error of ~0.3
-                            moves the softmax probabilities that drive EVERY gradient by tens of percent: the
-                            gradient tolerance is dominated by that amplification, not by the backward kernels
-                            (whose own error is what the parity mode bounds).
+  performance mode (set_precision(torch.bfloat16): 16-bit MFMA operands, fp32 accumulate -- IEEE half for the PointBERT
+                            tokenizer, the transformer blocks and the text tower since round 3, bf16 only where a
+                            tensor is not bounded by a normalisation: PointNet2 / PointMLP / the part-seg decoder):
+                            logits 0.1 absolute (measured 0.049; 0.28 with bf16 operands), loss 0.01 (0.0027),
+                            every gradient 1.5e-2 relative L2 (measured <= 0.85e-2; 5-6e-2 with bf16 operands);
+                            tools/bf16_error.py attributes the error stage by stage.
 FPS indices / kNN neighbour sets are bit-exact in both modes (they never leave fp32).
 """
 import os
@@ -53,7 +53,7 @@ def oracle_inputs():
     return torch.from_numpy(pc), start
 
 
-@pytest.mark.parametrize("precision,ltol,gtol", [(torch.float32, 2e-3, 1e-3), (torch.bfloat16, 0.5, 9e-2)])
+@pytest.mark.parametrize("precision,ltol,gtol", [(torch.float32, 2e-3, 1e-3), (torch.bfloat16, 0.1, 1.5e-2)])
 @pytest.mark.parametrize("head_type", [0, 1, 2, 3])
 def test_train_step_matches_oracle_and_golden(head_type, precision, ltol, gtol):
     from ppt_amd.train import Trainer
@@ -69,7 +69,7 @@ def test_train_step_matches_oracle_and_golden(head_type, precision, ltol, gtol):
     # ---- against the golden fixture captured from the reference
     err = np.abs(pred.detach().cpu().numpy() - g["logits"]).max()
     _bound(f"step h{head_type} {precision} logits abs err", err, ltol)
-    _bound(f"step h{head_type} {precision} loss abs err", abs(loss.item() - float(g["loss"])), 1e-3 if precision == torch.float32 else 0.1)
+    _bound(f"step h{head_type} {precision} loss abs err", abs(loss.item() - float(g["loss"])), 1e-3 if precision == torch.float32 else 0.01)
     # ---- gradients against the oracle (full tensors)
     masks = [(torch.from_numpy(a[0]), torch.from_numpy(a[1])) for a in g["dp_masks"]]
     nl = m.prompt_learner.name_lengths
@@ -103,7 +103,7 @@ def test_train_step_matches_oracle_and_golden(head_type, precision, ltol, gtol):
             assert d < 5e-5, (k, d)
 
 
-@pytest.mark.parametrize("precision,tol", [(torch.float32, 2e-3), (torch.bfloat16, 0.55)])
+@pytest.mark.parametrize("precision,tol", [(torch.float32, 2e-3), (torch.bfloat16, 0.1)])
 def test_eval_forward_matches_golden(precision, tol):
     g = np.load(os.path.join(G, "g_eval.npz"))
     f0 = np.load(os.path.join(G, "g_step_h0.npz"))
@@ -114,7 +114,7 @@ def test_eval_forward_matches_golden(precision, tol):
     with torch.no_grad():
         feat = m.point_encoder(pc.cuda())
         logits = m(pc.cuda())
-    ftol = 5e-4 if precision == torch.float32 else 0.03
+    ftol = 5e-4 if precision == torch.float32 else 6e-3
     _bound(f"eval {precision} feature abs err", np.abs(feat.cpu().numpy() - g["pc_feat"]).max(), ftol)
     _bound(f"eval {precision} logits abs err", np.abs(logits.cpu().numpy() - g["logits"]).max(), tol)
     # argmax agreement is what validate() (main_cls.py:266-270) consumes
