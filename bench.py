@@ -116,6 +116,48 @@ def parity_mode_rate(cfg, pc, label, extra, steps, burn_in=6):
             "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "burn_in": burn_in}
 
 
+def operand_formats(model_name):
+    """Which 16-bit operand format each part of the performance mode computes in (engine.BLOCKS_F16 / TOKENIZER_F16,
+    ULIP_WITH_IMAGE.text_f16): IEEE half where the operands are bounded by a normalisation, bf16 elsewhere; fp32 accumulation,
+    fp32 residual streams / statistics / heads everywhere."""
+    from ppt_amd import engine
+    text = "f16" if os.environ.get("PPT_TEXT_F16", "1") != "0" else "bf16"
+    blocks = "f16" if engine.BLOCKS_F16 else "bf16"
+    tok = "f16" if engine.TOKENIZER_F16 else "bf16"
+    if model_name == "ULIP_PointBERT":
+        return {"text_tower": text, "pointbert_tokenizer": tok, "transformer_blocks": blocks, "heads": "f32"}
+    if model_name == "ULIP_PointBERT_partseg":
+        return {"text_tower": text, "pointbert_tokenizer": tok, "transformer_blocks": blocks, "partseg_decoder": "bf16", "per_point_head": "f16"}
+    return {"text_tower": text, "point_encoder": "bf16", "heads": "f32"}
+
+
+def measured_parity():
+    """The performance mode's error on the golden train step (tests/golden/g_step_h0.npz: B = 4 x 1024 points, head_type 0,
+    logits / loss / token gradient captured from the upstream reference; fixtures are data, no oracle involved): what the
+    headline number's arithmetic is worth, measured in the same process."""
+    from ppt_amd import weights as W
+    from ppt_amd.train import Trainer
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g_step_h0.npz"))
+    m = build_model("modelnet40", 0)
+    m.prompt_learner.embedding = W.synth_prompt_embedding(40, seed=0).cuda()
+    m.use_hip_graphs = m.point_encoder.use_hip_graphs = False
+    m.overlap_text_tower = False
+    m.train()
+    pc, _ = W.synth_clouds(4, 1024, seed=77)
+    m.point_encoder.fps_start = torch.from_numpy(g["fps_start"]).cuda()
+    m.point_encoder.drop_path_factors = torch.from_numpy(g["dp_masks"]).cuda()
+    tr = Trainer(m, lr=3e-3, label_smoothing=0.2, distributed=False)
+    loss, pred = tr.step(torch.from_numpy(pc).cuda(), torch.from_numpy(g["labels"]).cuda())
+    torch.cuda.synchronize()
+    gt = m.prompt_learner.learnable_tokens.grad.detach().cpu().numpy()
+    gr = g["grad_prompt_learner.learnable_tokens"]
+    return {"fixture": "tests/golden/g_step_h0.npz (reference logits / loss / gradient, B = 4)",
+            "logits_abs_err": round(float(np.abs(pred.detach().float().cpu().numpy() - g["logits"]).max()), 4),
+            "logits_abs_max": round(float(np.abs(g["logits"]).max()), 1),
+            "loss_abs_err": round(abs(float(loss.item()) - float(g["loss"])), 5),
+            "token_grad_rel_l2": round(float(np.linalg.norm(gt - gr) / np.linalg.norm(gr)), 5)}
+
+
 def build_model(dataset="modelnet40", head_type=HEAD_TYPE, precision=torch.bfloat16, model="ULIP_PointBERT", task="cls"):
     from ppt_amd import weights as W
     from ppt_amd.models import ULIP_models as M
@@ -387,13 +429,18 @@ def main():
                "value": round(total / elapsed, 2), "unit": "point-clouds/s", "n_gpus": world, "steps": a.steps,
                "warmup": a.warmup, "burn_in": BURN_IN_STEPS, "ms_per_step": round(1e3 * elapsed / a.steps, 3),
                "ms_per_step_median": round(median_ms, 3), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "scaling": "weak", "vs_baseline": None,
+               "dtype": "f16" if set(operand_formats(cfg.get("model", "ULIP_PointBERT")).values()) <= {"f16", "f32"} else "f16/bf16",
+               "data": "synthetic",
                "config": {"workload": cfg["name"] + ", train-mode BN + DropPath, fwd + CE(ls 0.2) + bwd + AdamW",
+                          "operand_formats": operand_formats(cfg.get("model", "ULIP_PointBERT")),
                           "per_gpu_batch": PER_GPU_BATCH, "global_batch": PER_GPU_BATCH * world, "npoints": NPOINTS,
                           "classes": n_classes, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
                "roofline": roof}
         if world == 1 and not force_dist and not a.no_parity_mode:
             out["parity_mode"] = parity_mode_rate(cfg, pc, label, trainer.extra_inputs, max(3, a.steps // 2))
+            if a.config == "C2":
+                out["parity"] = measured_parity()
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         if world == 1 and not force_dist and a.config == "C2" and not a.no_secondary:

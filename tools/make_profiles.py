@@ -15,7 +15,7 @@ import pandas as pd
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # the bf16 MFMA GEMM family (what bench.py's roofline object is about): tile GEMMs, the fused mini-PointNet kernels, the
 # weight-stationary short-K linears and the fused ViT MLP
-GEMM_BF16 = r"gemm_kernel.*<unsigned short|mpn[134]_kernel|rowgemm_kernel|vit_mlp_kernel"
+GEMM_BF16 = r"gemm_kernel.*<(unsigned short|f16_t)|gemm_tn_kernel|mpn[134]_kernel|rowgemm_kernel|vit_mlp_kernel"
 CONFIGS = ("c2", "c3", "c4", "c5", "mlp")
 TRACE_STEPS = 40 + 5 + 10                   # burn-in + warm-up + timed steps of the traced command
 
@@ -62,37 +62,84 @@ def section(rnd, cfg, d, out):
           "| kernel | launches/step | avg us | ms/step | % of kernel time |", "|---|---|---|---|---|"]
     for nm, r in t.head(16).iterrows():
         md.append(f"| `{nm[:90]}` | {r['count'] / n:.1f} | {r['mean'] / 1e3:.1f} | {r['sum'] / n / 1e6:.3f} | {100 * r['sum'] / total:.1f} |")
-    if cfg == "c2" and os.path.isdir(os.path.join(d, "pmc_fetch")) and os.path.isdir(os.path.join(d, "pmc_write")):
-        def pmc(sub, name):
-            c = pd.read_csv(find(os.path.join(d, sub), "*counter_collection.csv"))
-            c = c[(c.Counter_Name == name) & c.Kernel_Name.str.contains(GEMM_BF16)]
-            return c.Counter_Value.sum(), len(c)
-        f, nf = pmc("pmc_fetch", "FETCH_SIZE")
-        w, nw = pmc("pmc_write", "WRITE_SIZE")
-        traffic = {
-            "kernel": "bf16 GEMM family (gemm_kernel* <unsigned short>, mpn1 / mpn3 / mpn4_kernel, rowgemm_kernel, vit_mlp_kernel)",
-            "command": "PPT_HIP_GRAPHS=0 rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) --output-format csv -- "
-                       "python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode",
-            "launches_counted": int(nf), "fetch_size_kb_sum": float(f), "write_size_kb_sum": float(w),
-            "correction": "gfx950: FETCH_SIZE reports 1/2 of wide coalesced reads -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact; both in KiB",
-            "fetch_bytes_per_launch": 2 * f * 1024 / nf, "write_bytes_per_launch": w * 1024 / nw,
-        }
-        traffic["hbm_bytes_per_launch"] = traffic["fetch_bytes_per_launch"] + traffic["write_bytes_per_launch"]
-        json.dump(traffic, open(os.path.join(out, f"{rnd}_gemm_hbm_traffic.json"), "w"), indent=1)
-        md += ["", f"`{rnd}_gemm_hbm_traffic.json`: HBM bytes of the GEMM family from two PMC passes -- {traffic['hbm_bytes_per_launch'] / 1e6:.1f} MB per launch "
-               f"({traffic['fetch_bytes_per_launch'] / 1e6:.1f} read + {traffic['write_bytes_per_launch'] / 1e6:.1f} written) over {nf} launches."]
+    pf, pw = os.path.join(d, f"pmc_{cfg}_fetch"), os.path.join(d, f"pmc_{cfg}_write")
+    if os.path.isdir(pf) and os.path.isdir(pw):
+        import re
+        def summ(sub):
+            return pd.read_csv(find(sub, "*counter_summary.csv"))
+        f, w = summ(pf), summ(pw)
+        f = f[f.Counter_Name == "FETCH_SIZE"].set_index("Kernel_Name")
+        w = w[w.Counter_Name == "WRITE_SIZE"].set_index("Kernel_Name")
+        fam_f, fam_w = f[f.index.str.contains(GEMM_BF16)], w[w.index.str.contains(GEMM_BF16)]
+        nf, nw = int(fam_f["count"].sum()), int(fam_w["count"].sum())
+        if cfg == "c2" and nf:
+            traffic = {
+                "kernel": "16-bit MFMA GEMM family (gemm_kernel* <unsigned short | f16_t>, gemm_tn_kernel, mpn1 / mpn3 / mpn4_kernel, rowgemm_kernel, vit_mlp_kernel)",
+                "command": "PPT_HIP_GRAPHS=0 rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) --output-format csv -- "
+                           "python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-secondary",
+                "launches_counted": nf, "fetch_size_kb_sum": float(fam_f["sum"].sum()), "write_size_kb_sum": float(fam_w["sum"].sum()),
+                "correction": "gfx950: FETCH_SIZE reports 1/2 of wide coalesced reads -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact; both in KiB",
+                "fetch_bytes_per_launch": 2 * float(fam_f["sum"].sum()) * 1024 / nf, "write_bytes_per_launch": float(fam_w["sum"].sum()) * 1024 / nw,
+            }
+            traffic["hbm_bytes_per_launch"] = traffic["fetch_bytes_per_launch"] + traffic["write_bytes_per_launch"]
+            json.dump(traffic, open(os.path.join(out, f"{rnd}_gemm_hbm_traffic.json"), "w"), indent=1)
+            md += ["", f"`{rnd}_gemm_hbm_traffic.json`: HBM bytes of the GEMM family from two PMC passes -- {traffic['hbm_bytes_per_launch'] / 1e6:.1f} MB per launch "
+                   f"({traffic['fetch_bytes_per_launch'] / 1e6:.1f} read + {traffic['write_bytes_per_launch'] / 1e6:.1f} written) over {nf} launches."]
+        # per-kernel HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, KiB -> bytes), joined with the kernel-trace average duration
+        dur = tr.groupby("nm").dur.mean()
+        rows = []
+        for k in f.index:
+            if k not in w.index:
+                continue
+            fb, wb = 2 * f.loc[k, "sum"] * 1024 / f.loc[k, "count"], w.loc[k, "sum"] * 1024 / w.loc[k, "count"]
+            us = dur.get(k, float("nan")) / 1e3
+            rows.append((k, int(f.loc[k, "count"]), fb, wb, us, (fb + wb) / (us * 1e-6) / 1e9 if us == us and us > 0 else float("nan")))
+        rows.sort(key=lambda r: -(r[2] + r[3]) * r[1])
+        pd.DataFrame(rows, columns=["kernel", "launches_counted", "fetch_bytes_per_launch(x2)", "write_bytes_per_launch", "avg_us(kernel trace)", "GB_per_s"]) \
+            .to_csv(os.path.join(out, f"{rnd}_{cfg}_hbm_per_kernel.csv"), index=False)
+        md += ["", f"`{rnd}_{cfg}_hbm_per_kernel.csv`: HBM bytes per launch of every kernel (PMC FETCH_SIZE x 2 + WRITE_SIZE, separate passes, eager launches) beside its "
+               "kernel-trace average duration.  Index kernels and the largest movers:", "",
+               "| kernel | read MB / launch | written MB / launch | avg us | GB/s | % of 8 TB/s |", "|---|---|---|---|---|---|"]
+        want = [r for r in rows if re.search(r"fps_kernel|knn_group|ball_query", r[0])] + [r for r in rows if not re.search(r"fps_kernel|knn_group|ball_query", r[0])][:8]
+        for k, n_, fb, wb, us, gbs in want:
+            md.append(f"| `{k[:80]}` | {fb / 1e6:.3f} | {wb / 1e6:.3f} | {us:.1f} | {gbs:.0f} | {gbs / 80:.2f} |")
+    psq, pg = os.path.join(d, f"pmc_{cfg}_sq"), os.path.join(d, f"pmc_{cfg}_grbm")
+    if os.path.isdir(psq) and os.path.isdir(pg):
+        sq = pd.read_csv(find(psq, "*counter_summary.csv")).pivot(index="Kernel_Name", columns="Counter_Name", values="sum")
+        cnt = pd.read_csv(find(psq, "*counter_summary.csv")).groupby("Kernel_Name")["count"].first()
+        gr = pd.read_csv(find(pg, "*counter_summary.csv"))
+        gr = gr[gr.Counter_Name == "GRBM_GUI_ACTIVE"].set_index("Kernel_Name")
+        rows = []
+        for k in sq.index:
+            if k not in gr.index or not re.search(GEMM_BF16 + r"|attn_", k):
+                continue
+            cyc = gr.loc[k, "sum"] / gr.loc[k, "count"] / 8.0              # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+            mf = sq.loc[k, "SQ_VALU_MFMA_BUSY_CYCLES"] / cnt[k]
+            rows.append((k, int(cnt[k]), cyc, mf, mf / (cyc * 1024.0) if cyc > 0 else float("nan"), sq.loc[k, "SQ_BUSY_CYCLES"] / cnt[k],
+                         sq.loc[k, "SQ_WAVE_CYCLES"] / cnt[k], sq.loc[k, "SQ_WAIT_ANY"] / cnt[k], sq.loc[k, "SQ_WAIT_INST_ANY"] / cnt[k],
+                         sq.loc[k, "SQ_ACTIVE_INST_ANY"] / cnt[k], sq.loc[k, "SQ_LDS_BANK_CONFLICT"] / cnt[k], sq.loc[k, "SQ_LDS_IDX_ACTIVE"] / cnt[k]))
+        rows.sort(key=lambda r: -r[2] * r[1])
+        cols = ["kernel", "launches_counted", "gpu_cycles_per_launch(GRBM_GUI_ACTIVE/8)", "SQ_VALU_MFMA_BUSY_CYCLES", "mfma_busy_frac(=busy/(cycles*1024 SIMDs))",
+                "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"]
+        pd.DataFrame(rows, columns=cols).to_csv(os.path.join(out, f"{rnd}_{cfg}_mfma_util.csv"), index=False)
+        md += ["", f"`{rnd}_{cfg}_mfma_util.csv`: matrix-pipe utilisation of the MFMA kernels from the SQ counters (one `--pmc` pass of eight SQ counters, one of "
+               "GRBM_GUI_ACTIVE): MFMA-busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1 024 SIMDs); a fully issued bf16 / fp16 "
+               "MFMA stream reads 1.0 = 2.5 PFLOP/s.", "", "| kernel | launches | cycles / launch | MFMA-busy fraction | wave cycles waiting (WAIT_ANY / WAVE_CYCLES) | LDS conflict / LDS active |",
+               "|---|---|---|---|---|---|"]
+        for r in rows[:10]:
+            md.append(f"| `{r[0][:80]}` | {r[1]} | {r[2]:.0f} | {r[4]:.3f} | {r[7] / r[6] if r[6] else float('nan'):.2f} | {r[10] / r[11] if r[11] else float('nan'):.3f} |")
     return md
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--round", default="r02")
+    ap.add_argument("--round", default="r03")
     ap.add_argument("--dir", required=True)
     a = ap.parse_args()
     out = os.path.join(ROOT, "profiles")
     md = [f"# profiles (round {a.round[1:].lstrip('0') or '0'})", "",
           "One MI355X, one process; every file below comes from ONE gpurun session (`bash tools/profile_all.sh`, then "
-          f"`python tools/make_profiles.py --round {a.round} --dir <that session's output>`).  Round-1 files (`r01_*`) are kept for comparison.", ""]
+          f"`python tools/make_profiles.py --round {a.round} --dir <that session's output>`).  Earlier rounds' files (`r01_*`, `r02_*`) are kept for comparison.", ""]
     for cfg in CONFIGS:
         if os.path.exists(os.path.join(a.dir, f"bench_{cfg}.json")):
             md += section(a.round, cfg, a.dir, out) + [""]
