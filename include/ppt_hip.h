@@ -314,7 +314,8 @@ int ppt_bn_rows_bwd_reduce(const float *dy, const float *x, const float *scale, 
                            const float *rstd, int relu, int64_t M, int C, float *part_g, float *part_gx, void *stream);
 int ppt_bn_rows_bwd_apply(const float *dy, const float *x, const float *scale, const float *shift, const float *mean,
                           const float *rstd, const float *sum_g, const float *sum_gx, int relu, int batch_stats, int64_t M,
-                          int C, float *dx, void *dx_bf16, void *stream);     /* dx f32 and / or a bf16 copy (either may be NULL) */
+                          int C, float *dx, void *dx_half, int half_dtype, void *stream);
+                          /* dx f32 and / or a 16-bit copy in half_dtype = PPT_BF16 | PPT_F16 (either pointer may be NULL) */
 int ppt_conv1_stats_max_partials(int64_t M);
 int ppt_conv1_stats_rows_per_partial(void);
 

@@ -113,7 +113,7 @@ _SIGNATURES = {
     "ppt_bn_rows_bwd_reduce": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int,
                                        c_void_p, c_void_p, c_void_p]),
     "ppt_bn_rows_bwd_apply": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                      c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+                                      c_int, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "ppt_bn_finalize_workspace_bytes": (ctypes.c_size_t, [c_int, c_int]),
     "ppt_gn_stats_chunks": (c_int, [c_int]),
     "ppt_gn_bwd_chunks": (c_int, [c_int]),

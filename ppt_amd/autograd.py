@@ -22,7 +22,7 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, prec):
-        mult = 8 if prec == torch.bfloat16 else 4
+        mult = 8 if prec in ops.HALF else 4
         x2 = x.detach().float()
         w2 = w.detach().reshape(w.shape[0], -1).float()
         xt, wt = _pad_k(x2, mult, prec), _pad_k(w2, mult, prec)
@@ -154,7 +154,7 @@ def batch_norm_relu_rows(x, bn, training):
 # converted (ppt_convert), padded, concatenated or gathered by ATen kernels on the way.
 # =================================================================================================
 def _mult(prec):
-    return 8 if prec == torch.bfloat16 else 4
+    return 8 if prec in ops.HALF else 4
 
 
 def _w_operand(w, prec):
@@ -193,8 +193,9 @@ def _conv_bn_relu_fwd(xT, w, b, bn, training, prec, out_dtype):
 def _conv_bn_relu_bwd(dh, saved, training, prec, w, need_dx):
     """-> (dx [M, Kp] f32 | None, dW like w, db [N], dgamma, dbeta) for _conv_bn_relu_fwd; dh [M, N] f32."""
     xT, wT, y, sc, sh, mean, rstd = saved
-    bf = prec == torch.bfloat16
-    res = ops.bn_rows_backward(dh.contiguous().float(), y, sc, sh, mean, rstd, True, training, want_dx=not bf, want_bf16=bf)
+    bf = prec in ops.HALF
+    res = ops.bn_rows_backward(dh.contiguous().float(), y, sc, sh, mean, rstd, True, training, want_dx=not bf, want_bf16=bf,
+                               half_dtype=prec if bf else torch.bfloat16)
     dgamma, dbeta = res[1], res[2]
     dyT = res[3] if bf else res[0]
     K = w[0].numel()
@@ -378,7 +379,7 @@ def partseg_decoder_forward(pe, f_a, f_b, f_c, center, c1, c2, pts, cls_label, d
     F0, k5 = _fp_forward(pe.propagation_0, pts, c1, f0, L4, True)
     k6 = _Ctx((True,))
     y = _ConvBNReLURows.forward(k6, F0.reshape(B * N, -1), pe.conv1.weight, pe.conv1.bias, pe.bn1.weight, pe.bn1.bias,
-                                (pe.bn1, pe.training), pe._precision).view(B, N, -1)
+                                (pe.bn1, pe.training), pe._dec_precision).view(B, N, -1)
     if drop is not None:
         y = y * drop
     return y, (k1, k2, k3a, k3b, k4a, k4b, k5, k6, drop, (B, N))

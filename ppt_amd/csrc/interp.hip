@@ -21,6 +21,9 @@ template <> struct pair_store<float> {
 template <> struct pair_store<bf16_t> {
     static __device__ __forceinline__ void put(bf16_t *p, float a, float b) { *reinterpret_cast<uint32_t *>(p) = pack_bf16x2(a, b); }
 };
+template <> struct pair_store<f16_t> {
+    static __device__ __forceinline__ void put(f16_t *p, float a, float b) { *reinterpret_cast<uint32_t *>(p) = pack_f16x2(a, b); }
+};
 
 // one thread per PAIR of output columns (c, c + 1) of one row; ld is even
 template <typename TO>
@@ -169,13 +172,16 @@ extern "C" int ppt_three_nn_interp_fwd(const float *points1, int D1, const float
 {
     if (!points2 || !idx || !dist || !out || B <= 0 || N <= 0 || S <= 0 || D2 <= 0 || D1 < 0 || (D1 > 0 && !points1)) return PPT_EINVAL;
     if (ld_out < D1 + D2 || (ld_out & 1)) return PPT_EINVAL;
-    if (out_dtype != PPT_F32 && out_dtype != PPT_BF16) return PPT_EINVAL;
+    if (out_dtype != PPT_F32 && out_dtype != PPT_BF16 && out_dtype != PPT_F16) return PPT_EINVAL;
     const int64_t rows = (int64_t)B * N;
     const int64_t total = rows * (ld_out / 2);
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     if (out_dtype == PPT_BF16)
         hipLaunchKernelGGL(three_nn_interp_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, ppt_stream(stream), points1, D1, points2, D2, idx,
                            dist, N, S, rows, ld_out, (bf16_t *)out, weight_out);
+    else if (out_dtype == PPT_F16)
+        hipLaunchKernelGGL(three_nn_interp_fwd_kernel<f16_t>, dim3(grid), dim3(256), 0, ppt_stream(stream), points1, D1, points2, D2, idx,
+                           dist, N, S, rows, ld_out, (f16_t *)out, weight_out);
     else
         hipLaunchKernelGGL(three_nn_interp_fwd_kernel<float>, dim3(grid), dim3(256), 0, ppt_stream(stream), points1, D1, points2, D2, idx,
                            dist, N, S, rows, ld_out, (float *)out, weight_out);

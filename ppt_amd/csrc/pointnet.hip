@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_apply_kernel(const float *__r
                                                                 const float *__restrict__ mean, const float *__restrict__ rstd,
                                                                 const float *__restrict__ sum_g, const float *__restrict__ sum_gx,
                                                                 int relu, int batch_stats, int64_t M, int C, float *__restrict__ dx,
-                                                                bf16_t *__restrict__ dx_bf16)
+                                                                uint16_t *__restrict__ dx_half, int half_dtype)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void bn_rows_bwd_apply_kernel(const float *__r
         if (relu && !(fmaf(v, sc, sh) > 0.f)) g = 0.f;
         const float o = sc * (g - mg - (v - mu) * rs * mgx);
         if (dx) dx[(r0 + r) * C + c] = o;
-        if (dx_bf16) dx_bf16[(r0 + r) * C + c] = f32_to_bf16(o);
+        if (dx_half) dx_half[(r0 + r) * C + c] = from_f32_dt(half_dtype, o);
     }
 }
 
@@ -451,6 +451,8 @@ extern "C" int ppt_bn_act_rows(const float *x, int M, int C, const float *scale,
         hipLaunchKernelGGL(bn_act_rows_kernel<float>, grid, dim3(256), 0, ppt_stream(stream), x, n, C, scale, shift, mask, (float *)y);
     else if (y_dtype == PPT_BF16)
         hipLaunchKernelGGL(bn_act_rows_kernel<bf16_t>, grid, dim3(256), 0, ppt_stream(stream), x, n, C, scale, shift, mask, (bf16_t *)y);
+    else if (y_dtype == PPT_F16)
+        hipLaunchKernelGGL(bn_act_rows_kernel<f16_t>, grid, dim3(256), 0, ppt_stream(stream), x, n, C, scale, shift, mask, (f16_t *)y);
     else
         return PPT_EINVAL;
     PPT_CHECK_LAUNCH();
@@ -564,14 +566,15 @@ extern "C" int ppt_bn_rows_bwd_reduce(const float *dy, const float *x, const flo
 
 extern "C" int ppt_bn_rows_bwd_apply(const float *dy, const float *x, const float *scale, const float *shift, const float *mean,
                                      const float *rstd, const float *sum_g, const float *sum_gx, int relu, int batch_stats,
-                                     int64_t M, int C, float *dx, void *dx_bf16, void *stream)
+                                     int64_t M, int C, float *dx, void *dx_half, int half_dtype, void *stream)
 {
-    if (!dy || !x || !scale || !shift || !mean || !rstd || (!dx && !dx_bf16) || M <= 0 || C <= 0 || (M + RS_ROWS - 1) / RS_ROWS > 65535)
+    if (!dy || !x || !scale || !shift || !mean || !rstd || (!dx && !dx_half) || M <= 0 || C <= 0 || (M + RS_ROWS - 1) / RS_ROWS > 65535)
         return PPT_EINVAL;
+    if (dx_half && half_dtype != PPT_BF16 && half_dtype != PPT_F16) return PPT_EINVAL;
     if (batch_stats && (!sum_g || !sum_gx)) return PPT_EINVAL;
     hipLaunchKernelGGL(bn_rows_bwd_apply_kernel, dim3((C + 255) / 256, (unsigned)((M + RS_ROWS - 1) / RS_ROWS)), dim3(256), 0,
                        ppt_stream(stream), dy, x, scale, shift, mean, rstd, sum_g, sum_gx, relu, batch_stats, M, C, dx,
-                       (bf16_t *)dx_bf16);
+                       (uint16_t *)dx_half, half_dtype);
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }

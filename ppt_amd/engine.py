@@ -85,6 +85,10 @@ BLOCKS_F16 = os.environ.get("PPT_BLOCKS_F16", "1") != "0"
 # activations are raw Conv1d outputs in front of a BatchNorm (y2, y3) and group maxima: |values| of order 1-100, fp16's range is
 # 65 504; the conv1 output is rebuilt in fp32 from the coordinates and never stored.
 TOKENIZER_F16 = os.environ.get("PPT_TOKENIZER_F16", "1") != "0"
+# ... and the GEMM operands of the part-segmentation decoder (feature propagation, DGCNN propagation, conv1; PPT_DECODER_F16=0:
+# bf16).  Its activations stay fp32 between layers either way; what changes is the rounding of each GEMM's two operands
+# (8 -> 11 significand bits) in the forward and of dY in the backward.
+DECODER_F16 = os.environ.get("PPT_DECODER_F16", "1") != "0"
 
 
 def _stage_wc(wc, stage):

@@ -499,6 +499,7 @@ class PointTransformer_partseg(nn.Module):
         self.decoder_gate = None          # event after which this iteration may read the decoder's parameters (train.Trainer)
         self.group_ahead = None           # stream for the grouping stage of a step whose inputs the caller vouches for (Trainer)
         self._ahead = graphs.AheadStage()
+        self.precision = torch.bfloat16   # (the setter also hands the decoder modules their operand format)
 
     @property
     def precision(self):
@@ -508,8 +509,10 @@ class PointTransformer_partseg(nn.Module):
     def precision(self, dtype):
         self._precision = dtype
         self._graphs.clear()
+        # the decoder's GEMM operand format: IEEE half in the performance mode (engine.DECODER_F16), else as the backbone
+        self._dec_precision = torch.float16 if (dtype == torch.bfloat16 and engine.DECODER_F16) else dtype
         for m in (self.propagation_0, self.propagation_1, self.propagation_2, self.dgcnn_pro_1, self.dgcnn_pro_2):
-            m.precision = dtype
+            m.precision = self._dec_precision
 
     _cache = PointTransformer._cache
     _cfg = PointTransformer._cfg
@@ -606,7 +609,7 @@ class PointTransformer_partseg(nn.Module):
         f2 = self.dgcnn_pro_2.forward_rows(center, feats[2], c2, f2)
         f1 = self.dgcnn_pro_1.forward_rows(c2, f2, c1, f1)
         f0 = self.propagation_0.forward_rows(pts, c1, f0, f1)
-        y = conv_bn_relu_rows(f0.reshape(B * N, -1), self.conv1, self.bn1, self.training, self._precision)
+        y = conv_bn_relu_rows(f0.reshape(B * N, -1), self.conv1, self.bn1, self.training, self._dec_precision)
         y = y.view(B, N, -1)
         if self.dropout_mask is not None:
             y = y * self.dropout_mask.to(dev)

@@ -538,8 +538,8 @@ def rows_stats(x):
     return (ps, pq), rpp
 
 
-def bn_rows_backward(dy, x, scale, shift, mean, rstd, relu, batch_stats, want_dx=True, want_bf16=False):
-    """BatchNorm1d(+ReLU) backward over rows: -> (dx [M,C] f32 | None, d gamma [C], d beta [C][, dx as bf16])."""
+def bn_rows_backward(dy, x, scale, shift, mean, rstd, relu, batch_stats, want_dx=True, want_bf16=False, half_dtype=torch.bfloat16):
+    """BatchNorm1d(+ReLU) backward over rows: -> (dx [M,C] f32 | None, d gamma [C], d beta [C][, dx in half_dtype (bf16 | f16)])."""
     _chk(dy, torch.float32, "dy"); _chk(x, torch.float32, "x")
     M, C = x.shape
     rpp = _lib.lib().ppt_rows_stats_rows_per_partial()
@@ -550,9 +550,9 @@ def bn_rows_backward(dy, x, scale, shift, mean, rstd, relu, batch_stats, want_dx
                                                  _p(pg), _p(pgx), _stream()), "ppt_bn_rows_bwd_reduce")
     sg, sgx = reduce_rows(pg), reduce_rows(pgx)
     dx = torch.empty_like(x) if want_dx else None
-    dxb = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    dxb = torch.empty(x.shape, dtype=half_dtype, device=x.device) if want_bf16 else None
     _lib.check(_lib.lib().ppt_bn_rows_bwd_apply(_p(dy), _p(x), _p(scale), _p(shift), _p(mean), _p(rstd), _p(sg), _p(sgx),
-                                                int(relu), int(batch_stats), M, C, _p(dx), _p(dxb), _stream()),
+                                                int(relu), int(batch_stats), M, C, _p(dx), _p(dxb), _DT[half_dtype], _stream()),
                "ppt_bn_rows_bwd_apply")
     return (dx, sgx, sg, dxb) if want_bf16 else (dx, sgx, sg)
 
