@@ -477,8 +477,10 @@ int ppt_bn_act_rows(const float *x, int M, int C, const float *scale, const floa
  *   row layout: out[i] = slot[i] >= 0 ? tokens[slot[i]] + pos_rows[i] : base[i]; base [rows, W] = frozen embedding +
  *   positional embedding per row (a constant), slot [rows] i32, pos_rows [rows, W].  W % 4 == 0.
  * prompt_rows_bwd: d_tokens[t] = sum of g[row] over rows_of[t * max_rows + k] (ascending, -1 terminated). */
-int ppt_adamw_step(float *p, const float *g, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
-                   float eps, float weight_decay, int step, void *stream);
+int ppt_adamw_step(float *p, float *g, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int step, float grad_scale, void *stream);
+                   /* grad_scale: g is multiplied by it first (1 / loss scale of the caller; 1 = none) and, when != 1, the
+                    * product is written back to g, so that g ends as the gradient of the un-scaled loss */
 int ppt_prompt_rows(const float *base, const int *slot, const float *tokens, const float *pos_rows, int rows, int W, float *out,
                     void *stream);
 int ppt_prompt_rows_bwd(const float *g, const int *rows_of, int max_rows, int n_tok, int W, float *d_tokens, void *stream);

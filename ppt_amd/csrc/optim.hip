@@ -13,14 +13,17 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void adamw_step_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+__global__ __launch_bounds__(256) void adamw_step_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
                                                          float *__restrict__ v, int64_t n, float decay, float omb1, float b2,
-                                                         float omb2, float inv_sqrt_bc2, float eps, float step_size, int prio)
+                                                         float omb2, float inv_sqrt_bc2, float eps, float step_size, float grad_scale, int prio)
 {
     PPT_PRIO(prio);
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float gi = g[i];
+    // grad_scale != 1: g holds the gradient of (loss / grad_scale) -- train.Trainer's loss scaling; the true gradient is
+    // written back so that g reads like the reference's .grad afterwards (a power of two: exact)
+    const float gi = g[i] * grad_scale;
+    if (grad_scale != 1.f) g[i] = gi;
     float pi = p[i] * decay;
     const float mi = m[i] + (gi - m[i]) * omb1;
     const float vi = v[i] * b2 + omb2 * gi * gi;
@@ -80,14 +83,14 @@ __global__ __launch_bounds__(256) void prompt_rows_bwd_kernel(const float *__res
 
 }  // namespace
 
-extern "C" int ppt_adamw_step(float *p, const float *g, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
-                              float beta2, float eps, float weight_decay, int step, void *stream)
+extern "C" int ppt_adamw_step(float *p, float *g, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, int step, float grad_scale, void *stream)
 {
-    if (!p || !g || !exp_avg || !exp_avg_sq || n <= 0 || step <= 0) return PPT_EINVAL;
+    if (!p || !g || !exp_avg || !exp_avg_sq || n <= 0 || step <= 0 || !(grad_scale > 0.f)) return PPT_EINVAL;
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     hipLaunchKernelGGL(adamw_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ppt_stream(stream), p, g, exp_avg, exp_avg_sq, n,
                        (float)(1.0 - (double)lr * weight_decay), 1.0f - beta1, beta2, 1.0f - beta2, (float)(1.0 / sqrt(bc2)), eps,
-                       (float)((double)lr / bc1), ppt_get_wave_priority());
+                       (float)((double)lr / bc1), grad_scale, ppt_get_wave_priority());
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }

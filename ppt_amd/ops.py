@@ -905,12 +905,13 @@ def gemm_tn_splitk(x_a, x_b, min_blocks=768, max_splits=16):
     return reduce_rows(part.view(S, N1 * N2)).view(N1, N2)
 
 
-def adamw_step(p, g, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step):
-    """torch.optim.AdamW's update of ONE tensor in one launch (ppt_adamw_step); p, exp_avg, exp_avg_sq updated in place."""
+def adamw_step(p, g, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    """torch.optim.AdamW's update of ONE tensor in one launch (ppt_adamw_step); p, exp_avg, exp_avg_sq updated in place.
+    grad_scale != 1: g is first multiplied by it IN PLACE (the un-scaling of a loss-scaled backward)."""
     for t, nm in ((p, "p"), (g, "g"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
         _chk(t, torch.float32, nm)
     _lib.check(_lib.lib().ppt_adamw_step(_p(p), _p(g), _p(exp_avg), _p(exp_avg_sq), p.numel(), lr, beta1, beta2, eps, weight_decay,
-                                         int(step), _stream()), "ppt_adamw_step")
+                                         int(step), float(grad_scale), _stream()), "ppt_adamw_step")
 
 
 def prompt_rows(base, slot, tokens, pos_rows):

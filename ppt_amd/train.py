@@ -210,6 +210,18 @@ class Trainer:
         # multi-tensor kernels of the foreach implementation, while few tensors train: every kernel of the prompt chain costs a
         # dispatch round trip.  The torch optimizer object stays the owner of hyper-parameters and state (state_dict()).
         self.fused_adamw = os.environ.get("PPT_FUSED_ADAMW", "1") != "0"
+        # Loss scaling for the performance mode's fp16 operand stages (text tower, PointBERT tokenizer + blocks, part-seg decoder:
+        # engine.*_F16): their backward carries activation gradients in IEEE half, which keeps 11 bits only down to 6.1e-5.  The
+        # criterion is a MEAN over the rows of the batch, so the gradients shrink with the batch (1 / (B x points) per logit in
+        # part segmentation) and would slide into the subnormals: measured (tools/f16_grad_range.py), the error of the golden
+        # step's gradients is flat while the seed gradient is >= 1 / 4 ... 1 / 512 per row and grows 4x per 8x below that,
+        # with no overflow up to 32 768x above.  "auto": backward is seeded with S = the number of rows in the mean rounded down
+        # to a power of two (i.e. the towers see the gradient of ~the SUM over rows: batch-size invariant, mid-plateau) and the
+        # gradients are multiplied by 1 / S -- exact -- before the optimizer reads them (inside ppt_adamw_step, or one foreach
+        # multiply), so .grad, the all-reduce and AdamW see what the reference's would.  A number fixes S; None / 1 turns it
+        # off.  Not applied in the fp32 parity mode.  `step(check_finite=True)` raises on a non-finite loss as main_cls.py does.
+        self.loss_scale = os.environ.get("PPT_LOSS_SCALE", "auto")
+        self._seeds = {}
         # logit_scale is frozen in every PPT configuration (ULIP_models.py:487-507) and its value lies inside the clamp range:
         # main_cls.py:213's per-step clamp is then idempotent -- applied once here, and per step only if it ever trains
         if hasattr(model, "logit_scale"):
@@ -325,13 +337,17 @@ class Trainer:
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
             from . import autograd as _ag
             _ag.STATIC_GRADS_OK = self.sync.lazy                    # .grad dropped before every backward, read before the next replay
+            S = self._loss_scale_for(label, loss)
             try:
-                loss.backward()                                     # (retain_graph only served Q2)
+                if S == 1.0:
+                    loss.backward()                                 # (retain_graph only served Q2)
+                else:
+                    loss.backward(gradient=self._seed(S, loss))
             finally:
                 _ag.STATIC_GRADS_OK = False
             if self.distributed:
                 self.sync.all_reduce()
-            self._optimizer_step()
+            self._optimizer_step(1.0 / S)
             if model.logit_scale.requires_grad:
                 model.logit_scale.data.clamp_(0, 4.6052)            # main_cls.py:213 (frozen: clamped once in __init__)
         if side is not None and not self._point_side_frozen:
@@ -362,12 +378,31 @@ class Trainer:
             return _CrossEntropyRows.apply(logits.contiguous(), labels.contiguous(), float(self.criterion.label_smoothing))
         return self.criterion(logits, labels)
 
-    def _optimizer_step(self):
+    def _loss_scale_for(self, label, loss):
+        """The factor backward is seeded with (see __init__): a power of two, 1.0 = no scaling."""
+        ls = self.loss_scale
+        if ls in (None, "", "0", "1", "none", "off") or not loss.is_cuda or getattr(self.model, "precision", None) != torch.bfloat16:
+            return 1.0
+        if ls == "auto":
+            return float(2 ** max(0, int(label.numel()).bit_length() - 1))
+        return float(ls)
+
+    def _seed(self, S, loss):
+        key = (S, loss.device, loss.dtype)
+        if key not in self._seeds:
+            self._seeds[key] = torch.full((), S, dtype=loss.dtype, device=loss.device)
+        return self._seeds[key]
+
+    def _optimizer_step(self, inv_scale=1.0):
+        """AdamW over the tensors that got a gradient; inv_scale: 1 / the loss scale of this backward, folded in first."""
         opt = self.optimizer
         params = [(g, p) for g in opt.param_groups for p in g['params'] if p.grad is not None]
         if not (self.fused_adamw and params and len(params) <= 8 and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
                                                                         and p.grad.is_contiguous() for _, p in params)
                 and not any(g.get('amsgrad') or g.get('maximize') for g, _ in params)):
+            if inv_scale != 1.0 and params:
+                with torch.no_grad():
+                    torch._foreach_mul_([p.grad for _, p in params], inv_scale)
             opt.step()
             return
         from . import ops
@@ -382,7 +417,7 @@ class Trainer:
                 st['step'] += 1
                 b1, b2 = g['betas']
                 ops.adamw_step(p.data, p.grad, st['exp_avg'], st['exp_avg_sq'], float(g['lr']), float(b1), float(b2), float(g['eps']),
-                               float(g['weight_decay']), int(st['step'].item()))
+                               float(g['weight_decay']), int(st['step'].item()), grad_scale=inv_scale)
                 # the kernel wrote through a raw pointer: tell autograd's version counter, as torch.optim.AdamW's in-place ops
                 # would.  Two caches key on it -- ULIP_WITH_IMAGE._te_cache (validate()'s text features) and
                 # engine.WeightCache (the bf16 / transposed operand copies of a trained last-block weight) -- and would otherwise

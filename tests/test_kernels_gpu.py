@@ -1087,6 +1087,23 @@ def test_adamw_step_matches_torch(ops):
         assert (v - opt.state[p_ref]['exp_avg_sq']).abs().max().item() <= 1e-6 * v.abs().max().item()
 
 
+def test_adamw_step_unscales_a_loss_scaled_gradient_in_place(ops):
+    """grad_scale = 1 / S (train.Trainer's loss scaling): the update is the one of the un-scaled gradient, bit for bit (S is a
+    power of two), and g is left holding that gradient."""
+    g = torch.Generator().manual_seed(1)
+    p0 = torch.randn(40, 512, generator=g) * 0.02
+    grad = torch.randn(40, 512, generator=g).cuda() * 1e-3
+    outs = []
+    for S in (1.0, 4096.0):
+        p, m, v = p0.clone().cuda(), torch.zeros(40, 512).cuda(), torch.zeros(40, 512).cuda()
+        gs = grad * S
+        ops.adamw_step(p, gs, m, v, 3e-3, 0.9, 0.98, 1e-8, 0.1, 1, grad_scale=1.0 / S)
+        assert torch.equal(gs, grad)
+        outs.append((p, m, v))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("position", ["front", "middle", "end"])
 def test_prompt_rows_are_the_prompt_learner_splice(ops, position):
     """ppt_prompt_rows / ppt_prompt_rows_bwd against PromptLearner.forward + positional add written with torch ops and its

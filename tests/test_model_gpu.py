@@ -103,6 +103,41 @@ def test_train_step_matches_oracle_and_golden(head_type, precision, ltol, gtol):
             assert d < 5e-5, (k, d)
 
 
+def test_loss_scaling_keeps_fp16_gradients_out_of_the_subnormals():
+    """The performance mode's fp16 stages carry activation gradients in IEEE half.  With the criterion's mean over a batch
+    2048x the golden one (emulated: the golden step's loss x 1/2048) the un-scaled backward loses the token gradient to
+    fp16 subnormals; with train.Trainer's loss scale the gradient (as left in .grad: un-scaled again) stays at the golden
+    accuracy.  The default ("auto" = rows of the mean, here 4) is covered by test_train_step_matches_oracle_and_golden."""
+    from ppt_amd.train import Trainer
+    g = np.load(os.path.join(G, "g_step_h3.npz"))
+    pc, _ = oracle_inputs()
+    shrink = 1.0 / 2048
+    errs = {}
+    for scale in (None, 4 * 2048):
+        m, sd = build(3, torch.bfloat16)
+        m.train()
+        m.point_encoder.fps_start = torch.from_numpy(g["fps_start"]).cuda()
+        m.point_encoder.drop_path_factors = torch.from_numpy(g["dp_masks"]).cuda()
+        tr = Trainer(m, lr=3e-3, label_smoothing=0.2, distributed=False)
+        tr.fused_head, tr.loss_scale = False, scale
+        inner = tr._loss
+        tr._loss = lambda a, b: inner(a, b) * shrink
+        tr.step(pc.cuda(), torch.from_numpy(g["labels"]).cuda())
+        torch.cuda.synchronize()
+        live = dict(m.named_parameters())
+        for k in ("prompt_learner.learnable_tokens", "point_encoder.blocks.blocks.11.attn.qkv.weight"):
+            gr = torch.from_numpy(g["grad_" + k] if "grad_" + k in g.files else g["gradsub_" + k])
+            gg = live[k].grad.detach().cpu() / shrink
+            gg = gg if gg.shape == gr.shape else gg.flatten()[::97]
+            errs[(scale, k)] = ((gg - gr).norm() / gr.norm()).item()
+    for (scale, k), e in errs.items():
+        print(f"PARITY loss scale {scale} (loss x 1/2048) grad {k} rel-L2: {e:.4g}")
+        if scale is None:
+            assert e > 0.03, (k, e)            # the failure the scale is there for
+        else:
+            assert e < 1.5e-2, (k, e)
+
+
 @pytest.mark.parametrize("precision,tol", [(torch.float32, 2e-3), (torch.bfloat16, 0.1)])
 def test_eval_forward_matches_golden(precision, tol):
     g = np.load(os.path.join(G, "g_eval.npz"))
@@ -701,10 +736,11 @@ def test_partseg_train_step_matches_golden(precision):
     loss.backward()
     f32 = precision == torch.float32
     err = np.abs(pred.detach().cpu().numpy()[:, ::16] - g["logits_sub"]).max()
-    # bf16 mode: logits are logit_scale (14.3) x a cosine; operand rounding through 12 blocks + the decoder moves them by
-    # a few % of their range (|logits| <= 47 here), and by how much depends on summation order -- measured 1.3 (2.8 %), bound 4 %
-    _bound(f"partseg {precision} logits abs err", err, 2e-2 if f32 else 0.04 * float(np.abs(g["logits_sub"]).max()))
-    assert abs(loss.item() - float(g["loss"])) < (1e-3 if f32 else 0.3)
+    # performance mode: logits are logit_scale (14.3) x a cosine, |logits| <= 47 here.  With bf16 operands everywhere they moved
+    # by 1.27; with fp16 operands in the text tower, tokenizer, blocks and decoder GEMMs and the fp16 per-point head: 0.254
+    # (tools/f16_grad_range.py partseg), bound 0.3
+    _bound(f"partseg {precision} logits abs err", err, 2e-2 if f32 else 0.3)
+    _bound(f"partseg {precision} loss abs err", abs(loss.item() - float(g["loss"])), 1e-3 if f32 else 0.005)
     live = dict(m.named_parameters())
     top = ("point_encoder.conv1.weight", "point_encoder.bn1.weight", "point_encoder.bn1.bias", "prompt_learner.learnable_tokens")
     worst = 0.0
@@ -722,14 +758,14 @@ def test_partseg_train_step_matches_golden(precision):
             assert rel < (2e-3 if k in top else 6e-2), (k, rel)
             assert abs(live[k].grad.double().norm().item() / ref_n - 1) < 6e-2, k
         elif k in top:
-            _bound(f"partseg bf16 grad {k} rel-L2", rel, 0.22)
+            _bound(f"partseg bf16 grad {k} rel-L2", rel, 0.09)              # measured: conv1.weight 0.058, tokens 0.002 (bf16: 0.15)
         elif live[k].dim() >= 2:
             # bf16: logits = 100 x a cosine, so a feature error of a few 1e-3 moves a logit by ~1 and the per-point softmax by
             # tens of percent (and flips max-pool arg-maxima): measured rel-L2 0.18 ... 0.38 on the decoder's weight matrices,
             # while their NORMS agree within 1.2 % and the directions within 1 - cos <= 0.074.  All three are bounded.
             # (1-D norm parameters are sums with heavy cancellation and are only pinned in fp32 mode.)
             cos = float(np.dot(sub, ref) / (np.linalg.norm(sub) * np.linalg.norm(ref)))
-            _bound(f"partseg bf16 grad {k} rel-L2", rel, 0.5)
+            _bound(f"partseg bf16 grad {k} rel-L2", rel, 0.2)               # measured with fp16 operands: <= 0.137 (bf16: 0.38)
             _bound(f"partseg bf16 grad {k} |norm ratio - 1|", abs(live[k].grad.double().norm().item() / ref_n - 1), 0.03)
             _bound(f"partseg bf16 grad {k} 1 - cos", 1 - cos, 0.1)
 
