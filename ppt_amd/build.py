@@ -20,7 +20,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # (the BatchNorm chunk sums of the GEMM epilogue: v_pk_add_f32 x8, s_nop 0 between, horizontal op_sel add) gave wrong
 # lanes 16-31 in ~1e-4 of the chunks, different ones on every run, on gfx950 with ROCm 7.2 (tools/gemm_determinism.py);
 # the scalar chain is bit-stable.  PPT_SLP=1 re-enables it for A/B timing.
-COMMON = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
+COMMON = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-inline-asm",
           "-fno-gpu-rdc"] + ([] if os.environ.get("PPT_SLP") == "1" else ["-fno-slp-vectorize"])
 PER_FILE = {"fps.hip": ["-ffp-contract=off"], "knn_group.hip": ["-ffp-contract=off"]}
 

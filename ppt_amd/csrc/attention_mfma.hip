@@ -34,22 +34,35 @@ __device__ __forceinline__ int v_off(int key, int dbyte) { return key * 128 + (d
 __device__ __forceinline__ float lane_xor32_max(float v) { return xor32_max(v); }
 __device__ __forceinline__ float lane_xor32_sum(float v) { return xor32_sum(v); }
 
+// Workgroup -> (query block, batch x head): the dispatcher deals consecutive workgroups round-robin to the 8 XCDs, each with an
+// L2 of its own.  With the query blocks of one (batch, head) on consecutive workgroup ids its K / V rows were fetched from HBM
+// by up to five XCDs (PMC: 139 MB read per launch at T = 513, B = 32 for 38 MB of qkv).  When the number of (batch, head)
+// pairs is a multiple of 8 the ids are dealt so that all query blocks of a pair land on ONE XCD, next to each other in time.
+// (Tried: T = 4 x 128 + 1 as four blocks of FIVE waves, the fifth wave of the last block owning the class-token row, instead of
+// a fifth block that streams every K / V tile for one row: 36.3 -> 49.0 us.  Five-wave workgroups fit three to a CU instead of
+// five, and this kernel lives on occupancy.  The ViT shape has a kernel of its own: attn_fwd_resident below.)
 template <bool CAUSAL, typename F>
 __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out,
                                                      float *__restrict__ lse, int Tfull, int H, float c /* scale*log2(e) */,
-                                                     int P, int C, int prio)
+                                                     int P, int C, int prio, int xcd_map)
 {
     __shared__ __align__(16) unsigned char smem[4 * TILE];    // K0 K1 V0 V1
     PPT_PRIO(prio);
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int bh = blockIdx.y, b = bh / H, head = bh % H;
+    int bh = blockIdx.y, qblk = blockIdx.x;
+    if (xcd_map && (gridDim.y & 7) == 0) {
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x, slot = lin >> 3;
+        bh = (slot / (int)gridDim.x) * 8 + (lin & 7);
+        qblk = slot % (int)gridDim.x;
+    }
+    const int b = bh / H, head = bh % H;
     const int64_t rs = 3 * (int64_t)H * HD;
     const int T = am_len(Tfull, P, C, b), q_lo = am_qlo(P, C, b);     // (attn_rowmap.h: b is a virtual sequence when P > 0)
     const bf16_t *qb = qkv + head * HD;
     const bf16_t *kb = qb + H * HD, *vb = qb + 2 * H * HD;
-    const int q0 = blockIdx.x * QB + w * 32;
+    const int q0 = qblk * QB + w * 32;
     const int qrow = q0 + r;
 
     uint4 qf[4];
@@ -89,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(const bf16_t *__restrict
         }
     };
 
-    const int q_hi = min(T, (int)(blockIdx.x + 1) * QB) - 1;          // last query row of this workgroup
+    const int q_hi = min(T, (int)(qblk + 1) * QB) - 1;                // last query row of this workgroup
     const int nkt = CAUSAL ? min((T + KVT - 1) / KVT, q_hi / KVT + 1) : (Tk + KVT - 1) / KVT;
 
     f32x16_t ot[2];
@@ -237,6 +250,289 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma(const bf16_t *__restrict
             }
         if (lse && h == 0) lse[am_stat(Tfull, P, H, b, head, qrow)] = (m + __log2f(lt)) * 0.6931471805599453f;
     }
+}
+
+
+// =================================================================================================
+// The ViT shape (point_encoder.py:46-55: T = 64 n + 1 <= 513 tokens, non-causal): K and V of one (batch, head) are
+// 2 x 64 KB -- they FIT in the 160 KB of LDS of a CU.  One workgroup of 8 waves per (batch, head):
+//   * the 64 n keys go to LDS ONCE, by LDS-DMA (global_load_lds, 1 KB per wave and instruction: wave w brings rows 8 w .. 8 w + 7
+//     of every 64-key tile of K and of V), in tile order; a wave waits for its own pieces of tile kt with a counted vmcnt
+//     and the workgroup meets at one barrier per tile -- the fill runs ahead of the arithmetic, nothing is staged through
+//     registers, no tile is ever fetched twice (the streaming kernel above: every 128-query block re-streams all keys through
+//     a register-staged double buffer -- 5 blocks x 8 tiles x 2 barriers of latency per (batch, head), 139 MB from HBM per
+//     launch for 38 MB of qkv);
+//   * wave w owns the 64 queries 64 w .. 64 w + 63 as TWO 32-column B operands, so every K fragment (ds_read_b128) and every
+//     transposed V fragment (ds_read_b64_tr_b16) feeds two MFMAs: half the LDS fragment traffic per flop;
+//   * the last key (the 64 n + 1st) initialises the running softmax state as in the streaming kernel;
+//   * the last QUERY row -- a 513th row would cost a ninth wave a whole pass -- is done beside the matrix work on the vector
+//     ALU: wave w takes key tile w (lane = key: 64-term dot product against the wave-uniform query, softmax pieces by DPP
+//     reductions, then lane = output dimension: 64 readlane-broadcast weights x V[key][lane]); the 8 partial (max, sum, O[64])
+//     meet in LDS and wave 0 folds them with the last key's term.
+// Same products, exponentials and fp32 accumulation as the streaming kernel; the summation order over keys is the same for
+// rows < 64 n (tile order, last key first) and differs for the last row.
+// =================================================================================================
+constexpr int RES_MAXK = 512, RES_SCR_STRIDE = 68;
+// Diagnostic build only (tools/attn_stamp.py compiles this file with -DPPT_ATTN_STAMP into its own library): lane 0 of every
+// wave stores s_memtime at its phase boundaries into the buffer passed as `lse`: [workgroup][wave][16].
+#ifdef PPT_ATTN_STAMP
+#define ATTN_STAMP(slot) do { if (lane == 0) reinterpret_cast<unsigned long long *>(lse)[((size_t)blockIdx.x * 8 + w) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ATTN_STAMP(slot) do { } while (0)
+#endif
+constexpr int RES_LDS = 2 * RES_MAXK * 128 + 8 * RES_SCR_STRIDE * 4;
+
+template <typename F, int NKT>
+__global__ __launch_bounds__(512) void attn_fwd_resident(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out, float *__restrict__ lse,
+                                                         int T, int H, float c /* scale*log2(e) */, int prio, int skew)
+{
+    extern __shared__ __align__(16) unsigned char rsm[];
+    unsigned char *Ks = rsm, *Vs = rsm + RES_MAXK * 128;
+    float *scr = reinterpret_cast<float *>(rsm + 2 * RES_MAXK * 128);
+    PPT_PRIO(prio);
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.x, b = bh / H, head = bh % H;
+    const int64_t rs = 3 * (int64_t)H * HD;
+    constexpr int nkt = NKT, H1 = (NKT + 1) / 2;                       // key tiles; the first H1 are waited for first
+    const int Tk = NKT * KVT;                                          // keys in LDS (whole tiles); key Tk = T - 1 is peeled
+    const bf16_t *qb = qkv + (int64_t)b * T * rs + head * HD;          // row 0 of this sequence, q of this head
+    const bf16_t *kb = qb + H * HD, *vb = qb + 2 * H * HD;
+    const int q0 = 64 * w;
+    const bool active = q0 < Tk;                                       // wave-uniform
+    ATTN_STAMP(0);
+
+    // ---- plain loads first (they complete in order, ahead of the fill): Q fragments, the last key / value
+    uint4 qf[2][4];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            qf[qt][kk] = make_uint4(0, 0, 0, 0);
+            if (active) qf[qt][kk] = *reinterpret_cast<const uint4 *>(qb + (int64_t)(q0 + 32 * qt + r) * rs + 16 * kk + 8 * h);
+        }
+    const bf16_t *kl = kb + (int64_t)Tk * rs, *vl = vb + (int64_t)Tk * rs;
+    uint4 klf[4];
+    uint2 vlf[2][4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) klf[kk] = *reinterpret_cast<const uint4 *>(kl + 16 * kk + 8 * h);
+#pragma unroll
+    for (int dtile = 0; dtile < 2; ++dtile)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) vlf[dtile][gq] = *reinterpret_cast<const uint2 *>(vl + 32 * dtile + 8 * gq + 4 * h);
+
+    // ---- the fill: tile by tile, K piece then V piece of this wave (rows 8 w .. 8 w + 7 of the tile), swizzled on the source side.
+    // (The two compiler fences keep the plain loads OLDER than every piece: hipcc otherwise sinks some of them between the pieces
+    // and then waits for vmcnt(0) -- the whole fill -- before the first use of a Q fragment.)
+    asm volatile("" ::: "memory");
+    {
+        const int lr = 8 * w + (lane >> 3);                            // row inside the tile this lane feeds
+        const int kc = (lane & 7) ^ ((lr >> 1) & 7);                   // K image: chunk c of row r sits in slot c ^ ((r >> 1) & 7)
+        const int vc = (lane & 7) ^ (((lr >> 1) & 1) << 2);            // V image: byte bit 6 ^= bit 1 of the key <-> chunk bit 2
+#pragma unroll
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int64_t row = (int64_t)(kt * KVT + lr) * rs;
+            lds_dma16(kb + row + kc * 8, Ks + (kt * KVT + 8 * w) * 128);
+            lds_dma16(vb + row + vc * 8, Vs + (kt * KVT + 8 * w) * 128);
+        }
+    }
+
+    asm volatile("" ::: "memory");
+    ATTN_STAMP(1);
+    // ---- running state, initialised from the last key (m = c q.k_last, l = 1, O = v_last)
+    f32x16_t ot[2][2];
+    float m[2], l[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float dot = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const uint32_t kw[4] = {klf[kk].x, klf[kk].y, klf[kk].z, klf[kk].w};
+            const uint32_t qw[4] = {qf[qt][kk].x, qf[qt][kk].y, qf[qt][kk].z, qf[qt][kk].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                dot = fmaf(h16<F>::lo(kw[e]), h16<F>::lo(qw[e]), dot);
+                dot = fmaf(h16<F>::hi(kw[e]), h16<F>::hi(qw[e]), dot);
+            }
+        }
+        m[qt] = lane_xor32_sum(dot) * c;
+        l[qt] = h == 0 ? 1.0f : 0.0f;
+#pragma unroll
+        for (int dtile = 0; dtile < 2; ++dtile)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                ot[qt][dtile][4 * gq + 0] = h16<F>::lo(vlf[dtile][gq].x); ot[qt][dtile][4 * gq + 1] = h16<F>::hi(vlf[dtile][gq].x);
+                ot[qt][dtile][4 * gq + 2] = h16<F>::lo(vlf[dtile][gq].y); ot[qt][dtile][4 * gq + 3] = h16<F>::hi(vlf[dtile][gq].y);
+            }
+    }
+
+    const int g = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+    const int tr_key = 4 * (g >> 1) + tq;
+    const int tr_dbyte = (16 * (g & 1) + 4 * tp) * 2;
+
+    // Two waits, two barriers: the first H1 tiles, then the rest (in-order completion: this wave's 2 (nkt - H1) youngest pieces
+    // may still fly at the first).  One barrier per TILE kept the eight waves in lockstep -- the two waves of a SIMD then want the
+    // matrix pipe at the same time (S = K Q^T), then the vector ALU at the same time (softmax), then the matrix pipe again:
+    // in-kernel stamps showed 4 820 cycles per tile = the SUM of both waves' MFMA and VALU cycles.  Behind each barrier the upper
+    // four waves (the second wave of every SIMD) sleep `skew` x 64 cycles, about half a tile, so that one wave's softmax runs
+    // under the other's MFMAs.
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt == 0 || kt == H1) {
+            if (kt == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (NKT - H1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (w >= 4 && skew > 0) for (int i = 0; i < skew; ++i) __builtin_amdgcn_s_sleep(1);
+        }
+        ATTN_STAMP(3 + kt);
+        if (!active) continue;
+        const unsigned char *Kc = Ks + kt * TILE, *Vc = Vs + kt * TILE;
+        f32x16_t st[2][2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) st[qt][sub][e] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            uint4 kf[2];
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) kf[sub] = *reinterpret_cast<const uint4 *>(Kc + k_off(32 * sub + r, 2 * kk + h));
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) st[qt][sub] = h16<F>::mfma32(kf[sub], qf[qt][kk], st[qt][sub]);
+        }
+        uint4 pf[2][2][2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float mx = st[qt][0][0];
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) mx = fmaxf(mx, st[qt][sub][e]);
+            mx = lane_xor32_max(mx);
+            const float mn = fmaxf(m[qt], mx * c);
+            const float alpha = __builtin_amdgcn_exp2f(m[qt] - mn);
+            m[qt] = mn;
+            float psum = 0.f;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(st[qt][sub][e], c, -mn));
+                    st[qt][sub][e] = pv;
+                    psum += pv;
+                }
+            l[qt] = fmaf(l[qt], alpha, psum);
+#pragma unroll
+            for (int dtile = 0; dtile < 2; ++dtile)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) ot[qt][dtile][e] *= alpha;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+                    pf[qt][sub][s2] = make_uint4(h16<F>::pack2(st[qt][sub][8 * s2 + 0], st[qt][sub][8 * s2 + 1]),
+                                                 h16<F>::pack2(st[qt][sub][8 * s2 + 2], st[qt][sub][8 * s2 + 3]),
+                                                 h16<F>::pack2(st[qt][sub][8 * s2 + 4], st[qt][sub][8 * s2 + 5]),
+                                                 h16<F>::pack2(st[qt][sub][8 * s2 + 6], st[qt][sub][8 * s2 + 7]));
+        }
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int dtile = 0; dtile < 2; ++dtile) {
+                    const int key0 = 32 * sub + 16 * s2 + tr_key;
+                    struct { s4_t a, b; } vf;
+                    vf.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s4_t *)(Vc + v_off(key0, tr_dbyte + 64 * dtile)));
+                    vf.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s4_t *)(Vc + v_off(key0 + 8, tr_dbyte + 64 * dtile)));
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt)
+                        ot[qt][dtile] = h16<F>::mfma32(__builtin_bit_cast(uint4, vf), pf[qt][sub][s2], ot[qt][dtile]);
+                }
+    }
+
+    ATTN_STAMP(11);
+    // ---- rows < Tk out
+#ifndef PPT_ATTN_STAMP
+    if (active) {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const int qrow = q0 + 32 * qt + r;
+            const float lt = lane_xor32_sum(l[qt]);
+            const float inv = 1.0f / lt;
+            bf16_t *ob = out + ((int64_t)b * T + qrow) * (H * HD) + head * HD;
+#pragma unroll
+            for (int dtile = 0; dtile < 2; ++dtile)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const uint2 u = make_uint2(h16<F>::pack2(ot[qt][dtile][4 * gq + 0] * inv, ot[qt][dtile][4 * gq + 1] * inv),
+                                               h16<F>::pack2(ot[qt][dtile][4 * gq + 2] * inv, ot[qt][dtile][4 * gq + 3] * inv));
+                    *reinterpret_cast<uint2 *>(ob + 32 * dtile + 8 * gq + 4 * h) = u;
+                }
+            if (lse && h == 0) lse[((int64_t)b * H + head) * T + qrow] = (m[qt] + __log2f(lt)) * 0.6931471805599453f;
+        }
+    }
+#else
+    if (active && ot[0][0][0] == 12345.678f && ot[1][1][3] == 1.5f && l[0] + l[1] == 7.f) out[0] = 0;       // (keep the work alive)
+#endif
+    ATTN_STAMP(12);
+
+    // ---- the last query row (position Tk): wave w < nkt takes key tile w
+    const uint32_t *qc = reinterpret_cast<const uint32_t *>(qb + (int64_t)Tk * rs);      // 32 packed pairs, wave-uniform
+    if (w < nkt) {
+        const unsigned char *Kc = Ks + w * TILE, *Vc = Vs + w * TILE;
+        float dot = 0.f;                                                // lane = key 64 w + lane
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) {
+            const uint4 kv = *reinterpret_cast<const uint4 *>(Kc + k_off(lane, ch));
+            const uint32_t kw[4] = {kv.x, kv.y, kv.z, kv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t qv = qc[4 * ch + e];
+                dot = fmaf(h16<F>::lo(kw[e]), h16<F>::lo(qv), dot);
+                dot = fmaf(h16<F>::hi(kw[e]), h16<F>::hi(qv), dot);
+            }
+        }
+        const float sc = dot * c;
+        const float mw = wave_reduce_max(sc);
+        const float pk = __builtin_amdgcn_exp2f(sc - mw);
+        const float lw = wave_reduce_sum(pk);
+        float acc = 0.f;                                                // lane = output dimension
+#pragma unroll
+        for (int k = 0; k < 64; ++k) {
+            const float pw = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(pk), k));
+            const uint16_t vv = *reinterpret_cast<const uint16_t *>(Vc + v_off(k, 2 * lane));
+            acc = fmaf(pw, h16<F>::to_f32(vv), acc);
+        }
+        if (lane == 0) { scr[w * RES_SCR_STRIDE] = mw; scr[w * RES_SCR_STRIDE + 1] = lw; }
+        scr[w * RES_SCR_STRIDE + 4 + lane] = acc;
+    }
+    ATTN_STAMP(13);
+    __syncthreads();
+    if (w == 0) {
+        const uint16_t *qh = reinterpret_cast<const uint16_t *>(qc);
+        const float self = wave_reduce_sum(h16<F>::to_f32(qh[lane]) * h16<F>::to_f32(kl[lane])) * c;     // the last key against itself
+        float M = self;
+        for (int i = 0; i < nkt; ++i) M = fmaxf(M, scr[i * RES_SCR_STRIDE]);
+        const float es = __builtin_amdgcn_exp2f(self - M);
+        float L = es, O = es * h16<F>::to_f32(vl[lane]);
+        for (int i = 0; i < nkt; ++i) {
+            const float e = __builtin_amdgcn_exp2f(scr[i * RES_SCR_STRIDE] - M);
+            L = fmaf(scr[i * RES_SCR_STRIDE + 1], e, L);
+            O = fmaf(scr[i * RES_SCR_STRIDE + 4 + lane], e, O);
+        }
+        out[((int64_t)b * T + Tk) * (H * HD) + head * HD + lane] = h16<F>::from_f32(O / L);
+#ifndef PPT_ATTN_STAMP
+        if (lse && lane == 0) lse[((int64_t)b * H + head) * T + Tk] = (M + __log2f(L)) * 0.6931471805599453f;
+#endif
+    }
+    ATTN_STAMP(14);
 }
 
 
@@ -651,15 +947,37 @@ extern "C" int ppt_attention_fwd_mfma_bf16(const void *qkv, void *out, float *ls
                                            int causal, int P, int fmt, hipStream_t s)
 {
     if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 7)) return ppt_attention_fwd_quad_bf16(qkv, out, lse, Bt, T, H, scale, causal, P, fmt, s);
-    dim3 grid((T + QB - 1) / QB, (Bt + (P > 0)) * H);
     const float c = scale * 1.4426950408889634f;
     const int prio = ppt_get_wave_priority();
+    // the ViT shape with enough (batch, head) pairs to fill the chip: K / V resident in LDS (attn_fwd_resident)
+    static const bool resident_ok = getenv("PPT_ATTN_RESIDENT") == nullptr || atoi(getenv("PPT_ATTN_RESIDENT")) != 0;
+    if (resident_ok && !causal && P == 0 && (T % KVT) == 1 && T - 1 >= 6 * KVT && T - 1 <= RES_MAXK && Bt * H >= 128) {
+        static const int skew = getenv("PPT_ATTN_SKEW") ? atoi(getenv("PPT_ATTN_SKEW")) : 20;
+#define PPT_RES_ATTR(FF, NN) (void)hipFuncSetAttribute((const void *)attn_fwd_resident<FF, NN>, hipFuncAttributeMaxDynamicSharedMemorySize, RES_LDS)
+        static const bool attr = [] {
+            PPT_RES_ATTR(bf16_t, 6); PPT_RES_ATTR(bf16_t, 7); PPT_RES_ATTR(bf16_t, 8);
+            PPT_RES_ATTR(f16_t, 6); PPT_RES_ATTR(f16_t, 7); PPT_RES_ATTR(f16_t, 8);
+            return true;
+        }();
+        (void)attr;
+#undef PPT_RES_ATTR
+#define PPT_RES_LAUNCH(FF, NN) hipLaunchKernelGGL((attn_fwd_resident<FF, NN>), dim3(Bt * H), dim3(512), RES_LDS, s, (const bf16_t *)qkv, (bf16_t *)out, lse, T, H, c, prio, skew)
+        const int n = (T - 1) / KVT;
+        if (fmt == PPT_F16) { if (n == 6) PPT_RES_LAUNCH(f16_t, 6); else if (n == 7) PPT_RES_LAUNCH(f16_t, 7); else PPT_RES_LAUNCH(f16_t, 8); }
+        else { if (n == 6) PPT_RES_LAUNCH(bf16_t, 6); else if (n == 7) PPT_RES_LAUNCH(bf16_t, 7); else PPT_RES_LAUNCH(bf16_t, 8); }
+#undef PPT_RES_LAUNCH
+        PPT_CHECK_LAUNCH();
+        return PPT_OK;
+    }
+    dim3 grid((T + QB - 1) / QB, (Bt + (P > 0)) * H);
+    const dim3 block(256);
+    static const int xcd_map = getenv("PPT_ATTN_XCD_MAP") == nullptr || atoi(getenv("PPT_ATTN_XCD_MAP")) != 0;
     if (fmt == PPT_F16) {
-        if (causal) hipLaunchKernelGGL((attn_fwd_mfma<true, f16_t>), grid, dim3(256), 0, s, (const bf16_t *)qkv, (bf16_t *)out, lse, T, H, c, P, Bt, prio);
-        else hipLaunchKernelGGL((attn_fwd_mfma<false, f16_t>), grid, dim3(256), 0, s, (const bf16_t *)qkv, (bf16_t *)out, lse, T, H, c, P, Bt, prio);
+        if (causal) hipLaunchKernelGGL((attn_fwd_mfma<true, f16_t>), grid, block, 0, s, (const bf16_t *)qkv, (bf16_t *)out, lse, T, H, c, P, Bt, prio, xcd_map);
+        else hipLaunchKernelGGL((attn_fwd_mfma<false, f16_t>), grid, block, 0, s, (const bf16_t *)qkv, (bf16_t *)out, lse, T, H, c, P, Bt, prio, xcd_map);
     } else {
-        if (causal) hipLaunchKernelGGL((attn_fwd_mfma<true, bf16_t>), grid, dim3(256), 0, s, (const bf16_t *)qkv, (bf16_t *)out, lse, T, H, c, P, Bt, prio);
-        else hipLaunchKernelGGL((attn_fwd_mfma<false, bf16_t>), grid, dim3(256), 0, s, (const bf16_t *)qkv, (bf16_t *)out, lse, T, H, c, P, Bt, prio);
+        if (causal) hipLaunchKernelGGL((attn_fwd_mfma<true, bf16_t>), grid, block, 0, s, (const bf16_t *)qkv, (bf16_t *)out, lse, T, H, c, P, Bt, prio, xcd_map);
+        else hipLaunchKernelGGL((attn_fwd_mfma<false, bf16_t>), grid, block, 0, s, (const bf16_t *)qkv, (bf16_t *)out, lse, T, H, c, P, Bt, prio, xcd_map);
     }
     PPT_CHECK_LAUNCH();
     return PPT_OK;

@@ -959,8 +959,7 @@ __device__ __forceinline__ void glds_slab(const T *base, int64_t ld, int rows, i
         const int r = rg + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);       // source chunk that belongs in LDS slot lane&7 of row r
         const T *src = base + (int64_t)min(r0 + r, rows - 1) * ld + k0 + c * EPC;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                         (__attribute__((address_space(3))) void *)(tile + rg * ROWB), 16, 0, 0);
+        lds_dma16(src, tile + rg * ROWB);
     }
 }
 
@@ -1092,8 +1091,7 @@ __device__ __forceinline__ void glds_half(const T *base, int64_t ld, int rows, i
         const int r = rg + (lane >> 2);
         const int c = (lane & 3) ^ ((r >> 2) & 3);       // source chunk that belongs in LDS slot lane&3 of row r
         const T *src = base + (int64_t)min(r0 + r, rows - 1) * ld + k0 + c * EPC;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                         (__attribute__((address_space(3))) void *)(tile + rg * ROWH), 16, 0, 0);
+        lds_dma16(src, tile + rg * ROWH);
     }
 }
 

@@ -193,6 +193,24 @@ __device__ __forceinline__ uint32_t float_order_key(float f)
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
+// ---- LDS-DMA: global_load_lds_dwordx4 (64 lanes x 16 B -> 1 KiB of LDS starting at `lds`, in lane order) ----------------
+// Issued from inline asm, NOT through __builtin_amdgcn_global_load_lds: hipcc (ROCm 7.2) cannot tell which LDS bytes an LDS-DMA
+// writes, so its wait-count pass puts `s_waitcnt vmcnt(0)` in front of the first ds_read that follows one -- found in the
+// ISA of the 64x64 GEMM's K loop: the slab issued two stages AHEAD was waited for before the current slab's MFMAs, i.e. the
+// three-stage ring ran as one load latency per slab.  The asm form is invisible to that pass; the kernels already place their
+// own counted vmcnt waits (in-order completion), and a compiler-inserted vmcnt(N) for one of ITS loads stays safe with
+// unknown younger operations in the queue (it then waits for more, never for less).
+// `lds` must be wave-uniform; PPT_LDS_DMA_BUILTIN restores the builtin (A/B runs).
+__device__ __forceinline__ void lds_dma16(const void *gsrc, void *lds)
+{
+#ifdef PPT_LDS_DMA_BUILTIN
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc, (__attribute__((address_space(3))) void *)lds, 16, 0, 0);
+#else
+    const uint32_t m0v = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)lds;
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gsrc), "s"(m0v) : "memory", "m0");
+#endif
+}
+
 static inline hipStream_t ppt_stream(void *s) { return (hipStream_t)s; }
 
 // 16-byte NON-TEMPORAL store of a kernel's bulk output (the mini-PointNet activations: hundreds of MB per step, read back by

@@ -358,6 +358,32 @@ def test_attention_fwd_bwd(ops, dtype, tol, Bt, T, H, causal):
     assert err < tol * 4, err
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2e-2), (torch.float16, 3e-3)])
+@pytest.mark.parametrize("Bt,T,H", [(22, 513, 6), (11, 385, 12)])
+def test_attention_fwd_lds_resident_vit_kernel(ops, dtype, tol, Bt, T, H):
+    """attn_fwd_resident (T = 64 n + 1, >= 128 (batch, head) pairs: K / V of a pair resident in LDS, the class-token query row
+    on the vector ALU) against the fp32 reference -- every row, the last one in particular -- with the softmax statistics, and
+    against the streaming kernel the other shapes use (PPT_ATTN_RESIDENT=0 cannot be flipped in-process: a sub-batch below
+    the 128-pair threshold takes the streaming kernel)."""
+    rng = np.random.default_rng(T + H)
+    qkv = rng.standard_normal((Bt * T, 3 * H * 64)).astype(np.float32)
+    qkv[:, :H * 64] *= 2.0                                                # sharper softmax than unit-variance scores
+    qd = dev(qkv, dtype)
+    out, lse = ops.attention_fwd(qd, Bt, T, H, 0.125, False)
+    q32 = qd.float().cpu()
+    ref = _attn_ref(q32, Bt, T, H, 0.125, False)
+    err = (out.float().cpu() - ref).abs()
+    assert err.max().item() < tol, err.max().item()
+    assert err.view(Bt, T, -1)[:, T - 1].max().item() < tol                # the vector-ALU row
+    q, k, _ = q32.view(Bt, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    lse_ref = torch.logsumexp((q @ k.transpose(-2, -1)) * 0.125, -1)       # [Bt, H, T]
+    assert (lse.cpu().view(Bt, H, T) - lse_ref).abs().max().item() < 2e-3
+    nb = 120 // H                                                          # < 128 pairs: the streaming kernel, same rows
+    out_s, lse_s = ops.attention_fwd(qd[:nb * T].contiguous(), nb, T, H, 0.125, False)
+    assert (out[:nb * T].float() - out_s.float()).abs().max().item() < tol / 2
+    assert (lse.view(Bt, H, T)[:nb] - lse_s.view(nb, H, T)).abs().max().item() < 1e-4
+
+
 # ------------------------------------------------------------------ small ops
 def test_conv1_stats_bn_finalize(ops):
     rng = np.random.default_rng(21)

@@ -14,7 +14,7 @@ for r in range(rounds):
             env[k] = val
         if name.startswith("bench:"):                 # bench.py's own loop (any configuration): ms per step, then two zeros
             out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", name[6:], "--steps", "120", "--warmup", "20",
-                                  "--no-cpu-baseline", "--no-roofline", "--no-parity-mode"], env=env, capture_output=True, text=True)
+                                  "--no-cpu-baseline", "--no-roofline", "--no-parity-mode", "--no-secondary"], env=env, capture_output=True, text=True)
             m = re.search(r'"ms_per_step": ([\d.]+)(), "()', out.stdout)
             m = m or re.search(r'"ms_per_step": ([\d.]+)()()', out.stdout)
         else:

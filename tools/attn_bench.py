@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ppt_amd import ops
 for B, T, H, causal in ((32, 513, 6, False), (64, 513, 6, False), (40, 37, 8, True)):
-    qkv = torch.randn(B * T, 3 * H * 64, device="cuda").bfloat16()
+    qkv = torch.randn(B * T, 3 * H * 64, device="cuda").half()
     f = lambda: ops.attention_fwd(qkv, B, T, H, 0.125, causal, want_lse=False)
     for _ in range(3): f()
     torch.cuda.synchronize()
