@@ -284,7 +284,7 @@ constexpr int RES_LDS = 2 * RES_MAXK * 128 + 8 * RES_SCR_STRIDE * 4;
 
 template <typename F, int NKT>
 __global__ __launch_bounds__(512) void attn_fwd_resident(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out, float *__restrict__ lse,
-                                                         int T, int H, float c /* scale*log2(e) */, int prio, int skew)
+                                                         int T, int H, float c /* scale*log2(e) */, int prio)
 {
     extern __shared__ __align__(16) unsigned char rsm[];
     unsigned char *Ks = rsm, *Vs = rsm + RES_MAXK * 128;
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(512) void attn_fwd_resident(const bf16_t *__restric
     const int r = lane & 31, h = lane >> 5;
     const int bh = blockIdx.x, b = bh / H, head = bh % H;
     const int64_t rs = 3 * (int64_t)H * HD;
-    constexpr int nkt = NKT, H1 = (NKT + 1) / 2;                       // key tiles; the first H1 are waited for first
+    constexpr int nkt = NKT;
     const int Tk = NKT * KVT;                                          // keys in LDS (whole tiles); key Tk = T - 1 is peeled
     const bf16_t *qb = qkv + (int64_t)b * T * rs + head * HD;          // row 0 of this sequence, q of this head
     const bf16_t *kb = qb + H * HD, *vb = qb + 2 * H * HD;
@@ -322,22 +322,22 @@ __global__ __launch_bounds__(512) void attn_fwd_resident(const bf16_t *__restric
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) vlf[dtile][gq] = *reinterpret_cast<const uint2 *>(vl + 32 * dtile + 8 * gq + 4 * h);
 
-    // ---- the fill: tile by tile, K piece then V piece of this wave (rows 8 w .. 8 w + 7 of the tile), swizzled on the source side.
-    // (The two compiler fences keep the plain loads OLDER than every piece: hipcc otherwise sinks some of them between the pieces
-    // and then waits for vmcnt(0) -- the whole fill -- before the first use of a Q fragment.)
+    // ---- the fill: per 64-key tile one K piece and one V piece of this wave (rows 8 w .. 8 w + 7 of the tile), swizzled on the
+    // source side.  Tiles 0 and 1 here, tile kt + 2 behind the barrier of tile kt: issued all at once, the 16 pieces held every
+    // wave at the issue stage for 7 500 cycles (in-kernel stamps: a CU's memory pipeline takes ~1 KB per 26 cycles) before its
+    // first MFMA.  (The two compiler fences keep the plain loads OLDER than every piece: hipcc otherwise sinks some of them
+    // between the pieces.)
     asm volatile("" ::: "memory");
-    {
-        const int lr = 8 * w + (lane >> 3);                            // row inside the tile this lane feeds
-        const int kc = (lane & 7) ^ ((lr >> 1) & 7);                   // K image: chunk c of row r sits in slot c ^ ((r >> 1) & 7)
-        const int vc = (lane & 7) ^ (((lr >> 1) & 1) << 2);            // V image: byte bit 6 ^= bit 1 of the key <-> chunk bit 2
-#pragma unroll
-        for (int kt = 0; kt < nkt; ++kt) {
-            const int64_t row = (int64_t)(kt * KVT + lr) * rs;
-            lds_dma16(kb + row + kc * 8, Ks + (kt * KVT + 8 * w) * 128);
-            lds_dma16(vb + row + vc * 8, Vs + (kt * KVT + 8 * w) * 128);
-        }
-    }
-
+    const int lr = 8 * w + (lane >> 3);                                // row inside the tile this lane feeds
+    const int kc = (lane & 7) ^ ((lr >> 1) & 7);                       // K image: chunk c of row r sits in slot c ^ ((r >> 1) & 7)
+    const int vc = (lane & 7) ^ (((lr >> 1) & 1) << 2);                // V image: byte bit 6 ^= bit 1 of the key <-> chunk bit 2
+    const bf16_t *ksrc = kb + (int64_t)lr * rs + kc * 8, *vsrc = vb + (int64_t)lr * rs + vc * 8;
+    auto fill = [&](int kt) {
+        lds_dma16(ksrc + (int64_t)kt * KVT * rs, Ks + (kt * KVT + 8 * w) * 128);
+        lds_dma16(vsrc + (int64_t)kt * KVT * rs, Vs + (kt * KVT + 8 * w) * 128);
+    };
+    fill(0);
+    if (nkt > 1) fill(1);
     asm volatile("" ::: "memory");
     ATTN_STAMP(1);
     // ---- running state, initialised from the last key (m = c q.k_last, l = 1, O = v_last)
@@ -371,19 +371,18 @@ __global__ __launch_bounds__(512) void attn_fwd_resident(const bf16_t *__restric
     const int tr_key = 4 * (g >> 1) + tq;
     const int tr_dbyte = (16 * (g & 1) + 4 * tp) * 2;
 
-    // Two waits, two barriers: the first H1 tiles, then the rest (in-order completion: this wave's 2 (nkt - H1) youngest pieces
-    // may still fly at the first).  One barrier per TILE kept the eight waves in lockstep -- the two waves of a SIMD then want the
-    // matrix pipe at the same time (S = K Q^T), then the vector ALU at the same time (softmax), then the matrix pipe again:
-    // in-kernel stamps showed 4 820 cycles per tile = the SUM of both waves' MFMA and VALU cycles.  Behind each barrier the upper
-    // four waves (the second wave of every SIMD) sleep `skew` x 64 cycles, about half a tile, so that one wave's softmax runs
-    // under the other's MFMAs.
+    // One counted wait + one barrier per tile: in-order completion, so with this wave's two youngest pieces (tile kt + 1) still
+    // flying its pieces of tile kt have landed; behind the barrier everybody's have, and tile kt + 2 is requested.  The fill is
+    // paced by what a CU pulls out of L2 (~600 cycles per tile), a tile's arithmetic takes ~4 000 (the loop is bound by the
+    // vector ALU: 2 waves x ~1 700 issue cycles of softmax per tile and SIMD), so only tile 0 is ever waited for.
+    // (Tried: two barriers -- after half of the tiles, after all -- with the upper four waves sleeping half a tile behind each
+    // so that one wave's softmax would run under the other's MFMAs: no change per tile.)
+#pragma unroll
     for (int kt = 0; kt < nkt; ++kt) {
-        if (kt == 0 || kt == H1) {
-            if (kt == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (NKT - H1)) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (w >= 4 && skew > 0) for (int i = 0; i < skew; ++i) __builtin_amdgcn_s_sleep(1);
-        }
+        if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nkt) fill(kt + 2);
         ATTN_STAMP(3 + kt);
         if (!active) continue;
         const unsigned char *Kc = Ks + kt * TILE, *Vc = Vs + kt * TILE;
@@ -426,10 +425,13 @@ __global__ __launch_bounds__(512) void attn_fwd_resident(const bf16_t *__restric
                     psum += pv;
                 }
             l[qt] = fmaf(l[qt], alpha, psum);
+            // (the running maximum moves in the first tiles and then rarely: skip the 32 rescaling multiplies when no lane's did)
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-            for (int dtile = 0; dtile < 2; ++dtile)
+                for (int dtile = 0; dtile < 2; ++dtile)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) ot[qt][dtile][e] *= alpha;
+                    for (int e = 0; e < 16; ++e) ot[qt][dtile][e] *= alpha;
+            }
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
@@ -952,7 +954,6 @@ extern "C" int ppt_attention_fwd_mfma_bf16(const void *qkv, void *out, float *ls
     // the ViT shape with enough (batch, head) pairs to fill the chip: K / V resident in LDS (attn_fwd_resident)
     static const bool resident_ok = getenv("PPT_ATTN_RESIDENT") == nullptr || atoi(getenv("PPT_ATTN_RESIDENT")) != 0;
     if (resident_ok && !causal && P == 0 && (T % KVT) == 1 && T - 1 >= 6 * KVT && T - 1 <= RES_MAXK && Bt * H >= 128) {
-        static const int skew = getenv("PPT_ATTN_SKEW") ? atoi(getenv("PPT_ATTN_SKEW")) : 20;
 #define PPT_RES_ATTR(FF, NN) (void)hipFuncSetAttribute((const void *)attn_fwd_resident<FF, NN>, hipFuncAttributeMaxDynamicSharedMemorySize, RES_LDS)
         static const bool attr = [] {
             PPT_RES_ATTR(bf16_t, 6); PPT_RES_ATTR(bf16_t, 7); PPT_RES_ATTR(bf16_t, 8);
@@ -961,7 +962,7 @@ extern "C" int ppt_attention_fwd_mfma_bf16(const void *qkv, void *out, float *ls
         }();
         (void)attr;
 #undef PPT_RES_ATTR
-#define PPT_RES_LAUNCH(FF, NN) hipLaunchKernelGGL((attn_fwd_resident<FF, NN>), dim3(Bt * H), dim3(512), RES_LDS, s, (const bf16_t *)qkv, (bf16_t *)out, lse, T, H, c, prio, skew)
+#define PPT_RES_LAUNCH(FF, NN) hipLaunchKernelGGL((attn_fwd_resident<FF, NN>), dim3(Bt * H), dim3(512), RES_LDS, s, (const bf16_t *)qkv, (bf16_t *)out, lse, T, H, c, prio)
         const int n = (T - 1) / KVT;
         if (fmt == PPT_F16) { if (n == 6) PPT_RES_LAUNCH(f16_t, 6); else if (n == 7) PPT_RES_LAUNCH(f16_t, 7); else PPT_RES_LAUNCH(f16_t, 8); }
         else { if (n == 6) PPT_RES_LAUNCH(bf16_t, 6); else if (n == 7) PPT_RES_LAUNCH(bf16_t, 7); else PPT_RES_LAUNCH(bf16_t, 8); }

@@ -111,10 +111,11 @@ FUSED_CONV12 = os.environ.get("PPT_FUSED_CONV12", "1") != "0"      # 0: the gene
 # 11-27 % faster each; C2 (16 416 rows) 3.99 -> 4.17 ms although two of the three are ~10 % faster in isolation -- its
 # workgroups take a whole CU each (8 waves x 256 VGPRs), and with only 7 row tiles per workgroup to amortise the weight
 # preload the small win is paid back by the text tower's kernels, which can no longer share those CUs.  PPT_ROWGEMM=0 / 1
-# forces it off / on.
+# forces it off / on.  (Round 3, after the LDS-DMA fix of ppt_common.h made the prompt chain's GEMMs 6-23 % faster: C2 3.422 ->
+# 3.345 ms WITH it, same box, tools/ab_env.py -- the threshold went from 24 000 to 16 000 rows.)
 FUSED_MLP = os.environ.get("PPT_FUSED_MLP", "1") != "0"             # LayerNorm + fc1 + GELU + fc2 + residual of a frozen block: one kernel
 _RG = os.environ.get("PPT_ROWGEMM", "")
-ROWGEMM_MIN_ROWS = 1 << 30 if _RG == "0" else (0 if _RG == "1" else 24000)
+ROWGEMM_MIN_ROWS = 1 << 30 if _RG == "0" else (0 if _RG == "1" else 16000)
 
 
 def _bn_params(sd, p):

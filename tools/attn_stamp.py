@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""In-kernel phase timing of attn_fwd_resident (csrc/attention_mfma.hip, ATTN_STAMP): s_memtime ticks (100 MHz) per phase.
+"""In-kernel phase timing of attn_fwd_resident (csrc/attention_mfma.hip, ATTN_STAMP): s_memtime ticks (shader cycles) per phase.
 
     bash tools/build_variant.sh attnstamp -DPPT_ATTN_STAMP && python tools/attn_stamp.py"""
 import ctypes, os, sys
@@ -30,6 +30,6 @@ prev = 0
 for i, n in enumerate(names):
     if n == "-":
         continue
-    print(f"{n:12s} median {med(s[:, :, i] - s[:, :, 0]) * 10:8.0f} ns after entry (+{(med(s[:, :, i] - s[:, :, 0]) - prev) * 10:6.0f})   max {(s[:, :, i] - s[:, :, 0]).max() * 10} ns")
+    print(f"{n:12s} median {med(s[:, :, i] - s[:, :, 0]) :8.0f} cycles after entry (+{(med(s[:, :, i] - s[:, :, 0]) - prev):6.0f})   max {(s[:, :, i] - s[:, :, 0]).max()} cycles")
     prev = med(s[:, :, i] - s[:, :, 0])
-print("entry spread (last workgroup entry - first):", (s[:, :, 0].max() - t0) * 10, "ns; last exit:", (s[:, :, 14].max() - t0) * 10, "ns")
+print("entry spread (last workgroup entry - first):", (s[:, :, 0].max() - t0), "cycles; last exit:", (s[:, :, 14].max() - t0), "cycles")
