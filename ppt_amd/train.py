@@ -255,8 +255,11 @@ class Trainer:
         self._tower_used = None
         # With a fully frozen point side (head_type 0) the tower already runs back to back on its stream with the whole
         # prompt side underneath it, the step is throughput-bound and hiding FPS buys nothing (C2: 4.22 ms without, 4.29
-        # with); with a trainable last block the caller's stream has bubbles and it does (C3: 8.85 -> 8.28 ms).
-        self.group_ahead_when_frozen = False
+        # with); with a trainable last block the caller's stream has bubbles and it does (C3: 8.85 -> 8.28 ms).  Round 3: with the
+        # faster prompt chain the tower is the longer side and the 0.22 ms of serial FPS picks at its head now count -- C2
+        # 3.349 -> 3.283 ms with the grouping stage ahead (same box, tools/ab_env.py): on by default, PPT_GROUP_AHEAD_FROZEN=0
+        # turns it off.
+        self.group_ahead_when_frozen = os.environ.get("PPT_GROUP_AHEAD_FROZEN", "1") != "0"
         # head_type 0: only the prompt learner trains, so the point tower never reads a parameter the optimizer writes
         self._point_side_frozen = all(n.startswith("prompt_learner.") or not p.requires_grad
                                       for n, p in model.named_parameters())
