@@ -15,7 +15,7 @@ untimed steps, then EXACTLY --steps K steps bracketed by barrier + torch.cuda.sy
 time; "ms_per_step_median" is the median of the K per-step times taken with HIP events on the caller's stream.
 
 Prints ONE JSON line (rank 0): metric/value/unit..., plus
-  "roofline":     the dominant kernel (the bf16 MFMA GEMM family) -- algorithmic FLOPs / its summed launch
+  "roofline":     the dominant kernel (the 16-bit -- fp16 / bf16 -- MFMA GEMM family) -- algorithmic FLOPs / its summed launch
                   time measured with HIP events on the launch stream during a second, instrumented pass
                   over the same K steps -- against the 2.5 PFLOP/s dense bf16 peak;
                   "roofline.kernels" lists EVERY hot kernel of that pass the same way: FPS / kNN / ball query against
@@ -408,7 +408,7 @@ def main():
             if a.config == "C2" and os.path.exists(tf):
                 traffic = round(json.load(open(tf))["hbm_bytes_per_launch"])
                 break
-        roof = {"bound": "mfma", "kernel": "bf16 GEMM family (ppt_amd/csrc/gemm.hip, mpn1/mpn3/mpn4.hip)",
+        roof = {"bound": "mfma", "kernel": "16-bit (fp16 / bf16) MFMA GEMM family (ppt_amd/csrc/gemm.hip, rowgemm.hip, mlp_fused.hip, mpn1/mpn3/mpn4.hip)",
                 "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                 "launches_per_step": g["launches"] // a.steps,

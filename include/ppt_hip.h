@@ -34,11 +34,14 @@ extern "C" {
 #define PPT_F32 0
 #define PPT_BF16 1
 #define PPT_F16 2   /* IEEE half operands / fp32 accumulate: the MFMA rate of bf16 with 11 significand bits instead of 8 -- the
-                     * operand format of the transformer-side GEMMs / attention (activations bounded by LayerNorm, residual stream
-                     * in fp32, gradients scaled); bf16 stays the format of the tokenizer's un-normalised activations */
+                     * operand format of the performance mode's text tower, PointBERT tokenizer + blocks and part-seg decoder
+                     * (residual stream and statistics in fp32; the backward is seeded with a power-of-two loss scale by the
+                     * host, ppt_adamw_step un-scales); bf16 stays the format of PointNet++ / PointMLP */
 
 const char *ppt_strerror(int code);
-/* ABI version of this header (currently 2); bumped on any signature change or added entry point. */
+/* ABI version of this header (currently 3); bumped on any signature change or added entry point.
+ * 3: PPT_F16 (dtype arguments / struct fields), ppt_cross_entropy_rows (ignored labels, loss[2]), ppt_adamw_step (grad_scale),
+ *    ppt_bn_rows_bwd_apply (half_dtype), ppt_*_half entry points. */
 int ppt_abi_version(void);
 
 /* ---- H1: farthest point sampling ---------------------------------------------------------

@@ -53,11 +53,11 @@ def section(rnd, cfg, d, out):
           f"`{rnd}_bench_{cfg}.json`: `python bench.py --config {cfg.upper()}` -> **{bench['value']} clouds/s**, {bench['ms_per_step']} ms/step "
           f"(median step {bench.get('ms_per_step_median')} ms; {bench['steps']} steps after {bench.get('burn_in')} burn-in + {bench['warmup']} warm-up)"
           + (f"; fp32 parity mode {par.get('value')} clouds/s ({par.get('ms_per_step')} ms/step)" if par else "") + ".", "",
-          f"roofline (bf16 GEMM family, HIP-event brackets in an eager pass): {roof.get('achieved')} TFLOP/s = {100 * (roof.get('frac') or 0):.1f} % of 2.5 "
+          f"roofline (16-bit MFMA GEMM family, HIP-event brackets in an eager pass): {roof.get('achieved')} TFLOP/s = {100 * (roof.get('frac') or 0):.1f} % of 2.5 "
           f"PFLOP/s, {roof.get('launches_per_step')} launches/step, avg {roof.get('avg_launch_us')} us.", "",
           f"`{rnd}_bench_{cfg}_kernel_stats.csv`: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --config {cfg.upper()} --steps 10 "
           f"--warmup 5 --no-cpu-baseline --no-roofline --no-parity-mode` ({n} steps in the trace).  {len(tr) / n:.0f} kernels/step, "
-          f"{total / n / 1e6:.2f} ms/step of kernel time over all streams; bf16 GEMM family {len(g) / n:.0f} launches/step, avg {g.dur.mean() / 1e3:.1f} us, "
+          f"{total / n / 1e6:.2f} ms/step of kernel time over all streams; 16-bit GEMM family {len(g) / n:.0f} launches/step, avg {g.dur.mean() / 1e3:.1f} us, "
           f"{g.dur.sum() / n / 1e6:.2f} ms/step; ATen / runtime-copy kernels {len(at) / n:.1f} launches/step, {at.dur.sum() / n / 1e6:.3f} ms/step.", "",
           "| kernel | launches/step | avg us | ms/step | % of kernel time |", "|---|---|---|---|---|"]
     for nm, r in t.head(16).iterrows():
