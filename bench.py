@@ -127,7 +127,8 @@ def operand_formats(model_name):
     if model_name == "ULIP_PointBERT":
         return {"text_tower": text, "pointbert_tokenizer": tok, "transformer_blocks": blocks, "heads": "f32"}
     if model_name == "ULIP_PointBERT_partseg":
-        return {"text_tower": text, "pointbert_tokenizer": tok, "transformer_blocks": blocks, "partseg_decoder": "bf16", "per_point_head": "f16"}
+        return {"text_tower": text, "pointbert_tokenizer": tok, "transformer_blocks": blocks,
+                "partseg_decoder": "f16" if engine.DECODER_F16 else "bf16", "per_point_head": "f16"}
     return {"text_tower": text, "point_encoder": "bf16", "heads": "f32"}
 
 
@@ -256,8 +257,10 @@ def main_eval(a):
     out = {"metric": METRICS[a.config].replace("fwd+bwd", "validate() forward"), "value": round(B * a.steps / dt, 2),
            "unit": "point-clouds/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "burn_in": BURN_IN_STEPS,
            "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "bf16", "data": "synthetic",
+           "dtype": "f16" if set(operand_formats(cfg.get("model", "ULIP_PointBERT")).values()) <= {"f16", "f32"} else "f16/bf16",
+           "data": "synthetic",
            "config": {"workload": cfg["name"] + ", eval-mode forward under no_grad (validate(), main_cls.py:237-299)",
+                      "operand_formats": operand_formats(cfg.get("model", "ULIP_PointBERT")),
                       "per_gpu_batch": B, "npoints": N, "parallelism": "dp1"}}
     print(json.dumps(out), flush=True)
 
