@@ -263,8 +263,34 @@ def vit_block_forward(sd, p, wc, x, pos, B, Tn, heads, dp1, dp2, save=None, pos_
     return x_out
 
 
+def tokenize_points(sd, p, wc, pc, fps_start, bn_train, cfg, update_running=True, grouped=None):
+    """The part of PointTransformer.forward in front of the blocks (point_encoder.py:234-249): Group (FPS + kNN), the
+    mini-PointNet encoder, reduce_dim, cls token / cls_pos and pos_embed -> (x2, pos2), both [B*Tn, D] fp32 (Tn = G + 1).
+    A function of the input cloud and frozen weights alone: train.Trainer can run it ahead of the step (PointTransformer._group_ahead)."""
+    G, D = cfg["num_group"], cfg["trans_dim"]
+    Tn = G + 1
+    # grouped = (nbhd, center): Group.forward was already run (ahead of the step, on its own stream)
+    nbhd, center = grouped if grouped is not None else group_points(pc, G, cfg["group_size"], fps_start)
+    B = center.shape[0]
+    dev = center.device
+    wct = _stage_wc(wc, "tokenizer")
+    tok = mini_pointnet(sd, p + "encoder.", wct, nbhd, bn_train, update_running)
+    x = torch.empty((B, Tn, D), dtype=torch.float32, device=dev)
+    pos = torch.empty((B, Tn, D), dtype=torch.float32, device=dev)
+    x[:, 0] = sd[p + "cls_token"].view(D)
+    pos[:, 0] = sd[p + "cls_pos"].view(D)
+    x2, pos2 = x.view(B * Tn, D), pos.view(B * Tn, D)
+    # reduce_dim and pos_embed write straight into rows 1.. of every sample (batched GEMM)
+    ops.gemm(tok, wct.get(sd[p + "reduce_dim.weight"]), out=x2[1:], M=G, bias=sd[p + "reduce_dim.bias"], batch=B,
+             strideA=G * tok.shape[1], strideC=Tn * D)
+    pe = ops.linear3_gelu(center.view(B * G, 3), sd[p + "pos_embed.0.weight"], sd[p + "pos_embed.0.bias"], wct.dtype)
+    ops.gemm(pe, wct.get(sd[p + "pos_embed.2.weight"]), out=pos2[1:], M=G, bias=sd[p + "pos_embed.2.bias"], batch=B,
+             strideA=G * pe.shape[1], strideC=Tn * D)
+    return x2, pos2, center
+
+
 def point_encoder_forward(sd, p, wc, pc, fps_start, dp, bn_train, save_tier, cfg, update_running=True, fetch=None,
-                          last_block=None, resume=None, grouped=None):
+                          last_block=None, resume=None, grouped=None, tokens=None):
     """PointTransformer.forward (point_encoder.py:234-257) -> (feat [B,2*D] fp32, saved | None).
     dp: DropPath factors [depth,2,B] fp32 or None; save_tier > 0 keeps block-(depth-1) activations.
 
@@ -272,28 +298,18 @@ def point_encoder_forward(sd, p, wc, pc, fps_start, dp, bn_train, save_tier, cfg
     last_block=False runs the tokenizer and blocks 0 .. depth-2 -- everything that is frozen whatever the head_type --
     and returns (x2, pos2), both [B*Tn, D] fp32, x2 with the last block's "+ pos" already added;
     resume=(x2, pos2) runs the last block, the final norm and the pooling on them.
-    grouped=(neighbourhoods [B,G,n,3], centres [B,G,3]) replaces pc / fps_start."""
+    grouped=(neighbourhoods [B,G,n,3], centres [B,G,3]) replaces pc / fps_start; tokens=(x2, pos2) = tokenize_points' result
+    (x2 is updated in place) replaces the whole tokenizer."""
     T = wc.dtype
     G, D, depth, heads = cfg["num_group"], cfg["trans_dim"], cfg["depth"], cfg["num_heads"]
     Tn = G + 1
+    center = None
     if resume is None:
-        # grouped = (nbhd, center): Group.forward was already run (ahead of the step, on its own stream)
-        nbhd, center = grouped if grouped is not None else group_points(pc, G, cfg["group_size"], fps_start)
-        B = center.shape[0]
-        dev = center.device
-        wct = _stage_wc(wc, "tokenizer")
-        tok = mini_pointnet(sd, p + "encoder.", wct, nbhd, bn_train, update_running)
-        x = torch.empty((B, Tn, D), dtype=torch.float32, device=dev)
-        pos = torch.empty((B, Tn, D), dtype=torch.float32, device=dev)
-        x[:, 0] = sd[p + "cls_token"].view(D)
-        pos[:, 0] = sd[p + "cls_pos"].view(D)
-        x2, pos2 = x.view(B * Tn, D), pos.view(B * Tn, D)
-        # reduce_dim and pos_embed write straight into rows 1.. of every sample (batched GEMM)
-        ops.gemm(tok, wct.get(sd[p + "reduce_dim.weight"]), out=x2[1:], M=G, bias=sd[p + "reduce_dim.bias"], batch=B,
-                 strideA=G * tok.shape[1], strideC=Tn * D)
-        pe = ops.linear3_gelu(center.view(B * G, 3), sd[p + "pos_embed.0.weight"], sd[p + "pos_embed.0.bias"], wct.dtype)
-        ops.gemm(pe, wct.get(sd[p + "pos_embed.2.weight"]), out=pos2[1:], M=G, bias=sd[p + "pos_embed.2.bias"], batch=B,
-                 strideA=G * pe.shape[1], strideC=Tn * D)
+        if tokens is not None:
+            x2, pos2 = tokens
+        else:
+            x2, pos2, center = tokenize_points(sd, p, wc, pc, fps_start, bn_train, cfg, update_running, grouped)
+        B = x2.shape[0] // Tn
         first, pos_in_x = 0, False
     else:
         x2, pos2 = resume

@@ -24,8 +24,10 @@ class GraphedCall:
     overwrites them, callers that keep a result across replays clone it); `keepalive` is anything else
     the capture allocated that a later graph reads (saved activations)."""
 
-    def __init__(self, fn, inputs, pool=None):
-        self.static_in = [t.clone() for t in inputs]
+    def __init__(self, fn, inputs, pool=None, alias_inputs=False):
+        # alias_inputs: the inputs ARE static buffers (another graph's outputs, handed over in place): captured as they are, and
+        # __call__ copies nothing for an input that is the captured tensor itself
+        self.static_in = list(inputs) if alias_inputs else [t.clone() for t in inputs]
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: only THIS thread's calls are checked against the capture.  Under a process group RCCL's watchdog thread
         # polls the events of earlier collectives (the DDP-constructor broadcast, the previous step's all-reduce); in the default
@@ -39,7 +41,8 @@ class GraphedCall:
 
     def __call__(self, *inputs):
         for dst, src in zip(self.static_in, inputs):
-            dst.copy_(src)
+            if dst is not src:
+                dst.copy_(src)
         self.graph.replay()
         return self.outputs, self.keepalive
 

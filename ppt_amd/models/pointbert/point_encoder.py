@@ -187,17 +187,21 @@ class _PointEncoderFn(torch.autograd.Function):
         ahead = module.group_ahead if (use_graph and module._graphs.ready(("group", tuple(pc.shape), drawn))) else None
         if not split and use_graph and module._graphs.ready(key):
             if ahead is not None:
-                # FPS + kNN ran (or run right now) on the grouping stream, overlapping the previous iteration's blocks
-                grouped, slot = module._group_ahead(pc, fps_start, drawn, ahead)
+                # FPS + kNN (and, tokenize_ahead, the whole tokenizer) ran -- or run right now -- on the grouping stream,
+                # overlapping the previous iteration's blocks
+                tk = module.tokenize_ahead
+                grouped, slot = module._group_ahead(pc, fps_start, drawn, ahead, tokenize=tk)
                 ins = list(grouped) + ([dp] if dp is not None else [])
 
                 def build():
                     def fn(nb_, ce_, *rest):
                         dp_ = module._draw_drop_path(B, pc.device) if drawn else (rest[0] if rest else None)
-                        feat_, _ = engine.point_encoder_forward(sd, "", cache, None, None, dp_, train, 0, cfg, grouped=(nb_, ce_))
+                        kw = dict(tokens=(nb_, ce_)) if tk else dict(grouped=(nb_, ce_))
+                        feat_, _ = engine.point_encoder_forward(sd, "", cache, None, None, dp_, train, 0, cfg, **kw)
                         return (feat_,), None
-                    return graphs.GraphedCall(fn, ins)
-                (feat,), _ = module._graphs.get(key + ("grouped",), build)(*ins)
+                    # (the tokens are handed over in place: one tower graph per ping-pong pair instead of 2 x 25 MB of copies)
+                    return graphs.GraphedCall(fn, ins, alias_inputs=tk and dp is None)
+                (feat,), _ = module._graphs.get(key + ((("tokens", slot) if dp is None else ("tokens",)) if tk else ("grouped",)), build)(*ins)
                 module._group_consumed(slot)
                 ctx.saved = None
                 return feat.clone()
@@ -220,17 +224,19 @@ class _PointEncoderFn(torch.autograd.Function):
             if use_graph and module._graphs.ready(key):
                 slot = None
                 if ahead is not None:
-                    grouped, slot = module._group_ahead(pc, fps_start, drawn, ahead)
+                    tk = module.tokenize_ahead
+                    grouped, slot = module._group_ahead(pc, fps_start, drawn, ahead, tokenize=tk)
                     ins = list(grouped) + ([dp] if dp is not None else [])
 
                     def build():
                         def fn(nb_, ce_, *rest):
                             dp_ = module._draw_drop_path(B, pc.device) if drawn else (rest[0] if rest else None)
+                            kw = dict(tokens=(nb_, ce_)) if tk else dict(grouped=(nb_, ce_))
                             x2_, pos2_ = engine.point_encoder_forward(sd, "", cache, None, None, dp_, train, 0, cfg,
-                                                                      last_block=False, grouped=(nb_, ce_))
+                                                                      last_block=False, **kw)
                             return (x2_, pos2_) + ((dp_,) if dp_ is not None else ()), None
-                        return graphs.GraphedCall(fn, ins)
-                    key = key + ("grouped",)
+                        return graphs.GraphedCall(fn, ins, alias_inputs=tk and dp is None)
+                    key = key + ((("tokens", slot) if dp is None else ("tokens",)) if tk else ("grouped",))
                 else:
                     ins = [pc] if drawn else [pc, fps_start] + ([dp] if dp is not None else [])
 
@@ -317,6 +323,9 @@ class PointTransformer(nn.Module):
         # cloud is complete in memory at the time of the call (train.Trainer.inputs_ready): it then overlaps the previous
         # iteration's transformer blocks instead of heading this one's critical path.  None: grouping stays in the tower.
         self.group_ahead = None
+        # ... and with it the rest of the tokenizer (mini-PointNet, reduce_dim, pos_embed: frozen in every PPT configuration, a
+        # function of the cloud alone, HBM-bound where the blocks it then runs beside are not).  PPT_TOKENIZE_AHEAD=0: FPS + kNN only.
+        self.tokenize_ahead = os.environ.get("PPT_TOKENIZE_AHEAD", "1") != "0"
         self._group_slot = 0
         self._group_free = [None, None]
         self.fps_start = None            # [B] int64: injected FPS start indices (else torch.randint)
@@ -373,26 +382,34 @@ class PointTransformer(nn.Module):
         total = sum(1 for q in self.parameters() if q.requires_grad)
         return in_last > 0, total > in_last
 
-    def _group_ahead(self, pc, fps_start, drawn, side):
+    def _group_ahead(self, pc, fps_start, drawn, side, tokenize=False):
         """Group.forward (dvae.py:159-181) of `pc` on `side`, replayed from one of two hipGraphs with their own output
         buffers (the previous tower may still be reading the other pair).  The caller's stream is made to wait for the
         result; `side` waits for nothing but the tower that last read this pair -- NOT for the caller's stream, which is
-        the point: the caller guarantees `pc` (and `fps_start`) are complete in memory.  -> ((nbhd, center), slot)."""
+        the point: the caller guarantees `pc` (and `fps_start`) are complete in memory.  -> ((nbhd, center), slot).
+        tokenize: the stage runs the whole tokenizer (engine.tokenize_points: + mini-PointNet, reduce_dim, pos_embed -- frozen
+        weights, train-mode BatchNorm statistics of this batch) -> ((x2, pos2), slot), the blocks' input."""
         main = torch.cuda.current_stream()
         slot = self._group_slot = 1 - self._group_slot
         B, N = pc.shape[0], pc.shape[1]
         G, n = self.num_group, self.group_size
         ins = [pc] if drawn else [pc, fps_start]
+        key = ("group", tuple(pc.shape), drawn, slot)
+        if tokenize:
+            sd, cache, cfg, train = self._live_state(), self._cache(), self._cfg(), self.training
+            key = ("tokens", tuple(pc.shape), drawn, train, cache.dtype, ops.get_persistent_occupancy(), slot)
 
         def build():
             def fn(pc_, *rest):
                 start_ = torch.randint(0, N, (B,), dtype=torch.long, device=pc_.device) if drawn else rest[0]   # misc.py:59
+                if tokenize:
+                    return tuple(engine.tokenize_points(sd, "", cache, pc_, start_, train, cfg)[:2]), None
                 return tuple(engine.group_points(pc_, G, n, start_)), None
             return graphs.GraphedCall(fn, ins)
         with torch.cuda.stream(side):
             if self._group_free[slot] is not None:
                 side.wait_event(self._group_free[slot])
-            grouped, _ = self._graphs.get(("group", tuple(pc.shape), drawn, slot), build)(*ins)
+            grouped, _ = self._graphs.get(key, build)(*ins)
             done = side.record_event()
         for t in ins:
             t.record_stream(side)

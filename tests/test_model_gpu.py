@@ -219,8 +219,8 @@ def test_overlapped_text_tower_is_identical():
 def test_run_ahead_training_is_identical(head_type):
     """Trainer.step with the prompt side queued on the text stream (and, for head_type 0, the next iteration's
     point tower running ahead of the optimizer), without and with the text tower replayed from hipGraphs, and with
-    FPS + kNN of an iteration running ahead on the grouping stream, must produce exactly the losses and parameters of the
-    single-stream eager step."""
+    FPS + kNN + the frozen tokenizer of an iteration running ahead on the grouping stream, must produce exactly the losses and
+    parameters of the single-stream eager step."""
     from ppt_amd.train import Trainer
     pc, start = oracle_inputs()
     label = torch.tensor([3, 17, 0, 39]).cuda()
@@ -248,8 +248,12 @@ def test_run_ahead_training_is_identical(head_type):
         assert bool(m._graphs.entries) == hip_graphs          # the text tower really was replayed from a hipGraph
         # ... and the point tower: all of it for head_type 0, the frozen prefix in front of the last block otherwise
         tower = "point_fwd" if head_type == 0 else "point_prefix"
-        kinds = sorted(k[0] + ("+grouped" if k[-1] == "grouped" else "") for k in m.point_encoder._graphs.entries)
-        assert kinds == ([] if not hip_graphs else [tower] if not group_ahead else ["group", "group", tower + "+grouped"])
+        kinds = sorted(k[0] + ("+" + k[-1] if k[-1] in ("grouped", "tokens") else "") for k in m.point_encoder._graphs.entries)
+        # (with the grouping stage ahead the whole tokenizer runs there -- PointTransformer.tokenize_ahead -- and the tower graph
+        # starts at the blocks)
+        stage = "tokens" if m.point_encoder.tokenize_ahead else "group"
+        assert kinds == ([] if not hip_graphs else [tower] if not group_ahead
+                         else sorted([stage, stage, tower + ("+tokens" if stage == "tokens" else "+grouped")]))
     la, pa, wa = results[0]
     for lb, pb, wb in results[1:]:
         assert la == lb
