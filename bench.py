@@ -290,7 +290,7 @@ def main():
     # (the prompt side's backward -> AdamW -> forward chain is then what the head waits for; see graphs.shared_text_stream)
     c0_ = CONFIGS[a.config]
     graphs.shared_text_stream(priority=-1 if (c0_["head_type"] == 0 and c0_.get("model", "ULIP_PointBERT") == "ULIP_PointBERT") else 0)
-    frozen_too = os.environ.get("PPT_GROUP_AHEAD_FROZEN") == "1"          # experiment: also for a fully frozen PointBERT (C2)
+    frozen_too = os.environ.get("PPT_GROUP_AHEAD_FROZEN", "1") != "0"     # also for a fully frozen PointBERT (C2): pays since round 3
     c_ = CONFIGS[a.config]
     group_ahead = GROUP_AHEAD and (frozen_too or (c_["head_type"] > 0 and c_.get("model", "ULIP_PointBERT") == "ULIP_PointBERT")
                                    or c_.get("model") in ("ULIP_PN_MSG", "ULIP_PN_MLP", "ULIP_PointBERT_partseg"))

@@ -668,9 +668,12 @@ class ULIP_WITH_IMAGE(nn.Module):
         its persistent kernels leave CUs to the text stream (ops.persistent_occupancy; PPT_TOWER_OCCUPANCY percent.  Round 2: 60,
         the optimum of 200 / 150 / 100 / 75 / 60 / 50 / 40 / 30 % of a workgroup per CU, C2 3.67 -> 3.50 ms.  Round 3, with the
         prompt chain's GEMMs 6-23 % faster the chain needs less room: 60 / 70 / 80 / 85 / 90 / 100 % -> 3.344 / 3.314 / 3.272 /
-        3.281 / 3.400 / 3.613 ms on one box, default 80)."""
+        3.281 / 3.400 / 3.613 ms on one box with the tokenizer in the tower's graph; with the tokenizer running ahead on its own
+        stream (PointTransformer.tokenize_ahead, the default) 50 / 60 / 70 % -> 3.249 / 3.212 / 3.205 ms and 80 % 3.27: default 70.
+        The step sits on a plateau now -- 3.20 ... 3.27 ms for every combination of {grouping ahead, tokenizer ahead, neither} x
+        {60 ... 85 %} on that box: what remains is the kernels' own resource time.)"""
         if self.training and torch.is_grad_enabled() and self.chain_priority():
-            return ops.persistent_occupancy(int(os.environ.get("PPT_TOWER_OCCUPANCY", "80")))
+            return ops.persistent_occupancy(int(os.environ.get("PPT_TOWER_OCCUPANCY", "70")))
         if self.training and torch.is_grad_enabled() and os.environ.get("PPT_TOWER_OCCUPANCY_ALWAYS"):
             return ops.persistent_occupancy(int(os.environ["PPT_TOWER_OCCUPANCY_ALWAYS"]))       # (experiments)
         if self.training and torch.is_grad_enabled() and os.environ.get("PPT_TOWER_PRIO", "1") == "1":
