@@ -231,9 +231,18 @@ typedef struct ppt_vit_mlp_params {
     int workgroups;
     int n_chunks, rows_per_chunk;
     int dtype;                       /* PPT_BF16 (also 0) or PPT_F16: the 16-bit format of W1 / W2 and of the in-kernel operands */
+    /* optional (ABI 3): the attention branch's tail in front -- x_mid = x + proj_row_scale[m / rows] * (proj_a Wp^T + proj_b)
+     * (point_encoder.py:57-58,77) is formed first, written to `out`, and is what the MLP branch then reads.  proj_a [M, D] in
+     * `dtype`; proj_W = attn.proj.weight [D, D] through ppt_vit_proj_retile.  proj_a == NULL: plain form. */
+    const void *proj_a;
+    const void *proj_W;
+    const float *proj_b;
+    const float *proj_row_scale;
+    int proj_row_scale_rows;
 } ppt_vit_mlp_params;
 
 int ppt_vit_mlp_retile(const void *W1, const void *W2, void *W1_tiled, void *W2_tiled, void *stream);
+int ppt_vit_proj_retile(const void *Wp, void *Wp_tiled, void *stream);
 int ppt_vit_mlp_bf16(const ppt_vit_mlp_params *p, void *stream);
 
 /* ---- LayerNorm --------------------------------------------------------------------------------

@@ -40,6 +40,7 @@ class VitMlpParams(ctypes.Structure):
         ("ln_eps", c_float), ("b1", c_void_p), ("b2", c_void_p), ("row_scale", c_void_p), ("row_scale_rows", c_int),
         ("residual2", c_void_p), ("M", c_int), ("D", c_int), ("hidden", c_int), ("workgroups", c_int), ("n_chunks", c_int),
         ("rows_per_chunk", c_int), ("dtype", c_int),
+        ("proj_a", c_void_p), ("proj_W", c_void_p), ("proj_b", c_void_p), ("proj_row_scale", c_void_p), ("proj_row_scale_rows", c_int),
     ]
 
 
@@ -84,6 +85,7 @@ _SIGNATURES = {
                                      c_void_p]),
     "ppt_sum_groups": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "ppt_vit_mlp_retile": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ppt_vit_proj_retile": (c_int, [c_void_p, c_void_p, c_void_p]),
     "ppt_vit_mlp_bf16": (c_int, [ctypes.POINTER(VitMlpParams), c_void_p]),
     "ppt_rowgemm_bf16": (c_int, [ctypes.POINTER(RowGemmParams), c_void_p]),
     "ppt_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

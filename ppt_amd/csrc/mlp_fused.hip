@@ -18,6 +18,13 @@
 //   GEMM2: acc[80 x (48 w .. 48 w + 47)] += U[80 x 128] . W2[48 w .., slab]^T                5 x 3 blocks x 4 k-steps
 // Products are formed transposed (D[n][m], v_mfma_f32_16x16x32_bf16 with the weight as first operand), so a lane holds
 // four consecutive columns of a row: 8-byte LDS writes of the slab, 16-byte accesses of the residual stream.
+//
+// Round 3 -- the attention branch's tail rides in front (p.proj_a != NULL): the chunk's rows of the attention output `a`
+// (16-bit, [M, 384]) go to the LDS image first, x_mid = x + drop_path1 * (a Wp^T + bp) (point_encoder.py:57-58, 77) is formed
+// with Wp streamed in fragment order exactly like W2 (same output layout: a lane owns 4 consecutive columns of a row in each
+// of its 15 blocks), written back to the residual stream, and normalised IN REGISTERS: the row statistics (two passes, as
+// nn.LayerNorm) meet through LDS (the slab buffers are idle until GEMM1), and the normalised rows replace `a` in the image.
+// One launch and one read + one write of the fp32 residual stream fewer per block than proj (rowgemm.hip) + this kernel.
 #include "ppt_common.h"
 #include "ppt_act.h"
 
@@ -83,6 +90,119 @@ __global__ __launch_bounds__(512, 2) void vit_mlp_kernel(const ppt_vit_mlp_param
         const int row0 = chunk * p.rows_per_chunk;
         const int nrow = min(p.rows_per_chunk, p.M - row0);
         __syncthreads();                                                 // constants are in LDS; the previous chunk's readers are done
+        if (p.proj_a) {
+            // ---- (a) the chunk's rows of the attention output -> LDS image (16 bytes per thread and step; rows past the chunk: zeros)
+            {
+                const bf16_t *A = (const bf16_t *)p.proj_a;
+                for (int i = threadIdx.x; i < R * (D / 8); i += 512) {
+                    const int lr = i / (D / 8), c8 = i % (D / 8);
+                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    if (lr < nrow) v = *reinterpret_cast<const uint4 *>(A + (size_t)(row0 + lr) * D + 8 * c8);
+                    *reinterpret_cast<uint4 *>(h2 + lr * HP + 16 * c8) = v;
+                }
+            }
+            __syncthreads();
+            // ---- (b) acc = a . Wp^T: this wave's 48 output columns, weight fragments streamed four k-steps deep (register budget 128)
+            // (buffer loads: one VGPR of lane offset + a scalar fragment offset.  With plain pointers hipcc formed the 36 per-lane
+            // 64-bit fragment addresses at kernel entry, spilled them around the MLP phase's 248 registers and reloaded one inside
+            // every MFMA group of this loop.)
+            const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.proj_W), 0, 8 * 36 * 64 * 16, 0x00020000);
+            auto pfrag = [&](int nb, int ks) {
+                return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane * 16, (w * 36 + nb * 12 + ks) * 1024, 0));
+            };
+            f32x4_t pa[RB][3];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int nb = 0; nb < 3; ++nb) pa[rb][nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            {
+                uint4 wf[4][3];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int nb = 0; nb < 3; ++nb) wf[ks][nb] = pfrag(nb, ks);
+                const unsigned char *ha = h2 + l15 * HP + 16 * kg;
+#pragma unroll
+                for (int ks = 0; ks < D / 32; ++ks) {
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) {
+                        const uint4 f = *reinterpret_cast<const uint4 *>(ha + rb * 16 * HP + 64 * ks);
+#pragma unroll
+                        for (int nb = 0; nb < 3; ++nb) pa[rb][nb] = h16<F>::mfma16(wf[ks & 3][nb], f, pa[rb][nb]);
+                    }
+                    if (ks + 4 < D / 32) {
+#pragma unroll
+                        for (int nb = 0; nb < 3; ++nb) wf[ks & 3][nb] = pfrag(nb, ks + 4);
+                    }
+                }
+            }
+            // ---- (c) x_mid = x + drop_path1 * (acc + bp) -> the residual stream; partial row sums -> LDS
+            float *psum = reinterpret_cast<float *>(ub);                  // [R][32] partials, then [R] mean / rstd behind them
+            float *stat = psum + R * 32;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const int lr = 16 * rb + l15;
+                const int m = row0 + min(lr, nrow - 1);
+                const float rs1 = p.proj_row_scale ? p.proj_row_scale[m / p.proj_row_scale_rows] : 1.0f;
+                float sum = 0.f;
+#pragma unroll
+                for (int nb = 0; nb < 3; ++nb) {
+                    const int n = 48 * w + 16 * nb + 4 * kg;
+                    const float4 xv = *reinterpret_cast<const float4 *>(p.x + (size_t)m * D + n);
+                    const float4 bv = p.proj_b ? *reinterpret_cast<const float4 *>(p.proj_b + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    pa[rb][nb][0] = (pa[rb][nb][0] + bv.x) * rs1 + xv.x; pa[rb][nb][1] = (pa[rb][nb][1] + bv.y) * rs1 + xv.y;
+                    pa[rb][nb][2] = (pa[rb][nb][2] + bv.z) * rs1 + xv.z; pa[rb][nb][3] = (pa[rb][nb][3] + bv.w) * rs1 + xv.w;
+                    if (lr < nrow)
+                        *reinterpret_cast<float4 *>(p.out + (size_t)m * D + n) = make_float4(pa[rb][nb][0], pa[rb][nb][1], pa[rb][nb][2], pa[rb][nb][3]);
+                    sum += (pa[rb][nb][0] + pa[rb][nb][1]) + (pa[rb][nb][2] + pa[rb][nb][3]);
+                }
+                psum[lr * 32 + 4 * w + kg] = sum;
+            }
+            __syncthreads();                                              // (also: every wave is done reading `a` from the image)
+            if (threadIdx.x < R) {
+                float t = 0.f;
+#pragma unroll
+                for (int i = 0; i < 32; ++i) t += psum[threadIdx.x * 32 + i];
+                stat[threadIdx.x] = t * (1.0f / (float)D);
+            }
+            __syncthreads();
+            float mean_r[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const int lr = 16 * rb + l15;
+                mean_r[rb] = stat[lr];
+                float q = 0.f;
+#pragma unroll
+                for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const float d = pa[rb][nb][i] - mean_r[rb]; q = fmaf(d, d, q); }
+                psum[lr * 32 + 4 * w + kg] = q;
+            }
+            __syncthreads();
+            if (threadIdx.x < R) {
+                float t = 0.f;
+#pragma unroll
+                for (int i = 0; i < 32; ++i) t += psum[threadIdx.x * 32 + i];
+                stat[R + threadIdx.x] = 1.0f / sqrtf(t * (1.0f / (float)D) + p.ln_eps);
+            }
+            __syncthreads();
+            // ---- (d) LayerNorm(x_mid) -> the image (rows past the chunk: zeros, as the plain prologue leaves them)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const int lr = 16 * rb + l15;
+                const float rstd = stat[R + lr];
+#pragma unroll
+                for (int nb = 0; nb < 3; ++nb) {
+                    const int n = 48 * w + 16 * nb + 4 * kg;
+                    const float4 g = *reinterpret_cast<const float4 *>(gam + n), b = *reinterpret_cast<const float4 *>(bet + n);
+                    uint2 o = make_uint2(0u, 0u);
+                    if (lr < nrow)
+                        o = make_uint2(h16<F>::pack2((pa[rb][nb][0] - mean_r[rb]) * rstd * g.x + b.x, (pa[rb][nb][1] - mean_r[rb]) * rstd * g.y + b.y),
+                                       h16<F>::pack2((pa[rb][nb][2] - mean_r[rb]) * rstd * g.z + b.z, (pa[rb][nb][3] - mean_r[rb]) * rstd * g.w + b.w));
+                    *reinterpret_cast<uint2 *>(h2 + lr * HP + 2 * n) = o;
+                }
+            }
+        } else
         // ---- LayerNorm of the chunk's rows -> H2 (bf16): 16 threads per row, 32 rows per pass; rows past the chunk are zeros
         {
             const int r = threadIdx.x >> 4, jj = threadIdx.x & 15;
@@ -200,6 +320,7 @@ __global__ __launch_bounds__(512, 2) void vit_mlp_kernel(const ppt_vit_mlp_param
         // The residual rows are all requested first (the 96 weight registers are free now): consumed where they are issued,
         // every 16 x 16 block paid a memory round trip (12 600 cycles for the 15 blocks of a chunk).
         {
+            const float *xres = p.proj_a ? (const float *)p.out : p.x;       // (fused: x_mid, written by these same lanes in (c))
             float4 res[RB][3];
             float rs[RB];
 #pragma unroll
@@ -207,7 +328,7 @@ __global__ __launch_bounds__(512, 2) void vit_mlp_kernel(const ppt_vit_mlp_param
                 const int m = row0 + min(16 * rb + l15, nrow - 1);
                 rs[rb] = p.row_scale ? p.row_scale[m / p.row_scale_rows] : 1.0f;
 #pragma unroll
-                for (int nb = 0; nb < 3; ++nb) res[rb][nb] = *reinterpret_cast<const float4 *>(p.x + (size_t)m * D + 48 * w + 16 * nb + 4 * kg);
+                for (int nb = 0; nb < 3; ++nb) res[rb][nb] = *reinterpret_cast<const float4 *>(xres + (size_t)m * D + 48 * w + 16 * nb + 4 * kg);
             }
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
@@ -251,7 +372,25 @@ __global__ __launch_bounds__(256) void vit_mlp_retile_kernel(const bf16_t *__res
     *reinterpret_cast<uint4 *>(W2t + (size_t)i * 8) = b;
 }
 
+// fragment order of the proj weight (see pfrag() in the kernel): Wpt[w][f = 12 nb + ks][lane] = Wp[48 w + 16 nb + l15][32 ks + 8 kg .. + 8)
+__global__ __launch_bounds__(256) void vit_proj_retile_kernel(const bf16_t *__restrict__ Wp, bf16_t *__restrict__ Wpt)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;                        // over 8 * 36 * 64 pieces
+    if (i >= 8 * 36 * 64) return;
+    const int lane = i & 63, f = (i >> 6) % 36, w = i / (64 * 36);
+    const int l15 = lane & 15, kg = lane >> 4, nb = f / 12, ks = f % 12;
+    *reinterpret_cast<uint4 *>(Wpt + (size_t)i * 8) = *reinterpret_cast<const uint4 *>(Wp + (size_t)(48 * w + 16 * nb + l15) * D + 32 * ks + 8 * kg);
+}
+
 }  // namespace
+
+extern "C" int ppt_vit_proj_retile(const void *Wp, void *Wp_tiled, void *stream)
+{
+    if (!Wp || !Wp_tiled || (((uintptr_t)Wp | (uintptr_t)Wp_tiled) & 15)) return PPT_EINVAL;
+    hipLaunchKernelGGL(vit_proj_retile_kernel, dim3((8 * 36 * 64 + 255) / 256), dim3(256), 0, ppt_stream(stream), (const bf16_t *)Wp, (bf16_t *)Wp_tiled);
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
 
 extern "C" int ppt_vit_mlp_retile(const void *W1, const void *W2, void *W1t, void *W2t, void *stream)
 {
@@ -271,6 +410,10 @@ extern "C" int ppt_vit_mlp_bf16(const ppt_vit_mlp_params *pp, void *stream)
     if (p.dtype != PPT_BF16 && p.dtype != PPT_F16 && p.dtype != 0) return PPT_EINVAL;          // (0: callers of ABI 2 -- bf16)
     if (p.row_scale && p.row_scale_rows <= 0) return PPT_EINVAL;
     if (((uintptr_t)p.x | (uintptr_t)p.out | (uintptr_t)p.W1 | (uintptr_t)p.W2 | (uintptr_t)p.residual2) & 15) return PPT_EINVAL;
+    if (p.proj_a) {                                                      // the fused attention-branch tail (see the file header)
+        if (!p.proj_W || (p.proj_row_scale && p.proj_row_scale_rows <= 0)) return PPT_EINVAL;
+        if (((uintptr_t)p.proj_a | (uintptr_t)p.proj_W | (uintptr_t)p.proj_b) & 15) return PPT_EINVAL;
+    }
     static const int cus = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);

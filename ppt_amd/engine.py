@@ -114,6 +114,7 @@ FUSED_CONV12 = os.environ.get("PPT_FUSED_CONV12", "1") != "0"      # 0: the gene
 # forces it off / on.  (Round 3, after the LDS-DMA fix of ppt_common.h made the prompt chain's GEMMs 6-23 % faster: C2 3.422 ->
 # 3.345 ms WITH it, same box, tools/ab_env.py -- the threshold went from 24 000 to 16 000 rows.)
 FUSED_MLP = os.environ.get("PPT_FUSED_MLP", "1") != "0"             # LayerNorm + fc1 + GELU + fc2 + residual of a frozen block: one kernel
+FUSED_PROJ = os.environ.get("PPT_FUSED_PROJ", "1") != "0"           # ... with attn.proj + DropPath + residual in front of it (rowgemm path)
 _RG = os.environ.get("PPT_ROWGEMM", "")
 ROWGEMM_MIN_ROWS = 1 << 30 if _RG == "0" else (0 if _RG == "1" else 16000)
 
@@ -216,9 +217,19 @@ def vit_block_forward(sd, p, wc, x, pos, B, Tn, heads, dp1, dp2, save=None, pos_
             h, _, _ = ops.layernorm_fwd(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], T, add=pos, write_xs=x)
             qkv = ops.rowgemm(h, wc.get(sd[p + "attn.qkv.weight"]))
         a, _ = ops.attention_fwd(qkv, B, Tn, heads, ATTN_SCALE, False, want_lse=False)
+        fused_mlp = FUSED_MLP and sd[p + "mlp.fc1.weight"].shape[0] == 1536
+        if fused_mlp and FUSED_PROJ:
+            # attn.proj + DropPath + residual ride in front of the MLP kernel (csrc/mlp_fused.hip, round 3)
+            w1t, w2t = _mlp_weights(sd, p, wc)
+            wp = sd[p + "attn.proj.weight"]
+            wpt = wc.derived(("vit_proj_tiled", p), (wp,), lambda: ops.vit_proj_retile(wc.get(wp)))
+            ops.vit_mlp(x, w1t, sd[p + "mlp.fc1.bias"], w2t, sd[p + "mlp.fc2.bias"],
+                        (sd[p + "norm2.weight"], sd[p + "norm2.bias"]), row_scale=dp2, row_scale_rows=Tn,
+                        residual2=pos if add_pos_out else None, proj=(a, wpt, sd[p + "attn.proj.bias"], dp1, Tn))
+            return x
         ops.rowgemm(a, wc.get(sd[p + "attn.proj.weight"]), bias=sd[p + "attn.proj.bias"], residual=x, out=x, row_scale=dp1,
                     row_scale_rows=Tn)
-        if FUSED_MLP and sd[p + "mlp.fc1.weight"].shape[0] == 1536:
+        if fused_mlp:
             w1t, w2t = _mlp_weights(sd, p, wc)
             ops.vit_mlp(x, w1t, sd[p + "mlp.fc1.bias"], w2t, sd[p + "mlp.fc2.bias"],
                         (sd[p + "norm2.weight"], sd[p + "norm2.bias"]), row_scale=dp2, row_scale_rows=Tn,

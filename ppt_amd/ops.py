@@ -318,9 +318,20 @@ def vit_mlp_retile(w1, w2):
     return w1t, w2t
 
 
-def vit_mlp(x, w1, b1, w2, b2, ln, *, out=None, ln_eps=1e-5, row_scale=None, row_scale_rows=0, residual2=None, workgroups=0):
+def vit_proj_retile(wp):
+    """attn.proj.weight [384,384] (16-bit) -> the fragment-ordered copy the fused proj prologue of ppt_vit_mlp_bf16 reads."""
+    assert wp.dtype in HALF and tuple(wp.shape) == (384, 384)
+    _chk(wp, wp.dtype, "wp")
+    wpt = torch.empty_like(wp)
+    _lib.check(_lib.lib().ppt_vit_proj_retile(_p(wp), _p(wpt), _stream()), "ppt_vit_proj_retile")
+    return wpt
+
+
+def vit_mlp(x, w1, b1, w2, b2, ln, *, out=None, ln_eps=1e-5, row_scale=None, row_scale_rows=0, residual2=None, workgroups=0, proj=None):
     """ppt_vit_mlp_bf16 (csrc/mlp_fused.hip): out = x + row_scale * (GELU(LN(x) w1^T + b1) w2^T + b2) (+ residual2), x [M,384]
-    f32, w1 / w2: the fragment-ordered bf16 weights of vit_mlp_retile; out defaults to x (in place)."""
+    f32, w1 / w2: the fragment-ordered bf16 weights of vit_mlp_retile; out defaults to x (in place).
+    proj = (a [M,384] 16-bit, wp_tiled (vit_proj_retile), bias | None, row_scale1 | None, rows): the attention branch's tail in
+    front -- x <- x + row_scale1 * (a wp^T + bias) first (written to out), then the MLP branch on that."""
     assert w1.dtype in HALF and w2.dtype == w1.dtype
     _chk(x, torch.float32, "x"); _chk(w1, w1.dtype, "w1"); _chk(w2, w1.dtype, "w2")
     M, D = x.shape
@@ -330,8 +341,15 @@ def vit_mlp(x, w1, b1, w2, b2, ln, *, out=None, ln_eps=1e-5, row_scale=None, row
     p.x, p.out, p.W1, p.W2, p.ln_w, p.ln_b, p.ln_eps = _p(x), _p(out), _p(w1), _p(w2), _p(ln[0]), _p(ln[1]), ln_eps
     p.b1, p.b2, p.row_scale, p.row_scale_rows, p.residual2 = _p(b1), _p(b2), _p(row_scale), row_scale_rows, _p(residual2)
     p.M, p.D, p.hidden, p.workgroups = M, D, w1.shape[0], workgroups
+    flops = 4.0 * M * D * w1.shape[0]
+    if proj is not None:
+        a, wpt, pb, rs1, rs1_rows = proj
+        assert a.dtype == w1.dtype and wpt.dtype == w1.dtype and tuple(a.shape) == (M, D)
+        _chk(a, a.dtype, "proj a"); _chk(wpt, a.dtype, "proj w")
+        p.proj_a, p.proj_W, p.proj_b, p.proj_row_scale, p.proj_row_scale_rows = _p(a), _p(wpt), _p(pb), _p(rs1), int(rs1_rows)
+        flops += 2.0 * M * D * D
     if profiler is not None:
-        profiler.begin("gemm_bf16", 4.0 * M * D * w1.shape[0], "ppt_vit_mlp_bf16 (LN + fc1 + GELU + fc2 + residual)")
+        profiler.begin("gemm_bf16", flops, "ppt_vit_mlp_bf16 (" + ("proj + residual + " if proj is not None else "") + "LN + fc1 + GELU + fc2 + residual)")
     _lib.check(_lib.lib().ppt_vit_mlp_bf16(ctypes.byref(p), _stream()), "ppt_vit_mlp_bf16")
     if profiler is not None:
         profiler.end()

@@ -1196,6 +1196,50 @@ def test_vit_mlp_matches_the_unfused_chain(ops, M, rows, pos):
     assert torch.equal(x2, out)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,rows", [(16416, 513), (1000, 0), (83, 7)])
+def test_vit_mlp_with_the_proj_prologue_matches_proj_then_mlp(ops, M, rows, dtype):
+    """ppt_vit_mlp_bf16 with proj_a set (x_mid = x + drop_path1 * (a Wp^T + bp) formed in front, then the MLP branch on it)
+    against the two launches it replaces -- ppt_rowgemm_bf16 in residual form, then the plain fused MLP -- and against fp32
+    torch math on the operands the MFMAs see; in place; bit-reproducible; ragged last chunk."""
+    g = torch.Generator().manual_seed(M + 1)
+    D, Hd = 384, 1536
+    x = torch.randn(M, D, generator=g) * 2 + torch.randn(M, 1, generator=g)
+    a = torch.randn(M, D, generator=g)
+    wp, bp = torch.randn(D, D, generator=g) * D ** -0.5, 0.1 * torch.randn(D, generator=g)
+    gam, bet = 1 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    w1, b1 = torch.randn(Hd, D, generator=g) * D ** -0.5, 0.1 * torch.randn(Hd, generator=g)
+    w2, b2 = torch.randn(D, Hd, generator=g) * Hd ** -0.5, 0.1 * torch.randn(D, generator=g)
+    nr = (M + rows - 1) // rows if rows else 0
+    rs1 = (torch.floor(0.9 + torch.rand(nr, generator=g)) / 0.9) if rows else None
+    rs2 = (torch.floor(0.8 + torch.rand(nr, generator=g)) / 0.8) if rows else None
+    rd = lambda t: t.to(dtype).float()
+    y1 = rd(a) @ rd(wp).t() + bp
+    xm = x + (y1 * rs1.repeat_interleave(rows)[:M, None] if rows else y1)
+    h = rd(torch.nn.functional.layer_norm(xm, (D,), gam, bet, 1e-5))
+    u = rd(torch.nn.functional.gelu(h @ rd(w1).t() + b1))
+    y2 = u @ rd(w2).t() + b2
+    want = xm + (y2 * rs2.repeat_interleave(rows)[:M, None] if rows else y2)
+    xd, ad = x.cuda(), a.cuda().to(dtype)
+    w1t, w2t = ops.vit_mlp_retile(w1.cuda().to(dtype), w2.cuda().to(dtype))
+    wpd = wp.cuda().to(dtype)
+    wpt = ops.vit_proj_retile(wpd)
+    kw = dict(row_scale=rs2.cuda(), row_scale_rows=rows) if rows else {}
+    proj = (ad, wpt, bp.cuda(), rs1.cuda() if rows else None, rows if rows else 0)
+    out = xd.clone()
+    ops.vit_mlp(out, w1t, b1.cuda(), w2t, b2.cuda(), (gam.cuda(), bet.cuda()), proj=proj, **kw)
+    tol = (2e-2 if dtype == torch.bfloat16 else 4e-3) * max(1.0, (want - x).abs().max().item())
+    assert (out.cpu() - want).abs().max().item() < tol
+    # the two launches it replaces
+    ref = xd.clone()
+    ops.rowgemm(ad, wpd, bias=bp.cuda(), residual=ref, out=ref, row_scale=rs1.cuda() if rows else None, row_scale_rows=rows)
+    ops.vit_mlp(ref, w1t, b1.cuda(), w2t, b2.cuda(), (gam.cuda(), bet.cuda()), **kw)
+    assert (out - ref).abs().max().item() < tol / 2
+    again = xd.clone()
+    ops.vit_mlp(again, w1t, b1.cuda(), w2t, b2.cuda(), (gam.cuda(), bet.cuda()), proj=proj, **kw)
+    assert torch.equal(again, out)
+
+
 @pytest.mark.parametrize("tag,N,M,dup,cols", [("d", 8192, 1024, False, 3), ("e", 2048, 512, True, 6)])
 def test_dataset_fps_is_bit_exact(tag, N, M, dup, cols):
     """ppt_amd.data.farthest_point_sample(point, npoint) (data/dataset_3d.py:40-61 on the FPS kernel): the rows the reference
