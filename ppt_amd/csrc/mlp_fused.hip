@@ -33,7 +33,10 @@ namespace {
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 constexpr int D = 384, HID = 1536, HC = 128, NJ = HID / HC;       // model dims, hidden slab
-constexpr int RB = 5, R = 16 * RB;                                 // row blocks / rows per chunk (capacity)
+#ifndef PPT_MLP_RB
+#define PPT_MLP_RB 5
+#endif
+constexpr int RB = PPT_MLP_RB, R = 16 * RB;                        // row blocks / rows per chunk (capacity)
 constexpr int HP = 2 * D + 32, UP = 2 * HC + 32;                   // LDS pitches (bytes): = 32 mod 256 -> conflict-free b128 fragment reads
 constexpr int H2_BYTES = R * HP, U_BYTES = R * UP;
 constexpr int LDS_BYTES = H2_BYTES + 2 * U_BYTES + (2 * D + HID + D) * 4;

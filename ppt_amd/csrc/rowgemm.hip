@@ -332,7 +332,10 @@ int launch(const ppt_rowgemm_params &p, hipStream_t s, int cus)
     ppt_rowgemm_params q = p;
     q.groups = (p.N + G::NB - 1) / G::NB;
     const int tiles = (p.M + 31) / 32;
-    // walkers per column group: a multiple of 8 (the XCD-aware id mapping), as many as fill the chip, no more than tiles
+    // walkers per column group: a multiple of 8 (the XCD-aware id mapping), as many as fill the chip -- or the share of it the
+    // caller leaves to this stream (ppt_set_persistent_occupancy: these workgroups take a whole CU each) --, no more than tiles
+    static const int honour = [] { const char *e = getenv("PPT_ROWGEMM_OCCUPANCY"); return e ? atoi(e) : 1; }();
+    if (p.walkers <= 0 && honour) cus = cus * ppt_get_persistent_occupancy() / 100;
     int walkers = p.walkers > 0 ? p.walkers : cus / q.groups;
     if (walkers > tiles) walkers = tiles;
     walkers = (walkers + 7) / 8 * 8;
