@@ -971,11 +971,16 @@ __device__ __forceinline__ void glds_slab(const T *base, int64_t ld, int rows, i
 #else
 #define GEMM_STAMP(slot) do { } while (0)
 #endif
-template <typename T, int BM, int BN>
+// NSTAGE: LDS stages of the ring = slabs in flight + 1.  Three (48 KiB: three workgroups of the 64 x 64 tile per CU).  FOUR
+// (64 KiB, three slabs in flight) was measured for the prompt chain's small grids (<= 256 workgroups: one per CU whatever the
+// LDS size) after the LDS-DMA ring actually ran as a ring (ppt_common.h lds_dma16): 6.7 -> 6.9 us at K = 512, 13.0 -> 13.4 us at
+// K = 2048, C2 3.05 -> 3.10 ms -- the K loop is not short of bytes in flight, it runs at what ONE CU's LDS-DMA path takes
+// (~27 B/clk).  PPT_GEMM_DEEP_BELOW=<workgroups> selects it (default 0: never).
+template <typename T, int BM, int BN, int NSTAGE = 3>
 __global__ __launch_bounds__(NT, BM == 64 ? 3 : 1) void gemm_kernel_glds(const ppt_gemm_params p)   // (a waves-per-SIMD floor keeps the accumulators out of AGPRs)
 {
     constexpr int WM = BM / 2, WN = BN / 2, TI = WM / 32, TJ = WN / 32;
-    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES, NSTAGE = 3;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
     constexpr int LOADS_PER_SLAB = BM / 32 + BN / 32;    // LDS-DMA instructions per wave per slab
     constexpr int PARK_BYTES = 4 * WM * WN * 4;
     __shared__ __align__(16) unsigned char smem[NSTAGE * STAGE > PARK_BYTES ? NSTAGE * STAGE : PARK_BYTES];
@@ -1005,20 +1010,19 @@ __global__ __launch_bounds__(NT, BM == 64 ? 3 : 1) void gemm_kernel_glds(const p
         glds_slab<T, BM>(A, p.lda, p.M, m0, slab * BK, smem + stage * STAGE, w, lane);
         glds_slab<T, BN>(B, p.ldb, p.N, n0, slab * BK, smem + stage * STAGE + A_BYTES, w, lane);
     };
-    issue(0, 0);
-    issue(min(1, last), 1);
+#pragma unroll
+    for (int i = 0; i < NSTAGE - 1; ++i) issue(min(i, last), i);
     EpiPre<TI, TJ> epre;                                  // (behind the first slabs, as in gemm_kernel_glds_h)
     epilogue_prefetch<TI, TJ>(p, epre, lane, m0 + wm * WM, n0 + wn * WN);
     GEMM_STAMP(1);
     int stage = 0;
     for (int s = 0; s < nslab; ++s) {
-        // own copies of slab s have landed (the LOADS_PER_SLAB youngest, slab s+1, may still fly) ...
-        if constexpr (LOADS_PER_SLAB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        // own copies of slab s have landed (the LOADS_PER_SLAB * (NSTAGE - 2) youngest, slabs s+1 .., may still fly) ...
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS_PER_SLAB * (NSTAGE - 2)) : "memory");
         __builtin_amdgcn_s_barrier();                     // ... and so have everybody else's: slab s is readable
         if (s == 0) GEMM_STAMP(2);
-        int nstage = stage + 2; if (nstage >= NSTAGE) nstage -= NSTAGE;
-        issue(min(s + 2, last), nstage);                  // stage (s+2)%3 was last read at slab s-1, before this barrier
+        int nstage = stage + NSTAGE - 1; if (nstage >= NSTAGE) nstage -= NSTAGE;
+        issue(min(s + NSTAGE - 1, last), nstage);         // that stage was last read at slab s-1, before this barrier
         mma_slab<T, TI, TJ>(smem + stage * STAGE, smem + stage * STAGE + A_BYTES, wm * WM, wn * WN, lane, acc);
         stage = stage + 1 == NSTAGE ? 0 : stage + 1;
     }
@@ -1215,6 +1219,14 @@ int launch_gemm_tile(const ppt_gemm_params &p, hipStream_t s)
     constexpr int BKE = ROWB / sizeof(T);
     // (three 32 KiB stages of the 128x128 tile leave one workgroup per CU: measured slower than register staging)
     if (use_glds && BM == 64 && p.a_mode == PPT_A_PLAIN && p.K % BKE == 0) {
+        static const int deep_below = [] { const char *e = getenv("PPT_GEMM_DEEP_BELOW"); return e ? atoi(e) : 0; }();
+        if constexpr (BM == 64 && BN == 64) {
+            if ((int)(grid.x * grid.y * grid.z) < deep_below && p.K / BKE >= 4) {
+                hipLaunchKernelGGL((gemm_kernel_glds<T, 64, 64, 4>), grid, dim3(NT), 0, s, p);
+                PPT_CHECK_LAUNCH();
+                return PPT_OK;
+            }
+        }
         hipLaunchKernelGGL((gemm_kernel_glds<T, BM, BN>), grid, dim3(NT), 0, s, p);
         PPT_CHECK_LAUNCH();
         return PPT_OK;
