@@ -448,10 +448,13 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         if world == 1 and not force_dist and a.config == "C2" and not a.no_secondary:
             out["secondary"] = secondary_runs()
-        print(json.dumps(out), flush=True)
     if world > 1 or force_dist:
         dist.barrier()                       # rank 0 spends a few seconds more (roofline passes): tear down together
         dist.destroy_process_group()
+    if rank == 0:
+        # (after the teardown: RCCL writes a "Librccl path" line to stdout on the way; the JSON line stays the LAST line)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
