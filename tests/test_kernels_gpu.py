@@ -846,6 +846,23 @@ def test_rowgemm_matches_the_tile_gemm_path(ops):
     assert (d > 0).float().mean().item() < 0.05, "almost every element is bit-identical"
 
 
+def test_rowgemm_grid_follows_the_persistent_occupancy_and_results_do_not(ops):
+    """ppt_rowgemm_bf16 sizes its grid for the share of the CUs ppt_set_persistent_occupancy leaves to the calling thread's
+    launches (its workgroups take a whole CU each); what a row tile computes does not depend on which walker takes it."""
+    g = torch.Generator().manual_seed(9)
+    M, K, N = 16416, 384, 1152
+    x = (torch.randn(M, K, generator=g) * 2).cuda()
+    gam, bet = (1 + 0.2 * torch.randn(K, generator=g)).cuda(), (0.2 * torch.randn(K, generator=g)).cuda()
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).cuda().to(torch.float16)
+    full = ops.rowgemm(x, w, ln=(gam, bet))
+    for pct in (70, 25):
+        with ops.persistent_occupancy(pct):
+            assert ops.get_persistent_occupancy() == pct
+            part = ops.rowgemm(x, w, ln=(gam, bet))
+        assert torch.equal(part, full), pct
+    assert ops.get_persistent_occupancy() == 100
+
+
 def test_rowgemm_rejects_what_it_does_not_support(ops):
     a = torch.zeros(64, 256, dtype=torch.bfloat16, device="cuda")
     w = torch.zeros(64, 256, dtype=torch.bfloat16, device="cuda")
