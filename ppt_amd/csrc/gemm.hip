@@ -975,7 +975,10 @@ __device__ __forceinline__ void glds_slab(const T *base, int64_t ld, int rows, i
 // (64 KiB, three slabs in flight) was measured for the prompt chain's small grids (<= 256 workgroups: one per CU whatever the
 // LDS size) after the LDS-DMA ring actually ran as a ring (ppt_common.h lds_dma16): 6.7 -> 6.9 us at K = 512, 13.0 -> 13.4 us at
 // K = 2048, C2 3.05 -> 3.10 ms -- the K loop is not short of bytes in flight, it runs at what ONE CU's LDS-DMA path takes
-// (~27 B/clk).  PPT_GEMM_DEEP_BELOW=<workgroups> selects it (default 0: never).
+// (~27 B/clk).  PPT_GEMM_DEEP_BELOW=<workgroups> selects it (default 0: never).  (Also measured and removed: four HELPER waves per
+// workgroup that only issue half of the DMA pieces and meet the barriers -- 12.6 -> 12.0 us at K = 2048 alone, C2 3.11 -> 3.19 ms in
+// the step: the rate is a property of the CU, not of how many waves ask, and 512-thread workgroups are harder to place beside the
+// tower.  What would help these 104-workgroup launches is MORE CUs: 32 x 64 tiles.)
 template <typename T, int BM, int BN, int NSTAGE = 3>
 __global__ __launch_bounds__(NT, BM == 64 ? 3 : 1) void gemm_kernel_glds(const ppt_gemm_params p)   // (a waves-per-SIMD floor keeps the accumulators out of AGPRs)
 {
