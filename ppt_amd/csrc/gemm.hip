@@ -978,7 +978,9 @@ __device__ __forceinline__ void glds_slab(const T *base, int64_t ld, int rows, i
 // (~27 B/clk).  PPT_GEMM_DEEP_BELOW=<workgroups> selects it (default 0: never).  (Also measured and removed: four HELPER waves per
 // workgroup that only issue half of the DMA pieces and meet the barriers -- 12.6 -> 12.0 us at K = 2048 alone, C2 3.11 -> 3.19 ms in
 // the step: the rate is a property of the CU, not of how many waves ask, and 512-thread workgroups are harder to place beside the
-// tower.  What would help these 104-workgroup launches is MORE CUs: 32 x 64 tiles.)
+// tower.  And 32 x 64 tiles -- 208 two-wave workgroups, five 12 KiB stages, bit-identical results -- to put these 104-workgroup
+// launches on more CUs: 12.2 -> 12.8 us plain, 12.6 -> 17.1 us with the residual epilogue, C2 3.08 -> 3.35 ms.  Two waves do not
+// keep a CU's DMA path as busy as four.  The 64 x 64 / four-wave / three-stage kernel is where these shapes stay.)
 template <typename T, int BM, int BN, int NSTAGE = 3>
 __global__ __launch_bounds__(NT, BM == 64 ? 3 : 1) void gemm_kernel_glds(const ppt_gemm_params p)   // (a waves-per-SIMD floor keeps the accumulators out of AGPRs)
 {
