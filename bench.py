@@ -236,9 +236,13 @@ def main_eval(a):
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     from ppt_amd import graphs, weights as W
     graphs.shared_text_stream()
+    graphs.shared_group_stream()
     cfg = CONFIGS[a.config]
     model = build_model(cfg["dataset"], cfg["head_type"], model=cfg.get("model", "ULIP_PointBERT"), task=cfg.get("task", "cls"))
     model.eval()
+    # the synthetic batch is resident and complete before every call: the next batch's grouping / tokenizer stage may start
+    # when forward() is called (ULIP_WITH_IMAGE.eval_inputs_ready; PPT_EVAL_AHEAD=0 for the in-order forward)
+    model.eval_inputs_ready = os.environ.get("PPT_EVAL_AHEAD", "1") != "0"
     B, N = cfg["batch"], cfg["npoints"]
     pc = torch.from_numpy(W.synth_clouds(B, N, seed=1234)[0]).cuda()
     extra = ()

@@ -580,6 +580,11 @@ class ULIP_WITH_IMAGE(nn.Module):
         # positions in front of the class name are the same in every prompt: computed once (PPT_SHARE_TEXT_PREFIX=0: A/B runs)
         self.share_text_prefix = os.environ.get("PPT_SHARE_TEXT_PREFIX", "1") != "0"
         self.text_f16 = os.environ.get("PPT_TEXT_F16", "1") != "0"
+        # validate() (no_grad, eval mode): True = the caller vouches that every `pc` passed to forward() is COMPLETE in device
+        # memory when forward() is called (a resident tensor, or a loader that synchronised its copy stream) -- the grouping /
+        # tokenizer stage of a batch then runs on its own stream as soon as forward() is called, i.e. under the previous batch's
+        # transformer blocks (as train.Trainer.inputs_ready does for training steps)
+        self.eval_inputs_ready = False
         self._chain_prio = None
         self._handoff = False               # inside forward_loss: graph outputs go straight into the next graph's input (no clone)
         self._handoff_grad = os.environ.get("PPT_HANDOFF", "1") != "0"
@@ -784,8 +789,19 @@ class ULIP_WITH_IMAGE(nn.Module):
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 text_embed = self._text_embed()
-        with self._tower_room():
-            pc_embed = self.encode_pc(pc, cls_label) if self.task == 'partseg' else self.encode_pc(pc)
+        pe = self.point_encoder
+        ahead = (self.eval_inputs_ready and not self.training and not torch.is_grad_enabled() and pc.is_cuda
+                 and hasattr(pe, "group_ahead") and self.task != 'partseg')
+        if ahead:
+            # validate() with resident inputs (eval_inputs_ready): the next batch's FPS + kNN + tokenizer on the grouping stream,
+            # under this batch's blocks -- the same ahead stage train.Trainer uses (PointTransformer._group_ahead)
+            pe.group_ahead = graphs.shared_group_stream()
+        try:
+            with self._tower_room():
+                pc_embed = self.encode_pc(pc, cls_label) if self.task == 'partseg' else self.encode_pc(pc)
+        finally:
+            if ahead:
+                pe.group_ahead = None
         if side is not None:
             cur.wait_stream(side)
             text_embed.record_stream(cur)

@@ -834,6 +834,32 @@ def test_eval_text_cache_fast_path():
 
 
 @pytest.mark.parametrize("head_type", [0, 3])
+def test_eval_with_the_tokenizer_ahead_is_identical(head_type):
+    """validate() with ULIP_WITH_IMAGE.eval_inputs_ready: the grouping / tokenizer stage of each batch on its own stream, replayed
+    from ping-pong graphs under the previous batch's blocks, gives bit-identical logits to the in-order forward -- over enough
+    different batches to go through warm-up, capture and both buffer pairs."""
+    pc, start = oracle_inputs()
+    outs = []
+    for ahead in (False, True):
+        m, _ = build(head_type, torch.bfloat16)
+        m.eval()
+        m.eval_inputs_ready = ahead
+        m.point_encoder.fps_start = torch.from_numpy(start).cuda()
+        res = []
+        with torch.no_grad():
+            for it in range(7):
+                batch = torch.roll(pc, it, 0).cuda()
+                torch.cuda.synchronize()                       # the batch is complete on the device before forward() is called
+                res.append(m(batch).clone())
+        torch.cuda.synchronize()
+        outs.append(res)
+        kinds = {k[0] for k in m.point_encoder._graphs.entries}
+        assert ("tokens" in kinds) == ahead
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("head_type", [0, 3])
 def test_single_rank_rccl_step_is_identical(head_type):
     """SURVEY §8(e) on one GPU: Trainer(distributed=True) under a single-rank `nccl` (RCCL) process group -- the N-GPU code
     path: one all-reduce of the flat gradient buffer on the text stream, BatchNorm buffers re-bound for the broadcast --
