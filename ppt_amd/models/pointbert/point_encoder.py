@@ -513,6 +513,7 @@ class PointTransformer_partseg(nn.Module):
         self._graphs = graphs.GraphCache()
         self._graph_injected = False      # tests: allow the graph with injected (static) RNG tensors
         self.graph_decoder = os.environ.get("PPT_PARTSEG_GRAPH_DECODER", "1") != "0"
+        self.backbone_ahead = os.environ.get("PPT_PARTSEG_BACKBONE_AHEAD", "1") != "0"   # with group_ahead: the whole frozen backbone runs ahead
         self.decoder_gate = None          # event after which this iteration may read the decoder's parameters (train.Trainer)
         self.group_ahead = None           # stream for the grouping stage of a step whose inputs the caller vouches for (Trainer)
         self._ahead = graphs.AheadStage()
@@ -592,7 +593,16 @@ class PointTransformer_partseg(nn.Module):
         slot = None
         if (pts.is_cuda and self.use_hip_graphs and graphs.enabled and ops.profiler is None and (not injected or self._graph_injected)
                 and not torch.cuda.is_current_stream_capturing() and self._graphs.ready(key)):
-            if self.group_ahead is not None:
+            if self.group_ahead is not None and self.backbone_ahead:
+                # ... and the WHOLE frozen backbone with it (round 3): tokenizer, the 12 blocks and the three feature taps are a
+                # function of the cloud, the frozen weights and RNG draws made inside the stage's graph -- nothing the optimizer
+                # writes -- so the next step's backbone runs under this step's decoder (hundreds of small kernels that leave
+                # most of the chip idle) instead of in front of it
+                outs, slot = self._ahead.run(self._graphs, ("partseg_backbone_ahead", (B, N), self.training, self._precision), backbone,
+                                             [pts], self.group_ahead)
+                f_a, f_b, f_c, center, c1, c2 = (o.clone() for o in outs)
+                self._ahead.consumed(slot)
+            elif self.group_ahead is not None:
                 # the caller vouches that `pts` is complete in memory (train.Trainer.inputs_ready): the grouping stage runs on its
                 # own stream as soon as the step is called -- under the previous iteration's decoder backward (0.3 ms of serial
                 # FPS walks off the head of the caller's stream) -- and only the blocks wait for it (graphs.AheadStage)

@@ -804,12 +804,14 @@ def test_partseg_graphed_step_is_bit_identical_to_eager():
         pe.use_hip_graphs, pe._graph_injected = graphed, True
         tr = Trainer(m, lr=1e-3, label_smoothing=0.2, distributed=False)
         tr.extra_inputs = (onehot,)
-        tr.inputs_ready = graphed                  # (the grouping stage then runs ahead on its own stream)
+        tr.inputs_ready = graphed                  # (the frozen backbone then runs ahead on its own stream)
         losses = [tr.step(pc, labels)[0] for _ in range(6)]
         tr.finish()
         torch.cuda.synchronize()
-        # grouping stage (two slots) + blocks + decoder forward + decoder backward when graphed, nothing otherwise
-        assert (len(pe._graphs.entries) == 5) == graphed and (graphed or not pe._graphs.entries), list(pe._graphs.entries)
+        # the ahead stage (two slots: the whole frozen backbone -- PointTransformer_partseg.backbone_ahead -- or the grouping stage +
+        # one blocks graph) + decoder forward + decoder backward when graphed, nothing otherwise
+        want = 4 if pe.backbone_ahead else 5
+        assert (len(pe._graphs.entries) == want) == graphed and (graphed or not pe._graphs.entries), list(pe._graphs.entries)
         outs[graphed] = ([l.item() for l in losses], {n: q.detach().cpu().clone() for n, q in m.named_parameters() if q.requires_grad},
                          {n: b.detach().cpu().clone() for n, b in pe.named_buffers()})
     assert outs[False][0] == outs[True][0], (outs[False][0], outs[True][0])
