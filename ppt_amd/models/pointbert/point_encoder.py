@@ -250,6 +250,10 @@ class _PointEncoderFn(torch.autograd.Function):
                 outs, _ = g(*ins)
                 if slot is not None:
                     module._group_consumed(slot)
+                    # (with the tokens handed over in place the prefix's outputs -- and with them the activations the last block
+                    # keeps for its backward -- LIVE in the stage's ping-pong buffers: backward() moves the pair's "free" event
+                    # behind itself, or the stage of step i + 2, which waits for nothing else, could overwrite them first)
+                    ctx.ahead_slot = slot
                 g.generation = getattr(g, "generation", 0) + 1
                 ctx.prefix_graph, ctx.prefix_generation = g, g.generation
                 cut, dp = (outs[0], outs[1]), (outs[2] if len(outs) > 2 else None)
@@ -276,6 +280,8 @@ class _PointEncoderFn(torch.autograd.Function):
             raise RuntimeError("the point tower's captured activations were overwritten by a later forward; set "
                                "model.point_encoder.use_hip_graphs = False to keep several forwards alive before backward")
         grads = engine.point_encoder_backward(m._live_state(), m._cache(), ctx.saved, dfeat.contiguous().float(), ctx.tier)
+        if getattr(ctx, "ahead_slot", None) is not None:
+            m._group_consumed(ctx.ahead_slot)
         out = []
         for n in ctx.names:
             g = grads[n]

@@ -262,6 +262,36 @@ def test_run_ahead_training_is_identical(head_type):
             assert torch.equal(wa[n], wb[n]), n
 
 
+def test_ahead_stage_buffers_are_released_behind_the_backward_that_reads_them():
+    """head_type 3 with every RNG draw on the device: the tokenizer's ping-pong buffers are handed to the prefix graph IN PLACE,
+    so the activations the last block keeps for its backward live in them.  The pair must be marked free behind that backward
+    (the stage of step i + 2 waits for nothing else) -- i.e. twice per step once the graphs run: after the forward, and again
+    after the backward."""
+    from ppt_amd.train import Trainer
+    pc, _ = oracle_inputs()
+    label = torch.tensor([3, 17, 0, 39]).cuda()
+    m, _ = build(3, torch.bfloat16)
+    m.overlap_text_tower = True
+    m.train()
+    tr = Trainer(m, lr=3e-3, label_smoothing=0.2, distributed=False)
+    tr.inputs_ready = True
+    pe = m.point_encoder
+    calls = []
+    inner = pe._group_consumed
+    pe._group_consumed = lambda slot: (calls.append(slot), inner(slot))[1]
+    per_step = []
+    for it in range(7):
+        n0 = len(calls)
+        loss, _ = tr.step(torch.roll(pc, it, 0).cuda(), label)
+        per_step.append(len(calls) - n0)
+    tr.finish()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss)
+    assert any(k[0] == "tokens" for k in pe._graphs.entries), list(pe._graphs.entries)
+    assert any(k[0] == "point_prefix" and "tokens" in k[-2:] for k in pe._graphs.entries), list(pe._graphs.entries)
+    assert per_step[-1] == 2 and per_step[-2] == 2, per_step
+
+
 @pytest.mark.parametrize("head_type", [1, 2, 3])
 def test_validation_between_training_epochs_reads_current_weights(head_type):
     """validate() under no_grad after further training must see the CURRENT last-block weights.  A
