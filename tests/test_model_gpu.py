@@ -262,11 +262,10 @@ def test_run_ahead_training_is_identical(head_type):
             assert torch.equal(wa[n], wb[n]), n
 
 
-def test_ahead_stage_buffers_are_released_behind_the_backward_that_reads_them():
-    """head_type 3 with every RNG draw on the device: the tokenizer's ping-pong buffers are handed to the prefix graph IN PLACE,
-    so the activations the last block keeps for its backward live in them.  The pair must be marked free behind that backward
-    (the stage of step i + 2 waits for nothing else) -- i.e. twice per step once the graphs run: after the forward, and again
-    after the backward."""
+def test_saved_activations_do_not_live_in_the_ahead_stage_buffers():
+    """head_type 3 with every RNG draw on the device and the tokenizer running ahead: the last block keeps activations for its
+    backward, and the stage of a later step (which waits for the forward only) rewrites its ping-pong buffers -- so the prefix graph
+    must read the tokens into buffers of its own.  No tensor the autograd node saves may alias a stage output."""
     from ppt_amd.train import Trainer
     pc, _ = oracle_inputs()
     label = torch.tensor([3, 17, 0, 39]).cuda()
@@ -276,20 +275,17 @@ def test_ahead_stage_buffers_are_released_behind_the_backward_that_reads_them():
     tr = Trainer(m, lr=3e-3, label_smoothing=0.2, distributed=False)
     tr.inputs_ready = True
     pe = m.point_encoder
-    calls = []
-    inner = pe._group_consumed
-    pe._group_consumed = lambda slot: (calls.append(slot), inner(slot))[1]
-    per_step = []
-    for it in range(7):
-        n0 = len(calls)
+    for it in range(6):
         loss, _ = tr.step(torch.roll(pc, it, 0).cuda(), label)
-        per_step.append(len(calls) - n0)
     tr.finish()
     torch.cuda.synchronize()
     assert torch.isfinite(loss)
-    assert any(k[0] == "tokens" for k in pe._graphs.entries), list(pe._graphs.entries)
-    assert any(k[0] == "point_prefix" and "tokens" in k[-2:] for k in pe._graphs.entries), list(pe._graphs.entries)
-    assert per_step[-1] == 2 and per_step[-2] == 2, per_step
+    stage = [g for k, g in pe._graphs.entries.items() if k[0] == "tokens"]
+    prefix = [g for k, g in pe._graphs.entries.items() if k[0] == "point_prefix"]
+    assert len(stage) == 2 and len(prefix) == 1
+    stage_ptrs = {t.data_ptr() for g in stage for t in g.outputs}
+    assert not any(t.data_ptr() in stage_ptrs for t in prefix[0].static_in)
+    assert not any(t.data_ptr() in stage_ptrs for t in prefix[0].outputs if torch.is_tensor(t))
 
 
 @pytest.mark.parametrize("head_type", [1, 2, 3])
