@@ -266,7 +266,9 @@ int ppt_layernorm_bwd(const float *dy, const float *xs, const float *w, const fl
  * ULIP_models.py:38,49-51 with the causal mask of :224-230 (L=77).
  * qkv [Bt, T, 3, H, hd] packed as produced by the qkv / in_proj GEMM (row stride 3*H*hd);
  * out [Bt, T, H*hd]; lse [Bt, H, T] f32 (log-sum-exp of the scaled scores, for the backward).
- * hd == 64.  bf16: flash-style MFMA kernel; f32: VALU kernel (parity mode). */
+ * hd == 64.  16-bit (dtype PPT_BF16 | PPT_F16): flash-style MFMA kernels -- for the ViT shape (non-causal, T = 64 n + 1 <= 513,
+ * Bt * H >= 128) the one that keeps K / V of a (batch, head) resident in LDS (csrc/attention_mfma.hip: attn_fwd_resident);
+ * f32: VALU kernel (parity mode). */
 int ppt_attention_fwd(const void *qkv, void *out, float *lse, int Bt, int T, int H, int hd,
                       float scale, int causal, int dtype, void *stream);
 /* dqkv [Bt,T,3,H,hd] (dtype) from dout [Bt,T,H*hd] (dtype); `delta` [Bt,H,T] f32 workspace. */
