@@ -494,7 +494,8 @@ int ppt_bn_act_rows(const float *x, int M, int C, const float *scale, const floa
 int ppt_adamw_step(float *p, float *g, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int step, float grad_scale, void *stream);
                    /* grad_scale: g is multiplied by it first (1 / loss scale of the caller; 1 = none) and, when != 1, the
-                    * product is written back to g, so that g ends as the gradient of the un-scaled loss */
+                    * product is written back to g, so that g ends as the gradient of the un-scaled loss; an element whose
+                    * scaled gradient is not finite is then skipped (p, moments unchanged, g = 0) */
 int ppt_prompt_rows(const float *base, const int *slot, const float *tokens, const float *pos_rows, int rows, int W, float *out,
                     void *stream);
 int ppt_prompt_rows_bwd(const float *g, const int *rows_of, int max_rows, int n_tok, int W, float *d_tokens, void *stream);

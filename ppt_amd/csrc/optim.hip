@@ -23,7 +23,14 @@ __global__ __launch_bounds__(256) void adamw_step_kernel(float *__restrict__ p, 
     // grad_scale != 1: g holds the gradient of (loss / grad_scale) -- train.Trainer's loss scaling; the true gradient is
     // written back so that g reads like the reference's .grad afterwards (a power of two: exact)
     const float gi = g[i] * grad_scale;
-    if (grad_scale != 1.f) g[i] = gi;
+    if (grad_scale != 1.f) {
+        // A loss-scaled backward through fp16 operand stages can overflow where the fp32 reference would not: an element whose
+        // gradient is not finite is left alone this step (parameter and moments keep their values, the gradient reads 0) instead
+        // of poisoning the state for good.  (torch.cuda.amp.GradScaler skips the whole step and shrinks the scale; that needs a
+        // grid-wide flag -- a second kernel on the prompt chain.  Never seen with the default scale: DESIGN section 5.)
+        if (!(fabsf(gi) <= 3.0e38f)) { g[i] = 0.f; return; }
+        g[i] = gi;
+    }
     float pi = p[i] * decay;
     const float mi = m[i] + (gi - m[i]) * omb1;
     const float vi = v[i] * b2 + omb2 * gi * gi;

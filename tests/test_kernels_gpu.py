@@ -1145,6 +1145,15 @@ def test_adamw_step_unscales_a_loss_scaled_gradient_in_place(ops):
         outs.append((p, m, v))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+    # a non-finite element of a loss-scaled gradient is skipped (parameter and moments untouched, gradient reads 0), the rest updates
+    p, m, v = p0.clone().cuda(), torch.full((40, 512), 0.5).cuda(), torch.full((40, 512), 0.25).cuda()
+    gs = grad * 4096.0
+    gs[3, 7], gs[5, 9], gs[11, 0] = float("inf"), float("nan"), float("-inf")
+    ops.adamw_step(p, gs, m, v, 3e-3, 0.9, 0.98, 1e-8, 0.1, 1, grad_scale=1.0 / 4096.0)
+    bad = torch.zeros(40, 512, dtype=torch.bool); bad[3, 7] = bad[5, 9] = bad[11, 0] = True
+    assert torch.isfinite(p).all() and torch.isfinite(m).all() and torch.isfinite(v).all()
+    assert torch.equal(p.cpu()[bad], p0[bad]) and (m.cpu()[bad] == 0.5).all() and (v.cpu()[bad] == 0.25).all() and (gs.cpu()[bad] == 0).all()
+    assert not torch.equal(p.cpu()[~bad], p0[~bad]) and torch.equal(gs.cpu()[~bad], grad.cpu()[~bad])
 
 
 @pytest.mark.parametrize("position", ["front", "middle", "end"])
