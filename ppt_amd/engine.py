@@ -252,10 +252,21 @@ def vit_block_forward(sd, p, wc, x, pos, B, Tn, heads, dp1, dp2, save=None, pos_
     qkv = ops.gemm(h, wc.get(sd[p + "attn.qkv.weight"]), out_dtype=T)
     a, lse = ops.attention_fwd(qkv, B, Tn, heads, ATTN_SCALE, False, want_lse=keep)
     x_mid = torch.empty_like(x) if keep else xs
+    fused_mlp = (FUSED_MLP and not keep and T in ops.HALF and x.shape[1] == 384 and sd[p + "mlp.fc1.weight"].shape[0] == 1536
+                 and x_mid.is_contiguous())
+    if fused_mlp and FUSED_PROJ and a.is_contiguous() and x.shape[0] >= 8192:
+        # frozen block: attn.proj + DropPath + residual in front of the fused MLP kernel (csrc/mlp_fused.hip, round 3).  From
+        # ~100 chunks of 80 rows on: with few rows the MLP kernel runs on a handful of CUs and the proj GEMM in front of it is
+        # better off as a launch of its own over all of them (C5, 2 064 rows: 6.39 ms separate, 6.44 fused)
+        w1t, w2t = _mlp_weights(sd, p, wc)
+        wp = sd[p + "attn.proj.weight"]
+        wpt = wc.derived(("vit_proj_tiled", p), (wp,), lambda: ops.vit_proj_retile(wc.get(wp)))
+        return ops.vit_mlp(xs, w1t, sd[p + "mlp.fc1.bias"], w2t, sd[p + "mlp.fc2.bias"],
+                           (sd[p + "norm2.weight"], sd[p + "norm2.bias"]), row_scale=dp2, row_scale_rows=Tn,
+                           residual2=pos if add_pos_out else None, proj=(a, wpt, sd[p + "attn.proj.bias"], dp1, Tn))
     ops.gemm(a, wc.get(sd[p + "attn.proj.weight"]), out=x_mid, bias=sd[p + "attn.proj.bias"], row_scale=dp1,
              row_scale_rows=Tn, residual=xs)
-    if (FUSED_MLP and not keep and T in ops.HALF and x.shape[1] == 384 and sd[p + "mlp.fc1.weight"].shape[0] == 1536
-            and x_mid.is_contiguous()):
+    if fused_mlp:
         # frozen block: LayerNorm + fc1 + GELU + fc2 + DropPath + residual (+ the next block's "+ pos") in one kernel
         w1t, w2t = _mlp_weights(sd, p, wc)
         return ops.vit_mlp(x_mid, w1t, sd[p + "mlp.fc1.bias"], w2t, sd[p + "mlp.fc2.bias"],
