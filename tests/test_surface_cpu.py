@@ -316,3 +316,28 @@ def test_top_level_load_state_dict_resets_the_point_encoders_caches():
     m._graphs.entries["stale"] = object()
     m.load_state_dict({'point_encoder.blocks.blocks.11.mlp.fc2.bias': torch.zeros(384)}, strict=False)
     assert pe._wc is None and pe._sd is None and not pe._graphs.entries and not m._graphs.entries
+
+
+def test_loss_scale_rule():
+    """train.Trainer's loss scale: "auto" = the number of rows the criterion averages over, rounded down to a
+    power of two, only in the performance mode on a GPU; a number fixes it; None / "0" / "1" turn it off."""
+    from types import SimpleNamespace
+    import torch
+    from ppt_amd.train import Trainer
+    tr = Trainer.__new__(Trainer)
+    tr.model = SimpleNamespace(precision=torch.bfloat16)
+    gpu_loss, cpu_loss = SimpleNamespace(is_cuda=True), SimpleNamespace(is_cuda=False)
+    tr.loss_scale = "auto"
+    assert tr._loss_scale_for(torch.zeros(32, dtype=torch.long), gpu_loss) == 32.0
+    assert tr._loss_scale_for(torch.zeros(48, dtype=torch.long), gpu_loss) == 32.0
+    assert tr._loss_scale_for(torch.zeros(16, 2048, dtype=torch.long), gpu_loss) == 32768.0
+    assert tr._loss_scale_for(torch.zeros(1, dtype=torch.long), gpu_loss) == 1.0
+    assert tr._loss_scale_for(torch.zeros(32, dtype=torch.long), cpu_loss) == 1.0
+    tr.model.precision = torch.float32                        # parity mode: never scaled
+    assert tr._loss_scale_for(torch.zeros(32, dtype=torch.long), gpu_loss) == 1.0
+    tr.model.precision = torch.bfloat16
+    for off in (None, "0", "1", "off"):
+        tr.loss_scale = off
+        assert tr._loss_scale_for(torch.zeros(32, dtype=torch.long), gpu_loss) == 1.0
+    tr.loss_scale = 4096
+    assert tr._loss_scale_for(torch.zeros(32, dtype=torch.long), gpu_loss) == 4096.0
