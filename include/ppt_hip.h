@@ -35,13 +35,17 @@ extern "C" {
 #define PPT_BF16 1
 #define PPT_F16 2   /* IEEE half operands / fp32 accumulate: the MFMA rate of bf16 with 11 significand bits instead of 8 -- the
                      * operand format of the performance mode's text tower, PointBERT tokenizer + blocks and part-seg decoder
-                     * (residual stream and statistics in fp32; the backward is seeded with a power-of-two loss scale by the
-                     * host, ppt_adamw_step un-scales); bf16 stays the format of PointNet++ / PointMLP */
+                     * (residual stream and statistics in fp32; every backward stage that carries gradients in half multiplies
+                     * what it receives by a power-of-two scale and what it hands out by its inverse -- ppt_convert_scaled, the
+                     * alpha of ppt_rows_matmul_f32, ppt_gemm's row_scale, ppt_prompt_rows_bwd's scale; host side:
+                     * ppt_amd/gradscale.py); bf16 stays the format of PointNet++ / PointMLP */
 
 const char *ppt_strerror(int code);
-/* ABI version of this header (currently 3); bumped on any signature change or added entry point.
+/* ABI version of this header (currently 4); bumped on any signature change or added entry point.
  * 3: PPT_F16 (dtype arguments / struct fields), ppt_cross_entropy_rows (ignored labels, loss[2]), ppt_adamw_step (grad_scale),
- *    ppt_bn_rows_bwd_apply (half_dtype), ppt_*_half entry points. */
+ *    ppt_bn_rows_bwd_apply (half_dtype), ppt_*_half entry points.
+ * 4: gradient scaling local to the 16-bit backward stages -- ppt_convert_scaled (new), ppt_rows_matmul_f32 (alpha),
+ *    ppt_prompt_rows_bwd (scale); ppt_adamw_step (skipped counter), ppt_adamw_multi (new); ppt_cross_entropy_rows (ignore_index). */
 int ppt_abi_version(void);
 
 /* ---- H1: farthest point sampling ---------------------------------------------------------
@@ -424,16 +428,19 @@ int ppt_gemm_tn_half(const void *A, int64_t lda, const void *B, int64_t ldb, int
                      int dtype, void *stream);
 
 /* nn.CrossEntropyLoss(label_smoothing, reduction='mean') over R rows of C <= 96 classes and its gradient (main_partseg.py:213;
- * main_cls.py:52,196).  A label outside [0, C) (ignore_index = -100) is an ignored row, as in ATen: no loss, zero gradient, not
- * counted in the mean.  loss: TWO floats -- loss[0] = the mean over the counted rows, loss[1] = R / counted rows (exactly 1 when
+ * main_cls.py:52,196).  A row whose label == ignore_index (outside [0, C); torch's default -100) is an ignored row, as in ATen:
+ * no loss, zero gradient, not counted in the mean.  Any OTHER label outside [0, C) is a corrupt label (ATen: device assert): the
+ * loss comes back NaN so that the caller's non-finite check fires (its gradient row is zero).
+ * loss: TWO floats -- loss[0] = the mean over the counted rows, loss[1] = R / counted rows (exactly 1 when
  * none is ignored); dlogits [R,C] = d loss / d logits scaled by 1 / R: multiply by loss[1] for the exact gradient.
  * partial: scratch of 2 * ceil(R / 128) floats.  Fixed summation order. */
-int ppt_cross_entropy_rows(const float *logits, const int64_t *labels, float smoothing, int64_t R, int C, float *loss, float *dlogits,
-                           float *partial, void *stream);
+int ppt_cross_entropy_rows(const float *logits, const int64_t *labels, float smoothing, int64_t R, int C, int64_t ignore_index,
+                           float *loss, float *dlogits, float *partial, void *stream);
 
-/* out[M,N] = A[M,K] . W[K,N], fp32, few rows (K <= 1536, K % 32 == 0): the EOT projection `x @ self.text_projection`
- * (ULIP_models.py:222) and its backward.  W row-major as stored ([K,N]). */
-int ppt_rows_matmul_f32(const float *A, const float *W, int M, int K, int N, float *out, void *stream);
+/* out[M,N] = alpha * A[M,K] . W[K,N], fp32, few rows (K <= 1536, K % 32 == 0): the EOT projection `x @ self.text_projection`
+ * (ULIP_models.py:222) and its backward.  W row-major as stored ([K,N]).  alpha > 0: 1, or the power-of-two gradient scale with
+ * which the text tower's backward enters its 16-bit stages (the product by a power of two is exact). */
+int ppt_rows_matmul_f32(const float *A, const float *W, int M, int K, int N, float alpha, float *out, void *stream);
 
 /* ---- the step between the towers when only the prompt trains (head_type 0) --------------------------
  * head_logits: spc[B,E] = exp(logit_scale) * feat[B,F] @ w[F,E] (w = pc_projection as stored, ULIP_models.py:257), logits[B,C] =
@@ -490,18 +497,34 @@ int ppt_bn_act_rows(const float *x, int M, int C, const float *scale, const floa
  * prompt_rows: PromptLearner.forward (ULIP_models.py:104-151) + the positional add of encode_text (:210) in the text tower's
  *   row layout: out[i] = slot[i] >= 0 ? tokens[slot[i]] + pos_rows[i] : base[i]; base [rows, W] = frozen embedding +
  *   positional embedding per row (a constant), slot [rows] i32, pos_rows [rows, W].  W % 4 == 0.
- * prompt_rows_bwd: d_tokens[t] = sum of g[row] over rows_of[t * max_rows + k] (ascending, -1 terminated). */
+ * prompt_rows_bwd: d_tokens[t] = scale * sum of g[row] over rows_of[t * max_rows + k] (ascending, -1 terminated); scale > 0:
+ *   1, or the inverse of the gradient scale the text tower's backward ran with.
+ * adamw_multi: adamw_step for `count` tensors (each with its own step number) in one launch per PPT_ADAMW_MAX_TENSORS tensors;
+ *   `tensors` is a HOST array (it travels as a kernel argument). */
 int ppt_adamw_step(float *p, float *g, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
-                   float eps, float weight_decay, int step, float grad_scale, void *stream);
-                   /* grad_scale: g is multiplied by it first (1 / loss scale of the caller; 1 = none) and, when != 1, the
-                    * product is written back to g, so that g ends as the gradient of the un-scaled loss; an element whose
-                    * scaled gradient is not finite is then skipped (p, moments unchanged, g = 0) */
+                   float eps, float weight_decay, int step, float grad_scale, uint64_t *skipped, void *stream);
+                   /* grad_scale: g is multiplied by it first (1 / loss scale of a caller that scaled its loss; 1 = none) and,
+                    * when != 1, the product is written back to g, so that g ends as the gradient of the un-scaled loss.
+                    * An element whose gradient is not finite is skipped (p, moments unchanged, g = 0) and counted in
+                    * *skipped (device memory, 64-bit, atomically incremented; may be NULL): a 16-bit backward stage can
+                    * overflow where the fp32 reference cannot, and one such step must not poison the moments for good. */
+#define PPT_ADAMW_MAX_TENSORS 64
+typedef struct ppt_adamw_tensor {
+    float *p, *g, *exp_avg, *exp_avg_sq;     /* device, f32, contiguous, n elements each */
+    int64_t n;
+    int step;                                /* >= 1: this update's number for this tensor (bias corrections) */
+} ppt_adamw_tensor;
+int ppt_adamw_multi(const ppt_adamw_tensor *tensors, int count, float lr, float beta1, float beta2, float eps, float weight_decay,
+                    float grad_scale, uint64_t *skipped, void *stream);
 int ppt_prompt_rows(const float *base, const int *slot, const float *tokens, const float *pos_rows, int rows, int W, float *out,
                     void *stream);
-int ppt_prompt_rows_bwd(const float *g, const int *rows_of, int max_rows, int n_tok, int W, float *d_tokens, void *stream);
+int ppt_prompt_rows_bwd(const float *g, const int *rows_of, int max_rows, int n_tok, int W, float scale, float *d_tokens, void *stream);
 
 /* dtype conversion / transposition helpers (weights are converted once, activations never). */
 int ppt_convert(const void *src, int src_dtype, void *dst, int dst_dtype, int64_t n, void *stream);
+/* dst = convert(src * scale), scale > 0: the operand copy of an fp32 activation gradient at the entry of a 16-bit backward
+ * stage, multiplied by the stage's power-of-two gradient scale on the way (exact; ppt_amd/gradscale.py). */
+int ppt_convert_scaled(const void *src, int src_dtype, void *dst, int dst_dtype, int64_t n, float scale, void *stream);
 /* src [rows, cols] contiguous -> dst [cols, rows] with row stride ld_dst >= rows (padding untouched) */
 int ppt_transpose(const void *src, int src_dtype, void *dst, int dst_dtype, int rows, int cols,
                   int64_t ld_dst, void *stream);

@@ -49,6 +49,11 @@ class BallMulti(ctypes.Structure):
     _fields_ = [("n", c_int), ("r2", c_float * 3), ("K", c_int * 3), ("idx", c_void_p * 3), ("gxyz", c_void_p * 3)]
 
 
+class AdamwTensor(ctypes.Structure):
+    """struct ppt_adamw_tensor (include/ppt_hip.h)."""
+    _fields_ = [("p", c_void_p), ("g", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p), ("n", c_int64), ("step", c_int)]
+
+
 class RowGemmParams(ctypes.Structure):
     """struct ppt_rowgemm_params (include/ppt_hip.h) -- field order must match the header."""
     _fields_ = [
@@ -61,13 +66,13 @@ class RowGemmParams(ctypes.Structure):
 
 _SIGNATURES = {
     "ppt_abi_version": (c_int, []),
-    "ppt_cross_entropy_rows": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ppt_cross_entropy_rows": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ppt_gn_finish": (c_int, [c_void_p, c_int, c_int, c_int, ctypes.c_double, ctypes.c_double, c_int, c_void_p, c_void_p, c_void_p]),
     "ppt_set_wave_priority": (None, [c_int]),
     "ppt_get_wave_priority": (c_int, []),
     "ppt_set_persistent_occupancy": (None, [c_int]),
     "ppt_get_persistent_occupancy": (c_int, []),
-    "ppt_rows_matmul_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ppt_rows_matmul_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "ppt_fps_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ppt_knn_group_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ppt_square_distance_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -153,10 +158,12 @@ _SIGNATURES = {
     "ppt_linear3_gelu": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "ppt_cls_max_pool": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ppt_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int,
-                               c_float, c_void_p]),
+                               c_float, c_void_p, c_void_p]),
+    "ppt_adamw_multi": (c_int, [c_void_p, c_int, c_float, c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
     "ppt_prompt_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
-    "ppt_prompt_rows_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ppt_prompt_rows_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "ppt_convert": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
+    "ppt_convert_scaled": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_float, c_void_p]),
     "ppt_transpose": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_void_p]),
     "ppt_reduce_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
 }

@@ -3,7 +3,7 @@ models/pointbert/pointnet2_utils.py:297-467).  The frozen towers do not use thes
 the hand-scheduled pipelines of ppt_amd.engine."""
 import torch
 
-from . import ops
+from . import gradscale, ops
 
 
 def _pad_k(t, mult, dtype):
@@ -29,9 +29,11 @@ class _Linear(torch.autograd.Function):
         y = ops.gemm(xt, wt, out_dtype=torch.float32, bias=b.detach().float().contiguous() if b is not None else None)
         ctx.save_for_backward(xt, wt)
         ctx.k, ctx.wshape, ctx.has_bias, ctx.prec = x2.shape[1], w.shape, b is not None, prec
+        ctx.grad_scale = gradscale.current(prec, default_rows=x2.shape[0])      # a 16-bit backward stage (ppt_amd/gradscale.py)
         return y
 
     @staticmethod
+    @gradscale.scaled_backward
     def backward(ctx, dy):
         xt, wt = ctx.saved_tensors
         prec = ctx.prec
@@ -223,9 +225,11 @@ class _FeaturePropagation(torch.autograd.Function):
         ctx.s0, ctx.s1, ctx.idx, ctx.wgt = s0, s1, idx, wgt
         ctx.training, ctx.prec, ctx.w0, ctx.w1 = training, prec, w0, w1
         ctx.D1, ctx.S, ctx.D2 = (0 if p1 is None else p1.shape[2]), p2.shape[1], p2.shape[2]
+        ctx.grad_scale = gradscale.current(prec, default_rows=B * N)           # a 16-bit backward stage (ppt_amd/gradscale.py)
         return h1.view(B, N, -1)
 
     @staticmethod
+    @gradscale.scaled_backward
     def backward(ctx, dout):
         B, N, C = dout.shape
         dh0, dW1, db1, dg1, dbe1 = _conv_bn_relu_bwd(dout.reshape(B * N, C), ctx.s1, ctx.training, ctx.prec, ctx.w1, True)
@@ -252,9 +256,11 @@ class _ConvBNReLURows(torch.autograd.Function):
         xT = _pad_k(x.detach().float().contiguous(), _mult(prec), prec)
         h, s = _conv_bn_relu_fwd(xT, w, b, bn, training, prec, torch.float32)
         ctx.s, ctx.training, ctx.prec, ctx.w, ctx.K = s, training, prec, w, x.shape[1]
+        ctx.grad_scale = gradscale.current(prec, default_rows=x.shape[0])      # a 16-bit backward stage (ppt_amd/gradscale.py)
         return h
 
     @staticmethod
+    @gradscale.scaled_backward
     def backward(ctx, dh):
         dx, dW, db, dg, dbe = _conv_bn_relu_bwd(dh, ctx.s, ctx.training, ctx.prec, ctx.w, ctx.needs_input_grad[0])
         if dx is not None and dx.shape[1] != ctx.K:
@@ -293,9 +299,11 @@ class _DGCNNLayer(torch.autograd.Function):
         out, arg, mean, rstd = ops.gn_lrelu_max_forward(y, g, b, gn.num_groups, gn.eps, slope)
         ctx.saved = (xkT, xqT, waT, wdT, y, out, arg, mean, rstd, g, idx)
         ctx.groups, ctx.slope, ctx.prec, ctx.w, ctx.C, ctx.S, ctx.same = gn.num_groups, slope, prec, w, C, S, x_q is x_k
+        ctx.grad_scale = gradscale.current(prec, default_rows=B * Nq)          # a 16-bit backward stage (ppt_amd/gradscale.py)
         return out
 
     @staticmethod
+    @gradscale.scaled_backward
     def backward(ctx, dout):
         xkT, xqT, waT, wdT, y, out, arg, mean, rstd, g, idx = ctx.saved
         B, Nq, K, Cout = y.shape
@@ -385,24 +393,34 @@ def partseg_decoder_forward(pe, f_a, f_b, f_c, center, c1, c2, pts, cls_label, d
     return y, (k1, k2, k3a, k3b, k4a, k4b, k5, k6, drop, (B, N))
 
 
-def partseg_decoder_backward(ctxs, dy):
-    """dy [B,N,128] -> the gradients of partseg_decoder_params(pe), in that order."""
+def partseg_decoder_backward(ctxs, dy, grad_scale=1.0):
+    """dy [B,N,128] -> the gradients of partseg_decoder_params(pe), in that order.
+    grad_scale = S: the whole decoder is ONE gradient-scaled stage (ppt_amd/gradscale.py) -- dy x S on the way in, the 47
+    parameter gradients x 1 / S in one multi-tensor launch on the way out; the per-module backwards run un-wrapped (`.raw`)."""
     k1, k2, k3a, k3b, k4a, k4b, k5, k6, drop, (B, N) = ctxs
+    S = float(grad_scale)
     dy = dy.float()
     if drop is not None:
-        dy = dy * drop
-    g6 = _ConvBNReLURows.backward(k6, dy.reshape(B * N, -1).contiguous())
-    g5 = _FeaturePropagation.backward(k5, g6[0].reshape(B, N, -1))                       # -> d L4 (points2 of propagation_0)
-    g4b = _DGCNNLayer.backward(k4b, g5[0])
-    g4a = _DGCNNLayer.backward(k4a, g4b[0] + g4b[1])                                      # L3 is both operands of layer 2
-    g2 = _FeaturePropagation.backward(k2, g4a[1])                                         # F1 = propagation_1's output
-    g3b = _DGCNNLayer.backward(k3b, g4a[0])                                               # L2 = dgcnn_pro_2's output
-    g3a = _DGCNNLayer.backward(k3a, g3b[0] + g3b[1])
-    g1 = _FeaturePropagation.backward(k1, g3a[1])                                         # F2 = propagation_2's output
+        dy = dy * (drop if S == 1.0 else drop * S)
+    elif S != 1.0:
+        dy = dy * S
+    fp_bwd, dg_bwd, cv_bwd = _FeaturePropagation.backward.raw, _DGCNNLayer.backward.raw, _ConvBNReLURows.backward.raw
+    g6 = cv_bwd(k6, dy.reshape(B * N, -1).contiguous())
+    g5 = fp_bwd(k5, g6[0].reshape(B, N, -1))                                             # -> d L4 (points2 of propagation_0)
+    g4b = dg_bwd(k4b, g5[0])
+    g4a = dg_bwd(k4a, g4b[0] + g4b[1])                                                    # L3 is both operands of layer 2
+    g2 = fp_bwd(k2, g4a[1])                                                               # F1 = propagation_1's output
+    g3b = dg_bwd(k3b, g4a[0])                                                             # L2 = dgcnn_pro_2's output
+    g3a = dg_bwd(k3a, g3b[0] + g3b[1])
+    g1 = fp_bwd(k1, g3a[1])                                                               # F2 = propagation_2's output
     out = list(g5[1:9]) + list(g2[1:9]) + list(g1[1:9])
     for gd in (g4a, g4b, g3a, g3b):
         out += [gd[2], gd[3], gd[4]]
-    return out + [g6[1], g6[2], g6[3], g6[4]]
+    out = out + [g6[1], g6[2], g6[3], g6[4]]
+    if S != 1.0:
+        out = [o.contiguous() for o in out]            # (a weight gradient may be a column slice of its padded GEMM result)
+        gradscale.unscale_(out, S)
+    return out
 
 
 STATIC_GRADS_OK = False          # set by train.Trainer.step around loss.backward(): see _PartsegDecoder.backward
@@ -429,6 +447,7 @@ class _PartsegDecoder(torch.autograd.Function):
         (y,), ctxs = g(*ins)
         g.generation = getattr(g, "generation", 0) + 1
         ctx.pe, ctx.g, ctx.key, ctx.generation, ctx.ctxs = pe, g, key, g.generation, ctxs
+        ctx.grad_scale = gradscale.current(pe._dec_precision, default_rows=pts.shape[0] * pts.shape[1])
         return y.clone()
 
     @staticmethod
@@ -438,12 +457,13 @@ class _PartsegDecoder(torch.autograd.Function):
             raise RuntimeError("the part-seg decoder's captured activations were overwritten by a later forward; set "
                                "point_encoder.use_hip_graphs = False to keep several forwards alive before backward")
         ctxs, fwd = ctx.ctxs, ctx.g
+        S = ctx.grad_scale
 
         def build():
             def fn(d):
-                return tuple(partseg_decoder_backward(ctxs, d)), None
+                return tuple(partseg_decoder_backward(ctxs, d, grad_scale=S)), None
             return graphs.GraphedCall(fn, [dy.contiguous()], pool=fwd.pool())
-        grads, _ = ctx.pe._graphs.get(("partseg_decoder_bwd",) + ctx.key[1:], build)(dy.contiguous())
+        grads, _ = ctx.pe._graphs.get(("partseg_decoder_bwd",) + ctx.key[1:] + (S,), build)(dy.contiguous())
         # Inside train.Trainer.step (STATIC_GRADS_OK): fresh tensor objects over the graph's static buffers, which autograd adopts
         # as .grad without a copy -- the step drops every .grad before each backward and its optimizer reads them before the next
         # replay overwrites them.  Any other caller (gradient accumulation, a custom loop holding p.grad) gets copies: an adopted

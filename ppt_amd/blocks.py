@@ -12,7 +12,7 @@ Operand precision: `precision` = torch.bfloat16 (bf16 MFMA operands, fp32 accumu
 """
 import torch
 
-from . import ops
+from . import gradscale, ops
 from .ops import ACT_GELU, ACT_NONE, ACT_QUICKGELU
 
 DEFAULT_PRECISION = torch.bfloat16
@@ -66,9 +66,11 @@ class _MlpFn(torch.autograd.Function):
         y = ops.gemm(f, _opnd(w2, T, "w"), out_dtype=torch.float32, bias=b2.detach().float() if b2 is not None else None)
         ctx.save_for_backward(xt, pre, f, w1, w2)
         ctx.act, ctx.T, ctx.shape, ctx.has_b = act, T, x.shape, (b1 is not None, b2 is not None)
+        ctx.grad_scale = gradscale.current(T, default_rows=x2.shape[0])     # a 16-bit backward stage (ppt_amd/gradscale.py)
         return y.view(*x.shape[:-1], w2.shape[0])
 
     @staticmethod
+    @gradscale.scaled_backward
     def backward(ctx, dy):
         xt, pre, f, w1, w2 = ctx.saved_tensors
         T = ctx.T
@@ -103,9 +105,11 @@ class _SelfAttentionFn(torch.autograd.Function):
         y = ops.gemm(a, _opnd(wproj, T, "w"), out_dtype=torch.float32, bias=bproj.detach().float() if bproj is not None else None)
         ctx.save_for_backward(xt, qkv, a, lse, wqkv, wproj)
         ctx.cfg = (B, Tn, D, heads, scale, causal, T, bqkv is not None, bproj is not None)
+        ctx.grad_scale = gradscale.current(T, default_rows=x2.shape[0])     # a 16-bit backward stage (ppt_amd/gradscale.py)
         return y.view(B, Tn, D)
 
     @staticmethod
+    @gradscale.scaled_backward
     def backward(ctx, dy):
         xt, qkv, a, lse, wqkv, wproj = ctx.saved_tensors
         B, Tn, D, heads, scale, causal, T, has_bq, has_bp = ctx.cfg

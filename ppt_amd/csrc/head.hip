@@ -63,7 +63,7 @@ __global__ __launch_bounds__(HT) void head_project_kernel(const float *__restric
 constexpr int HS = 8;
 __global__ __launch_bounds__(512) void head_project8_kernel(const float *__restrict__ feat, const float *__restrict__ w,
                                                             const float *__restrict__ logit_scale, int B, int F, int E,
-                                                            float *__restrict__ spc, int prio)
+                                                            float *__restrict__ spc, int prio, float alpha)
 {
     PPT_PRIO(prio);
     extern __shared__ float sm[];                         // [HS][F] feat rows, then [8 waves][HS][64] partials
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(512) void head_project8_kernel(const float *__restr
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += part[(k * HS + s_) * 64 + lane];
-        spc[(size_t)(b0 + s_) * E + e] = logit_scale ? __expf(logit_scale[0]) * t : t;
+        spc[(size_t)(b0 + s_) * E + e] = logit_scale ? __expf(logit_scale[0]) * t : alpha * t;      // (alpha: a power of two or 1 -- exact)
     }
 }
 
@@ -192,7 +192,7 @@ extern "C" int ppt_head_logits(const float *feat, const float *w, const float *t
     if (F > 8192 || B > 65535) return PPT_EUNSUPPORTED;
     if (F <= 1536 && F % 32 == 0 && (((uintptr_t)feat) & 15) == 0)
         hipLaunchKernelGGL(head_project8_kernel, dim3((E + 63) / 64, (B + HS - 1) / HS), dim3(512), sizeof(float) * (size_t)(HS * F + 8 * HS * 64),
-                           ppt_stream(stream), feat, w, logit_scale, B, F, E, spc, ppt_get_wave_priority());
+                           ppt_stream(stream), feat, w, logit_scale, B, F, E, spc, ppt_get_wave_priority(), 1.0f);
     else
         hipLaunchKernelGGL(head_project_kernel, dim3((E + 63) / 64, B), dim3(HT), sizeof(float) * (size_t)(F + 256), ppt_stream(stream),
                            feat, w, logit_scale, F, E, spc);
@@ -209,7 +209,8 @@ extern "C" int ppt_head_logits(const float *feat, const float *w, const float *t
 // ce_rows_finish in workgroup order (fixed).  Replaces log_softmax + nll_loss forward / backward + the smoothing ops.
 constexpr int CE_ROWS = 128;
 __global__ __launch_bounds__(CE_ROWS) void ce_rows_kernel(const float *__restrict__ logits, const int64_t *__restrict__ labels, float eps,
-                                                          int64_t R, int C, float *__restrict__ dlogits, float *__restrict__ partial)
+                                                          int64_t R, int C, int64_t ignore_index, float *__restrict__ dlogits,
+                                                          float *__restrict__ partial)
 {
     extern __shared__ float sm[];                         // [CE_ROWS][C + 1] (odd pitch for C even: no bank conflicts on the row walk)
     __shared__ float red[CE_ROWS], redc[CE_ROWS];
@@ -222,19 +223,22 @@ __global__ __launch_bounds__(CE_ROWS) void ce_rows_kernel(const float *__restric
     if ((int)threadIdx.x < nrow) {
         float *x = sm + threadIdx.x * pitch;
         const int64_t y64 = labels[r0 + threadIdx.x];
-        // a label outside [0, C) -- nn.CrossEntropyLoss's ignore_index (-100 by default) -- is an IGNORED row, as in ATen: no
-        // loss, zero gradient, not counted in the mean (ce_rows_finish divides by the number of counted rows)
+        // label == ignore_index (nn.CrossEntropyLoss: -100 by default) is an IGNORED row, as in ATen: no loss, zero gradient, not
+        // counted in the mean (ce_rows_finish divides by the number of counted rows).  Any OTHER label outside [0, C) is a
+        // corrupt label: ATen raises a device assert; here the row's loss is NaN, so the mean is NaN and the caller's
+        // non-finite-loss check (main_cls.py:205-207) fires instead of the row being dropped silently.
         const bool valid = y64 >= 0 && y64 < (int64_t)C;
+        const bool corrupt = !valid && y64 != ignore_index;
         const int y = valid ? (int)y64 : 0;
         float m = x[0], sx = 0.f;
         for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
         float z = 0.f;
         for (int c = 0; c < C; ++c) { z += expf(x[c] - m); sx += x[c]; }
         const float lse = m + logf(z);
-        lr = valid ? (1.0f - eps) * (lse - x[y]) + eps * (lse - sx / (float)C) : 0.f;
+        lr = valid ? (1.0f - eps) * (lse - x[y]) + eps * (lse - sx / (float)C) : (corrupt ? __uint_as_float(0x7fc00000u) : 0.f);
         const float inv_r = valid ? 1.0f / (float)R : 0.f, base = eps / (float)C;
         for (int c = 0; c < C; ++c) x[c] = (expf(x[c] - lse) - (base + (c == y ? 1.0f - eps : 0.f))) * inv_r;
-        cnt = valid ? 1.f : 0.f;
+        cnt = (valid || corrupt) ? 1.f : 0.f;
     }
     red[threadIdx.x] = lr;
     redc[threadIdx.x] = cnt;
@@ -259,14 +263,14 @@ __global__ __launch_bounds__(64) void ce_rows_finish(const float *__restrict__ p
     loss[1] = cnt > 0.0 ? (float)((double)r / cnt) : 0.f;
 }
 
-extern "C" int ppt_cross_entropy_rows(const float *logits, const int64_t *labels, float smoothing, int64_t R, int C, float *loss,
-                                      float *dlogits, float *partial, void *stream)
+extern "C" int ppt_cross_entropy_rows(const float *logits, const int64_t *labels, float smoothing, int64_t R, int C, int64_t ignore_index,
+                                      float *loss, float *dlogits, float *partial, void *stream)
 {
     if (!logits || !labels || !loss || !dlogits || !partial || R <= 0 || C <= 0) return PPT_EINVAL;
     if (C > 96) return PPT_EUNSUPPORTED;                  // (rows stay in LDS: CE_ROWS x (C | 1) floats)
     const int nwg = (int)((R + CE_ROWS - 1) / CE_ROWS);
     hipLaunchKernelGGL(ce_rows_kernel, dim3(nwg), dim3(CE_ROWS), sizeof(float) * (size_t)CE_ROWS * (C | 1), ppt_stream(stream), logits, labels,
-                       smoothing, R, C, dlogits, partial);
+                       smoothing, R, C, ignore_index, dlogits, partial);
     PPT_CHECK_LAUNCH();
     hipLaunchKernelGGL(ce_rows_finish, dim3(1), dim3(64), 0, ppt_stream(stream), partial, nwg, (float)R, loss);
     PPT_CHECK_LAUNCH();
@@ -276,12 +280,12 @@ extern "C" int ppt_cross_entropy_rows(const float *logits, const int64_t *labels
 // out[M,N] = A[M,K] . W[K,N] in fp32 for a FEW rows (the text tower's EOT projection x @ text_projection, ULIP_models.py:222, and
 // its backward: 40 rows): head_project8_kernel without the scale.  The fp32 MFMA tile loop ran these 10 MFLOP in 18.9 us (eight
 // workgroups walking K serially); here ~4 us.
-extern "C" int ppt_rows_matmul_f32(const float *A, const float *W, int M, int K, int N, float *out, void *stream)
+extern "C" int ppt_rows_matmul_f32(const float *A, const float *W, int M, int K, int N, float alpha, float *out, void *stream)
 {
-    if (!A || !W || !out || M <= 0 || K <= 0 || N <= 0) return PPT_EINVAL;
+    if (!A || !W || !out || M <= 0 || K <= 0 || N <= 0 || !(alpha > 0.f)) return PPT_EINVAL;
     if (K > 1536 || (K % 32) != 0 || M > 65535 * HS || (((uintptr_t)A) & 15)) return PPT_EUNSUPPORTED;
     hipLaunchKernelGGL(head_project8_kernel, dim3((N + 63) / 64, (M + HS - 1) / HS), dim3(512), sizeof(float) * (size_t)(HS * K + 8 * HS * 64),
-                       ppt_stream(stream), A, W, (const float *)nullptr, M, K, N, out, ppt_get_wave_priority());
+                       ppt_stream(stream), A, W, (const float *)nullptr, M, K, N, out, ppt_get_wave_priority(), alpha);
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }

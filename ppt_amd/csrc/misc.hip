@@ -49,10 +49,27 @@ __global__ __launch_bounds__(CMP_W * 64) void cls_max_pool_kernel(const TX *__re
 }
 
 template <typename TS, typename TD>
-__global__ void convert_kernel(const TS *__restrict__ s, TD *__restrict__ d, int64_t n)
+__global__ void convert_kernel(const TS *__restrict__ s, TD *__restrict__ d, int64_t n, float scale)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        dt<TD>::store(d + i, dt<TS>::load(s + i));
+        dt<TD>::store(d + i, dt<TS>::load(s + i) * scale);
+}
+
+// fp32 -> 16-bit, eight values per thread (two 16-byte loads, one 16-byte store): the operand copy of an activation gradient at
+// the entry of a 16-bit backward stage -- [B x N, 128 ... 512] rows in part segmentation -- where the element-per-thread walk above
+// issued 16x the memory instructions.  scale: the stage's power-of-two gradient scale (ppt_convert_scaled), exact.
+template <typename TD>
+__global__ __launch_bounds__(256) void convert8_kernel(const float *__restrict__ s, TD *__restrict__ d, int64_t n8, float scale)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const float4 a = reinterpret_cast<const float4 *>(s)[2 * i], b = reinterpret_cast<const float4 *>(s)[2 * i + 1];
+        uint4 o;
+        o.x = h16<TD>::pack2(a.x * scale, a.y * scale);
+        o.y = h16<TD>::pack2(a.z * scale, a.w * scale);
+        o.z = h16<TD>::pack2(b.x * scale, b.y * scale);
+        o.w = h16<TD>::pack2(b.z * scale, b.w * scale);
+        reinterpret_cast<uint4 *>(d)[i] = o;
+    }
 }
 
 template <typename TS, typename TD>
@@ -191,12 +208,22 @@ __global__ __launch_bounds__(256) void reduce_rows_small_kernel(const float *__r
 }
 
 template <typename TS>
-int convert_from(const void *src, void *dst, int dd, int64_t n, hipStream_t s)
+int convert_from(const void *src, void *dst, int dd, int64_t n, float scale, hipStream_t s)
 {
+    if constexpr (sizeof(TS) == 4) {
+        if ((dd == PPT_BF16 || dd == PPT_F16) && (n & 7) == 0 && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0) {
+            const int64_t n8 = n >> 3;
+            const unsigned grid8 = (unsigned)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : 8192);
+            if (dd == PPT_BF16) hipLaunchKernelGGL(convert8_kernel<bf16_t>, dim3(grid8), dim3(256), 0, s, (const float *)src, (bf16_t *)dst, n8, scale);
+            else hipLaunchKernelGGL(convert8_kernel<f16_t>, dim3(grid8), dim3(256), 0, s, (const float *)src, (f16_t *)dst, n8, scale);
+            PPT_CHECK_LAUNCH();
+            return PPT_OK;
+        }
+    }
     const unsigned grid = (unsigned)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
-    if (dd == PPT_BF16) hipLaunchKernelGGL((convert_kernel<TS, bf16_t>), dim3(grid), dim3(256), 0, s, (const TS *)src, (bf16_t *)dst, n);
-    else if (dd == PPT_F16) hipLaunchKernelGGL((convert_kernel<TS, f16_t>), dim3(grid), dim3(256), 0, s, (const TS *)src, (f16_t *)dst, n);
-    else if (dd == PPT_F32) hipLaunchKernelGGL((convert_kernel<TS, float>), dim3(grid), dim3(256), 0, s, (const TS *)src, (float *)dst, n);
+    if (dd == PPT_BF16) hipLaunchKernelGGL((convert_kernel<TS, bf16_t>), dim3(grid), dim3(256), 0, s, (const TS *)src, (bf16_t *)dst, n, scale);
+    else if (dd == PPT_F16) hipLaunchKernelGGL((convert_kernel<TS, f16_t>), dim3(grid), dim3(256), 0, s, (const TS *)src, (f16_t *)dst, n, scale);
+    else if (dd == PPT_F32) hipLaunchKernelGGL((convert_kernel<TS, float>), dim3(grid), dim3(256), 0, s, (const TS *)src, (float *)dst, n, scale);
     else return PPT_EINVAL;
     PPT_CHECK_LAUNCH();
     return PPT_OK;
@@ -231,13 +258,18 @@ extern "C" int ppt_cls_max_pool(const void *x, int x_dtype, int B, int T, int D,
     return PPT_OK;
 }
 
+extern "C" int ppt_convert_scaled(const void *src, int src_dtype, void *dst, int dst_dtype, int64_t n, float scale, void *stream)
+{
+    if (!src || !dst || n <= 0 || !(scale > 0.f)) return PPT_EINVAL;
+    if (src_dtype == PPT_F32) return convert_from<float>(src, dst, dst_dtype, n, scale, ppt_stream(stream));
+    if (src_dtype == PPT_BF16) return convert_from<bf16_t>(src, dst, dst_dtype, n, scale, ppt_stream(stream));
+    if (src_dtype == PPT_F16) return convert_from<f16_t>(src, dst, dst_dtype, n, scale, ppt_stream(stream));
+    return PPT_EINVAL;
+}
+
 extern "C" int ppt_convert(const void *src, int src_dtype, void *dst, int dst_dtype, int64_t n, void *stream)
 {
-    if (!src || !dst || n <= 0) return PPT_EINVAL;
-    if (src_dtype == PPT_F32) return convert_from<float>(src, dst, dst_dtype, n, ppt_stream(stream));
-    if (src_dtype == PPT_BF16) return convert_from<bf16_t>(src, dst, dst_dtype, n, ppt_stream(stream));
-    if (src_dtype == PPT_F16) return convert_from<f16_t>(src, dst, dst_dtype, n, ppt_stream(stream));
-    return PPT_EINVAL;
+    return ppt_convert_scaled(src, src_dtype, dst, dst_dtype, n, 1.0f, stream);
 }
 
 extern "C" int ppt_transpose(const void *src, int src_dtype, void *dst, int dst_dtype, int rows, int cols, int64_t ld_dst,

@@ -7,36 +7,76 @@
 //   * prompt_rows: PromptLearner.forward (ULIP_models.py:104-151) + the positional add of encode_text (:210) for the row
 //     layout the text tower runs on: row i = base[i] (the frozen embedding + positional embedding, a constant of the
 //     model) or, where slot[i] >= 0, learnable_tokens[slot[i]] + pos[i];
-//   * prompt_rows_bwd: d learnable_tokens[t] = sum over the rows i with slot[i] == t of g[i], rows taken in ascending order
-//     (owner-computes: deterministic, no atomics) -- the backward of the splice.
+//   * prompt_rows_bwd: d learnable_tokens[t] = scale * sum over the rows i with slot[i] == t of g[i], rows taken in ascending
+//     order (owner-computes: deterministic, no atomics) -- the backward of the splice; scale = 1 / the text tower's gradient
+//     scale (ppt_amd/gradscale.py), a power of two;
+//   * adamw_multi: the same AdamW update for up to PPT_ADAMW_MAX_TENSORS tensors in ONE launch (the tensor table travels as a
+//     kernel argument) -- head_type >= 1 trains 4 ... 13 tensors, part segmentation 47.
+// Both AdamW kernels leave an element whose gradient is not finite alone (parameter and moments unchanged, gradient zeroed) and
+// COUNT it in a device word the caller reads when it wants to (train.Trainer.nonfinite_grad_elements): the fp32 reference
+// cannot overflow where a 16-bit backward stage can, and main_cls.py:205-207 stops on a non-finite loss.
 #include "ppt_common.h"
 
 namespace {
 
-__global__ __launch_bounds__(256) void adamw_step_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
-                                                         float *__restrict__ v, int64_t n, float decay, float omb1, float b2,
-                                                         float omb2, float inv_sqrt_bc2, float eps, float step_size, float grad_scale, int prio)
+// one element of torch.optim.AdamW's single-tensor update; returns false (nothing written but g = 0) for a non-finite gradient
+__device__ __forceinline__ bool adamw_element(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+                                              int64_t i, float decay, float omb1, float b2, float omb2, float inv_sqrt_bc2, float eps,
+                                              float step_size, float grad_scale)
 {
-    PPT_PRIO(prio);
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    // grad_scale != 1: g holds the gradient of (loss / grad_scale) -- train.Trainer's loss scaling; the true gradient is
+    // grad_scale != 1: g holds the gradient of (loss / grad_scale) -- a caller that scaled its loss; the true gradient is
     // written back so that g reads like the reference's .grad afterwards (a power of two: exact)
     const float gi = g[i] * grad_scale;
-    if (grad_scale != 1.f) {
-        // A loss-scaled backward through fp16 operand stages can overflow where the fp32 reference would not: an element whose
-        // gradient is not finite is left alone this step (parameter and moments keep their values, the gradient reads 0) instead
-        // of poisoning the state for good.  (torch.cuda.amp.GradScaler skips the whole step and shrinks the scale; that needs a
-        // grid-wide flag -- a second kernel on the prompt chain.  Never seen with the default scale: DESIGN section 5.)
-        if (!(fabsf(gi) <= 3.0e38f)) { g[i] = 0.f; return; }
-        g[i] = gi;
-    }
+    // A backward through fp16 operand stages can overflow where the fp32 reference would not: an element whose gradient is not
+    // finite is left alone this step (parameter and moments keep their values, the gradient reads 0) instead of poisoning the
+    // state for good, and is counted.
+    if (!(fabsf(gi) <= 3.0e38f)) { g[i] = 0.f; return false; }
+    if (grad_scale != 1.f) g[i] = gi;
     float pi = p[i] * decay;
     const float mi = m[i] + (gi - m[i]) * omb1;
     const float vi = v[i] * b2 + omb2 * gi * gi;
     const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
     pi = pi - step_size * (mi / denom);
     p[i] = pi; m[i] = mi; v[i] = vi;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void adamw_step_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
+                                                         float *__restrict__ v, int64_t n, float decay, float omb1, float b2,
+                                                         float omb2, float inv_sqrt_bc2, float eps, float step_size, float grad_scale,
+                                                         unsigned long long *__restrict__ skipped, int prio)
+{
+    PPT_PRIO(prio);
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (!adamw_element(p, g, m, v, i, decay, omb1, b2, omb2, inv_sqrt_bc2, eps, step_size, grad_scale) && skipped) atomicAdd(skipped, 1ull);
+}
+
+// the tensor table of ppt_adamw_multi as a kernel argument (48 B per tensor: 64 tensors = 3 KB of the 4 KB argument segment)
+struct adamw_table {
+    float *p[PPT_ADAMW_MAX_TENSORS], *g[PPT_ADAMW_MAX_TENSORS], *m[PPT_ADAMW_MAX_TENSORS], *v[PPT_ADAMW_MAX_TENSORS];
+    int64_t n[PPT_ADAMW_MAX_TENSORS];
+    float step_size[PPT_ADAMW_MAX_TENSORS], inv_sqrt_bc2[PPT_ADAMW_MAX_TENSORS];
+    int first_block[PPT_ADAMW_MAX_TENSORS + 1];          // workgroups [first_block[t], first_block[t + 1]) walk tensor t, 1024 elements each
+    int count;
+};
+
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const adamw_table tb, float decay, float omb1, float b2, float omb2, float eps,
+                                                          float grad_scale, unsigned long long *__restrict__ skipped, int prio)
+{
+    PPT_PRIO(prio);
+    int t = 0;                                            // (wave-uniform: blockIdx only -- scalar loads of the argument segment)
+    while (t + 1 < tb.count && (int)blockIdx.x >= tb.first_block[t + 1]) ++t;
+    const int64_t base = (int64_t)((int)blockIdx.x - tb.first_block[t]) * 1024;
+    unsigned bad = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t i = base + u * 256 + threadIdx.x;
+        if (i < tb.n[t] && !adamw_element(tb.p[t], tb.g[t], tb.m[t], tb.v[t], i, decay, omb1, b2, omb2, tb.inv_sqrt_bc2[t], eps,
+                                          tb.step_size[t], grad_scale))
+            ++bad;
+    }
+    if (bad && skipped) atomicAdd(skipped, (unsigned long long)bad);
 }
 
 __global__ __launch_bounds__(256) void prompt_rows_kernel(const float *__restrict__ base, const int *__restrict__ slot,
@@ -63,7 +103,7 @@ __global__ __launch_bounds__(256) void prompt_rows_kernel(const float *__restric
 
 // one thread per (token, 4 columns); the token's rows are listed (ascending) in rows_of[token * max_rows ...], -1 terminated
 __global__ __launch_bounds__(256) void prompt_rows_bwd_kernel(const float *__restrict__ g, const int *__restrict__ rows_of, int max_rows,
-                                                              int n_tok, int W, float *__restrict__ d_tokens, int prio)
+                                                              int n_tok, int W, float *__restrict__ d_tokens, int prio, float scale)
 {
     PPT_PRIO(prio);
     const int w4 = W >> 2;
@@ -85,20 +125,50 @@ __global__ __launch_bounds__(256) void prompt_rows_bwd_kernel(const float *__res
             if (row[u] >= 0) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
         if (row[7] < 0) break;
     }
-    *reinterpret_cast<float4 *>(d_tokens + (int64_t)t * W + c) = acc;
+    *reinterpret_cast<float4 *>(d_tokens + (int64_t)t * W + c) = make_float4(acc.x * scale, acc.y * scale, acc.z * scale, acc.w * scale);
 }
 
 }  // namespace
 
 extern "C" int ppt_adamw_step(float *p, float *g, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, float beta1,
-                              float beta2, float eps, float weight_decay, int step, float grad_scale, void *stream)
+                              float beta2, float eps, float weight_decay, int step, float grad_scale, uint64_t *skipped, void *stream)
 {
     if (!p || !g || !exp_avg || !exp_avg_sq || n <= 0 || step <= 0 || !(grad_scale > 0.f)) return PPT_EINVAL;
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     hipLaunchKernelGGL(adamw_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ppt_stream(stream), p, g, exp_avg, exp_avg_sq, n,
                        (float)(1.0 - (double)lr * weight_decay), 1.0f - beta1, beta2, 1.0f - beta2, (float)(1.0 / sqrt(bc2)), eps,
-                       (float)((double)lr / bc1), grad_scale, ppt_get_wave_priority());
+                       (float)((double)lr / bc1), grad_scale, (unsigned long long *)skipped, ppt_get_wave_priority());
     PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
+extern "C" int ppt_adamw_multi(const ppt_adamw_tensor *tensors, int count, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, float grad_scale, uint64_t *skipped, void *stream)
+{
+    if (!tensors || count <= 0 || !(grad_scale > 0.f)) return PPT_EINVAL;
+    for (int i = 0; i < count; ++i)
+        if (!tensors[i].p || !tensors[i].g || !tensors[i].exp_avg || !tensors[i].exp_avg_sq || tensors[i].n <= 0 || tensors[i].step <= 0)
+            return PPT_EINVAL;
+    for (int c0 = 0; c0 < count; c0 += PPT_ADAMW_MAX_TENSORS) {
+        adamw_table tb;
+        tb.count = count - c0 < PPT_ADAMW_MAX_TENSORS ? count - c0 : PPT_ADAMW_MAX_TENSORS;
+        int64_t blocks = 0;
+        for (int i = 0; i < tb.count; ++i) {
+            const ppt_adamw_tensor &t = tensors[c0 + i];
+            const double bc1 = 1.0 - pow((double)beta1, t.step), bc2 = 1.0 - pow((double)beta2, t.step);
+            tb.p[i] = t.p; tb.g[i] = t.g; tb.m[i] = t.exp_avg; tb.v[i] = t.exp_avg_sq; tb.n[i] = t.n;
+            tb.step_size[i] = (float)((double)lr / bc1);
+            tb.inv_sqrt_bc2[i] = (float)(1.0 / sqrt(bc2));
+            tb.first_block[i] = (int)blocks;
+            blocks += (t.n + 1023) / 1024;
+            if (blocks > 0x7fffffff) return PPT_EUNSUPPORTED;
+        }
+        tb.first_block[tb.count] = (int)blocks;
+        hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, ppt_stream(stream), tb,
+                           (float)(1.0 - (double)lr * weight_decay), 1.0f - beta1, beta2, 1.0f - beta2, eps, grad_scale,
+                           (unsigned long long *)skipped, ppt_get_wave_priority());
+        PPT_CHECK_LAUNCH();
+    }
     return PPT_OK;
 }
 
@@ -113,11 +183,12 @@ extern "C" int ppt_prompt_rows(const float *base, const int *slot, const float *
     return PPT_OK;
 }
 
-extern "C" int ppt_prompt_rows_bwd(const float *g, const int *rows_of, int max_rows, int n_tok, int W, float *d_tokens, void *stream)
+extern "C" int ppt_prompt_rows_bwd(const float *g, const int *rows_of, int max_rows, int n_tok, int W, float scale, float *d_tokens,
+                                   void *stream)
 {
-    if (!g || !rows_of || !d_tokens || max_rows <= 0 || n_tok <= 0 || W <= 0 || (W & 3)) return PPT_EINVAL;
+    if (!g || !rows_of || !d_tokens || max_rows <= 0 || n_tok <= 0 || W <= 0 || (W & 3) || !(scale > 0.f)) return PPT_EINVAL;
     hipLaunchKernelGGL(prompt_rows_bwd_kernel, dim3((n_tok * (W / 4) + 255) / 256), dim3(256), 0, ppt_stream(stream), g, rows_of, max_rows,
-                       n_tok, W, d_tokens, ppt_get_wave_priority());
+                       n_tok, W, d_tokens, ppt_get_wave_priority(), scale);
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }

@@ -375,11 +375,19 @@ def _wgrad(dy_t, x_t):
     return ops.gemm_tn_splitk(dy_t, x_t)
 
 
-def point_encoder_backward(sd, wc, s, dfeat, tier):
+def point_encoder_backward(sd, wc, s, dfeat, tier, grad_scale=1.0):
     """Backward of the un-frozen part (ULIP_models.py:461-470): final LN -> block depth-1.
-    Returns {param name: grad} for the tier's parameters."""
+    Returns {param name: grad} for the tier's parameters.
+    grad_scale = S (ppt_amd/gradscale.py): the block's activation gradients travel in its 16-bit operand format; dfeat is
+    multiplied by the power of two S on the way in ([B, 2D]: one tiny launch) and every returned gradient by 1 / S on the way
+    out (one multi-tensor launch) -- the caller sees the true fp32 gradients."""
     wc = s.get("wc", wc)                       # (the cache block depth-1 ran its forward with: STAGE_DTYPE diagnostics)
     T = wc.dtype
+    if grad_scale != 1.0:
+        from . import gradscale
+        grads = point_encoder_backward(sd, wc, s, dfeat * float(grad_scale), tier)
+        gradscale.unscale_(list(grads.values()), float(grad_scale))
+        return grads
     B, Tn, D, heads, p = s["B"], s["Tn"], s["D"], s["heads"], s["prefix"]
     M = B * Tn
     grads = {}
@@ -893,17 +901,23 @@ def _f32_cache(wc):
     return c[1]
 
 
-def text_tower_backward(sd, wc, s, dout):
+def text_tower_backward(sd, wc, s, dout, grad_scale=1.0):
     """Input gradient of encode_text: dout [C,E] -> d prompts [C,L,W] fp32.  The tower is frozen
     (ULIP_models.py:487-507), so no weight gradient is ever formed: 4 dX GEMMs, 2 LayerNorm
     backwards and one attention backward per layer.  With a shared prefix (text_tower_forward) the gradient of the shared
-    rows is handed to prompt 0; the caller (PromptLearner's index_put) sums over the prompts anyway."""
+    rows is handed to prompt 0; the caller (PromptLearner's index_put) sums over the prompts anyway.
+
+    grad_scale = S (ppt_amd/gradscale.py): the layers' activation gradients travel in the tower's 16-bit operand format, so the
+    gradient enters them multiplied by the power of two S -- folded into the very first product, d_hn = S * dout @ P^T -- and
+    leaves multiplied by 1 / S: in the row-layout mode by the CALLER (ops.prompt_rows_bwd(..., scale = 1 / S) folds it into the
+    kernel that sums the rows onto the tokens; the returned g is still scaled), otherwise here."""
     T = wc.dtype
+    S = float(grad_scale)
     C, L, Wd, heads, P, M = s["C"], s["L"], s["W"], s["heads"], s["P"], s["M"]
     wc32 = _f32_cache(wc)
-    d_hn = ops.rows_matmul(dout.contiguous(), wc32.get(sd["text_projection"], "wt")) if dout.shape[0] <= 256 else None
+    d_hn = ops.rows_matmul(dout.contiguous(), wc32.get(sd["text_projection"], "wt"), alpha=S) if dout.shape[0] <= 256 else None
     if d_hn is None:
-        d_hn = ops.gemm(dout.contiguous(), wc32.get(sd["text_projection"], "w"), out_dtype=torch.float32)
+        d_hn = ops.gemm(dout.contiguous() if S == 1.0 else dout * S, wc32.get(sd["text_projection"], "w"), out_dtype=torch.float32)
     d_eot, _, _ = ops.layernorm_bwd(d_hn, s["x_eot"], sd["ln_final.weight"], s["meanf"], s["rstdf"])
     g = torch.zeros((M, Wd), dtype=torch.float32, device=dout.device)
     g.index_copy_(0, s["rows"], d_eot)
@@ -927,7 +941,9 @@ def text_tower_backward(sd, wc, s, dout):
         _, _, _, g_t = ops.layernorm_bwd(d_h, ly["x"], sd[p + "ln_1.weight"], ly["mean1"], ly["rstd1"], dx=g,
                                          accumulate=True, copy_dtype=Tm)
     if s["rows_mode"]:
-        return g                                            # gradient of the row-layout input (ops.prompt_rows_bwd folds it)
+        return g                                            # gradient of the row-layout input, STILL scaled by S (ops.prompt_rows_bwd folds it and 1 / S)
+    if S != 1.0:
+        g.mul_(1.0 / S)
     if not P and L == s["Lfull"]:
         return g.view(C, L, Wd)
     full = torch.zeros((C, s["Lfull"], Wd), dtype=torch.float32, device=dout.device)   # positions past the last EOT: zero gradient

@@ -15,7 +15,7 @@ import torch
 from torch import nn
 
 from .. import blocks as _blk
-from .. import engine, graphs, ops
+from .. import engine, gradscale, graphs, ops
 
 _DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data")
 CONTEXT_LENGTH = 77
@@ -345,6 +345,7 @@ class _TextTowerFn(torch.autograd.Function):
         key = ("text_fwd", tuple(prompts.shape), save, eff, pre, cache.dtype, prio)
         gc = model._graphs
         ctx.model, ctx.graph = model, None
+        ctx.grad_scale = gradscale.current(cache.dtype) if save else 1.0       # the backward's power-of-two scale, fixed now
         if prompts.is_cuda and model.use_hip_graphs and ops.profiler is None and gc.ready(key):
             def build():
                 def fn(pr):
@@ -370,9 +371,10 @@ class _TextTowerFn(torch.autograd.Function):
         if dout.is_cuda:
             dout.record_stream(torch.cuda.current_stream())     # produced on the caller's stream, read on the text stream
         prio = m.chain_priority()
+        S = ctx.grad_scale
         if ctx.graph is None:
             with ops.wave_priority(prio):
-                return None, engine.text_tower_backward(sd, cache, ctx.saved, dout), None
+                return None, engine.text_tower_backward(sd, cache, ctx.saved, dout, grad_scale=S), None
         if ctx.graph.generation != ctx.generation:
             raise RuntimeError("the text tower's captured activations were overwritten by a later forward; set "
                                "model.use_hip_graphs = False to keep several forwards alive before backward")
@@ -381,9 +383,9 @@ class _TextTowerFn(torch.autograd.Function):
         def build():
             def fn(d):
                 with ops.wave_priority(prio):
-                    return (engine.text_tower_backward(sd, cache, saved, d),), None
+                    return (engine.text_tower_backward(sd, cache, saved, d, grad_scale=S),), None
             return graphs.GraphedCall(fn, [dout.contiguous()], pool=fwd.pool())
-        (dp,), _ = m._graphs.get(("text_bwd",) + ctx.key[1:], build)(dout)
+        (dp,), _ = m._graphs.get(("text_bwd",) + ctx.key[1:] + (S,), build)(dout)
         return None, dp.clone(), None
 
 
@@ -418,6 +420,7 @@ class _TextTowerTokensFn(torch.autograd.Function):
         key = ("text_fwd_tok", tuple(tok.shape), save, eff, pre, cache.dtype, prio)
         gc = model._graphs
         ctx.model, ctx.graph, ctx.rows_of, ctx.n_tok = model, None, rows_of, tok.shape[0]
+        ctx.grad_scale = gradscale.current(cache.dtype) if save else 1.0       # the backward's power-of-two scale, fixed now
         if tok.is_cuda and model.use_hip_graphs and ops.profiler is None and gc.ready(key):
             def build():
                 def fn(tk):
@@ -445,10 +448,13 @@ class _TextTowerTokensFn(torch.autograd.Function):
         rows_of, n_tok = ctx.rows_of, ctx.n_tok
 
         prio = m.chain_priority()
+        S = ctx.grad_scale
 
         def run(d, saved):
+            # the scale enters in the first product of the tower's backward and leaves in the kernel that folds the rows onto
+            # the tokens: no launch more than without it
             with ops.wave_priority(prio):
-                return ops.prompt_rows_bwd(engine.text_tower_backward(sd, cache, saved, d), rows_of, n_tok)
+                return ops.prompt_rows_bwd(engine.text_tower_backward(sd, cache, saved, d, grad_scale=S), rows_of, n_tok, scale=1.0 / S)
 
         if ctx.graph is None:
             return None, run(dout.contiguous(), ctx.saved)
@@ -461,7 +467,7 @@ class _TextTowerTokensFn(torch.autograd.Function):
             def fn(d):
                 return (run(d, saved),), None
             return graphs.GraphedCall(fn, [dout.contiguous()], pool=fwd.pool())
-        (dt,), _ = m._graphs.get(("text_bwd_tok",) + ctx.key[1:], build)(dout)
+        (dt,), _ = m._graphs.get(("text_bwd_tok",) + ctx.key[1:] + (S,), build)(dout)
         # learnable_tokens is a leaf whose .grad exists (a view of the Trainer's flat buffer): autograd ADDS dt into it on this
         # stream before anything can replay the graph again -- no copy needed then
         tok_grad = m.prompt_learner.learnable_tokens.grad
@@ -472,13 +478,17 @@ class _MatmulNT(torch.autograd.Function):
     """a [M,K] @ b[N,K]^T with fp32 results.  prec = torch.float32: fp32 operands on the fp32 MFMA (the classification
     heads: projection and logits of a few dozen rows); prec = torch.float16 / torch.bfloat16: 16-bit operands, fp32
     accumulation -- the per-POINT head of part segmentation (32 768 rows x 50 parts) in the performance mode, where the fp32
-    MFMA (1/16 of the 16-bit rate) cost 1.06 ms of a 14 ms step."""
+    MFMA (1/16 of the 16-bit rate) cost 1.06 ms of a 14 ms step.  The 16-bit backward is a gradient-scaled stage of its own
+    (ppt_amd/gradscale.py): dC is multiplied by the power of two S while it is converted, dA leaves through the GEMM's row scale
+    1 / S, dB by one small multiply -- d logits of a mean over 32 768 rows is ~1e-5 per element, a subnormal in half."""
 
     @staticmethod
     def forward(ctx, a, b, prec):
         a, b = a.contiguous().float(), b.contiguous().float()
         ctx.save_for_backward(a, b)
         ctx.prec = prec if (prec in ops.HALF and a.shape[1] % 8 == 0) else torch.float32
+        ctx.grad_scale = gradscale.current(ctx.prec, default_rows=a.shape[0])
+        ctx.inv = gradscale.inv_tensor(ctx.grad_scale, a.device) if ctx.grad_scale != 1.0 else None
         if ctx.prec in ops.HALF:
             return ops.gemm(ops.convert(a, prec), ops.convert(b, prec), out_dtype=torch.float32)
         return ops.gemm(a, b, out_dtype=torch.float32)
@@ -490,12 +500,16 @@ class _MatmulNT(torch.autograd.Function):
         da = db = None
         T = ctx.prec if ctx.prec in ops.HALF else torch.float32
         mult = 8 if T in ops.HALF else 4
+        S = ctx.grad_scale
+        rs = dict(row_scale=ctx.inv, row_scale_rows=dc.shape[0]) if S != 1.0 else {}
         if ctx.needs_input_grad[0]:                      # dA[M,K] = dC[M,N] @ B[N,K]; N padded to the chunk size
             n = dc.shape[1]
             dcp = dc if n % mult == 0 else torch.nn.functional.pad(dc, (0, mult - n % mult))
-            da = ops.gemm(ops.convert(dcp, T), ops.transpose(ops.convert(b, T), pad_to=mult), out_dtype=torch.float32)
+            da = ops.gemm(ops.convert(dcp, T, scale=S), ops.transpose(ops.convert(b, T), pad_to=mult), out_dtype=torch.float32, **rs)
         if ctx.needs_input_grad[1]:                      # dB[N,K] = dC[M,N]^T @ A[M,K]
-            db = ops.gemm_tn_splitk(ops.convert(dc, T), ops.convert(a, T))
+            db = ops.gemm_tn_splitk(ops.convert(dc, T, scale=S), ops.convert(a, T))
+            if S != 1.0:
+                db = db * (1.0 / S)
         return da, db, None
 
 
@@ -786,6 +800,13 @@ class ULIP_WITH_IMAGE(nn.Module):
 
     def forward(self, pc, cls_label=None):
         """ULIP_models.py:260-283 -> logits [B,C] (partseg: [B,N,C])."""
+        # the rows the caller's criterion will average over: fixes the power-of-two scale of every 16-bit backward stage created
+        # by this forward (ppt_amd/gradscale.py) -- a plain `loss.backward()` (main_cls.py:197, main_partseg.py:214) is then
+        # scaled and un-scaled inside the nodes
+        with gradscale.rows(pc.shape[0] * (pc.shape[1] if self.task == 'partseg' else 1)):
+            return self._forward(pc, cls_label)
+
+    def _forward(self, pc, cls_label=None):
         cur = torch.cuda.current_stream()
         side = None
         if self.overlap_text_tower and pc.is_cuda:
@@ -824,6 +845,10 @@ class ULIP_WITH_IMAGE(nn.Module):
         """forward + CrossEntropyLoss(label_smoothing) for the case where nothing on the point side trains (head_type 0):
         same two-stream schedule as forward(), but everything between the towers is one fused, graph-replayed node
         (_HeadLossFn) instead of ~25 autograd-tracked launches.  -> (loss, logits)."""
+        with gradscale.rows(pc.shape[0]):
+            return self._forward_loss(pc, labels, smoothing)
+
+    def _forward_loss(self, pc, labels, smoothing):
         cur = torch.cuda.current_stream()
         side = self.text_stream() if (self.overlap_text_tower and pc.is_cuda) else None
         if side is not None:

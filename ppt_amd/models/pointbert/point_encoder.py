@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 
 from ... import blocks as _blk
-from ... import engine, graphs, ops
+from ... import engine, gradscale, graphs, ops
 from .dvae import Encoder, Group
 
 
@@ -163,6 +163,9 @@ class _PointEncoderFn(torch.autograd.Function):
     def forward(ctx, module, pc, fps_start, dp, tier, names, *params):
         sd, cache, cfg, train = module._live_state(), module._cache(), module._cfg(), module.training
         ctx.module, ctx.tier, ctx.names = module, tier, names
+        # the power-of-two scale of the last block's 16-bit backward, fixed now (ppt_amd/gradscale.py; a bare PointTransformer
+        # under its own criterion: the batch size)
+        ctx.grad_scale = gradscale.current(engine._stage_wc(cache, "last_block").dtype, default_rows=pc.shape[0]) if tier > 0 else 1.0
         # a hipGraph bakes in the device pointers of everything it reads, including the WeightCache's operand copies,
         # which are re-made whenever the optimizer changes a parameter: a section that reads a trainable parameter is
         # never captured.  With an un-frozen last block (head_type >= 1) only the frozen prefix (tokenizer + blocks
@@ -279,7 +282,8 @@ class _PointEncoderFn(torch.autograd.Function):
         if g is not None and g.generation != ctx.prefix_generation:
             raise RuntimeError("the point tower's captured activations were overwritten by a later forward; set "
                                "model.point_encoder.use_hip_graphs = False to keep several forwards alive before backward")
-        grads = engine.point_encoder_backward(m._live_state(), m._cache(), ctx.saved, dfeat.contiguous().float(), ctx.tier)
+        grads = engine.point_encoder_backward(m._live_state(), m._cache(), ctx.saved, dfeat.contiguous().float(), ctx.tier,
+                                              grad_scale=ctx.grad_scale)
         out = []
         for n in ctx.names:
             g = grads[n]

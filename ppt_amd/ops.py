@@ -259,17 +259,19 @@ class wave_priority:
         _lib.lib().ppt_set_wave_priority(self.old)
 
 
-def cross_entropy_rows(logits, labels, smoothing):
+def cross_entropy_rows(logits, labels, smoothing, ignore_index=-100):
     """(loss 0-d, dlogits [R,C], scale 0-d) of nn.CrossEntropyLoss(label_smoothing=smoothing) with mean reduction
-    (ppt_cross_entropy_rows).  Rows whose label lies outside [0, C) are ignored as ATen ignores ignore_index; dlogits is scaled
-    by 1 / R and `scale` = R / counted rows (1.0 when none is ignored) completes it."""
+    (ppt_cross_entropy_rows).  Rows whose label == ignore_index (outside [0, C)) are ignored as ATen ignores them; any other label
+    outside [0, C) makes the loss NaN (ATen: device assert).  dlogits is scaled by 1 / R and `scale` = R / counted rows (1.0 when
+    none is ignored) completes it."""
+    assert not (0 <= ignore_index < logits.shape[1]), "ignore_index inside [0, C) is not covered by ppt_cross_entropy_rows"
     _chk(logits, torch.float32, "logits"); _chk(labels, torch.int64, "labels")
     R, C = logits.shape
     out = torch.empty((2,), dtype=torch.float32, device=logits.device)
     dlogits = torch.empty_like(logits)
     partial = torch.empty((2 * ((R + 127) // 128),), dtype=torch.float32, device=logits.device)
-    _lib.check(_lib.lib().ppt_cross_entropy_rows(_p(logits), _p(labels), float(smoothing), R, C, _p(out), _p(dlogits), _p(partial),
-                                                 _stream()), "ppt_cross_entropy_rows")
+    _lib.check(_lib.lib().ppt_cross_entropy_rows(_p(logits), _p(labels), float(smoothing), R, C, int(ignore_index), _p(out), _p(dlogits),
+                                                 _p(partial), _stream()), "ppt_cross_entropy_rows")
     return out[0], dlogits, out[1]
 
 
@@ -292,8 +294,8 @@ def get_persistent_occupancy():
     return _lib.lib().ppt_get_persistent_occupancy()
 
 
-def rows_matmul(a, w_kn):
-    """out [M,N] = a [M,K] @ w_kn [K,N], fp32, for a few rows (ppt_rows_matmul_f32) -- None when the shape is not covered."""
+def rows_matmul(a, w_kn, alpha=1.0):
+    """out [M,N] = alpha * a [M,K] @ w_kn [K,N], fp32, for a few rows (ppt_rows_matmul_f32) -- None when the shape is not covered."""
     _chk(a, torch.float32, "a"); _chk(w_kn, torch.float32, "w_kn")
     M, K = a.shape
     N = w_kn.shape[1]
@@ -302,7 +304,7 @@ def rows_matmul(a, w_kn):
     out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     if profiler is not None:
         profiler.begin("gemm_f32", 2.0 * M * N * K, "ppt_rows_matmul_f32")
-    _lib.check(_lib.lib().ppt_rows_matmul_f32(_p(a), _p(w_kn), M, K, N, _p(out), _stream()), "ppt_rows_matmul_f32")
+    _lib.check(_lib.lib().ppt_rows_matmul_f32(_p(a), _p(w_kn), M, K, N, float(alpha), _p(out), _stream()), "ppt_rows_matmul_f32")
     if profiler is not None:
         profiler.end()
     return out
@@ -827,13 +829,18 @@ def cls_max_pool(x, want_argmax=False):
     return out, am
 
 
-def convert(src, dst_dtype):
+def convert(src, dst_dtype, scale=1.0):
+    """src in another dtype; scale != 1: convert(src * scale) -- the operand copy of an fp32 activation gradient entering a 16-bit
+    backward stage, multiplied by the stage's power-of-two gradient scale on the way (ppt_convert_scaled)."""
     _chk(src, None, "src")
-    if src.dtype == dst_dtype:
+    if src.dtype == dst_dtype and scale == 1.0:
         return src
     dst = torch.empty(src.shape, dtype=dst_dtype, device=src.device)
-    _lib.check(_lib.lib().ppt_convert(_p(src), dtype_code(src), _p(dst), dtype_code(dst), src.numel(), _stream()),
-               "ppt_convert")
+    if scale == 1.0:
+        _lib.check(_lib.lib().ppt_convert(_p(src), dtype_code(src), _p(dst), dtype_code(dst), src.numel(), _stream()), "ppt_convert")
+    else:
+        _lib.check(_lib.lib().ppt_convert_scaled(_p(src), dtype_code(src), _p(dst), dtype_code(dst), src.numel(), float(scale), _stream()),
+                   "ppt_convert_scaled")
     return dst
 
 
@@ -923,13 +930,30 @@ def gemm_tn_splitk(x_a, x_b, min_blocks=768, max_splits=16):
     return reduce_rows(part.view(S, N1 * N2)).view(N1, N2)
 
 
-def adamw_step(p, g, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+def adamw_step(p, g, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, skipped=None):
     """torch.optim.AdamW's update of ONE tensor in one launch (ppt_adamw_step); p, exp_avg, exp_avg_sq updated in place.
-    grad_scale != 1: g is first multiplied by it IN PLACE (the un-scaling of a loss-scaled backward)."""
+    grad_scale != 1: g is first multiplied by it IN PLACE (the un-scaling of a caller's loss-scaled backward).  An element whose
+    gradient is not finite is skipped and counted in `skipped` (1-element int64 device tensor, or None)."""
     for t, nm in ((p, "p"), (g, "g"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
         _chk(t, torch.float32, nm)
+    if skipped is not None:
+        _chk(skipped, torch.int64, "skipped")
     _lib.check(_lib.lib().ppt_adamw_step(_p(p), _p(g), _p(exp_avg), _p(exp_avg_sq), p.numel(), lr, beta1, beta2, eps, weight_decay,
-                                         int(step), float(grad_scale), _stream()), "ppt_adamw_step")
+                                         int(step), float(grad_scale), _p(skipped), _stream()), "ppt_adamw_step")
+
+
+def adamw_multi(items, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0, skipped=None):
+    """The same update for a list of (p, g, exp_avg, exp_avg_sq, step) in one launch per 64 tensors (ppt_adamw_multi)."""
+    arr = (_lib.AdamwTensor * len(items))()
+    for a, (p, g, m, v, step) in zip(arr, items):
+        for t, nm in ((p, "p"), (g, "g"), (m, "exp_avg"), (v, "exp_avg_sq")):
+            _chk(t, torch.float32, nm)
+        assert g.numel() == p.numel() == m.numel() == v.numel()
+        a.p, a.g, a.exp_avg, a.exp_avg_sq, a.n, a.step = _p(p), _p(g), _p(m), _p(v), p.numel(), int(step)
+    if skipped is not None:
+        _chk(skipped, torch.int64, "skipped")
+    _lib.check(_lib.lib().ppt_adamw_multi(ctypes.cast(arr, ctypes.c_void_p), len(items), lr, beta1, beta2, eps, weight_decay,
+                                          float(grad_scale), _p(skipped), _stream()), "ppt_adamw_multi")
 
 
 def prompt_rows(base, slot, tokens, pos_rows):
@@ -942,10 +966,11 @@ def prompt_rows(base, slot, tokens, pos_rows):
     return out
 
 
-def prompt_rows_bwd(g, rows_of, n_tok):
-    """d tokens [n_tok, W] = sums of the rows of g listed per token in rows_of [n_tok, max_rows] i32 (-1 terminated)."""
+def prompt_rows_bwd(g, rows_of, n_tok, scale=1.0):
+    """d tokens [n_tok, W] = scale * sums of the rows of g listed per token in rows_of [n_tok, max_rows] i32 (-1 terminated)."""
     _chk(g, torch.float32, "g"); _chk(rows_of, torch.int32, "rows_of")
     W = g.shape[1]
     out = torch.empty((n_tok, W), dtype=torch.float32, device=g.device)
-    _lib.check(_lib.lib().ppt_prompt_rows_bwd(_p(g), _p(rows_of), rows_of.shape[1], n_tok, W, _p(out), _stream()), "ppt_prompt_rows_bwd")
+    _lib.check(_lib.lib().ppt_prompt_rows_bwd(_p(g), _p(rows_of), rows_of.shape[1], n_tok, W, float(scale), _p(out), _stream()),
+               "ppt_prompt_rows_bwd")
     return out

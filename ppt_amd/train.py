@@ -182,16 +182,16 @@ class _CrossEntropyRows(torch.autograd.Function):
     """nn.CrossEntropyLoss(label_smoothing) as one node: the forward pass over the logits also forms d loss / d logits."""
 
     @staticmethod
-    def forward(ctx, logits, labels, smoothing):
+    def forward(ctx, logits, labels, smoothing, ignore_index=-100):
         from . import ops
-        loss, dlogits, scale = ops.cross_entropy_rows(logits, labels, smoothing)
+        loss, dlogits, scale = ops.cross_entropy_rows(logits, labels, smoothing, ignore_index)
         ctx.save_for_backward(dlogits, scale)
         return loss
 
     @staticmethod
     def backward(ctx, dloss):
         dlogits, scale = ctx.saved_tensors
-        return dlogits * (dloss * scale), None, None
+        return dlogits * (dloss * scale), None, None, None
 
 
 class Trainer:
@@ -210,18 +210,14 @@ class Trainer:
         # multi-tensor kernels of the foreach implementation, while few tensors train: every kernel of the prompt chain costs a
         # dispatch round trip.  The torch optimizer object stays the owner of hyper-parameters and state (state_dict()).
         self.fused_adamw = os.environ.get("PPT_FUSED_ADAMW", "1") != "0"
-        # Loss scaling for the performance mode's fp16 operand stages (text tower, PointBERT tokenizer + blocks, part-seg decoder:
-        # engine.*_F16): their backward carries activation gradients in IEEE half, which keeps 11 bits only down to 6.1e-5.  The
-        # criterion is a MEAN over the rows of the batch, so the gradients shrink with the batch (1 / (B x points) per logit in
-        # part segmentation) and would slide into the subnormals: measured (tools/f16_grad_range.py), the error of the golden
-        # step's gradients is flat while the seed gradient is >= 1 / 4 ... 1 / 512 per row and grows 4x per 8x below that,
-        # with no overflow up to 32 768x above.  "auto": backward is seeded with S = the number of rows in the mean rounded down
-        # to a power of two (i.e. the towers see the gradient of ~the SUM over rows: batch-size invariant, mid-plateau) and the
-        # gradients are multiplied by 1 / S -- exact -- before the optimizer reads them (inside ppt_adamw_step, or one foreach
-        # multiply), so .grad, the all-reduce and AdamW see what the reference's would.  A number fixes S; None / 1 turns it
-        # off.  Not applied in the fp32 parity mode.  `step(check_finite=True)` raises on a non-finite loss as main_cls.py does.
-        self.loss_scale = os.environ.get("PPT_LOSS_SCALE", "auto")
-        self._seeds = {}
+        # Gradient scaling for the performance mode's fp16 backward stages is NOT done here (rounds 2-3 seeded backward() with a
+        # loss scale and un-scaled inside the optimizer -- which an unchanged main_cls.py / main_partseg.py loop never got): every
+        # autograd node that carries gradients in half scales what it receives and un-scales what it hands out itself
+        # (ppt_amd/gradscale.py), so `loss.backward()` below is the reference's plain call and .grad, the all-reduce and AdamW see
+        # true fp32 gradients on every rank whatever the local batch size.  What remains here is the defence: both AdamW kernels
+        # skip an element whose gradient is not finite and count it (`nonfinite_grad_elements()`); `step(check_finite=True)`
+        # raises on a non-finite loss as main_cls.py:205-207 does, and on a non-zero count.
+        self._skipped = None
         # logit_scale is frozen in every PPT configuration (ULIP_models.py:487-507) and its value lies inside the clamp range:
         # main_cls.py:213's per-step clamp is then idempotent -- applied once here, and per step only if it ever trains
         if hasattr(model, "logit_scale"):
@@ -340,17 +336,13 @@ class Trainer:
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
             from . import autograd as _ag
             _ag.STATIC_GRADS_OK = self.sync.lazy                    # .grad dropped before every backward, read before the next replay
-            S = self._loss_scale_for(label, loss)
             try:
-                if S == 1.0:
-                    loss.backward()                                 # (retain_graph only served Q2)
-                else:
-                    loss.backward(gradient=self._seed(S, loss))
+                loss.backward()                                     # main_cls.py:197 (retain_graph only served Q2)
             finally:
                 _ag.STATIC_GRADS_OK = False
             if self.distributed:
                 self.sync.all_reduce()
-            self._optimizer_step(1.0 / S)
+            self._optimizer_step()
             if model.logit_scale.requires_grad:
                 model.logit_scale.data.clamp_(0, 4.6052)            # main_cls.py:213 (frozen: clamped once in __init__)
         if side is not None and not self._point_side_frozen:
@@ -365,43 +357,42 @@ class Trainer:
                 pe.decoder_gate = side.record_event()
             else:
                 main.wait_stream(side)                              # the point tower reads updated parameters
-        if check_finite and not math.isfinite(loss.item()):         # main_cls.py:205-207
-            raise FloatingPointError(f"Loss is {loss.item()}, stopping training")
+        if check_finite:
+            if not math.isfinite(loss.item()):                      # main_cls.py:205-207
+                raise FloatingPointError(f"Loss is {loss.item()}, stopping training")
+            bad = self.nonfinite_grad_elements()
+            if bad:
+                raise FloatingPointError(f"{bad} gradient elements were not finite (skipped by the optimizer), stopping training")
         self.it += 1
         return loss, pred
 
     def _loss(self, logits, labels):
         """self.criterion (main_cls.py:52: CrossEntropyLoss with label smoothing, mean reduction); on a GPU with <= 96 classes the
         loss and its gradient come from one pass over the logits (ops.cross_entropy_rows) instead of ~10 ATen kernels."""
-        # (ppt_cross_entropy_rows treats a label outside [0, C) -- nn.CrossEntropyLoss's ignore_index = -100 -- as an ignored row:
-        # zero loss and gradient, left out of the mean, as ATen does)
+        # (ppt_cross_entropy_rows treats label == ignore_index -- nn.CrossEntropyLoss's default -100 -- as an ignored row: zero loss
+        # and gradient, left out of the mean, as ATen does; any OTHER label outside [0, C) makes the loss NaN where ATen raises a
+        # device assert: step(check_finite=True) then stops as main_cls.py:205-207 does)
         ign = self.criterion.ignore_index
         if logits.is_cuda and logits.dtype == torch.float32 and logits.shape[1] <= 96 and labels.dtype == torch.int64 \
                 and self.criterion.weight is None and self.criterion.reduction == 'mean' and not (0 <= ign < logits.shape[1]):
-            return _CrossEntropyRows.apply(logits.contiguous(), labels.contiguous(), float(self.criterion.label_smoothing))
+            return _CrossEntropyRows.apply(logits.contiguous(), labels.contiguous(), float(self.criterion.label_smoothing), int(ign))
         return self.criterion(logits, labels)
 
-    def _loss_scale_for(self, label, loss):
-        """The factor backward is seeded with (see __init__): a power of two, 1.0 = no scaling."""
-        ls = self.loss_scale
-        if ls in (None, "", "0", "1", "none", "off") or not loss.is_cuda or getattr(self.model, "precision", None) != torch.bfloat16:
-            return 1.0
-        if ls == "auto":
-            return float(2 ** max(0, int(label.numel()).bit_length() - 1))
-        return float(ls)
-
-    def _seed(self, S, loss):
-        key = (S, loss.device, loss.dtype)
-        if key not in self._seeds:
-            self._seeds[key] = torch.full((), S, dtype=loss.dtype, device=loss.device)
-        return self._seeds[key]
+    def nonfinite_grad_elements(self):
+        """How many gradient elements the AdamW kernels have skipped so far because they were not finite (one host read; the
+        text stream's queued work is waited for)."""
+        if self._skipped is None:
+            return 0
+        return int(self._skipped.item())
 
     def _optimizer_step(self, inv_scale=1.0):
-        """AdamW over the tensors that got a gradient; inv_scale: 1 / the loss scale of this backward, folded in first."""
+        """AdamW over the tensors that got a gradient: ONE launch (ppt_adamw_step for a single tensor, ppt_adamw_multi for up to
+        64 per launch: torch.optim.AdamW's arithmetic, state kept in the torch optimizer) instead of the ~10 multi-tensor kernels
+        of the foreach implementation.  inv_scale: for callers that scaled their loss themselves (folded in first)."""
         opt = self.optimizer
         params = [(g, p) for g in opt.param_groups for p in g['params'] if p.grad is not None]
-        if not (self.fused_adamw and params and len(params) <= 8 and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
-                                                                        and p.grad.is_contiguous() for _, p in params)
+        if not (self.fused_adamw and params and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
+                                                    and p.grad.is_contiguous() and p.grad.dtype == torch.float32 for _, p in params)
                 and not any(g.get('amsgrad') or g.get('maximize') for g, _ in params)):
             if inv_scale != 1.0 and params:
                 with torch.no_grad():
@@ -409,8 +400,11 @@ class Trainer:
             opt.step()
             return
         from . import ops
+        if self._skipped is None:
+            self._skipped = torch.zeros((1,), dtype=torch.int64, device=params[0][1].device)
         prio = self.model.chain_priority() if hasattr(self.model, "chain_priority") else 0
         with torch.no_grad(), ops.wave_priority(prio):
+            by_group = {}
             for g, p in params:
                 st = opt.state[p]
                 if not st:                                   # the layout torch.optim.AdamW._init_group creates
@@ -418,9 +412,16 @@ class Trainer:
                     st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st['step'] += 1
+                by_group.setdefault(id(g), (g, []))[1].append((p.data, p.grad, st['exp_avg'], st['exp_avg_sq'], int(st['step'].item())))
+            for g, items in by_group.values():
                 b1, b2 = g['betas']
-                ops.adamw_step(p.data, p.grad, st['exp_avg'], st['exp_avg_sq'], float(g['lr']), float(b1), float(b2), float(g['eps']),
-                               float(g['weight_decay']), int(st['step'].item()), grad_scale=inv_scale)
+                hyper = (float(g['lr']), float(b1), float(b2), float(g['eps']), float(g['weight_decay']))
+                if len(items) == 1:
+                    p_, g_, m_, v_, step = items[0]
+                    ops.adamw_step(p_, g_, m_, v_, *hyper, step, grad_scale=inv_scale, skipped=self._skipped)
+                else:
+                    ops.adamw_multi(items, *hyper, grad_scale=inv_scale, skipped=self._skipped)
+            for _, p in params:
                 # the kernel wrote through a raw pointer: tell autograd's version counter, as torch.optim.AdamW's in-place ops
                 # would.  Two caches key on it -- ULIP_WITH_IMAGE._te_cache (validate()'s text features) and
                 # engine.WeightCache (the bf16 / transposed operand copies of a trained last-block weight) -- and would otherwise

@@ -1060,27 +1060,36 @@ def test_cross_entropy_rows_matches_torch(ops, R, C, eps):
     assert (dl - gref).abs().max().item() < 2e-6 / R * 10 + 1e-7
 
 
-@pytest.mark.parametrize("R,C,eps", [(700, 50, 0.2), (64, 15, 0.0)])
-def test_cross_entropy_rows_ignores_out_of_range_labels(ops, R, C, eps):
-    """a label of -100 (nn.CrossEntropyLoss's ignore_index) or >= C is an ignored row, as in ATen -- no loss,
-    zero gradient, left out of the mean -- instead of an out-of-range LDS read."""
+@pytest.mark.parametrize("R,C,eps,ign", [(700, 50, 0.2, -100), (64, 15, 0.0, -100), (300, 50, 0.2, 255)])
+def test_cross_entropy_rows_ignores_the_ignore_index_only(ops, R, C, eps, ign):
+    """A row whose label == ignore_index (nn.CrossEntropyLoss: -100 by default; main_partseg-style 255 too) is an ignored row, as
+    in ATen -- no loss, zero gradient, left out of the mean.  ADVICE r3 (low): any OTHER label outside [0, C) is a corrupt label --
+    ATen raises a device assert -- and must not be dropped silently: the loss comes back NaN."""
     g = torch.Generator().manual_seed(R)
     logits = (torch.randn(R, C, generator=g) * 4).cuda().requires_grad_(True)
     labels = torch.randint(0, C, (R,), generator=g)
-    labels[::7] = -100
+    labels[::7] = ign
     labels = labels.cuda()
-    ref = torch.nn.CrossEntropyLoss(label_smoothing=eps)(logits.double(), labels)
+    ref = torch.nn.CrossEntropyLoss(label_smoothing=eps, ignore_index=ign)(logits.double(), labels)
     (gref,) = torch.autograd.grad(ref, logits)
-    loss, dl, scale = ops.cross_entropy_rows(logits.detach(), labels, eps)
-    n_valid = int((labels >= 0).sum())
+    loss, dl, scale = ops.cross_entropy_rows(logits.detach(), labels, eps, ign)
+    n_valid = int((labels != ign).sum())
     assert abs(scale.item() - R / n_valid) < 1e-6 * R / n_valid
     assert abs(loss.item() - ref.item()) < 2e-6 * max(1.0, abs(ref.item()))
     assert (dl * scale - gref).abs().max().item() < 2e-5 / n_valid + 1e-7
     assert dl[::7].abs().max().item() == 0.0
     from ppt_amd.train import _CrossEntropyRows
     lg = logits.detach().clone().requires_grad_(True)
-    _CrossEntropyRows.apply(lg, labels, eps).backward()
+    _CrossEntropyRows.apply(lg, labels, eps, ign).backward()
     assert (lg.grad - gref).abs().max().item() < 2e-5 / n_valid + 1e-7
+    for corrupt in (C, C + 7, -1):
+        if corrupt == ign:
+            continue
+        bad = labels.clone()
+        bad[5] = corrupt
+        loss_b, dl_b, _ = ops.cross_entropy_rows(logits.detach(), bad, eps, ign)
+        assert torch.isnan(loss_b).item(), corrupt
+        assert torch.isfinite(dl_b).all() and dl_b[5].abs().max().item() == 0.0
 
 
 def test_wave_priority_changes_no_result(ops):
@@ -1131,8 +1140,8 @@ def test_adamw_step_matches_torch(ops):
 
 
 def test_adamw_step_unscales_a_loss_scaled_gradient_in_place(ops):
-    """grad_scale = 1 / S (train.Trainer's loss scaling): the update is the one of the un-scaled gradient, bit for bit (S is a
-    power of two), and g is left holding that gradient."""
+    """grad_scale = 1 / S (a caller that scaled its loss): the update is the one of the un-scaled gradient, bit for bit (S is a
+    power of two), and g is left holding that gradient.  A non-finite gradient element is skipped AND counted."""
     g = torch.Generator().manual_seed(1)
     p0 = torch.randn(40, 512, generator=g) * 0.02
     grad = torch.randn(40, 512, generator=g).cuda() * 1e-3
@@ -1145,15 +1154,85 @@ def test_adamw_step_unscales_a_loss_scaled_gradient_in_place(ops):
         outs.append((p, m, v))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
-    # a non-finite element of a loss-scaled gradient is skipped (parameter and moments untouched, gradient reads 0), the rest updates
-    p, m, v = p0.clone().cuda(), torch.full((40, 512), 0.5).cuda(), torch.full((40, 512), 0.25).cuda()
-    gs = grad * 4096.0
-    gs[3, 7], gs[5, 9], gs[11, 0] = float("inf"), float("nan"), float("-inf")
-    ops.adamw_step(p, gs, m, v, 3e-3, 0.9, 0.98, 1e-8, 0.1, 1, grad_scale=1.0 / 4096.0)
-    bad = torch.zeros(40, 512, dtype=torch.bool); bad[3, 7] = bad[5, 9] = bad[11, 0] = True
-    assert torch.isfinite(p).all() and torch.isfinite(m).all() and torch.isfinite(v).all()
-    assert torch.equal(p.cpu()[bad], p0[bad]) and (m.cpu()[bad] == 0.5).all() and (v.cpu()[bad] == 0.25).all() and (gs.cpu()[bad] == 0).all()
-    assert not torch.equal(p.cpu()[~bad], p0[~bad]) and torch.equal(gs.cpu()[~bad], grad.cpu()[~bad])
+    # a non-finite element is skipped (parameter and moments untouched, gradient reads 0) and counted, the rest updates -- with and
+    # without a caller-side scale
+    for S in (4096.0, 1.0):
+        p, m, v = p0.clone().cuda(), torch.full((40, 512), 0.5).cuda(), torch.full((40, 512), 0.25).cuda()
+        gs = grad * S
+        gs[3, 7], gs[5, 9], gs[11, 0] = float("inf"), float("nan"), float("-inf")
+        skipped = torch.zeros(1, dtype=torch.int64, device="cuda")
+        ops.adamw_step(p, gs, m, v, 3e-3, 0.9, 0.98, 1e-8, 0.1, 1, grad_scale=1.0 / S, skipped=skipped)
+        bad = torch.zeros(40, 512, dtype=torch.bool); bad[3, 7] = bad[5, 9] = bad[11, 0] = True
+        assert skipped.item() == 3
+        assert torch.isfinite(p).all() and torch.isfinite(m).all() and torch.isfinite(v).all()
+        assert torch.equal(p.cpu()[bad], p0[bad]) and (m.cpu()[bad] == 0.5).all() and (v.cpu()[bad] == 0.25).all() and (gs.cpu()[bad] == 0).all()
+        assert not torch.equal(p.cpu()[~bad], p0[~bad]) and torch.equal(gs.cpu()[~bad], grad.cpu()[~bad])
+        ops.adamw_step(p, gs, m, v, 3e-3, 0.9, 0.98, 1e-8, 0.1, 2, grad_scale=1.0, skipped=skipped)      # (now finite everywhere)
+        assert skipped.item() == 3
+
+
+@pytest.mark.parametrize("count", [1, 13, 47, 70])
+def test_adamw_multi_is_the_single_tensor_kernel_per_tensor(ops, count):
+    """ppt_adamw_multi (one launch per 64 tensors, the table as a kernel argument) against ppt_adamw_step tensor by tensor: bit
+    identical parameters and moments for sizes from 1 element to a 1536 x 384 matrix, per-tensor step numbers, and the skip
+    counter; and against torch.optim.AdamW itself for one step."""
+    g = torch.Generator().manual_seed(count)
+    shapes = [(1,), (128,), (384,), (1536, 384), (50, 512), (1023,), (1025,), (384, 387)]
+    ps = [torch.randn(shapes[i % len(shapes)], generator=g) * 0.05 for i in range(count)]
+    gs = [torch.randn(shapes[i % len(shapes)], generator=g) * 10.0 ** ((i % 5) - 3) for i in range(count)]
+    steps = [1 + (i % 3) for i in range(count)]
+    hyper = (3e-3, 0.9, 0.98, 1e-8, 0.1)
+    a = [(p.clone().cuda(), gr.clone().cuda(), torch.full(p.shape, 0.01).cuda(), torch.full(p.shape, 0.02).cuda()) for p, gr in zip(ps, gs)]
+    b = [(p.clone().cuda(), gr.clone().cuda(), torch.full(p.shape, 0.01).cuda(), torch.full(p.shape, 0.02).cuda()) for p, gr in zip(ps, gs)]
+    if count > 1:
+        a[1][1].view(-1)[0] = float("nan"); b[1][1].view(-1)[0] = float("nan")
+        a[-1][1].view(-1)[-1] = float("inf"); b[-1][1].view(-1)[-1] = float("inf")
+    sk_a, sk_b = torch.zeros(1, dtype=torch.int64, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda")
+    for (p, gr, m, v), st in zip(a, steps):
+        ops.adamw_step(p, gr, m, v, *hyper, st, skipped=sk_a)
+    ops.adamw_multi([(p, gr, m, v, st) for (p, gr, m, v), st in zip(b, steps)], *hyper, skipped=sk_b)
+    assert sk_a.item() == sk_b.item() == (2 if count > 1 else 0)
+    for ta, tb in zip(a, b):
+        for x, y in zip(ta, tb):
+            assert torch.equal(x, y)
+    # one step of torch.optim.AdamW on fresh state
+    params = [torch.nn.Parameter(p.clone().cuda()) for p in ps]
+    opt = torch.optim.AdamW(params, lr=3e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.1)
+    items = []
+    for q, gr in zip(params, gs):
+        q.grad = gr.clone().cuda()
+        items.append((q.detach().clone(), gr.clone().cuda(), torch.zeros_like(q), torch.zeros_like(q), 1))
+    opt.step()
+    ops.adamw_multi(items, *hyper)
+    for q, it in zip(params, items):
+        assert (it[0] - q.detach()).abs().max().item() < 2e-7 * max(1.0, q.abs().max().item())
+
+
+def test_scaled_entry_and_exit_kernels_are_exact(ops):
+    """The three places a gradient scale is folded into an existing kernel (ppt_amd/gradscale.py): ppt_convert_scaled,
+    ppt_rows_matmul_f32's alpha, ppt_prompt_rows_bwd's scale.  A power of two commutes with every rounding involved: results are
+    bit-identical to scaling the input (resp. the output) with a separate multiply; the 8-wide conversion path equals the scalar one."""
+    g = torch.Generator().manual_seed(7)
+    x = (torch.randn(4096, 136, generator=g) * 1e-5).cuda()
+    for T in (torch.float16, torch.bfloat16):
+        for S in (1.0, 1024.0, 32768.0):
+            got = ops.convert(x, T, scale=S)
+            assert torch.equal(got, (x * S).to(T)), (T, S)
+            odd = x.view(-1)[1:1 + 4099].contiguous()              # unaligned start, length not a multiple of 8: the scalar path
+            assert torch.equal(ops.convert(odd, T, scale=S), (odd * S).to(T))
+        assert ops.convert(x.to(T), T) is not None
+    a = torch.randn(40, 512, generator=g).cuda() * 1e-3
+    w = torch.randn(512, 512, generator=g).cuda() * 0.05
+    base = ops.rows_matmul(a, w)
+    for S in (64.0, 32768.0):
+        assert torch.equal(ops.rows_matmul(a, w, alpha=S), base * S)
+    gr = torch.randn(817, 512, generator=g).cuda()
+    rows_of = torch.full((32, 40), -1, dtype=torch.int32)
+    for t in range(32):
+        rows_of[t, :20] = torch.arange(20, dtype=torch.int32) * 40 + t
+    rows_of = rows_of.cuda()
+    base = ops.prompt_rows_bwd(gr, rows_of, 32)
+    assert torch.equal(ops.prompt_rows_bwd(gr, rows_of, 32, scale=1.0 / 4096.0), base * (1.0 / 4096.0))
 
 
 @pytest.mark.parametrize("position", ["front", "middle", "end"])

@@ -105,34 +105,39 @@ def test_train_step_matches_oracle_and_golden(head_type, precision, ltol, gtol):
 
 def test_loss_scaling_keeps_fp16_gradients_out_of_the_subnormals():
     """The performance mode's fp16 stages carry activation gradients in IEEE half.  With the criterion's mean over a batch
-    2048x the golden one (emulated: the golden step's loss x 1/2048) the un-scaled backward loses the token gradient to
-    fp16 subnormals; with train.Trainer's loss scale the gradient (as left in .grad: un-scaled again) stays at the golden
-    accuracy.  The default ("auto" = rows of the mean, here 4) is covered by test_train_step_matches_oracle_and_golden."""
-    from ppt_amd.train import Trainer
+    2048x the golden one (emulated: the golden step's loss x 1/2048) an un-scaled backward loses the token gradient to fp16
+    subnormals; with the nodes' own gradient scale (ppt_amd/gradscale.py) the gradient an UNCHANGED caller finds in .grad after a
+    plain `loss.backward()` (main_cls.py:194-198) stays at the golden accuracy.  The default ("auto" = rows of the mean, here 4) is
+    covered by test_train_step_matches_oracle_and_golden."""
+    from ppt_amd import gradscale
     g = np.load(os.path.join(G, "g_step_h3.npz"))
     pc, _ = oracle_inputs()
     shrink = 1.0 / 2048
     errs = {}
-    for scale in (None, 4 * 2048):
-        m, sd = build(3, torch.bfloat16)
-        m.train()
-        m.point_encoder.fps_start = torch.from_numpy(g["fps_start"]).cuda()
-        m.point_encoder.drop_path_factors = torch.from_numpy(g["dp_masks"]).cuda()
-        tr = Trainer(m, lr=3e-3, label_smoothing=0.2, distributed=False)
-        tr.fused_head, tr.loss_scale = False, scale
-        inner = tr._loss
-        tr._loss = lambda a, b: inner(a, b) * shrink
-        tr.step(pc.cuda(), torch.from_numpy(g["labels"]).cuda())
-        torch.cuda.synchronize()
-        live = dict(m.named_parameters())
-        for k in ("prompt_learner.learnable_tokens", "point_encoder.blocks.blocks.11.attn.qkv.weight"):
-            gr = torch.from_numpy(g["grad_" + k] if "grad_" + k in g.files else g["gradsub_" + k])
-            gg = live[k].grad.detach().cpu() / shrink
-            gg = gg if gg.shape == gr.shape else gg.flatten()[::97]
-            errs[(scale, k)] = ((gg - gr).norm() / gr.norm()).item()
+    old = gradscale.POLICY
+    try:
+        for scale in ("off", str(4 * 2048)):
+            gradscale.POLICY = scale
+            m, sd = build(3, torch.bfloat16)
+            m.train()
+            m.point_encoder.fps_start = torch.from_numpy(g["fps_start"]).cuda()
+            m.point_encoder.drop_path_factors = torch.from_numpy(g["dp_masks"]).cuda()
+            criterion = torch.nn.CrossEntropyLoss(label_smoothing=0.2)
+            pred = m(pc.cuda())
+            loss = criterion(pred, torch.from_numpy(g["labels"]).cuda()) * shrink
+            loss.backward()
+            torch.cuda.synchronize()
+            live = dict(m.named_parameters())
+            for k in ("prompt_learner.learnable_tokens", "point_encoder.blocks.blocks.11.attn.qkv.weight"):
+                gr = torch.from_numpy(g["grad_" + k] if "grad_" + k in g.files else g["gradsub_" + k])
+                gg = live[k].grad.detach().cpu() / shrink
+                gg = gg if gg.shape == gr.shape else gg.flatten()[::97]
+                errs[(scale, k)] = ((gg - gr).norm() / gr.norm()).item()
+    finally:
+        gradscale.POLICY = old
     for (scale, k), e in errs.items():
-        print(f"PARITY loss scale {scale} (loss x 1/2048) grad {k} rel-L2: {e:.4g}")
-        if scale is None:
+        print(f"PARITY gradient scale {scale} (loss x 1/2048) grad {k} rel-L2: {e:.4g}")
+        if scale == "off":
             assert e > 0.03, (k, e)            # the failure the scale is there for
         else:
             assert e < 1.5e-2, (k, e)
@@ -788,14 +793,17 @@ def test_partseg_train_step_matches_golden(precision):
             assert rel < (2e-3 if k in top else 6e-2), (k, rel)
             assert abs(live[k].grad.double().norm().item() / ref_n - 1) < 6e-2, k
         elif k in top:
-            _bound(f"partseg bf16 grad {k} rel-L2", rel, 0.09)              # measured: conv1.weight 0.058, tokens 0.002 (bf16: 0.15)
+            _bound(f"partseg bf16 grad {k} rel-L2", rel, 0.07)              # measured: conv1.weight 0.058, tokens 0.002 (bf16: 0.15)
         elif live[k].dim() >= 2:
             # bf16: logits = 100 x a cosine, so a feature error of a few 1e-3 moves a logit by ~1 and the per-point softmax by
             # tens of percent (and flips max-pool arg-maxima): measured rel-L2 0.18 ... 0.38 on the decoder's weight matrices,
             # while their NORMS agree within 1.2 % and the directions within 1 - cos <= 0.074.  All three are bounded.
             # (1-D norm parameters are sums with heavy cancellation and are only pinned in fp32 mode.)
             cos = float(np.dot(sub, ref) / (np.linalg.norm(sub) * np.linalg.norm(ref)))
-            _bound(f"partseg bf16 grad {k} rel-L2", rel, 0.2)               # measured with fp16 operands: <= 0.137 (bf16: 0.38)
+            # measured with fp16 operands: <= 0.137 (bf16: 0.38), bound 0.15.  Not reachable below ~0.1 with ANY 16-bit operand format:
+            # the decoder is ill-conditioned in its input features -- in fp32, 1e-4 relative noise on the backbone's feature taps
+            # already moves these gradients by 5 % (tests/test_fullsize_gpu.py, C5 conditioning leg; tools/partseg_error.py)
+            _bound(f"partseg bf16 grad {k} rel-L2", rel, 0.15)
             _bound(f"partseg bf16 grad {k} |norm ratio - 1|", abs(live[k].grad.double().norm().item() / ref_n - 1), 0.03)
             _bound(f"partseg bf16 grad {k} 1 - cos", 1 - cos, 0.1)
 
@@ -907,6 +915,64 @@ def test_single_rank_rccl_step_is_identical(head_type):
     # the collective and the re-bound buffers must not cost step time (measured < 3 %; the bound is wide because this is a
     # 12-step wall-clock sample in a child process on a shared box: a tight one failed once in a run that took 1.6x as long overall)
     assert res["ms_dist"] < 1.35 * res["ms_plain"] + 0.5, res
+
+
+def test_two_ranks_real_model_on_one_gpu(tmp_path):
+    """SURVEY §8(e) with the REAL model on N = 2 ranks (reference main_cls.py:39,47-49,74-76): two processes on
+    cuda:0 run ULIP_PointBERT head_type 3 under train.Trainer(distributed=True) on the halves of a B = 8 batch -- seeded `seed +
+    rank`, with DIFFERENT initial prompt tokens / last block per rank.  Checked against single-process runs (child processes:
+    tests/dist_two_ranks.py):
+      * the DDP-constructor broadcast makes rank 1's trainable set equal rank 0's (it differed before);
+      * the all-reduced gradient of step 1 is the mean of the two halves' single-process gradients;
+      * after 3 steps every trained parameter is bit-identical on both ranks;
+      * after finish() both ranks hold rank 0's BatchNorm running statistics = those of a single-process run on rank 0's half."""
+    import subprocess
+    import sys
+    script = os.path.join(ROOT, "tests", "dist_two_ranks.py")
+    out = str(tmp_path)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29655", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, script, "rank", str(r), out], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    logs = []
+    for p_ in procs:
+        try:
+            o, _ = p_.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o)
+    assert all(p_.returncode == 0 for p_ in procs), "\n".join(l[-3000:] for l in logs)
+    r = subprocess.run([sys.executable, script, "ref", out], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    r0, r1 = (torch.load(os.path.join(out, f"rank{k}.pt")) for k in range(2))
+    ref = torch.load(os.path.join(out, "ref.pt"))
+    names = sorted(r0["params"])
+    assert len(names) == 12 and r0["init_broadcasts"] >= 1
+    # the ranks started apart, the constructor's broadcast brought rank 1 to rank 0
+    assert any(not torch.equal(r0["before"][n], r1["before"][n]) for n in names)
+    for n in names:
+        assert torch.equal(r1["after_bcast"][n], r0["before"][n]) and torch.equal(r0["after_bcast"][n], r0["before"][n]), n
+    # step 1: the reduced gradient is the mean of the two single-process gradients
+    worst, exact = 0.0, 0
+    for n in names:
+        mean = (ref["grads"][0][n] + ref["grads"][1][n]) / 2
+        assert torch.equal(r0["grads_step1"][n], r1["grads_step1"][n]), n
+        e = ((r0["grads_step1"][n] - mean).norm() / mean.norm()).item()
+        worst, exact = max(worst, e), exact + int(torch.equal(r0["grads_step1"][n], mean))
+        assert e < 1e-5, (n, e)
+    print(f"two ranks ({r0['backend']}): reduced gradient vs mean of single-process gradients: worst rel-L2 {worst:.3g}, "
+          f"{exact}/{len(names)} tensors bit-identical")
+    # 3 steps: the same parameters on both ranks, bit for bit; they moved; nothing was skipped
+    for n in names:
+        assert torch.equal(r0["params"][n], r1["params"][n]), n
+    assert any(not torch.equal(r0["params"][n], r0["before"][n]) for n in names)
+    assert r0["skipped"] == 0 and r1["skipped"] == 0 and np.isfinite(r0["losses"]).all() and np.isfinite(r1["losses"]).all()
+    assert r0["losses"] != r1["losses"]                               # different halves
+    # BatchNorm running statistics: rank 0's, everywhere, = a single-process run over rank 0's inputs
+    for k in r0["bn"]:
+        assert torch.equal(r0["bn"][k], r1["bn"][k]), k
+        assert torch.equal(r0["bn"][k], ref["bn_half0"][k]), k
 
 
 def test_rowgemm_tower_matches_the_tile_gemm_tower():

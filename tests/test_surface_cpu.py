@@ -318,26 +318,59 @@ def test_top_level_load_state_dict_resets_the_point_encoders_caches():
     assert pe._wc is None and pe._sd is None and not pe._graphs.entries and not m._graphs.entries
 
 
-def test_loss_scale_rule():
-    """train.Trainer's loss scale: "auto" = the number of rows the criterion averages over, rounded down to a
-    power of two, only in the performance mode on a GPU; a number fixes it; None / "0" / "1" turn it off."""
-    from types import SimpleNamespace
+def test_gradient_scale_rule():
+    """ppt_amd/gradscale.py: a 16-bit backward stage's scale is fixed at forward time -- "auto" = the number of rows the caller's
+    criterion averages over (announced by the model's forward through `rows`), rounded down to a power of two; fp32 stages are
+    never scaled; a number fixes it; "off" / "0" / "1" turn it off; outside any `rows` context a node falls back to its own rows."""
     import torch
-    from ppt_amd.train import Trainer
-    tr = Trainer.__new__(Trainer)
-    tr.model = SimpleNamespace(precision=torch.bfloat16)
-    gpu_loss, cpu_loss = SimpleNamespace(is_cuda=True), SimpleNamespace(is_cuda=False)
-    tr.loss_scale = "auto"
-    assert tr._loss_scale_for(torch.zeros(32, dtype=torch.long), gpu_loss) == 32.0
-    assert tr._loss_scale_for(torch.zeros(48, dtype=torch.long), gpu_loss) == 32.0
-    assert tr._loss_scale_for(torch.zeros(16, 2048, dtype=torch.long), gpu_loss) == 32768.0
-    assert tr._loss_scale_for(torch.zeros(1, dtype=torch.long), gpu_loss) == 1.0
-    assert tr._loss_scale_for(torch.zeros(32, dtype=torch.long), cpu_loss) == 1.0
-    tr.model.precision = torch.float32                        # parity mode: never scaled
-    assert tr._loss_scale_for(torch.zeros(32, dtype=torch.long), gpu_loss) == 1.0
-    tr.model.precision = torch.bfloat16
-    for off in (None, "0", "1", "off"):
-        tr.loss_scale = off
-        assert tr._loss_scale_for(torch.zeros(32, dtype=torch.long), gpu_loss) == 1.0
-    tr.loss_scale = 4096
-    assert tr._loss_scale_for(torch.zeros(32, dtype=torch.long), gpu_loss) == 4096.0
+    from ppt_amd import gradscale as gs
+    old = gs.POLICY
+    try:
+        gs.POLICY = "auto"
+        with gs.rows(32):
+            assert gs.current(torch.float16) == 32.0 and gs.current(torch.bfloat16) == 32.0
+            assert gs.current(torch.float32) == 1.0                   # parity mode: never scaled
+            with gs.rows(48):
+                assert gs.current(torch.float16) == 32.0
+            assert gs.current(torch.float16) == 32.0
+        with gs.rows(16 * 2048):
+            assert gs.current(torch.float16) == 32768.0
+        with gs.rows(1):
+            assert gs.current(torch.float16) == 1.0
+        assert gs.current(torch.float16) == 1.0                       # no context, no default
+        assert gs.current(torch.float16, default_rows=4096) == 4096.0
+        for off in ("0", "1", "off", "none", ""):
+            gs.POLICY = off
+            with gs.rows(32):
+                assert gs.current(torch.float16) == 1.0
+        gs.POLICY = "4096"
+        with gs.rows(32):
+            assert gs.current(torch.float16) == 4096.0 and gs.current(torch.float32) == 1.0
+    finally:
+        gs.POLICY = old
+
+
+def test_scaled_backward_wrapper_is_exact():
+    """gradscale.scaled_backward: incoming gradients x S, outgoing x 1 / S -- the caller sees what the raw backward would have
+    produced for a linear backward (CPU: the wrapper itself is plain torch)."""
+    import torch
+    from ppt_amd import gradscale as gs
+
+    class Ctx:
+        grad_scale = 64.0
+
+    seen = {}
+
+    def raw(ctx, d):
+        seen["in"] = d.clone()
+        return d * 3.0, None, d.sum()
+
+    wrapped = gs.scaled_backward(raw)
+    d = torch.randn(5, 7)
+    a, b, c = wrapped(Ctx(), d)
+    assert torch.equal(seen["in"], d * 64.0) and b is None
+    assert torch.equal(a, d * 3.0) and torch.allclose(c, d.sum(), rtol=1e-6)
+    assert wrapped.raw is raw
+    Ctx.grad_scale = 1.0
+    a2, _, _ = wrapped(Ctx(), d)
+    assert torch.equal(a2, d * 3.0) and torch.equal(seen["in"], d)
