@@ -45,7 +45,9 @@ const char *ppt_strerror(int code);
  * 3: PPT_F16 (dtype arguments / struct fields), ppt_cross_entropy_rows (ignored labels, loss[2]), ppt_adamw_step (grad_scale),
  *    ppt_bn_rows_bwd_apply (half_dtype), ppt_*_half entry points.
  * 4: gradient scaling local to the 16-bit backward stages -- ppt_convert_scaled (new), ppt_rows_matmul_f32 (alpha),
- *    ppt_prompt_rows_bwd (scale); ppt_adamw_step (skipped counter), ppt_adamw_multi (new); ppt_cross_entropy_rows (ignore_index). */
+ *    ppt_prompt_rows_bwd (scale); ppt_adamw_step (skipped counter), ppt_adamw_multi (new); ppt_cross_entropy_rows (ignore_index);
+ *    ppt_mini_pointnet_conv34_half + ppt_mpn34_retile + ppt_scale_rows_convert (new), ppt_mini_pointnet_conv3_half (y may be
+ *    NULL: statistics only). */
 int ppt_abi_version(void);
 
 /* ---- H1: farthest point sampling ---------------------------------------------------------
@@ -384,6 +386,15 @@ int ppt_mini_pointnet_conv4_bf16(const void *A, int64_t M, int K, const float *a
 int ppt_mini_pointnet_conv12_half(const float *pts, int64_t M, const float *w1, const float *b1, const float *a_scale,
                                   const float *a_shift, int C1, const void *W2, const float *bias2, int N, void *y2, void *gmax,
                                   int dtype, void *stream);
+/* ---- conv3 + BatchNorm + ReLU + conv4 + max as ONE kernel (csrc/mpn34.hip; SURVEY 8(f) N1, dvae.py:194-199, 211-214) ---------
+ * tok[g, :] = max over the 32 rows m of group g of  W4 . relu(W3s . y2[m, :] + gs[g, :]) + bias4.   y2 [M,256] 16-bit; W3s [512,256]
+ * 16-bit = the local half of the conv3 weight with the folded BatchNorm scale multiplied in (scale[n] * W3[n, 256:512]); gs
+ * [M/32, 512] f32 = scale * (global half of conv3 per group, bias included) + shift; W4_tiled = ppt_mpn34_retile(W4 [256,512]);
+ * tok [M/32, 256] 16-bit.  M % 32 == 0.  The [M,512] intermediate never reaches HBM.
+ * ppt_mini_pointnet_conv3_half with y == NULL (part_sum / part_m2 given) is the statistics pass of the training step in front of it. */
+int ppt_mpn34_retile(const void *W4, void *W4_tiled, void *stream);
+int ppt_mini_pointnet_conv34_half(const void *y2, int64_t M, const void *W3s, const float *gs, const void *W4_tiled,
+                                  const float *bias4, void *tok, int dtype, void *stream);
 int ppt_mini_pointnet_conv3_half(const void *A, int64_t M, int K, const void *W, const float *gterm, int N, void *y, float *part_sum,
                                  float *part_m2, int dtype, void *stream);
 int ppt_mini_pointnet_conv4_half(const void *A, int64_t M, int K, const float *a_scale, const float *a_shift, const void *W,
@@ -525,6 +536,11 @@ int ppt_convert(const void *src, int src_dtype, void *dst, int dst_dtype, int64_
 /* dst = convert(src * scale), scale > 0: the operand copy of an fp32 activation gradient at the entry of a 16-bit backward
  * stage, multiplied by the stage's power-of-two gradient scale on the way (exact; ppt_amd/gradscale.py). */
 int ppt_convert_scaled(const void *src, int src_dtype, void *dst, int dst_dtype, int64_t n, float scale, void *stream);
+/* out[n][k] = convert(scale[n] * W[n][k]) for an [N, K] window of a row-major f32 matrix (row stride ldw elements; K % 4 == 0, ldw %
+ * 4 == 0, 16-byte aligned), out [N, K] contiguous in out_dtype; bs (optional, [N] f32) = scale * b + shift (b / shift may be NULL).
+ * A folded BatchNorm multiplied into the weight rows of the conv in front of it (csrc/mpn34.hip's W3s / gs). */
+int ppt_scale_rows_convert(const float *W, int64_t ldw, int N, int K, const float *scale, void *out, int out_dtype, const float *b,
+                           const float *shift, float *bs, void *stream);
 /* src [rows, cols] contiguous -> dst [cols, rows] with row stride ld_dst >= rows (padding untouched) */
 int ppt_transpose(const void *src, int src_dtype, void *dst, int dst_dtype, int rows, int cols,
                   int64_t ld_dst, void *stream);

@@ -141,6 +141,8 @@ _SIGNATURES = {
                                               c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "ppt_mini_pointnet_conv3_half": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                              c_int, c_void_p]),
+    "ppt_mpn34_retile": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "ppt_mini_pointnet_conv34_half": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ppt_mini_pointnet_conv4_half": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                              c_int, c_void_p]),
     "ppt_conv12_stats_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
@@ -163,6 +165,7 @@ _SIGNATURES = {
     "ppt_prompt_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ppt_prompt_rows_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "ppt_convert": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
+    "ppt_scale_rows_convert": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ppt_convert_scaled": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_float, c_void_p]),
     "ppt_transpose": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_void_p]),
     "ppt_reduce_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),

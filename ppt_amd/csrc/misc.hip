@@ -72,6 +72,31 @@ __global__ __launch_bounds__(256) void convert8_kernel(const float *__restrict__
     }
 }
 
+// out[n][k] = T(scale[n] * W[n][k]) over an [N, K] window of a row-major f32 matrix (row stride ldw); workgroup 0 also folds a bias:
+// bs[n] = scale[n] * b[n] + shift[n].  The folded BatchNorm of a conv's OUTPUT multiplied into that conv's weight rows
+// (engine.mini_pointnet -> csrc/mpn34.hip); one thread per 4 consecutive k.
+template <typename TD>
+__global__ __launch_bounds__(256) void scale_rows_convert_kernel(const float *__restrict__ W, int64_t ldw, int N, int K,
+                                                                 const float *__restrict__ scale, TD *__restrict__ out,
+                                                                 const float *__restrict__ b, const float *__restrict__ shift,
+                                                                 float *__restrict__ bs)
+{
+    const int k4 = K >> 2;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < (int64_t)N * k4) {
+        const int n = (int)(i / k4), k = 4 * (int)(i - (int64_t)n * k4);
+        const float sc = scale[n];
+        const float4 v = *reinterpret_cast<const float4 *>(W + (int64_t)n * ldw + k);
+        if constexpr (sizeof(TD) == 2) {
+            *reinterpret_cast<uint2 *>(out + (int64_t)n * K + k) = make_uint2(h16<TD>::pack2(v.x * sc, v.y * sc), h16<TD>::pack2(v.z * sc, v.w * sc));
+        } else {
+            *reinterpret_cast<float4 *>(out + (int64_t)n * K + k) = make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc);
+        }
+    }
+    if (bs && blockIdx.x == 0)
+        for (int n = threadIdx.x; n < N; n += 256) bs[n] = scale[n] * (b ? b[n] : 0.f) + (shift ? shift[n] : 0.f);
+}
+
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void transpose_kernel(const TS *__restrict__ s, TD *__restrict__ d, int rows, int cols,
                                                         int64_t ldd)
@@ -252,6 +277,24 @@ extern "C" int ppt_cls_max_pool(const void *x, int x_dtype, int B, int T, int D,
         hipLaunchKernelGGL(cls_max_pool_kernel<bf16_t>, dim3((D + 63) / 64, B), dim3(CMP_W * 64), 0, ppt_stream(stream), (const bf16_t *)x, T, D, out, argmax);
     else if (x_dtype == PPT_F16)
         hipLaunchKernelGGL(cls_max_pool_kernel<f16_t>, dim3((D + 63) / 64, B), dim3(CMP_W * 64), 0, ppt_stream(stream), (const f16_t *)x, T, D, out, argmax);
+    else
+        return PPT_EINVAL;
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
+extern "C" int ppt_scale_rows_convert(const float *W, int64_t ldw, int N, int K, const float *scale, void *out, int out_dtype,
+                                      const float *b, const float *shift, float *bs, void *stream)
+{
+    if (!W || !scale || !out || N <= 0 || K <= 0 || (K & 3) || ldw < K || (ldw & 3)) return PPT_EINVAL;
+    if ((((uintptr_t)W) | ((uintptr_t)out)) & 15) return PPT_EINVAL;
+    const unsigned grid = (unsigned)(((int64_t)N * (K / 4) + 255) / 256);
+    if (out_dtype == PPT_BF16)
+        hipLaunchKernelGGL(scale_rows_convert_kernel<bf16_t>, dim3(grid), dim3(256), 0, ppt_stream(stream), W, ldw, N, K, scale, (bf16_t *)out, b, shift, bs);
+    else if (out_dtype == PPT_F16)
+        hipLaunchKernelGGL(scale_rows_convert_kernel<f16_t>, dim3(grid), dim3(256), 0, ppt_stream(stream), W, ldw, N, K, scale, (f16_t *)out, b, shift, bs);
+    else if (out_dtype == PPT_F32)
+        hipLaunchKernelGGL(scale_rows_convert_kernel<float>, dim3(grid), dim3(256), 0, ppt_stream(stream), W, ldw, N, K, scale, (float *)out, b, shift, bs);
     else
         return PPT_EINVAL;
     PPT_CHECK_LAUNCH();

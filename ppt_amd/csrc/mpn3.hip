@@ -7,6 +7,8 @@
 // every wave reads its A fragments from there, adds the group term, forms the chunk statistics in registers and sends its
 // 32 x 64 bf16 block out through a wave-private LDS transpose as 128-byte row pieces.  Same k order as the generic path:
 // y3 is bit-identical.
+// Round 4: y == NULL -- the statistics pass alone (STORE = false): the BatchNorm partials of y3 without y3 itself, for the
+// training step whose second pass is the fused conv3 + BN + ReLU + conv4 + max kernel (csrc/mpn34.hip).
 #include "ppt_common.h"
 #include <stdlib.h>
 
@@ -17,7 +19,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 constexpr int M3_K = 256, M3_N = 512, M3_KS = M3_K / 16, M3_PITCH = 2 * M3_K + 16, M3_BUF = 32 * M3_PITCH;
 constexpr int M3_TP = 64 * 2 + 16, M3_TR = 32 * M3_TP;             // a wave's 32 x 64 bf16 transpose tile
 
-template <typename F, bool STATS>
+template <typename F, bool STATS, bool STORE>
 __global__ __launch_bounds__(512, 2) void mpn3_kernel(const bf16_t *__restrict__ A, int n_tiles, const bf16_t *__restrict__ W,
                                                        const float *__restrict__ gterm, bf16_t *__restrict__ y,
                                                        float *__restrict__ part_sum, float *__restrict__ part_m2)
@@ -86,6 +88,7 @@ __global__ __launch_bounds__(512, 2) void mpn3_kernel(const bf16_t *__restrict__
                     part_m2[(size_t)t * M3_N + n] = q;
                 }
             }
+            if constexpr (STORE)
 #pragma unroll
             for (int q2 = 0; q2 < 8; ++q2) {                        // neighbour lanes trade values: 4-byte LDS writes (mpn1.hip)
                 const int e0 = 2 * q2, e1 = 2 * q2 + 1;
@@ -97,14 +100,16 @@ __global__ __launch_bounds__(512, 2) void mpn3_kernel(const bf16_t *__restrict__
                 *reinterpret_cast<uint32_t *>(tr + row * M3_TP + (32 * j + (col & ~1)) * 2) = packed;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if constexpr (STORE) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int q2 = 0; q2 < 4; ++q2) {
-            const int row = 8 * q2 + (lane >> 3), ch = lane & 7;
-            const uint4 o = *reinterpret_cast<const uint4 *>(tr + row * M3_TP + ch * 16);
-            ppt_store16_stream(y + ((size_t)t * 32 + row) * M3_N + 64 * w + ch * 8, o);
+            for (int q2 = 0; q2 < 4; ++q2) {
+                const int row = 8 * q2 + (lane >> 3), ch = lane & 7;
+                const uint4 o = *reinterpret_cast<const uint4 *>(tr + row * M3_TP + ch * 16);
+                ppt_store16_stream(y + ((size_t)t * 32 + row) * M3_N + 64 * w + ch * 8, o);
+            }
         }
         M3_STAGE(cur ^ 1);                                          // last read in iteration it - 1, before its barrier
         __syncthreads();
@@ -119,17 +124,19 @@ extern "C" int ppt_mini_pointnet_conv3_half(const void *A, int64_t M, int K, con
                                             float *part_sum, float *part_m2, int dtype, void *stream)
 {
     if (dtype != PPT_BF16 && dtype != PPT_F16) return PPT_EINVAL;
-    if (!A || !W || !gterm || !y || M <= 0 || ((part_sum == nullptr) != (part_m2 == nullptr))) return PPT_EINVAL;
+    if (!A || !W || !gterm || M <= 0 || ((part_sum == nullptr) != (part_m2 == nullptr)) || (!y && !part_sum)) return PPT_EINVAL;
     if (K != M3_K || N != M3_N || M % 32) return PPT_EUNSUPPORTED;
     if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)y) & 15) return PPT_EINVAL;
     constexpr int lds = 2 * M3_BUF + 8 * M3_TR;
     static const int cus = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        (void)hipFuncSetAttribute((const void *)mpn3_kernel<bf16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void *)mpn3_kernel<bf16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void *)mpn3_kernel<f16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute((const void *)mpn3_kernel<f16_t, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void *)mpn3_kernel<bf16_t, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void *)mpn3_kernel<bf16_t, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void *)mpn3_kernel<f16_t, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void *)mpn3_kernel<f16_t, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void *)mpn3_kernel<bf16_t, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void *)mpn3_kernel<f16_t, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         return n > 0 ? n : 256;
     }();
     const int64_t tiles = M / 32;
@@ -138,10 +145,10 @@ extern "C" int ppt_mini_pointnet_conv3_half(const void *A, int64_t M, int K, con
     int64_t want = (int64_t)cus * ppt_get_persistent_occupancy() / 100;
     want = want < 8 ? 8 : want;
     const int grid = (int)(tiles < want ? tiles : want);
-#define PPT_M3(FF, ST) hipLaunchKernelGGL((mpn3_kernel<FF, ST>), dim3(grid), dim3(512), lds, ppt_stream(stream), (const bf16_t *)A, (int)tiles, \
-                                          (const bf16_t *)W, gterm, (bf16_t *)y, part_sum, part_m2)
-    if (dtype == PPT_F16) { if (part_sum) PPT_M3(f16_t, true); else PPT_M3(f16_t, false); }
-    else { if (part_sum) PPT_M3(bf16_t, true); else PPT_M3(bf16_t, false); }
+#define PPT_M3(FF, ST, SO) hipLaunchKernelGGL((mpn3_kernel<FF, ST, SO>), dim3(grid), dim3(512), lds, ppt_stream(stream), (const bf16_t *)A, (int)tiles, \
+                                              (const bf16_t *)W, gterm, (bf16_t *)y, part_sum, part_m2)
+    if (dtype == PPT_F16) { if (!y) PPT_M3(f16_t, true, false); else if (part_sum) PPT_M3(f16_t, true, true); else PPT_M3(f16_t, false, true); }
+    else { if (!y) PPT_M3(bf16_t, true, false); else if (part_sum) PPT_M3(bf16_t, true, true); else PPT_M3(bf16_t, false, true); }
 #undef PPT_M3
     PPT_CHECK_LAUNCH();
     return PPT_OK;

@@ -106,6 +106,15 @@ def _stage_wc(wc, stage):
 
 
 FUSED_CONV12 = os.environ.get("PPT_FUSED_CONV12", "1") != "0"      # 0: the generic PPT_A_CONV1 GEMM (A/B comparisons)
+# conv3 + BN + ReLU + conv4 + max as ONE kernel (csrc/mpn34.hip).  Alone on the chip at C2's size (524 288 points,
+# tools/mpn34_bench.py): 283 us = 1.0 PFLOP/s executed, against 466 us for conv3 (y3 written) + conv4 (y3 read back).
+#   eval (BatchNorm is a constant affine): ON -- validate() 2.425 -> 2.363 ms per batch of 32 (the tokenizer runs beside the
+#     previous batch's blocks, so most of the 183 us were hidden already);
+#   train: OFF -- the batch statistics need a conv3 pass of their own in front (mpn3 without its store: 178 us), 461 us
+#     against 466 alone, and in the C2 step 3.305 against 3.220 ms (tower 2.764 / 2.679, same-box A/B tools/ab_env.py): the
+#     137 GFLOP computed twice cost more beside the prompt chain than the 1.1 GB of HBM traffic they save.  PPT_FUSED_CONV34_TRAIN=1.
+FUSED_CONV34 = os.environ.get("PPT_FUSED_CONV34", "1") != "0"
+FUSED_CONV34_TRAIN = os.environ.get("PPT_FUSED_CONV34_TRAIN", "0") != "0"
 # csrc/rowgemm.hip (weight-stationary K = 384 linears with the LayerNorm applied while the rows are staged) from this many
 # token rows on.  Measured (same box, graph-replayed steps): C3 (32 832 rows) 7.60 -> 7.18 ms per step, the three linears
 # 11-27 % faster each; C2 (16 416 rows) 3.99 -> 4.17 ms although two of the three are ~10 % faster in isolation -- its
@@ -164,12 +173,41 @@ def mini_pointnet(sd, p, wc, nbhd, bn_train, update_running=True):
                       a_scale=sc1, a_shift=sh1, bias=sd[p + "first_conv.3.bias"], pool_max=gmax)
     # cat([global, local]) @ W3^T  ==  local @ W3[:,256:]^T + (global @ W3[:,:256]^T + b3) per group
     w3 = sd[p + "second_conv.0.weight"]
+    g2, be2, rm2, rv2, nb2 = _bn_params(sd, p + "second_conv.1.")
+    w4p = sd[p + "second_conv.3.weight"]
+    fused34 = (FUSED_CONV34 and T in ops.HALF and FUSED_CONV12 and tuple(w3.shape[:2]) == (512, 512) and tuple(w4p.shape[:2]) == (256, 512)
+               and y2.is_contiguous() and (not bn_train or FUSED_CONV34_TRAIN))
+    if fused34 and not bn_train:
+        # eval (validate(), main_cls.py:237-299 -- SURVEY 8(f) N1): BatchNorm 2 is a constant affine and is folded INTO conv3:
+        # W3s = scale o W3, b3s = scale * b3 + shift (two small launches per forward -- not cached: the running statistics are
+        # written through raw pointers and by hipGraph replays, which no version counter sees).  The group term then comes out of
+        # its GEMM as the per-group bias gs, and conv3 + BN + ReLU + conv4 + max is one kernel (csrc/mpn34.hip): y3 never exists.
+        sc2, sh2 = ops.bn_finalize(g2, be2, False, running_mean=rm2, running_var=rv2)
+        w3f = wc.get(w3, "f32")
+        w3s_a, b3s = ops.scale_rows_convert(w3f, sc2, T, cols=(0, 256), bias=sd[p + "second_conv.0.bias"], shift=sh2)
+        w3s_b = ops.scale_rows_convert(w3f, sc2, T, cols=(256, 512))
+        gs = ops.gemm(gmax, w3s_a, out_dtype=torch.float32, bias=b3s, algo_k=0)
+        w4t = wc.derived(("mpn34_w4t", p), (w4p,), lambda: ops.mpn34_retile(wc.get(w4p)))
+        return ops.mini_pointnet_conv34(y2, w3s_b, gs, w4t, sd[p + "second_conv.3.bias"])
     gterm = ops.gemm(gmax, wc.get(w3, cols=(0, 256)), out_dtype=torch.float32, bias=sd[p + "second_conv.0.bias"],
                      algo_k=0)      # its FLOPs are accounted to the 512-wide conv3 (algo_k=512 below)
-    g2, be2, rm2, rv2, nb2 = _bn_params(sd, p + "second_conv.1.")
     w3b = wc.get(w3, cols=(256, 512))
     fused3 = (T in ops.HALF and FUSED_CONV12 and tuple(w3b.shape) == (512, 256) and w3b.stride(0) == 256
               and y2.is_contiguous() and gterm.is_contiguous())          # csrc/mpn3.hip: W3b in registers, rows read once
+    if fused34 and fused3:
+        # train: the batch statistics of y3 need every row before any row can be normalised -- a statistics pass that computes
+        # conv3 WITHOUT writing it (mpn3.hip, store = False), then the fused kernel on the folded weights of THIS batch:
+        # 137 GFLOP recomputed (C2) against 1.1 GB of HBM traffic saved
+        cs = torch.empty((M // 32, 512), dtype=torch.float32, device=dev)
+        cq = torch.empty_like(cs)
+        ops.mini_pointnet_conv3(y2, w3b, gterm, (cs, cq), store=False)
+        sc2, sh2 = ops.bn_finalize(g2, be2, True, partials=(cs, cq), rows_per_partial=32, count=M,
+                                   running_mean=rm2, running_var=rv2, num_batches_tracked=nb2,
+                                   update_running=update_running)
+        w3s_b = ops.scale_rows_convert(wc.get(w3, "f32"), sc2, T, cols=(256, 512))
+        gs = torch.addcmul(sh2, gterm, sc2)
+        w4t = wc.derived(("mpn34_w4t", p), (w4p,), lambda: ops.mpn34_retile(wc.get(w4p)))
+        return ops.mini_pointnet_conv34(y2, w3s_b, gs, w4t, sd[p + "second_conv.3.bias"])
     if bn_train:
         cs = torch.empty((M // 32, 512), dtype=torch.float32, device=dev)
         cq = torch.empty_like(cs)

@@ -710,14 +710,16 @@ def mini_pointnet_conv12(pts, w1, b1, a_scale, a_shift, w2, bias2):
     return y2, gmax
 
 
-def mini_pointnet_conv3(A, w, gterm, col_stats=None):
+def mini_pointnet_conv3(A, w, gterm, col_stats=None, store=True):
     """A [M,256] bf16, w [512,256] bf16, gterm [M/32,512] f32 -> y [M,512] bf16 = A @ w^T + gterm[group] (+ BatchNorm partials
-    into col_stats) -- ppt_mini_pointnet_conv3_bf16.  The FLOPs are accounted at the 512-wide conv this is the local half of."""
+    into col_stats) -- ppt_mini_pointnet_conv3_bf16.  The FLOPs are accounted at the 512-wide conv this is the local half of.
+    store=False: the statistics pass alone (y is not written; returns None)."""
     assert w.dtype in HALF
     _chk(A, w.dtype, "A"); _chk(w, w.dtype, "w"); _chk(gterm, torch.float32, "gterm")
     M, K = A.shape
     N = w.shape[0]
-    y = torch.empty((M, N), dtype=w.dtype, device=A.device)
+    assert store or col_stats is not None
+    y = torch.empty((M, N), dtype=w.dtype, device=A.device) if store else None
     ps, pm = col_stats if col_stats is not None else (None, None)
     if profiler is not None:
         # model: the 512-wide Conv1d on cat(global, local) (dvae.py:194); executed: the local half (the global half is one row
@@ -728,6 +730,36 @@ def mini_pointnet_conv3(A, w, gterm, col_stats=None):
     if profiler is not None:
         profiler.end()
     return y
+
+
+def mpn34_retile(w4):
+    """W4 [256,512] 16-bit -> the fragment order csrc/mpn34.hip streams (ppt_mpn34_retile)."""
+    assert w4.dtype in HALF and tuple(w4.shape) == (256, 512)
+    _chk(w4, w4.dtype, "w4")
+    out = torch.empty_like(w4)
+    _lib.check(_lib.lib().ppt_mpn34_retile(_p(w4), _p(out), _stream()), "ppt_mpn34_retile")
+    return out
+
+
+def mini_pointnet_conv34(y2, w3s, gs, w4_tiled, bias4):
+    """tok [M/32,256] = max over each group of 32 rows of relu(y2 @ w3s^T + gs[group]) @ w4^T + bias4, the [M,512] intermediate
+    never leaving the chip (ppt_mini_pointnet_conv34_half).  y2 [M,256], w3s [512,256] (BatchNorm scale folded in), w4_tiled from
+    mpn34_retile, all one 16-bit format; gs [M/32,512] f32."""
+    T = w3s.dtype
+    assert T in HALF and tuple(w3s.shape) == (512, 256) and w4_tiled.dtype == T and w4_tiled.numel() == 256 * 512
+    _chk(y2, T, "y2"); _chk(w3s, T, "w3s"); _chk(w4_tiled, T, "w4_tiled"); _chk(gs, torch.float32, "gs")
+    M = y2.shape[0]
+    assert y2.shape[1] == 256 and tuple(gs.shape) == (M // 32, 512) and M % 32 == 0
+    tok = torch.empty((M // 32, 256), dtype=T, device=y2.device)
+    if profiler is not None:
+        # model: the 512-wide conv3 on cat(global, local) + conv4; executed: the local half of conv3 (17 k-steps) + conv4
+        profiler.begin("gemm_bf16", 2.0 * M * 512 * 512 + 2.0 * M * 256 * 512, "ppt_mini_pointnet_conv34_half",
+                       executed=2.0 * M * 512 * 272 + 2.0 * M * 256 * 512)
+    _lib.check(_lib.lib().ppt_mini_pointnet_conv34_half(_p(y2), M, _p(w3s), _p(gs), _p(w4_tiled), _p(bias4), _p(tok), dtype_code(T), _stream()),
+               "ppt_mini_pointnet_conv34_half")
+    if profiler is not None:
+        profiler.end()
+    return tok
 
 
 def mini_pointnet_conv4(A, a_scale, a_shift, w, bias):
@@ -842,6 +874,22 @@ def convert(src, dst_dtype, scale=1.0):
         _lib.check(_lib.lib().ppt_convert_scaled(_p(src), dtype_code(src), _p(dst), dtype_code(dst), src.numel(), float(scale), _stream()),
                    "ppt_convert_scaled")
     return dst
+
+
+def scale_rows_convert(W, scale, out_dtype, cols=None, bias=None, shift=None):
+    """convert(scale[:, None] * W[:, cols[0]:cols[1]]) for a row-major f32 matrix W [N, Kfull] -> [N, K] contiguous in out_dtype
+    (ppt_scale_rows_convert); with bias / shift also returns scale * bias + shift [N] f32."""
+    _chk(W, torch.float32, "W"); _chk(scale, torch.float32, "scale")
+    N, Kf = W.shape
+    c0, c1 = cols if cols is not None else (0, Kf)
+    K = c1 - c0
+    out = torch.empty((N, K), dtype=out_dtype, device=W.device)
+    want_bs = bias is not None or shift is not None
+    bs = torch.empty((N,), dtype=torch.float32, device=W.device) if want_bs else None
+    src = W if c0 == 0 else W[:, c0:]
+    _lib.check(_lib.lib().ppt_scale_rows_convert(ctypes.c_void_p(src.data_ptr()), Kf, N, K, _p(scale), _p(out), dtype_code(out), _p(bias), _p(shift),
+                                                 _p(bs), _stream()), "ppt_scale_rows_convert")
+    return (out, bs) if want_bs else out
 
 
 def transpose(src, dst_dtype=None, pad_to=1):

@@ -1374,3 +1374,61 @@ def test_dataset_fps_is_bit_exact(tag, N, M, dup, cols):
     assert idx2[0] == want_start and np.random.randint(0, 1 << 30) == want_next      # ONE draw, where the reference draws (:51)
     with pytest.raises(TypeError):
         PD.farthest_point_sample(pts.astype(np.float64), 8)
+
+
+# ------------------------------------------------------------------ fused conv3 + BN + ReLU + conv4 + max (csrc/mpn34.hip)
+@pytest.mark.parametrize("T", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("tiles", [2, 7, 1027, 4096])
+def test_mini_pointnet_conv34_matches_fp32_math_on_the_same_operands(ops, T, tiles):
+    """ppt_mini_pointnet_conv34_half (conv3 -> folded BatchNorm -> ReLU -> conv4 -> max over the group, the [M,512]
+    intermediate never leaving the chip) against fp32 torch math on the operands the MFMAs see -- y2, the scale-folded W3s and W4
+    rounded to the 16-bit format, the ReLU output rounded once -- for even / odd group counts and more chunks than workgroups;
+    the per-group bias gs rides in the matrix pipe as a hi + lo pair: its fp32 value must come through to ~1e-6 relative.
+    Bit-reproducible; ppt_scale_rows_convert (the fold) against torch."""
+    g = torch.Generator().manual_seed(tiles)
+    M = 32 * tiles
+    y2 = (torch.randn(M, 256, generator=g) * 1.5).cuda().to(T)
+    w3 = (torch.randn(512, 512, generator=g) * 512 ** -0.5).cuda()
+    b3 = (0.1 * torch.randn(512, generator=g)).cuda()
+    sc = (0.5 + torch.rand(512, generator=g)).cuda() * torch.where(torch.rand(512, generator=g) < 0.1, -1.0, 1.0).cuda()
+    sh = (0.3 * torch.randn(512, generator=g)).cuda()
+    w4 = (torch.randn(256, 512, generator=g) * 512 ** -0.5).cuda()
+    b4 = (0.1 * torch.randn(256, generator=g)).cuda()
+    gmax = torch.randn(tiles, 256, generator=g).cuda()
+    # the fold (engine.mini_pointnet): W3s = scale o W3, b3s = scale * b3 + shift
+    w3s_a, b3s = ops.scale_rows_convert(w3, sc, T, cols=(0, 256), bias=b3, shift=sh)
+    w3s_b = ops.scale_rows_convert(w3, sc, T, cols=(256, 512))
+    assert torch.equal(w3s_a, (w3[:, :256] * sc[:, None]).to(T)) and torch.equal(w3s_b, (w3[:, 256:] * sc[:, None]).to(T))
+    assert torch.allclose(b3s, sc * b3 + sh, rtol=1e-6, atol=1e-7)
+    gs = (gmax @ w3s_a.float().T + b3s) * 3.0                      # (a large group term: the hi + lo split has to carry it)
+    w4t = ops.mpn34_retile(w4.to(T))
+    tok = ops.mini_pointnet_conv34(y2, w3s_b, gs.contiguous(), w4t, b4)
+    tok2 = ops.mini_pointnet_conv34(y2, w3s_b, gs.contiguous(), w4t, b4)
+    assert torch.equal(tok, tok2)
+    y3 = y2.float() @ w3s_b.float().T + gs.repeat_interleave(32, dim=0)
+    a = torch.relu(y3).to(T).float()
+    ref = (a @ w4.to(T).float().T + b4).view(tiles, 32, 256).max(dim=1).values
+    err = (tok.float() - ref).abs().max().item()
+    ulp = 2.0 ** (-10 if T == torch.float16 else -7)
+    # one rounding of the output + the rare 1-ulp flip of a ReLU output whose fp32 sum came out in another order
+    assert err < 1.5 * ulp * max(1.0, ref.abs().max().item()), err
+    # ... and against the UNFUSED kernels (conv3 + affine-prologue conv4) on un-folded weights: same function, other roundings
+    if tiles <= 1027:
+        gterm = (gs - sh) / sc
+        y3u = ops.mini_pointnet_conv3(y2, (w3[:, 256:]).contiguous().to(T), gterm.contiguous())
+        toku = ops.mini_pointnet_conv4(y3u, sc, sh, w4.to(T), b4)
+        assert (tok.float() - toku.float()).abs().max().item() < 0.05 * max(1.0, ref.abs().max().item())
+
+
+def test_mini_pointnet_conv3_statistics_pass_without_store(ops):
+    """ppt_mini_pointnet_conv3_half with y == NULL: the same BatchNorm partials, bit for bit, as the storing pass."""
+    g = torch.Generator().manual_seed(3)
+    M = 32 * 333
+    y2 = torch.randn(M, 256, generator=g).cuda().to(torch.float16)
+    w = (torch.randn(512, 256, generator=g) * 0.06).cuda().to(torch.float16)
+    gterm = torch.randn(M // 32, 512, generator=g).cuda()
+    st_a = (torch.empty(M // 32, 512, device="cuda"), torch.empty(M // 32, 512, device="cuda"))
+    st_b = (torch.empty(M // 32, 512, device="cuda"), torch.empty(M // 32, 512, device="cuda"))
+    y = ops.mini_pointnet_conv3(y2, w, gterm, st_a)
+    assert ops.mini_pointnet_conv3(y2, w, gterm, st_b, store=False) is None and y is not None
+    assert torch.equal(st_a[0], st_b[0]) and torch.equal(st_a[1], st_b[1])
