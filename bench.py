@@ -176,7 +176,7 @@ def build_model(dataset="modelnet40", head_type=HEAD_TYPE, precision=torch.bfloa
     # start token's row is the same in every prompt) -- which is what lets the text tower share the prompts' common prefix
     m.prompt_learner.embedding = W.synth_prompt_embedding_from_tokens(m.tokenized_prompts, seed=0)
     m.cuda()
-    m.set_precision(precision)
+    m.set_precision("fp32" if precision == torch.float32 else "mixed16")
     return m
 
 
@@ -214,12 +214,19 @@ def secondary_runs():
     --config X --no-roofline --no-parity-mode --no-cpu-baseline; the parent's GPU work is finished and synchronised by now."""
     import subprocess
     out = {}
-    runs = [("C3", ["--config", "C3"]), ("C4", ["--config", "C4"]), ("C5", ["--config", "C5"]), ("C2_eval", ["--config", "C2", "--eval"])]
-    for name, extra in runs:
+    # *_in_order: the same step WITHOUT the opt-in the headline runs with (Trainer.inputs_ready / eval_inputs_ready: the caller
+    # vouches that the batch is resident, so the next step's FPS + kNN + tokenizer -- C5: the whole frozen backbone -- run under
+    # the current one): what a caller gets who hands over batches that are merely queued on the stream (VERDICT r3 weak #9)
+    in_order = {"PPT_GROUP_AHEAD": "0", "PPT_EVAL_AHEAD": "0"}
+    runs = [("C3", ["--config", "C3"], {}), ("C4", ["--config", "C4"], {}), ("C5", ["--config", "C5"], {}),
+            ("C2_eval", ["--config", "C2", "--eval"], {}),
+            ("C2_in_order", ["--config", "C2"], in_order), ("C3_in_order", ["--config", "C3"], in_order),
+            ("C5_in_order", ["--config", "C5"], in_order), ("C2_eval_in_order", ["--config", "C2", "--eval"], in_order)]
+    for name, extra, env in runs:
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", "30", "--warmup", "5", "--no-roofline", "--no-parity-mode",
                "--no-cpu-baseline", "--no-secondary"] + extra
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=ROOT)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=ROOT, env=dict(os.environ, **env))
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             j = json.loads(line[-1])
             out[name] = {"metric": j["metric"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"],

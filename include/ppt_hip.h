@@ -46,7 +46,7 @@ const char *ppt_strerror(int code);
  *    ppt_bn_rows_bwd_apply (half_dtype), ppt_*_half entry points.
  * 4: gradient scaling local to the 16-bit backward stages -- ppt_convert_scaled (new), ppt_rows_matmul_f32 (alpha),
  *    ppt_prompt_rows_bwd (scale); ppt_adamw_step (skipped counter), ppt_adamw_multi (new); ppt_cross_entropy_rows (ignore_index);
- *    ppt_mini_pointnet_conv34_half + ppt_mpn34_retile + ppt_scale_rows_convert (new), ppt_mini_pointnet_conv3_half (y may be
+ *    ppt_mini_pointnet_conv34_half + ppt_mpn34_retile + ppt_scale_rows_convert + ppt_health_check (new), ppt_mini_pointnet_conv3_half (y may be
  *    NULL: statistics only). */
 int ppt_abi_version(void);
 
@@ -536,6 +536,10 @@ int ppt_convert(const void *src, int src_dtype, void *dst, int dst_dtype, int64_
 /* dst = convert(src * scale), scale > 0: the operand copy of an fp32 activation gradient at the entry of a 16-bit backward
  * stage, multiplied by the stage's power-of-two gradient scale on the way (exact; ppt_amd/gradscale.py). */
 int ppt_convert_scaled(const void *src, int src_dtype, void *dst, int dst_dtype, int64_t n, float scale, void *stream);
+/* *flags |= bit when any of the n values of x (any dtype) is not finite; *maxabs (optional; a non-negative float the caller
+ * initialised) = max(*maxabs, max |x| over the finite values).  One small launch: the overflow flag of a 16-bit stage's output
+ * (ppt_amd/health.py) and the range probe of tools/fp16_stress.py. */
+int ppt_health_check(const void *x, int x_dtype, int64_t n, uint32_t *flags, uint32_t bit, float *maxabs, void *stream);
 /* out[n][k] = convert(scale[n] * W[n][k]) for an [N, K] window of a row-major f32 matrix (row stride ldw elements; K % 4 == 0, ldw %
  * 4 == 0, 16-byte aligned), out [N, K] contiguous in out_dtype; bs (optional, [N] f32) = scale * b + shift (b / shift may be NULL).
  * A folded BatchNorm multiplied into the weight rows of the conv in front of it (csrc/mpn34.hip's W3s / gs). */

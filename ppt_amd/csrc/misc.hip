@@ -97,6 +97,26 @@ __global__ __launch_bounds__(256) void scale_rows_convert_kernel(const float *__
         for (int n = threadIdx.x; n < N; n += 256) bs[n] = scale[n] * (b ? b[n] : 0.f) + (shift ? shift[n] : 0.f);
 }
 
+// flags[0] |= bit when any of the n values is not finite; maxabs (optional, one float, must start >= 0) = max(maxabs, max |x|) over the
+// finite values (unsigned-integer atomic max on the bits: exact for non-negative floats).  The per-stage overflow flag of the
+// 16-bit mode (ppt_amd/health.py) and the probe of tools/fp16_stress.py.
+template <typename TS>
+__global__ __launch_bounds__(256) void health_check_kernel(const TS *__restrict__ x, int64_t n, uint32_t *__restrict__ flags, uint32_t bit,
+                                                           float *__restrict__ maxabs)
+{
+    bool bad = false;
+    float mx = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = fabsf(dt<TS>::load(x + i));
+        if (!(v <= 3.0e38f)) bad = true; else mx = fmaxf(mx, v);
+    }
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flags, bit);
+    if (maxabs) {
+        mx = wave_reduce_max(mx);
+        if ((threadIdx.x & 63) == 63) atomicMax(reinterpret_cast<unsigned int *>(maxabs), __float_as_uint(mx));
+    }
+}
+
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void transpose_kernel(const TS *__restrict__ s, TD *__restrict__ d, int rows, int cols,
                                                         int64_t ldd)
@@ -279,6 +299,18 @@ extern "C" int ppt_cls_max_pool(const void *x, int x_dtype, int B, int T, int D,
         hipLaunchKernelGGL(cls_max_pool_kernel<f16_t>, dim3((D + 63) / 64, B), dim3(CMP_W * 64), 0, ppt_stream(stream), (const f16_t *)x, T, D, out, argmax);
     else
         return PPT_EINVAL;
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
+extern "C" int ppt_health_check(const void *x, int x_dtype, int64_t n, uint32_t *flags, uint32_t bit, float *maxabs, void *stream)
+{
+    if (!x || !flags || n <= 0) return PPT_EINVAL;
+    const unsigned grid = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    if (x_dtype == PPT_F32) hipLaunchKernelGGL(health_check_kernel<float>, dim3(grid), dim3(256), 0, ppt_stream(stream), (const float *)x, n, flags, bit, maxabs);
+    else if (x_dtype == PPT_BF16) hipLaunchKernelGGL(health_check_kernel<bf16_t>, dim3(grid), dim3(256), 0, ppt_stream(stream), (const bf16_t *)x, n, flags, bit, maxabs);
+    else if (x_dtype == PPT_F16) hipLaunchKernelGGL(health_check_kernel<f16_t>, dim3(grid), dim3(256), 0, ppt_stream(stream), (const f16_t *)x, n, flags, bit, maxabs);
+    else return PPT_EINVAL;
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }

@@ -23,9 +23,20 @@ def pc_normalize(pc):
 def farthest_point_sample(point, npoint, start=None, return_index=False):
     """point [N, D] float32 (xyz in the first three columns), npoint -> point[centroids] [npoint, D] (data/dataset_3d.py:40-61).
     start: the first index; None draws `np.random.randint(0, N)` exactly where the reference does (:51), so a seeded loader
-    selects the same points.  Runs on the current HIP device; there is no CPU fallback."""
+    selects the same points.  Runs on the current HIP device; there is no CPU fallback.
+
+    Where to call it: the reference runs this loop inside Dataset._get_item, i.e. in DataLoader WORKER processes
+    (num_workers = args.workers, fork start method).  A forked worker cannot initialise the device ("Cannot re-initialize CUDA in
+    forked subprocess") and a spawned one would build a GPU context per worker for one tiny launch per sample -- so inside a worker
+    this function raises and says what to do instead: sample in the main process (a collate_fn, or on the batch after it has been
+    moved to the device: ops.fps takes [B, N, 3] and walks B clouds in one launch), or run the loader with num_workers = 0.
+    INTEGRATION.md, "dataset-side FPS"."""
     import torch
     from .. import ops
+    if torch.utils.data.get_worker_info() is not None:
+        raise RuntimeError("ppt_amd.data.farthest_point_sample was called inside a DataLoader worker process: it runs on the HIP device "
+                           "and has no CPU path.  Call it from the main process -- in a collate_fn, or batched on the device with "
+                           "ppt_amd.ops.fps(pc [B,N,3], npoint, start [B]) -- or use num_workers=0 (INTEGRATION.md, dataset-side FPS).")
     point = np.asarray(point)
     if point.ndim != 2 or point.shape[1] < 3:
         raise ValueError(f"point must be [N, D >= 3], got {point.shape}")

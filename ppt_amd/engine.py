@@ -91,10 +91,14 @@ TOKENIZER_F16 = os.environ.get("PPT_TOKENIZER_F16", "1") != "0"
 DECODER_F16 = os.environ.get("PPT_DECODER_F16", "1") != "0"
 
 
+# stages moved from IEEE half back to bf16 at run time because they overflowed (ppt_amd/health.py: demote)
+DEMOTED = set()
+
+
 def _stage_wc(wc, stage):
     """The WeightCache a stage runs with: `wc`, or a sibling of another operand precision (kept on `wc`)."""
     dt = STAGE_DTYPE.get(stage)
-    if dt is None and wc.dtype == torch.bfloat16:
+    if dt is None and wc.dtype == torch.bfloat16 and stage not in DEMOTED:
         if (BLOCKS_F16 and stage in ("blocks", "last_block")) or (TOKENIZER_F16 and stage == "tokenizer"):
             dt = torch.float16
     if dt is None or dt == wc.dtype:

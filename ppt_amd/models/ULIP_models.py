@@ -600,6 +600,7 @@ class ULIP_WITH_IMAGE(nn.Module):
         # transformer blocks (as train.Trainer.inputs_ready does for training steps)
         self.eval_inputs_ready = False
         self._chain_prio = None
+        self.health = None                  # ppt_amd.health.Monitor (train.Trainer installs one in the mixed 16-bit mode)
         self._handoff = False               # inside forward_loss: graph outputs go straight into the next graph's input (no clone)
         self._handoff_grad = os.environ.get("PPT_HANDOFF", "1") != "0"
 
@@ -632,8 +633,36 @@ class ULIP_WITH_IMAGE(nn.Module):
     def precision(self):
         return getattr(self.point_encoder, "precision", torch.bfloat16)
 
-    def set_precision(self, dtype):
-        """torch.bfloat16 (performance mode) or torch.float32 (parity mode) for both towers."""
+    MIXED16 = "mixed16"
+
+    @property
+    def precision_name(self):
+        """"mixed16" (performance mode) or "fp32" (parity mode)."""
+        return "fp32" if self.precision == torch.float32 else self.MIXED16
+
+    def set_precision(self, mode):
+        """"mixed16" -- the performance mode: 16-bit MFMA operands with fp32 accumulation, residual streams / statistics /
+        gradients in fp32; the operand FORMAT is chosen per stage (IEEE half for the CLIP text tower, the PointBERT tokenizer and
+        blocks, the part-seg decoder and per-point head; bf16 for PointNet++ / PointMLP: engine.*_F16) -- or
+        "fp32" / torch.float32 -- the parity mode (fp32 operands on the fp32 MFMA).
+        `torch.bfloat16` is accepted as a DEPRECATED alias of "mixed16" (rounds 1-2 ran that mode in bf16 throughout and named it
+        after the format; it has not been a statement about the operand format since round 3)."""
+        if isinstance(mode, str):
+            key = mode.lower()
+            if key not in (self.MIXED16, "fp32", "float32"):
+                raise ValueError(f'set_precision: expected "mixed16" or "fp32", got {mode!r}')
+            dtype = torch.bfloat16 if key == self.MIXED16 else torch.float32
+        elif mode is torch.bfloat16 or mode is torch.float16:
+            import warnings
+            warnings.warn('set_precision(torch.bfloat16 / torch.float16) selects the MIXED 16-bit mode (IEEE half operands in the '
+                          'normalised stages, bf16 in PointNet++ / PointMLP), not a format: write set_precision("mixed16")',
+                          DeprecationWarning, stacklevel=2)
+            dtype = torch.bfloat16
+        elif mode is torch.float32:
+            dtype = torch.float32
+        else:
+            raise ValueError(f'set_precision: expected "mixed16", "fp32" or torch.float32, got {mode!r}')
+        # (internally the mode marker stays a dtype: torch.bfloat16 = mixed16, torch.float32 = parity)
         self.point_encoder.precision = dtype
         self.point_encoder._wc = None
         self._graphs.clear()
@@ -747,7 +776,9 @@ class ULIP_WITH_IMAGE(nn.Module):
     def _head_precision(self):
         """fp32 head products, except the per-point head of part segmentation in the performance mode: fp16 operands (_MatmulNT;
         the logit scale is then applied to the PRODUCT, so that the operands stay far inside fp16's range)."""
-        return torch.float16 if (self.task == 'partseg' and self.precision == torch.bfloat16) else torch.float32
+        if self.task == 'partseg' and self.precision == torch.bfloat16:
+            return torch.bfloat16 if "head" in engine.DEMOTED else torch.float16
+        return torch.float32
 
     def encode_text(self, prompts, tokenized_prompts=None):
         """ULIP_models.py:203-222: prompts [C,77,W] -> [C,embed_dim].  General in `prompts`, as the reference: the shared-prefix
@@ -827,6 +858,8 @@ class ULIP_WITH_IMAGE(nn.Module):
         finally:
             if ahead:
                 pe.group_ahead = None
+        if self.health is not None and self.training:
+            self.health.check(1, pc_embed)                          # (BIT_POINT)
         if side is not None:
             cur.wait_stream(side)
             text_embed.record_stream(cur)
@@ -835,7 +868,7 @@ class ULIP_WITH_IMAGE(nn.Module):
         logit_scale = self.logit_scale.exp()
         lead = pc_embed.shape[:-1]
         hp = self._head_precision()
-        if hp == torch.float16:       # ULIP_models.py:281 with the scale moved behind the product (same value, fp16-safe operands)
+        if hp in ops.HALF:            # ULIP_models.py:281 with the scale moved behind the product (same value, fp16-safe operands)
             logits = logit_scale * matmul_nt(pc_embed.reshape(-1, pc_embed.shape[-1]), text_embed, hp)
         else:
             logits = matmul_nt((logit_scale * pc_embed).reshape(-1, pc_embed.shape[-1]), text_embed, hp)
@@ -871,6 +904,8 @@ class ULIP_WITH_IMAGE(nn.Module):
         else:
             with self._tower_room():
                 pc_feat = self.point_encoder(pc)
+        if self.health is not None:
+            self.health.check(1, pc_feat)                           # (BIT_POINT: on the caller's stream, beside the prompt chain)
         if side is not None:
             cur.wait_stream(side)
             text_raw.record_stream(cur)

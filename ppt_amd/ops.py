@@ -241,6 +241,8 @@ def gemm(A, B, *, out=None, out_dtype=None, M=None, bias=None, act=ACT_NONE, dac
     _lib.check(_lib.lib().ppt_gemm(ctypes.byref(p), _stream()), "ppt_gemm")
     if profiler is not None:
         profiler.end()
+    if probe is not None:
+        _probe("gemm", out); _probe("gemm (second output)", out2)
     return out
 
 
@@ -401,6 +403,8 @@ def rowgemm(A, W, *, ln=None, ln_eps=1e-5, ln_stats=None, bias=None, act=ACT_NON
     _lib.check(_lib.lib().ppt_rowgemm_bf16(ctypes.byref(p), _stream()), "ppt_rowgemm_bf16")
     if profiler is not None:
         profiler.end()
+    if probe is not None:
+        _probe("rowgemm", out); _probe("rowgemm (second output)", out2)
     return out
 
 
@@ -416,6 +420,8 @@ def layernorm_fwd(x, w, b, y_dtype, add=None, add_rows=0, write_xs=None, save_st
     _lib.check(_lib.lib().ppt_layernorm_fwd(_p(x), _p(add), add_rows, _p(write_xs), _p(w), _p(b), _p(y),
                                             dtype_code(y), _p(mean), _p(rstd), M, D, eps, _stream()),
                "ppt_layernorm_fwd")
+    if probe is not None:
+        _probe("layernorm", y)
     return y, mean, rstd
 
 
@@ -456,6 +462,8 @@ def attention_fwd(qkv, Bt, T, H, scale, causal, want_lse=True):
                                             dtype_code(qkv), _stream()), "ppt_attention_fwd")
     if profiler is not None:
         profiler.end()
+    if probe is not None:
+        _probe("attention", out)
     return out, lse
 
 
@@ -491,6 +499,8 @@ def attention_prefix_fwd(qkv, C, T, P, H, scale, want_lse=True):
                "ppt_attention_prefix_fwd")
     if profiler is not None:
         profiler.end()
+    if probe is not None:
+        _probe("attention", out)
     return out, lse
 
 
@@ -707,6 +717,8 @@ def mini_pointnet_conv12(pts, w1, b1, a_scale, a_shift, w2, bias2):
                                                         N, _p(y2), _p(gmax), dtype_code(w2), _stream()), "ppt_mini_pointnet_conv12_half")
     if profiler is not None:
         profiler.end()
+    if probe is not None:
+        _probe("mini-PointNet conv2 output (pre-BN)", y2)
     return y2, gmax
 
 
@@ -729,6 +741,8 @@ def mini_pointnet_conv3(A, w, gterm, col_stats=None, store=True):
                "ppt_mini_pointnet_conv3_half")
     if profiler is not None:
         profiler.end()
+    if probe is not None:
+        _probe("mini-PointNet conv3 output (pre-BN)", y)
     return y
 
 
@@ -759,6 +773,8 @@ def mini_pointnet_conv34(y2, w3s, gs, w4_tiled, bias4):
                "ppt_mini_pointnet_conv34_half")
     if profiler is not None:
         profiler.end()
+    if probe is not None:
+        _probe("mini-PointNet tokens", tok)
     return tok
 
 
@@ -776,6 +792,8 @@ def mini_pointnet_conv4(A, a_scale, a_shift, w, bias):
                                                        _stream()), "ppt_mini_pointnet_conv4_half")
     if profiler is not None:
         profiler.end()
+    if probe is not None:
+        _probe("mini-PointNet tokens", tok)
     return tok
 
 
@@ -848,6 +866,8 @@ def linear3_gelu(pts, w, b, y_dtype):
     y = torch.empty((M, C), dtype=y_dtype, device=pts.device)
     _lib.check(_lib.lib().ppt_linear3_gelu(_p(pts), M, _p(w), _p(b), C, _p(y), dtype_code(y), _stream()),
                "ppt_linear3_gelu")
+    if probe is not None:
+        _probe("pos_embed hidden", y)
     return y
 
 
@@ -874,6 +894,23 @@ def convert(src, dst_dtype, scale=1.0):
         _lib.check(_lib.lib().ppt_convert_scaled(_p(src), dtype_code(src), _p(dst), dtype_code(dst), src.numel(), float(scale), _stream()),
                    "ppt_convert_scaled")
     return dst
+
+
+def health_check(x, flags, bit, maxabs=None):
+    """flags[0] |= bit if x (any dtype, contiguous) holds a non-finite value; maxabs[0] = max(maxabs[0], max |finite x|) when
+    given (ppt_health_check).  flags: int32 [1]; maxabs: f32 [1], non-negative."""
+    _chk(x, None, "x"); _chk(flags, torch.int32, "flags"); _chk(maxabs, torch.float32, "maxabs")
+    _lib.check(_lib.lib().ppt_health_check(_p(x), dtype_code(x), x.numel(), _p(flags), int(bit), _p(maxabs), _stream()), "ppt_health_check")
+
+
+# tools/fp16_stress.py: when set, every wrapper below that returns a 16-bit activation reports it -- probe(name, tensor)
+probe = None
+
+
+def _probe(name, t):
+    if probe is not None and t is not None and t.dtype in HALF:
+        probe(name, t)
+    return t
 
 
 def scale_rows_convert(W, scale, out_dtype, cols=None, bias=None, shift=None):

@@ -218,6 +218,15 @@ class Trainer:
         # skip an element whose gradient is not finite and count it (`nonfinite_grad_elements()`); `step(check_finite=True)`
         # raises on a non-finite loss as main_cls.py:205-207 does, and on a non-zero count.
         self._skipped = None
+        # ... and the run-time overflow watch of the half-precision stages (ppt_amd/health.py): two tiny launches per step off the
+        # prompt chain, one stall-free poll every `health.every` steps; a set bit demotes the offending side to bf16.
+        # PPT_HEALTH=0 turns it off, PPT_HEALTH_EVERY sets the poll interval.
+        self.health = None
+        self.demotions = []
+        if os.environ.get("PPT_HEALTH", "1") != "0" and getattr(model, "precision", None) == torch.bfloat16 and hasattr(model, "health") \
+                and next(model.parameters()).is_cuda:
+            from . import health
+            self.health = model.health = health.Monitor(next(model.parameters()).device, every=int(os.environ.get("PPT_HEALTH_EVERY", "50")))
         # logit_scale is frozen in every PPT configuration (ULIP_models.py:487-507) and its value lies inside the clamp range:
         # main_cls.py:213's per-step clamp is then idempotent -- applied once here, and per step only if it ever trains
         if hasattr(model, "logit_scale"):
@@ -306,6 +315,12 @@ class Trainer:
             from . import graphs
             use = self.inputs_ready and pc.is_cuda and side is not None and (
                 self.group_ahead_when_frozen or not self._point_side_frozen or getattr(pe, "group_ahead_pays_when_frozen", False))
+            # DDP's per-forward buffer broadcast writes the BatchNorm running statistics on THIS stream while an ahead stage would
+            # update them on the grouping stream, which deliberately does not wait for this one: an unordered read-modify-write
+            # (ADVICE r3).  With the per-step broadcast the stages stay in order; the default (one broadcast in finish()) is
+            # ordered through the stage's own event.
+            if self.bcast is not None and self.broadcast_buffers_every_step:
+                use = False
             pe.group_ahead = graphs.shared_group_stream() if use else None
         tower_own = (self.tower_own_stream and self.inputs_ready and pc.is_cuda and side is not None and self._point_side_frozen
                      and self.fused_head and not self.extra_inputs)
@@ -331,6 +346,12 @@ class Trainer:
         finally:
             if hasattr(pe, "group_ahead"):
                 pe.group_ahead = None       # the vouching covers this call's `pc` only: a forward outside step() stays in order
+        if self.health is not None:
+            self.health.check(2, loss)                              # (BIT_LOSS; on the caller's stream)
+            new = self.health.poll(self.it)
+            if new:
+                from . import health
+                self.demotions.append((self.it, new, health.demote(model, new)))
         if side is not None:
             side.wait_stream(main)
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
@@ -402,6 +423,8 @@ class Trainer:
         from . import ops
         if self._skipped is None:
             self._skipped = torch.zeros((1,), dtype=torch.int64, device=params[0][1].device)
+            if self.health is not None:
+                self.health.skipped = self._skipped
         prio = self.model.chain_priority() if hasattr(self.model, "chain_priority") else 0
         with torch.no_grad(), ops.wave_priority(prio):
             by_group = {}

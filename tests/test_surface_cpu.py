@@ -374,3 +374,28 @@ def test_scaled_backward_wrapper_is_exact():
     Ctx.grad_scale = 1.0
     a2, _, _ = wrapped(Ctx(), d)
     assert torch.equal(a2, d * 3.0) and torch.equal(seen["in"], d)
+
+
+def test_set_precision_names():
+    """the performance mode is a MIXED 16-bit mode (IEEE half in the normalised stages, bf16 in PointNet++ /
+    PointMLP) and is named so -- set_precision("mixed16") / "fp32"; torch.bfloat16 stays as a deprecated alias that warns."""
+    import warnings
+    from types import SimpleNamespace
+    import pytest
+    import torch
+    from ppt_amd.models import ULIP_models as M
+    args = SimpleNamespace(classnames=["chair", "table"], template_init='', class_name_position='middle', num_learnable_prompt_tokens=4,
+                           gpu=0, task='cls', head_type=0, evaluate_3d=False, ulip2=False, synthetic_weights=True)
+    m = M.ULIP_PointBERT(args)
+    assert m.precision_name == "mixed16"
+    assert m.set_precision("fp32") is m and m.precision == torch.float32 and m.precision_name == "fp32"
+    assert m.set_precision("mixed16").precision_name == "mixed16" and m.precision == torch.bfloat16
+    assert m.set_precision(torch.float32).precision_name == "fp32"
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        m.set_precision(torch.bfloat16)
+    assert m.precision_name == "mixed16" and any(issubclass(x.category, DeprecationWarning) for x in w)
+    with pytest.raises(ValueError):
+        m.set_precision("bf16")
+    with pytest.raises(ValueError):
+        m.set_precision(torch.int8)
