@@ -417,7 +417,7 @@ def main():
         g_ms = g["ms"] - overhead_ms * g["launches"]
         achieved = g["executed"] / (g_ms * 1e-3) / 1e12          # EXECUTED FLOPs; the model's figure beside it
         traffic = None          # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE), see profiles/
-        for rnd in ("r03", "r02", "r01"):
+        for rnd in ("r04", "r03", "r02", "r01"):
             tf = os.path.join(ROOT, "profiles", f"{rnd}_gemm_hbm_traffic.json")
             if a.config == "C2" and os.path.exists(tf):
                 traffic = round(json.load(open(tf))["hbm_bytes_per_launch"])
