@@ -719,9 +719,11 @@ class ULIP_WITH_IMAGE(nn.Module):
         3.281 / 3.400 / 3.613 ms on one box with the tokenizer in the tower's graph; with the tokenizer running ahead on its own
         stream (PointTransformer.tokenize_ahead, the default) 50 / 60 / 70 % -> 3.249 / 3.212 / 3.205 ms and 80 % 3.27: default 70.
         The step sits on a plateau now -- 3.20 ... 3.27 ms for every combination of {grouping ahead, tokenizer ahead, neither} x
-        {60 ... 85 %} on that box: what remains is the kernels' own resource time.)"""
+        {60 ... 85 %} on that box: what remains is the kernels' own resource time.  Round 4, re-measured on two boxes after the
+        prompt chain lost its un-scaling multiply and gained the one-launch optimizer: 60 / 70 / 80 / 85 / 90 / 100 % -> 3.309 /
+        3.233 / 3.154 | 3.115 / 3.125 / 3.197 / 3.581 ms: default 80.)"""
         if self.training and torch.is_grad_enabled() and self.chain_priority():
-            return ops.persistent_occupancy(int(os.environ.get("PPT_TOWER_OCCUPANCY", "70")))
+            return ops.persistent_occupancy(int(os.environ.get("PPT_TOWER_OCCUPANCY", "80")))
         if not self.training and not torch.is_grad_enabled() and self.eval_inputs_ready:
             # validate() with the next batch's tokenizer on its own stream: its persistent kernels leave a fifth of the CUs to
             # the blocks they run beside (C2 eval 2.44 -> 2.40 ms; 60 %: 2.43, 40 %: 2.56)
