@@ -37,7 +37,7 @@ def run(h, g, f32_stages):
     sd = W.ulip_pointbert_state_dict(seed=0)
     m.load_state_dict(sd, strict=False)
     m.prompt_learner.embedding = W.synth_prompt_embedding(40, seed=0)
-    m.cuda().set_precision(torch.bfloat16)
+    m.cuda().set_precision("mixed16")
     m.use_hip_graphs = m.point_encoder.use_hip_graphs = False
     m.overlap_text_tower = False
     engine.STAGE_DTYPE.clear()

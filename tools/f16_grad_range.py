@@ -33,7 +33,7 @@ def run(h, g, s, all_bf16):
         m = M.ULIP_PointBERT(args)
     m.load_state_dict(W.ulip_pointbert_state_dict(seed=0), strict=False)
     m.prompt_learner.embedding = W.synth_prompt_embedding(40, seed=0)
-    m.cuda().set_precision(torch.bfloat16)
+    m.cuda().set_precision("mixed16")
     m.use_hip_graphs = m.point_encoder.use_hip_graphs = False
     m.overlap_text_tower = False
     engine.STAGE_DTYPE.clear()
@@ -45,13 +45,18 @@ def run(h, g, s, all_bf16):
     pc, _ = W.synth_clouds(4, 1024, seed=77)
     m.point_encoder.fps_start = torch.from_numpy(g["fps_start"]).cuda()
     m.point_encoder.drop_path_factors = torch.from_numpy(g["dp_masks"]).cuda()
-    tr = Trainer(m, lr=3e-3, label_smoothing=0.2, distributed=False)
-    tr.fused_head = False
-    tr.loss_scale = None
-    inner = tr._loss
-    tr._loss = lambda a, b: inner(a, b) * s
-    tr.step(torch.from_numpy(pc).cuda(), torch.from_numpy(g["labels"]).cuda())
-    torch.cuda.synchronize()
+    # (the sweep measures the UN-scaled half backward: the nodes' own gradient scale, ppt_amd/gradscale.py, is switched off)
+    from ppt_amd import gradscale
+    old_policy, gradscale.POLICY = gradscale.POLICY, "off"
+    try:
+        tr = Trainer(m, lr=3e-3, label_smoothing=0.2, distributed=False)
+        tr.fused_head = False
+        inner = tr._loss
+        tr._loss = lambda a, b: inner(a, b) * s
+        tr.step(torch.from_numpy(pc).cuda(), torch.from_numpy(g["labels"]).cuda())
+        torch.cuda.synchronize()
+    finally:
+        gradscale.POLICY = old_policy
     engine.STAGE_DTYPE.clear()
     return {k: p.grad.detach().cpu().double() / s for k, p in m.named_parameters() if p.grad is not None}
 
@@ -66,7 +71,7 @@ def run_partseg(g, s, all_bf16):
         m = M.ULIP_PointBERT_partseg(args)
     m.load_state_dict(W.ulip_partseg_state_dict(seed=0), strict=False)
     m.prompt_learner.embedding = W.synth_prompt_embedding(50, seed=0)
-    m.cuda().set_precision(torch.bfloat16)
+    m.cuda().set_precision("mixed16")
     m.overlap_text_tower = False
     engine.STAGE_DTYPE.clear()
     if all_bf16:

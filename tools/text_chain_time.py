@@ -12,7 +12,7 @@ args = SimpleNamespace(classnames=M.dataset_classnames("modelnet40"), template_i
 m = M.ULIP_PointBERT(args)
 m.load_state_dict(W.ulip_pointbert_state_dict(seed=0), strict=False)
 m.prompt_learner.embedding = W.synth_prompt_embedding_from_tokens(m.tokenized_prompts, seed=0)
-m.cuda().set_precision(torch.bfloat16)
+m.cuda().set_precision("mixed16")
 m.text_precision = fmt
 m.overlap_text_tower = False
 cot = torch.randn(40, 512, generator=torch.Generator().manual_seed(1)).cuda()
