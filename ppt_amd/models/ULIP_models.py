@@ -721,9 +721,13 @@ class ULIP_WITH_IMAGE(nn.Module):
         The step sits on a plateau now -- 3.20 ... 3.27 ms for every combination of {grouping ahead, tokenizer ahead, neither} x
         {60 ... 85 %} on that box: what remains is the kernels' own resource time.  Round 4, re-measured on two boxes after the
         prompt chain lost its un-scaling multiply and gained the one-launch optimizer: 60 / 70 / 80 / 85 / 90 / 100 % -> 3.309 /
-        3.233 / 3.154 | 3.115 / 3.125 / 3.197 / 3.581 ms: default 80.)"""
+        3.233 / 3.154 | 3.115 / 3.125 / 3.197 / 3.581 ms IN ORDER (tools/step_parts.py), but with the grouping / tokenizer stage
+        running ahead (Trainer.inputs_ready, bench.py's loop) the chain is the longer side again and wants more room: ahead 70 /
+        80 % -> 3.064 / 3.155 ms, in order 70 / 80 / 90 % -> 3.185 / 3.104 / 3.180 ms (same box, tools/ab_env.py bench:C2).  The
+        default follows the mode: 70 % when this step's grouping ran ahead, 80 % in order.)"""
         if self.training and torch.is_grad_enabled() and self.chain_priority():
-            return ops.persistent_occupancy(int(os.environ.get("PPT_TOWER_OCCUPANCY", "80")))
+            ahead = getattr(self.point_encoder, "group_ahead", None) is not None
+            return ops.persistent_occupancy(int(os.environ.get("PPT_TOWER_OCCUPANCY", "70" if ahead else "80")))
         if not self.training and not torch.is_grad_enabled() and self.eval_inputs_ready:
             # validate() with the next batch's tokenizer on its own stream: its persistent kernels leave a fifth of the CUs to
             # the blocks they run beside (C2 eval 2.44 -> 2.40 ms; 60 %: 2.43, 40 %: 2.56)
