@@ -59,6 +59,22 @@ def test_c2_full_batch_32x1024():
             feats[prec] = m.point_encoder(pc).float().cpu()
     rel = ((feats[torch.bfloat16] - feats[torch.float32]).norm() / feats[torch.float32].norm()).item()
     assert rel < 2e-2, rel
+    # ---- the eval tokenizer's ONE-kernel second half (csrc/mpn34.hip) against the two-kernel path it replaces
+    # (conv3 written to HBM, BatchNorm + ReLU applied while conv4 reads it back), whole batch, and no further from fp32
+    from ppt_amd import engine
+    saved = engine.FUSED_CONV34
+    try:
+        engine.FUSED_CONV34 = False
+        m.point_encoder._graphs.clear()
+        with torch.no_grad():
+            unfused = m.point_encoder(pc).float().cpu()
+    finally:
+        engine.FUSED_CONV34 = saved
+        m.point_encoder._graphs.clear()
+    rel_f = ((feats[torch.bfloat16] - unfused).norm() / unfused.norm()).item()
+    rel_u = ((unfused - feats[torch.float32]).norm() / feats[torch.float32].norm()).item()
+    print(f"PARITY C2 eval features, 16-bit vs fp32: fused conv3+conv4 {rel:.4g}, unfused {rel_u:.4g}; fused vs unfused {rel_f:.4g}")
+    assert rel_f < 5e-3 and rel < rel_u * 1.25 + 1e-4, (rel, rel_u, rel_f)
     # ---- the training step is bit-reproducible
     runs = []
     for _ in range(2):
