@@ -46,7 +46,7 @@ const char *ppt_strerror(int code);
  *    ppt_bn_rows_bwd_apply (half_dtype), ppt_*_half entry points.
  * 4: gradient scaling local to the 16-bit backward stages -- ppt_convert_scaled (new), ppt_rows_matmul_f32 (alpha),
  *    ppt_prompt_rows_bwd (scale); ppt_adamw_step (skipped counter), ppt_adamw_multi (new); ppt_cross_entropy_rows (ignore_index);
- *    ppt_mini_pointnet_conv34_half + ppt_mpn34_retile + ppt_scale_rows_convert + ppt_health_check (new), ppt_mini_pointnet_conv3_half (y may be
+ *    ppt_mini_pointnet_conv34_half + ppt_mpn34_retile + ppt_scale_rows_convert + ppt_health_check + ppt_weights_prep (new), ppt_mini_pointnet_conv3_half (y may be
  *    NULL: statistics only). */
 int ppt_abi_version(void);
 
@@ -536,6 +536,18 @@ int ppt_convert(const void *src, int src_dtype, void *dst, int dst_dtype, int64_
 /* dst = convert(src * scale), scale > 0: the operand copy of an fp32 activation gradient at the entry of a 16-bit backward
  * stage, multiplied by the stage's power-of-two gradient scale on the way (exact; ppt_amd/gradscale.py). */
 int ppt_convert_scaled(const void *src, int src_dtype, void *dst, int dst_dtype, int64_t n, float scale, void *stream);
+/* The 16-bit operand copies of MANY trained weights in one launch (the part-seg decoder re-makes 15 of them, each with its
+ * transpose, every step: pointbert/pointnet2_utils.py:297-467 trains all of its convs).  Item i: A = w[:, col0 : col0 + K] (f32, row
+ * stride ldw elements), minus w[:, sub_col0 : sub_col0 + K] when sub_col0 >= 0 (DGCNN_Propagation's Wb - Wa, see
+ * ppt_amd/autograd.py); out [N, Kp] = convert(A) with columns K .. Kp - 1 zero (may be NULL); out_t [Kp, N] = its transpose (may be
+ * NULL).  `items` is a HOST array (it travels as a kernel argument, PPT_WPREP_MAX items per launch); dtype = PPT_BF16 | PPT_F16. */
+#define PPT_WPREP_MAX 32
+typedef struct ppt_wprep_item {
+    const float *w; int64_t ldw;
+    int N, col0, K, sub_col0, Kp;
+    void *out, *out_t;
+} ppt_wprep_item;
+int ppt_weights_prep(const ppt_wprep_item *items, int count, int dtype, void *stream);
 /* *flags |= bit when any of the n values of x (any dtype) is not finite; *maxabs (optional; a non-negative float the caller
  * initialised) = max(*maxabs, max |x| over the finite values).  One small launch: the overflow flag of a 16-bit stage's output
  * (ppt_amd/health.py) and the range probe of tools/fp16_stress.py. */

@@ -54,6 +54,12 @@ class AdamwTensor(ctypes.Structure):
     _fields_ = [("p", c_void_p), ("g", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p), ("n", c_int64), ("step", c_int)]
 
 
+class WprepItem(ctypes.Structure):
+    """struct ppt_wprep_item (include/ppt_hip.h)."""
+    _fields_ = [("w", c_void_p), ("ldw", c_int64), ("N", c_int), ("col0", c_int), ("K", c_int), ("sub_col0", c_int), ("Kp", c_int),
+                ("out", c_void_p), ("out_t", c_void_p)]
+
+
 class RowGemmParams(ctypes.Structure):
     """struct ppt_rowgemm_params (include/ppt_hip.h) -- field order must match the header."""
     _fields_ = [
@@ -165,6 +171,7 @@ _SIGNATURES = {
     "ppt_prompt_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ppt_prompt_rows_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "ppt_convert": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
+    "ppt_weights_prep": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "ppt_health_check": (c_int, [c_void_p, c_int, c_int64, c_void_p, ctypes.c_uint32, c_void_p, c_void_p]),
     "ppt_scale_rows_convert": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ppt_convert_scaled": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_float, c_void_p]),

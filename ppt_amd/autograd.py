@@ -1,6 +1,8 @@
 """torch.autograd bridges onto the C-ABI GEMM for layers whose WEIGHTS train (the part-segmentation decoder,
 models/pointbert/pointnet2_utils.py:297-467).  The frozen towers do not use these: their forward/backward are
 the hand-scheduled pipelines of ppt_amd.engine."""
+import os
+
 import torch
 
 from . import gradscale, ops
@@ -164,12 +166,13 @@ def _w_operand(w, prec):
     return _pad_k(w.detach().reshape(w.shape[0], -1).float(), _mult(prec), prec)
 
 
-def _conv_bn_relu_fwd(xT, w, b, bn, training, prec, out_dtype):
+def _conv_bn_relu_fwd(xT, w, b, bn, training, prec, out_dtype, wprep=None):
     """relu(bn(conv(x))) over rows (pointnet2_utils.py:362-366): x [M, Kp] in the operand dtype -> (h [M, N] in out_dtype,
     what the backward needs).  The conv output is kept in fp32 (the BatchNorm statistics and its backward read it); its
-    chunk statistics come out of the GEMM epilogue."""
+    chunk statistics come out of the GEMM epilogue.  wprep = (operand copy [N, Kp], its transpose [Kp, N]) when the caller made
+    them already (decoder_weight_prep: all of the decoder's weights in one launch)."""
     M = xT.shape[0]
-    wT = _w_operand(w, prec)
+    wT, wTT = wprep if wprep is not None else (_w_operand(w, prec), None)
     N = wT.shape[0]
     st = None
     if training and M % 32 == 0:
@@ -185,7 +188,7 @@ def _conv_bn_relu_fwd(xT, w, b, bn, training, prec, out_dtype):
         sc, sh, mean, rstd = ops.bn_finalize(g, be, False, running_mean=bn.running_mean, running_var=bn.running_var, eps=bn.eps,
                                              want_moments=True)
     h = ops.bn_act_rows(y, sc, sh, out_dtype)
-    return h, (xT, wT, y, sc, sh, mean, rstd)
+    return h, (xT, wT, y, sc, sh, mean, rstd, wTT)
 
 
 # (Tried: the weight-gradient work of every layer -- dW, db: nothing downstream waits for them -- forked onto a second stream
@@ -194,7 +197,7 @@ def _conv_bn_relu_fwd(xT, w, b, bn, training, prec, out_dtype):
 # branch's pending reads.  The backward stays one chain.)
 def _conv_bn_relu_bwd(dh, saved, training, prec, w, need_dx):
     """-> (dx [M, Kp] f32 | None, dW like w, db [N], dgamma, dbeta) for _conv_bn_relu_fwd; dh [M, N] f32."""
-    xT, wT, y, sc, sh, mean, rstd = saved
+    xT, wT, y, sc, sh, mean, rstd, wTT = saved
     bf = prec in ops.HALF
     res = ops.bn_rows_backward(dh.contiguous().float(), y, sc, sh, mean, rstd, True, training, want_dx=not bf, want_bf16=bf,
                                half_dtype=prec if bf else torch.bfloat16)
@@ -204,7 +207,7 @@ def _conv_bn_relu_bwd(dh, saved, training, prec, w, need_dx):
     dW = ops.gemm_tn_splitk(dyT, xT)
     dW = (dW if dW.shape[1] == K else dW[:, :K]).reshape(w.shape)
     db = ops.col_sums(dyT)
-    dx = ops.gemm(dyT, ops.transpose(wT), out_dtype=torch.float32) if need_dx else None
+    dx = ops.gemm(dyT, wTT if wTT is not None else ops.transpose(wT), out_dtype=torch.float32) if need_dx else None
     return dx, dW, db, dgamma, dbeta
 
 
@@ -220,8 +223,9 @@ class _FeaturePropagation(torch.autograd.Function):
         p2 = points2.detach().float().contiguous()
         p1 = points1.detach().float().contiguous() if points1 is not None else None
         rows, wgt = ops.three_nn_interp(p1, p2, idx, dist, prec, _mult(prec))
-        h0, s0 = _conv_bn_relu_fwd(rows, w0, b0, mod.mlp_bns[0], training, prec, prec)
-        h1, s1 = _conv_bn_relu_fwd(h0, w1, b1, mod.mlp_bns[1], training, prec, torch.float32)
+        wp = getattr(ctx, "wprep", None) or (None, None)
+        h0, s0 = _conv_bn_relu_fwd(rows, w0, b0, mod.mlp_bns[0], training, prec, prec, wprep=wp[0])
+        h1, s1 = _conv_bn_relu_fwd(h0, w1, b1, mod.mlp_bns[1], training, prec, torch.float32, wprep=wp[1])
         ctx.s0, ctx.s1, ctx.idx, ctx.wgt = s0, s1, idx, wgt
         ctx.training, ctx.prec, ctx.w0, ctx.w1 = training, prec, w0, w1
         ctx.D1, ctx.S, ctx.D2 = (0 if p1 is None else p1.shape[2]), p2.shape[1], p2.shape[2]
@@ -254,7 +258,7 @@ class _ConvBNReLURows(torch.autograd.Function):
     def forward(ctx, x, w, b, g, be, conv_bn, prec):
         bn, training = conv_bn
         xT = _pad_k(x.detach().float().contiguous(), _mult(prec), prec)
-        h, s = _conv_bn_relu_fwd(xT, w, b, bn, training, prec, torch.float32)
+        h, s = _conv_bn_relu_fwd(xT, w, b, bn, training, prec, torch.float32, wprep=getattr(ctx, "wprep", None))
         ctx.s, ctx.training, ctx.prec, ctx.w, ctx.K = s, training, prec, w, x.shape[1]
         ctx.grad_scale = gradscale.current(prec, default_rows=x.shape[0])      # a 16-bit backward stage (ppt_amd/gradscale.py)
         return h
@@ -287,8 +291,13 @@ class _DGCNNLayer(torch.autograd.Function):
         K = idx.shape[2]
         w2 = w.detach().reshape(w.shape[0], -1).float()
         Cout = w2.shape[0]
-        waT = _pad_k(w2[:, :C], _mult(prec), prec)
-        wdT = _pad_k(w2[:, C:] - w2[:, :C], _mult(prec), prec)
+        wp = getattr(ctx, "wprep", None)
+        if wp is not None:
+            (waT, waTT), (wdT, wdTT) = wp
+        else:
+            waT = _pad_k(w2[:, :C], _mult(prec), prec)
+            wdT = _pad_k(w2[:, C:] - w2[:, :C], _mult(prec), prec)
+            waTT = wdTT = None
         xkT = _pad_k(x_k.detach().reshape(B * S, C).float(), _mult(prec), prec)
         xqT = xkT if x_q is x_k else _pad_k(x_q.detach().reshape(B * Nq, C).float(), _mult(prec), prec)
         P = ops.gemm(xkT, waT, out_dtype=torch.float32)
@@ -297,7 +306,7 @@ class _DGCNNLayer(torch.autograd.Function):
         y = y.view(B, Nq, K, Cout)
         g, b = gn_w.detach().float().contiguous(), gn_b.detach().float().contiguous()
         out, arg, mean, rstd = ops.gn_lrelu_max_forward(y, g, b, gn.num_groups, gn.eps, slope)
-        ctx.saved = (xkT, xqT, waT, wdT, y, out, arg, mean, rstd, g, idx)
+        ctx.saved = (xkT, xqT, waT, wdT, y, out, arg, mean, rstd, g, idx, waTT, wdTT)
         ctx.groups, ctx.slope, ctx.prec, ctx.w, ctx.C, ctx.S, ctx.same = gn.num_groups, slope, prec, w, C, S, x_q is x_k
         ctx.grad_scale = gradscale.current(prec, default_rows=B * Nq)          # a 16-bit backward stage (ppt_amd/gradscale.py)
         return out
@@ -305,7 +314,7 @@ class _DGCNNLayer(torch.autograd.Function):
     @staticmethod
     @gradscale.scaled_backward
     def backward(ctx, dout):
-        xkT, xqT, waT, wdT, y, out, arg, mean, rstd, g, idx = ctx.saved
+        xkT, xqT, waT, wdT, y, out, arg, mean, rstd, g, idx, waTT, wdTT = ctx.saved
         B, Nq, K, Cout = y.shape
         C, prec = ctx.C, ctx.prec
         dy, dgamma, dbeta = ops.gn_lrelu_max_backward(y, dout.contiguous().float(), out, arg, mean, rstd, g, ctx.groups, ctx.slope)
@@ -318,9 +327,9 @@ class _DGCNNLayer(torch.autograd.Function):
         dW = torch.cat([dWa - dWd, dWd], dim=1).reshape(ctx.w.shape)
         dxk = dxq = None
         if ctx.needs_input_grad[0]:
-            dxk = ops.gemm(dPT, ops.transpose(waT), out_dtype=torch.float32)[:, :C].reshape(B, ctx.S, C)
+            dxk = ops.gemm(dPT, waTT if waTT is not None else ops.transpose(waT), out_dtype=torch.float32)[:, :C].reshape(B, ctx.S, C)
         if ctx.needs_input_grad[1]:
-            dxq = ops.gemm(dQT, ops.transpose(wdT), out_dtype=torch.float32)[:, :C].reshape(B, Nq, C)
+            dxq = ops.gemm(dQT, wdTT if wdTT is not None else ops.transpose(wdT), out_dtype=torch.float32)[:, :C].reshape(B, Nq, C)
         return dxk, dxq, dW, dgamma, dbeta, None, None, None, None
 
 
@@ -357,18 +366,56 @@ def partseg_decoder_params(pe):
     return ps + [pe.conv1.weight, pe.conv1.bias, pe.bn1.weight, pe.bn1.bias]
 
 
-def _fp_forward(mod, xyz1, xyz2, points1, points2, need_dp2):
+DECODER_WPREP = os.environ.get("PPT_DECODER_WPREP", "1") != "0"          # 0: per-weight conversions (A/B runs)
+
+
+def decoder_weight_prep(pe):
+    """The 16-bit operand copy AND its transpose of every conv weight of the decoder -- 6 feature-propagation convs, the Wa /
+    (Wb - Wa) halves of the 4 DGCNN convs, conv1: 15 pairs -- in ONE launch (ppt_weights_prep) instead of ~41: per weight and step
+    the per-module path pays a zero-fill + padded copy or a slice copy + convert (+ a subtraction for Wb - Wa) in the forward and a
+    transpose in the backward, and these weights all train, so nothing can be cached across steps.  Same values bit for bit.
+    -> {key: (wT [N, Kp], wTT [Kp, N])}, keys (module, layer index) / (module, layer, 'a' | 'd'); None in the fp32 mode."""
+    prec = pe._dec_precision
+    if prec not in ops.HALF or not DECODER_WPREP:
+        return None
+    mult = _mult(prec)
+    keys, items = [], []
+
+    def add(key, w, col0, K, sub):
+        w2 = w.detach().reshape(w.shape[0], -1)
+        if w2.dtype != torch.float32 or not w2.is_contiguous():
+            w2 = w2.float().contiguous()
+        keys.append(key)
+        items.append((w2, col0, K, sub, (K + mult - 1) // mult * mult))
+    for fp in (pe.propagation_0, pe.propagation_1, pe.propagation_2):
+        for li, conv in enumerate(fp.mlp_convs):
+            add((fp, li), conv.weight, 0, conv.weight.shape[1], None)
+    for dg in (pe.dgcnn_pro_1, pe.dgcnn_pro_2):
+        for li, layer in enumerate((dg.layer1, dg.layer2)):
+            C = layer[0].weight.shape[1] // 2
+            add((dg, li, 'a'), layer[0].weight, 0, C, None)             # Wa
+            add((dg, li, 'd'), layer[0].weight, C, C, 0)                # Wb - Wa
+    add((pe, 'conv1'), pe.conv1.weight, 0, pe.conv1.weight.shape[1], None)
+    return dict(zip(keys, ops.weights_prep(items, prec)))
+
+
+def _fp_forward(mod, xyz1, xyz2, points1, points2, need_dp2, prep=None):
     idx, _, d = ops.knn_group(xyz2.contiguous().float(), xyz1.contiguous().float(), 3, want_nbhd=False, want_dist=True)
     c = _Ctx((need_dp2,))
+    if prep is not None:
+        c.wprep = (prep[(mod, 0)], prep[(mod, 1)])
     c0, c1, n0, n1 = mod.mlp_convs[0], mod.mlp_convs[1], mod.mlp_bns[0], mod.mlp_bns[1]
     out = _FeaturePropagation.forward(c, points2, c0.weight, c0.bias, n0.weight, n0.bias, c1.weight, c1.bias, n1.weight, n1.bias,
                                       mod, idx, d, points1, mod.precision)
     return out, c
 
 
-def _dg_forward(mod, seq, coor_q, x_q, coor_k, x_k, need_k, need_q):
+def _dg_forward(mod, seq, coor_q, x_q, coor_k, x_k, need_k, need_q, prep=None):
     idx, _ = ops.knn_group(coor_k.contiguous(), coor_q.contiguous(), mod.k, want_nbhd=False)
     c = _Ctx((need_k, need_q))
+    if prep is not None:
+        li = 0 if seq is mod.layer1 else 1
+        c.wprep = (prep[(mod, li, 'a')], prep[(mod, li, 'd')])
     out = _DGCNNLayer.forward(c, x_k, x_q, seq[0].weight, seq[1].weight, seq[1].bias, idx, seq[1], 0.2, mod.precision)
     return out, c
 
@@ -378,14 +425,17 @@ def partseg_decoder_forward(pe, f_a, f_b, f_c, center, c1, c2, pts, cls_label, d
     factors [B,N,128] or None."""
     B, N, _ = pts.shape
     f0 = torch.cat([cls_label.float().view(B, 1, 16).expand(-1, N, -1), pts], dim=-1)
-    F2, k1 = _fp_forward(pe.propagation_2, c2, center, c2, f_b, False)
-    F1, k2 = _fp_forward(pe.propagation_1, c1, center, c1, f_a, False)
-    L1, k3a = _dg_forward(pe.dgcnn_pro_2, pe.dgcnn_pro_2.layer1, c2, F2, center, f_c, False, True)
-    L2, k3b = _dg_forward(pe.dgcnn_pro_2, pe.dgcnn_pro_2.layer2, c2, L1, c2, L1, True, True)
-    L3, k4a = _dg_forward(pe.dgcnn_pro_1, pe.dgcnn_pro_1.layer1, c1, F1, c2, L2, True, True)
-    L4, k4b = _dg_forward(pe.dgcnn_pro_1, pe.dgcnn_pro_1.layer2, c1, L3, c1, L3, True, True)
-    F0, k5 = _fp_forward(pe.propagation_0, pts, c1, f0, L4, True)
+    prep = decoder_weight_prep(pe)               # every weight's operand copy + transpose: one launch
+    F2, k1 = _fp_forward(pe.propagation_2, c2, center, c2, f_b, False, prep)
+    F1, k2 = _fp_forward(pe.propagation_1, c1, center, c1, f_a, False, prep)
+    L1, k3a = _dg_forward(pe.dgcnn_pro_2, pe.dgcnn_pro_2.layer1, c2, F2, center, f_c, False, True, prep)
+    L2, k3b = _dg_forward(pe.dgcnn_pro_2, pe.dgcnn_pro_2.layer2, c2, L1, c2, L1, True, True, prep)
+    L3, k4a = _dg_forward(pe.dgcnn_pro_1, pe.dgcnn_pro_1.layer1, c1, F1, c2, L2, True, True, prep)
+    L4, k4b = _dg_forward(pe.dgcnn_pro_1, pe.dgcnn_pro_1.layer2, c1, L3, c1, L3, True, True, prep)
+    F0, k5 = _fp_forward(pe.propagation_0, pts, c1, f0, L4, True, prep)
     k6 = _Ctx((True,))
+    if prep is not None:
+        k6.wprep = prep[(pe, 'conv1')]
     y = _ConvBNReLURows.forward(k6, F0.reshape(B * N, -1), pe.conv1.weight, pe.conv1.bias, pe.bn1.weight, pe.bn1.bias,
                                 (pe.bn1, pe.training), pe._dec_precision).view(B, N, -1)
     if drop is not None:

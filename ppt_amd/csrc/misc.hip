@@ -252,6 +252,50 @@ __global__ __launch_bounds__(256) void reduce_rows_small_kernel(const float *__r
     out[d] = accumulate ? out[d] + (float)s : (float)s;
 }
 
+// ---- operand copies of many weights in ONE launch (ppt_weights_prep) --------------------------------------------------------------
+// item i: A = W_i[:, col0 : col0 + K] (f32, row stride ldw), minus W_i[:, sub_col0 : sub_col0 + K] when sub_col0 >= 0 (the DGCNN layer's
+// Wb - Wa); out [N, Kp] = A in the 16-bit format, columns K .. Kp - 1 zero; out_t [Kp, N] = its transpose (the B operand of dX = dY @ W).
+// A workgroup = one 32 x 32 tile of one item (found by a scan of the block prefix), transposed through LDS.
+struct wprep_table {
+    const float *w[PPT_WPREP_MAX];
+    void *out[PPT_WPREP_MAX], *out_t[PPT_WPREP_MAX];
+    int ldw[PPT_WPREP_MAX], N[PPT_WPREP_MAX], col0[PPT_WPREP_MAX], K[PPT_WPREP_MAX], sub_col0[PPT_WPREP_MAX], Kp[PPT_WPREP_MAX];
+    int first_block[PPT_WPREP_MAX + 1];
+    int count;
+};
+
+template <typename TD>
+__global__ __launch_bounds__(256) void weights_prep_kernel(const wprep_table tb)
+{
+    __shared__ float tile[32][33];
+    int t = 0;
+    while (t + 1 < tb.count && (int)blockIdx.x >= tb.first_block[t + 1]) ++t;
+    const int N = tb.N[t], K = tb.K[t], Kp = tb.Kp[t], ldw = tb.ldw[t];
+    const int tiles_k = (Kp + 31) / 32;
+    const int lb = (int)blockIdx.x - tb.first_block[t];
+    const int n0 = (lb / tiles_k) * 32, k0 = (lb % tiles_k) * 32;
+    const float *w = tb.w[t] + tb.col0[t];
+    const float *ws = tb.sub_col0[t] >= 0 ? tb.w[t] + tb.sub_col0[t] : nullptr;
+    TD *out = reinterpret_cast<TD *>(tb.out[t]), *out_t = reinterpret_cast<TD *>(tb.out_t[t]);
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;                 // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int n = n0 + i, k = k0 + tx;
+        float v = 0.f;
+        if (n < N && k < K) {
+            v = w[(int64_t)n * ldw + k];
+            if (ws) v -= ws[(int64_t)n * ldw + k];
+        }
+        tile[i][tx] = v;
+        if (n < N && k < Kp && out) dt<TD>::store(out + (int64_t)n * Kp + k, v);
+    }
+    __syncthreads();
+    if (out_t)
+        for (int i = ty; i < 32; i += 8) {
+            const int k = k0 + i, n = n0 + tx;
+            if (k < Kp && n < N) dt<TD>::store(out_t + (int64_t)k * N + n, tile[tx][i]);
+        }
+}
+
 template <typename TS>
 int convert_from(const void *src, void *dst, int dd, int64_t n, float scale, hipStream_t s)
 {
@@ -300,6 +344,32 @@ extern "C" int ppt_cls_max_pool(const void *x, int x_dtype, int B, int T, int D,
     else
         return PPT_EINVAL;
     PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
+extern "C" int ppt_weights_prep(const ppt_wprep_item *items, int count, int dtype, void *stream)
+{
+    if (!items || count <= 0 || (dtype != PPT_BF16 && dtype != PPT_F16)) return PPT_EINVAL;
+    for (int c0 = 0; c0 < count; c0 += PPT_WPREP_MAX) {
+        wprep_table tb;
+        tb.count = count - c0 < PPT_WPREP_MAX ? count - c0 : PPT_WPREP_MAX;
+        int64_t blocks = 0;
+        for (int i = 0; i < tb.count; ++i) {
+            const ppt_wprep_item &it = items[c0 + i];
+            if (!it.w || (!it.out && !it.out_t) || it.N <= 0 || it.K <= 0 || it.Kp < it.K || it.col0 < 0 || it.ldw < it.col0 + it.K ||
+                (it.sub_col0 >= 0 && it.ldw < it.sub_col0 + it.K))
+                return PPT_EINVAL;
+            tb.w[i] = it.w; tb.out[i] = it.out; tb.out_t[i] = it.out_t; tb.ldw[i] = (int)it.ldw; tb.N[i] = it.N; tb.col0[i] = it.col0;
+            tb.K[i] = it.K; tb.sub_col0[i] = it.sub_col0; tb.Kp[i] = it.Kp;
+            tb.first_block[i] = (int)blocks;
+            blocks += (int64_t)((it.N + 31) / 32) * ((it.Kp + 31) / 32);
+            if (blocks > 0x7fffffff) return PPT_EUNSUPPORTED;
+        }
+        tb.first_block[tb.count] = (int)blocks;
+        if (dtype == PPT_F16) hipLaunchKernelGGL(weights_prep_kernel<f16_t>, dim3((unsigned)blocks), dim3(256), 0, ppt_stream(stream), tb);
+        else hipLaunchKernelGGL(weights_prep_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, ppt_stream(stream), tb);
+        PPT_CHECK_LAUNCH();
+    }
     return PPT_OK;
 }
 

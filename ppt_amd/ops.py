@@ -896,6 +896,25 @@ def convert(src, dst_dtype, scale=1.0):
     return dst
 
 
+def weights_prep(items, dtype):
+    """items: list of (w f32 [N, ld] contiguous 2-D view, col0, K, sub_col0 | None, Kp) -> list of (out [N, Kp], out_t [Kp, N]) in
+    `dtype`: convert(w[:, col0:col0+K] (- w[:, sub_col0:sub_col0+K])), zero-padded to Kp columns, and its transpose -- ONE launch for
+    all items (ppt_weights_prep)."""
+    assert dtype in HALF
+    arr = (_lib.WprepItem * len(items))()
+    outs = []
+    for a, (w, col0, K, sub, Kp) in zip(arr, items):
+        _chk(w, torch.float32, "w")
+        assert w.dim() == 2
+        N = w.shape[0]
+        out = torch.empty((N, Kp), dtype=dtype, device=w.device)
+        out_t = torch.empty((Kp, N), dtype=dtype, device=w.device)
+        a.w, a.ldw, a.N, a.col0, a.K, a.sub_col0, a.Kp, a.out, a.out_t = _p(w), w.shape[1], N, col0, K, (-1 if sub is None else sub), Kp, _p(out), _p(out_t)
+        outs.append((out, out_t))
+    _lib.check(_lib.lib().ppt_weights_prep(ctypes.cast(arr, ctypes.c_void_p), len(items), dtype_code(dtype), _stream()), "ppt_weights_prep")
+    return outs
+
+
 def health_check(x, flags, bit, maxabs=None):
     """flags[0] |= bit if x (any dtype, contiguous) holds a non-finite value; maxabs[0] = max(maxabs[0], max |finite x|) when
     given (ppt_health_check).  flags: int32 [1]; maxabs: f32 [1], non-negative."""

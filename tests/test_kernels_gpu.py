@@ -1432,3 +1432,24 @@ def test_mini_pointnet_conv3_statistics_pass_without_store(ops):
     y = ops.mini_pointnet_conv3(y2, w, gterm, st_a)
     assert ops.mini_pointnet_conv3(y2, w, gterm, st_b, store=False) is None and y is not None
     assert torch.equal(st_a[0], st_b[0]) and torch.equal(st_a[1], st_b[1])
+
+
+def test_weights_prep_matches_the_per_weight_conversions(ops):
+    """ppt_weights_prep (every decoder weight's padded 16-bit operand copy + its transpose in one launch) against the per-weight
+    path it replaces (ppt_amd.autograd._pad_k / ops.transpose): bit-identical, including the DGCNN layer's Wb - Wa difference,
+    K not a multiple of 8 (zero padding), N not a multiple of 32, and more items than one launch takes."""
+    from ppt_amd.autograd import _pad_k
+    g = torch.Generator().manual_seed(5)
+    for T in (torch.float16, torch.bfloat16):
+        ws = [(torch.randn(1536, 387, generator=g) * 0.05).cuda(), (torch.randn(384, 1536, generator=g) * 0.03).cuda(),
+              (torch.randn(512, 768, generator=g) * 0.04).cuda(), (torch.randn(128, 384, generator=g) * 0.05).cuda(),
+              (torch.randn(50, 403, generator=g) * 0.05).cuda()]
+        items = [(ws[0], 0, 387, None, 392), (ws[1], 0, 1536, None, 1536), (ws[2], 0, 384, None, 384), (ws[2], 384, 384, 0, 384),
+                 (ws[3], 0, 384, None, 384), (ws[4], 0, 403, None, 408)]
+        items = items * 7                                              # 42 items: two launches
+        outs = ops.weights_prep(items, T)
+        for (w, c0, K, sub, Kp), (o, ot) in zip(items, outs):
+            a = w[:, c0:c0 + K] - (w[:, sub:sub + K] if sub is not None else 0)
+            ref = _pad_k(a.contiguous(), 8, T)
+            assert tuple(o.shape) == (w.shape[0], Kp) and torch.equal(o, ref)
+            assert torch.equal(ot, ops.transpose(ref)) and torch.equal(ot, ref.t().contiguous())
