@@ -416,15 +416,23 @@ def main():
         g = summ["gemm_bf16"]
         g_ms = g["ms"] - overhead_ms * g["launches"]
         achieved = g["executed"] / (g_ms * 1e-3) / 1e12          # EXECUTED FLOPs; the model's figure beside it
-        traffic = None          # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE), see profiles/
-        for rnd in ("r04", "r03", "r02", "r01"):
+        # HBM bytes per launch of the family: NOT measured in this run (PMC counters need rocprofv3 around the process) -- the
+        # figure of the newest committed profile of this same command (two --pmc passes: FETCH_SIZE x2 + WRITE_SIZE), labelled
+        # with its source; likewise the rocprofv3 kernel-trace fraction of that round beside the live event-bracket one
+        traffic = traffic_source = rocprof_family = None
+        for rnd in ("r05", "r04", "r03", "r02", "r01"):
             tf = os.path.join(ROOT, "profiles", f"{rnd}_gemm_hbm_traffic.json")
             if a.config == "C2" and os.path.exists(tf):
-                traffic = round(json.load(open(tf))["hbm_bytes_per_launch"])
+                tj = json.load(open(tf))
+                traffic = round(tj["hbm_bytes_per_launch"])
+                traffic_source = f"profiles/{rnd}_gemm_hbm_traffic.json (rocprofv3 --pmc passes of this command, round {rnd[1:]}; not measured in this run)"
+                rocprof_family = tj.get("rocprof_family")
                 break
         roof = {"bound": "mfma", "kernel": "16-bit (fp16 / bf16) MFMA GEMM family (ppt_amd/csrc/gemm.hip, rowgemm.hip, mlp_fused.hip, mpn1/mpn3/mpn4.hip)",
                 "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                "frac_source": "live HIP-event brackets on the launch stream, dispatch gap subtracted (reads ~8 % above rocprofv3's kernel-only durations)",
+                "rocprof_family": rocprof_family,
                 "launches_per_step": g["launches"] // a.steps,
                 "avg_launch_us": round(1e3 * g_ms / g["launches"], 2),
                 "avg_bracket_us": round(1e3 * g["ms"] / g["launches"], 2), "event_overhead_us": round(1e3 * overhead_ms, 2),

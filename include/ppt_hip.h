@@ -41,7 +41,8 @@ extern "C" {
                      * ppt_amd/gradscale.py); bf16 stays the format of PointNet++ / PointMLP */
 
 const char *ppt_strerror(int code);
-/* ABI version of this header (currently 4); bumped on any signature change or added entry point.
+/* ABI version of this header (currently 5); bumped on any signature change or added entry point.
+ * 5: ppt_labels_check (new).
  * 3: PPT_F16 (dtype arguments / struct fields), ppt_cross_entropy_rows (ignored labels, loss[2]), ppt_adamw_step (grad_scale),
  *    ppt_bn_rows_bwd_apply (half_dtype), ppt_*_half entry points.
  * 4: gradient scaling local to the 16-bit backward stages -- ppt_convert_scaled (new), ppt_rows_matmul_f32 (alpha),
@@ -516,9 +517,11 @@ int ppt_adamw_step(float *p, float *g, float *exp_avg, float *exp_avg_sq, int64_
                    float eps, float weight_decay, int step, float grad_scale, uint64_t *skipped, void *stream);
                    /* grad_scale: g is multiplied by it first (1 / loss scale of a caller that scaled its loss; 1 = none) and,
                     * when != 1, the product is written back to g, so that g ends as the gradient of the un-scaled loss.
-                    * An element whose gradient is not finite is skipped (p, moments unchanged, g = 0) and counted in
-                    * *skipped (device memory, 64-bit, atomically incremented; may be NULL): a 16-bit backward stage can
-                    * overflow where the fp32 reference cannot, and one such step must not poison the moments for good. */
+                    * skipped != NULL (device memory, 64-bit, atomically incremented): an element whose gradient is not
+                    * finite is skipped (p, moments unchanged, g = 0) and counted there -- a 16-bit backward stage can
+                    * overflow where the fp32 reference cannot, and one such step must not poison the moments for good.
+                    * skipped == NULL: torch.optim.AdamW's own behaviour (a NaN gradient propagates; main_cls.py:205-207
+                    * then stops the run) -- what the fp32 parity mode passes (ABI 5). */
 #define PPT_ADAMW_MAX_TENSORS 64
 typedef struct ppt_adamw_tensor {
     float *p, *g, *exp_avg, *exp_avg_sq;     /* device, f32, contiguous, n elements each */
@@ -552,6 +555,11 @@ int ppt_weights_prep(const ppt_wprep_item *items, int count, int dtype, void *st
  * initialised) = max(*maxabs, max |x| over the finite values).  One small launch: the overflow flag of a 16-bit stage's output
  * (ppt_amd/health.py) and the range probe of tools/fp16_stress.py. */
 int ppt_health_check(const void *x, int x_dtype, int64_t n, uint32_t *flags, uint32_t bit, float *maxabs, void *stream);
+/* *flags |= bit when any of the n labels is outside [0, C) and != ignore_index: a corrupt label, where ATen's
+ * nn.CrossEntropyLoss raises a device assert (main_cls.py:196, main_partseg.py:213).  ppt_cross_entropy_rows / ppt_head_ce_bwd
+ * make the loss NaN for such a row; this flag lets the caller tell a DATA bug from a numeric overflow (ppt_amd/health.py:
+ * BIT_LABEL raises, it never demotes a stage). */
+int ppt_labels_check(const int64_t *labels, int64_t n, int64_t C, int64_t ignore_index, uint32_t *flags, uint32_t bit, void *stream);
 /* out[n][k] = convert(scale[n] * W[n][k]) for an [N, K] window of a row-major f32 matrix (row stride ldw elements; K % 4 == 0, ldw %
  * 4 == 0, 16-byte aligned), out [N, K] contiguous in out_dtype; bs (optional, [N] f32) = scale * b + shift (b / shift may be NULL).
  * A folded BatchNorm multiplied into the weight rows of the conv in front of it (csrc/mpn34.hip's W3s / gs). */

@@ -173,6 +173,7 @@ _SIGNATURES = {
     "ppt_convert": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
     "ppt_weights_prep": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "ppt_health_check": (c_int, [c_void_p, c_int, c_int64, c_void_p, ctypes.c_uint32, c_void_p, c_void_p]),
+    "ppt_labels_check": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, ctypes.c_uint32, c_void_p]),
     "ppt_scale_rows_convert": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ppt_convert_scaled": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_float, c_void_p]),
     "ppt_transpose": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_void_p]),

@@ -66,7 +66,9 @@ class _MlpFn(torch.autograd.Function):
         y = ops.gemm(f, _opnd(w2, T, "w"), out_dtype=torch.float32, bias=b2.detach().float() if b2 is not None else None)
         ctx.save_for_backward(xt, pre, f, w1, w2)
         ctx.act, ctx.T, ctx.shape, ctx.has_b = act, T, x.shape, (b1 is not None, b2 is not None)
-        ctx.grad_scale = gradscale.current(T, default_rows=x2.shape[0])     # a 16-bit backward stage (ppt_amd/gradscale.py)
+        # a 16-bit backward stage (ppt_amd/gradscale.py).  Default when no criterion announced its row count: the BATCH size, not
+        # the token rows -- a bare block's caller averages over samples, and B x T would over-scale by ~2^9
+        ctx.grad_scale = gradscale.current(T, default_rows=x.shape[0] if x.dim() >= 3 else x2.shape[0])
         return y.view(*x.shape[:-1], w2.shape[0])
 
     @staticmethod
@@ -105,7 +107,7 @@ class _SelfAttentionFn(torch.autograd.Function):
         y = ops.gemm(a, _opnd(wproj, T, "w"), out_dtype=torch.float32, bias=bproj.detach().float() if bproj is not None else None)
         ctx.save_for_backward(xt, qkv, a, lse, wqkv, wproj)
         ctx.cfg = (B, Tn, D, heads, scale, causal, T, bqkv is not None, bproj is not None)
-        ctx.grad_scale = gradscale.current(T, default_rows=x2.shape[0])     # a 16-bit backward stage (ppt_amd/gradscale.py)
+        ctx.grad_scale = gradscale.current(T, default_rows=B)       # a 16-bit backward stage; default: the batch size (see _MlpFn)
         return y.view(B, Tn, D)
 
     @staticmethod

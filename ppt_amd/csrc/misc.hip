@@ -117,6 +117,18 @@ __global__ __launch_bounds__(256) void health_check_kernel(const TS *__restrict_
     }
 }
 
+// flags[0] |= bit when any label is outside [0, C) and is not ignore_index: a corrupt label (ATen: device assert)
+__global__ __launch_bounds__(256) void labels_check_kernel(const int64_t *__restrict__ labels, int64_t n, int64_t C, int64_t ignore_index,
+                                                           uint32_t *__restrict__ flags, uint32_t bit)
+{
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t y = labels[i];
+        if ((y < 0 || y >= C) && y != ignore_index) bad = true;
+    }
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flags, bit);
+}
+
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void transpose_kernel(const TS *__restrict__ s, TD *__restrict__ d, int rows, int cols,
                                                         int64_t ldd)
@@ -381,6 +393,15 @@ extern "C" int ppt_health_check(const void *x, int x_dtype, int64_t n, uint32_t 
     else if (x_dtype == PPT_BF16) hipLaunchKernelGGL(health_check_kernel<bf16_t>, dim3(grid), dim3(256), 0, ppt_stream(stream), (const bf16_t *)x, n, flags, bit, maxabs);
     else if (x_dtype == PPT_F16) hipLaunchKernelGGL(health_check_kernel<f16_t>, dim3(grid), dim3(256), 0, ppt_stream(stream), (const f16_t *)x, n, flags, bit, maxabs);
     else return PPT_EINVAL;
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
+extern "C" int ppt_labels_check(const int64_t *labels, int64_t n, int64_t C, int64_t ignore_index, uint32_t *flags, uint32_t bit, void *stream)
+{
+    if (!labels || !flags || n <= 0 || C <= 0) return PPT_EINVAL;
+    const unsigned grid = (unsigned)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256);
+    hipLaunchKernelGGL(labels_check_kernel, dim3(grid), dim3(256), 0, ppt_stream(stream), labels, n, C, ignore_index, flags, bit);
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }

@@ -12,8 +12,8 @@
 //     scale (ppt_amd/gradscale.py), a power of two;
 //   * adamw_multi: the same AdamW update for up to PPT_ADAMW_MAX_TENSORS tensors in ONE launch (the tensor table travels as a
 //     kernel argument) -- head_type >= 1 trains 4 ... 13 tensors, part segmentation 47.
-// Both AdamW kernels leave an element whose gradient is not finite alone (parameter and moments unchanged, gradient zeroed) and
-// COUNT it in a device word the caller reads when it wants to (train.Trainer.nonfinite_grad_elements): the fp32 reference
+// Given a skip counter (the mixed 16-bit mode), both AdamW kernels leave an element whose gradient is not finite alone (parameter and
+// moments unchanged, gradient zeroed) and COUNT it in that device word, which the caller reads when it wants to (train.Trainer.nonfinite_grad_elements): the fp32 reference
 // cannot overflow where a 16-bit backward stage can, and main_cls.py:205-207 stops on a non-finite loss.
 #include "ppt_common.h"
 
@@ -22,7 +22,7 @@ namespace {
 // one element of torch.optim.AdamW's single-tensor update; returns false (nothing written but g = 0) for a non-finite gradient
 __device__ __forceinline__ bool adamw_element(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
                                               int64_t i, float decay, float omb1, float b2, float omb2, float inv_sqrt_bc2, float eps,
-                                              float step_size, float grad_scale)
+                                              float step_size, float grad_scale, bool guard)
 {
     // grad_scale != 1: g holds the gradient of (loss / grad_scale) -- a caller that scaled its loss; the true gradient is
     // written back so that g reads like the reference's .grad afterwards (a power of two: exact)
@@ -30,7 +30,9 @@ __device__ __forceinline__ bool adamw_element(float *__restrict__ p, float *__re
     // A backward through fp16 operand stages can overflow where the fp32 reference would not: an element whose gradient is not
     // finite is left alone this step (parameter and moments keep their values, the gradient reads 0) instead of poisoning the
     // state for good, and is counted.
-    if (!(fabsf(gi) <= 3.0e38f)) { g[i] = 0.f; return false; }
+    // guard == false (no skip counter passed: the fp32 parity mode, where no stage can overflow that the reference's would not):
+    // torch.optim.AdamW's behaviour -- a NaN gradient propagates into the parameter and main_cls.py:205-207 stops the run.
+    if (guard && !(fabsf(gi) <= 3.0e38f)) { g[i] = 0.f; return false; }
     if (grad_scale != 1.f) g[i] = gi;
     float pi = p[i] * decay;
     const float mi = m[i] + (gi - m[i]) * omb1;
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256) void adamw_step_kernel(float *__restrict__ p, 
     PPT_PRIO(prio);
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    if (!adamw_element(p, g, m, v, i, decay, omb1, b2, omb2, inv_sqrt_bc2, eps, step_size, grad_scale) && skipped) atomicAdd(skipped, 1ull);
+    if (!adamw_element(p, g, m, v, i, decay, omb1, b2, omb2, inv_sqrt_bc2, eps, step_size, grad_scale, skipped != nullptr)) atomicAdd(skipped, 1ull);
 }
 
 // the tensor table of ppt_adamw_multi as a kernel argument (48 B per tensor: 64 tensors = 3 KB of the 4 KB argument segment)
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const adamw_table tb, 
     for (int u = 0; u < 4; ++u) {
         const int64_t i = base + u * 256 + threadIdx.x;
         if (i < tb.n[t] && !adamw_element(tb.p[t], tb.g[t], tb.m[t], tb.v[t], i, decay, omb1, b2, omb2, tb.inv_sqrt_bc2[t], eps,
-                                          tb.step_size[t], grad_scale))
+                                          tb.step_size[t], grad_scale, skipped != nullptr))
             ++bad;
     }
     if (bad && skipped) atomicAdd(skipped, (unsigned long long)bad);

@@ -26,9 +26,12 @@ class WeightCache:
     """Operand-dtype / pre-transposed copies of parameters.  Frozen parameters are converted once;
     a trainable parameter is re-converted when the optimiser has bumped its version counter."""
 
-    def __init__(self, dtype):
+    def __init__(self, dtype, demoted=None):
         self.dtype = dtype
         self._c = {}
+        # stages of the OWNING model that ppt_amd/health.py moved from IEEE half back to bf16 at run time (the owner's set,
+        # shared by reference: per model, not per process -- ADVICE r4)
+        self.demoted = demoted if demoted is not None else set()
 
     def get(self, t, kind="w", cols=None, pad_to=None):
         """kind 'w': [N,K] operand copy (optionally a column slice; K zero-padded to a multiple of pad_to) in
@@ -91,21 +94,18 @@ TOKENIZER_F16 = os.environ.get("PPT_TOKENIZER_F16", "1") != "0"
 DECODER_F16 = os.environ.get("PPT_DECODER_F16", "1") != "0"
 
 
-# stages moved from IEEE half back to bf16 at run time because they overflowed (ppt_amd/health.py: demote)
-DEMOTED = set()
-
-
 def _stage_wc(wc, stage):
-    """The WeightCache a stage runs with: `wc`, or a sibling of another operand precision (kept on `wc`)."""
+    """The WeightCache a stage runs with: `wc`, or a sibling of another operand precision (kept on `wc`).  A stage that the
+    owning model's health monitor demoted (WeightCache.demoted; ppt_amd/health.py) stays on bf16."""
     dt = STAGE_DTYPE.get(stage)
-    if dt is None and wc.dtype == torch.bfloat16 and stage not in DEMOTED:
+    if dt is None and wc.dtype == torch.bfloat16 and stage not in wc.demoted:
         if (BLOCKS_F16 and stage in ("blocks", "last_block")) or (TOKENIZER_F16 and stage == "tokenizer"):
             dt = torch.float16
     if dt is None or dt == wc.dtype:
         return wc
     alts = wc.__dict__.setdefault("_alts", {})
     if dt not in alts:
-        alts[dt] = WeightCache(dt)
+        alts[dt] = WeightCache(dt, wc.demoted)
     return alts[dt]
 
 

@@ -14,98 +14,148 @@ have (tools/fp16_stress.py builds such weights and prints the per-stage ranges).
   * the optimizer kernels skip -- and count -- every gradient element that is not finite (csrc/optim.hip), so the parameters and
     Adam moments of the steps in between stay clean (a NaN loss makes every gradient NaN: the whole step is a no-op, as
     torch.cuda.amp.GradScaler would make it);
+  * the word is CLEARED behind every read (stream-ordered, on the stream the checks are queued on) and the skip counter is compared
+    with its value at the previous poll, so every poll reports what happened SINCE the last one and a later, different overflow is
+    seen as well (ADVICE r4: a sticky word let BIT_POINT / BIT_LOSS mask every later BIT_GRAD);
   * on a set bit the Trainer DEMOTES the offending side to bf16 (same MFMA rate, fp32's exponent range, 8 significand bits) for
     the rest of the run and says so: BIT_POINT -> tokenizer + blocks (+ part-seg decoder); BIT_LOSS alone -> text tower + head;
     BIT_GRAD (the optimizer's skip counter moved although features and loss were finite: a BACKWARD stage overflowed -- with
     gains of 10 the text tower's half gradients do, tools/fp16_stress.py) -> every stage with a 16-bit backward: text tower,
-    un-frozen last block, part-seg decoder and head.
+    un-frozen last block, part-seg decoder and head;
+  * when events keep arriving and nothing is left to demote (bf16 has fp32's range: then it is not a half overflow -- diverging
+    training or bad data), or a label is outside [0, C) (BIT_LABEL: ATen raises a device assert there), the Trainer raises
+    FloatingPointError / ValueError instead of skipping steps silently.
 """
+import contextlib
 import warnings
 
 import torch
 
-BIT_POINT, BIT_LOSS, BIT_GRAD = 1, 2, 4
+BIT_POINT, BIT_LOSS, BIT_GRAD, BIT_LABEL = 1, 2, 4, 8
+GIVE_UP_AFTER = 3            # consecutive polls with an event that no demotion can answer -> FloatingPointError
 
 
 class Monitor:
     def __init__(self, device, every=50):
         self.flags = torch.zeros((1,), dtype=torch.int32, device=device)
-        self.host = torch.zeros((1,), dtype=torch.int32).pin_memory() if torch.cuda.is_available() else torch.zeros((1,), dtype=torch.int32)
-        self.host_skipped = torch.zeros((1,), dtype=torch.int64).pin_memory() if torch.cuda.is_available() else torch.zeros((1,), dtype=torch.int64)
+        pin = torch.cuda.is_available()
+        self.host = torch.zeros((1,), dtype=torch.int32).pin_memory() if pin else torch.zeros((1,), dtype=torch.int32)
+        self.host_skipped = torch.zeros((1,), dtype=torch.int64).pin_memory() if pin else torch.zeros((1,), dtype=torch.int64)
         self.every = int(every)
         self._pending = None
-        self.seen = 0
+        self.seen = 0                       # every bit ever reported (a log, NOT a mask: detection stays armed)
         self.polls = 0
         self.skipped_seen = 0
+        self.unanswered = 0                 # consecutive polls whose event found nothing left to demote (train.Trainer)
         self.skipped = None                 # the optimizer's device counter of skipped (non-finite) gradient elements (train.Trainer)
 
     def check(self, bit, t):
-        """queue the non-finite check of tensor t on the current stream (ppt_health_check)"""
+        """queue the non-finite check of tensor t on the current stream (ppt_health_check).  Every check of a run is queued on
+        the stream poll() is called on (the caller's), which is what makes the clear in poll() race-free."""
         from . import ops
         if t is not None and t.is_cuda and t.numel():
             ops.health_check(t.detach().contiguous(), self.flags, bit)
 
-    def poll(self, step):
-        """-> bits newly seen (0 almost always).  Every `every` steps the flag word is copied to pinned memory behind the work
-        queued so far; the copy is looked at when it has completed -- normally one poll later -- so nothing ever waits."""
+    def check_labels(self, labels, n_classes, ignore_index=-100):
+        """queue the corrupt-label check (ppt_labels_check): BIT_LABEL is a data bug, reported as such, never a demotion"""
+        from . import ops
+        if labels is not None and labels.is_cuda and labels.dtype == torch.int64 and labels.numel():
+            ops.labels_check(labels.contiguous(), n_classes, ignore_index, self.flags, BIT_LABEL)
+
+    def _resolve(self):
+        bits = int(self.host.item())
+        sk = int(self.host_skipped.item())
+        # gradient elements were skipped since the last poll although features and loss were finite in the same window: a 16-bit
+        # BACKWARD stage overflowed.  (A NaN loss makes every gradient NaN: those skips are the BIT_LOSS event, not a new one.)
+        if sk > self.skipped_seen and not (bits & (BIT_POINT | BIT_LOSS | BIT_LABEL)):
+            bits |= BIT_GRAD
+        self.skipped_seen = sk
+        self.seen |= bits
+        if not bits:
+            self.unanswered = 0             # (a clean window: "consecutive" starts over)
+        return bits
+
+    def poll(self, step, side=None):
+        """-> the bits set since the previous poll (0 almost always).  Every `every` steps the flag word is copied to pinned
+        memory behind the work queued so far and cleared behind the copy; the optimizer's skip counter is copied on `side`, the
+        stream the optimizer runs on (train.Trainer: the text stream), i.e. behind this step's AdamW (a copy on the
+        caller's stream raced with it).  The copies are looked at when they have completed -- normally one poll later -- so
+        nothing ever waits.  Call at the END of a step, after the optimizer has been queued."""
         new = 0
-        if self._pending is not None and self._pending.query():
+        if self._pending is not None and all(e.query() for e in self._pending):
             self._pending = None
-            bits = int(self.host.item())
-            sk = int(self.host_skipped.item())
-            if sk > self.skipped_seen and not (bits & (BIT_POINT | BIT_LOSS)) and not (self.seen & BIT_GRAD):
-                bits |= BIT_GRAD
-            self.skipped_seen = sk
-            new = bits & ~self.seen
-            self.seen |= new
+            new = self._resolve()
         if self.every > 0 and step % self.every == 0 and self._pending is None and self.flags.is_cuda:
             self.host.copy_(self.flags, non_blocking=True)
+            self.flags.zero_()                                     # (same stream: behind the copy, in front of the next check)
+            evs = [torch.cuda.Event()]
+            evs[0].record()
             if self.skipped is not None:
-                # (the counter is written on the text stream: order the copy behind that stream's work queued so far)
-                self.host_skipped.copy_(self.skipped, non_blocking=True)
-            self._pending = torch.cuda.Event()
-            self._pending.record()
+                with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                    self.host_skipped.copy_(self.skipped, non_blocking=True)
+                    if side is not None:
+                        evs.append(torch.cuda.Event())
+                        evs[1].record()
+                    else:
+                        evs[0].record()
+            self._pending = evs
             self.polls += 1
         return new
 
-    def read_now(self):
-        """blocking read (tests, end of an epoch)"""
-        bits = int(self.flags.item())
-        new = bits & ~self.seen
-        self.seen |= bits
-        return new
+    def read_now(self, side=None):
+        """blocking read of everything since the last poll (tests, end of an epoch, after a FloatingPointError)"""
+        if self._pending is not None:
+            for e in self._pending:
+                e.synchronize()
+            self._pending = None
+            new = self._resolve()
+        else:
+            new = 0
+        if side is not None:
+            side.synchronize()
+        self.host.copy_(self.flags)
+        self.flags.zero_()
+        if self.skipped is not None:
+            self.host_skipped.copy_(self.skipped)
+        return new | self._resolve()
 
 
 def demote(model, bits):
-    """Move the side named by `bits` from IEEE half to bf16 operands for the rest of the run; returns what was done."""
-    from . import engine
+    """Move the side named by `bits` from IEEE half to bf16 operands for the rest of the run; returns what was done -- an empty
+    list when every stage the bits point at already runs on bf16 (the caller counts those: Monitor.unanswered)."""
     done = []
     pe = getattr(model, "point_encoder", None)
-    if bits & BIT_POINT:
-        engine.DEMOTED.update(("tokenizer", "blocks", "last_block", "decoder"))
+    demoted = model.__dict__.setdefault("demoted", set())
+    point_left = not {"tokenizer", "blocks", "last_block", "decoder"} <= demoted
+    if bits & BIT_POINT and point_left:
+        # (non-finite features make the loss non-finite too: BIT_LOSS in the same window is this event's echo, not a second one)
+        demoted.update(("tokenizer", "blocks", "last_block", "decoder"))
         if pe is not None and hasattr(pe, "_dec_precision"):
             pe.precision = pe.precision                           # (the setter re-derives the decoder's operand format)
         done.append("point tower (tokenizer, transformer blocks" + (", part-seg decoder" if hasattr(pe, "_dec_precision") else "") + ")")
-    elif bits & (BIT_LOSS | BIT_GRAD):
-        # the features were finite and the loss was not: the text tower or the head products; or both were finite and gradient
-        # elements were not: a 16-bit BACKWARD stage -- the text tower, the un-frozen last block, the decoder, the per-point head
+    elif bits & (BIT_POINT | BIT_LOSS | BIT_GRAD):
+        # the features were finite (or the point tower is on bf16 already) and the loss was not: the text tower or the head
+        # products; or both were finite and gradient elements were not: a 16-bit BACKWARD stage -- the text tower, the un-frozen
+        # last block, the decoder, the per-point head
         if getattr(model, "text_f16", False):
             model.text_f16 = False
             done.append("CLIP text tower")
-        engine.DEMOTED.add("head")
-        done.append("per-point head")
-        if bits & BIT_GRAD:
-            engine.DEMOTED.update(("last_block", "decoder"))
+        if "head" not in demoted:
+            demoted.add("head")
+            done.append("per-point head")
+        if bits & BIT_GRAD and not {"last_block", "decoder"} <= demoted:
+            demoted.update(("last_block", "decoder"))
             if pe is not None and hasattr(pe, "_dec_precision"):
                 pe.precision = pe.precision
             done.append("last block / part-seg decoder (the stages with a 16-bit backward)")
+    if not done:
+        return done
     if hasattr(model, "reset_caches"):
         model.reset_caches()                                      # operand copies and captured graphs were made for the old format
     elif pe is not None and hasattr(pe, "_graphs"):
         pe._graphs.clear()
-    if done:
-        warnings.warn("ppt_amd: a 16-bit stage overflowed IEEE half (non-finite " +
-                      ("point features" if bits & BIT_POINT else ("loss" if bits & BIT_LOSS else "gradients")) +
-                      "); its steps were skipped by the optimizer and these stages now run on bf16 operands: " + "; ".join(done),
-                      RuntimeWarning, stacklevel=3)
+    warnings.warn("ppt_amd: a 16-bit stage overflowed IEEE half (non-finite " +
+                  ("point features" if bits & BIT_POINT else ("loss" if bits & BIT_LOSS else "gradients")) +
+                  "); its steps were skipped by the optimizer and these stages now run on bf16 operands: " + "; ".join(done),
+                  RuntimeWarning, stacklevel=3)
     return done

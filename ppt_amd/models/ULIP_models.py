@@ -601,6 +601,9 @@ class ULIP_WITH_IMAGE(nn.Module):
         self.eval_inputs_ready = False
         self._chain_prio = None
         self.health = None                  # ppt_amd.health.Monitor (train.Trainer installs one in the mixed 16-bit mode)
+        # stages this model's monitor moved from IEEE half to bf16 (health.demote); ONE set per model, shared with the point
+        # encoder and every WeightCache of either
+        self.demoted = point_encoder.__dict__.setdefault("demoted", set()) if isinstance(point_encoder, nn.Module) else set()
         self._handoff = False               # inside forward_loss: graph outputs go straight into the next graph's input (no clone)
         self._handoff_grad = os.environ.get("PPT_HANDOFF", "1") != "0"
 
@@ -685,7 +688,7 @@ class ULIP_WITH_IMAGE(nn.Module):
         if want is None:
             want = torch.float16 if (self.precision == torch.bfloat16 and self.text_f16) else self.precision
         if self._wc is None or self._wc.dtype != want:
-            self._wc = engine.WeightCache(want)
+            self._wc = engine.WeightCache(want, self.demoted)
         return self._wc
 
     def _live_state(self):
@@ -783,7 +786,7 @@ class ULIP_WITH_IMAGE(nn.Module):
         """fp32 head products, except the per-point head of part segmentation in the performance mode: fp16 operands (_MatmulNT;
         the logit scale is then applied to the PRODUCT, so that the operands stay far inside fp16's range)."""
         if self.task == 'partseg' and self.precision == torch.bfloat16:
-            return torch.bfloat16 if "head" in engine.DEMOTED else torch.float16
+            return torch.bfloat16 if "head" in self.demoted else torch.float16
         return torch.float32
 
     def encode_text(self, prompts, tokenized_prompts=None):

@@ -344,7 +344,7 @@ class PointTransformer(nn.Module):
     # ---- plumbing -------------------------------------------------------------------------
     def _cache(self):
         if self._wc is None or self._wc.dtype != self.precision:
-            self._wc = engine.WeightCache(self.precision)
+            self._wc = engine.WeightCache(self.precision, self.__dict__.setdefault("demoted", set()))
         return self._wc
 
     def _live_state(self):
@@ -536,7 +536,7 @@ class PointTransformer_partseg(nn.Module):
         self._precision = dtype
         self._graphs.clear()
         # the decoder's GEMM operand format: IEEE half in the performance mode (engine.DECODER_F16), else as the backbone
-        self._dec_precision = torch.float16 if (dtype == torch.bfloat16 and engine.DECODER_F16 and "decoder" not in engine.DEMOTED) else dtype
+        self._dec_precision = torch.float16 if (dtype == torch.bfloat16 and engine.DECODER_F16 and "decoder" not in self.__dict__.setdefault("demoted", set())) else dtype
         for m in (self.propagation_0, self.propagation_1, self.propagation_2, self.dgcnn_pro_1, self.dgcnn_pro_2):
             m.precision = self._dec_precision
 

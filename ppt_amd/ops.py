@@ -915,6 +915,13 @@ def weights_prep(items, dtype):
     return outs
 
 
+def labels_check(labels, n_classes, ignore_index, flags, bit):
+    """flags[0] |= bit when a label lies outside [0, n_classes) and is not ignore_index (ppt_labels_check)."""
+    _chk(labels, torch.int64, "labels"); _chk(flags, torch.int32, "flags")
+    _lib.check(_lib.lib().ppt_labels_check(_p(labels), labels.numel(), int(n_classes), int(ignore_index), _p(flags), int(bit), _stream()),
+               "ppt_labels_check")
+
+
 def health_check(x, flags, bit, maxabs=None):
     """flags[0] |= bit if x (any dtype, contiguous) holds a non-finite value; maxabs[0] = max(maxabs[0], max |finite x|) when
     given (ppt_health_check).  flags: int32 [1]; maxabs: f32 [1], non-negative."""

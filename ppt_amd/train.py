@@ -82,9 +82,15 @@ class FlatGradSync:
             self.flat = g.detach().view(-1)
             self.views = [self.flat.view_as(self.params[0])]        # (readers of either see the reduced gradient)
             return
+        used = None
         if self.lazy:
             with torch.no_grad():
                 have = [(v, p.grad) for p, v in zip(self.params, self.views) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+                # a parameter no node wrote a gradient for (part-seg's conv2: constructed, unused in forward) travels as zeros and
+                # KEEPS .grad = None afterwards -- DistributedDataParallel(find_unused_parameters=True), main_partseg.py:48, leaves
+                # the gradient of a globally unused parameter untouched, so the reference's AdamW never decays or tracks it.  The
+                # graph is the same on every rank, so "unused here" is "unused everywhere".
+                used = [p.grad is not None for p in self.params]
                 for p, v in zip(self.params, self.views):
                     if p.grad is None:
                         v.zero_()
@@ -99,8 +105,9 @@ class FlatGradSync:
         if w > 1:
             self.flat.div_(w)
         if self.lazy:
-            for p, v in zip(self.params, self.views):
-                p.grad = v
+            for p, v, u in zip(self.params, self.views, used):
+                if u:
+                    p.grad = v
 
 
 class BufferBroadcast:
@@ -348,10 +355,7 @@ class Trainer:
                 pe.group_ahead = None       # the vouching covers this call's `pc` only: a forward outside step() stays in order
         if self.health is not None:
             self.health.check(2, loss)                              # (BIT_LOSS; on the caller's stream)
-            new = self.health.poll(self.it)
-            if new:
-                from . import health
-                self.demotions.append((self.it, new, health.demote(model, new)))
+            self.health.check_labels(label, pred.shape[-1], self.criterion.ignore_index)
         if side is not None:
             side.wait_stream(main)
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
@@ -378,6 +382,8 @@ class Trainer:
                 pe.decoder_gate = side.record_event()
             else:
                 main.wait_stream(side)                              # the point tower reads updated parameters
+        if self.health is not None:
+            self._health_poll(side)
         if check_finite:
             if not math.isfinite(loss.item()):                      # main_cls.py:205-207
                 raise FloatingPointError(f"Loss is {loss.item()}, stopping training")
@@ -386,6 +392,32 @@ class Trainer:
                 raise FloatingPointError(f"{bad} gradient elements were not finite (skipped by the optimizer), stopping training")
         self.it += 1
         return loss, pred
+
+    def _health_poll(self, side):
+        """End of a step (the optimizer is queued): look at what the monitor saw since its last poll and answer it -- demote the
+        half stage that overflowed (between steps: nothing of this step is in flight on the host any more, so the graphs and
+        operand copies demote() drops are re-made by the NEXT forward); a corrupt label raises; events that no demotion can
+        answer any more raise after health.GIVE_UP_AFTER polls instead of being skipped silently for the rest of the run."""
+        from . import health
+        mon = self.health
+        new = mon.poll(self.it, side)
+        if not new:
+            return
+        if new & health.BIT_LABEL:
+            raise ValueError("ppt_amd: a label outside [0, C) that is not ignore_index reached the criterion "
+                             "(nn.CrossEntropyLoss raises a device assert there): the loss of that step was NaN and the "
+                             "optimizer skipped it -- a DATA error, not a numeric overflow")
+        done = health.demote(self.model, new)
+        self.demotions.append((self.it, new, done))
+        if done:
+            mon.unanswered = 0
+            return
+        mon.unanswered += 1
+        if mon.unanswered >= health.GIVE_UP_AFTER:
+            what = "point features" if new & health.BIT_POINT else ("loss" if new & health.BIT_LOSS else "gradient elements")
+            raise FloatingPointError(f"ppt_amd: non-finite {what} in {mon.unanswered} consecutive health polls although every 16-bit "
+                                     "stage already runs on bf16 operands (fp32's range): this is not a half overflow -- the optimizer "
+                                     f"has skipped {mon.skipped_seen} gradient elements so far; stopping instead of skipping silently")
 
     def _loss(self, logits, labels):
         """self.criterion (main_cls.py:52: CrossEntropyLoss with label smoothing, mean reduction); on a GPU with <= 96 classes the
@@ -421,7 +453,10 @@ class Trainer:
             opt.step()
             return
         from . import ops
-        if self._skipped is None:
+        # the non-finite skip exists for the 16-bit backward stages only: in the fp32 parity mode the kernels get no counter and
+        # behave as torch.optim.AdamW does -- a NaN gradient reaches the parameter and main_cls.py:205-207 stops the run
+        guard = getattr(self.model, "precision", None) != torch.float32
+        if self._skipped is None and guard:
             self._skipped = torch.zeros((1,), dtype=torch.int64, device=params[0][1].device)
             if self.health is not None:
                 self.health.skipped = self._skipped
@@ -441,9 +476,9 @@ class Trainer:
                 hyper = (float(g['lr']), float(b1), float(b2), float(g['eps']), float(g['weight_decay']))
                 if len(items) == 1:
                     p_, g_, m_, v_, step = items[0]
-                    ops.adamw_step(p_, g_, m_, v_, *hyper, step, grad_scale=inv_scale, skipped=self._skipped)
+                    ops.adamw_step(p_, g_, m_, v_, *hyper, step, grad_scale=inv_scale, skipped=self._skipped if guard else None)
                 else:
-                    ops.adamw_multi(items, *hyper, grad_scale=inv_scale, skipped=self._skipped)
+                    ops.adamw_multi(items, *hyper, grad_scale=inv_scale, skipped=self._skipped if guard else None)
             for _, p in params:
                 # the kernel wrote through a raw pointer: tell autograd's version counter, as torch.optim.AdamW's in-place ops
                 # would.  Two caches key on it -- ULIP_WITH_IMAGE._te_cache (validate()'s text features) and
@@ -489,6 +524,27 @@ def reference_optimizer_state(model, optimizer):
             state[pos[id(p)]] = sd['state'][local]
     groups.append({**{k: v for k, v in g_sd.items() if k != 'params'}, 'params': list(range(len(all_params)))})
     return {'state': state, 'param_groups': groups}
+
+
+def load_reference_optimizer_state(model, optimizer, ref_state):
+    """Inverse of reference_optimizer_state: `ref_state` is an optimizer state dict indexed over model.parameters() (what
+    main_cls.py:58 / main_partseg.py:62 build and `checkpoint_best.pt` holds); `optimizer` covers any subset of the model's
+    parameters (train.Trainer: the trainable ones).  Hyper-parameters of the one param group and the per-parameter state
+    (`step`, `exp_avg`, `exp_avg_sq`) are taken over; `step` stays a host tensor, the moments go to the parameter's device."""
+    pos = {id(p): i for i, p in enumerate(model.parameters())}
+    assert len(optimizer.param_groups) == 1 and len(ref_state['param_groups']) == 1, "one param group, as main_cls.py:58"
+    g = optimizer.param_groups[0]
+    for k, v in ref_state['param_groups'][0].items():
+        if k != 'params':
+            g[k] = v
+    optimizer.state.clear()
+    for p in g['params']:
+        st = ref_state['state'].get(pos[id(p)])
+        if st is None:
+            continue
+        optimizer.state[p] = {k: (v.detach().clone().to(p.device) if torch.is_tensor(v) and k != 'step' else
+                                  (v.detach().clone().cpu() if torch.is_tensor(v) else v)) for k, v in st.items()}
+    return optimizer
 
 
 def checkpoint_payload(model, optimizer, epoch, best_acc, args, head_type=0, partseg=False, best_mean_class_iou=None,

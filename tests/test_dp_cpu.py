@@ -137,20 +137,27 @@ def _real_worker(rank, world, port, head_type, ret):
     from types import SimpleNamespace
     from ppt_amd.models import ULIP_models as M
     from ppt_amd.train import Trainer
-    args = SimpleNamespace(classnames=M.dataset_classnames("modelnet40"), template_init='', class_name_position='middle',
-                           num_learnable_prompt_tokens=32, gpu=0, task='cls', head_type=head_type, evaluate_3d=False,
-                           ulip2=False, synthetic_weights=True)
+    partseg = head_type == "partseg"
+    args = SimpleNamespace(classnames=M.dataset_classnames("shapenetpart" if partseg else "modelnet40"), template_init='',
+                           class_name_position='middle', num_learnable_prompt_tokens=32, gpu=0, task='partseg' if partseg else 'cls',
+                           head_type=0 if partseg else head_type, evaluate_3d=False, ulip2=False, synthetic_weights=True)
     torch.manual_seed(0 + rank)          # main_cls.py:39: seed = args.seed + rank -> every rank draws its own initial values
     with contextlib.redirect_stdout(io.StringIO()):
-        m = M.ULIP_PointBERT(args)
+        m = M.ULIP_PointBERT_partseg(args) if partseg else M.ULIP_PointBERT(args)
     trainable = [(n, p) for n, p in m.named_parameters() if p.requires_grad]
+    n_all = len(trainable)
+    # part segmentation: conv2 is constructed but never used in forward (main_partseg.py:48 find_unused_parameters=True): it
+    # must get NO gradient, its slice of the flat buffer is reduced as zeros and AdamW never touches it
+    unused = [(n, p) for n, p in trainable if n.startswith("point_encoder.conv2.")]
+    unused_init = {n: p.detach().clone() for n, p in unused}
+    trainable_used = [(n, p) for n, p in trainable if not n.startswith("point_encoder.conv2.")]
     init_own = {n: p.detach().clone() for n, p in trainable}
     g = torch.Generator().manual_seed(99)
     coef = {n: torch.randn(p.shape, generator=g) * 1e-2 for n, p in trainable}
     w = torch.randn(40, generator=g)
 
     def fake_forward(pc):
-        s = sum((p * coef[n]).sum() for n, p in trainable)
+        s = sum((p * coef[n]).sum() for n, p in trainable_used)
         return pc.mean(dim=(1, 2)).unsqueeze(1) * w.unsqueeze(0) * (1.0 + s)
     m.forward = fake_forward
     bn = m.point_encoder.encoder.first_conv[1]
@@ -199,6 +206,9 @@ def _real_worker(rank, world, port, head_type, ret):
                      views_ok=views_ok, grad=grad_last.numpy(), rm_mid=rm_mid.numpy(), rm=bn.running_mean.numpy().copy(),
                      params={n: p.detach().numpy().copy() for n, p in trainable}, steps=steps, bc_init=bc_init,
                      init_differs=any(not torch.equal(init_own[n], after_ctor[n]) for n in init_own),
+                     n_tensors=n_all, unused=[n for n, _ in unused],
+                     unused_untouched=all(p.grad is None or not p.grad.abs().sum() for _, p in unused) and
+                     all(torch.equal(p.detach(), after_ctor[n]) for n, p in unused) and not any(tr.optimizer.state.get(p) for _, p in unused),
                      after_ctor={n: v.numpy() for n, v in after_ctor.items()}, after_first=after_first,
                      still_view=bn.running_mean.data_ptr() == m.state_dict()["point_encoder.encoder.first_conv.1.running_mean"].data_ptr())
     dist.all_reduce, dist.broadcast = real_ar, real_bc
@@ -206,16 +216,28 @@ def _real_worker(rank, world, port, head_type, ret):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("head_type", [0, 3])
+@pytest.mark.parametrize("head_type", [0, 3, "partseg"])
 def test_real_trainable_sets_one_allreduce_per_step(head_type):
+    """head_type 0 / 3: the recognition sets.  "partseg": ULIP_PointBERT_partseg's trainable set (main_partseg.py:48-62) -- the
+    whole decoder + conv1 / bn1 + the prompt, ~21 MB of fp32 gradients in ONE all-reduce, and conv2, which is constructed but
+    unused in forward (the reference needs find_unused_parameters=True for it): no gradient, no optimizer state, unchanged."""
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_real_worker, args=(world, _free_port(), head_type, ret), nprocs=world, join=True)
     r0, r1 = ret[0], ret[1]
-    assert r0["n_flat"] == r1["n_flat"] == REAL_SIZES[head_type]
+    if head_type == "partseg":
+        want = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g_partseg.npz"))["trainable"].tolist()
+        assert r0["n_tensors"] == len(want) == 43          # (the reference's own list: 41 that get gradients + conv2's two)
+        assert sorted(r0["unused"]) == ["point_encoder.conv2.bias", "point_encoder.conv2.weight"]
+        assert r0["unused_untouched"] and r1["unused_untouched"]
+        assert 20e6 < 4 * r0["n_flat"] < 22e6
+        size = r0["n_flat"]
+    else:
+        size = REAL_SIZES[head_type]
+    assert r0["n_flat"] == r1["n_flat"] == size
     # exactly ONE all-reduce per step, over the whole flat buffer, and no broadcast inside the steps
-    assert r0["ar"] == r1["ar"] == r0["steps"] and set(r0["numel"]) == {REAL_SIZES[head_type]}
+    assert r0["ar"] == r1["ar"] == r0["steps"] and set(r0["numel"]) == {size}
     assert r0["bc_during"] == r1["bc_during"] == 0 and r0["bc_total"] == r1["bc_total"] == 1
     # DDP's constructor broadcast (main_cls.py:47-49): the ranks were seeded seed + rank (main_cls.py:39), so rank 1 drew its
     # own learnable tokens / last block; after Trainer() it holds rank 0's, which kept its own

@@ -1168,22 +1168,9 @@ def test_text_tower_fused_paths_match_the_unfused_tower():
     assert cos > 0.995, cos
 
 
-def test_health_monitor_demotes_an_overflowing_half_stage():
-    """VERDICT r3 #5(b, c): the mixed 16-bit mode watches itself (ppt_amd/health.py).  (1) ppt_health_check flags non-finite values
-    and tracks max |x|.  (2) On weights with LayerNorm gains of 10, outlier channels and a x 10 residual stream -- the hazards of
-    real checkpoints, tools/fp16_stress.py -- the text tower's half backward overflows although features and loss stay finite:
-    the optimizer skips and counts those gradient elements, the monitor sees the counter move (BIT_GRAD), the Trainer demotes the
-    16-bit backward stages to bf16 and training continues with finite gradients, nothing skipped any more, parameters finite."""
-    import warnings
-    from ppt_amd import engine, health, ops
-    from ppt_amd.train import Trainer
-    x = torch.randn(5000, device="cuda")
-    flags, mx = torch.zeros(1, dtype=torch.int32, device="cuda"), torch.zeros(1, device="cuda")
-    ops.health_check(x, flags, 4, mx)
-    assert flags.item() == 0 and mx.item() == x.abs().max().item()
-    x[4321] = float("inf")
-    ops.health_check(x.to(torch.float16), flags, 4, mx)
-    assert flags.item() == 4
+def _stressed_model(head_type=0):
+    """LayerNorm gains of 10, four x30 outlier channels per LayerNorm, a x10 residual stream: the hazards of real checkpoints
+    (tools/fp16_stress.py) -- on these the text tower's half BACKWARD overflows although features and loss stay finite."""
     sd = W.ulip_pointbert_state_dict(seed=0)
     gen = torch.Generator().manual_seed(7)
     for k in list(sd):
@@ -1193,16 +1180,49 @@ def test_health_monitor_demotes_an_overflowing_half_stage():
             sd[k] = v
         if k.endswith(("cls_token", "pos_embed.2.weight")) or k in ("positional_embedding", "token_embedding.weight"):
             sd[k] = sd[k] * 10.0
-    m, _ = build(0, torch.bfloat16)
+    m, _ = build(head_type, torch.bfloat16)
     m.load_state_dict(sd, strict=False)
     m.prompt_learner.embedding = W.synth_prompt_embedding(40, seed=0) * 10.0
     m.train()
+    return m
+
+
+class _health_every:
+    def __init__(self, n):
+        self.n = str(n)
+
+    def __enter__(self):
+        self.old = os.environ.get("PPT_HEALTH_EVERY")
+        os.environ["PPT_HEALTH_EVERY"] = self.n
+
+    def __exit__(self, *a):
+        if self.old is None:
+            os.environ.pop("PPT_HEALTH_EVERY", None)
+        else:
+            os.environ["PPT_HEALTH_EVERY"] = self.old
+
+
+def test_health_monitor_demotes_an_overflowing_half_stage():
+    """VERDICT r3 #5(b, c): the mixed 16-bit mode watches itself (ppt_amd/health.py).  (1) ppt_health_check flags non-finite values
+    and tracks max |x|.  (2) On weights with LayerNorm gains of 10, outlier channels and a x 10 residual stream -- the hazards of
+    real checkpoints, tools/fp16_stress.py -- the text tower's half backward overflows although features and loss stay finite:
+    the optimizer skips and counts those gradient elements, the monitor sees the counter move (BIT_GRAD), the Trainer demotes the
+    16-bit backward stages to bf16 and training continues with finite gradients, nothing skipped any more, parameters finite.
+    The demotion is the MODEL's (ULIP_WITH_IMAGE.demoted), not the process's: a second model built afterwards starts in half."""
+    import warnings
+    from ppt_amd import health, ops
+    from ppt_amd.train import Trainer
+    x = torch.randn(5000, device="cuda")
+    flags, mx = torch.zeros(1, dtype=torch.int32, device="cuda"), torch.zeros(1, device="cuda")
+    ops.health_check(x, flags, 4, mx)
+    assert flags.item() == 0 and mx.item() == x.abs().max().item()
+    x[4321] = float("inf")
+    ops.health_check(x.to(torch.float16), flags, 4, mx)
+    assert flags.item() == 4
+    m = _stressed_model()
     pc, _ = oracle_inputs()
     labels = torch.tensor([1, 2, 3, 4]).cuda()
-    old = os.environ.get("PPT_HEALTH_EVERY")
-    os.environ["PPT_HEALTH_EVERY"] = "1"
-    engine.DEMOTED.clear()
-    try:
+    with _health_every(1):
         tr = Trainer(m, distributed=False)
         assert tr.health is not None and m.health is tr.health
         with warnings.catch_warnings(record=True) as caught:
@@ -1218,9 +1238,88 @@ def test_health_monitor_demotes_an_overflowing_half_stage():
         assert skipped[-1] == skipped[-3], skipped                      # nothing skipped any more after the demotion
         assert np.isfinite(loss.item()) and all(bool(torch.isfinite(p).all()) for p in m.parameters())
         assert torch.isfinite(m.prompt_learner.learnable_tokens.grad).all()
-    finally:
-        engine.DEMOTED.clear()
-        if old is None:
-            os.environ.pop("PPT_HEALTH_EVERY", None)
-        else:
-            os.environ["PPT_HEALTH_EVERY"] = old
+        assert {"head", "last_block", "decoder"} <= m.demoted and m.point_encoder.demoted is m.demoted
+    other, _ = build(0, torch.bfloat16)
+    assert not other.demoted and other.text_f16, "a demotion must not leak into other models of the process"
+
+
+def test_health_monitor_stays_armed_after_an_event():
+    """the flag word used to be sticky -- after the first BIT_POINT / BIT_LOSS event nothing new was ever
+    reported, so a LATER half-backward overflow was skipped by AdamW every step, silently, for the rest of the run.  Now the word
+    is cleared behind every read: (1) an injected non-finite feature event demotes the point tower; (2) the text tower's backward
+    overflow that follows is still seen as BIT_GRAD and demotes the text side; (3) once nothing is left to demote, events that
+    keep arriving raise FloatingPointError instead of making every step a silent no-op."""
+    import warnings
+    from ppt_amd import health
+    from ppt_amd.train import Trainer
+    m = _stressed_model()
+    pc, _ = oracle_inputs()
+    pc = pc.cuda()
+    labels = torch.tensor([1, 2, 3, 4]).cuda()
+    with _health_every(1), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tr = Trainer(m, distributed=False)
+        # (1) a non-finite point-feature event in the first window (injected: the flag the tower's check would have set), together
+        # with its echo BIT_LOSS
+        tr.health.check(health.BIT_POINT, torch.tensor([float("inf")], device="cuda"))
+        tr.health.check(health.BIT_LOSS, torch.tensor([float("nan")], device="cuda"))
+        for _ in range(8):
+            tr.step(pc, labels)
+            tr.finish()
+        bits = [d[1] for d in tr.demotions]
+        assert bits[0] & health.BIT_POINT and {"tokenizer", "blocks"} <= m.demoted
+        # (2) ... did not mask the gradient overflow of the text tower's half backward
+        assert any(b & health.BIT_GRAD for b in bits[1:]), bits
+        assert m.text_f16 is False
+        n_skipped = tr.nonfinite_grad_elements()
+        for _ in range(3):
+            tr.step(pc, labels)
+            tr.finish()
+        assert tr.nonfinite_grad_elements() == n_skipped            # training goes on, nothing skipped any more
+        # (3) every stage is on bf16 now: a loss that keeps coming back non-finite is not a half overflow
+        with pytest.raises(FloatingPointError):
+            for _ in range(3 * health.GIVE_UP_AFTER):
+                tr.health.check(health.BIT_LOSS, torch.tensor([float("nan")], device="cuda"))
+                tr.step(pc, labels)
+                tr.finish()
+
+
+def test_corrupt_label_is_reported_as_a_data_error_not_an_overflow():
+    """a label outside [0, C) that is not ignore_index makes the loss NaN (ATen: device assert).  The monitor must not
+    read that as a half overflow and demote the text tower for good: BIT_LABEL raises ValueError at the next poll, nothing demoted."""
+    from ppt_amd.train import Trainer
+    pc, _ = oracle_inputs()
+    pc = pc.cuda()
+    for head_type in (0, 3):                                        # fused head (ppt_head_ce_bwd) and ppt_cross_entropy_rows
+        m, _ = build(head_type, torch.bfloat16)
+        m.train()
+        with _health_every(1):
+            tr = Trainer(m, distributed=False)
+            tr.step(pc, torch.tensor([1, 2, 3, 4]).cuda())
+            with pytest.raises(ValueError, match="label"):
+                for _ in range(3):
+                    tr.step(pc, torch.tensor([1, 2, 40, 4]).cuda())
+                    tr.finish()
+        assert not m.demoted and m.text_f16 and not tr.demotions
+        assert all(bool(torch.isfinite(p).all()) for p in m.parameters())      # the NaN step was skipped by the optimizer
+
+
+def test_fp32_mode_keeps_the_reference_nan_behaviour():
+    """the non-finite skip belongs to the 16-bit backward stages.  In the fp32 parity mode the AdamW kernels get no skip
+    counter and do what torch.optim.AdamW does: a NaN gradient reaches the parameter (main_cls.py:205-207 then stops the run)."""
+    from ppt_amd import ops
+    p = torch.ones(8, device="cuda")
+    g = torch.zeros(8, device="cuda")
+    g[3] = float("nan")
+    m_, v_ = torch.zeros(8, device="cuda"), torch.zeros(8, device="cuda")
+    ops.adamw_step(p, g, m_, v_, 1e-3, 0.9, 0.98, 1e-8, 0.1, 1, skipped=None)
+    assert torch.isnan(p[3]) and torch.isfinite(p[[0, 1, 2, 4, 5, 6, 7]]).all()
+    p2 = torch.ones(8, device="cuda")
+    sk = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ops.adamw_step(p2, g.clone(), torch.zeros(8, device="cuda"), torch.zeros(8, device="cuda"), 1e-3, 0.9, 0.98, 1e-8, 0.1, 1, skipped=sk)
+    assert p2[3].item() == 1.0 and sk.item() == 1
+    ref = torch.ones(8, device="cuda", requires_grad=True)
+    opt = torch.optim.AdamW([ref], lr=1e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.1, foreach=False)
+    ref.grad = g.clone()
+    opt.step()
+    assert torch.equal(torch.isnan(ref.detach()), torch.isnan(p)) and torch.equal(ref.detach()[[0, 1, 2]], p[[0, 1, 2]])

@@ -71,12 +71,11 @@ labels = torch.from_numpy(np.random.default_rng(0).integers(0, 40, size=(B,))).c
 
 def probed_step(sd, demoted):
     """one forward + backward with every intermediate exposed; -> ({(tower, kernel): (max |x|, non-finite?)}, loss)"""
-    engine.DEMOTED.clear()
-    if demoted:
-        engine.DEMOTED.update(("tokenizer", "blocks", "last_block"))
     saved = (engine.FUSED_MLP, engine.FUSED_PROJ, engine.ROWGEMM_MIN_ROWS, engine.FUSED_CONV12)
     engine.FUSED_MLP, engine.FUSED_PROJ, engine.ROWGEMM_MIN_ROWS = False, False, 1 << 30
     m = build(sd)
+    if demoted:                                # (the model's own set: ppt_amd/health.py demote() fills it at run time)
+        m.demoted.update(("tokenizer", "blocks", "last_block"))
     m.text_f16 = not demoted
     m.use_hip_graphs = m.point_encoder.use_hip_graphs = False
     m.overlap_text_tower = False
@@ -102,7 +101,6 @@ def probed_step(sd, demoted):
     finally:
         ops.probe = None
         engine.FUSED_MLP, engine.FUSED_PROJ, engine.ROWGEMM_MIN_ROWS, engine.FUSED_CONV12 = saved
-        engine.DEMOTED.clear()
     g = m.prompt_learner.learnable_tokens.grad
     return {k: (v[0].item(), bool(v[1].item())) for k, v in rec.items()}, loss.item(), bool(torch.isfinite(g).all()) if g is not None else False
 
