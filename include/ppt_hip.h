@@ -42,7 +42,7 @@ extern "C" {
 
 const char *ppt_strerror(int code);
 /* ABI version of this header (currently 5); bumped on any signature change or added entry point.
- * 5: ppt_labels_check (new).
+ * 5: ppt_labels_check (new), ppt_gemm256 (new: the 256-row macro-tile GEMM core).
  * 3: PPT_F16 (dtype arguments / struct fields), ppt_cross_entropy_rows (ignored labels, loss[2]), ppt_adamw_step (grad_scale),
  *    ppt_bn_rows_bwd_apply (half_dtype), ppt_*_half entry points.
  * 4: gradient scaling local to the 16-bit backward stages -- ppt_convert_scaled (new), ppt_rows_matmul_f32 (alpha),
@@ -158,6 +158,16 @@ typedef struct ppt_gemm_params {
 #define PPT_ACT_QUICKGELU 3  /* x*sigmoid(1.702x), ULIP_models.py:30-32 */
 
 int ppt_gemm(const ppt_gemm_params *p, void *stream);
+/* The 256-row macro-tile core of ppt_gemm, called explicitly (csrc/gemm256.hip; ABI 5): 16-bit operands, a_mode PLAIN, K % 32 == 0,
+ * K >= 64, no pooling; 256 x 256 output tiles per 512-thread workgroup (256 x 128 for narrow N), both operands through a ring of
+ * LDS-DMA stages, the same epilogues.  ppt_gemm routes the large plain problems (every nn.Linear of the frozen ViT blocks over the
+ * 16 k-32 k token rows of a batch: point_encoder.py:14-30,46-58) here by itself; PPT_GEMM256=0 in the environment turns that off.
+ * PPT_EUNSUPPORTED when the problem is outside these limits (nothing launched). */
+int ppt_gemm256(const ppt_gemm_params *p, void *stream);
+/* ppt_gemm's automatic use of that core for this host thread's following launches: 0 off, 1 on, -1 (default) what the
+ * environment says (PPT_GEMM256, default on).  For same-process A/B timing. */
+void ppt_set_gemm256(int mode);
+int ppt_get_gemm256(void);
 
 /* Wave (issue) priority of the launches this host thread makes from now on: != 0 raises it (s_setprio 3) in the kernels of the
  * prompt chain -- ppt_gemm's 64x64 tile loop, LayerNorm forward / backward, the causal / short attention kernels, the head,

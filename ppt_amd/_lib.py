@@ -74,6 +74,8 @@ _SIGNATURES = {
     "ppt_abi_version": (c_int, []),
     "ppt_cross_entropy_rows": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ppt_gn_finish": (c_int, [c_void_p, c_int, c_int, c_int, ctypes.c_double, ctypes.c_double, c_int, c_void_p, c_void_p, c_void_p]),
+    "ppt_set_gemm256": (None, [c_int]),
+    "ppt_get_gemm256": (c_int, []),
     "ppt_set_wave_priority": (None, [c_int]),
     "ppt_get_wave_priority": (c_int, []),
     "ppt_set_persistent_occupancy": (None, [c_int]),
@@ -90,6 +92,7 @@ _SIGNATURES = {
                                 c_void_p]),
     "ppt_bn_act_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ppt_gemm": (c_int, [ctypes.POINTER(GemmParams), c_void_p]),
+    "ppt_gemm256": (c_int, [ctypes.POINTER(GemmParams), c_void_p]),
     "ppt_three_nn_interp_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int,
                                         c_int, c_void_p, c_void_p]),
     "ppt_scatter_rows_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,

@@ -18,6 +18,11 @@ static thread_local int g_wave_priority = 0;
 extern "C" void ppt_set_wave_priority(int prio) { g_wave_priority = prio > 0 ? 1 : 0; }
 extern "C" int ppt_get_wave_priority(void) { return g_wave_priority; }
 
+// -1: the environment's PPT_GEMM256 (default on); 0 / 1: ppt_gemm's automatic use of the 256-row macro-tile core off / on
+static thread_local int g_gemm256 = -1;
+extern "C" void ppt_set_gemm256(int mode) { g_gemm256 = mode < 0 ? -1 : (mode ? 1 : 0); }
+extern "C" int ppt_get_gemm256(void) { return g_gemm256; }
+
 static thread_local int g_persistent_percent = 100;
 extern "C" void ppt_set_persistent_occupancy(int percent) { g_persistent_percent = percent < 10 ? 10 : (percent > 100 ? 100 : percent); }
 extern "C" int ppt_get_persistent_occupancy(void) { return g_persistent_percent; }

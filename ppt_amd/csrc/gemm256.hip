@@ -1,0 +1,245 @@
+// gemm256.hip -- the 256-row macro-tile GEMM core (round 5): C[M,N] = epilogue(A[M,K] . B[N,K]^T), 16-bit operands.
+//
+// Why another tile loop.  Every kernel of gemm.hip moves its operands L2 -> LDS, and what a CU takes in from L2 is ~30 B/clk
+// whatever is in flight (16 TB/s over the chip at 16 issuing waves).  A tile loop therefore tops out at
+// (FLOP per fill byte) x 16 TB/s: 64 FLOP/B for the 128 x 128 tile = 1.0 PFLOP/s at the very best, 0.15-0.25 of the 2.5 PFLOP/s peak
+// in practice.  A 256 x 256 tile needs half the bytes per FLOP (128 FLOP/B), a 256 x 128 tile two thirds (85 FLOP/B).
+//
+// Geometry.  512 threads = 8 waves, ONE workgroup per CU for the 256 x 256 tile (waves 2 x 4, each 128 x 64 = 4 x 2 MFMA tiles of
+// 32 x 32: 128 accumulator registers), two for the 256 x 128 tile (waves 4 x 2, each 64 x 64: 64 accumulators, 128 VGPRs per wave).
+// K is walked in 64-BYTE half-slabs (32 values) through a ring of LDS stages filled by LDS-DMA (global_load_lds_dwordx4, the
+// XOR swizzle applied to the source address: ppt_common.h lds_dma16, gemm.hip gemm_kernel_glds_h), counted vmcnt, one raw s_barrier
+// per stage, NSTAGE - 1 stages in flight.  The epilogues are gemm_common.h's: the register-layout one (bias / GELU / per-group term +
+// BatchNorm partials; compile-time variants) and, for row-major fp32 operands (the residual stream of proj / fc2), the 16-byte LDS
+// walk over an fp32 park, taken in two 64-row halves for the 128-row wave tile.
+#include "gemm_common.h"
+
+namespace {
+
+constexpr int NT2 = 512, ROWH = 64;
+__device__ __forceinline__ int lds_off_h(int row, int chunk) { return row * ROWH + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+// ROWS x 64 bytes of an operand -> LDS, by the 8 waves of the workgroup: ROWS / 128 pieces of 1 KiB (16 rows) per wave
+template <typename T, int ROWS>
+__device__ __forceinline__ void glds_half8(const T *base, int64_t ld, int rows, int r0, int k0, unsigned char *tile, int w, int lane)
+{
+    constexpr int EPC = 16 / sizeof(T);
+    constexpr int PER_WAVE = ROWS / 128;
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const int rg = (w * PER_WAVE + i) * 16;
+        const int r = rg + (lane >> 2);
+        const int c = (lane & 3) ^ ((r >> 2) & 3);       // source chunk that belongs in LDS slot lane&3 of row r
+        const T *src = base + (int64_t)min(r0 + r, rows - 1) * ld + k0 + c * EPC;
+        lds_dma16(src, tile + rg * ROWH);
+    }
+}
+
+template <typename T, int TI, int TJ>
+__device__ __forceinline__ void mma_half8(const unsigned char *As, const unsigned char *Bs, int arow0, int brow0, int lane,
+                                          f32x16_t (&acc)[TI][TJ])
+{
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        uint4 a[TI], b[TJ];
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+            b[j] = *reinterpret_cast<const uint4 *>(Bs + lds_off_h(brow0 + j * 32 + r, kk * 2 + h));
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+            a[i] = *reinterpret_cast<const uint4 *>(As + lds_off_h(arow0 + i * 32 + r, kk * 2 + h));
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+                acc[i][j] = h16<T>::mfma32(a[i], b[j], acc[i][j]);
+    }
+}
+
+// rows [HALF * PR, (HALF + 1) * PR) of a wave's accumulators -> fp32 park -> epilogue_vec8 (compile-time HALF: a runtime index into
+// the accumulator array would send it to scratch)
+template <int HALF, int PR, int TI, int TJ>
+__device__ __forceinline__ void park_walk(const ppt_gemm_params &p, f32x16_t (&acc)[TI][TJ], float *ct, int lane, int mw, int nw, int64_t zc)
+{
+    constexpr int WN = TJ * 32;
+    const int h = lane >> 5, cl = lane & 31;
+#pragma unroll
+    for (int i = 0; i < PR / 32; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ct[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * WN + j * 32 + cl] = acc[HALF * (PR / 32) + i][j][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    epilogue_vec8<PR, WN, 1>(p, ct, lane, mw + HALF * PR, nw, zc);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename T, int BN, int NSTAGE, int EPI>
+// (the LDS-walk epilogue of the EPI < 0 kernels needs more than the 128 registers that two workgroups per CU would leave)
+__global__ __launch_bounds__(NT2, (BN == 256 || EPI < 0) ? 2 : 4) void gemm256_kernel(const ppt_gemm_params p)
+{
+    constexpr int BM = 256;
+    constexpr int WGM = BN == 256 ? 2 : 4, WGN = 8 / WGM;                     // wave grid
+    constexpr int WM = BM / WGM, WN = BN / WGN, TI = WM / 32, TJ = WN / 32;    // 128 x 64 (4 x 2 tiles) or 64 x 64 (2 x 2)
+    constexpr int A_BYTES = BM * ROWH, B_BYTES = BN * ROWH, STAGE = A_BYTES + B_BYTES;
+    constexpr int LOADS = BM / 128 + BN / 128;                                 // LDS-DMA instructions per wave per stage
+    constexpr int PARK16 = 8 * WM * WN * 2;                                    // 16-bit park of epilogue_regs
+    constexpr int PR = 32;                                                     // rows of a wave tile parked in fp32 at a time
+    constexpr int PARK32 = 8 * PR * 64 * 4;                                    // fp32 park of epilogue_vec8
+    constexpr int RING = NSTAGE * STAGE;
+    constexpr int SMEM = RING > PARK16 ? (RING > PARK32 ? RING : PARK32) : (PARK16 > PARK32 ? PARK16 : PARK32);
+    __shared__ __align__(16) unsigned char smem[SMEM];
+    constexpr int BK = ROWH / sizeof(T);
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    PPT_PRIO(p.wave_prio);
+    const int wm = w / WGN, wn = w % WGN;
+    const int nwg = gridDim.x * gridDim.y;
+    const int lin0 = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q8 = nwg / 8, r8 = nwg % 8, xcd = lin0 % 8;                   // same XCD-aware remap as gemm_kernel
+    const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + lin0 / 8;
+    const int n0 = (lin % gridDim.x) * BN, m0 = (lin / gridDim.x) * BM;
+    const T *A = reinterpret_cast<const T *>(p.A) + (int64_t)blockIdx.z * p.strideA;
+    const T *B = reinterpret_cast<const T *>(p.B) + (int64_t)blockIdx.z * p.strideB;
+
+    f32x16_t acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const int nslab = p.K / BK, last = nslab - 1;
+    auto issue = [&](int slab, int stage) {
+        glds_half8<T, BM>(A, p.lda, p.M, m0, slab * BK, smem + stage * STAGE, w, lane);
+        glds_half8<T, BN>(B, p.ldb, p.N, n0, slab * BK, smem + stage * STAGE + A_BYTES, w, lane);
+    };
+#pragma unroll
+    for (int i = 0; i < NSTAGE - 1; ++i) issue(min(i, last), i);
+    EpiPre<TI, TJ> epre;                                  // (behind the first stages: the K loop must not start later for it)
+    epilogue_prefetch<TI, TJ, (EPI < 0 || (EPI & EPI_GROUP) != 0)>(p, epre, lane, m0 + wm * WM, n0 + wn * WN);
+    int stage = 0;
+    for (int s = 0; s < nslab; ++s) {
+        // own copies of slab s have landed (the LOADS * (NSTAGE - 2) youngest, slabs s+1 .., may still fly) ...
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS * (NSTAGE - 2)) : "memory");
+        __builtin_amdgcn_s_barrier();                     // ... and so have everybody else's: slab s is readable
+        int nstage = stage + NSTAGE - 1; if (nstage >= NSTAGE) nstage -= NSTAGE;
+        issue(min(s + NSTAGE - 1, last), nstage);         // that stage was last read at slab s-1, before this barrier
+        mma_half8<T, TI, TJ>(smem + stage * STAGE, smem + stage * STAGE + A_BYTES, wm * WM, wn * WN, lane, acc);
+        stage = stage + 1 == NSTAGE ? 0 : stage + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // surplus prefetches must not land on the parked tile
+    __builtin_amdgcn_s_barrier();
+
+    const int64_t zc = (int64_t)blockIdx.z * p.strideC;
+    const int mw = m0 + wm * WM, nw = n0 + wn * WN;
+    if constexpr (EPI >= 0) {
+        epilogue_regs<TI, TJ, EPI, 1>(p, acc, epre, smem + w * (WM * WN * 2), lane, mw, nw, zc);
+    } else {
+        // row-major fp32 operands (residual stream, saved pre-activation, second output): the LDS walk, PR rows of the wave tile
+        // at a time (an fp32 park of the whole 128 x 64 wave tile would be 256 KiB per workgroup)
+        static_assert(WN == 64 && (WM / PR == 2 || WM / PR == 4), "park geometry");
+        float *ct = reinterpret_cast<float *>(smem) + w * (PR * 64);
+        park_walk<0, PR, TI, TJ>(p, acc, ct, lane, mw, nw, zc);
+        park_walk<1, PR, TI, TJ>(p, acc, ct, lane, mw, nw, zc);
+        if constexpr (WM / PR == 4) {
+            park_walk<2, PR, TI, TJ>(p, acc, ct, lane, mw, nw, zc);
+            park_walk<3, PR, TI, TJ>(p, acc, ct, lane, mw, nw, zc);
+        }
+    }
+}
+
+extern "C" int ppt_get_gemm256(void);
+
+int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+template <typename T>
+int launch256(const ppt_gemm_params &p, int bn, hipStream_t s)
+{
+    const int batch = p.batch > 0 ? p.batch : 1;
+    dim3 grid((p.N + bn - 1) / bn, (p.M + 255) / 256, batch);
+    if (grid.y > 65535 || grid.z > 65535) return PPT_EUNSUPPORTED;
+    // the register-layout epilogue exists as three compile-time variants (plain / bias + GELU / per-group term + BatchNorm
+    // partials: qkv, fc1, conv3); everything else takes the LDS walk (EPI = -1), which has no statistics / group term
+    int epi = (p.C && reg_epilogue_ok<4>(p, 0)) ? epi_mask(p) : -1;
+    if (epi != 0 && epi != EPI_GELU && !(bn == 256 && epi == (EPI_GROUP | EPI_STATS))) epi = -1;
+    if (bn == 256) {
+        switch (epi) {
+        case 0: hipLaunchKernelGGL((gemm256_kernel<T, 256, 4, 0>), grid, dim3(NT2), 0, s, p); break;
+        case EPI_GELU: hipLaunchKernelGGL((gemm256_kernel<T, 256, 4, EPI_GELU>), grid, dim3(NT2), 0, s, p); break;
+        case EPI_GROUP | EPI_STATS: hipLaunchKernelGGL((gemm256_kernel<T, 256, 4, EPI_GROUP | EPI_STATS>), grid, dim3(NT2), 0, s, p); break;
+        default: hipLaunchKernelGGL((gemm256_kernel<T, 256, 4, -1>), grid, dim3(NT2), 0, s, p); break;
+        }
+    } else {
+        switch (epi) {
+        case 0: hipLaunchKernelGGL((gemm256_kernel<T, 128, 3, 0>), grid, dim3(NT2), 0, s, p); break;
+        case EPI_GELU: hipLaunchKernelGGL((gemm256_kernel<T, 128, 3, EPI_GELU>), grid, dim3(NT2), 0, s, p); break;
+        default: hipLaunchKernelGGL((gemm256_kernel<T, 128, 3, -1>), grid, dim3(NT2), 0, s, p); break;
+        }
+    }
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
+}  // namespace
+
+// The host side of the choice.  force: 0 = ppt_gemm's automatic dispatch (size gates), 1 = explicit call (only the hard limits).
+// Returns PPT_OK when launched, PPT_EUNSUPPORTED when this core does not take the problem.
+extern "C" int ppt_gemm256_dispatch(const ppt_gemm_params *pp, int force, void *stream)
+{
+    const ppt_gemm_params &p = *pp;
+    if (p.dtype != PPT_BF16 && p.dtype != PPT_F16) return PPT_EUNSUPPORTED;
+    if (p.a_mode != PPT_A_PLAIN || !p.A || (p.K % 32) != 0 || p.K < 64) return PPT_EUNSUPPORTED;
+    if (p.batch > 1 && (p.strideC % 8) != 0) return PPT_EUNSUPPORTED;
+    if (p.pool_max) return PPT_EUNSUPPORTED;               // (pools over 64-row groups assume TI == 2 wave tiles)
+    // tile width: 256 columns when N fills them (N % 256 == 0, or wide enough that the ragged last tile is a small share),
+    // else 128 (N = 384: three tiles instead of two with a quarter of the second one empty)
+    const int bn = (p.N % 256 == 0 || (p.N >= 1024 && (p.N % 256) >= 128)) ? 256 : 128;
+    const bool regs = p.C && reg_epilogue_ok<4>(p, 0);
+    const int mask = regs ? epi_mask(p) : -1;
+    const bool special = mask == 0 || mask == EPI_GELU || (bn == 256 && mask == (EPI_GROUP | EPI_STATS));
+    if (!special) {                                       // the LDS-walk epilogue: 16-byte friendly operands only, no statistics
+        if (p.col_sum || p.group_add) return PPT_EUNSUPPORTED;
+        bool ok = (p.N % 8) == 0;
+        if (p.C) ok = ok && (p.ldc % 8) == 0 && al16(p.C);
+        if (p.C2) ok = ok && (p.ldc2 % 8) == 0 && al16(p.C2);
+        if (p.bias) ok = ok && al16(p.bias);
+        if (p.dact_pre) ok = ok && (p.ld_dact % 8) == 0 && al16(p.dact_pre);
+        if (p.residual) ok = ok && (p.ld_res % 8) == 0 && al16(p.residual);
+        if (p.residual2) ok = ok && (p.ld_res2 % 8) == 0 && al16(p.residual2);
+        if (p.batch > 1 && ((p.strideC % 8) != 0)) ok = false;
+        if (!ok) return PPT_EUNSUPPORTED;
+    }
+    static const int enabled = env_int("PPT_GEMM256", 1);
+    static const int min_rows = env_int("PPT_GEMM256_MIN_ROWS", 8192);
+    if (!force) {
+        const int mode = ppt_get_gemm256();
+        if (!(mode < 0 ? enabled : mode) || p.M < min_rows) return PPT_EUNSUPPORTED;
+    }
+    hipStream_t s = ppt_stream(stream);
+    return p.dtype == PPT_BF16 ? launch256<bf16_t>(p, bn, s) : launch256<f16_t>(p, bn, s);
+}
+
+extern "C" int ppt_gemm256(const ppt_gemm_params *pp, void *stream)
+{
+    if (!pp) return PPT_EINVAL;
+    ppt_gemm_params q = *pp;
+    if (!q.wave_prio) q.wave_prio = ppt_get_wave_priority();
+    if (q.M <= 0 || q.N <= 0 || q.K <= 0 || !q.B || !q.A) return PPT_EINVAL;
+    if (q.K % 8 || q.lda % 8 || q.ldb % 8 || ((uintptr_t)q.A & 15) || ((uintptr_t)q.B & 15)) return PPT_EINVAL;
+    if ((q.col_sum == nullptr) != (q.col_sqsum == nullptr)) return PPT_EINVAL;
+    if (q.group_add && q.group_rows <= 0) return PPT_EINVAL;
+    if (q.row_scale && q.row_scale_rows <= 0) return PPT_EINVAL;
+    if (q.batch > 1 && (q.C2 || q.col_sum || q.pool_max || q.residual || q.residual2 || q.dact_pre || q.group_add)) return PPT_EUNSUPPORTED;
+    return ppt_gemm256_dispatch(&q, 1, stream);
+}

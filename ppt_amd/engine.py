@@ -128,6 +128,10 @@ FUSED_CONV34_TRAIN = os.environ.get("PPT_FUSED_CONV34_TRAIN", "0") != "0"
 # 3.345 ms WITH it, same box, tools/ab_env.py -- the threshold went from 24 000 to 16 000 rows.)
 FUSED_MLP = os.environ.get("PPT_FUSED_MLP", "1") != "0"             # LayerNorm + fc1 + GELU + fc2 + residual of a frozen block: one kernel
 FUSED_PROJ = os.environ.get("PPT_FUSED_PROJ", "1") != "0"           # ... with attn.proj + DropPath + residual in front of it (rowgemm path)
+# which kernel each linear of a FROZEN ViT block runs on from ROWGEMM_MIN_ROWS token rows on (vit_block_forward):
+# PPT_BLOCK_QKV = rowgemm | v2, PPT_BLOCK_PROJ = fused | rowgemm | v2, PPT_BLOCK_MLP = fused | rowgemm | v2
+BLOCK_PATH = {"qkv": os.environ.get("PPT_BLOCK_QKV", "rowgemm"), "proj": os.environ.get("PPT_BLOCK_PROJ", "fused"),
+              "mlp": os.environ.get("PPT_BLOCK_MLP", "fused")}
 _RG = os.environ.get("PPT_ROWGEMM", "")
 ROWGEMM_MIN_ROWS = 1 << 30 if _RG == "0" else (0 if _RG == "1" else 16000)
 
@@ -251,16 +255,28 @@ def vit_block_forward(sd, p, wc, x, pos, B, Tn, heads, dp1, dp2, save=None, pos_
     T = wc.dtype
     keep = save is not None
     if x.shape[0] >= ROWGEMM_MIN_ROWS and T in ops.HALF and not keep and x.shape[1] in ops.ROWGEMM_K:
-        # frozen block, nothing kept: the K = 384 linears with the weight stationary in registers (csrc/rowgemm.hip); both
-        # LayerNorms are applied while the rows are staged, the residual stream is updated in place
-        if pos_in_x:
+        # frozen block, nothing kept: every linear picks its kernel (BLOCK_PATH; round 5) --
+        #   "rowgemm": csrc/rowgemm.hip, the K = 384 weight stationary in registers, the LayerNorm applied while the rows are staged;
+        #   "v2": a LayerNorm launch + ppt_gemm, which routes these row counts to the 256-row macro-tile core (csrc/gemm256.hip);
+        #   "fused" (proj / mlp): attn.proj in front of / the whole MLP branch inside csrc/mlp_fused.hip.
+        # The residual stream is updated in place; the sums are formed in the same order on every path.
+        path = BLOCK_PATH
+        fused_ok = FUSED_MLP and sd[p + "mlp.fc1.weight"].shape[0] == 1536
+        mlp = path["mlp"] if (fused_ok or path["mlp"] != "fused") else "rowgemm"
+        proj = path["proj"] if not (path["proj"] == "fused" and not (mlp == "fused" and FUSED_PROJ)) else "rowgemm"
+        if pos_in_x and path["qkv"] == "rowgemm":
             qkv = ops.rowgemm(x, wc.get(sd[p + "attn.qkv.weight"]), ln=(sd[p + "norm1.weight"], sd[p + "norm1.bias"]))
         else:           # (the first block: x + pos is formed -- and written back -- by the LayerNorm kernel)
-            h, _, _ = ops.layernorm_fwd(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], T, add=pos, write_xs=x)
-            qkv = ops.rowgemm(h, wc.get(sd[p + "attn.qkv.weight"]))
+            if pos_in_x:
+                h, _, _ = ops.layernorm_fwd(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], T)
+            else:
+                h, _, _ = ops.layernorm_fwd(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], T, add=pos, write_xs=x)
+            if path["qkv"] == "rowgemm":
+                qkv = ops.rowgemm(h, wc.get(sd[p + "attn.qkv.weight"]))
+            else:
+                qkv = ops.gemm(h, wc.get(sd[p + "attn.qkv.weight"]), out_dtype=T)
         a, _ = ops.attention_fwd(qkv, B, Tn, heads, ATTN_SCALE, False, want_lse=False)
-        fused_mlp = FUSED_MLP and sd[p + "mlp.fc1.weight"].shape[0] == 1536
-        if fused_mlp and FUSED_PROJ:
+        if proj == "fused":
             # attn.proj + DropPath + residual ride in front of the MLP kernel (csrc/mlp_fused.hip, round 3)
             w1t, w2t = _mlp_weights(sd, p, wc)
             wp = sd[p + "attn.proj.weight"]
@@ -269,16 +285,24 @@ def vit_block_forward(sd, p, wc, x, pos, B, Tn, heads, dp1, dp2, save=None, pos_
                         (sd[p + "norm2.weight"], sd[p + "norm2.bias"]), row_scale=dp2, row_scale_rows=Tn,
                         residual2=pos if add_pos_out else None, proj=(a, wpt, sd[p + "attn.proj.bias"], dp1, Tn))
             return x
-        ops.rowgemm(a, wc.get(sd[p + "attn.proj.weight"]), bias=sd[p + "attn.proj.bias"], residual=x, out=x, row_scale=dp1,
-                    row_scale_rows=Tn)
-        if fused_mlp:
+        if proj == "v2":
+            ops.gemm(a, wc.get(sd[p + "attn.proj.weight"]), out=x, bias=sd[p + "attn.proj.bias"], row_scale=dp1, row_scale_rows=Tn,
+                     residual=x)
+        else:
+            ops.rowgemm(a, wc.get(sd[p + "attn.proj.weight"]), bias=sd[p + "attn.proj.bias"], residual=x, out=x, row_scale=dp1,
+                        row_scale_rows=Tn)
+        if mlp == "fused":
             w1t, w2t = _mlp_weights(sd, p, wc)
             ops.vit_mlp(x, w1t, sd[p + "mlp.fc1.bias"], w2t, sd[p + "mlp.fc2.bias"],
                         (sd[p + "norm2.weight"], sd[p + "norm2.bias"]), row_scale=dp2, row_scale_rows=Tn,
                         residual2=pos if add_pos_out else None)
             return x
-        f = ops.rowgemm(x, wc.get(sd[p + "mlp.fc1.weight"]), ln=(sd[p + "norm2.weight"], sd[p + "norm2.bias"]),
-                        bias=sd[p + "mlp.fc1.bias"], act=ACT_GELU)
+        if mlp == "v2":
+            h2, _, _ = ops.layernorm_fwd(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"], T)
+            f = ops.gemm(h2, wc.get(sd[p + "mlp.fc1.weight"]), out_dtype=T, bias=sd[p + "mlp.fc1.bias"], act=ACT_GELU)
+        else:
+            f = ops.rowgemm(x, wc.get(sd[p + "mlp.fc1.weight"]), ln=(sd[p + "norm2.weight"], sd[p + "norm2.bias"]),
+                            bias=sd[p + "mlp.fc1.bias"], act=ACT_GELU)
         ops.gemm(f, wc.get(sd[p + "mlp.fc2.weight"]), out=x, bias=sd[p + "mlp.fc2.bias"], row_scale=dp2, row_scale_rows=Tn,
                  residual=x, residual2=pos if add_pos_out else None)
         return x

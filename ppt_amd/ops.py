@@ -186,7 +186,7 @@ def gemm(A, B, *, out=None, out_dtype=None, M=None, bias=None, act=ACT_NONE, dac
          group_add=None, group_rows=0, row_scale=None, row_scale_rows=0, residual=None,
          residual2=None, out2=None, out2_pre=False, col_stats=None, pool_max=None, pool_min=None, pool_rows=0,
          batch=1, strideA=0, strideB=0, strideC=0,
-         a_mode=A_PLAIN, a_scale=None, a_shift=None, pts=None, w1=None, b1=None, want_out=True, algo_k=None):
+         a_mode=A_PLAIN, a_scale=None, a_shift=None, pts=None, w1=None, b1=None, want_out=True, algo_k=None, core=None):
     """C[M,N] = epilogue(prologue(A)[M,K] @ B[N,K]^T) -- see struct ppt_gemm_params.
     A [M,K] (or None with a_mode=A_CONV1 and pts [M,3]); B [N,K]; 2-D, last-dim contiguous
     (row stride may exceed K).  Returns out (or None when want_out=False)."""
@@ -238,7 +238,10 @@ def gemm(A, B, *, out=None, out_dtype=None, M=None, bias=None, act=ACT_NONE, dac
         profiler.begin("gemm_" + ("bf16" if p.dtype != PPT_F32 else "f32"), 2.0 * M * N * kk * max(1, batch),
                        "ppt_gemm " + ({PPT_BF16: "bf16", PPT_F16: "f16"}.get(p.dtype, "f32")) + (" (A-prologue)" if a_mode != A_PLAIN else ""),
                        executed=2.0 * M * N * K * max(1, batch))
-    _lib.check(_lib.lib().ppt_gemm(ctypes.byref(p), _stream()), "ppt_gemm")
+    if core == "256":                  # the 256-row macro-tile core, explicitly (tests / tools; ppt_gemm picks it by itself)
+        _lib.check(_lib.lib().ppt_gemm256(ctypes.byref(p), _stream()), "ppt_gemm256")
+    else:
+        _lib.check(_lib.lib().ppt_gemm(ctypes.byref(p), _stream()), "ppt_gemm")
     if profiler is not None:
         profiler.end()
     if probe is not None:

@@ -96,8 +96,8 @@ def test_cls_checkpoint_written_on_the_gpu_resumes_bit_identically(head_type, tm
     for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
         if p.requires_grad:
             assert q.is_cuda and q.requires_grad, n
+    tr_b = prepare(b)                                # (also injects the FPS start indices: validate() draws them at random otherwise)
     assert torch.equal(_eval_logits(b, pc), logits_a)
-    tr_b = prepare(b)
     load_reference_optimizer_state(b, tr_b.optimizer, ckpt['optimizer'])
     tr_b.it = 3
     loss_b, pred_b = tr_b.step(torch.roll(pc, 3, 0), label)
@@ -126,7 +126,7 @@ def test_cls_checkpoint_written_on_the_gpu_resumes_bit_identically(head_type, tm
     loss_c.backward()
     opt_c.step()
     torch.cuda.synchronize()
-    assert abs(loss_c.item() - loss_a.item()) < 1e-5
+    assert abs(loss_c.item() - loss_a.item()) < 1e-5 * abs(loss_a.item())       # (ATen's criterion vs the fused head: fp32 rounding)
     for n, q in c.named_parameters():
         if q.requires_grad:
             d = (q - after_a[n]).abs().max().item()
@@ -189,8 +189,8 @@ def test_partseg_checkpoint_written_on_the_gpu_resumes_bit_identically(tmp_path)
     assert len(ref_opt.state) == len(trained) - 1                           # conv2 (unused in forward) never stepped
     load_prompt_checkpoint(b, ckpt)
     b.reset_caches()
-    assert torch.equal(_eval_logits(b, pc, onehot), logits_a)
     tr_b = prepare(b)
+    assert torch.equal(_eval_logits(b, pc, onehot), logits_a)
     load_reference_optimizer_state(b, tr_b.optimizer, ckpt['optimizer'])
     tr_b.it = 3
     loss_b, _ = tr_b.step(pc, labels)

@@ -271,6 +271,95 @@ def test_gemm_residual_epilogue_full_size(ops, dtype, M, N, K):
     assert torch.allclose(d.float().cpu(), want, rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,kind", [
+    (16416, 1152, 384, "plain"),        # qkv of a C2 batch: ragged M (64.125 row tiles), ragged N for 256-wide tiles (4.5)
+    (16416, 1536, 384, "gelu"),         # fc1: bias + GELU, 16-bit C
+    (16416, 384, 1536, "residual"),     # fc2: fp32 residual stream in place, DropPath row scale, + pos; 256 x 128 tiles
+    (8200, 384, 384, "residual"),       # proj-shaped, ragged last row tile of 8 rows
+    (9000, 640, 64, "dact"),            # derivative epilogue with a saved pre-activation + second (pre) output; K = 2 half-slabs
+    (16384, 512, 256, "stats"),         # conv3-shaped: per-group term + BatchNorm chunk statistics
+    (4096, 4096, 4096, "plain"),        # square, 256 tiles = one per CU
+    (3000, 256, 96, "batched"),         # blockIdx.z batches with strides
+])
+def test_gemm256_core_is_the_tile_loop_bit_for_bit(ops, dtype, M, N, K, kind):
+    """csrc/gemm256.hip (256 x 256 / 256 x 128 macro-tiles, 8 waves, LDS-DMA ring) against the 64 x 64 / 128 x 128 tile loops of
+    gemm.hip on the same launch: both walk K in ascending 16-wide MFMA steps into fp32 accumulators and share the epilogue code, so
+    the results are the SAME BITS; plus an fp32 reference on the operands' 16-bit values; plus run-to-run reproducibility."""
+    from ppt_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.default_rng(M + 3 * N + 7 * K)
+    A = dev(rng.standard_normal((M, K)).astype(np.float32), dtype)
+    Bm = dev((rng.standard_normal((N, K)) / math.sqrt(K)).astype(np.float32), dtype)
+    bias = dev(rng.standard_normal(N).astype(np.float32))
+    kw, out_dtype = {}, dtype
+    base = None
+    if kind == "gelu":
+        kw = dict(bias=bias, act=ops.ACT_GELU)
+    elif kind == "residual":
+        res = dev(rng.standard_normal((M, N)).astype(np.float32))
+        res2 = dev(rng.standard_normal((M, N)).astype(np.float32))
+        rs = dev(rng.random((M + 512) // 513).astype(np.float32))
+        kw = dict(bias=bias, row_scale=rs, row_scale_rows=513, residual=res, residual2=res2)
+        out_dtype = torch.float32
+    elif kind == "dact":
+        pre = dev(rng.standard_normal((M, N)).astype(np.float32), dtype)
+        kw = dict(act=ops.ACT_GELU, dact_pre=pre)
+    elif kind == "stats":
+        gadd = dev(rng.standard_normal((M // 32, N)).astype(np.float32))
+        kw = dict(bias=bias, group_add=gadd, group_rows=32)
+
+    def launch(core):
+        k2 = dict(kw)
+        extra = {}
+        if kind == "stats":
+            cs = torch.full(((M + 31) // 32, N), float("nan"), device="cuda"); cq = torch.full_like(cs, float("nan"))
+            k2["col_stats"] = (cs, cq)
+            extra = dict(cs=cs, cq=cq)
+        if kind == "dact":
+            o2 = torch.empty((M, N), dtype=torch.float32, device="cuda")
+            k2.update(out2=o2)
+            extra = dict(o2=o2)
+        if kind == "batched":
+            Mb = M // 3
+            out = torch.full((3 * Mb, N), float("nan"), dtype=out_dtype, device="cuda")
+            ops.gemm(A[:Mb], Bm, out=out, M=Mb, batch=3, strideA=Mb * K, strideB=0, strideC=Mb * N, core=core, **k2)
+        else:
+            out = ops.gemm(A, Bm, out_dtype=out_dtype, core=core, **k2)
+        torch.cuda.synchronize()
+        return out, extra
+    lib.ppt_set_gemm256(0)
+    try:
+        old, old_x = launch(None)
+        new, new_x = launch("256")
+        again, _ = launch("256")
+    finally:
+        lib.ppt_set_gemm256(-1)
+    assert torch.equal(new, again), "not reproducible"
+    assert torch.equal(old, new), (old.float() - new.float()).abs().max().item()
+    for k in old_x:
+        assert torch.equal(old_x[k], new_x[k]), k
+    auto, _ = launch(None)                               # ... and ppt_gemm routes problems of this size here by itself
+    assert torch.equal(auto, new)
+    # fp32 reference on a window of rows (first tile, the ragged last tile)
+    for rs_ in (slice(0, 512), slice(max(0, (M // 3 if kind == "batched" else M) - 300), M // 3 if kind == "batched" else M)):
+        ref = A[rs_].float() @ Bm.float().t()
+        if kind in ("gelu", "residual", "stats"):
+            ref = ref + bias
+        if kind == "stats":
+            ref = ref + gadd.repeat_interleave(32, 0)[rs_]
+        if kind == "gelu":
+            ref = torch.nn.functional.gelu(ref)
+        if kind == "residual":
+            ref = ref * rs.repeat_interleave(513)[:M][rs_, None] + res[rs_] + res2[rs_]
+        if kind == "dact":
+            x = pre[rs_].float().requires_grad_(True)
+            (gd,) = torch.autograd.grad(torch.nn.functional.gelu(x).sum(), x)
+            ref = ref * gd
+        tol = 4e-2 if dtype == torch.bfloat16 else 1e-2
+        assert torch.allclose(new[rs_].float(), ref, rtol=tol, atol=tol * (2 if K > 1024 else 1)), (new[rs_].float() - ref).abs().max().item()
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_gemm_prologues(ops, dtype):
     rng = np.random.default_rng(12)
