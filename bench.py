@@ -208,6 +208,19 @@ def cpu_baseline(max_seconds=30.0):
                       f"{len(times)} timed steps after 1 warm-up, median {med:.2f} s/step"}
 
 
+def host_feed(tensors, steps):
+    """PPT_BENCH_FEED=prefetch: the batch arrives from the HOST every step, as in main_cls.py:171-194 -- `steps` batches of pinned
+    host tensors (what DataLoader(pin_memory=True) hands out; the same synthetic batch each time) through
+    ppt_amd.data.DevicePrefetcher, whose copy-stream event lets the input-only stages run ahead WITHOUT the caller vouching
+    for anything (Trainer.inputs_ready / eval_inputs_ready stay False)."""
+    from ppt_amd.data import DevicePrefetcher
+    host = tuple(t.cpu().pin_memory() for t in tensors)
+    return iter(DevicePrefetcher((host for _ in range(steps)), depth=2))
+
+
+FEED = os.environ.get("PPT_BENCH_FEED", "resident")
+
+
 def secondary_runs():
     """Short runs of the other BASELINE configurations (and of validate()) as CHILD processes of this one, so that the driver's
     single `python bench.py` also times them (VERDICT r2 #4c): {name: {value, ms_per_step, ...}}.  Each child is this script with
@@ -218,8 +231,13 @@ def secondary_runs():
     # vouches that the batch is resident, so the next step's FPS + kNN + tokenizer -- C5: the whole frozen backbone -- run under
     # the current one): what a caller gets who hands over batches that are merely queued on the stream
     in_order = {"PPT_GROUP_AHEAD": "0", "PPT_EVAL_AHEAD": "0"}
+    # *_prefetch (round 5): batches copied from pinned host memory every step through ppt_amd.data.DevicePrefetcher, nothing
+    # vouched for -- the unchanged caller's loop with its loader wrapped
+    feed = {"PPT_BENCH_FEED": "prefetch"}
     runs = [("C3", ["--config", "C3"], {}), ("C4", ["--config", "C4"], {}), ("C5", ["--config", "C5"], {}),
             ("C2_eval", ["--config", "C2", "--eval"], {}),
+            ("C2_prefetch", ["--config", "C2"], feed), ("C3_prefetch", ["--config", "C3"], feed),
+            ("C5_prefetch", ["--config", "C5"], feed), ("C2_eval_prefetch", ["--config", "C2", "--eval"], feed),
             ("C2_in_order", ["--config", "C2"], in_order), ("C3_in_order", ["--config", "C3"], in_order),
             ("C5_in_order", ["--config", "C5"], in_order), ("C2_eval_in_order", ["--config", "C2", "--eval"], in_order)]
     for name, extra, env in runs:
@@ -249,19 +267,20 @@ def main_eval(a):
     model.eval()
     # the synthetic batch is resident and complete before every call: the next batch's grouping / tokenizer stage may start
     # when forward() is called (ULIP_WITH_IMAGE.eval_inputs_ready; PPT_EVAL_AHEAD=0 for the in-order forward)
-    model.eval_inputs_ready = os.environ.get("PPT_EVAL_AHEAD", "1") != "0"
+    model.eval_inputs_ready = os.environ.get("PPT_EVAL_AHEAD", "1") != "0" and FEED != "prefetch"
     B, N = cfg["batch"], cfg["npoints"]
     pc = torch.from_numpy(W.synth_clouds(B, N, seed=1234)[0]).cuda()
     extra = ()
     if cfg.get("task") == "partseg":
         extra = (torch.nn.functional.one_hot(torch.arange(B) % 16, 16).float().cuda(),)
+    feed = host_feed((pc,), BURN_IN_STEPS + a.warmup + a.steps) if FEED == "prefetch" else None
     with torch.no_grad():
         for _ in range(BURN_IN_STEPS + a.warmup):
-            logits = model(pc, *extra)
+            logits = model(next(feed)[0] if feed else pc, *extra)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(a.steps):
-            logits = model(pc, *extra)
+            logits = model(next(feed)[0] if feed else pc, *extra)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     assert torch.isfinite(logits).all()
@@ -270,7 +289,7 @@ def main_eval(a):
            "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f16" if set(operand_formats(cfg.get("model", "ULIP_PointBERT")).values()) <= {"f16", "f32"} else "f16/bf16",
            "data": "synthetic",
-           "config": {"workload": cfg["name"] + ", eval-mode forward under no_grad (validate(), main_cls.py:237-299)",
+           "config": {"workload": cfg["name"] + ", eval-mode forward under no_grad (validate(), main_cls.py:237-299)", "feed": FEED,
                       "operand_formats": operand_formats(cfg.get("model", "ULIP_PointBERT")),
                       "per_gpu_batch": B, "npoints": N, "parallelism": "dp1"}}
     print(json.dumps(out), flush=True)
@@ -326,7 +345,7 @@ def main():
     model.train()
     trainer = Trainer(model, lr=3e-3, label_smoothing=0.2, distributed=world > 1 or force_dist)
     # the synthetic batch is resident and complete before the first step: FPS + kNN of a step may start when it is called
-    trainer.inputs_ready = group_ahead
+    trainer.inputs_ready = group_ahead and FEED != "prefetch"
     trainer.group_ahead_when_frozen = frozen_too
     pc_np, _ = W.synth_clouds(PER_GPU_BATCH, NPOINTS, seed=1234 + rank)
     pc = torch.from_numpy(pc_np).cuda()
@@ -343,10 +362,11 @@ def main():
 
     # burn-in before the W warm-up steps: on a fresh box the first ~100 ms of GPU work run at ramping clocks, and the first
     # two calls of every shape run eagerly and then capture their hipGraphs -- neither belongs in a W as small as 1
+    feed = host_feed((pc, label), BURN_IN_STEPS + a.warmup + a.steps) if FEED == "prefetch" else None
     for _ in range(BURN_IN_STEPS):
-        trainer.step(pc, label)
+        trainer.step(*(next(feed) if feed else (pc, label)))
     for _ in range(a.warmup):
-        trainer.step(pc, label)
+        trainer.step(*(next(feed) if feed else (pc, label)))
     barrier()
     # K steps bracketed by barrier + synchronize (the contract's `value`); a HIP event on the caller's stream after every
     # step also gives the per-step times (hipEvents, median reported beside the mean)
@@ -357,7 +377,7 @@ def main():
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(a.steps):
-        loss, _ = trainer.step(pc, label)
+        loss, _ = trainer.step(*(next(feed) if feed else (pc, label)))
         marks[i + 1].record()
     trainer.finish()                         # (the deferred BatchNorm-buffer broadcast of a multi-rank run is timed too)
     barrier()
@@ -454,7 +474,7 @@ def main():
                "scaling": "weak", "vs_baseline": None,
                "dtype": "f16" if set(operand_formats(cfg.get("model", "ULIP_PointBERT")).values()) <= {"f16", "f32"} else "f16/bf16",
                "data": "synthetic",
-               "config": {"workload": cfg["name"] + ", train-mode BN + DropPath, fwd + CE(ls 0.2) + bwd + AdamW",
+               "config": {"workload": cfg["name"] + ", train-mode BN + DropPath, fwd + CE(ls 0.2) + bwd + AdamW", "feed": FEED,
                           "operand_formats": operand_formats(cfg.get("model", "ULIP_PointBERT")),
                           "per_gpu_batch": PER_GPU_BATCH, "global_batch": PER_GPU_BATCH * world, "npoints": NPOINTS,
                           "classes": n_classes, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},

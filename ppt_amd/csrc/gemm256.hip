@@ -17,14 +17,28 @@
 namespace {
 
 constexpr int NT2 = 512, ROWH = 64;
+#ifdef PPT_GEMM256_WHOLE_EPILOGUE
+constexpr bool SLICED_EPILOGUE = false;        // (A/B builds: the whole-tile register epilogue of gemm_common.h)
+#else
+constexpr bool SLICED_EPILOGUE = true;
+#endif
+
+// Diagnostic build only (tools/gemm256_stamp.py compiles this file with -DPPT_GEMM_STAMP into its own library): lane 0 of every wave
+// stores s_memtime at entry / prologue DMA issued / first stage readable / K loop done / stores done into the buffer p.pool_min
+// points at (unused by these launches; ppt_gemm256 rejects pool_max).
+#ifdef PPT_GEMM_STAMP
+#define G256_STAMP(slot) do { if (lane == 0 && p.pool_min) reinterpret_cast<unsigned long long *>(p.pool_min)[((size_t)((blockIdx.y * gridDim.x + blockIdx.x) * 8 + w)) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define G256_STAMP(slot) do { } while (0)
+#endif
 __device__ __forceinline__ int lds_off_h(int row, int chunk) { return row * ROWH + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
-// ROWS x 64 bytes of an operand -> LDS, by the 8 waves of the workgroup: ROWS / 128 pieces of 1 KiB (16 rows) per wave
-template <typename T, int ROWS>
+// ROWS x 64 bytes of an operand -> LDS, by the NW waves of the workgroup: ROWS / (16 NW) pieces of 1 KiB (16 rows) per wave
+template <typename T, int ROWS, int NW = 8>
 __device__ __forceinline__ void glds_half8(const T *base, int64_t ld, int rows, int r0, int k0, unsigned char *tile, int w, int lane)
 {
     constexpr int EPC = 16 / sizeof(T);
-    constexpr int PER_WAVE = ROWS / 128;
+    constexpr int PER_WAVE = ROWS / (16 * NW);
 #pragma unroll
     for (int i = 0; i < PER_WAVE; ++i) {
         const int rg = (w * PER_WAVE + i) * 16;
@@ -57,6 +71,127 @@ __device__ __forceinline__ void mma_half8(const unsigned char *As, const unsigne
     }
 }
 
+// The two halves of a stage's work as separate steps (the staggered schedule below): all fragments of a 32-deep stage into
+// registers (6 x 2 ds_read_b128 for the 128 x 64 wave tile), then 16 MFMAs on registers only.
+template <int TI, int TJ> struct StageFrags { uint4 a[2][TI], b[2][TJ]; };
+
+template <int TI, int TJ>
+__device__ __forceinline__ void load_frags(StageFrags<TI, TJ> &f, const unsigned char *As, const unsigned char *Bs, int arow0, int brow0, int lane)
+{
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+            f.b[kk][j] = *reinterpret_cast<const uint4 *>(Bs + lds_off_h(brow0 + j * 32 + r, kk * 2 + h));
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+            f.a[kk][i] = *reinterpret_cast<const uint4 *>(As + lds_off_h(arow0 + i * 32 + r, kk * 2 + h));
+    }
+}
+
+template <typename T, int TI, int TJ>
+__device__ __forceinline__ void mma_frags(const StageFrags<TI, TJ> &f, f32x16_t (&acc)[TI][TJ])
+{
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+                acc[i][j] = h16<T>::mfma32(f.a[kk][i], f.b[kk][j], acc[i][j]);
+}
+
+// epilogue_regs (gemm_common.h) taken ONE 32-ROW SLICE of the wave tile at a time: the slice's values (bias, per-group term, BatchNorm
+// partials, activation -- the same expressions in the same order: same bits) are parked as 16-bit, read back as 16-byte row pieces and
+// stored, and the NEXT slice's arithmetic is issued while those stores drain.  Why: a CU retires ~12 B/clk of global stores whatever it
+// does (in-kernel stamps, tools/gemm256_stamp.py: 9 900 cycles for the 128 KiB of a 256 x 256 tile, 18 500 with the GELU in front of
+// them), and with one workgroup per CU nothing else covers that tail; sliced, the tail is max(stores, arithmetic) instead of their sum.
+// The park is 4 KiB per wave.
+template <int TI, int TJ, int EPI>
+__device__ __forceinline__ void epilogue_regs_sliced(const ppt_gemm_params &p, f32x16_t (&acc)[TI][TJ], const EpiPre<TI, TJ> &pre,
+                                                     unsigned char *park, int lane, int mw, int nw, int64_t zc)
+{
+    constexpr int act = EPI >> EPI_ACT_SHIFT;
+    constexpr bool has_group = (EPI & EPI_GROUP) != 0, has_stats = (EPI & EPI_STATS) != 0;
+    static_assert(TJ == 2 && (EPI & EPI_POOL) == 0, "64-column wave tiles, no pooling");
+    constexpr int WN = TJ * 32, ROWBYTES = WN * 2;
+    const int cl = lane & 31, h = lane >> 5, odd = cl & 1;
+    const int lane_byte = (4 * h + odd) * ROWBYTES + (cl >> 1) * 4;
+    constexpr int CPR = WN / 8, RP = 64 / CPR;                        // 16-byte chunks per row, rows per pass
+    const int ch = lane % CPR, rl = lane / CPR;
+    uint16_t *C = reinterpret_cast<uint16_t *>(p.C) + zc;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        const int mg = mw + i * 32;                                   // first row of this slice (wave-uniform)
+        const bool full = mg + 32 <= p.M;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int n = nw + j * 32 + cl;
+            const bool nok = n < p.N;
+            const float bias = pre.bias[j];
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] + bias;
+            if (has_group) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += pre.g[i][j][r < 8 ? 0 : 1];
+            }
+            if (has_stats && mg < p.M) {
+                bool rv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = full || (mg + (r & 3) + 8 * (r >> 2) + 4 * h) < p.M;
+                float sacc = 0.f, q = 0.f, mean;
+                if (full) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc += v[r];
+                    sacc = xor32_sum(sacc);
+                    mean = sacc * (1.0f / 32.0f);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { const float d = v[r] - mean; q = fmaf(d, d, q); }
+                    q = xor32_sum(q);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc += rv[r] ? v[r] : 0.f;
+                    sacc = xor32_sum(sacc);
+                    mean = sacc / (float)min(32, p.M - mg);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { const float d = v[r] - mean; q = rv[r] ? fmaf(d, d, q) : q; }
+                    q = xor32_sum(q);
+                }
+                if (h == 0 && nok) {
+                    p.col_sum[(int64_t)(mg >> 5) * p.N + n] = sacc;
+                    p.col_sqsum[(int64_t)(mg >> 5) * p.N + n] = q;
+                }
+            }
+            if (act != PPT_ACT_NONE) act_fwd_n<true, 16>(v, act);
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                // even lane keeps row(r): (own, neighbour's); odd lane keeps row(r+1): (neighbour's, own)
+                const float give = odd ? v[r] : v[r + 1];
+                const float got = __uint_as_float(dpp_mov<0xB1, 0xf>(__float_as_uint(give)));   // quad_perm [1,0,3,2]
+                const uint32_t wd = pack2_dt(p.c_dtype, odd ? got : v[r], odd ? v[r + 1] : got);
+                const int jb = (j ^ odd) << 6;                        // the written row (r + odd) is odd exactly on odd lanes
+                *reinterpret_cast<uint32_t *>(park + ((r & 3) + 8 * (r >> 2)) * ROWBYTES + jb + lane_byte) = wd;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int pass = 0; pass < 32 / RP; ++pass) {
+            const int row = pass * RP + rl;
+            const int m = mg + row;
+            const uint4 d = *reinterpret_cast<const uint4 *>(park + row * ROWBYTES + ((ch * 16) ^ ((row & 1) << 6)));
+            const int n = nw + ch * 8;
+            if (m < p.M && n < p.N) *reinterpret_cast<uint4 *>(C + (int64_t)m * p.ldc + n) = d;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");         // (the slice buffer is rewritten by the next slice)
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 // rows [HALF * PR, (HALF + 1) * PR) of a wave's accumulators -> fp32 park -> epilogue_vec8 (compile-time HALF: a runtime index into
 // the accumulator array would send it to scratch)
 template <int HALF, int PR, int TI, int TJ>
@@ -80,7 +215,7 @@ __device__ __forceinline__ void park_walk(const ppt_gemm_params &p, f32x16_t (&a
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <typename T, int BN, int NSTAGE, int EPI>
+template <typename T, int BN, int NSTAGE, int EPI, bool PP>
 // (the LDS-walk epilogue of the EPI < 0 kernels needs more than the 128 registers that two workgroups per CU would leave)
 __global__ __launch_bounds__(NT2, (BN == 256 || EPI < 0) ? 2 : 4) void gemm256_kernel(const ppt_gemm_params p)
 {
@@ -98,6 +233,7 @@ __global__ __launch_bounds__(NT2, (BN == 256 || EPI < 0) ? 2 : 4) void gemm256_k
     constexpr int BK = ROWH / sizeof(T);
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    G256_STAMP(0);
     PPT_PRIO(p.wave_prio);
     const int wm = w / WGN, wn = w % WGN;
     const int nwg = gridDim.x * gridDim.y;
@@ -124,23 +260,61 @@ __global__ __launch_bounds__(NT2, (BN == 256 || EPI < 0) ? 2 : 4) void gemm256_k
     for (int i = 0; i < NSTAGE - 1; ++i) issue(min(i, last), i);
     EpiPre<TI, TJ> epre;                                  // (behind the first stages: the K loop must not start later for it)
     epilogue_prefetch<TI, TJ, (EPI < 0 || (EPI & EPI_GROUP) != 0)>(p, epre, lane, m0 + wm * WM, n0 + wn * WN);
+    G256_STAMP(1);
     int stage = 0;
+    if constexpr (PP) {
+        // STAGGERED schedule (round 5, v2): a wave alternates LOAD(s) -- the stage's fragments into registers, the LDS-DMA of slab
+        // s + 3, the counted wait -- and COMPUTE(s) -- 16 MFMAs on registers -- with a workgroup barrier after each; waves 4-7 run
+        // ONE SEGMENT BEHIND waves 0-3 (one extra barrier up front, one less at the end).  Every SIMD holds one wave of each
+        // half, so while one computes the other loads: the matrix pipe never waits for a barrier or an LDS read.  (v1 above lets
+        // all 8 waves meet at one barrier per stage and then issue DMA + reads together: measured 0.36 of peak at 8192^3.)
+        // Slab s is read in segments 2s (waves 0-3) and 2s + 1 (waves 4-7); its slot is refilled with slab s + 4, issued in
+        // segments >= 2s + 2; a wave's wait at the end of LOAD(s) covers its pieces of slab s + 1, two segments before anyone
+        // reads them.
+        static_assert(NSTAGE == 4, "slot arithmetic below");
+        const bool late = w >= 4;
+        StageFrags<TI, TJ> fr;
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS * 2) : "memory");        // own pieces of slab 0 have landed
+        __builtin_amdgcn_s_barrier();                                              // ... everybody's
+        G256_STAMP(2);
+        if (late) __builtin_amdgcn_s_barrier();
+        for (int s = 0; s < nslab; ++s) {
+            load_frags<TI, TJ>(fr, smem + stage * STAGE, smem + stage * STAGE + A_BYTES, wm * WM, wn * WN, lane);
+            issue(min(s + 3, last), (stage + 3) & 3);
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" :: "n"(LOADS * 2) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            mma_frags<T, TI, TJ>(fr, acc);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            stage = (stage + 1) & 3;
+        }
+        if (!late) __builtin_amdgcn_s_barrier();
+    } else {
     for (int s = 0; s < nslab; ++s) {
         // own copies of slab s have landed (the LOADS * (NSTAGE - 2) youngest, slabs s+1 .., may still fly) ...
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS * (NSTAGE - 2)) : "memory");
         __builtin_amdgcn_s_barrier();                     // ... and so have everybody else's: slab s is readable
+        if (s == 0) G256_STAMP(2);
         int nstage = stage + NSTAGE - 1; if (nstage >= NSTAGE) nstage -= NSTAGE;
         issue(min(s + NSTAGE - 1, last), nstage);         // that stage was last read at slab s-1, before this barrier
         mma_half8<T, TI, TJ>(smem + stage * STAGE, smem + stage * STAGE + A_BYTES, wm * WM, wn * WN, lane, acc);
         stage = stage + 1 == NSTAGE ? 0 : stage + 1;
     }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // surplus prefetches must not land on the parked tile
     __builtin_amdgcn_s_barrier();
+    G256_STAMP(3);
 
     const int64_t zc = (int64_t)blockIdx.z * p.strideC;
     const int mw = m0 + wm * WM, nw = n0 + wn * WN;
     if constexpr (EPI >= 0) {
-        epilogue_regs<TI, TJ, EPI, 1>(p, acc, epre, smem + w * (WM * WN * 2), lane, mw, nw, zc);
+        if constexpr (SLICED_EPILOGUE) epilogue_regs_sliced<TI, TJ, EPI>(p, acc, epre, smem + w * (32 * WN * 2), lane, mw, nw, zc);
+        else epilogue_regs<TI, TJ, EPI, 1>(p, acc, epre, smem + w * (WM * WN * 2), lane, mw, nw, zc);
     } else {
         // row-major fp32 operands (residual stream, saved pre-activation, second output): the LDS walk, PR rows of the wave tile
         // at a time (an fp32 park of the whole 128 x 64 wave tile would be 256 KiB per workgroup)
@@ -153,6 +327,65 @@ __global__ __launch_bounds__(NT2, (BN == 256 || EPI < 0) ? 2 : 4) void gemm256_k
             park_walk<3, PR, TI, TJ>(p, acc, ct, lane, mw, nw, zc);
         }
     }
+#ifdef PPT_GEMM_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    G256_STAMP(4);
+#endif
+}
+
+// ---- the half-height tile: 128 x 256 per 256-thread workgroup, TWO workgroups per CU -------------------------------------------
+// Same wave tile (128 x 64: 4 waves as 1 x 4), 24 KiB stages (A 8 + B 16), three of them: 72 KiB, 200 VGPRs -> two workgroups
+// share a CU and nothing ties them together, so one's epilogue (a CU retires ~12 B/clk of stores: the 64 KiB of a tile take ~5 000
+// cycles, its GELU as long again) runs under the other's K loop.  The price is the fill: 85 FLOP per L2 -> LDS byte instead of 128.
+// For the short-K, wide-N linears (qkv, fc1: K = 384), where the 256 x 256 tile spends as long in its epilogue as in its K loop.
+template <typename T, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm128x256_kernel(const ppt_gemm_params p)
+{
+    constexpr int BM = 128, BN = 256, NSTAGE = 3;
+    constexpr int WM = 128, WN = 64, TI = 4, TJ = 2;
+    constexpr int A_BYTES = BM * ROWH, B_BYTES = BN * ROWH, STAGE = A_BYTES + B_BYTES;
+    constexpr int LOADS = BM / 64 + BN / 64;                                   // LDS-DMA instructions per wave per stage (6)
+    __shared__ __align__(16) unsigned char smem[NSTAGE * STAGE];
+    static_assert(NSTAGE * STAGE >= 4 * 32 * WN * 2, "sliced park");
+    constexpr int BK = ROWH / sizeof(T);
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    PPT_PRIO(p.wave_prio);
+    const int nwg = gridDim.x * gridDim.y;
+    const int lin0 = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q8 = nwg / 8, r8 = nwg % 8, xcd = lin0 % 8;
+    const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + lin0 / 8;
+    const int n0 = (lin % gridDim.x) * BN, m0 = (lin / gridDim.x) * BM;
+    const T *A = reinterpret_cast<const T *>(p.A) + (int64_t)blockIdx.z * p.strideA;
+    const T *B = reinterpret_cast<const T *>(p.B) + (int64_t)blockIdx.z * p.strideB;
+    const int nslab = p.K / BK, last = nslab - 1;
+    auto issue = [&](int slab, int stage) {
+        glds_half8<T, BM, 4>(A, p.lda, p.M, m0, slab * BK, smem + stage * STAGE, w, lane);
+        glds_half8<T, BN, 4>(B, p.ldb, p.N, n0, slab * BK, smem + stage * STAGE + A_BYTES, w, lane);
+    };
+    issue(0, 0);
+    issue(min(1, last), 1);
+    f32x16_t acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    EpiPre<TI, TJ> epre;
+    epilogue_prefetch<TI, TJ, (EPI & EPI_GROUP) != 0>(p, epre, lane, m0, n0 + w * WN);
+    int stage = 0;
+    for (int s = 0; s < nslab; ++s) {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS) : "memory");      // own pieces of slab s landed (slab s + 1 may fly)
+        __builtin_amdgcn_s_barrier();
+        int nstage = stage + 2; if (nstage >= NSTAGE) nstage -= NSTAGE;
+        issue(min(s + 2, last), nstage);                  // that stage was last read at slab s - 1, before this barrier
+        mma_half8<T, TI, TJ>(smem + stage * STAGE, smem + stage * STAGE + A_BYTES, 0, w * WN, lane, acc);
+        stage = stage + 1 == NSTAGE ? 0 : stage + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    epilogue_regs_sliced<TI, TJ, EPI>(p, acc, epre, smem + w * (32 * WN * 2), lane, m0, n0 + w * WN, (int64_t)blockIdx.z * p.strideC);
 }
 
 extern "C" int ppt_get_gemm256(void);
@@ -163,7 +396,7 @@ int env_int(const char *name, int dflt)
     return e ? atoi(e) : dflt;
 }
 
-template <typename T>
+template <typename T, bool PPV>
 int launch256(const ppt_gemm_params &p, int bn, hipStream_t s)
 {
     const int batch = p.batch > 0 ? p.batch : 1;
@@ -173,18 +406,33 @@ int launch256(const ppt_gemm_params &p, int bn, hipStream_t s)
     // partials: qkv, fc1, conv3); everything else takes the LDS walk (EPI = -1), which has no statistics / group term
     int epi = (p.C && reg_epilogue_ok<4>(p, 0)) ? epi_mask(p) : -1;
     if (epi != 0 && epi != EPI_GELU && !(bn == 256 && epi == (EPI_GROUP | EPI_STATS))) epi = -1;
+    // 128 x 256 tiles, two workgroups per CU, up to this K.  Measured (r05): no gain over the 256 x 256 tile -- fc1 47.4 vs 45.4 us,
+    // qkv 31.0 vs 32.2 us at 16 416 rows: what it wins back under the other workgroup's K loop it loses to the 1.5 x fill bytes
+    // per FLOP.  Off by default; PPT_GEMM256_HALF_K=512 to re-measure.
+    static const int half_k = env_int("PPT_GEMM256_HALF_K", 0);
+    if (bn == 256 && epi >= 0 && p.K <= half_k) {
+        dim3 g2((p.N + 255) / 256, (p.M + 127) / 128, batch);
+        if (g2.y > 65535) return PPT_EUNSUPPORTED;
+        switch (epi) {
+        case 0: hipLaunchKernelGGL((gemm128x256_kernel<T, 0>), g2, dim3(256), 0, s, p); break;
+        case EPI_GELU: hipLaunchKernelGGL((gemm128x256_kernel<T, EPI_GELU>), g2, dim3(256), 0, s, p); break;
+        default: hipLaunchKernelGGL((gemm128x256_kernel<T, EPI_GROUP | EPI_STATS>), g2, dim3(256), 0, s, p); break;
+        }
+        PPT_CHECK_LAUNCH();
+        return PPT_OK;
+    }
     if (bn == 256) {
         switch (epi) {
-        case 0: hipLaunchKernelGGL((gemm256_kernel<T, 256, 4, 0>), grid, dim3(NT2), 0, s, p); break;
-        case EPI_GELU: hipLaunchKernelGGL((gemm256_kernel<T, 256, 4, EPI_GELU>), grid, dim3(NT2), 0, s, p); break;
-        case EPI_GROUP | EPI_STATS: hipLaunchKernelGGL((gemm256_kernel<T, 256, 4, EPI_GROUP | EPI_STATS>), grid, dim3(NT2), 0, s, p); break;
-        default: hipLaunchKernelGGL((gemm256_kernel<T, 256, 4, -1>), grid, dim3(NT2), 0, s, p); break;
+        case 0: hipLaunchKernelGGL((gemm256_kernel<T, 256, 4, 0, PPV>), grid, dim3(NT2), 0, s, p); break;
+        case EPI_GELU: hipLaunchKernelGGL((gemm256_kernel<T, 256, 4, EPI_GELU, PPV>), grid, dim3(NT2), 0, s, p); break;
+        case EPI_GROUP | EPI_STATS: hipLaunchKernelGGL((gemm256_kernel<T, 256, 4, EPI_GROUP | EPI_STATS, PPV>), grid, dim3(NT2), 0, s, p); break;
+        default: hipLaunchKernelGGL((gemm256_kernel<T, 256, 4, -1, PPV>), grid, dim3(NT2), 0, s, p); break;
         }
     } else {
         switch (epi) {
-        case 0: hipLaunchKernelGGL((gemm256_kernel<T, 128, 3, 0>), grid, dim3(NT2), 0, s, p); break;
-        case EPI_GELU: hipLaunchKernelGGL((gemm256_kernel<T, 128, 3, EPI_GELU>), grid, dim3(NT2), 0, s, p); break;
-        default: hipLaunchKernelGGL((gemm256_kernel<T, 128, 3, -1>), grid, dim3(NT2), 0, s, p); break;
+        case 0: hipLaunchKernelGGL((gemm256_kernel<T, 128, 3, 0, false>), grid, dim3(NT2), 0, s, p); break;
+        case EPI_GELU: hipLaunchKernelGGL((gemm256_kernel<T, 128, 3, EPI_GELU, false>), grid, dim3(NT2), 0, s, p); break;
+        default: hipLaunchKernelGGL((gemm256_kernel<T, 128, 3, -1, false>), grid, dim3(NT2), 0, s, p); break;
         }
     }
     PPT_CHECK_LAUNCH();
@@ -204,7 +452,8 @@ extern "C" int ppt_gemm256_dispatch(const ppt_gemm_params *pp, int force, void *
     if (p.pool_max) return PPT_EUNSUPPORTED;               // (pools over 64-row groups assume TI == 2 wave tiles)
     // tile width: 256 columns when N fills them (N % 256 == 0, or wide enough that the ragged last tile is a small share),
     // else 128 (N = 384: three tiles instead of two with a quarter of the second one empty)
-    const int bn = (p.N % 256 == 0 || (p.N >= 1024 && (p.N % 256) >= 128)) ? 256 : 128;
+    static const int force_bn = env_int("PPT_GEMM256_BN", 0);       // (experiments: 128 / 256 forces the tile width)
+    const int bn = force_bn ? force_bn : ((p.N % 256 == 0 || (p.N >= 1024 && (p.N % 256) >= 128)) ? 256 : 128);
     const bool regs = p.C && reg_epilogue_ok<4>(p, 0);
     const int mask = regs ? epi_mask(p) : -1;
     const bool special = mask == 0 || mask == EPI_GELU || (bn == 256 && mask == (EPI_GROUP | EPI_STATS));
@@ -223,11 +472,22 @@ extern "C" int ppt_gemm256_dispatch(const ppt_gemm_params *pp, int force, void *
     static const int enabled = env_int("PPT_GEMM256", 1);
     static const int min_rows = env_int("PPT_GEMM256_MIN_ROWS", 8192);
     if (!force) {
+        // Where this core wins (tools/gemm256_bench.py, same-process interleaved A/B against the 64 x 64 / 128 x 128 loops;
+        // profiles/r05_gemm_core.md): every long-K problem (K >= 768: +7 ... +50 %), and short-K ones whose epilogue is a plain /
+        // residual store and whose grid is at least two full rounds of the 256 CUs (32 768 x 1536 x 384: +20 %).  Where it loses:
+        // short K with an activation epilogue or a 1.5-round grid (fc1 / qkv of a C2 batch: 16 416 x 1536 x 384 + GELU 47 vs 42 us)
+        // -- with ONE workgroup per CU nothing covers the tile's store tail (a CU retires ~12 B/clk of global stores: 128 KiB of
+        // C = 9 900 cycles, the GELU in front of it as long again, against 18 000 cycles of K loop at K = 384).
         const int mode = ppt_get_gemm256();
         if (!(mode < 0 ? enabled : mode) || p.M < min_rows) return PPT_EUNSUPPORTED;
+        static const int long_k = env_int("PPT_GEMM256_LONG_K", 768);
+        const int64_t tiles = (int64_t)((p.M + 255) / 256) * ((p.N + bn - 1) / bn) * (p.batch > 0 ? p.batch : 1);
+        if (p.K < long_k && !(p.act == PPT_ACT_NONE && tiles >= 512)) return PPT_EUNSUPPORTED;
     }
     hipStream_t s = ppt_stream(stream);
-    return p.dtype == PPT_BF16 ? launch256<bf16_t>(p, bn, s) : launch256<f16_t>(p, bn, s);
+    static const int stagger = env_int("PPT_GEMM256_PP", 1);         // the staggered schedule (0: one barrier per stage, v1)
+    if (stagger) return p.dtype == PPT_BF16 ? launch256<bf16_t, true>(p, bn, s) : launch256<f16_t, true>(p, bn, s);
+    return p.dtype == PPT_BF16 ? launch256<bf16_t, false>(p, bn, s) : launch256<f16_t, false>(p, bn, s);
 }
 
 extern "C" int ppt_gemm256(const ppt_gemm_params *pp, void *stream)

@@ -1,2 +1,3 @@
 """Host-side data helpers on the path's kernels: the dataset's numpy farthest point sampling."""
 from .dataset_3d import farthest_point_sample, pc_normalize  # noqa: F401
+from .prefetch import DevicePrefetcher  # noqa: F401

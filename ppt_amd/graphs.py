@@ -98,6 +98,20 @@ def shared_text_stream(device=None, priority=None):
     return _TEXT_STREAMS[dev]
 
 
+def ready_event(t):
+    """The event that marks tensor `t` complete in device memory, if its producer attached one (ppt_amd.data.DevicePrefetcher:
+    the end of the host-to-device copy on the copy stream), else None.  An input-only stage may then start on its own stream
+    behind this event alone -- it need not wait for the caller's stream, and the caller need not vouch for anything."""
+    return getattr(t, "_ppt_ready", None)
+
+
+def wait_inputs(stream, tensors):
+    for t in tensors:
+        ev = ready_event(t)
+        if ev is not None:
+            stream.wait_event(ev)
+
+
 class AheadStage:
     """A shape-static stage that depends on the step's INPUTS only (FPS, ball queries, kNN), replayed on its own stream
     as soon as the step is called -- under the previous iteration's compute instead of at the head of this one's.  Two
@@ -116,6 +130,7 @@ class AheadStage:
         with torch.cuda.stream(side):
             if self.free[slot] is not None:
                 side.wait_event(self.free[slot])
+            wait_inputs(side, ins)                    # (a DevicePrefetcher batch: behind its copy; a vouched-for tensor: nothing)
             outs, _ = cache.get(tuple(key) + (slot,), lambda: GraphedCall(fn, ins))(*ins)
             done = side.record_event()
         for t in ins:

@@ -731,7 +731,7 @@ class ULIP_WITH_IMAGE(nn.Module):
         if self.training and torch.is_grad_enabled() and self.chain_priority():
             ahead = getattr(self.point_encoder, "group_ahead", None) is not None
             return ops.persistent_occupancy(int(os.environ.get("PPT_TOWER_OCCUPANCY", "70" if ahead else "80")))
-        if not self.training and not torch.is_grad_enabled() and self.eval_inputs_ready:
+        if not self.training and not torch.is_grad_enabled() and (self.eval_inputs_ready or getattr(self.point_encoder, "group_ahead", None) is not None):
             # validate() with the next batch's tokenizer on its own stream: its persistent kernels leave a fifth of the CUs to
             # the blocks they run beside (C2 eval 2.44 -> 2.40 ms; 60 %: 2.43, 40 %: 2.56)
             return ops.persistent_occupancy(int(os.environ.get("PPT_EVAL_OCCUPANCY", "80")))
@@ -855,7 +855,7 @@ class ULIP_WITH_IMAGE(nn.Module):
             with torch.cuda.stream(side):
                 text_embed = self._text_embed()
         pe = self.point_encoder
-        ahead = (self.eval_inputs_ready and not self.training and not torch.is_grad_enabled() and pc.is_cuda
+        ahead = ((self.eval_inputs_ready or graphs.ready_event(pc) is not None) and not self.training and not torch.is_grad_enabled() and pc.is_cuda
                  and hasattr(pe, "group_ahead") and self.task != 'partseg')
         if ahead:
             # validate() with resident inputs (eval_inputs_ready): the next batch's FPS + kNN + tokenizer on the grouping stream,

@@ -417,6 +417,7 @@ class PointTransformer(nn.Module):
         with torch.cuda.stream(side):
             if self._group_free[slot] is not None:
                 side.wait_event(self._group_free[slot])
+            graphs.wait_inputs(side, ins)             # (a DevicePrefetcher batch: behind its copy; a vouched-for tensor: nothing)
             grouped, _ = self._graphs.get(key, build)(*ins)
             done = side.record_event()
         for t in ins:

@@ -320,7 +320,10 @@ class Trainer:
         pe = getattr(model, "point_encoder", None)
         if hasattr(pe, "group_ahead"):
             from . import graphs
-            use = self.inputs_ready and pc.is_cuda and side is not None and (
+            # the batch is known to be complete in device memory at a point the ahead stage can wait for: the caller vouches for it
+            # (inputs_ready), or its producer attached the event of its copy (ppt_amd.data.DevicePrefetcher)
+            ready = self.inputs_ready or graphs.ready_event(pc) is not None
+            use = ready and pc.is_cuda and side is not None and (
                 self.group_ahead_when_frozen or not self._point_side_frozen or getattr(pe, "group_ahead_pays_when_frozen", False))
             # DDP's per-forward buffer broadcast writes the BatchNorm running statistics on THIS stream while an ahead stage would
             # update them on the grouping stream, which deliberately does not wait for this one: an unordered read-modify-write

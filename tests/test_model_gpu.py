@@ -267,6 +267,57 @@ def test_run_ahead_training_is_identical(head_type):
             assert torch.equal(wa[n], wb[n]), n
 
 
+@pytest.mark.parametrize("head_type", [0, 3])
+def test_device_prefetcher_feeds_the_ahead_stage_bit_identically(head_type):
+    """an unchanged main_cls.py:171-194 loop whose loader is wrapped in ppt_amd.data.DevicePrefetcher.  The batches
+    come from pinned HOST memory every step (a different one each step), nothing is vouched for (Trainer.inputs_ready False): the
+    tokenizer stage of a step still runs ahead on the grouping stream, behind the EVENT of the batch's own copy.  Losses, logits
+    and trained parameters are the in-order run's, bit for bit; eval (validate()) likewise."""
+    from ppt_amd import graphs
+    from ppt_amd.data import DevicePrefetcher
+    from ppt_amd.train import Trainer
+    pc, start = oracle_inputs()
+    label = torch.tensor([3, 17, 0, 39])
+    host = [(torch.roll(pc, it, 0).contiguous().pin_memory(), label.pin_memory()) for it in range(7)]
+    results = []
+    for fed in (False, True):
+        m, _ = build(head_type, torch.bfloat16)
+        m.overlap_text_tower = True
+        m.train()
+        m.point_encoder.fps_start = torch.from_numpy(start).cuda()
+        m.point_encoder.drop_path_factors = torch.ones(12, 2, 4)
+        tr = Trainer(m, lr=3e-3, label_smoothing=0.2, distributed=False)
+        assert tr.inputs_ready is False
+        losses = []
+        if fed:
+            for pc_d, lab_d in DevicePrefetcher(host):
+                assert graphs.ready_event(pc_d) is not None
+                pc_d = pc_d.cuda(non_blocking=True)                 # main_cls.py:188: a no-op on a device tensor
+                loss, pred = tr.step(pc_d, lab_d)
+                losses.append(loss)
+        else:
+            for pc_h, lab_h in host:
+                loss, pred = tr.step(pc_h.cuda(), lab_h.cuda())
+                losses.append(loss)
+        tr.finish()
+        torch.cuda.synchronize()
+        kinds = {k[0] for k in m.point_encoder._graphs.entries}
+        assert ("tokens" in kinds or "group" in kinds) == fed, kinds       # the ahead stage ran exactly when the copies carried events
+        m.eval()
+        with torch.no_grad():
+            if fed:
+                ev = [m(b[0]).float().clone() for b in DevicePrefetcher(host[:4])]
+            else:
+                ev = [m(b[0].cuda()).float().clone() for b in host[:4]]
+        results.append(([l.item() for l in losses], pred.clone(), {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad}, ev))
+    (la, pa, wa, ea), (lb, pb, wb, eb) = results
+    assert la == lb and torch.equal(pa, pb)
+    for n in wa:
+        assert torch.equal(wa[n], wb[n]), n
+    for x, y in zip(ea, eb):
+        assert torch.equal(x, y)
+
+
 def test_saved_activations_do_not_live_in_the_ahead_stage_buffers():
     """head_type 3 with every RNG draw on the device and the tokenizer running ahead: the last block keeps activations for its
     backward, and the stage of a later step (which waits for the forward only) rewrites its ping-pong buffers -- so the prefix graph

@@ -27,6 +27,13 @@ def shapes(rows):
         "fc2": dict(M=rows, N=384, K=1536, bias=True, residual=True),
         "proj": dict(M=rows, N=384, K=384, bias=True, residual=True),
         "conv3": dict(M=rows * 32 // 1, N=512, K=256) if False else dict(M=524288, N=512, K=256),
+        "dg1": dict(M=131072, N=512, K=768),                 # C5 decoder shapes (16 x 2048 points, k = 4 neighbours)
+        "dg1b": dict(M=131072, N=768, K=512),
+        "dg2": dict(M=131072, N=384, K=1024),
+        "p1": dict(M=32768, N=384, K=1536, bias=True),
+        "p0b": dict(M=32768, N=1536, K=384),
+        "fc1c3": dict(M=32832, N=1536, K=384, bias=True, act=ops.ACT_GELU),
+        "fc2c3": dict(M=32832, N=384, K=1536, bias=True, residual=True),
         "sq4k": dict(M=4096, N=4096, K=4096),
         "sq8k": dict(M=8192, N=8192, K=8192),
     }
