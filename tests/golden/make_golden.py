@@ -150,10 +150,14 @@ def set_droppath(m, masks):
         blk.drop_path.forward = fwd
 
 
-def gen_encoder_and_step(tok, head_types=(0, 1, 2, 3)):
+def gen_encoder_and_step(tok, head_types=(0, 1, 2, 3), profile=""):
+    """profile "": the std-0.02 synthetic weights; "ckpt": the same train step on checkpoint-LIKE magnitudes
+    (ppt_amd.weights.checkpoint_like: LayerNorm gains up to 10, outlier channels, 3 x larger weight matrices) -> g_step_h{n}_ckpt.npz."""
     names = tok["datasets"]["modelnet40"]
     name_lengths = [len(tok["name_tokens"][n.replace("_", " ")]) for n in names]
     sd = W.ulip_pointbert_state_dict(seed=0)
+    if profile == "ckpt":
+        sd = W.checkpoint_like(sd, seed=0)
     emb = W.synth_prompt_embedding(len(names), seed=0)
     B, N = 4, 1024
     pc_np, start = W.synth_clouds(B, N, seed=77)
@@ -178,7 +182,7 @@ def gen_encoder_and_step(tok, head_types=(0, 1, 2, 3)):
         eot = m.tokenized_prompts.argmax(-1).numpy()
         assert m.prompt_learner.name_lengths == name_lengths
 
-        if head_type == 0:
+        if head_type == 0 and not profile:
             # ---- G4: mini-PointNet in eval and train BN modes (dvae.py:184-215)
             cidx = O.fps(pc_np, 512, start)
             _, nb, ce = O.group(pc_np, cidx, 32)
@@ -232,7 +236,7 @@ def gen_encoder_and_step(tok, head_types=(0, 1, 2, 3)):
         print(f"[h{head_type}] loss ref {loss.item():.6f} oracle {res['loss'].item():.6f}")
         e = (pred.detach() - res["logits"]).abs().max().item()
         print(f"[h{head_type}] logits max|diff| {e:.3e} (|logits|max {pred.abs().max().item():.2f})")
-        assert e < 5e-3 and abs(loss.item() - res["loss"].item()) < 1e-4
+        assert e < (5e-3 if not profile else 5e-2) and abs(loss.item() - res["loss"].item()) < (1e-4 if not profile else 5e-3)
         assert sorted(grads) == sorted(res["grads"]), (sorted(grads), sorted(res["grads"]))
         fx = dict(logits=pred.detach().numpy(), loss=np.float32(loss.item()), labels=labels.numpy(),
                   eot=eot.astype(np.int16), fps_start=start,
@@ -244,7 +248,7 @@ def gen_encoder_and_step(tok, head_types=(0, 1, 2, 3)):
             # so that the optimiser restatement is pinned tightly, independent of gradient noise.
             pe = (newp[k] - O.adamw_update(sd[k], g, {}, 3e-3)).abs().max().item()
             print(f"[h{head_type}] grad {k}: |g| {g.norm().item():.3e} rel.err {rel:.2e}; post-AdamW max|diff| {pe:.2e}")
-            assert rel < 2e-3 and pe < 1e-6
+            assert rel < (2e-3 if not profile else 2e-2) and pe < 1e-6
             if g.numel() <= 20000:
                 fx["grad_" + k] = g.numpy()
                 fx["new_" + k] = newp[k].numpy()
@@ -256,9 +260,9 @@ def gen_encoder_and_step(tok, head_types=(0, 1, 2, 3)):
             ee = (msd[k].float() - v.float()).abs().max().item()
             assert ee < 1e-5, (k, ee)
             fx["stat_" + k] = msd[k].numpy()
-        np.savez_compressed(os.path.join(HERE, f"g_step_h{head_type}.npz"), **fx)
+        np.savez_compressed(os.path.join(HERE, f"g_step_h{head_type}{'_' + profile if profile else ''}.npz"), **fx)
 
-        if head_type == 0:
+        if head_type == 0 and not profile:
             # eval-mode forward (validate(), main_cls.py:237-299): running stats, no DropPath
             m.load_state_dict({k: v for k, v in sd.items()}, strict=False)
             m.prompt_learner.embedding = emb.clone()
@@ -608,10 +612,13 @@ if __name__ == "__main__":
         gen_blocks(gen_tokens())
     elif sys.argv[1:2] == ["steps"]:            # the train-step fixtures of the given head_types only
         gen_encoder_and_step(gen_tokens(), tuple(int(h) for h in sys.argv[2:]))
+    elif sys.argv[1:2] == ["ckpt"]:             # ... on checkpoint-like weight magnitudes (VERDICT r4 #4b)
+        gen_encoder_and_step(gen_tokens(), tuple(int(h) for h in sys.argv[2:]) or (0, 3), profile="ckpt")
     else:
         tok = gen_tokens()
         gen_index()
         gen_encoder_and_step(tok)
+        gen_encoder_and_step(tok, (0, 3), profile="ckpt")
         gen_pointnet2_msg()
         gen_pointnet2_ssg()
         gen_pointmlp()

