@@ -132,6 +132,20 @@ def operand_formats(model_name):
     return {"text_tower": text, "point_encoder": "bf16", "heads": "f32"}
 
 
+def formats_of(model, model_name):
+    """operand_formats() corrected by what the model decided at run time: the text tower's half-vs-fp32 self-check
+    (ULIP_WITH_IMAGE.calibrate_text_precision) and the health monitor's demotions."""
+    f = operand_formats(model_name)
+    if getattr(model, "text_precision", None) is torch.float32:
+        f["text_tower"] = "f32"
+    cal = getattr(model, "text_calibration", None)
+    if cal:
+        f["text_tower_half_vs_fp32_rel_l2"] = round(cal["rel_l2"], 6)
+    if getattr(model, "demoted", None):
+        f["demoted_to_bf16"] = sorted(model.demoted)
+    return f
+
+
 def measured_parity():
     """The performance mode's error on the golden train step (tests/golden/g_step_h0.npz: B = 4 x 1024 points, head_type 0,
     logits / loss / token gradient captured from the upstream reference; fixtures are data, no oracle involved): what the
@@ -290,7 +304,7 @@ def main_eval(a):
            "dtype": "f16" if set(operand_formats(cfg.get("model", "ULIP_PointBERT")).values()) <= {"f16", "f32"} else "f16/bf16",
            "data": "synthetic",
            "config": {"workload": cfg["name"] + ", eval-mode forward under no_grad (validate(), main_cls.py:237-299)", "feed": FEED,
-                      "operand_formats": operand_formats(cfg.get("model", "ULIP_PointBERT")),
+                      "operand_formats": formats_of(model, cfg.get("model", "ULIP_PointBERT")),
                       "per_gpu_batch": B, "npoints": N, "parallelism": "dp1"}}
     print(json.dumps(out), flush=True)
 
@@ -475,7 +489,7 @@ def main():
                "dtype": "f16" if set(operand_formats(cfg.get("model", "ULIP_PointBERT")).values()) <= {"f16", "f32"} else "f16/bf16",
                "data": "synthetic",
                "config": {"workload": cfg["name"] + ", train-mode BN + DropPath, fwd + CE(ls 0.2) + bwd + AdamW", "feed": FEED,
-                          "operand_formats": operand_formats(cfg.get("model", "ULIP_PointBERT")),
+                          "operand_formats": formats_of(model, cfg.get("model", "ULIP_PointBERT")),
                           "per_gpu_batch": PER_GPU_BATCH, "global_batch": PER_GPU_BATCH * world, "npoints": NPOINTS,
                           "classes": n_classes, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
                "roofline": roof}

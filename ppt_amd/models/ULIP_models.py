@@ -601,6 +601,11 @@ class ULIP_WITH_IMAGE(nn.Module):
         self.eval_inputs_ready = False
         self._chain_prio = None
         self.health = None                  # ppt_amd.health.Monitor (train.Trainer installs one in the mixed 16-bit mode)
+        # The text tower's operand format: None = what the mode says (IEEE half in "mixed16"); torch.float32 = fp32 operands whatever
+        # the mode (PPT_TEXT_PRECISION=fp32, or calibrate_text_precision() below found half too coarse for THESE weights).
+        self.text_precision = torch.float32 if os.environ.get("PPT_TEXT_PRECISION", "").lower() in ("fp32", "float32") else None
+        self.text_calibration = None        # what calibrate_text_precision measured: {"rel_l2": ..., "threshold": ..., "demoted": bool}
+        self._text_calibrated = False
         # stages this model's monitor moved from IEEE half to bf16 (health.demote); ONE set per model, shared with the point
         # encoder and every WeightCache of either
         self.demoted = point_encoder.__dict__.setdefault("demoted", set()) if isinstance(point_encoder, nn.Module) else set()
@@ -668,6 +673,10 @@ class ULIP_WITH_IMAGE(nn.Module):
         # (internally the mode marker stays a dtype: torch.bfloat16 = mixed16, torch.float32 = parity)
         self.point_encoder.precision = dtype
         self.point_encoder._wc = None
+        self._text_calibrated = False
+        if self.text_calibration is not None and self.text_calibration.get("demoted"):
+            self.text_precision = None              # (a calibration's verdict belongs to the mode and weights it was taken on)
+        self.text_calibration = None
         self._graphs.clear()
         if hasattr(self.point_encoder, "_graphs"):
             self.point_encoder._graphs.clear()
@@ -753,6 +762,10 @@ class ULIP_WITH_IMAGE(nn.Module):
         self._wc = None
         self._te_cache = None
         self._chain_prio = None
+        self._text_calibrated = False               # new weights: the half-vs-fp32 check of the text tower runs again
+        if self.text_calibration is not None and self.text_calibration.get("demoted"):
+            self.text_precision = None
+        self.text_calibration = None
         self._graphs.clear()
         pe = getattr(self, "point_encoder", None)
         if pe is not None:
@@ -811,8 +824,58 @@ class ULIP_WITH_IMAGE(nn.Module):
         lead = pc_feat.shape[:-1]
         return matmul_nt(pc_feat.reshape(-1, pc_feat.shape[-1]), wt, self._head_precision()).view(*lead, -1)
 
+    TEXT_CALIBRATION_THRESHOLD = 1e-2
+
+    def calibrate_text_precision(self, threshold=None, force=False):
+        """The mixed 16-bit mode checks ITSELF against fp32 on the weights it was given (round 5).  Every parity
+        bound of this repository was measured on std-0.02 synthetic weights, where the CLIP text tower on IEEE-half operands is within
+        1e-3 of fp32.  On checkpoint-LIKE magnitudes (ppt_amd.weights.checkpoint_like: LayerNorm gains with 5-10 x outlier channels,
+        3 x larger weight matrices -- attention scores of O(100)) the same tower is off by 8 % rms of the logit range and the token
+        gradient by more than its own norm: finite, so health.Monitor never sees it (tools/ckpt_like_error.py: text tower 14.3 of
+        |logits| <= 72; with the text tower on fp32 operands 0.49, every other stage left in half).  So, once per weight set, the text
+        features of the CURRENT prompts are computed on half and on fp32 operands (two forwards of the 817-row tower, no_grad, eager)
+        and compared: relative L2 distance of the L2-normalised features above `threshold` (default 1e-2; 2.6e-4 on the synthetic
+        weights) -> the text tower runs on fp32 operands from here on (`text_precision = torch.float32`), with a warning.  The result
+        is kept in `text_calibration`.  PPT_TEXT_CALIBRATE=0 turns the check off; set_precision / load_state_dict re-arm it."""
+        if (self._text_calibrated and not force) or os.environ.get("PPT_TEXT_CALIBRATE", "1") == "0":
+            return self.text_calibration
+        self._text_calibrated = True
+        tok = self.prompt_learner.learnable_tokens
+        if self.precision != torch.bfloat16 or self.text_precision is not None or not tok.is_cuda:
+            return self.text_calibration
+        if torch.cuda.is_current_stream_capturing():
+            self._text_calibrated = False
+            return self.text_calibration
+        thr = self.TEXT_CALIBRATION_THRESHOLD if threshold is None else float(threshold)
+        graphs_on, self.use_hip_graphs = self.use_hip_graphs, False
+        try:
+            with torch.no_grad():
+                lo = self._text_raw().float()
+                self.text_precision, self._wc = torch.float32, None
+                hi = self._text_raw().float()
+        finally:
+            self.use_hip_graphs = graphs_on
+            self.text_precision, self._wc = None, None
+        lo = lo / lo.norm(dim=-1, keepdim=True)
+        hi = hi / hi.norm(dim=-1, keepdim=True)
+        rel = float(((lo - hi).norm() / hi.norm()).item())
+        bad = not (rel <= thr)                      # (NaN -> demote as well)
+        self.text_calibration = {"rel_l2": rel, "threshold": thr, "demoted": bad}
+        self._te_cache = None
+        if bad:
+            import warnings
+            self.text_precision = torch.float32
+            self._graphs.clear()
+            warnings.warn(f"ppt_amd: on these weights the CLIP text tower on IEEE-half operands differs from fp32 by {rel:.3g} "
+                          f"(relative L2 of the normalised text features; threshold {thr:g}): the text tower runs on fp32 operands "
+                          "from here on (slower prompt chain, reference-grade text features and token gradients).  "
+                          "PPT_TEXT_CALIBRATE=0 keeps half.", RuntimeWarning, stacklevel=3)
+        return self.text_calibration
+
     def _text_raw(self):
         """encode_text(prompt_learner()) -- through the one-kernel prompt assembly (_TextTowerTokensFn) on a GPU."""
+        if not self._text_calibrated:
+            self.calibrate_text_precision()
         tok = self.prompt_learner.learnable_tokens
         if self.fused_prompt_rows and tok.is_cuda and self.prompt_learner.class_name_position in ("front", "middle", "end"):
             return _TextTowerTokensFn.apply(self, tok)

@@ -188,7 +188,7 @@ def test_partseg_checkpoint_written_on_the_gpu_resumes_bit_identically(tmp_path)
     ref_opt = torch.optim.AdamW(b.parameters(), lr=5.0)                      # main_partseg.py:62
     ref_opt.load_state_dict(ckpt['optimizer'])
     trained = [n for n, p in b.named_parameters() if p.requires_grad]
-    assert len(ref_opt.state) == len(trained) - 1                           # conv2 (unused in forward) never stepped
+    assert len(ref_opt.state) == len(trained) - 2                           # conv2.{weight,bias} (unused in forward) never stepped
     load_prompt_checkpoint(b, ckpt)
     b.reset_caches()
     tr_b = prepare(b)
