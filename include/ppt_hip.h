@@ -42,7 +42,8 @@ extern "C" {
 
 const char *ppt_strerror(int code);
 /* ABI version of this header (currently 5); bumped on any signature change or added entry point.
- * 5: ppt_labels_check (new), ppt_gemm256 (new: the 256-row macro-tile GEMM core).
+ * 5: ppt_labels_check (new), ppt_gemm256 (new: the 256-row macro-tile GEMM core), ppt_set_gemm256 / ppt_get_gemm256 (new),
+ *    ppt_layernorm_fwd_sum / ppt_layernorm_bwd_sum (new: split-K consumers), ppt_adamw_* (skipped == NULL: no guard).
  * 3: PPT_F16 (dtype arguments / struct fields), ppt_cross_entropy_rows (ignored labels, loss[2]), ppt_adamw_step (grad_scale),
  *    ppt_bn_rows_bwd_apply (half_dtype), ppt_*_half entry points.
  * 4: gradient scaling local to the 16-bit backward stages -- ppt_convert_scaled (new), ppt_rows_matmul_f32 (alpha),
@@ -276,6 +277,16 @@ int ppt_layernorm_fwd(const float *x, const float *add, int add_rows, float *xs,
 int ppt_layernorm_bwd(const float *dy, const float *xs, const float *w, const float *mean,
                       const float *rstd, float *dx, int accumulate_dx, void *dx_copy, int dx_copy_dtype,
                       float *dw_partial, float *db_partial, int partial_rows, int M, int D, void *stream);
+/* The consumer side of a SPLIT-K linear (ABI 5; the prompt chain's K = 1536 / 2048 linears over 817 rows, ULIP_models.py:35-67:
+ * 104 workgroups walking K serially at one CU's L2 -> LDS rate): the S partial products are written by ppt_gemm as plain fp32
+ * slices parts[S][M][D] (batch = S, no epilogue) and the LayerNorm that reads the result adds them up in slice order -- no reduction
+ * launch, no atomics, fixed summation order.
+ * fwd_sum: row = x + bias + parts[0] + ... + parts[S-1] (bias [D] or NULL); xs receives the row, y = LN(row); D % 8 == 0, D <= 512.
+ * bwd_sum: ppt_layernorm_bwd's input-gradient form (no dw / db) with dy = parts[0] + ... + parts[S-1]. */
+int ppt_layernorm_fwd_sum(const float *x, const float *bias, const float *parts, int S, float *xs, const float *w, const float *b,
+                          void *y, int y_dtype, float *mean, float *rstd, int M, int D, float eps, void *stream);
+int ppt_layernorm_bwd_sum(const float *dy_parts, int S, const float *xs, const float *w, const float *mean, const float *rstd,
+                          float *dx, int accumulate_dx, void *dx_copy, int dx_copy_dtype, int M, int D, void *stream);
 
 /* ---- Attention ---------------------------------------------------------------------------------
  * softmax(scale * q k^T [+ causal mask]) v per (batch, head).  Replaces

@@ -106,6 +106,10 @@ _SIGNATURES = {
                                   c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "ppt_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                   c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ppt_layernorm_fwd_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                      c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "ppt_layernorm_bwd_sum": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                      c_void_p, c_int, c_int, c_int, c_void_p]),
     "ppt_col_sums": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p]),
     "ppt_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int,
                                   c_int, c_void_p]),

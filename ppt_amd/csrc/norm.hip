@@ -57,12 +57,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x
 // (+ two for the fused add) and ONE 16-byte bf16 store per lane instead of six 4-byte loads and six 2-byte stores;
 // gamma / beta stay in registers while the wave walks its rows (rows strided by the number of waves in the grid).
 // Same arithmetic as ln_fwd_kernel (two-pass mean / variance), summed in a different lane order.
-template <typename TY>
+// SUM (round 5): the row is x + bias + parts[0] + ... + parts[S-1] (added in that order) -- the consumer side of a split-K GEMM
+// whose S partial products were written as plain fp32 slices [S, M, D]: the reduction costs no launch of its own, no atomics, and
+// the summation order is fixed (the prompt chain's K = 2048 linears: engine.text_tower_forward).
+template <typename TY, bool SUM = false>
 __global__ __launch_bounds__(256) void ln_fwd_vec8_kernel(const float *__restrict__ x, const float *__restrict__ add,
                                                           int add_rows, float *__restrict__ xs,
                                                           const float *__restrict__ w, const float *__restrict__ b,
                                                           TY *__restrict__ y, float *__restrict__ mean_out,
-                                                          float *__restrict__ rstd_out, int M, int D, float eps, int prio)
+                                                          float *__restrict__ rstd_out, int M, int D, float eps, int prio,
+                                                          const float *__restrict__ sum_bias = nullptr,
+                                                          const float *__restrict__ parts = nullptr, int S = 0)
 {
     PPT_PRIO(prio);
     const int lane = threadIdx.x & 63;
@@ -84,6 +89,17 @@ __global__ __launch_bounds__(256) void ln_fwd_vec8_kernel(const float *__restric
             const float *ar = add + (size_t)(add_rows > 0 ? row % add_rows : row) * D + c;
             const float4 a0 = *reinterpret_cast<const float4 *>(ar), a1 = *reinterpret_cast<const float4 *>(ar + 4);
             v0.x += a0.x; v0.y += a0.y; v0.z += a0.z; v0.w += a0.w; v1.x += a1.x; v1.y += a1.y; v1.z += a1.z; v1.w += a1.w;
+        }
+        if constexpr (SUM) {
+            if (sum_bias) {
+                const float4 a0 = *reinterpret_cast<const float4 *>(sum_bias + c), a1 = *reinterpret_cast<const float4 *>(sum_bias + c + 4);
+                v0.x += a0.x; v0.y += a0.y; v0.z += a0.z; v0.w += a0.w; v1.x += a1.x; v1.y += a1.y; v1.z += a1.z; v1.w += a1.w;
+            }
+            for (int z = 0; z < S; ++z) {
+                const float *pr = parts + ((size_t)z * M + row) * D + c;
+                const float4 a0 = *reinterpret_cast<const float4 *>(pr), a1 = *reinterpret_cast<const float4 *>(pr + 4);
+                v0.x += a0.x; v0.y += a0.y; v0.z += a0.z; v0.w += a0.w; v1.x += a1.x; v1.y += a1.y; v1.z += a1.z; v1.w += a1.w;
+            }
         }
         float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
         float s = 0.f;
@@ -180,10 +196,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ d
 // row, a lane owns EIGHT consecutive columns -- two 16-byte loads per tensor, and the row of dx that the result is added to is
 // requested together with dy and xs instead of after the reduction (the scalar kernel's third dependent round trip); the bf16
 // operand copy leaves as one 16-byte store per lane.  8.5 -> ~5 us for 817 x 512 (24 launches per step of the prompt chain).
+// S > 0 (round 5): dy is the sum of S fp32 slices [S, M, D] (a split-K dX GEMM's partial products), added in slice order.
 __global__ __launch_bounds__(256) void ln_bwd_dx8_kernel(const float *__restrict__ dy, const float *__restrict__ xs,
                                                          const float *__restrict__ w, const float *__restrict__ mean,
                                                          const float *__restrict__ rstd, float *__restrict__ dx, int accumulate,
-                                                         void *__restrict__ dx_copy, int copy_dtype, int M, int D, int prio)
+                                                         void *__restrict__ dx_copy, int copy_dtype, int M, int D, int prio, int S = 0)
 {
     PPT_PRIO(prio);
     const int lane = threadIdx.x & 63;
@@ -194,6 +211,11 @@ __global__ __launch_bounds__(256) void ln_bwd_dx8_kernel(const float *__restrict
     float4 d0 = make_float4(0.f, 0.f, 0.f, 0.f), d1 = d0, x0 = d0, x1 = d0, a0 = d0, a1 = d0, w0 = d0, w1 = d0;
     if (act) {
         d0 = *reinterpret_cast<const float4 *>(dy + off); d1 = *reinterpret_cast<const float4 *>(dy + off + 4);
+        for (int z = 1; z < S; ++z) {
+            const float *pr = dy + (size_t)z * M * D + off;
+            const float4 e0 = *reinterpret_cast<const float4 *>(pr), e1 = *reinterpret_cast<const float4 *>(pr + 4);
+            d0.x += e0.x; d0.y += e0.y; d0.z += e0.z; d0.w += e0.w; d1.x += e1.x; d1.y += e1.y; d1.z += e1.z; d1.w += e1.w;
+        }
         x0 = *reinterpret_cast<const float4 *>(xs + off); x1 = *reinterpret_cast<const float4 *>(xs + off + 4);
         w0 = *reinterpret_cast<const float4 *>(w + lane * 8); w1 = *reinterpret_cast<const float4 *>(w + lane * 8 + 4);
         if (accumulate) { a0 = *reinterpret_cast<const float4 *>(dx + off); a1 = *reinterpret_cast<const float4 *>(dx + off + 4); }
@@ -290,6 +312,43 @@ extern "C" int ppt_layernorm_bwd(const float *dy, const float *xs, const float *
     }
     hipLaunchKernelGGL(ln_bwd_kernel, dim3((used + 3) / 4), dim3(256), 0, ppt_stream(stream), dy, xs, w, mean, rstd, dx,
                        accumulate_dx, dx_copy, dx_copy_dtype, dw_partial, db_partial, rpw, M, D, ppt_get_wave_priority());
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
+// LayerNorm of x + bias + parts[0] + ... + parts[S-1] (split-K consumer, see ln_fwd_vec8_kernel<.., true>); xs (required) receives
+// the summed row.  D % 8 == 0, D <= 512, 16-byte aligned operands.
+extern "C" int ppt_layernorm_fwd_sum(const float *x, const float *bias, const float *parts, int S, float *xs, const float *w, const float *b,
+                                     void *y, int y_dtype, float *mean, float *rstd, int M, int D, float eps, void *stream)
+{
+    if (!x || !parts || !xs || !w || !b || !y || S <= 0 || S > 8 || M <= 0 || D <= 0) return PPT_EINVAL;
+    if ((D % 8) != 0 || D > 512) return PPT_EUNSUPPORTED;
+    if ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)b | (uintptr_t)y | (uintptr_t)parts | (uintptr_t)xs | (uintptr_t)bias) & 15) != 0) return PPT_EINVAL;
+    dim3 vgrid(min((M + 3) / 4, 256 * 8));
+    if (y_dtype == PPT_BF16)
+        hipLaunchKernelGGL((ln_fwd_vec8_kernel<bf16_t, true>), vgrid, dim3(256), 0, ppt_stream(stream), x, (const float *)nullptr, 0, xs, w, b,
+                           (bf16_t *)y, mean, rstd, M, D, eps, ppt_get_wave_priority(), bias, parts, S);
+    else if (y_dtype == PPT_F16)
+        hipLaunchKernelGGL((ln_fwd_vec8_kernel<f16_t, true>), vgrid, dim3(256), 0, ppt_stream(stream), x, (const float *)nullptr, 0, xs, w, b,
+                           (f16_t *)y, mean, rstd, M, D, eps, ppt_get_wave_priority(), bias, parts, S);
+    else if (y_dtype == PPT_F32)
+        hipLaunchKernelGGL((ln_fwd_vec8_kernel<float, true>), vgrid, dim3(256), 0, ppt_stream(stream), x, (const float *)nullptr, 0, xs, w, b,
+                           (float *)y, mean, rstd, M, D, eps, ppt_get_wave_priority(), bias, parts, S);
+    else
+        return PPT_EINVAL;
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
+// ppt_layernorm_bwd's input-gradient form with dy = dy_parts[0] + ... + dy_parts[S-1] ([S, M, D] fp32, summed in that order).
+extern "C" int ppt_layernorm_bwd_sum(const float *dy_parts, int S, const float *xs, const float *w, const float *mean, const float *rstd,
+                                     float *dx, int accumulate_dx, void *dx_copy, int dx_copy_dtype, int M, int D, void *stream)
+{
+    if (!dy_parts || !xs || !w || !mean || !rstd || !dx || S <= 0 || S > 8 || M <= 0 || D <= 0) return PPT_EINVAL;
+    if ((D % 8) != 0 || D > 512) return PPT_EUNSUPPORTED;
+    if ((((uintptr_t)dy_parts | (uintptr_t)xs | (uintptr_t)w | (uintptr_t)dx | (uintptr_t)dx_copy) & 15) != 0) return PPT_EINVAL;
+    hipLaunchKernelGGL(ln_bwd_dx8_kernel, dim3((M + 3) / 4), dim3(256), 0, ppt_stream(stream), dy_parts, xs, w, mean, rstd, dx, accumulate_dx,
+                       dx_copy, dx_copy_dtype, M, D, ppt_get_wave_priority(), S);
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }

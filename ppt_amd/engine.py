@@ -840,6 +840,10 @@ def pointmlp_forward(sd, p, wc, pc, fps_starts, train, drop_masks, update_runnin
 # GEMM ~8 us of workgroups other kernels share a CU with, and the prompt chain runs BESIDE the point tower: interleaved same-box
 # A/B of the C2 step 3.87 (on) vs 3.79 ms (off) (tools/ab_env.py)
 TEXT_FUSE_LN = os.environ.get("PPT_TEXT_FUSE_LN", "0") != "0"
+# round 5: the text tower's K = 2048 / 1536 linears (c_proj forward; the dX products of c_fc and in_proj) as split-K launches whose
+# partial products are summed by the LayerNorm kernel that consumes them (ops.gemm_splitk + ops.layernorm_fwd_sum / _bwd_sum).
+# 16-bit operand modes only: the fp32 parity mode keeps the single-launch summation order.
+TEXT_SPLITK = os.environ.get("PPT_TEXT_SPLITK", "1") != "0"
 
 
 def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=None, prefix=0, rows_in=None):
@@ -904,9 +908,20 @@ def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=No
 
     def stats():
         return (torch.empty((M,), dtype=torch.float32, device=dev), torch.empty((M,), dtype=torch.float32, device=dev)) if save else None
+    # split-K for the K = 2048 linear (c_proj): with 817 rows it is 104 workgroups walking 32 K slabs each at ONE CU's L2 -> LDS rate
+    # (~9 of its 12.6 us); as four K slices it is 416 workgroups of 8 slabs, and the four fp32 partial products are added up -- with
+    # the residual and the bias -- by the LayerNorm that reads the result anyway (ops.layernorm_fwd_sum): no reduction launch.
+    splitk = TEXT_SPLITK and T in ops.HALF and Tm == T and not fuse and M <= 4096 and Wd == 512
+    pending = None                  # (x_mid, c_proj bias, partial products) of the previous layer: its output is formed by this layer's LN1
     for i in range(layers):
         p = f"transformer.resblocks.{i}."
-        if fuse and add is None:
+        if pending is not None:
+            x = torch.empty((M, Wd), dtype=torch.float32, device=dev)
+            h, mean1, rstd1 = ops.layernorm_fwd_sum(pending[0], pending[1], pending[2], sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], Ta,
+                                                    write_xs=x, save_stats=save)
+            pending = None
+            qkv = ops.gemm(h, wca.get(sd[p + "attn.in_proj_weight"]), out_dtype=Ta, bias=sd[p + "attn.in_proj_bias"])
+        elif fuse and add is None:
             # LayerNorm applied while the rows are staged (one node of the prompt chain instead of two); its statistics are
             # kept for the backward
             st1 = stats()
@@ -935,11 +950,14 @@ def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=No
             h2, mean2, rstd2 = ops.layernorm_fwd(x_mid, sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], Tm, save_stats=save)
             f = ops.gemm(h2, wcm.get(sd[p + "mlp.c_fc.weight"]), out_dtype=Tm, bias=sd[p + "mlp.c_fc.bias"],
                          act=ACT_QUICKGELU, out2=pre, out2_pre=True)
-        x_next = torch.empty_like(x)
-        ops.gemm(f, wcm.get(sd[p + "mlp.c_proj.weight"]), out=x_next, bias=sd[p + "mlp.c_proj.bias"], residual=x_mid)
         if save:
             saved["layers"].append(dict(x=x, mean1=mean1, rstd1=rstd1, qkv=qkv, a=a, lse=lse, x_mid=x_mid, mean2=mean2,
                                         rstd2=rstd2, pre=pre))
+        if splitk and i + 1 < layers:
+            pending = (x_mid, sd[p + "mlp.c_proj.bias"], ops.gemm_splitk(f, wcm.get(sd[p + "mlp.c_proj.weight"]), 4))
+            continue
+        x_next = torch.empty_like(x)
+        ops.gemm(f, wcm.get(sd[p + "mlp.c_proj.weight"]), out=x_next, bias=sd[p + "mlp.c_proj.bias"], residual=x_mid)
         x = x_next
         xin = x
     x_eot = x.index_select(0, rows)
@@ -989,23 +1007,33 @@ def text_tower_backward(sd, wc, s, dout, grad_scale=1.0):
     g.index_copy_(0, s["rows"], d_eot)
     wca, wcm = s.get("wca", wc), s.get("wcm", wc)              # (per-half operand precision: diagnostics, see the forward)
     Ta, Tm = wca.dtype, wcm.dtype
+    splitk = TEXT_SPLITK and T in ops.HALF and Ta == T and Tm == T and M <= 4096 and Wd == 512
     g_t = ops.convert(g, Tm)
     for i in reversed(range(len(s["layers"]))):
         p = f"transformer.resblocks.{i}."
         ly = s["layers"][i]
         d_pre = ops.gemm(g_t, wcm.get(sd[p + "mlp.c_proj.weight"], "wt"), out_dtype=Tm, act=ACT_QUICKGELU,
                          dact_pre=ly["pre"])
-        d_h2 = ops.gemm(d_pre, wcm.get(sd[p + "mlp.c_fc.weight"], "wt"), out_dtype=torch.float32)
-        _, _, _, g_t = ops.layernorm_bwd(d_h2, ly["x_mid"], sd[p + "ln_2.weight"], ly["mean2"], ly["rstd2"], dx=g,
-                                         accumulate=True, copy_dtype=Ta)
+        if splitk:
+            # K = 2048 over 817 rows: four K slices, added up by the LayerNorm backward that reads the product (see the forward)
+            _, g_t = ops.layernorm_bwd_sum(ops.gemm_splitk(d_pre, wcm.get(sd[p + "mlp.c_fc.weight"], "wt"), 4), ly["x_mid"],
+                                           sd[p + "ln_2.weight"], ly["mean2"], ly["rstd2"], g, accumulate=True, copy_dtype=Ta)
+        else:
+            d_h2 = ops.gemm(d_pre, wcm.get(sd[p + "mlp.c_fc.weight"], "wt"), out_dtype=torch.float32)
+            _, _, _, g_t = ops.layernorm_bwd(d_h2, ly["x_mid"], sd[p + "ln_2.weight"], ly["mean2"], ly["rstd2"], dx=g,
+                                             accumulate=True, copy_dtype=Ta)
         d_a = ops.gemm(g_t, wca.get(sd[p + "attn.out_proj.weight"], "wt"), out_dtype=Ta)
         if P:
             d_qkv = ops.attention_prefix_bwd(ly["qkv"], ly["a"], d_a, ly["lse"], C, L, P, heads, ATTN_SCALE)
         else:
             d_qkv = ops.attention_bwd(ly["qkv"], ly["a"], d_a, ly["lse"], C, L, heads, ATTN_SCALE, True)
-        d_h = ops.gemm(d_qkv, wca.get(sd[p + "attn.in_proj_weight"], "wt"), out_dtype=torch.float32)
-        _, _, _, g_t = ops.layernorm_bwd(d_h, ly["x"], sd[p + "ln_1.weight"], ly["mean1"], ly["rstd1"], dx=g,
-                                         accumulate=True, copy_dtype=Tm)
+        if splitk:                  # K = 1536: three slices
+            _, g_t = ops.layernorm_bwd_sum(ops.gemm_splitk(d_qkv, wca.get(sd[p + "attn.in_proj_weight"], "wt"), 3), ly["x"],
+                                           sd[p + "ln_1.weight"], ly["mean1"], ly["rstd1"], g, accumulate=True, copy_dtype=Tm)
+        else:
+            d_h = ops.gemm(d_qkv, wca.get(sd[p + "attn.in_proj_weight"], "wt"), out_dtype=torch.float32)
+            _, _, _, g_t = ops.layernorm_bwd(d_h, ly["x"], sd[p + "ln_1.weight"], ly["mean1"], ly["rstd1"], dx=g,
+                                             accumulate=True, copy_dtype=Tm)
     if s["rows_mode"]:
         return g                                            # gradient of the row-layout input, STILL scaled by S (ops.prompt_rows_bwd folds it and 1 / S)
     if S != 1.0:

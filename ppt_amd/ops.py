@@ -428,6 +428,51 @@ def layernorm_fwd(x, w, b, y_dtype, add=None, add_rows=0, write_xs=None, save_st
     return y, mean, rstd
 
 
+def layernorm_fwd_sum(x, bias, parts, w, b, y_dtype, write_xs, save_stats=False, eps=1e-5):
+    """y = LN(x + bias + parts[0] + ... + parts[S-1]) -- the consumer of a split-K linear (ppt_layernorm_fwd_sum): x f32 [M, D],
+    parts f32 [S, M, D] (the S partial products, ops.gemm_splitk), bias [D] or None; write_xs receives the summed rows.
+    Returns (y, mean, rstd)."""
+    _chk(x, torch.float32, "x"); _chk(parts, torch.float32, "parts"); _chk(write_xs, torch.float32, "write_xs")
+    D = x.shape[-1]
+    M = x.numel() // D
+    S = parts.shape[0]
+    assert parts.numel() == S * M * D
+    y = torch.empty(x.shape, dtype=y_dtype, device=x.device)
+    mean = torch.empty((M,), dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = torch.empty((M,), dtype=torch.float32, device=x.device) if save_stats else None
+    _lib.check(_lib.lib().ppt_layernorm_fwd_sum(_p(x), _p(bias), _p(parts), S, _p(write_xs), _p(w), _p(b), _p(y), dtype_code(y),
+                                                _p(mean), _p(rstd), M, D, eps, _stream()), "ppt_layernorm_fwd_sum")
+    if probe is not None:
+        _probe("layernorm", y)
+    return y, mean, rstd
+
+
+def layernorm_bwd_sum(dy_parts, xs, w, mean, rstd, dx, accumulate=True, copy_dtype=None):
+    """layernorm_bwd's input-gradient form with dy = dy_parts[0] + ... + dy_parts[S-1] ([S, M, D] f32) -> (dx, dx_copy)."""
+    _chk(dy_parts, torch.float32, "dy_parts"); _chk(xs, torch.float32, "xs")
+    D = xs.shape[-1]
+    M = xs.numel() // D
+    S = dy_parts.shape[0]
+    assert dy_parts.numel() == S * M * D
+    cp = torch.empty(xs.shape, dtype=copy_dtype, device=xs.device) if copy_dtype is not None else None
+    _lib.check(_lib.lib().ppt_layernorm_bwd_sum(_p(dy_parts), S, _p(xs), _p(w), _p(mean), _p(rstd), _p(dx), int(accumulate), _p(cp),
+                                                dtype_code(cp) if cp is not None else 0, M, D, _stream()), "ppt_layernorm_bwd_sum")
+    return dx, cp
+
+
+def gemm_splitk(A, B, S):
+    """The S partial products of A [M, K] @ B [N, K]^T over K slices of K / S as fp32 slices [S, M, N] (one batched ppt_gemm launch,
+    plain epilogue): for skinny problems (the prompt chain: 817 rows) whose K loop is what takes the time.  K / S must be a multiple
+    of 64 elements (the 64 x 64 LDS-DMA tile loop's slab)."""
+    M, K = A.shape
+    N = B.shape[0]
+    Ks = K // S
+    assert Ks * S == K and Ks % 64 == 0 and A.stride(1) == 1 and B.stride(1) == 1
+    part = torch.empty((S, M, N), dtype=torch.float32, device=A.device)
+    gemm(A[:, :Ks], B[:, :Ks], out=part.view(S * M, N), M=M, batch=S, strideA=Ks, strideB=Ks, strideC=M * N)
+    return part
+
+
 def layernorm_bwd(dy, xs, w, mean, rstd, dx=None, accumulate=False, want_wgrad=False, partial_rows=None,
                   copy_dtype=None):
     """-> (dx, dw, db[, dx_copy]).  dx f32; accumulate=True adds into the given dx; copy_dtype: also

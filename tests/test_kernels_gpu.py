@@ -271,6 +271,51 @@ def test_gemm_residual_epilogue_full_size(ops, dtype, M, N, K):
     assert torch.allclose(d.float().cpu(), want, rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("S,K", [(4, 2048), (3, 1536)])
+def test_splitk_linear_with_layernorm_consumers(ops, S, K):
+    """The prompt chain's skinny long-K linears as split-K launches (ops.gemm_splitk: S fp32 partial products from ONE batched
+    ppt_gemm) whose reduction rides in the LayerNorm that reads the result: ppt_layernorm_fwd_sum (x + bias + sum of the slices ->
+    LayerNorm, the summed row written back) and ppt_layernorm_bwd_sum (dy = sum of the slices).  Against the single-launch linear +
+    the plain LayerNorm kernels: the same values up to the fp32 summation order; bit-reproducible."""
+    M, D = 817, 512
+    rng = np.random.default_rng(S * 7 + K)
+    A = dev(rng.standard_normal((M, K)).astype(np.float32), torch.float16)
+    Wt = dev((rng.standard_normal((D, K)) / math.sqrt(K)).astype(np.float32), torch.float16)
+    bias = dev(rng.standard_normal(D).astype(np.float32))
+    x = dev(rng.standard_normal((M, D)).astype(np.float32))
+    g = dev(1.0 + 0.1 * rng.standard_normal(D).astype(np.float32))
+    b = dev(0.1 * rng.standard_normal(D).astype(np.float32))
+    parts = ops.gemm_splitk(A, Wt, S)
+    assert parts.shape == (S, M, D)
+    full = ops.gemm(A, Wt, out_dtype=torch.float32)
+    assert torch.allclose(parts.sum(0), full, rtol=1e-5, atol=2e-5)
+    for z in range(S):                                  # every slice is the product over ITS K range
+        ref = A[:, z * (K // S):(z + 1) * (K // S)].float() @ Wt[:, z * (K // S):(z + 1) * (K // S)].float().t()
+        assert torch.allclose(parts[z], ref, rtol=1e-4, atol=1e-4)
+    # forward consumer
+    xs = torch.empty_like(x)
+    y, mean, rstd = ops.layernorm_fwd_sum(x, bias, parts, g, b, torch.float16, write_xs=xs, save_stats=True)
+    want = x + bias
+    for z in range(S):
+        want = want + parts[z]
+    assert torch.equal(xs, want)                        # the summation order is the documented one
+    y_ref, mean_ref, rstd_ref = ops.layernorm_fwd(want, g, b, torch.float16, save_stats=True)
+    assert torch.equal(y, y_ref) and torch.equal(mean, mean_ref) and torch.equal(rstd, rstd_ref)
+    one = ops.gemm(A, Wt, out_dtype=torch.float32, bias=bias, residual=x)            # the single-launch linear it replaces
+    assert torch.allclose(xs, one, rtol=1e-5, atol=3e-5)
+    xs2 = torch.empty_like(x)
+    y2, _, _ = ops.layernorm_fwd_sum(x, bias, parts, g, b, torch.float16, write_xs=xs2, save_stats=True)
+    assert torch.equal(y, y2) and torch.equal(xs, xs2)
+    # backward consumer
+    dx0 = dev(rng.standard_normal((M, D)).astype(np.float32))
+    dx_a, cp_a = ops.layernorm_bwd_sum(parts, want, g, mean, rstd, dx0.clone(), accumulate=True, copy_dtype=torch.float16)
+    dy = parts[0].clone()
+    for z in range(1, S):
+        dy = dy + parts[z]
+    dx_b, _, _, cp_b = ops.layernorm_bwd(dy, want, g, mean, rstd, dx=dx0.clone(), accumulate=True, copy_dtype=torch.float16)
+    assert torch.equal(dx_a, dx_b) and torch.equal(cp_a, cp_b)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K,kind", [
     (16416, 1152, 384, "plain"),        # qkv of a C2 batch: ragged M (64.125 row tiles), ragged N for 256-wide tiles (4.5)

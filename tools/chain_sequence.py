@@ -19,7 +19,7 @@ for _, r in it.iterrows():
     gap = (r.Start_Timestamp - last_end[r.Stream_Id]) / 1e3 if r.Stream_Id in last_end else float("nan")
     last_end[r.Stream_Id] = r.End_Timestamp
     wgs = (r.Grid_Size_X * r.Grid_Size_Y * r.Grid_Size_Z) // max(1, r.Workgroup_Size_X * r.Workgroup_Size_Y * r.Workgroup_Size_Z)
-    rows.append((r.Stream_Id, r.name, r.dur, gap, wgs))
+    rows.append((r.Stream_Id, r["name"], r.dur, gap, wgs))
 print(f"{len(rows)} kernels in the iteration, {(it.End_Timestamp.max() - it.Start_Timestamp.min()) / 1e3:.0f} us wall, {it.dur.sum():.0f} us busy")
 for s, n, du, gap, wgs in rows:
     print(f"s{s:<3d} {du:7.1f} us  gap {gap:6.1f}  wgs {wgs:5d}  {n}")

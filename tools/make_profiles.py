@@ -15,7 +15,7 @@ import pandas as pd
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # the bf16 MFMA GEMM family (what bench.py's roofline object is about): tile GEMMs, the fused mini-PointNet kernels, the
 # weight-stationary short-K linears and the fused ViT MLP
-GEMM_BF16 = r"gemm_kernel.*<(unsigned short|f16_t)|gemm_tn_kernel|mpn[134]_kernel|rowgemm_kernel|vit_mlp_kernel"
+GEMM_BF16 = r"gemm_kernel.*<(unsigned short|f16_t)|gemm256_kernel|gemm128x256_kernel|gemm_tn_kernel|mpn[134]_kernel|rowgemm_kernel|vit_mlp_kernel"
 CONFIGS = ("c2", "c3", "c4", "c5", "mlp")
 TRACE_STEPS = 40 + 5 + 10                   # burn-in + warm-up + timed steps of the traced command
 
@@ -82,6 +82,15 @@ def section(rnd, cfg, d, out):
                 "fetch_bytes_per_launch": 2 * float(fam_f["sum"].sum()) * 1024 / nf, "write_bytes_per_launch": float(fam_w["sum"].sum()) * 1024 / nw,
             }
             traffic["hbm_bytes_per_launch"] = traffic["fetch_bytes_per_launch"] + traffic["write_bytes_per_launch"]
+            # the family's rate from the rocprofv3 KERNEL TRACE of the same command (kernel-only durations; bench.py's live figure
+            # comes from HIP-event brackets and reads ~8 % higher): executed FLOPs per step from the bench line's own accounting
+            ex = (roof.get("executed_gflop_per_launch") or 0) * (roof.get("launches_per_step") or 0)
+            fam_ms = g.dur.sum() / n / 1e6
+            if ex and fam_ms:
+                traffic["rocprof_family"] = {"launches_per_step": round(len(g) / n, 1), "avg_us": round(g.dur.mean() / 1e3, 2),
+                                             "ms_per_step": round(fam_ms, 3), "executed_gflop_per_step": round(ex, 1),
+                                             "achieved_tflops": round(ex / fam_ms, 1), "frac": round(ex / fam_ms / 2500.0, 4),
+                                             "source": f"profiles/{rnd}_bench_c2_kernel_stats.csv (rocprofv3 --kernel-trace --stats)"}
             json.dump(traffic, open(os.path.join(out, f"{rnd}_gemm_hbm_traffic.json"), "w"), indent=1)
             md += ["", f"`{rnd}_gemm_hbm_traffic.json`: HBM bytes of the GEMM family from two PMC passes -- {traffic['hbm_bytes_per_launch'] / 1e6:.1f} MB per launch "
                    f"({traffic['fetch_bytes_per_launch'] / 1e6:.1f} read + {traffic['write_bytes_per_launch'] / 1e6:.1f} written) over {nf} launches."]

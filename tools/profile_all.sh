@@ -1,10 +1,10 @@
 #!/bin/bash
 # On the GPU box (gpurun): the bench line and a rocprofv3 kernel trace of every configuration, and the two PMC passes of the
-# headline configuration -> gpurun_out/prof_r03/ (tools/make_profiles.py turns that into profiles/).
+# headline configuration -> gpurun_out/prof_r05/ (tools/make_profiles.py turns that into profiles/).
 #   gpurun --timeout 2400 -- 'bash tools/profile_all.sh [configs ...]'
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$ROOT/gpurun_out/${PPT_PROF_DIR:-prof_r03}
+OUT=$ROOT/gpurun_out/${PPT_PROF_DIR:-prof_r05}
 mkdir -p "$OUT"
 CFGS=${@:-C2 C3 C4 C5 MLP}
 cd /tmp && export TMPDIR=/tmp
