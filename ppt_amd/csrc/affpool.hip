@@ -121,13 +121,9 @@ __global__ __launch_bounds__(256) void affpool_kernel(const bf16_t *__restrict__
     }
 }
 
-int affpool_grid(int64_t units, int nwm)
+int affpool_grid(int64_t units, int nwm, hipStream_t st)
 {
-    static const int cus = [] {
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        return n > 0 ? n : 256;
-    }();
+    const int cus = ppt_cu_count(st);            // (of the stream's device, not process-global state)
     const int64_t blocks = (units + nwm - 1) / nwm;
     return (int)(blocks < (int64_t)cus * 4 ? blocks : (int64_t)cus * 4);
 }
@@ -144,7 +140,7 @@ extern "C" int ppt_affine_conv_pool_bf16(const void *A, int64_t lda, int64_t M, 
     hipStream_t s = ppt_stream(stream);
     const int64_t units = M / (pool_rows == 64 ? 64 : 32);
 #define AFP_LAUNCH(KS, TJ, NWN, PR)                                                                                            \
-    hipLaunchKernelGGL((affpool_kernel<KS, TJ, NWN, PR>), dim3(affpool_grid(units, 4 / NWN)), dim3(256), 0, s, (const bf16_t *)A, lda, \
+    hipLaunchKernelGGL((affpool_kernel<KS, TJ, NWN, PR>), dim3(affpool_grid(units, 4 / NWN, s)), dim3(256), 0, s, (const bf16_t *)A, lda, \
                        (int)units, a_scale, a_shift, (const bf16_t *)W, bias, pmax, pmin, part_sum, part_m2)
     if (K == 32 && N == 64 && pool_rows == 16) AFP_LAUNCH(2, 2, 1, 16);
     else if (K == 64 && N == 128 && pool_rows == 32) AFP_LAUNCH(4, 2, 2, 32);

@@ -240,7 +240,21 @@ __global__ __launch_bounds__(NT2, (BN == 256 || EPI < 0) ? 2 : 4) void gemm256_k
     const int lin0 = blockIdx.y * gridDim.x + blockIdx.x;
     const int q8 = nwg / 8, r8 = nwg % 8, xcd = lin0 % 8;                   // same XCD-aware remap as gemm_kernel
     const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + lin0 / 8;
-    const int n0 = (lin % gridDim.x) * BN, m0 = (lin / gridDim.x) * BM;
+    // ... and inside an XCD's run of tiles, GROUPS of GM tile rows are walked column-major: the ~32 tiles an XCD works on at one
+    // time then cover GM row panels x 32 / GM column panels instead of 1 x 32, so every operand slab is pulled over the fabric
+    // once per GM (A) resp. 32 / GM (B) tiles instead of A once per 32 and B once per TILE -- what matters when B does not fit the
+    // 4 MiB L2 (8192^3: 33 -> 12 panel streams per 32 tiles); for the tower's N <= 1536 it changes nothing measurable.
+    int tm, tn;
+    {
+        constexpr int GM = 4;
+        const int ncol = gridDim.x, nrow = gridDim.y;
+        const int grp = lin / (GM * ncol), first = grp * GM;
+        const int rows_here = min(GM, nrow - first);
+        const int t = lin - grp * GM * ncol;
+        tm = first + t % rows_here;
+        tn = t / rows_here;
+    }
+    const int n0 = tn * BN, m0 = tm * BM;
     const T *A = reinterpret_cast<const T *>(p.A) + (int64_t)blockIdx.z * p.strideA;
     const T *B = reinterpret_cast<const T *>(p.B) + (int64_t)blockIdx.z * p.strideB;
 

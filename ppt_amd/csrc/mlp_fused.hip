@@ -417,13 +417,13 @@ extern "C" int ppt_vit_mlp_bf16(const ppt_vit_mlp_params *pp, void *stream)
         if (!p.proj_W || (p.proj_row_scale && p.proj_row_scale_rows <= 0)) return PPT_EINVAL;
         if (((uintptr_t)p.proj_a | (uintptr_t)p.proj_W | (uintptr_t)p.proj_b) & 15) return PPT_EINVAL;
     }
-    static const int cus = [] {
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    static const int attrs_once = [] {
         (void)hipFuncSetAttribute((const void *)vit_mlp_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         (void)hipFuncSetAttribute((const void *)vit_mlp_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        return n > 0 ? n : 256;
+        return 0;
     }();
+    (void)attrs_once;
+    const int cus = ppt_cu_count(ppt_stream(stream));            // (of the stream's device, not process-global state)
     // chunks of at most R rows, a whole number of rounds over the CUs, every chunk as full as the division allows
     int wgs = p.workgroups > 0 ? p.workgroups : cus;
     int rounds = 1;

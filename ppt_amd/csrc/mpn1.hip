@@ -134,13 +134,9 @@ __global__ __launch_bounds__(256) void mpn1_kernel(const float *__restrict__ pts
     }
 }
 
-int mpn1_grid(int64_t tiles, int nwm)
+int mpn1_grid(int64_t tiles, int nwm, hipStream_t st)
 {
-    static const int cus = [] {
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        return n > 0 ? n : 256;
-    }();
+    const int cus = ppt_cu_count(st);            // (of the stream's device, not process-global state)
     const int64_t blocks = (tiles + nwm - 1) / nwm;
     int64_t want = (int64_t)cus * 3 * ppt_get_persistent_occupancy() / 100;        // (ppt_set_persistent_occupancy)
     want = want < 8 ? 8 : want;
@@ -159,10 +155,10 @@ extern "C" int ppt_mini_pointnet_conv12_half(const float *pts, int64_t M, const 
     if (((uintptr_t)W2 | (uintptr_t)y2) & 15) return PPT_EINVAL;
     const int64_t tiles = M / 32;
     if (dtype == PPT_F16)
-        hipLaunchKernelGGL((mpn1_kernel<f16_t, 128, 2, 4, true, false>), dim3(mpn1_grid(tiles, 1)), dim3(256), 0, ppt_stream(stream), pts,
+        hipLaunchKernelGGL((mpn1_kernel<f16_t, 128, 2, 4, true, false>), dim3(mpn1_grid(tiles, 1, ppt_stream(stream))), dim3(256), 0, ppt_stream(stream), pts,
                            (int)tiles, w1, b1, a_scale, a_shift, (const bf16_t *)W2, bias2, (bf16_t *)y2, (bf16_t *)gmax, nullptr, nullptr);
     else
-        hipLaunchKernelGGL((mpn1_kernel<bf16_t, 128, 2, 4, true, false>), dim3(mpn1_grid(tiles, 1)), dim3(256), 0, ppt_stream(stream), pts,
+        hipLaunchKernelGGL((mpn1_kernel<bf16_t, 128, 2, 4, true, false>), dim3(mpn1_grid(tiles, 1, ppt_stream(stream))), dim3(256), 0, ppt_stream(stream), pts,
                            (int)tiles, w1, b1, a_scale, a_shift, (const bf16_t *)W2, bias2, (bf16_t *)y2, (bf16_t *)gmax, nullptr, nullptr);
     PPT_CHECK_LAUNCH();
     return PPT_OK;
@@ -187,7 +183,7 @@ extern "C" int ppt_conv12_stats_bf16(const float *pts, int64_t M, const float *w
     const int64_t tiles = M / 32;
     hipStream_t s = ppt_stream(stream);
 #define MPN_LAUNCH(C, TJ_)                                                                                                 \
-    hipLaunchKernelGGL((mpn1_kernel<bf16_t, C, TJ_, 1, false, true>), dim3(mpn1_grid(tiles, 4)), dim3(256), 0, s, pts, (int)tiles, w1, b1, \
+    hipLaunchKernelGGL((mpn1_kernel<bf16_t, C, TJ_, 1, false, true>), dim3(mpn1_grid(tiles, 4, s)), dim3(256), 0, s, pts, (int)tiles, w1, b1, \
                        a_scale, a_shift, (const bf16_t *)W2, bias2, (bf16_t *)y2, nullptr, part_sum, part_m2)
     if (C1 == 32 && N == 32) MPN_LAUNCH(32, 1);
     else if (C1 == 64 && N == 64) MPN_LAUNCH(64, 2);

@@ -128,17 +128,17 @@ extern "C" int ppt_mini_pointnet_conv3_half(const void *A, int64_t M, int K, con
     if (K != M3_K || N != M3_N || M % 32) return PPT_EUNSUPPORTED;
     if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)y) & 15) return PPT_EINVAL;
     constexpr int lds = 2 * M3_BUF + 8 * M3_TR;
-    static const int cus = [] {
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    static const int attrs_once = [] {
         (void)hipFuncSetAttribute((const void *)mpn3_kernel<bf16_t, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void *)mpn3_kernel<bf16_t, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void *)mpn3_kernel<f16_t, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void *)mpn3_kernel<f16_t, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void *)mpn3_kernel<bf16_t, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute((const void *)mpn3_kernel<f16_t, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        return n > 0 ? n : 256;
+        return 0;
     }();
+    (void)attrs_once;
+    const int cus = ppt_cu_count(ppt_stream(stream));            // (of the stream's device, not process-global state)
     const int64_t tiles = M / 32;
     // ONE persistent workgroup per CU (alone the kernel is HBM-bound and as fast as with two: C2 tower 2.765 vs 2.776 ms), fewer
     // when the caller leaves room for the other stream (ppt_set_persistent_occupancy)

@@ -271,13 +271,13 @@ extern "C" int ppt_mini_pointnet_conv34_half(const void *y2, int64_t M, const vo
     if (!y2 || !W3s || !gs || !W4_tiled || !tok || M <= 0) return PPT_EINVAL;
     if (M % 32 || M / 32 > 0x3fffffff) return PPT_EUNSUPPORTED;
     if (((uintptr_t)y2 | (uintptr_t)W3s | (uintptr_t)W4_tiled) & 15) return PPT_EINVAL;
-    static const int cus = [] {
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    static const int attrs_once = [] {
         (void)hipFuncSetAttribute((const void *)mpn34_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         (void)hipFuncSetAttribute((const void *)mpn34_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        return n > 0 ? n : 256;
+        return 0;
     }();
+    (void)attrs_once;
+    const int cus = ppt_cu_count(ppt_stream(stream));            // (of the stream's device, not process-global state)
     const int tiles = (int)(M / 32), chunks = (tiles + 3) / 4;
     // one persistent workgroup per CU, fewer when the caller leaves room for the other stream (ppt_set_persistent_occupancy)
     int64_t want = (int64_t)cus * ppt_get_persistent_occupancy() / 100;

@@ -213,6 +213,25 @@ __device__ __forceinline__ void lds_dma16(const void *gsrc, void *lds)
 
 static inline hipStream_t ppt_stream(void *s) { return (hipStream_t)s; }
 
+// Compute units of the device the launch goes to -- taken from the STREAM (hipStreamGetDevice; the NULL stream: the current device),
+// not from process-global state: one process may drive several GPUs ("device selected from the pointer / stream").
+// Cached per device ordinal; a race on the cache writes the same value twice.
+static inline int ppt_cu_count(hipStream_t s)
+{
+    static int cache[64] = {0};
+    int dev = 0;
+    if (s == nullptr || hipStreamGetDevice(s, &dev) != hipSuccess) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+    if (dev < 0 || dev >= 64) dev = 0;
+    int n = cache[dev];
+    if (n <= 0) {
+        n = 256;
+        (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        if (n <= 0) n = 256;
+        cache[dev] = n;
+    }
+    return n;
+}
+
 // 16-byte NON-TEMPORAL store of a kernel's bulk output (the mini-PointNet activations: hundreds of MB per step, read back by
 // the next kernel from HBM anyway): the lines do not linger dirty in L2, so the end-of-kernel write-back of the small kernels
 // running beside this one (the prompt chain) has less to flush.  Same-box A/B against plain stores: C2 3.718 -> 3.702 ms,

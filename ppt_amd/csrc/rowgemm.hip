@@ -366,11 +366,7 @@ extern "C" int ppt_rowgemm_bf16(const ppt_rowgemm_params *pp, void *stream)
     if (p.act != PPT_ACT_NONE && p.act != PPT_ACT_GELU && p.act != PPT_ACT_QUICKGELU) return PPT_EUNSUPPORTED;
     if (((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.C | (uintptr_t)p.C2 | (uintptr_t)p.residual | (uintptr_t)p.residual2) & 15)
         return PPT_EINVAL;
-    static const int cus = [] {
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        return n > 0 ? n : 256;
-    }();
+    const int cus = ppt_cu_count(ppt_stream(stream));            // (of the stream's device, not process-global state)
     hipStream_t s = ppt_stream(stream);
 #define PPT_RG_ACT(FF, KK, LNV)                                                                                        \
     (p.act == PPT_ACT_GELU ? launch<FF, KK, LNV, EPI_BF16, PPT_ACT_GELU>(p, s, cus)                                      \
