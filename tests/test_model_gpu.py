@@ -1326,6 +1326,9 @@ def _stressed_model(head_type=0):
     m, _ = build(head_type, torch.bfloat16)
     m.load_state_dict(sd, strict=False)
     m.prompt_learner.embedding = W.synth_prompt_embedding(40, seed=0) * 10.0
+    # (these tests are about the RUN-TIME monitor: the load-time self-check of the text tower -- calibrate_text_precision, which on
+    # such weights moves the tower to fp32 operands before any step runs -- is switched off for them)
+    m._text_calibrated = True
     m.train()
     return m
 
@@ -1335,14 +1338,18 @@ class _health_every:
         self.n = str(n)
 
     def __enter__(self):
-        self.old = os.environ.get("PPT_HEALTH_EVERY")
+        # (PPT_TEXT_CALIBRATE=0: these tests are about the RUN-TIME monitor; the load-time self-check of the text tower --
+        # calibrate_text_precision -- would move the stressed tower to fp32 operands before any step could overflow)
+        self.old = {k: os.environ.get(k) for k in ("PPT_HEALTH_EVERY", "PPT_TEXT_CALIBRATE")}
         os.environ["PPT_HEALTH_EVERY"] = self.n
+        os.environ["PPT_TEXT_CALIBRATE"] = "0"
 
     def __exit__(self, *a):
-        if self.old is None:
-            os.environ.pop("PPT_HEALTH_EVERY", None)
-        else:
-            os.environ["PPT_HEALTH_EVERY"] = self.old
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def test_health_monitor_demotes_an_overflowing_half_stage():
