@@ -34,6 +34,8 @@ def shapes(rows):
         "p0b": dict(M=32768, N=1536, K=384),
         "fc1c3": dict(M=32832, N=1536, K=384, bias=True, act=ops.ACT_GELU),
         "fc2c3": dict(M=32832, N=384, K=1536, bias=True, residual=True),
+        "fc1keep": dict(M=32832, N=1536, K=384, bias=True, act=ops.ACT_GELU, out2=True),     # un-frozen block: GELU + saved pre-activation
+        "dpre": dict(M=32832, N=1536, K=384, act=ops.ACT_GELU, dact=True),                  # its backward: dX with the GELU derivative
         "sq4k": dict(M=4096, N=4096, K=4096),
         "sq8k": dict(M=8192, N=8192, K=8192),
     }
@@ -49,6 +51,11 @@ def make(cfg, dtype, dev):
         kw["bias"] = (torch.rand(N, generator=g) - 0.5).to(dev)
     if cfg.get("act"):
         kw["act"] = cfg["act"]
+    if cfg.get("out2"):
+        kw["out2"] = torch.empty(M, N, dtype=dtype, device=dev)
+        kw["out2_pre"] = True
+    if cfg.get("dact"):
+        kw["dact_pre"] = torch.randn(M, N, generator=g).to(dtype).to(dev)
     out_dtype = dtype
     res = None
     if cfg.get("residual"):
@@ -63,7 +70,7 @@ def reference(A, B, kw, res):
     y = A.float() @ B.float().t()
     if "bias" in kw:
         y = y + kw["bias"]
-    if kw.get("act") == ops.ACT_GELU:
+    if kw.get("act") == ops.ACT_GELU and "dact_pre" not in kw:
         y = torch.nn.functional.gelu(y)
     if res is not None:
         y = y + res
@@ -106,6 +113,8 @@ def main():
         for c in ("old", "256"):
             e = 0.0
             for rs in (rows, rows2):
+                if "dact_pre" in kw:
+                    continue                                  # (the derivative epilogue is checked by the tests; here: timing + identity)
                 ref = reference(A[rs], B, kw, None if res is None else res[rs])
                 e = max(e, (out[c][rs].float() - ref).abs().max().item())
             errs[c] = e
