@@ -81,6 +81,22 @@ __global__ __launch_bounds__(512) void head_project8_kernel(const float *__restr
     for (int s_ = 0; s_ < HS; ++s_) acc[s_] = 0.f;
     if (e < E) {
         int i = f0;
+        // (round 5: SIXTEEN weight loads in flight per lane instead of four -- a wave's walk is 64-96 dependent-latency steps of a
+        // 128-196 KB weight slice on 40 workgroups: 14-20 us in the step's traces, not the ~4 us of the stand-alone measurement;
+        // same products in the same order per sample: the sums are the same bits)
+        for (; i + 16 <= f1; i += 16) {
+            float wv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) wv[u] = w[(size_t)(i + u) * E + e];
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) {
+#pragma unroll
+                for (int s_ = 0; s_ < HS; ++s_) {
+                    const float4 f = *reinterpret_cast<const float4 *>(sm + s_ * F + i + u);
+                    acc[s_] = fmaf(f.w, wv[u + 3], fmaf(f.z, wv[u + 2], fmaf(f.y, wv[u + 1], fmaf(f.x, wv[u], acc[s_]))));
+                }
+            }
+        }
         for (; i + 4 <= f1; i += 4) {
             const float w0 = w[(size_t)(i + 0) * E + e], w1 = w[(size_t)(i + 1) * E + e], w2 = w[(size_t)(i + 2) * E + e],
                         w3 = w[(size_t)(i + 3) * E + e];

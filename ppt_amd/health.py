@@ -102,6 +102,27 @@ class Monitor:
             self.polls += 1
         return new
 
+    def poll_all_ranks(self, step, side=None, group=None):
+        """The data-parallel form of poll(): every rank must take the SAME demotion decision at the SAME step (a rank that re-captures
+        its graphs alone stalls the others' collective, and `event.query()` timing differs per rank -- ADVICE r4).  Every `every` steps:
+        a blocking read of this rank's word and skip counter, then ONE all-reduce (MAX over the ranks of [bit 0, bit 1, ..., counter])
+        so that each rank sees the union of the events; ~one device synchronisation per `every` steps."""
+        import torch.distributed as dist
+        if not (self.every > 0 and step % self.every == 0 and self.flags.is_cuda):
+            return 0
+        if side is not None:
+            side.synchronize()
+        bits = int(self.flags.item())
+        self.flags.zero_()
+        sk = int(self.skipped.item()) if self.skipped is not None else 0
+        v = torch.tensor([float((bits >> b) & 1) for b in range(4)] + [float(sk)], dtype=torch.float64, device=self.flags.device)
+        dist.all_reduce(v, op=dist.ReduceOp.MAX, group=group)
+        v = v.cpu()
+        self.host[0] = sum(int(v[b].item()) << b for b in range(4))
+        self.host_skipped[0] = int(v[4].item())
+        self.polls += 1
+        return self._resolve()
+
     def read_now(self, side=None):
         """blocking read of everything since the last poll (tests, end of an epoch, after a FloatingPointError)"""
         if self._pending is not None:

@@ -233,7 +233,9 @@ class Trainer:
         if os.environ.get("PPT_HEALTH", "1") != "0" and getattr(model, "precision", None) == torch.bfloat16 and hasattr(model, "health") \
                 and next(model.parameters()).is_cuda:
             from . import health
-            self.health = model.health = health.Monitor(next(model.parameters()).device, every=int(os.environ.get("PPT_HEALTH_EVERY", "50")))
+            # (under a process group a poll is ONE blocking read + all-reduce so that every rank decides alike: every 200 steps)
+            dflt = "200" if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else "50"
+            self.health = model.health = health.Monitor(next(model.parameters()).device, every=int(os.environ.get("PPT_HEALTH_EVERY", dflt)))
         # logit_scale is frozen in every PPT configuration (ULIP_models.py:487-507) and its value lies inside the clamp range:
         # main_cls.py:213's per-step clamp is then idempotent -- applied once here, and per step only if it ever trains
         if hasattr(model, "logit_scale"):
@@ -403,7 +405,8 @@ class Trainer:
         answer any more raise after health.GIVE_UP_AFTER polls instead of being skipped silently for the rest of the run."""
         from . import health
         mon = self.health
-        new = mon.poll(self.it, side)
+        # (under a process group every rank decides on the union of all ranks' events, at the same step: Monitor.poll_all_ranks)
+        new = mon.poll_all_ranks(self.it, side) if (self.distributed and dist.is_initialized()) else mon.poll(self.it, side)
         if not new:
             return
         if new & health.BIT_LABEL:
