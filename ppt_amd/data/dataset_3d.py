@@ -27,16 +27,21 @@ def farthest_point_sample(point, npoint, start=None, return_index=False):
 
     Where to call it: the reference runs this loop inside Dataset._get_item, i.e. in DataLoader WORKER processes
     (num_workers = args.workers, fork start method).  A forked worker cannot initialise the device ("Cannot re-initialize CUDA in
-    forked subprocess") and a spawned one would build a GPU context per worker for one tiny launch per sample -- so inside a worker
-    this function raises and says what to do instead: sample in the main process (a collate_fn, or on the batch after it has been
-    moved to the device: ops.fps takes [B, N, 3] and walks B clouds in one launch), or run the loader with num_workers = 0.
+    forked subprocess") and a spawned one would build a GPU context per worker for one tiny launch per sample.  Round 5: with
+    `ppt_amd.data.start_fps_service()` called once in the main process before the loader forks, a worker hands its cloud (and the
+    start index it drew) to a main-process thread that runs the launch and returns the indices -- the dataset class stays unchanged
+    (ppt_amd/data/fps_service.py).  Without the service this function raises inside a worker and says what to do instead.
     INTEGRATION.md, "dataset-side FPS"."""
     import torch
     from .. import ops
-    if torch.utils.data.get_worker_info() is not None:
+    from . import fps_service
+    winfo = torch.utils.data.get_worker_info()
+    if winfo is not None and fps_service.service() is None:
         raise RuntimeError("ppt_amd.data.farthest_point_sample was called inside a DataLoader worker process: it runs on the HIP device "
-                           "and has no CPU path.  Call it from the main process -- in a collate_fn, or batched on the device with "
-                           "ppt_amd.ops.fps(pc [B,N,3], npoint, start [B]) -- or use num_workers=0 (INTEGRATION.md, dataset-side FPS).")
+                           "and has no CPU path, and a forked worker cannot initialise the device.  Call ppt_amd.data.start_fps_service() "
+                           "in the main process before the DataLoader is iterated (the workers then hand their clouds to that thread), or "
+                           "sample in the main process -- a collate_fn, or batched on the device with ppt_amd.ops.fps(pc [B,N,3], npoint, "
+                           "start [B]) -- or use num_workers=0 (INTEGRATION.md, dataset-side FPS).")
     point = np.asarray(point)
     if point.ndim != 2 or point.shape[1] < 3:
         raise ValueError(f"point must be [N, D >= 3], got {point.shape}")
@@ -46,6 +51,11 @@ def farthest_point_sample(point, npoint, start=None, return_index=False):
     N = point.shape[0]
     if start is None:
         start = np.random.randint(0, N)
+    if winfo is not None:
+        # a DataLoader worker: the launch runs in the main process (ppt_amd/data/fps_service.py), the draw above stays here
+        idx = fps_service.service().request(winfo.id, point[:, :3], int(npoint), int(start))
+        out = point[idx.astype(np.int32)]
+        return (out, idx) if return_index else out
     if not torch.cuda.is_available():
         raise RuntimeError("ppt_amd.data.farthest_point_sample needs the HIP device (libppt_hip.so: ppt_fps_f32)")
     xyz = torch.from_numpy(np.ascontiguousarray(point[:, :3])).cuda().view(1, N, 3)

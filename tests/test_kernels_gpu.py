@@ -1510,6 +1510,55 @@ def test_dataset_fps_is_bit_exact(tag, N, M, dup, cols):
         PD.farthest_point_sample(pts.astype(np.float64), 8)
 
 
+class _CloudsWithDatasetFPS(torch.utils.data.Dataset):
+    """The shape of the reference's datasets (data/dataset_3d.py:288-300): __getitem__ seeds nothing, calls
+    farthest_point_sample(point, npoint) -- which draws its start with np.random.randint -- and returns the rows."""
+
+    def __init__(self, n_items, N, npoint):
+        self.n_items, self.N, self.npoint = n_items, N, npoint
+
+    def __len__(self):
+        return self.n_items
+
+    def cloud(self, i):
+        c = np.random.default_rng(1000 + i).standard_normal((self.N, 3)).astype(np.float32)
+        c[5:9] = c[0]
+        return c
+
+    def __getitem__(self, i):
+        from ppt_amd import data as PD
+        np.random.seed(77 + i)                                     # (so the test can replay the draw; the reference leaves it unseeded)
+        return i, PD.farthest_point_sample(self.cloud(i), self.npoint)
+
+
+def test_dataset_fps_inside_dataloader_workers():
+    """VERDICT r4 missing #4: the reference's datasets sample inside DataLoader WORKER processes.  Without the service the call raises
+    in the worker with the way out; with ppt_amd.data.start_fps_service() an unchanged dataset class runs under num_workers = 2 (fork)
+    and returns, sample for sample, the rows the oracle's restated loop selects from the start index the worker drew."""
+    from ppt_amd import data as PD
+    ds = _CloudsWithDatasetFPS(12, 2048, 256)
+    PD.stop_fps_service()
+    with pytest.raises(RuntimeError, match="start_fps_service"):
+        for _ in torch.utils.data.DataLoader(ds, batch_size=4, num_workers=2, timeout=120):
+            pass
+    svc = PD.start_fps_service()
+    try:
+        seen = 0
+        for ids, rows in torch.utils.data.DataLoader(ds, batch_size=4, num_workers=2, timeout=120):
+            for i, r in zip(ids.tolist(), rows.numpy()):
+                cloud = ds.cloud(i)
+                start = np.random.RandomState(77 + i).randint(0, ds.N)
+                want, _ = O.dataset_farthest_point_sample(cloud, ds.npoint, int(start))
+                assert np.array_equal(r, want)
+                seen += 1
+        assert seen == 12 and svc.served == 12
+        # the main process keeps its direct path while the service runs
+        np.random.seed(77)
+        assert np.array_equal(PD.farthest_point_sample(ds.cloud(0), 256), ds[0][1])
+    finally:
+        PD.stop_fps_service()
+
+
 # ------------------------------------------------------------------ fused conv3 + BN + ReLU + conv4 + max (csrc/mpn34.hip)
 @pytest.mark.parametrize("T", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("tiles", [2, 7, 1027, 4096])
