@@ -41,7 +41,9 @@ extern "C" {
                      * ppt_amd/gradscale.py); bf16 stays the format of PointNet++ / PointMLP */
 
 const char *ppt_strerror(int code);
-/* ABI version of this header (currently 5); bumped on any signature change or added entry point.
+/* ABI version of this header (currently 6); bumped on any signature change or added entry point.
+ * 6: ppt_gemm_params.split16 / split_a_pow2 / split_b_pow2 (new trailing fields: fp32 operands as hi + lo half pairs),
+ *    ppt_attention_fwd_split16 (new).
  * 5: ppt_labels_check (new), ppt_gemm256 (new: the 256-row macro-tile GEMM core), ppt_set_gemm256 / ppt_get_gemm256 (new),
  *    ppt_layernorm_fwd_sum / ppt_layernorm_bwd_sum (new: split-K consumers), ppt_adamw_* (skipped == NULL: no guard).
  * 3: PPT_F16 (dtype arguments / struct fields), ppt_cross_entropy_rows (ignored labels, loss[2]), ppt_adamw_step (grad_scale),
@@ -147,6 +149,13 @@ typedef struct ppt_gemm_params {
     /* batching (blockIdx.z): pointer offsets in ELEMENTS per batch */
     int batch; int64_t strideA, strideB, strideC;
     int wave_prio;                   /* != 0: the kernel raises its waves' issue priority (0: what ppt_set_wave_priority set) */
+    /* split16 (ABI 6; dtype must be PPT_F32): != 0 multiplies the fp32 operands as hi + lo IEEE-half pairs on the 16-bit matrix
+     * pipe -- A.B = A_hi.B_hi + A_hi.B_lo + A_lo.B_hi, fp32 accumulation -- instead of the fp32 MFMA: ~22 significand bits per
+     * operand (an absolute floor of 2^-25 after scaling, inf above 65 504) at ~3-5x the fp32 MFMA's rate.  Operand values are
+     * multiplied by 2^split_a_pow2 / 2^split_b_pow2 before the split (|.| <= 24) and the product by the inverse before the
+     * epilogue, so the caller places each operand's magnitudes in half's range; everything else (A prologues, epilogues,
+     * outputs) is the fp32 path's. */
+    int split16, split_a_pow2, split_b_pow2;
 } ppt_gemm_params;
 
 #define PPT_A_PLAIN 0
@@ -314,6 +323,12 @@ int ppt_attention_bwd(const void *qkv, const void *out, const void *dout, const 
  * [C + 1, P, 2, H * hd] and a last kernel folds them in sequence order (deterministic, no atomics).
  * lse / delta: [P + C (T - P), H] f32, indexed by ROW.  0 < P < T; hd == 64; same kernels as ppt_attention_fwd / _bwd. */
 size_t ppt_attention_prefix_workspace_bytes(int C, int P, int H, int hd);
+/* split16 forward (ABI 6; csrc/attention_split.hip): fp32 qkv / out in the layouts of ppt_attention_fwd (P == 0) or
+ * ppt_attention_prefix_fwd (P > 0, causal, C = Bt prompts), both products on the 16-bit matrix pipe from hi + lo IEEE-half pairs
+ * of the fp32 operands (K.Q^T and V^T.P each as three MFMAs, fp32 accumulation; softmax statistics, rescale and output fp32):
+ * the fp32 kernel's results to ~1e-6 at 4x its rate.  hd must be 64; qkv and out 16-byte aligned. */
+int ppt_attention_fwd_split16(const void *qkv, void *out, float *lse, int Bt, int T, int P, int H, int hd, float scale, int causal,
+                              void *stream);
 int ppt_attention_prefix_fwd(const void *qkv, void *out, float *lse, int C, int T, int P, int H, int hd, float scale, int dtype,
                              void *stream);
 int ppt_attention_prefix_bwd(const void *qkv, const void *out, const void *dout, const float *lse, float *delta, void *dqkv,

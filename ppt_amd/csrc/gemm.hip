@@ -25,9 +25,11 @@
 namespace {
 
 
-template <typename T, int A_MODE, int BM, int BN>
+template <typename T, int A_MODE, int BM, int BN, bool SPLIT = false>
 __global__ __launch_bounds__(NT, 2) void gemm_kernel(const ppt_gemm_params p)
 {
+    static_assert(!SPLIT || sizeof(T) == 4, "split16 is a mode of the fp32-operand kernel");
+    const float sa = SPLIT ? pow2f(p.split_a_pow2) : 1.0f, sb = SPLIT ? pow2f(p.split_b_pow2) : 1.0f;
     constexpr int WM = BM / 2, WN = BN / 2, TI = WM / 32, TJ = WN / 32, NRA = BM / 32, NRB = BN / 32;
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
     constexpr int STAGE_BYTES = 2 * (A_BYTES + B_BYTES), PARK_BYTES = 4 * WM * WN * 4;
@@ -87,8 +89,13 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const ppt_gemm_params p)
     do {                                                                      \
         finish_A<T, A_MODE, NRA>(SA, p, m0, (S) * BK, tab);                   \
         mask_plain<T, NRB>(SB, p.N, p.K, n0, (S) * BK);                       \
-        PPT_DBG_WRITE(write_stage<NRA>(SA, Abuf + ((BUF) & 1) * A_BYTES));    \
-        PPT_DBG_WRITE(write_stage<NRB>(SB, Bbuf + ((BUF) & 1) * B_BYTES));    \
+        if constexpr (SPLIT) {                                                \
+            write_stage_split<NRA, BM>(SA, Abuf + ((BUF) & 1) * A_BYTES, sa); \
+            write_stage_split<NRB, BN>(SB, Bbuf + ((BUF) & 1) * B_BYTES, sb); \
+        } else {                                                              \
+            PPT_DBG_WRITE(write_stage<NRA>(SA, Abuf + ((BUF) & 1) * A_BYTES)); \
+            PPT_DBG_WRITE(write_stage<NRB>(SB, Bbuf + ((BUF) & 1) * B_BYTES)); \
+        }                                                                     \
     } while (0)
     // STEP(s): multiply slab s; FREE set (held slab s) receives slab s+3; NEXT set (slab s+1) moves to LDS.
     // Loads and LDS writes are UNCONDITIONAL (slab indices clamped to the last slab; the surplus write
@@ -97,7 +104,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const ppt_gemm_params p)
 #define PPT_STEP(S, FA, FB, NA, NB)                                                                       \
     {                                                                                                     \
         PPT_LOAD(FA, FB, min((S) + 3, last));                                                             \
-        mma_slab<T, TI, TJ>(Abuf + ((S) & 1) * A_BYTES, Bbuf + ((S) & 1) * B_BYTES, wm * WM, wn * WN, lane, acc); \
+        if constexpr (SPLIT) mma_slab_split<TI, TJ, BM, BN>(Abuf + ((S) & 1) * A_BYTES, Bbuf + ((S) & 1) * B_BYTES, wm * WM, wn * WN, lane, acc); \
+        else mma_slab<T, TI, TJ>(Abuf + ((S) & 1) * A_BYTES, Bbuf + ((S) & 1) * B_BYTES, wm * WM, wn * WN, lane, acc); \
         PPT_WRITE(NA, NB, min((S) + 1, last), (S) + 1);                                                   \
         __syncthreads();                                                                                  \
     }
@@ -123,6 +131,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const ppt_gemm_params p)
 #undef PPT_STEP
 #undef PPT_WRITE
 #undef PPT_LOAD
+    if constexpr (SPLIT) scale_acc<TI, TJ>(acc, pow2f(-(p.split_a_pow2 + p.split_b_pow2)));
 
     // ---------------- epilogue ----------------
     // The operand tiles are dead (the loop ends on a barrier): every wave parks its fp32 accumulators in
@@ -439,7 +448,7 @@ bool glds_h_ok(const ppt_gemm_params &p, int64_t tiles128)
     return reg_epilogue_ok<2>(p, 0);
 }
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, bool SPLIT>
 int launch_gemm_tile(const ppt_gemm_params &p, hipStream_t s)
 {
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.batch > 0 ? p.batch : 1);
@@ -447,7 +456,7 @@ int launch_gemm_tile(const ppt_gemm_params &p, hipStream_t s)
     static const int use_glds = [] { const char *e = getenv("PPT_GEMM_GLDS"); return e ? atoi(e) : 1; }();
     constexpr int BKE = ROWB / sizeof(T);
     // (three 32 KiB stages of the 128x128 tile leave one workgroup per CU: measured slower than register staging)
-    if (use_glds && BM == 64 && p.a_mode == PPT_A_PLAIN && p.K % BKE == 0) {
+    if (!SPLIT && use_glds && BM == 64 && p.a_mode == PPT_A_PLAIN && p.K % BKE == 0) {   // (split16 splits between registers and LDS)
         static const int deep_below = [] { const char *e = getenv("PPT_GEMM_DEEP_BELOW"); return e ? atoi(e) : 0; }();
         if constexpr (BM == 64 && BN == 64) {
             if ((int)(grid.x * grid.y * grid.z) < deep_below && p.K / BKE >= 4) {
@@ -461,9 +470,9 @@ int launch_gemm_tile(const ppt_gemm_params &p, hipStream_t s)
         return PPT_OK;
     }
     switch (p.a_mode) {
-    case PPT_A_PLAIN: hipLaunchKernelGGL((gemm_kernel<T, PPT_A_PLAIN, BM, BN>), grid, dim3(NT), 0, s, p); break;
-    case PPT_A_AFFINE_RELU: hipLaunchKernelGGL((gemm_kernel<T, PPT_A_AFFINE_RELU, BM, BN>), grid, dim3(NT), 0, s, p); break;
-    case PPT_A_CONV1: hipLaunchKernelGGL((gemm_kernel<T, PPT_A_CONV1, BM, BN>), grid, dim3(NT), 0, s, p); break;
+    case PPT_A_PLAIN: hipLaunchKernelGGL((gemm_kernel<T, PPT_A_PLAIN, BM, BN, SPLIT>), grid, dim3(NT), 0, s, p); break;
+    case PPT_A_AFFINE_RELU: hipLaunchKernelGGL((gemm_kernel<T, PPT_A_AFFINE_RELU, BM, BN, SPLIT>), grid, dim3(NT), 0, s, p); break;
+    case PPT_A_CONV1: hipLaunchKernelGGL((gemm_kernel<T, PPT_A_CONV1, BM, BN, SPLIT>), grid, dim3(NT), 0, s, p); break;
     default: return PPT_EINVAL;
     }
     PPT_CHECK_LAUNCH();
@@ -476,12 +485,19 @@ int launch_gemm_tile(const ppt_gemm_params &p, hipStream_t s)
 // workgroups per CU, and for these short-K problems (K = 128..2048, every tile pays a load prologue and a
 // store epilogue) the extra latency hiding wins up to several thousand tiles.  Only the half-gigabyte
 // mini-PointNet GEMMs stay on 128x128 (and those that emit 64-row BatchNorm partials / 32-row pools).
-template <typename T>
+template <typename T, bool SPLIT = false>
 int launch_gemm(const ppt_gemm_params &p, hipStream_t s)
 {
     static const int small_below = [] { const char *e = getenv("PPT_GEMM_SMALL_BELOW"); return e ? atoi(e) : 4096; }();
     const int64_t tiles128 = (int64_t)((p.N + 127) / 128) * ((p.M + 127) / 128) * (p.batch > 0 ? p.batch : 1);
     const bool need128 = p.col_sum || p.pool_max;       // 32-row chunk partials / pools need 64-wide wave tiles
+    if constexpr (SPLIT) {
+        // split16: the register-staged kernel only (the split sits between its registers and LDS); 128 x 128 tiles (24 MFMAs per
+        // 32 values a thread splits) as soon as they fill the chip, 64 x 64 (6 per 16) below
+        static const int split_small_below = [] { const char *e = getenv("PPT_SPLIT16_SMALL_BELOW"); return e ? atoi(e) : 512; }();
+        if (!need128 && tiles128 < split_small_below) return launch_gemm_tile<T, 64, 64, true>(p, s);
+        return launch_gemm_tile<T, 128, 128, true>(p, s);
+    }
     if (glds_h_ok<T>(p, tiles128)) {
         dim3 grid((p.N + 127) / 128, (p.M + 127) / 128, p.batch > 0 ? p.batch : 1);
         if (grid.y > 65535 || grid.z > 65535) return PPT_EUNSUPPORTED;
@@ -503,8 +519,8 @@ int launch_gemm(const ppt_gemm_params &p, hipStream_t s)
         PPT_CHECK_LAUNCH();
         return PPT_OK;
     }
-    if (!need128 && tiles128 < small_below) return launch_gemm_tile<T, 64, 64>(p, s);
-    return launch_gemm_tile<T, 128, 128>(p, s);
+    if (!need128 && tiles128 < small_below) return launch_gemm_tile<T, 64, 64, false>(p, s);
+    return launch_gemm_tile<T, 128, 128, false>(p, s);
 }
 
 }  // namespace
@@ -519,6 +535,7 @@ extern "C" int ppt_gemm(const ppt_gemm_params *pp, void *stream)
     const ppt_gemm_params &p = q;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || !p.B) return PPT_EINVAL;
     if (p.dtype != PPT_F32 && p.dtype != PPT_BF16 && p.dtype != PPT_F16) return PPT_EINVAL;
+    if (p.split16 && (p.dtype != PPT_F32 || abs(p.split_a_pow2) > 24 || abs(p.split_b_pow2) > 24)) return PPT_EINVAL;
     // one 16-bit format per GEMM: outputs / saved pre-activations / pooled rows are fp32 or the operands' format
     if (p.dtype != PPT_F32) {
         if ((p.C && p.c_dtype != PPT_F32 && p.c_dtype != p.dtype) || (p.C2 && p.c2_dtype != PPT_F32 && p.c2_dtype != p.dtype) ||
@@ -547,5 +564,6 @@ extern "C" int ppt_gemm(const ppt_gemm_params *pp, void *stream)
         return PPT_EUNSUPPORTED;
     if (ppt_gemm256_dispatch(&p, 0, stream) == PPT_OK) return PPT_OK;     // the 256-row macro-tile core takes the big plain problems
     hipStream_t s = ppt_stream(stream);
+    if (p.dtype == PPT_F32 && p.split16) return launch_gemm<float, true>(p, s);   // hi + lo half products (gemm_common.h, split16)
     return p.dtype == PPT_BF16 ? launch_gemm<bf16_t>(p, s) : p.dtype == PPT_F16 ? launch_gemm<f16_t>(p, s) : launch_gemm<float>(p, s);
 }

@@ -288,6 +288,87 @@ __device__ __forceinline__ void mma_slab(const unsigned char *As, const unsigned
     }
 }
 
+// ---- split16: fp32 operands multiplied as hi + lo IEEE-half pairs on the 16-bit matrix pipe (ppt_gemm_params.split16) --------
+// x * s = hi + lo with hi = half(x * s), lo = half(x * s - hi): 22 significand bits while |x * s| >= 2^-2, an absolute floor of
+// 2^-25 below (half's subnormal step), inf above 65 504 -- s is the caller's power of two (split_a_pow2 / split_b_pow2).
+// A . B = A_lo . B_hi + A_hi . B_lo + A_hi . B_hi (A_lo . B_lo, < 2^-22 relative, is dropped): three v_mfma_f32_32x32x16_f16
+// (96 cycles) for the sixteen k that cost eight v_mfma_f32_32x32x2_f32 (512 cycles); fp32 accumulation as before.
+// The split happens where the register-staged kernel moves a slab from registers to LDS (after the A prologue, after the
+// out-of-range mask): a thread's 16-byte fp32 chunk (4 k) becomes 8 bytes of the tile's hi image and 8 of its lo image, so
+// every value is split ONCE per workgroup (~3 VALU instructions) and the K loop reads ready 16-bit fragments.  A tile's
+// two images take the bytes its fp32 image took: [ROWS][64 B] hi, then [ROWS][64 B] lo, 16-byte chunk c of row r at slot
+// c ^ ((r >> 2) & 3) (four rows per 256-byte bank row: the ds_read_b128 fragment reads touch 16 distinct slots).
+// (First version, measured and replaced: splitting at fragment-read time out of the fp32 LDS image -- every wave of a 2 x 2
+// workgroup splits both operands again, 96 VALU instructions per 6 MFMAs: 1.3-1.5x the fp32 MFMA, tools/split16_bench.py.)
+typedef _Float16 ppt_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int lds_off_s(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+__device__ __forceinline__ float pow2f(int e) { return __uint_as_float((uint32_t)(127 + e) << 23); }
+
+template <int NR, int ROWS>
+__device__ __forceinline__ void write_stage_split(const Stage<NR> &st, unsigned char *tile, float s)
+{
+    const int t = threadIdx.x, ch = t & 7;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int row = (t >> 3) + 32 * i;
+        const float x[4] = {__uint_as_float(st.v[i].x) * s, __uint_as_float(st.v[i].y) * s, __uint_as_float(st.v[i].z) * s,
+                            __uint_as_float(st.v[i].w) * s};
+        uint32_t H[2], L[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const _Float16 h0 = (_Float16)x[2 * q], h1 = (_Float16)x[2 * q + 1];
+            const ppt_h2 hh = {h0, h1};
+            const ppt_h2 ll = {(_Float16)(x[2 * q] - (float)h0), (_Float16)(x[2 * q + 1] - (float)h1)};
+            H[q] = __builtin_bit_cast(uint32_t, hh);
+            L[q] = __builtin_bit_cast(uint32_t, ll);
+        }
+        const int off = lds_off_s(row, ch >> 1) + (ch & 1) * 8;
+        *reinterpret_cast<uint2 *>(tile + off) = make_uint2(H[0], H[1]);
+        *reinterpret_cast<uint2 *>(tile + ROWS * 64 + off) = make_uint2(L[0], L[1]);
+    }
+}
+
+template <int TI, int TJ, int AROWS, int BROWS>
+__device__ __forceinline__ void mma_slab_split(const unsigned char *As, const unsigned char *Bs, int arow0, int brow0, int lane,
+                                               f32x16_t (&acc)[TI][TJ])
+{
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {                       // two 16-deep steps per 32-k slab
+        uint4 ah[TI], al[TI], bh[TJ], bl[TJ];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const unsigned char *q = As + lds_off_s(arow0 + i * 32 + r, kk * 2 + h);
+            ah[i] = *reinterpret_cast<const uint4 *>(q);
+            al[i] = *reinterpret_cast<const uint4 *>(q + AROWS * 64);
+        }
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const unsigned char *q = Bs + lds_off_s(brow0 + j * 32 + r, kk * 2 + h);
+            bh[j] = *reinterpret_cast<const uint4 *>(q);
+            bl[j] = *reinterpret_cast<const uint4 *>(q + BROWS * 64);
+        }
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                acc[i][j] = h16<f16_t>::mfma32(al[i], bh[j], acc[i][j]);
+                acc[i][j] = h16<f16_t>::mfma32(ah[i], bl[j], acc[i][j]);
+                acc[i][j] = h16<f16_t>::mfma32(ah[i], bh[j], acc[i][j]);
+            }
+    }
+}
+template <int TI, int TJ>
+__device__ __forceinline__ void scale_acc(f32x16_t (&acc)[TI][TJ], float inv)
+{
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
+}
+
 // ---- scalar epilogue (any N / alignment): WN lanes span a row, 64/WN rows per pass ----------------
 template <int WM, int WN>
 __device__ __forceinline__ void epilogue_scalar(const ppt_gemm_params &p, float *ct, int lane, int mw, int nw, int m0, int wm,

@@ -1063,11 +1063,11 @@ def head_loss_forward_backward(feat, wt, text_raw, logit_scale, labels, smoothin
         # w = pc_projection [F,E] as stored
         return ops.head_loss(feat.contiguous(), w.contiguous(), text_raw.contiguous(), logit_scale.contiguous(),
                              labels.contiguous(), smoothing)
-    pc = ops.gemm(feat.contiguous(), wt, out_dtype=torch.float32)                       # [B,E]
+    pc = ops.gemm(feat.contiguous(), wt, out_dtype=torch.float32, split=False)          # [B,E]  (the head: B rows, un-scaled gradients -> fp32 MFMA)
     nrm = text_raw.norm(dim=-1, keepdim=True)
     tn = text_raw / nrm
     spc = (logit_scale.exp() * pc).contiguous()
-    logits = ops.gemm(spc, tn.contiguous(), out_dtype=torch.float32)                    # [B,C]
+    logits = ops.gemm(spc, tn.contiguous(), out_dtype=torch.float32, split=False)       # [B,C]
     logp = torch.log_softmax(logits, dim=1)
     nll = -logp.gather(1, labels.view(B, 1)).squeeze(1)
     loss = ((1.0 - smoothing) * nll + smoothing * (-logp.mean(dim=1))).mean()
@@ -1075,6 +1075,6 @@ def head_loss_forward_backward(feat, wt, text_raw, logit_scale, labels, smoothin
     target.scatter_add_(1, labels.view(B, 1), torch.full((B, 1), 1.0 - smoothing, dtype=logp.dtype, device=logp.device))
     dlogits = (logp.exp() - target) / B
     # d tn [C,E] = dlogits^T [C,B] @ spc [B,E]   (NT GEMM on the transposed operands, K = B padded to the chunk size)
-    d_tn = ops.gemm(ops.transpose(dlogits, pad_to=4), ops.transpose(spc, pad_to=4), out_dtype=torch.float32)
+    d_tn = ops.gemm(ops.transpose(dlogits, pad_to=4), ops.transpose(spc, pad_to=4), out_dtype=torch.float32, split=False)
     d_raw = (d_tn - tn * (d_tn * tn).sum(dim=-1, keepdim=True)) / nrm
     return loss, logits, d_raw

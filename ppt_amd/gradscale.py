@@ -57,7 +57,11 @@ def current(stage_dtype, default_rows=1):
     """The scale S a node whose forward runs NOW will use in its backward: 1.0 unless the stage carries gradients in a 16-bit
     format; else a power of two from the announced row count (or the node's own default)."""
     if stage_dtype not in (torch.float16, torch.bfloat16):
-        return 1.0
+        # split16 (fp32 storage, hi + lo half products: ops.set_split16) scales like a 16-bit stage: the halves keep their 22 bits
+        # only above half's subnormals, and a mean-reduced loss puts un-scaled gradients far below them
+        from . import ops
+        if not (stage_dtype == torch.float32 and ops.split16_enabled()):
+            return 1.0
     pol = POLICY
     if pol in (None, "", "0", "1", "none", "off"):
         return 1.0

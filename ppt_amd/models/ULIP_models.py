@@ -604,6 +604,10 @@ class ULIP_WITH_IMAGE(nn.Module):
         # The text tower's operand format: None = what the mode says (IEEE half in "mixed16"); torch.float32 = fp32 operands whatever
         # the mode (PPT_TEXT_PRECISION=fp32, or calibrate_text_precision() below found half too coarse for THESE weights).
         self.text_precision = torch.float32 if os.environ.get("PPT_TEXT_PRECISION", "").lower() in ("fp32", "float32") else None
+        # a text tower on fp32 operands INSIDE the mixed mode (the override above, or the load-time check's verdict) forms its
+        # products from hi + lo half pairs (split16) instead of on the fp32 MFMA; PPT_TEXT_SPLIT16=0: the fp32 MFMA
+        self.text_split16 = os.environ.get("PPT_TEXT_SPLIT16", "1") != "0"
+        self.split16 = False
         self.text_calibration = None        # what calibrate_text_precision measured: {"rel_l2": ..., "threshold": ..., "demoted": bool}
         self._text_calibrated = False
         # stages this model's monitor moved from IEEE half to bf16 (health.demote); ONE set per model, shared with the point
@@ -646,20 +650,25 @@ class ULIP_WITH_IMAGE(nn.Module):
     @property
     def precision_name(self):
         """"mixed16" (performance mode) or "fp32" (parity mode)."""
-        return "fp32" if self.precision == torch.float32 else self.MIXED16
+        return ("split16" if getattr(self, "split16", False) else "fp32") if self.precision == torch.float32 else self.MIXED16
 
     def set_precision(self, mode):
         """"mixed16" -- the performance mode: 16-bit MFMA operands with fp32 accumulation, residual streams / statistics /
         gradients in fp32; the operand FORMAT is chosen per stage (IEEE half for the CLIP text tower, the PointBERT tokenizer and
         blocks, the part-seg decoder and per-point head; bf16 for PointNet++ / PointMLP: engine.*_F16) -- or
-        "fp32" / torch.float32 -- the parity mode (fp32 operands on the fp32 MFMA).
+        "fp32" / torch.float32 -- the parity mode (fp32 operands on the fp32 MFMA) -- or "split16": the parity mode's fp32 storage,
+        statistics and VALU attention, with every GEMM product formed on the 16-bit matrix pipe from hi + lo IEEE-half pairs of the
+        fp32 operands (ppt_gemm_params.split16: 22 significand bits per operand, ~2x the fp32 MFMA's rate, results at least as
+        close to an fp64 product as the fp32 MFMA's; gradient stages are scaled as in mixed16, ppt_amd/gradscale.py).
         `torch.bfloat16` is accepted as a DEPRECATED alias of "mixed16" (rounds 1-2 ran that mode in bf16 throughout and named it
         after the format; it has not been a statement about the operand format since round 3)."""
+        split16 = False
         if isinstance(mode, str):
             key = mode.lower()
-            if key not in (self.MIXED16, "fp32", "float32"):
-                raise ValueError(f'set_precision: expected "mixed16" or "fp32", got {mode!r}')
+            if key not in (self.MIXED16, "fp32", "float32", "split16"):
+                raise ValueError(f'set_precision: expected "mixed16", "split16" or "fp32", got {mode!r}')
             dtype = torch.bfloat16 if key == self.MIXED16 else torch.float32
+            split16 = key == "split16"
         elif mode is torch.bfloat16 or mode is torch.float16:
             import warnings
             warnings.warn('set_precision(torch.bfloat16 / torch.float16) selects the MIXED 16-bit mode (IEEE half operands in the '
@@ -670,7 +679,12 @@ class ULIP_WITH_IMAGE(nn.Module):
             dtype = torch.float32
         else:
             raise ValueError(f'set_precision: expected "mixed16", "fp32" or torch.float32, got {mode!r}')
-        # (internally the mode marker stays a dtype: torch.bfloat16 = mixed16, torch.float32 = parity)
+        # (internally the mode marker stays a dtype: torch.bfloat16 = mixed16, torch.float32 = parity; split16 is the parity mode's
+        # storage with every ppt_gemm product formed from hi + lo half pairs -- ops.set_split16, said by every _cache() call)
+        self.split16 = split16
+        for m in self.modules():
+            if m is not self and (hasattr(m, "_cache") or hasattr(m, "_wc")):
+                m.split16 = split16
         self.point_encoder.precision = dtype
         self.point_encoder._wc = None
         self._text_calibrated = False
@@ -698,6 +712,8 @@ class ULIP_WITH_IMAGE(nn.Module):
             want = torch.float16 if (self.precision == torch.bfloat16 and self.text_f16) else self.precision
         if self._wc is None or self._wc.dtype != want:
             self._wc = engine.WeightCache(want, self.demoted)
+        # split16: the whole model's mode, or the text tower alone when its load-time check sent it to fp32 operands
+        ops.set_split16(self.split16 or (want == torch.float32 and self.precision != torch.float32 and self.text_split16))
         return self._wc
 
     def _live_state(self):

@@ -345,6 +345,7 @@ class PointTransformer(nn.Module):
     def _cache(self):
         if self._wc is None or self._wc.dtype != self.precision:
             self._wc = engine.WeightCache(self.precision, self.__dict__.setdefault("demoted", set()))
+        ops.set_split16(self.__dict__.get("split16", False))       # (ULIP_WITH_IMAGE.set_precision("split16"))
         return self._wc
 
     def _live_state(self):

@@ -6,6 +6,7 @@ contiguous, of the stated dtype; wrappers allocate outputs and raise RuntimeErro
 code.  There is no CPU path.
 """
 import ctypes
+import os
 
 import torch
 
@@ -182,14 +183,38 @@ def ball_query(xyz, center, radius, K, want_grouped=False):
 
 
 # ---------------------------------------------------------------------------------------------
+# split16 (ppt_gemm_params.split16): the powers of two the A / B operand values are multiplied by before they are split into
+# hi + lo halves.  A: activations and S-scaled gradients (ppt_amd/gradscale.py) -- typical magnitude 1e-3 .. 1e2, left where they
+# are; B: weights (typically 0.01 .. 0.1, |w| < 4 095 required) -- x 16 puts them where half keeps all of hi + lo's 22 bits.
+SPLIT16_POW2 = (int(os.environ.get("PPT_SPLIT16_A_POW2", "0")), int(os.environ.get("PPT_SPLIT16_B_POW2", "4")))
+# Process-wide on purpose (not thread-local): a node's backward runs on autograd's device thread.  The last model that fetched its
+# WeightCache decides -- a model's backward follows its forward in every loop of the reference (main_cls.py:194-198).
+_SPLIT16 = False
+ATTN_SPLIT16 = os.environ.get("PPT_ATTN_SPLIT16", "1") != "0"      # 0: the split16 mode keeps the fp32 VALU attention forward
+
+
+def set_split16(on):
+    """fp32-operand ops.gemm calls that do not say `split=` themselves use the split16 products from now on (True) or the fp32
+    MFMA (False)."""
+    global _SPLIT16
+    _SPLIT16 = bool(on)
+
+
+def split16_enabled():
+    return _SPLIT16
+
+
 def gemm(A, B, *, out=None, out_dtype=None, M=None, bias=None, act=ACT_NONE, dact_pre=None,
          group_add=None, group_rows=0, row_scale=None, row_scale_rows=0, residual=None,
          residual2=None, out2=None, out2_pre=False, col_stats=None, pool_max=None, pool_min=None, pool_rows=0,
          batch=1, strideA=0, strideB=0, strideC=0,
-         a_mode=A_PLAIN, a_scale=None, a_shift=None, pts=None, w1=None, b1=None, want_out=True, algo_k=None, core=None):
+         a_mode=A_PLAIN, a_scale=None, a_shift=None, pts=None, w1=None, b1=None, want_out=True, algo_k=None, core=None, split=None):
     """C[M,N] = epilogue(prologue(A)[M,K] @ B[N,K]^T) -- see struct ppt_gemm_params.
     A [M,K] (or None with a_mode=A_CONV1 and pts [M,3]); B [N,K]; 2-D, last-dim contiguous
-    (row stride may exceed K).  Returns out (or None when want_out=False)."""
+    (row stride may exceed K).  Returns out (or None when want_out=False).
+    split (fp32 operands only): True / (a_pow2, b_pow2) multiplies hi + lo half pairs on the 16-bit matrix pipe (split16,
+    ppt_gemm_params.split16); False: the fp32 MFMA; None: what set_split16() last said (a model in the "split16" precision mode
+    says it whenever it fetches its WeightCache, in forward and in backward)."""
     p = GemmParams()
     N, K = B.shape
     if a_mode == A_CONV1:
@@ -232,6 +257,11 @@ def gemm(A, B, *, out=None, out_dtype=None, M=None, bias=None, act=ACT_NONE, dac
         p.pool_max, p.pool_dtype, p.pool_rows = _p(pool_max), dtype_code(pool_max), pool_rows
         p.pool_min = _p(pool_min)
     p.batch, p.strideA, p.strideB, p.strideC = batch, strideA, strideB, strideC
+    if split is None:
+        split = _SPLIT16
+    if split and p.dtype == PPT_F32:
+        p.split16 = 1
+        p.split_a_pow2, p.split_b_pow2 = split if isinstance(split, tuple) else SPLIT16_POW2
     if profiler is not None:
         kk = K if algo_k is None else algo_k
         # ("bf16" names the 16-bit MFMA family of the roofline table: bf16 and fp16 operands run at the same rate)
@@ -506,8 +536,12 @@ def attention_fwd(qkv, Bt, T, H, scale, causal, want_lse=True):
     lse = torch.empty((Bt, H, T), dtype=torch.float32, device=qkv.device) if want_lse else None
     if profiler is not None:
         profiler.begin("attention_fwd", 4.0 * Bt * H * T * T * 64 * (0.5 if causal else 1.0))
-    _lib.check(_lib.lib().ppt_attention_fwd(_p(qkv), _p(out), _p(lse), Bt, T, H, 64, scale, int(causal),
-                                            dtype_code(qkv), _stream()), "ppt_attention_fwd")
+    if qkv.dtype == torch.float32 and _SPLIT16 and ATTN_SPLIT16:      # split16 mode: both products from hi + lo half pairs
+        _lib.check(_lib.lib().ppt_attention_fwd_split16(_p(qkv), _p(out), _p(lse), Bt, T, 0, H, 64, scale, int(causal), _stream()),
+                   "ppt_attention_fwd_split16")
+    else:
+        _lib.check(_lib.lib().ppt_attention_fwd(_p(qkv), _p(out), _p(lse), Bt, T, H, 64, scale, int(causal),
+                                                dtype_code(qkv), _stream()), "ppt_attention_fwd")
     if profiler is not None:
         profiler.end()
     if probe is not None:
@@ -543,8 +577,12 @@ def attention_prefix_fwd(qkv, C, T, P, H, scale, want_lse=True):
     lse = torch.empty((rows, H), dtype=torch.float32, device=qkv.device) if want_lse else None
     if profiler is not None:
         profiler.begin("attention_fwd", 2.0 * (C * (T * T - P * P) + P * P) * H * 64)
-    _lib.check(_lib.lib().ppt_attention_prefix_fwd(_p(qkv), _p(out), _p(lse), C, T, P, H, 64, scale, dtype_code(qkv), _stream()),
-               "ppt_attention_prefix_fwd")
+    if qkv.dtype == torch.float32 and _SPLIT16 and ATTN_SPLIT16:
+        _lib.check(_lib.lib().ppt_attention_fwd_split16(_p(qkv), _p(out), _p(lse), C, T, P, H, 64, scale, 1, _stream()),
+                   "ppt_attention_fwd_split16")
+    else:
+        _lib.check(_lib.lib().ppt_attention_prefix_fwd(_p(qkv), _p(out), _p(lse), C, T, P, H, 64, scale, dtype_code(qkv), _stream()),
+                   "ppt_attention_prefix_fwd")
     if profiler is not None:
         profiler.end()
     if probe is not None:
