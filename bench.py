@@ -21,6 +21,8 @@ Prints ONE JSON line (rank 0): metric/value/unit..., plus
                   "roofline.kernels" lists EVERY hot kernel of that pass the same way: FPS / kNN / ball query against
                   8 TB/s with SURVEY §8(d)'s algorithmic bytes, attention and each GEMM kernel against the MFMA peak;
   "parity_mode":  clouds/s of the same step in the fp32 parity mode (N = 1 only);
+  "split16_mode": ... and in the split16 mode (fp32 storage, products from hi + lo half pairs on the 16-bit matrix pipe: the fp32
+                  mode's parity bounds at ~2x its rate);
   "cpu_baseline": the oracle (CPU restatement of the reference, `kind: "port"`) timed on this host's cores
                   on the reference's CPU-runnable case C1 (batch 8), rank 0, N=1 only.
 """
@@ -92,12 +94,15 @@ def kernel_table(by_kernel, overhead_ms, steps):
     return rows
 
 
-def parity_mode_rate(cfg, pc, label, extra, steps, burn_in=6):
-    """clouds/s of the SAME step with set_precision(torch.float32): fp32 operands on the fp32 MFMA / fp32 VALU attention,
-    the mode whose results meet the fp32-level tolerances of tests/test_model_gpu.py (VERDICT r1 #6)."""
+def parity_mode_rate(cfg, pc, label, extra, steps, burn_in=6, mode="fp32"):
+    """clouds/s of the SAME step with set_precision("fp32") -- fp32 operands on the fp32 MFMA / fp32 VALU attention -- or
+    set_precision("split16") -- the same fp32 storage with every GEMM and the attention forward formed from hi + lo half pairs on
+    the 16-bit matrix pipe: the two modes whose results meet the fp32-level tolerances of tests/test_model_gpu.py."""
     from ppt_amd.train import Trainer
     m = build_model(cfg["dataset"], cfg["head_type"], precision=torch.float32, model=cfg.get("model", "ULIP_PointBERT"),
                     task=cfg.get("task", "cls"))
+    if mode == "split16":
+        m.set_precision("split16")
     m.train()
     tr = Trainer(m, lr=3e-3, label_smoothing=0.2, distributed=False)
     tr.extra_inputs = extra
@@ -112,7 +117,7 @@ def parity_mode_rate(cfg, pc, label, extra, steps, burn_in=6):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert np.isfinite(loss.item())
-    return {"dtype": "f32", "value": round(pc.shape[0] * steps / dt, 2), "unit": "point-clouds/s",
+    return {"dtype": "f32" if mode == "fp32" else "f32 as hi+lo f16 pairs", "value": round(pc.shape[0] * steps / dt, 2), "unit": "point-clouds/s",
             "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "burn_in": burn_in}
 
 
@@ -495,6 +500,7 @@ def main():
                "roofline": roof}
         if world == 1 and not force_dist and not a.no_parity_mode:
             out["parity_mode"] = parity_mode_rate(cfg, pc, label, trainer.extra_inputs, max(3, a.steps // 2))
+            out["split16_mode"] = parity_mode_rate(cfg, pc, label, trainer.extra_inputs, max(3, a.steps // 2), mode="split16")
             if a.config == "C2":
                 out["parity"] = measured_parity()
         if world == 1 and not a.no_cpu_baseline:

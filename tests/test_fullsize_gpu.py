@@ -279,6 +279,24 @@ def test_c5_plain_partseg_loop_16bit_gradients_agree_with_fp32():
             over.append((n, r, bound))
     print(f"PARITY C5 plain loop worst deep matrix {worst[2]}, worst deep 1-D {worst[1]}")
     assert not over, over
+    # split16 (round 5: fp32 storage, every GEMM and the attention forward from hi + lo half pairs on the 16-bit matrix pipe): the
+    # mode for callers who need these deep gradients right without the fp32 MFMA's cost -- bound 2e-2 on the deep matrices
+    # (what is left is the decoder's conditioning acting on ~1e-6 relative differences), head side 1e-3
+    ls, gs = run("split16")
+    assert abs(ls - l32) < 1e-4, (ls, l32)
+    deep_s, head_s, over = ("", 0.0), ("", 0.0), []
+    for n in g32:
+        if _zero_by_construction(n):
+            continue
+        r = _rel(gs[n], g32[n])
+        if n in head_side:
+            head_s = max(head_s, (n, r), key=lambda t: t[1])
+        elif r > deep_s[1]:
+            deep_s = (n, r)
+        if not r < (5e-3 if n in head_side else 2e-2):
+            over.append((n, r))
+    print(f"PARITY C5 plain loop split16 vs fp32: worst deep tensor {deep_s}, worst head-side {head_s}, loss diff {abs(ls - l32):.3g}")
+    assert not over, over
     # the same loop with the nodes' scale switched off: what the unchanged caller got before round 4
     _, goff = run(torch.bfloat16, policy="off")
     ratios = {n: (_rel(goff[n], g32[n]), _rel(g16[n], g32[n])) for n in g32 if not _zero_by_construction(n)}

@@ -1510,6 +1510,151 @@ def test_dataset_fps_is_bit_exact(tag, N, M, dup, cols):
         PD.farthest_point_sample(pts.astype(np.float64), 8)
 
 
+# ------------------------------------------------------------------ split16: fp32 operands as hi + lo half pairs
+@pytest.mark.parametrize("M,N,K,kind", [
+    (817, 1536, 512, "plain"),           # the prompt chain's in_proj (64 x 64 tiles)
+    (817, 512, 2048, "residual"),        # c_proj: bias + fp32 residual
+    (16416, 1536, 384, "gelu"),          # fc1 of a C2 batch (128 x 128 tiles), ragged M
+    (1000, 200, 36, "plain"),            # ragged everything, K not a multiple of the 32-float slab
+    (9000, 640, 64, "dact"),             # derivative epilogue + second (pre-activation) output
+    (16384, 512, 256, "stats"),          # per-group term + BatchNorm chunk statistics + the 32-row max pool
+    (8192, 256, 128, "affine"),          # A prologue: BatchNorm + ReLU of the previous layer
+    (4096, 128, 0, "conv1"),             # A prologue: the K = 3 first conv from the points
+    (3000, 256, 96, "batched"),
+])
+def test_gemm_split16_is_fp32_grade(ops, M, N, K, kind):
+    """ppt_gemm_params.split16 (csrc/gemm_common.h: the fp32 operands multiplied as hi + lo IEEE-half pairs, three 16-bit MFMAs
+    per product, fp32 accumulation) against the fp32 MFMA on the same launch and against an fp64 product: every A prologue and
+    epilogue of the fp32 path, 64 x 64 and 128 x 128 tiles.  The split product is at least as close to fp64 as the fp32 MFMA's
+    (measured 2.7e-7 vs 4.2e-7 rel-L2); side outputs agree to the same level; reproducible bit for bit."""
+    rng = np.random.default_rng(M + 3 * N + 7 * K)
+    kw, a_kw = {}, {}
+    A = None
+    if kind == "conv1":
+        K = 128
+        pts = dev(rng.standard_normal((M, 3)).astype(np.float32))
+        w1, b1 = dev((rng.standard_normal((K, 3)) * 0.5).astype(np.float32)), dev(rng.standard_normal(K).astype(np.float32) * 0.1)
+        sc, sh = dev((rng.random(K) + 0.5).astype(np.float32)), dev(rng.standard_normal(K).astype(np.float32) * 0.1)
+        a_kw = dict(a_mode=ops.A_CONV1, pts=pts, w1=w1, b1=b1, a_scale=sc, a_shift=sh)
+        A_eff = torch.relu((pts.double() @ w1.double().t() + b1.double()) * sc.double() + sh.double())
+    else:
+        A = dev(rng.standard_normal((M, K)).astype(np.float32))
+        A[:, ::7] *= 20.0                                   # outlier channels
+        A_eff = A.double()
+        if kind == "affine":
+            sc, sh = dev((rng.random(K) + 0.5).astype(np.float32)), dev(rng.standard_normal(K).astype(np.float32))
+            a_kw = dict(a_mode=ops.A_AFFINE_RELU, a_scale=sc, a_shift=sh)
+            A_eff = torch.relu(A.double() * sc.double() + sh.double())
+    Bm = dev((rng.standard_normal((N, K)) / math.sqrt(K)).astype(np.float32))
+    bias = dev(rng.standard_normal(N).astype(np.float32))
+    ref = A_eff @ Bm.double().t()
+    if kind == "gelu":
+        kw = dict(bias=bias, act=ops.ACT_GELU)
+        ref = torch.nn.functional.gelu(ref + bias.double())
+    elif kind == "residual":
+        res = dev(rng.standard_normal((M, N)).astype(np.float32))
+        kw = dict(bias=bias, residual=res)
+        ref = ref + bias.double() + res.double()
+    elif kind == "dact":
+        pre = dev(rng.standard_normal((M, N)).astype(np.float32))
+        kw = dict(act=ops.ACT_QUICKGELU, dact_pre=pre)
+        sg = torch.sigmoid(1.702 * pre.double())
+        ref = ref * (sg * (1.0 + 1.702 * pre.double() * (1.0 - sg)))
+    elif kind == "stats":
+        gadd = dev(rng.standard_normal((M // 32, N)).astype(np.float32))
+        kw = dict(bias=bias, group_add=gadd, group_rows=32)
+        ref = ref + bias.double() + gadd.double().repeat_interleave(32, dim=0)
+
+    def launch(split):
+        k2, extra = dict(kw), {}
+        if kind == "stats":
+            cs = torch.full(((M + 31) // 32, N), float("nan"), device="cuda"); cq = torch.full_like(cs, float("nan"))
+            pm = torch.full((M // 32, N), float("nan"), device="cuda")
+            k2.update(col_stats=(cs, cq), pool_max=pm, pool_rows=32)
+            extra = dict(cs=cs, cq=cq, pm=pm)
+        if kind == "batched":
+            Mb = M // 3
+            out = torch.full((3 * Mb, N), float("nan"), device="cuda")
+            ops.gemm(A[:Mb], Bm, out=out, M=Mb, batch=3, strideA=Mb * K, strideB=0, strideC=Mb * N, split=split, **k2)
+        else:
+            out = ops.gemm(A, Bm, out_dtype=torch.float32, split=split, **a_kw, **k2)
+        torch.cuda.synchronize()
+        return out, extra
+    f32, f32_x = launch(False)
+    s16, s16_x = launch(True)
+    again, _ = launch(True)
+    assert torch.equal(s16, again), "not reproducible"
+    if kind == "batched":
+        ref = ref[:3 * (M // 3)]
+    scale = ref.abs().max().item()
+    e32 = (f32.double() - ref).abs().max().item() / scale
+    e16 = (s16.double() - ref).abs().max().item() / scale
+    r32 = ((f32.double() - ref).norm() / ref.norm()).item()
+    r16 = ((s16.double() - ref).norm() / ref.norm()).item()
+    print(f"PARITY split16 gemm {kind} {M}x{N}x{K}: max-err/max {e16:.2e} (fp32 MFMA {e32:.2e}), rel-L2 {r16:.2e} (fp32 MFMA {r32:.2e})")
+    assert e16 < 4e-6 and r16 < 2e-6 and r16 < 1.5 * r32 + 1e-7
+    for k in f32_x:
+        a, b = f32_x[k].double(), s16_x[k].double()
+        assert torch.isfinite(b).all() and ((a - b).norm() / a.norm()).item() < 1e-5, k
+    if kind == "plain" and K == 512:
+        # magnitudes: gradient-like A (1e-6) sinks under half's subnormal floor un-scaled and is recovered by the caller's power of two
+        tiny = A * 1e-6
+        want = tiny.double() @ Bm.double().t()
+        bad = ops.gemm(tiny, Bm, split=(0, 4))
+        good = ops.gemm(tiny, Bm, split=(20, 4))
+        assert ((bad.double() - want).norm() / want.norm()).item() > 1e-3
+        assert ((good.double() - want).norm() / want.norm()).item() < 1e-6
+        with pytest.raises(RuntimeError):
+            ops.gemm(A, Bm, split=(30, 0))                  # |pow2| <= 24
+        h = ops.gemm(A.half(), Bm.half(), split=True)      # 16-bit operands: `split` does not apply
+        assert torch.equal(h, ops.gemm(A.half(), Bm.half(), split=False))
+
+
+@pytest.mark.parametrize("name,Bt,T,H,causal,P,gain", [
+    ("vit", 32, 513, 6, False, 0, 1.0),                     # T = 64 n + 1: the peeled last key
+    ("vit, large scores", 8, 513, 6, False, 0, 3.0),
+    ("text", 40, 77, 8, True, 0, 1.0),
+    ("prefix-shared", 40, 77, 8, True, 17, 1.5),
+    ("ragged", 3, 200, 2, False, 0, 1.0),
+    ("causal, 5 key tiles", 5, 300, 4, True, 0, 2.0),
+])
+def test_attention_split16_forward_is_fp32_grade(ops, name, Bt, T, H, causal, P, gain):
+    """csrc/attention_split.hip (K.Q^T and V^T.P from hi + lo half pairs on the matrix pipe, fp32 softmax) against the fp32 VALU
+    kernel -- same layouts, prefix-shared included -- and against an fp64 softmax(QK^T)V."""
+    g = torch.Generator().manual_seed(T + P)
+    rows = Bt * T if P == 0 else ops.prefix_rows(Bt, T, P)
+    qkv = (torch.randn(rows, 3 * H * 64, generator=g) * gain).cuda()
+
+    def run(split):
+        ops.set_split16(split)
+        try:
+            if P:
+                return ops.attention_prefix_fwd(qkv, Bt, T, P, H, 0.125)
+            return ops.attention_fwd(qkv, Bt, T, H, 0.125, causal)
+        finally:
+            ops.set_split16(False)
+    o32, l32 = run(False)
+    o16, l16 = run(True)
+    o16b, _ = run(True)
+    torch.cuda.synchronize()
+    assert torch.equal(o16, o16b)
+    sc = o32.abs().max().item()
+    d = (o16 - o32).abs().max().item() / sc
+    dl = (l16 - l32).abs().max().item()
+    print(f"PARITY split16 attention {name}: out vs fp32 kernel max-err/max {d:.2e}, lse abs {dl:.2e}")
+    assert d < 5e-6 and dl < 5e-5
+    if P == 0:
+        q, k, v = qkv.double().view(Bt, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+        s_ = (q @ k.transpose(-1, -2)) * 0.125
+        if causal:
+            s_ = s_.masked_fill(torch.triu(torch.ones(T, T, dtype=torch.bool, device="cuda"), 1), float("-inf"))
+        want = (torch.softmax(s_, -1) @ v).permute(0, 2, 1, 3).reshape(Bt * T, H * 64)
+        e16 = (o16.double() - want).abs().max().item() / want.abs().max().item()
+        e32 = (o32.double() - want).abs().max().item() / want.abs().max().item()
+        print(f"PARITY split16 attention {name}: vs fp64 {e16:.2e} (fp32 kernel {e32:.2e})")
+        assert e16 < 5e-6
+
+
 class _CloudsWithDatasetFPS(torch.utils.data.Dataset):
     """The shape of the reference's datasets (data/dataset_3d.py:288-300): __getitem__ seeds nothing, calls
     farthest_point_sample(point, npoint) -- which draws its start with np.random.randint -- and returns the rows."""

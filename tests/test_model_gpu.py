@@ -239,7 +239,7 @@ def test_loss_scaling_keeps_fp16_gradients_out_of_the_subnormals():
             assert e < 1.5e-2, (k, e)
 
 
-@pytest.mark.parametrize("precision,tol", [(torch.float32, 2e-3), (torch.bfloat16, 0.1)])
+@pytest.mark.parametrize("precision,tol", [(torch.float32, 2e-3), ("split16", 2e-3), (torch.bfloat16, 0.1)])
 def test_eval_forward_matches_golden(precision, tol):
     g = np.load(os.path.join(G, "g_eval.npz"))
     f0 = np.load(os.path.join(G, "g_step_h0.npz"))
@@ -250,7 +250,7 @@ def test_eval_forward_matches_golden(precision, tol):
     with torch.no_grad():
         feat = m.point_encoder(pc.cuda())
         logits = m(pc.cuda())
-    ftol = 5e-4 if precision == torch.float32 else 6e-3
+    ftol = 5e-4 if precision in FP32_GRADE else 6e-3
     _bound(f"eval {precision} feature abs err", np.abs(feat.cpu().numpy() - g["pc_feat"]).max(), ftol)
     _bound(f"eval {precision} logits abs err", np.abs(logits.cpu().numpy() - g["logits"]).max(), tol)
     # argmax agreement is what validate() (main_cls.py:266-270) consumes
@@ -889,7 +889,7 @@ def test_ulip_pn_msg_train_step_runs_and_only_prompt_trains():
 
 
 # ------------------------------------------------------------------ part segmentation (BASELINE config C5)
-@pytest.mark.parametrize("precision", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("precision", [torch.float32, "split16", torch.bfloat16])
 def test_partseg_train_step_matches_golden(precision):
     """ULIP_PointBERT_partseg forward + CE + backward (main_partseg.py:204-215) on the golden case: B=2 x 2048 points
     with duplicate points, injected FPS starts / DropPath / Dropout.  fp32: logits 2e-2 abs (|logits| <= 47), loss 1e-3,
@@ -916,7 +916,7 @@ def test_partseg_train_step_matches_golden(precision):
     assert pred.shape == (2, 2048, 50)
     loss = torch.nn.CrossEntropyLoss(label_smoothing=0.2)(pred.reshape(-1, 50), labels.reshape(-1))
     loss.backward()
-    f32 = precision == torch.float32
+    f32 = precision in FP32_GRADE             # (split16 is held to the fp32 mode's bounds)
     err = np.abs(pred.detach().cpu().numpy()[:, ::16] - g["logits_sub"]).max()
     # performance mode: logits are logit_scale (14.3) x a cosine, |logits| <= 47 here.  With bf16 operands everywhere they moved
     # by 1.27; with fp16 operands in the text tower, tokenizer, blocks and decoder GEMMs and the fp16 per-point head: 0.254
@@ -937,6 +937,7 @@ def test_partseg_train_step_matches_golden(precision):
         ref = g["gradsub_" + k]
         rel = np.linalg.norm(sub - ref) / np.linalg.norm(ref)
         if f32:
+            worst = max(worst, rel if k not in top else 0.0)
             assert rel < (2e-3 if k in top else 6e-2), (k, rel)
             assert abs(live[k].grad.double().norm().item() / ref_n - 1) < 6e-2, k
         elif k in top:
@@ -953,6 +954,8 @@ def test_partseg_train_step_matches_golden(precision):
             _bound(f"partseg bf16 grad {k} rel-L2", rel, 0.15)
             _bound(f"partseg bf16 grad {k} |norm ratio - 1|", abs(live[k].grad.double().norm().item() / ref_n - 1), 0.03)
             _bound(f"partseg bf16 grad {k} 1 - cos", 1 - cos, 0.1)
+    if f32:
+        print(f"PARITY partseg {precision} worst deep-decoder gradient rel-L2: {worst:.4g} (bound 0.06)")
 
 
 def test_partseg_graphed_step_is_bit_identical_to_eager():

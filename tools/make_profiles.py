@@ -155,7 +155,14 @@ def main():
     extra = os.path.join(out, f"{a.round}_notes.md")
     if os.path.exists(extra):
         md += open(extra).read().splitlines()
-    open(os.path.join(out, "README.md"), "w").write("\n".join(md) + "\n")
+    # the hand-written part of the README (documents that are not generated from a trace) survives a regeneration
+    readme = os.path.join(out, "README.md")
+    keep = ""
+    if os.path.exists(readme):
+        old = open(readme).read()
+        i = old.find("## Round-5 documents beside the generated tables")
+        keep = "\n" + old[i:] if i >= 0 else ""
+    open(readme, "w").write("\n".join(md) + "\n" + keep)
     print("\n".join(md))
 
 
