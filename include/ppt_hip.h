@@ -43,7 +43,7 @@ extern "C" {
 const char *ppt_strerror(int code);
 /* ABI version of this header (currently 6); bumped on any signature change or added entry point.
  * 6: ppt_gemm_params.split16 / split_a_pow2 / split_b_pow2 (new trailing fields: fp32 operands as hi + lo half pairs),
- *    ppt_attention_fwd_split16 (new).
+ *    ppt_attention_fwd_split16 (new), ppt_pointmlp_cloud_rstd / ppt_pointmlp_pq (new).
  * 5: ppt_labels_check (new), ppt_gemm256 (new: the 256-row macro-tile GEMM core), ppt_set_gemm256 / ppt_get_gemm256 (new),
  *    ppt_layernorm_fwd_sum / ppt_layernorm_bwd_sum (new: split-K consumers), ppt_adamw_* (skipped == NULL: no guard).
  * 3: PPT_F16 (dtype arguments / struct fields), ppt_cross_entropy_rows (ignored labels, loss[2]), ppt_adamw_step (grad_scale),
@@ -462,6 +462,14 @@ int ppt_affine_conv_pool_bf16(const void *A, int64_t lda, int64_t M, int K, cons
  *   res_scale/res_shift (both or neither): res is a raw conv output, relu(res_scale*res + res_shift) is the block input. */
 int ppt_group_anchor_stats(const void *x, int x_dtype, const int64_t *idx, const int64_t *anchor, int B, int Nsrc, int S, int K,
                            int D, float *out, void *stream);
+/* PointMLP LocalGrouper, the rest of the "anchor" normalisation in two launches (ABI 6; pointMLP.py:170-175 and the transfer conv
+ * taken by linearity, engine.pointmlp_forward):
+ *   ppt_pointmlp_cloud_rstd: stats [B, S, 2] f32 (ppt_group_anchor_stats) -> r [B] = 1 / (unbiased std over n values + 1e-5), fp64 inside;
+ *   ppt_pointmlp_pq: PQ [B*N, 2C] f32, r [B], cidx [B, S] i64 (FPS indices), c0 [C] ->
+ *       P [B*N, C] = PQ[:, :C] * r[b];  Q [B*S, C] = (c0 + PQ[b*N + cidx, C:]) - P[b*N + cidx].  C % 4 == 0. */
+int ppt_pointmlp_cloud_rstd(const float *stats, int B, int S, double n, float *r, void *stream);
+int ppt_pointmlp_pq(const float *PQ, const float *r, const int64_t *cidx, const float *c0, float *P, float *Q, int B, int N, int S,
+                    int C, void *stream);
 int ppt_bn_res_act_rows(const void *x, int x_dtype, const void *res, int res_dtype, int64_t M, int C, int pool, const float *scale,
                         const float *shift, const float *res_scale, const float *res_shift, void *y, int y_dtype, void *stream);
 

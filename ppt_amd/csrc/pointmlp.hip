@@ -129,7 +129,94 @@ __global__ __launch_bounds__(256) void bn_res_act_rows_kernel(const void *__rest
     store_vec<VEC>(y, y_dtype, r * C + c, v);
 }
 
+// r[b] = 1 / (std_b + 1e-5), std_b the UNBIASED standard deviation over the n = S * k * d anchor-centred neighbour features of
+// cloud b (pointMLP.py:170-175), from the per-group (sum, sum of squares) of group_anchor_stats_kernel, in fp64 as the ATen
+// expression it replaces ([B,S,2].double().sum(1) -> var -> sqrt -> + eps -> reciprocal -> float: ~12 launches per stage).
+__global__ __launch_bounds__(256) void cloud_rstd_kernel(const float *__restrict__ st, int S, double n, float *__restrict__ r)
+{
+    __shared__ double sh[2][256];
+    const int b = blockIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < S; i += 256) {
+        const float2 v = *reinterpret_cast<const float2 *>(st + ((int64_t)b * S + i) * 2);
+        s += (double)v.x;
+        q += (double)v.y;
+    }
+    sh[0][threadIdx.x] = s;
+    sh[1][threadIdx.x] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double sum = sh[0][0], sq = sh[1][0];
+        double var = (sq - sum * sum / n) / (n - 1.0);
+        var = var < 0.0 ? 0.0 : var;
+        r[b] = (float)(1.0 / (sqrt(var) + 1e-5));
+    }
+}
+
+// The operands of the transfer conv by linearity (engine.pointmlp_forward): PQ [B*N, 2C] = [(Wa * alpha) . x | Wb . x] ->
+//   P[b, n, :] = PQ[b, n, :C] * r[b]                                        (the neighbour term, scaled by the cloud's 1 / std)
+//   Q[b, s, :] = (c0 + PQ[b, a, C:]) - P[b, a, :],  a = cidx[b, s]          (the anchor term)
+// -- the ATen expression's operations in its order, each rounded once (no contraction), in ONE launch instead of ~12.
+__global__ __launch_bounds__(256) void pointmlp_pq_kernel(const float *__restrict__ PQ, const float *__restrict__ r,
+                                                          const int64_t *__restrict__ cidx, const float *__restrict__ c0,
+                                                          float *__restrict__ P, float *__restrict__ Q, int B, int N, int S, int C)
+{
+    const int C4 = C >> 2;
+    const int64_t nP = (int64_t)B * N * C4, nQ = (int64_t)B * S * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nP + nQ; i += (int64_t)gridDim.x * 256) {
+        if (i < nP) {
+            const int64_t row = i / C4;
+            const int c = (int)(i % C4) * 4;
+            const float rb = r[row / N];
+            const float4 v = *reinterpret_cast<const float4 *>(PQ + row * 2 * C + c);
+            *reinterpret_cast<float4 *>(P + row * C + c) = make_float4(v.x * rb, v.y * rb, v.z * rb, v.w * rb);
+        } else {
+            const int64_t j = i - nP, qrow = j / C4;
+            const int c = (int)(j % C4) * 4;
+            const int b = (int)(qrow / S);
+            const int64_t a = (int64_t)b * N + cidx[qrow];
+            const float rb = r[b];
+            const float4 pa = *reinterpret_cast<const float4 *>(PQ + a * 2 * C + c);
+            const float4 qa = *reinterpret_cast<const float4 *>(PQ + a * 2 * C + C + c);
+            const float4 cc = *reinterpret_cast<const float4 *>(c0 + c);
+            // (the products are pinned in registers before the subtraction: -ffp-contract=fast would otherwise fold them into an
+            // fma and round once where the ATen expression rounds twice)
+            float p0 = pa.x * rb, p1 = pa.y * rb, p2 = pa.z * rb, p3 = pa.w * rb;
+            asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+            *reinterpret_cast<float4 *>(Q + qrow * C + c) =
+                make_float4((cc.x + qa.x) - p0, (cc.y + qa.y) - p1, (cc.z + qa.z) - p2, (cc.w + qa.w) - p3);
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int ppt_pointmlp_cloud_rstd(const float *stats, int B, int S, double n, float *r, void *stream)
+{
+    if (!stats || !r || B <= 0 || S <= 0 || !(n > 1.0)) return PPT_EINVAL;
+    hipLaunchKernelGGL(cloud_rstd_kernel, dim3(B), dim3(256), 0, ppt_stream(stream), stats, S, n, r);
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
+
+extern "C" int ppt_pointmlp_pq(const float *PQ, const float *r, const int64_t *cidx, const float *c0, float *P, float *Q, int B, int N,
+                               int S, int C, void *stream)
+{
+    if (!PQ || !r || !cidx || !c0 || !P || !Q || B <= 0 || N <= 0 || S <= 0 || C <= 0) return PPT_EINVAL;
+    if ((C % 4) || (((uintptr_t)PQ | (uintptr_t)c0 | (uintptr_t)P | (uintptr_t)Q) & 15)) return PPT_EUNSUPPORTED;
+    const int64_t n = ((int64_t)B * N + (int64_t)B * S) * (C / 4);
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pointmlp_pq_kernel, dim3(blocks), dim3(256), 0, ppt_stream(stream), PQ, r, cidx, c0, P, Q, B, N, S, C);
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
 
 extern "C" int ppt_group_anchor_stats(const void *x, int x_dtype, const int64_t *idx, const int64_t *anchor, int B, int Nsrc, int S,
                                       int K, int D, float *out, void *stream)

@@ -789,10 +789,14 @@ def pointmlp_forward(sd, p, wc, pc, fps_starts, train, drop_masks, update_runnin
             cidx, new_xyz = ops.fps(xyz, S, fps_starts[i])
             nidx, _ = ops.knn_group(xyz, new_xyz, k, want_idx=True, want_nbhd=False)
         # per-cloud std of the anchor-centred neighbour features (:174), unbiased, from per-group (sum, sumsq) in fp64
-        st = ops.group_anchor_stats(x, nidx, cidx, N).double().sum(1)
+        st = ops.group_anchor_stats(x, nidx, cidx, N)
         n = float(S * k * d)
-        var = ((st[:, 1] - st[:, 0] * st[:, 0] / n) / (n - 1.0)).clamp_min(0.0)
-        r = (1.0 / (var.sqrt() + 1e-5)).float()
+        if POINTMLP_FUSED_NORM:
+            r = ops.pointmlp_cloud_rstd(st, n)                                   # (one launch for the ~12 of the expression below)
+        else:
+            st = st.double().sum(1)
+            var = ((st[:, 1] - st[:, 0] * st[:, 0] / n) / (n - 1.0)).clamp_min(0.0)
+            r = (1.0 / (var.sqrt() + 1e-5)).float()
         pp = f"{p}pre_blocks_list.{i}."
         g = f"{p}local_grouper_list.{i}."
         wt, alpha, beta = sd[pp + "transfer.net.0.weight"], sd[g + "affine_alpha"], sd[g + "affine_beta"]
@@ -804,9 +808,12 @@ def pointmlp_forward(sd, p, wc, pc, fps_starts, train, drop_masks, update_runnin
             return ops.convert(torch.cat([wa, w2[:, d:]], 0).contiguous(), T), (w2[:, :d] @ beta.detach().reshape(d)).contiguous()
         wcat, c0 = wc.derived(("pointmlp_transfer", i), (wt, alpha, beta), fold)
         PQ = ops.gemm(x, wcat, out_dtype=torch.float32)                          # [B*N, 2C]: (Wa*alpha).x | Wb.x
-        P = (PQ[:, :C].reshape(B, N, C) * r.view(B, 1, 1)).reshape(B * N, C)
-        a = (torch.arange(B, device=dev).view(B, 1) * N + cidx).view(-1)
-        Q = (c0.view(1, C) + PQ[:, C:][a] - P[a]).contiguous()
+        if POINTMLP_FUSED_NORM and C % 4 == 0:
+            P, Q = ops.pointmlp_pq(PQ, r, cidx, c0, B, N)                        # (one launch, the same operations in the same order)
+        else:
+            P = (PQ[:, :C].reshape(B, N, C) * r.view(B, 1, 1)).reshape(B * N, C)
+            a = (torch.arange(B, device=dev).view(B, 1) * N + cidx).view(-1)
+            Q = (c0.view(1, C) + PQ[:, C:][a] - P[a]).contiguous()
         M = B * S * k
         # the transfer conv's output stays raw: its BN + ReLU (:246) is applied by the two readers of the first block
         y, part0 = ops.gather_add(P, Q, nidx, N, T, want_stats=train)
@@ -844,6 +851,9 @@ TEXT_FUSE_LN = os.environ.get("PPT_TEXT_FUSE_LN", "0") != "0"
 # partial products are summed by the LayerNorm kernel that consumes them (ops.gemm_splitk + ops.layernorm_fwd_sum / _bwd_sum).
 # 16-bit operand modes only: the fp32 parity mode keeps the single-launch summation order.
 TEXT_SPLITK = os.environ.get("PPT_TEXT_SPLITK", "1") != "0"
+# PointMLP's LocalGrouper normalisation as two launches per stage (csrc/pointmlp.hip: cloud_rstd_kernel, pointmlp_pq_kernel) instead of
+# ~25 ATen ones; PPT_POINTMLP_FUSED_NORM=0: the ATen expressions (A/B, bit-identity test).
+POINTMLP_FUSED_NORM = os.environ.get("PPT_POINTMLP_FUSED_NORM", "1") != "0"
 
 
 def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=None, prefix=0, rows_in=None):
@@ -911,7 +921,8 @@ def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=No
     # split-K for the K = 2048 linear (c_proj): with 817 rows it is 104 workgroups walking 32 K slabs each at ONE CU's L2 -> LDS rate
     # (~9 of its 12.6 us); as four K slices it is 416 workgroups of 8 slabs, and the four fp32 partial products are added up -- with
     # the residual and the bias -- by the LayerNorm that reads the result anyway (ops.layernorm_fwd_sum): no reduction launch.
-    splitk = TEXT_SPLITK and T in ops.HALF and Tm == T and not fuse and M <= 4096 and Wd == 512
+    # (16-bit modes and split16; the fp32 parity mode keeps the single-launch summation order)
+    splitk = TEXT_SPLITK and (T in ops.HALF or ops.split16_enabled()) and Tm == T and not fuse and M <= 4096 and Wd == 512
     pending = None                  # (x_mid, c_proj bias, partial products) of the previous layer: its output is formed by this layer's LN1
     for i in range(layers):
         p = f"transformer.resblocks.{i}."
@@ -1007,7 +1018,7 @@ def text_tower_backward(sd, wc, s, dout, grad_scale=1.0):
     g.index_copy_(0, s["rows"], d_eot)
     wca, wcm = s.get("wca", wc), s.get("wcm", wc)              # (per-half operand precision: diagnostics, see the forward)
     Ta, Tm = wca.dtype, wcm.dtype
-    splitk = TEXT_SPLITK and T in ops.HALF and Ta == T and Tm == T and M <= 4096 and Wd == 512
+    splitk = TEXT_SPLITK and (T in ops.HALF or ops.split16_enabled()) and Ta == T and Tm == T and M <= 4096 and Wd == 512
     g_t = ops.convert(g, Tm)
     for i in reversed(range(len(s["layers"]))):
         p = f"transformer.resblocks.{i}."

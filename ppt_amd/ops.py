@@ -933,6 +933,27 @@ def group_anchor_stats(x, idx, anchor, Nsrc):
     return out
 
 
+def pointmlp_cloud_rstd(stats, n):
+    """stats [B,S,2] f32 (group_anchor_stats) -> r [B] f32 = 1 / (unbiased std over the cloud's n values + 1e-5), fp64 inside
+    (pointMLP.py:174-175)."""
+    _chk(stats, torch.float32, "stats")
+    B, S, _ = stats.shape
+    r = torch.empty((B,), dtype=torch.float32, device=stats.device)
+    _lib.check(_lib.lib().ppt_pointmlp_cloud_rstd(_p(stats), B, S, float(n), _p(r), _stream()), "ppt_pointmlp_cloud_rstd")
+    return r
+
+
+def pointmlp_pq(PQ, r, cidx, c0, B, N):
+    """PQ [B*N, 2C] f32 -> (P [B*N, C] = PQ[:, :C] * r[b], Q [B*S, C] = (c0 + PQ[a, C:]) - P[a], a = b*N + cidx[b, s])."""
+    _chk(PQ, torch.float32, "PQ"); _chk(r, torch.float32, "r"); _chk(cidx, torch.int64, "cidx"); _chk(c0, torch.float32, "c0")
+    C = PQ.shape[1] // 2
+    S = cidx.shape[1]
+    P = torch.empty((B * N, C), dtype=torch.float32, device=PQ.device)
+    Q = torch.empty((B * S, C), dtype=torch.float32, device=PQ.device)
+    _lib.check(_lib.lib().ppt_pointmlp_pq(_p(PQ), _p(r), _p(cidx), _p(c0), _p(P), _p(Q), B, N, S, C, _stream()), "ppt_pointmlp_pq")
+    return P, Q
+
+
 def bn_res_act_rows(x, res, scale, shift, y_dtype, pool=1, res_affine=None):
     """relu(scale * x + shift + res') over rows [M,C]; pool > 1 returns the max over each `pool` consecutive rows.
     res' = res, or relu(rs * res + rh) with res_affine = (rs, rh)."""

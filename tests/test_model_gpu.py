@@ -777,6 +777,55 @@ def test_pointmlp_matches_golden(mode, precision, tol):
             assert (msd[k].cpu() - r).abs().max().item() < rtol * max(1.0, r.abs().max().item()), k
 
 
+@pytest.mark.parametrize("precision", [torch.float32, torch.bfloat16])
+def test_pointmlp_fused_normalisation_is_the_aten_expression(precision):
+    """ppt_pointmlp_cloud_rstd + ppt_pointmlp_pq (two launches per stage, csrc/pointmlp.hip) against the ~25 ATen launches they
+    replace (pointMLP.py:170-175 + the transfer conv's operands by linearity): P and Q are the same operations in the same order --
+    the same bits given the same r; r itself is an fp64 sum in another order, rounded to fp32 once -- equal or one ulp apart."""
+    from ppt_amd import engine
+    from ppt_amd.models.pointmlp.pointMLP import pointMLP
+    pc_np, s1 = W.synth_clouds(4, 1024, seed=61)
+    starts = [s1] + [W.synth_clouds(4, n, seed=64 + i)[1] for i, n in enumerate((512, 256, 128))]
+    sd = W.synth_state_dict(W.pointmlp_spec(prefix=""), seed=0)
+    outs = []
+    for fused in (False, True):
+        engine.POINTMLP_FUSED_NORM = fused
+        try:
+            m = pointMLP()
+            m.load_state_dict(sd)
+            m.cuda()
+            m.precision = precision
+            m.eval()
+            m.fps_start = tuple(torch.from_numpy(s).cuda() for s in starts)
+            outs.append(m(torch.from_numpy(pc_np).cuda()).float().cpu())
+        finally:
+            engine.POINTMLP_FUSED_NORM = True
+    d = (outs[0] - outs[1]).abs().max().item()
+    print(f"PARITY pointmlp fused normalisation vs ATen ({precision}): max abs diff {d:.3g} (|out| <= {outs[0].abs().max().item():.3g})")
+    # (bf16 operands: a one-ulp difference in r flips bf16 roundings downstream -- the golden test above bounds that mode)
+    assert d <= (2e-5 if precision == torch.float32 else 2e-2) * max(1.0, outs[0].abs().max().item())
+    # the kernels themselves, on the same r: bit for bit
+    from ppt_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, N, S, C = 3, 200, 50, 64
+    PQ = torch.randn(B * N, 2 * C, generator=g).cuda()
+    r = (torch.rand(B, generator=g) + 0.5).cuda()
+    cidx = torch.randint(0, N, (B, S), generator=g).cuda()
+    c0 = torch.randn(C, generator=g).cuda()
+    P, Q = ops.pointmlp_pq(PQ, r, cidx, c0, B, N)
+    Pw = (PQ[:, :C].reshape(B, N, C) * r.view(B, 1, 1)).reshape(B * N, C)
+    a = (torch.arange(B, device="cuda").view(B, 1) * N + cidx).view(-1)
+    Qw = (c0.view(1, C) + PQ[:, C:][a] - Pw[a]).contiguous()
+    assert torch.equal(P, Pw) and torch.equal(Q, Qw)
+    st = torch.rand(B, S, 2, generator=g).cuda() * torch.tensor([1.0, 40.0]).cuda()
+    n = float(S * 24 * 64)
+    rr = ops.pointmlp_cloud_rstd(st, n)
+    sd_ = st.double().sum(1)
+    var = ((sd_[:, 1] - sd_[:, 0] * sd_[:, 0] / n) / (n - 1.0)).clamp_min(0.0)
+    want = (1.0 / (var.sqrt() + 1e-5)).float()
+    assert ((rr - want).abs() <= 1.2e-7 * want.abs()).all()
+
+
 def test_pointmlp_elite_matches_oracle():
     """pointMLPElite() (pointMLP.py:366-370: res_expansion 0.25, uneven block counts) against the oracle on the same inputs."""
     from ppt_amd.models.pointmlp.pointMLP import pointMLPElite
