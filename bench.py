@@ -238,6 +238,7 @@ def host_feed(tensors, steps):
 
 
 FEED = os.environ.get("PPT_BENCH_FEED", "resident")
+BENCH_MODE = os.environ.get("PPT_BENCH_MODE", "mixed16")      # "split16": the step in the split16 precision mode (secondary legs)
 
 
 def secondary_runs():
@@ -258,7 +259,9 @@ def secondary_runs():
             ("C2_prefetch", ["--config", "C2"], feed), ("C3_prefetch", ["--config", "C3"], feed),
             ("C5_prefetch", ["--config", "C5"], feed), ("C2_eval_prefetch", ["--config", "C2", "--eval"], feed),
             ("C2_in_order", ["--config", "C2"], in_order), ("C3_in_order", ["--config", "C3"], in_order),
-            ("C5_in_order", ["--config", "C5"], in_order), ("C2_eval_in_order", ["--config", "C2", "--eval"], in_order)]
+            ("C5_in_order", ["--config", "C5"], in_order), ("C2_eval_in_order", ["--config", "C2", "--eval"], in_order),
+            # the split16 mode (fp32 storage, products from hi + lo half pairs: the fp32 mode's parity bounds) on the other configurations
+            ("C3_split16", ["--config", "C3"], {"PPT_BENCH_MODE": "split16"}), ("C5_split16", ["--config", "C5"], {"PPT_BENCH_MODE": "split16"})]
     for name, extra, env in runs:
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", "30", "--warmup", "5", "--no-roofline", "--no-parity-mode",
                "--no-cpu-baseline", "--no-secondary"] + extra
@@ -359,6 +362,8 @@ def main():
     global PER_GPU_BATCH, NPOINTS
     PER_GPU_BATCH, NPOINTS = cfg["batch"], cfg["npoints"]
     model = build_model(cfg["dataset"], cfg["head_type"], model=cfg.get("model", "ULIP_PointBERT"), task=cfg.get("task", "cls"))
+    if BENCH_MODE == "split16":        # (secondary legs: the fp32-grade mode on the 16-bit matrix pipe)
+        model.set_precision("split16")
     partseg = cfg.get("task") == "partseg"
     n_classes = len(model.prompt_learner.classnames)
     model.train()
@@ -491,7 +496,8 @@ def main():
                "warmup": a.warmup, "burn_in": BURN_IN_STEPS, "ms_per_step": round(1e3 * elapsed / a.steps, 3),
                "ms_per_step_median": round(median_ms, 3), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None,
-               "dtype": "f16" if set(operand_formats(cfg.get("model", "ULIP_PointBERT")).values()) <= {"f16", "f32"} else "f16/bf16",
+               "dtype": "f32 as hi+lo f16 pairs" if BENCH_MODE == "split16" else
+                        ("f16" if set(operand_formats(cfg.get("model", "ULIP_PointBERT")).values()) <= {"f16", "f32"} else "f16/bf16"),
                "data": "synthetic",
                "config": {"workload": cfg["name"] + ", train-mode BN + DropPath, fwd + CE(ls 0.2) + bwd + AdamW", "feed": FEED,
                           "operand_formats": formats_of(model, cfg.get("model", "ULIP_PointBERT")),
