@@ -587,7 +587,8 @@ int ppt_convert_scaled(const void *src, int src_dtype, void *dst, int dst_dtype,
  * transpose, every step: pointbert/pointnet2_utils.py:297-467 trains all of its convs).  Item i: A = w[:, col0 : col0 + K] (f32, row
  * stride ldw elements), minus w[:, sub_col0 : sub_col0 + K] when sub_col0 >= 0 (DGCNN_Propagation's Wb - Wa, see
  * ppt_amd/autograd.py); out [N, Kp] = convert(A) with columns K .. Kp - 1 zero (may be NULL); out_t [Kp, N] = its transpose (may be
- * NULL).  `items` is a HOST array (it travels as a kernel argument, PPT_WPREP_MAX items per launch); dtype = PPT_BF16 | PPT_F16. */
+ * NULL).  `items` is a HOST array (it travels as a kernel argument, PPT_WPREP_MAX items per launch); dtype = PPT_BF16 | PPT_F16 | PPT_F32
+ * (fp32 copies for the fp32 / split16 modes: ABI 6). */
 #define PPT_WPREP_MAX 32
 typedef struct ppt_wprep_item {
     const float *w; int64_t ldw;

@@ -367,6 +367,7 @@ def partseg_decoder_params(pe):
 
 
 DECODER_WPREP = os.environ.get("PPT_DECODER_WPREP", "1") != "0"          # 0: per-weight conversions (A/B runs)
+DECODER_WPREP_F32 = os.environ.get("PPT_DECODER_WPREP_F32", "1") != "0"  # the same single launch in the fp32 / split16 modes (copies: same bits)
 
 
 def decoder_weight_prep(pe):
@@ -376,7 +377,7 @@ def decoder_weight_prep(pe):
     transpose in the backward, and these weights all train, so nothing can be cached across steps.  Same values bit for bit.
     -> {key: (wT [N, Kp], wTT [Kp, N])}, keys (module, layer index) / (module, layer, 'a' | 'd'); None in the fp32 mode."""
     prec = pe._dec_precision
-    if prec not in ops.HALF or not DECODER_WPREP:
+    if not DECODER_WPREP or not (prec in ops.HALF or (prec == torch.float32 and DECODER_WPREP_F32)):
         return None
     mult = _mult(prec)
     keys, items = [], []

@@ -361,7 +361,7 @@ extern "C" int ppt_cls_max_pool(const void *x, int x_dtype, int B, int T, int D,
 
 extern "C" int ppt_weights_prep(const ppt_wprep_item *items, int count, int dtype, void *stream)
 {
-    if (!items || count <= 0 || (dtype != PPT_BF16 && dtype != PPT_F16)) return PPT_EINVAL;
+    if (!items || count <= 0 || (dtype != PPT_BF16 && dtype != PPT_F16 && dtype != PPT_F32)) return PPT_EINVAL;
     for (int c0 = 0; c0 < count; c0 += PPT_WPREP_MAX) {
         wprep_table tb;
         tb.count = count - c0 < PPT_WPREP_MAX ? count - c0 : PPT_WPREP_MAX;
@@ -379,6 +379,7 @@ extern "C" int ppt_weights_prep(const ppt_wprep_item *items, int count, int dtyp
         }
         tb.first_block[tb.count] = (int)blocks;
         if (dtype == PPT_F16) hipLaunchKernelGGL(weights_prep_kernel<f16_t>, dim3((unsigned)blocks), dim3(256), 0, ppt_stream(stream), tb);
+        else if (dtype == PPT_F32) hipLaunchKernelGGL(weights_prep_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, ppt_stream(stream), tb);   // (fp32 / split16 modes)
         else hipLaunchKernelGGL(weights_prep_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, ppt_stream(stream), tb);
         PPT_CHECK_LAUNCH();
     }

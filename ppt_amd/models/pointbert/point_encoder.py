@@ -345,7 +345,10 @@ class PointTransformer(nn.Module):
     def _cache(self):
         if self._wc is None or self._wc.dtype != self.precision:
             self._wc = engine.WeightCache(self.precision, self.__dict__.setdefault("demoted", set()))
-        ops.set_split16(self.__dict__.get("split16", False))       # (ULIP_WITH_IMAGE.set_precision("split16"))
+        if self.precision == torch.float32:
+            # (ULIP_WITH_IMAGE.set_precision("split16").  A 16-bit tower has no fp32 GEMM of its own and leaves the switch to the
+            # owner's text tower: a mixed-mode model whose text tower runs split16 then sees ONE value in forward and backward)
+            ops.set_split16(self.__dict__.get("split16", False))
         return self._wc
 
     def _live_state(self):

@@ -149,7 +149,8 @@ class Model(nn.Module):
         cfg = self._cfg
         if self._wc is None or self._wc.dtype != self.precision:
             self._wc = engine.WeightCache(self.precision)
-        ops.set_split16(self.__dict__.get("split16", False))
+        if self.precision == torch.float32:
+            ops.set_split16(self.__dict__.get("split16", False))
         n_src, s = [N], cfg["points"]                                    # points FPS draws its start from, per stage
         for r in cfg["reducers"][:-1]:
             s //= r

@@ -1007,7 +1007,7 @@ def weights_prep(items, dtype):
     """items: list of (w f32 [N, ld] contiguous 2-D view, col0, K, sub_col0 | None, Kp) -> list of (out [N, Kp], out_t [Kp, N]) in
     `dtype`: convert(w[:, col0:col0+K] (- w[:, sub_col0:sub_col0+K])), zero-padded to Kp columns, and its transpose -- ONE launch for
     all items (ppt_weights_prep)."""
-    assert dtype in HALF
+    assert dtype in HALF or dtype == torch.float32
     arr = (_lib.WprepItem * len(items))()
     outs = []
     for a, (w, col0, K, sub, Kp) in zip(arr, items):
