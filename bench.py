@@ -286,6 +286,8 @@ def main_eval(a):
     graphs.shared_group_stream()
     cfg = CONFIGS[a.config]
     model = build_model(cfg["dataset"], cfg["head_type"], model=cfg.get("model", "ULIP_PointBERT"), task=cfg.get("task", "cls"))
+    if BENCH_MODE == "split16":
+        model.set_precision("split16")
     model.eval()
     # the synthetic batch is resident and complete before every call: the next batch's grouping / tokenizer stage may start
     # when forward() is called (ULIP_WITH_IMAGE.eval_inputs_ready; PPT_EVAL_AHEAD=0 for the in-order forward)

@@ -154,7 +154,8 @@ typedef struct ppt_gemm_params {
      * operand (an absolute floor of 2^-25 after scaling, inf above 65 504) at ~3-5x the fp32 MFMA's rate.  Operand values are
      * multiplied by 2^split_a_pow2 / 2^split_b_pow2 before the split (|.| <= 24) and the product by the inverse before the
      * epilogue, so the caller places each operand's magnitudes in half's range; everything else (A prologues, epilogues,
-     * outputs) is the fp32 path's. */
+     * outputs) is the fp32 path's.  Large plain problems run on 256 x 128 tiles (csrc/gemm256.hip: gemm256s_kernel), the rest on
+     * the register-staged 128 x 128 / 64 x 64 loops -- the same bits either way; split16 == 2 keeps a launch on the loops (A/B). */
     int split16, split_a_pow2, split_b_pow2;
 } ppt_gemm_params;
 

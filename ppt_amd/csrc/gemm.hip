@@ -495,6 +495,7 @@ int launch_gemm(const ppt_gemm_params &p, hipStream_t s)
         // split16: the register-staged kernel only (the split sits between its registers and LDS); 128 x 128 tiles (24 MFMAs per
         // 32 values a thread splits) as soon as they fill the chip, 64 x 64 (6 per 16) below
         static const int split_small_below = [] { const char *e = getenv("PPT_SPLIT16_SMALL_BELOW"); return e ? atoi(e) : 512; }();
+        // (measured and not kept: 128 x 64 tiles for narrow N over many rows -- fc2 of a C2 batch 115.7 vs 116.6 us)
         if (!need128 && tiles128 < split_small_below) return launch_gemm_tile<T, 64, 64, true>(p, s);
         return launch_gemm_tile<T, 128, 128, true>(p, s);
     }
@@ -526,6 +527,7 @@ int launch_gemm(const ppt_gemm_params &p, hipStream_t s)
 }  // namespace
 
 extern "C" int ppt_gemm256_dispatch(const ppt_gemm_params *pp, int force, void *stream);      // gemm256.hip
+extern "C" int ppt_gemm256_split_dispatch(const ppt_gemm_params *pp, void *stream);
 
 extern "C" int ppt_gemm(const ppt_gemm_params *pp, void *stream)
 {
@@ -564,6 +566,9 @@ extern "C" int ppt_gemm(const ppt_gemm_params *pp, void *stream)
         return PPT_EUNSUPPORTED;
     if (ppt_gemm256_dispatch(&p, 0, stream) == PPT_OK) return PPT_OK;     // the 256-row macro-tile core takes the big plain problems
     hipStream_t s = ppt_stream(stream);
-    if (p.dtype == PPT_F32 && p.split16) return launch_gemm<float, true>(p, s);   // hi + lo half products (gemm_common.h, split16)
+    if (p.dtype == PPT_F32 && p.split16) {                                        // hi + lo half products (gemm_common.h, split16)
+        if (ppt_gemm256_split_dispatch(&p, stream) == PPT_OK) return PPT_OK;     // large plain problems: the 256 x 128 tile
+        return launch_gemm<float, true>(p, s);
+    }
     return p.dtype == PPT_BF16 ? launch_gemm<bf16_t>(p, s) : p.dtype == PPT_F16 ? launch_gemm<f16_t>(p, s) : launch_gemm<float>(p, s);
 }

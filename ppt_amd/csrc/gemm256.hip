@@ -453,7 +453,151 @@ int launch256(const ppt_gemm_params &p, int bn, hipStream_t s)
     return PPT_OK;
 }
 
+// ---- split16 on the 256 x 128 tile (fp32 operands as hi + lo half pairs: gemm_common.h) -----------------------------------------
+// The split16 products are bound by the L2 -> CU fill -- fp32 operands are twice half's bytes and a CU pulls 21-25 B/clk whatever
+// the tile (tools/split16_bench.py: 64 x 64 and 128 x 64 tiles tie at 116 us on fc2 of a C2 batch) -- so what a tile computes per
+// byte it loads is its speed: 16 FLOP/B at 64 x 64, 32 at 128 x 128, 43 at 256 x 128.  This is gemm.hip's register-staged split
+// loop (global -> registers, three slabs deep -> split -> hi / lo LDS images -> 16-bit fragments) on this file's 512-thread frame:
+// waves 4 x 2, wave tile 64 x 64, two 48 KiB LDS buffers, the grouped tile order, the 32-row fp32 LDS-walk epilogue.  Same K
+// order, same split, same epilogue arithmetic as the 64 x 64 / 128 x 128 split kernels: the same bits.
+template <int NR>
+__device__ __forceinline__ void load_rows512(Stage<NR> &st, const float *base, int64_t ld, int rows, int r0, int k0)
+{
+    const int t = threadIdx.x, ch = t & 7;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int r = r0 + (t >> 3) + 64 * i;               // (rows beyond the matrix read its last row: their products are never stored)
+        st.v[i] = *reinterpret_cast<const uint4 *>(base + (int64_t)min(r, rows - 1) * ld + k0 + ch * 4);
+    }
+}
+
+template <int BM, int BN, int TI, int TJ>
+__device__ __forceinline__ void split256_loop(const ppt_gemm_params &p, const float *A, const float *B, int m0, int n0, unsigned char *smem,
+                                              int arow0, int brow0, int lane, f32x16_t (&acc)[TI][TJ], float sa, float sb)
+{
+    constexpr int NRA = BM / 64, NRB = BN / 64, A_BYTES = BM * 128, B_BYTES = BN * 128, BUF = A_BYTES + B_BYTES;
+    const int nslab = p.K / 32, last = nslab - 1;
+    Stage<NRA> a0, a1, a2;
+    Stage<NRB> b0, b1, b2;
+#define S256_LOAD(SA, SB, S)                                            \
+    do {                                                                \
+        load_rows512<NRA>(SA, A, p.lda, p.M, m0, (S) * 32);             \
+        load_rows512<NRB>(SB, B, p.ldb, p.N, n0, (S) * 32);             \
+    } while (0)
+#define S256_WRITE(SA, SB, BUFI)                                                                    \
+    do {                                                                                            \
+        write_stage_split<NRA, BM, 64>(SA, smem + ((BUFI) & 1) * BUF, sa);                          \
+        write_stage_split<NRB, BN, 64>(SB, smem + ((BUFI) & 1) * BUF + A_BYTES, sb);                \
+    } while (0)
+#define S256_X(S) mma_slab_split<TI, TJ, BM, BN>(smem + ((S) & 1) * BUF, smem + ((S) & 1) * BUF + A_BYTES, arow0, brow0, lane, acc)
+    // STEP(s): multiply slab s out of LDS (X); the FREE register set (it held slab s) receives slab s + 3; the NEXT set (slab s + 1)
+    // is split into the other LDS buffer; one barrier per slab.  Loads and writes are unconditional (slab index clamped): the
+    // compiler's counted vmcnt keeps two slabs in flight.
+    // (Measured and not kept: the two wave groups STAGGERED -- waves 0-3 X | barrier | split + write | barrier, waves 4-7 the two
+    // halves in the other order, so that each SIMD's matrix pipe and vector ALU work at the same time: fc2 of a C2 batch 78 -> 82 us,
+    // 4096^3 405 -> 434 us as two straight-line loops; 135 us with the branch inside the loop, where the compiler drains the global
+    // loads.  What the loop waits for is the operand bytes -- ~16 B/clk/CU through global_load_dwordx4 -- not its own pipes.)
+#define S256_STEP(S, FA, FB, NA, NB)                                    \
+    {                                                                   \
+        S256_LOAD(FA, FB, min((S) + 3, last));                          \
+        S256_X(S);                                                      \
+        S256_WRITE(NA, NB, (S) + 1);                                    \
+        __syncthreads();                                                \
+    }
+    S256_LOAD(a0, b0, 0);
+    S256_LOAD(a1, b1, min(1, last));
+    S256_LOAD(a2, b2, min(2, last));
+    S256_WRITE(a0, b0, 0);
+    __syncthreads();
+    for (int s = 0;; s += 3) {
+        S256_STEP(s, a0, b0, a1, b1)
+        if (s + 1 >= nslab) break;
+        S256_STEP(s + 1, a1, b1, a2, b2)
+        if (s + 2 >= nslab) break;
+        S256_STEP(s + 2, a2, b2, a0, b0)
+        if (s + 3 >= nslab) break;
+    }
+#undef S256_STEP
+#undef S256_X
+#undef S256_WRITE
+#undef S256_LOAD
+}
+
+template <int BN>
+__global__ __launch_bounds__(NT2, 2) void gemm256s_kernel(const ppt_gemm_params p)
+{
+    constexpr int BM = 256, WGN = 2, WM = 64, WN = 64, TI = 2, TJ = 2;
+    static_assert(BN == 128, "wave grid 4 x 2 of 64 x 64 tiles");
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, BUF = A_BYTES + B_BYTES;      // hi + lo images: the fp32 image's bytes
+    constexpr int PR = 32, PARK32 = 8 * PR * 64 * 4;
+    __shared__ __align__(16) unsigned char smem[2 * BUF > PARK32 ? 2 * BUF : PARK32];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    PPT_PRIO(p.wave_prio);
+    const int wm = w / WGN, wn = w % WGN;
+    const int nwg = gridDim.x * gridDim.y;
+    const int lin0 = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q8 = nwg / 8, r8 = nwg % 8, xcd = lin0 % 8;                   // XCD-aware remap + grouped tile order (gemm256_kernel)
+    const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + lin0 / 8;
+    int tm, tn;
+    {
+        constexpr int GM = 4;
+        const int ncol = gridDim.x, nrow = gridDim.y;
+        const int grp = lin / (GM * ncol), first = grp * GM;
+        const int rows_here = min(GM, nrow - first);
+        const int t = lin - grp * GM * ncol;
+        tm = first + t % rows_here;
+        tn = t / rows_here;
+    }
+    const int n0 = tn * BN, m0 = tm * BM;
+    const float *A = reinterpret_cast<const float *>(p.A) + (int64_t)blockIdx.z * p.strideA;
+    const float *B = reinterpret_cast<const float *>(p.B) + (int64_t)blockIdx.z * p.strideB;
+    const float sa = pow2f(p.split_a_pow2), sb = pow2f(p.split_b_pow2);
+
+    f32x16_t acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    split256_loop<BM, BN, TI, TJ>(p, A, B, m0, n0, smem, wm * WM, wn * WN, lane, acc, sa, sb);
+    scale_acc<TI, TJ>(acc, pow2f(-(p.split_a_pow2 + p.split_b_pow2)));
+
+    const int64_t zc = (int64_t)blockIdx.z * p.strideC;
+    const int mw = m0 + wm * WM, nw = n0 + wn * WN;
+    float *ct = reinterpret_cast<float *>(smem) + w * (PR * 64);
+    park_walk<0, PR, TI, TJ>(p, acc, ct, lane, mw, nw, zc);
+    park_walk<1, PR, TI, TJ>(p, acc, ct, lane, mw, nw, zc);
+}
+
 }  // namespace
+
+// split16 (ppt_gemm_params.split16, fp32 operands): the 256 x 128 tile when the problem is large and plain enough for it.
+// PPT_OK when launched, PPT_EUNSUPPORTED when gemm.hip's 128 x 128 / 64 x 64 split kernels should take it.
+extern "C" int ppt_gemm256_split_dispatch(const ppt_gemm_params *pp, void *stream)
+{
+    const ppt_gemm_params &p = *pp;
+    static const int enabled = env_int("PPT_SPLIT16_256", 1);
+    static const int min_tiles = env_int("PPT_SPLIT16_256_MIN_TILES", 128);
+    if (!enabled || p.dtype != PPT_F32 || !p.split16 || p.split16 == 2) return PPT_EUNSUPPORTED;      // (2: the caller asks for the tile loops)
+    if (p.a_mode != PPT_A_PLAIN || !p.A || (p.K % 32) != 0 || p.K < 96) return PPT_EUNSUPPORTED;
+    if (p.pool_max || p.col_sum || p.group_add) return PPT_EUNSUPPORTED;     // (the LDS-walk epilogue: no statistics, no pools)
+    bool ok = (p.N % 8) == 0;
+    if (p.C) ok = ok && (p.ldc % 8) == 0 && al16(p.C);
+    if (p.C2) ok = ok && (p.ldc2 % 8) == 0 && al16(p.C2);
+    if (p.bias) ok = ok && al16(p.bias);
+    if (p.dact_pre) ok = ok && (p.ld_dact % 8) == 0 && al16(p.dact_pre);
+    if (p.residual) ok = ok && (p.ld_res % 8) == 0 && al16(p.residual);
+    if (p.residual2) ok = ok && (p.ld_res2 % 8) == 0 && al16(p.residual2);
+    if (p.batch > 1 && ((p.strideC % 8) != 0)) ok = false;
+    if (!ok) return PPT_EUNSUPPORTED;
+    dim3 grid((p.N + 127) / 128, (p.M + 255) / 256, p.batch > 0 ? p.batch : 1);
+    if ((int64_t)grid.x * grid.y * grid.z < min_tiles || grid.y > 65535 || grid.z > 65535) return PPT_EUNSUPPORTED;
+    hipLaunchKernelGGL((gemm256s_kernel<128>), grid, dim3(NT2), 0, ppt_stream(stream), p);
+    PPT_CHECK_LAUNCH();
+    return PPT_OK;
+}
 
 // The host side of the choice.  force: 0 = ppt_gemm's automatic dispatch (size gates), 1 = explicit call (only the hard limits).
 // Returns PPT_OK when launched, PPT_EUNSUPPORTED when this core does not take the problem.

@@ -304,13 +304,13 @@ typedef _Float16 ppt_h2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int lds_off_s(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
 __device__ __forceinline__ float pow2f(int e) { return __uint_as_float((uint32_t)(127 + e) << 23); }
 
-template <int NR, int ROWS>
+template <int NR, int ROWS, int STRIDE = 32>                 // STRIDE = threads / 8: rows one pass of the workgroup covers
 __device__ __forceinline__ void write_stage_split(const Stage<NR> &st, unsigned char *tile, float s)
 {
     const int t = threadIdx.x, ch = t & 7;
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-        const int row = (t >> 3) + 32 * i;
+        const int row = (t >> 3) + STRIDE * i;
         const float x[4] = {__uint_as_float(st.v[i].x) * s, __uint_as_float(st.v[i].y) * s, __uint_as_float(st.v[i].z) * s,
                             __uint_as_float(st.v[i].w) * s};
         uint32_t H[2], L[2];

@@ -260,7 +260,7 @@ def gemm(A, B, *, out=None, out_dtype=None, M=None, bias=None, act=ACT_NONE, dac
     if split is None:
         split = _SPLIT16
     if split and p.dtype == PPT_F32:
-        p.split16 = 1
+        p.split16 = 2 if core == "tiles" else 1          # ("tiles": keep the launch off the 256 x 128 split kernel -- A/B, tests)
         p.split_a_pow2, p.split_b_pow2 = split if isinstance(split, tuple) else SPLIT16_POW2
     if profiler is not None:
         kk = K if algo_k is None else algo_k

@@ -1515,6 +1515,8 @@ def test_dataset_fps_is_bit_exact(tag, N, M, dup, cols):
     (817, 1536, 512, "plain"),           # the prompt chain's in_proj (64 x 64 tiles)
     (817, 512, 2048, "residual"),        # c_proj: bias + fp32 residual
     (16416, 1536, 384, "gelu"),          # fc1 of a C2 batch (128 x 128 tiles), ragged M
+    (16416, 384, 1536, "residual"),      # fc2: narrow N over many rows -- 195 tiles of 256 x 128
+    (32768, 512, 96, "plain"),           # short K (3 slabs) on the 256 x 128 tile
     (1000, 200, 36, "plain"),            # ragged everything, K not a multiple of the 32-float slab
     (9000, 640, 64, "dact"),             # derivative epilogue + second (pre-activation) output
     (16384, 512, 256, "stats"),          # per-group term + BatchNorm chunk statistics + the 32-row max pool
@@ -1584,6 +1586,10 @@ def test_gemm_split16_is_fp32_grade(ops, M, N, K, kind):
     s16, s16_x = launch(True)
     again, _ = launch(True)
     assert torch.equal(s16, again), "not reproducible"
+    if kind in ("plain", "residual", "gelu", "dact"):
+        # the 256 x 128 tile (large plain problems) and the 128 x 128 / 64 x 64 loops walk K and split alike: the same bits
+        tiles = ops.gemm(A, Bm, out_dtype=torch.float32, split=True, core="tiles", **kw)
+        assert torch.equal(s16, tiles)
     if kind == "batched":
         ref = ref[:3 * (M // 3)]
     scale = ref.abs().max().item()

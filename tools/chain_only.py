@@ -12,6 +12,8 @@ torch.cuda.set_device(0)
 cfg = bench.CONFIGS["C2"]
 graphs.shared_text_stream(priority=-1)
 model = bench.build_model(cfg["dataset"], cfg["head_type"], torch.bfloat16, "ULIP_PointBERT", "cls")
+if os.environ.get("PPT_BENCH_MODE") == "split16":
+    model.set_precision("split16")
 model.train()
 tr = Trainer(model, lr=3e-3, label_smoothing=0.2, distributed=False)
 B, N = cfg["batch"], cfg["npoints"]
@@ -24,3 +26,10 @@ for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
     tr.step(pc, label)
 tr.finish()
 torch.cuda.synchronize()
+import time
+t0 = time.perf_counter()
+for _ in range(20):
+    tr.step(pc, label)
+tr.finish()
+torch.cuda.synchronize()
+print(f"chain alone: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms per iteration")

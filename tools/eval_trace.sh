@@ -1,0 +1,5 @@
+# gpurun -- 'bash tools/eval_trace.sh C2 [lines]': per-kernel table of validate()'s forward (bench.py --eval) in the mode PPT_BENCH_MODE says
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/et
+rocprofv3 --kernel-trace --output-format csv -d /tmp/et -o p -- python3 $GRAFT_REPO_ROOT/bench.py --config $1 --eval --steps 20 --warmup 5 > /tmp/et.log 2>&1
+python3 $GRAFT_REPO_ROOT/tools/chain_kernels.py /tmp/et 65 2>&1 | head -${2:-16} | cut -c1-140
