@@ -62,3 +62,10 @@ def test_arg_validation_without_gpu():
     assert L.ppt_gemm(ctypes.byref(p), None) == -1
     assert L.ppt_rowgemm_bf16(None, None) == -1
     assert L.ppt_rowgemm_bf16(ctypes.byref(_lib.RowGemmParams()), None) == -1
+
+
+def test_graft_entry_build_passes():
+    """__graft_entry__.build() -- what the driver runs as the "does it build" check: every translation unit compiles (or is
+    reused by content hash), the oracle's C restatement builds, and the library's ABI number is the header's."""
+    import __graft_entry__ as G
+    G.build()
