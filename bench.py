@@ -94,7 +94,7 @@ def kernel_table(by_kernel, overhead_ms, steps):
     return rows
 
 
-def parity_mode_rate(cfg, pc, label, extra, steps, burn_in=6, mode="fp32"):
+def parity_mode_rate(cfg, pc, label, extra, steps, burn_in=6, mode="fp32", like=None):
     """clouds/s of the SAME step with set_precision("fp32") -- fp32 operands on the fp32 MFMA / fp32 VALU attention -- or
     set_precision("split16") -- the same fp32 storage with every GEMM and the attention forward formed from hi + lo half pairs on
     the 16-bit matrix pipe: the two modes whose results meet the fp32-level tolerances of tests/test_model_gpu.py."""
@@ -106,6 +106,8 @@ def parity_mode_rate(cfg, pc, label, extra, steps, burn_in=6, mode="fp32"):
     m.train()
     tr = Trainer(m, lr=3e-3, label_smoothing=0.2, distributed=False)
     tr.extra_inputs = extra
+    if like is not None:               # the same promises the headline's trainer runs with (resident batch: the input stages run ahead)
+        tr.inputs_ready, tr.group_ahead_when_frozen = like.inputs_ready, like.group_ahead_when_frozen
     for _ in range(burn_in):
         tr.step(pc, label)
     tr.finish()
@@ -507,8 +509,8 @@ def main():
                           "classes": n_classes, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
                "roofline": roof}
         if world == 1 and not force_dist and not a.no_parity_mode:
-            out["parity_mode"] = parity_mode_rate(cfg, pc, label, trainer.extra_inputs, max(3, a.steps // 2))
-            out["split16_mode"] = parity_mode_rate(cfg, pc, label, trainer.extra_inputs, max(3, a.steps // 2), mode="split16")
+            out["parity_mode"] = parity_mode_rate(cfg, pc, label, trainer.extra_inputs, max(3, a.steps // 2), like=trainer)
+            out["split16_mode"] = parity_mode_rate(cfg, pc, label, trainer.extra_inputs, max(3, a.steps // 2), mode="split16", like=trainer)
             if a.config == "C2":
                 out["parity"] = measured_parity()
         if world == 1 and not a.no_cpu_baseline:

@@ -22,6 +22,11 @@ pc = torch.from_numpy(W.synth_clouds(B, N, seed=1234)[0]).cuda()
 label = torch.from_numpy(np.random.default_rng(0).integers(0, len(m.prompt_learner.classnames), size=(B, N) if partseg else (B,))).cuda()
 extra = (torch.nn.functional.one_hot(torch.arange(B) % 16, 16).float().cuda(),) if partseg else None
 tr = Trainer(m, lr=3e-3, label_smoothing=0.2, distributed=False)
+if os.environ.get('PPT_MODE_STEPS_VOUCH', '1') != '0':      # the resident batch is complete: input-only stages run ahead (as bench.py)
+    from ppt_amd import graphs
+    graphs.shared_group_stream()
+    tr.inputs_ready = True
+    tr.group_ahead_when_frozen = True
 if extra is not None:
     tr.extra_inputs = extra
 for _ in range(6):
