@@ -685,6 +685,8 @@ class ULIP_WITH_IMAGE(nn.Module):
         for m in self.modules():
             if m is not self and (hasattr(m, "_cache") or hasattr(m, "_wc")):
                 m.split16 = split16
+        if split16:
+            self._fit_split16_range()
         self.point_encoder.precision = dtype
         self.point_encoder._wc = None
         self._text_calibrated = False
@@ -700,6 +702,25 @@ class ULIP_WITH_IMAGE(nn.Module):
             if type(m).__name__ in ("Mlp", "Attention", "Block", "ResidualAttentionBlock"):
                 m.precision = dtype
         return self
+
+    def _fit_split16_range(self):
+        """split16 multiplies every weight by 2^b (ops.SPLIT16_POW2, default b = 4) before splitting it into hi + lo halves, and
+        half overflows at 65 504: with weights (or BatchNorm-folded weights) beyond ~2 000 the products would be inf.  Checked once
+        per set_precision("split16") on the matrices this model holds: b is lowered (process-wide, with a warning) until
+        4 x max|w| x 2^b stays below half's range -- the factor 4 is room for the BatchNorm folds (w x gamma / sigma)."""
+        mats = [q.detach() for q in self.parameters() if q.dim() >= 2 and q.is_floating_point()]
+        if not mats:
+            return
+        mx = max(float(q.abs().max()) for q in mats)
+        a, b = ops.SPLIT16_POW2
+        b_fit = b
+        while b_fit > -8 and 4.0 * mx * 2.0 ** b_fit >= 32768.0:
+            b_fit -= 1
+        if b_fit != b:
+            import warnings
+            warnings.warn(f"split16: max |weight| = {mx:.4g}; the weight operand's pre-scale is lowered from 2^{b} to 2^{b_fit} "
+                          f"(ops.SPLIT16_POW2) to keep the hi halves inside IEEE half's range")
+            ops.SPLIT16_POW2 = (a, b_fit)
 
     def _cache(self):
         # The text tower's operand format in the performance mode is IEEE half, not bf16 (PPT_TEXT_F16=0: bf16): same MFMA rate,
@@ -882,8 +903,11 @@ class ULIP_WITH_IMAGE(nn.Module):
             import warnings
             self.text_precision = torch.float32
             self._graphs.clear()
+            if self.text_split16:
+                self._fit_split16_range()
             warnings.warn(f"ppt_amd: on these weights the CLIP text tower on IEEE-half operands differs from fp32 by {rel:.3g} "
                           f"(relative L2 of the normalised text features; threshold {thr:g}): the text tower runs on fp32 operands "
+                          + ("multiplied as hi + lo half pairs (split16) " if self.text_split16 else "") +
                           "from here on (slower prompt chain, reference-grade text features and token gradients).  "
                           "PPT_TEXT_CALIBRATE=0 keeps half.", RuntimeWarning, stacklevel=3)
         return self.text_calibration

@@ -399,3 +399,33 @@ def test_set_precision_names():
         m.set_precision("bf16")
     with pytest.raises(ValueError):
         m.set_precision(torch.int8)
+
+
+def test_split16_range_fit_lowers_the_weight_prescale_for_huge_weights():
+    """set_precision("split16") checks once that 4 x max|w| x 2^b fits IEEE half (the hi halves of the split weights) and lowers b
+    with a warning otherwise (ULIP_WITH_IMAGE._fit_split16_range)."""
+    import warnings
+    from types import SimpleNamespace
+    import torch
+    from ppt_amd import ops
+    from ppt_amd.models import ULIP_models as M
+    args = SimpleNamespace(classnames=M.dataset_classnames("modelnet40"), template_init='', class_name_position='middle',
+                           num_learnable_prompt_tokens=32, gpu=0, task='cls', head_type=0, evaluate_3d=False, ulip2=False,
+                           synthetic_weights=True)
+    m = M.ULIP_PointBERT(args)
+    old = ops.SPLIT16_POW2
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            m._fit_split16_range()                       # freshly initialised weights: nothing to do, no warning
+        assert ops.SPLIT16_POW2 == old
+        with torch.no_grad():
+            m.text_projection[0, 0] = 3000.0
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            m._fit_split16_range()
+        assert any("split16" in str(x.message) for x in w)
+        b = ops.SPLIT16_POW2[1]
+        assert b < old[1] and 4.0 * 3000.0 * 2.0 ** b < 32768.0 <= 4.0 * 3000.0 * 2.0 ** (b + 1)
+    finally:
+        ops.SPLIT16_POW2 = old
