@@ -249,6 +249,85 @@ __global__ __launch_bounds__(256) void ln_bwd_dx8_kernel(const float *__restrict
     }
 }
 
+// The backward WITH weight / bias gradients (trainable LayerNorms: the un-frozen last PointBERT block, point_encoder.py:70-79) in
+// the 16-byte form: wave g walks rows [g * rpw, (g + 1) * rpw), a lane owns EIGHT consecutive columns (two float4 per tensor and
+// row), the NEXT row's dy / xs / dx are requested before this row's two wave reductions (ln_bwd_kernel: one 4-byte element per
+// lane and load, three dependent round trips per row -- 92 us for 32 832 x 384 at C3, 0.55 TB/s), and dw / db accumulate per
+// column in the lane's registers in row order -- the partial rows ln_bwd_kernel writes, bit for bit; dx sums its two row
+// statistics in ln_bwd_dx8_kernel's order.
+__global__ __launch_bounds__(256) void ln_bwd_w8_kernel(const float *__restrict__ dy, const float *__restrict__ xs,
+                                                        const float *__restrict__ w, const float *__restrict__ mean,
+                                                        const float *__restrict__ rstd, float *__restrict__ dx, int accumulate,
+                                                        void *__restrict__ dx_copy, int copy_dtype, float *__restrict__ dw_part,
+                                                        float *__restrict__ db_part, int rpw, int M, int D, int prio)
+{
+    PPT_PRIO(prio);
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int r0 = g * rpw, r1 = min(M, r0 + rpw);
+    if (r0 >= M) return;
+    const bool act = lane * 8 < D;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 w0 = z4, w1 = z4;
+    if (act) { w0 = *reinterpret_cast<const float4 *>(w + lane * 8); w1 = *reinterpret_cast<const float4 *>(w + lane * 8 + 4); }
+    const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    float dwa[8], dba[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { dwa[j] = 0.f; dba[j] = 0.f; }
+    float4 d0 = z4, d1 = z4, x0 = z4, x1 = z4, a0 = z4, a1 = z4;
+    auto fetch = [&](int row, float4 &D0, float4 &D1, float4 &X0, float4 &X1, float4 &A0, float4 &A1) {
+        if (act) {
+            const size_t off = (size_t)row * D + lane * 8;
+            D0 = *reinterpret_cast<const float4 *>(dy + off); D1 = *reinterpret_cast<const float4 *>(dy + off + 4);
+            X0 = *reinterpret_cast<const float4 *>(xs + off); X1 = *reinterpret_cast<const float4 *>(xs + off + 4);
+            if (accumulate) { A0 = *reinterpret_cast<const float4 *>(dx + off); A1 = *reinterpret_cast<const float4 *>(dx + off + 4); }
+        }
+    };
+    fetch(r0, d0, d1, x0, x1, a0, a1);
+    for (int row = r0; row < r1; ++row) {
+        float4 nd0 = z4, nd1 = z4, nx0 = z4, nx1 = z4, na0 = z4, na1 = z4;
+        if (row + 1 < r1) fetch(row + 1, nd0, nd1, nx0, nx1, na0, na1);       // in flight during this row's reductions
+        const float mu = mean[row], rs = rstd[row];
+        const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w}, xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        float gv[8], xh[8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            xh[j] = act ? (xv[j] - mu) * rs : 0.f;
+            dwa[j] += dv[j] * xh[j]; dba[j] += dv[j];
+            gv[j] = dv[j] * wv[j];
+            s1 += gv[j]; s2 += gv[j] * xh[j];
+        }
+        s1 = wave_reduce_sum(s1) / (float)D;
+        s2 = wave_reduce_sum(s2) / (float)D;
+        if (act) {
+            const size_t off = (size_t)row * D + lane * 8;
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = av[j] + rs * (gv[j] - s1 - xh[j] * s2);
+            *reinterpret_cast<float4 *>(dx + off) = make_float4(t[0], t[1], t[2], t[3]);
+            *reinterpret_cast<float4 *>(dx + off + 4) = make_float4(t[4], t[5], t[6], t[7]);
+            if (dx_copy) {
+                if (copy_dtype != PPT_F32) {
+                    *reinterpret_cast<uint4 *>((uint16_t *)dx_copy + off) = make_uint4(pack2_dt(copy_dtype, t[0], t[1]), pack2_dt(copy_dtype, t[2], t[3]),
+                                                                                       pack2_dt(copy_dtype, t[4], t[5]), pack2_dt(copy_dtype, t[6], t[7]));
+                } else {
+                    *reinterpret_cast<float4 *>((float *)dx_copy + off) = make_float4(t[0], t[1], t[2], t[3]);
+                    *reinterpret_cast<float4 *>((float *)dx_copy + off + 4) = make_float4(t[4], t[5], t[6], t[7]);
+                }
+            }
+        }
+        d0 = nd0; d1 = nd1; x0 = nx0; x1 = nx1; a0 = na0; a1 = na1;
+    }
+    if (act) {
+        float *pw = dw_part + (size_t)g * D + lane * 8, *pb = db_part + (size_t)g * D + lane * 8;
+        *reinterpret_cast<float4 *>(pw) = make_float4(dwa[0], dwa[1], dwa[2], dwa[3]);
+        *reinterpret_cast<float4 *>(pw + 4) = make_float4(dwa[4], dwa[5], dwa[6], dwa[7]);
+        *reinterpret_cast<float4 *>(pb) = make_float4(dba[0], dba[1], dba[2], dba[3]);
+        *reinterpret_cast<float4 *>(pb + 4) = make_float4(dba[4], dba[5], dba[6], dba[7]);
+    }
+}
+
 }  // namespace
 
 extern "C" int ppt_layernorm_fwd(const float *x, const float *add, int add_rows, float *xs, const float *w,
@@ -309,6 +388,14 @@ extern "C" int ppt_layernorm_bwd(const float *dy, const float *xs, const float *
     if (dw_partial && used < partial_rows) {
         (void)hipMemsetAsync(dw_partial + (size_t)used * D, 0, sizeof(float) * (size_t)(partial_rows - used) * D, ppt_stream(stream));
         (void)hipMemsetAsync(db_partial + (size_t)used * D, 0, sizeof(float) * (size_t)(partial_rows - used) * D, ppt_stream(stream));
+    }
+    static const bool w8 = getenv("PPT_LN_BWD_W8") == nullptr || atoi(getenv("PPT_LN_BWD_W8")) != 0;
+    if (w8 && dw_partial && D % 8 == 0 && D <= 512 &&
+        ((((uintptr_t)dy | (uintptr_t)xs | (uintptr_t)w | (uintptr_t)dx | (uintptr_t)dx_copy | (uintptr_t)dw_partial | (uintptr_t)db_partial) & 15) == 0)) {
+        hipLaunchKernelGGL(ln_bwd_w8_kernel, dim3((used + 3) / 4), dim3(256), 0, ppt_stream(stream), dy, xs, w, mean, rstd, dx,
+                           accumulate_dx, dx_copy, dx_copy_dtype, dw_partial, db_partial, rpw, M, D, ppt_get_wave_priority());
+        PPT_CHECK_LAUNCH();
+        return PPT_OK;
     }
     hipLaunchKernelGGL(ln_bwd_kernel, dim3((used + 3) / 4), dim3(256), 0, ppt_stream(stream), dy, xs, w, mean, rstd, dx,
                        accumulate_dx, dx_copy, dx_copy_dtype, dw_partial, db_partial, rpw, M, D, ppt_get_wave_priority());
