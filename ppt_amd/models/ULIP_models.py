@@ -513,6 +513,9 @@ class _MatmulNT(torch.autograd.Function):
         return da, db, None
 
 
+HEAD_ON_TEXT_STREAM = os.environ.get("PPT_HEAD_ON_TEXT_STREAM", "1") != "0"
+
+
 class _HeadLossFn(torch.autograd.Function):
     """(loss, logits) of one batch for the frozen-point-side case; the gradient w.r.t. the text features is formed in
     the forward (engine.head_loss_forward_backward) and handed out by backward.  Replayed from a hipGraph after
@@ -1018,6 +1021,21 @@ class ULIP_WITH_IMAGE(nn.Module):
                 pc_feat = self.point_encoder(pc)
         if self.health is not None:
             self.health.check(1, pc_feat)                           # (BIT_POINT: on the caller's stream, beside the prompt chain)
+        if side is not None and HEAD_ON_TEXT_STREAM:
+            # The head (projection, logits, loss, d loss / d text features: ~75 us of kernels) on the TEXT stream, between the text
+            # forward and the text backward it sits between anyway: the prompt chain -- the step's critical path -- then never
+            # leaves its stream.  On the caller's stream the chain crossed streams twice per step (text forward -> event -> head ->
+            # event -> text backward: ~195 us of wall for those 75 us in tools/chain_sequence.py).  The caller's stream waits for the
+            # head's results exactly where it used to produce them.
+            side.wait_stream(cur)                                   # the tower's features
+            with torch.cuda.stream(side):
+                loss, logits = _HeadLossFn.apply(self, pc_feat, text_raw, labels, smoothing)
+            pc_feat.record_stream(side)
+            labels.record_stream(side)
+            cur.wait_stream(side)
+            loss.record_stream(cur)
+            logits.record_stream(cur)
+            return loss, logits
         if side is not None:
             cur.wait_stream(side)
             text_raw.record_stream(cur)
