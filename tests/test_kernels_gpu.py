@@ -1521,6 +1521,7 @@ def test_dataset_fps_is_bit_exact(tag, N, M, dup, cols):
     (16416, 1536, 384, "gelu"),          # fc1 of a C2 batch (128 x 128 tiles), ragged M
     (16416, 384, 1536, "residual"),      # fc2: narrow N over many rows -- 195 tiles of 256 x 128
     (32768, 512, 96, "plain"),           # short K (3 slabs) on the 256 x 128 tile
+    (33001, 200, 160, "gelu"),           # ragged M and N on the 256 x 128 tile (258 tiles)
     (1000, 200, 36, "plain"),            # ragged everything, K not a multiple of the 32-float slab
     (9000, 640, 64, "dact"),             # derivative epilogue + second (pre-activation) output
     (16384, 512, 256, "stats"),          # per-group term + BatchNorm chunk statistics + the 32-row max pool
@@ -1627,6 +1628,10 @@ def test_gemm_split16_is_fp32_grade(ops, M, N, K, kind):
     ("prefix-shared", 40, 77, 8, True, 17, 1.5),
     ("ragged", 3, 200, 2, False, 0, 1.0),
     ("causal, 5 key tiles", 5, 300, 4, True, 0, 2.0),
+    ("five tokens", 2, 5, 1, False, 0, 1.0),                # less than one query block / key tile
+    ("one full tile, causal", 1, 64, 3, True, 0, 1.0),
+    ("65 = 64 + 1: peeled last key", 7, 65, 2, False, 0, 1.0),
+    ("prefix of one", 6, 20, 2, True, 1, 1.0),
 ])
 def test_attention_split16_forward_is_fp32_grade(ops, name, Bt, T, H, causal, P, gain):
     """csrc/attention_split.hip (K.Q^T and V^T.P from hi + lo half pairs on the matrix pipe, fp32 softmax) against the fp32 VALU
