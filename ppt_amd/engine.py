@@ -574,6 +574,7 @@ def _sa_level(sd, branches, wc, npoint, xyz, feats, start, train, upd, xyz_first
     out = torch.empty((B * S, sum(c_out)), dtype=T, device=dev)
     col = 0
     mult = 8 if T in ops.HALF else 4
+    src = cx = None                  # (what every branch of a level with input features shares: built once, not per branch)
     for i, (r, K, cb, bb) in enumerate(branches):
         if pre is not None:
             idx = gxyz = pre[1 + i]
@@ -603,16 +604,18 @@ def _sa_level(sd, branches, wc, npoint, xyz, feats, start, train, upd, xyz_first
             # layer 0 by linearity of the 1x1 conv: per source point P = W.[feat|xyz], per centre Q = b - W_xyz.c
             D = feats.shape[1]
             fo, xo = (3, 0) if xyz_first else (0, D)              # column offsets of the features / the coordinates
-            src = torch.zeros((B * N, (D + 3 + mult - 1) // mult * mult), dtype=T, device=dev)
-            src[:, fo:fo + D] = feats
-            src[:, xo:xo + 3] = xyz.view(B * N, 3)
+            if src is None:
+                src = torch.zeros((B * N, (D + 3 + mult - 1) // mult * mult), dtype=T, device=dev)
+                src[:, fo:fo + D] = feats
+                src[:, xo:xo + 3] = xyz.view(B * N, 3)
+                cx = _pad_cols(new_xyz.view(B * S, 3), 4, torch.float32)
             w0p = wc.get(w0, "w", pad_to=mult)
             P = ops.gemm(src, w0p, out_dtype=torch.float32)
-            wx = _pad_cols(w0.detach().reshape(C1, -1)[:, xo:xo + 3], 4, torch.float32)
-            cx = _pad_cols(new_xyz.view(B * S, 3), 4, torch.float32)
-            Q = ops.gemm(cx, wx, out_dtype=torch.float32)
-            Q = b0.view(1, C1) - Q
-            y0, part0 = ops.gather_add(P, Q.contiguous(), idx, N, T, want_stats=train)
+            # Q = b - W_xyz . c as ONE GEMM: the negated, padded coordinate columns of the (frozen) weight are a cached derived
+            # operand and the bias rides in the epilogue (same products, b + (-(W c)) = b - W c: the same bits)
+            wxn = wc.derived(("sa_wx_neg", cb, xo), (w0,), lambda w0=w0, xo=xo, C1=C1: _pad_cols(-w0.detach().reshape(C1, -1)[:, xo:xo + 3].float(), 4, torch.float32))
+            Q = ops.gemm(cx, wxn, out_dtype=torch.float32, bias=b0)
+            y0, part0 = ops.gather_add(P, Q, idx, N, T, want_stats=train)
             sc0, sh0 = _bn_affine(sd, bb + "0.", train, part0, 32, M, upd)
             y1 = ops.gemm(y0, wc.get(sd[cb + "1.weight"]), out_dtype=T, a_mode=A_AFFINE_RELU, a_scale=sc0, a_shift=sh0,
                           bias=sd[cb + "1.bias"], col_stats=st1)
