@@ -43,7 +43,7 @@ extern "C" {
 const char *ppt_strerror(int code);
 /* ABI version of this header (currently 6); bumped on any signature change or added entry point.
  * 6: ppt_gemm_params.split16 / split_a_pow2 / split_b_pow2 (new trailing fields: fp32 operands as hi + lo half pairs),
- *    ppt_attention_fwd_split16 (new), ppt_pointmlp_cloud_rstd / ppt_pointmlp_pq (new).
+ *    ppt_attention_fwd_split16 / ppt_attention_bwd_split16 (new), ppt_pointmlp_cloud_rstd / ppt_pointmlp_pq (new).
  * 5: ppt_labels_check (new), ppt_gemm256 (new: the 256-row macro-tile GEMM core), ppt_set_gemm256 / ppt_get_gemm256 (new),
  *    ppt_layernorm_fwd_sum / ppt_layernorm_bwd_sum (new: split-K consumers), ppt_adamw_* (skipped == NULL: no guard).
  * 3: PPT_F16 (dtype arguments / struct fields), ppt_cross_entropy_rows (ignored labels, loss[2]), ppt_adamw_step (grad_scale),
@@ -330,6 +330,13 @@ size_t ppt_attention_prefix_workspace_bytes(int C, int P, int H, int hd);
  * the fp32 kernel's results to ~1e-6 at 4x its rate.  hd must be 64; qkv and out 16-byte aligned. */
 int ppt_attention_fwd_split16(const void *qkv, void *out, float *lse, int Bt, int T, int P, int H, int hd, float scale, int causal,
                               void *stream);
+/* ... and the backward of the plain layout (P == 0): the arguments and results of ppt_attention_bwd with dtype PPT_F32 (delta is
+ * scratch the call fills), dS = P (dP - delta) scale and the three gradient products from hi + lo half pairs.  Rows of dO and the
+ * P / dS tiles are scaled by powers of two taken from their own largest element before they are split (block floating point,
+ * divided out exactly): the fp32 kernels' accuracy at any gradient magnitude.  The un-frozen ViT block at T = 513, B = 64: 2.7 +
+ * 1.4 ms on the fp32 VALU kernels. */
+int ppt_attention_bwd_split16(const void *qkv, const void *out, const void *dout, const float *lse, float *delta, void *dqkv, int Bt,
+                              int T, int H, int hd, float scale, int causal, void *stream);
 int ppt_attention_prefix_fwd(const void *qkv, void *out, float *lse, int C, int T, int P, int H, int hd, float scale, int dtype,
                              void *stream);
 int ppt_attention_prefix_bwd(const void *qkv, const void *out, const void *dout, const float *lse, float *delta, void *dqkv,

@@ -1670,6 +1670,51 @@ def test_attention_split16_forward_is_fp32_grade(ops, name, Bt, T, H, causal, P,
         assert e16 < 5e-6
 
 
+@pytest.mark.parametrize("name,Bt,T,H,causal,gscale", [
+    ("vit", 8, 513, 6, False, 1.0),
+    ("vit, small gradients", 4, 513, 6, False, 1e-3),
+    ("vit, tiny gradients", 2, 513, 6, False, 1e-7),
+    ("vit, huge gradients", 2, 513, 6, False, 3e4),
+    ("text", 40, 77, 8, True, 1.0),
+    ("ragged", 3, 200, 2, False, 1.0),
+    ("causal, 3 key blocks", 5, 300, 4, True, 1.0),
+    ("five tokens", 2, 5, 1, False, 1.0),
+])
+def test_attention_split16_backward_is_fp32_grade(ops, name, Bt, T, H, causal, gscale):
+    """ppt_attention_bwd_split16 (csrc/attention_split.hip: dK / dV and dQ kernels with every MFMA operand a hi + lo half pair)
+    against the fp32 VALU kernels on the same inputs and against fp64 autograd of softmax(q k^T scale) v."""
+    g = torch.Generator().manual_seed(T + Bt)
+    qkv = torch.randn(Bt * T, 3 * H * 64, generator=g).cuda()
+    dout = (torch.randn(Bt * T, H * 64, generator=g) * gscale).cuda()
+
+    def run(split):
+        ops.set_split16(split)
+        try:
+            out, lse = ops.attention_fwd(qkv, Bt, T, H, 0.125, causal)
+            return ops.attention_bwd(qkv, out, dout, lse, Bt, T, H, 0.125, causal)
+        finally:
+            ops.set_split16(False)
+    d32 = run(False)
+    d16 = run(True)
+    d16b = run(True)
+    torch.cuda.synchronize()
+    assert torch.equal(d16, d16b)
+    q64 = qkv.double().requires_grad_(True)
+    q, k, v = q64.view(Bt, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s_ = (q @ k.transpose(-1, -2)) * 0.125
+    if causal:
+        s_ = s_.masked_fill(torch.triu(torch.ones(T, T, dtype=torch.bool, device="cuda"), 1), float("-inf"))
+    o = (torch.softmax(s_, -1) @ v).permute(0, 2, 1, 3).reshape(Bt * T, H * 64)
+    o.backward(dout.double())
+    want = q64.grad
+    for part, sl in (("dq", slice(0, H * 64)), ("dk", slice(H * 64, 2 * H * 64)), ("dv", slice(2 * H * 64, 3 * H * 64))):
+        w_ = want[:, sl]
+        e16 = ((d16[:, sl].double() - w_).norm() / w_.norm()).item()
+        e32 = ((d32[:, sl].double() - w_).norm() / w_.norm()).item()
+        print(f"PARITY split16 attention backward {name} {part}: rel-L2 vs fp64 {e16:.2e} (fp32 kernels {e32:.2e})")
+        assert e16 < 3e-6 and e16 < 3 * e32 + 5e-7
+
+
 class _CloudsWithDatasetFPS(torch.utils.data.Dataset):
     """The shape of the reference's datasets (data/dataset_3d.py:288-300): __getitem__ seeds nothing, calls
     farthest_point_sample(point, npoint) -- which draws its start with np.random.randint -- and returns the rows."""
