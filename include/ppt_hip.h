@@ -330,13 +330,14 @@ size_t ppt_attention_prefix_workspace_bytes(int C, int P, int H, int hd);
  * the fp32 kernel's results to ~1e-6 at 4x its rate.  hd must be 64; qkv and out 16-byte aligned. */
 int ppt_attention_fwd_split16(const void *qkv, void *out, float *lse, int Bt, int T, int P, int H, int hd, float scale, int causal,
                               void *stream);
-/* ... and the backward of the plain layout (P == 0): the arguments and results of ppt_attention_bwd with dtype PPT_F32 (delta is
- * scratch the call fills), dS = P (dP - delta) scale and the three gradient products from hi + lo half pairs.  Rows of dO and the
+/* ... and the backward: the arguments and results of ppt_attention_bwd (P == 0, workspace may be NULL) or of
+ * ppt_attention_prefix_bwd (P > 0, causal, Bt = C prompts, workspace as there) with dtype PPT_F32 (delta is scratch the call
+ * fills), dS = P (dP - delta) scale and the three gradient products from hi + lo half pairs.  Rows of dO and the
  * P / dS tiles are scaled by powers of two taken from their own largest element before they are split (block floating point,
  * divided out exactly): the fp32 kernels' accuracy at any gradient magnitude.  The un-frozen ViT block at T = 513, B = 64: 2.7 +
  * 1.4 ms on the fp32 VALU kernels. */
-int ppt_attention_bwd_split16(const void *qkv, const void *out, const void *dout, const float *lse, float *delta, void *dqkv, int Bt,
-                              int T, int H, int hd, float scale, int causal, void *stream);
+int ppt_attention_bwd_split16(const void *qkv, const void *out, const void *dout, const float *lse, float *delta, void *dqkv,
+                              float *workspace, int Bt, int T, int P, int H, int hd, float scale, int causal, void *stream);
 int ppt_attention_prefix_fwd(const void *qkv, void *out, float *lse, int C, int T, int P, int H, int hd, float scale, int dtype,
                              void *stream);
 int ppt_attention_prefix_bwd(const void *qkv, const void *out, const void *dout, const float *lse, float *delta, void *dqkv,

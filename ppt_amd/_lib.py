@@ -119,7 +119,7 @@ _SIGNATURES = {
     "ppt_attention_prefix_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int, c_int]),
     "ppt_pointmlp_cloud_rstd": (c_int, [c_void_p, c_int, c_int, ctypes.c_double, c_void_p, c_void_p]),
     "ppt_pointmlp_pq": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "ppt_attention_bwd_split16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "ppt_attention_bwd_split16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "ppt_attention_fwd_split16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "ppt_attention_prefix_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "ppt_attention_prefix_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

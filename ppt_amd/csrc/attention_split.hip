@@ -276,9 +276,10 @@ __device__ __forceinline__ float pow2_for(float m, int target)        // power o
 }
 
 __global__ __launch_bounds__(256) void attn_delta_f32(const float *__restrict__ out, const float *__restrict__ dout, float *__restrict__ delta,
-                                                      int T, int H, int64_t rows /* Bt * T * H */)
+                                                      int T, int H, int P, int64_t rows /* physical rows x H */)
 {
-    // delta[(b * H + head) * T + pos] = sum_d out[b, pos, head, d] * dout[...]: one 16-lane group per (row, head)
+    // delta = sum_d out[row, head, d] * dout[row, head, d]: one 16-lane group per (physical row, head); stored where am_stat puts
+    // it -- [(b * H + head) * T + pos] in the plain layout, [row * H + head] in the prefix-shared one
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
     const int l = threadIdx.x & 15;
     if (i >= rows) return;
@@ -288,7 +289,20 @@ __global__ __launch_bounds__(256) void attn_delta_f32(const float *__restrict__ 
     const float4 g = *reinterpret_cast<const float4 *>(dout + (row * H + head) * HD + 4 * l);
     float d = a.x * g.x + a.y * g.y + a.z * g.z + a.w * g.w;
     d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4); d += __shfl_xor(d, 8);
-    if (l == 0) delta[((row / T) * H + head) * T + row % T] = d;
+    if (l == 0) delta[P > 0 ? i : ((row / T) * H + head) * T + row % T] = d;
+}
+
+// the fp32 partial dK / dV of the shared prefix rows, one slot per virtual sequence, folded in sequence order (attn_rowmap.h;
+// attention.hip: attn_prefix_reduce)
+__global__ __launch_bounds__(256) void attn_prefix_fold_f32(const float *__restrict__ part, int nseq, int P, int HHD, float *__restrict__ dqkv)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P * 2 * HHD) return;
+    float acc = 0.f;
+    const int64_t stride = (int64_t)P * 2 * HHD;
+    for (int v = 0; v < nseq; ++v) acc += part[i + v * stride];
+    const int pos = i / (2 * HHD), rem = i - pos * 2 * HHD;
+    dqkv[(int64_t)pos * 3 * HHD + HHD + rem] = acc;
 }
 
 constexpr int QT = 32, QTILE = QT * 128;          // a 32-row hi (or lo) image
@@ -337,7 +351,8 @@ __device__ __forceinline__ uint4 tr_frag(const unsigned char *img, int row0, int
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_split16(const float *__restrict__ qkv, const float *__restrict__ dout,
                                                             const float *__restrict__ lse, const float *__restrict__ delta,
-                                                            float *__restrict__ dqkv, int T, int H, float scale)
+                                                            float *__restrict__ dqkv, int Tfull, int H, float scale, int P, int C,
+                                                            float *__restrict__ part)
 {
     // images of the query tile: Q row / Q tr / dO' row / dO' tr, each hi + lo (8 x 4 KiB), + lse2[32] + delta'[32]
     __shared__ __align__(16) unsigned char smem[8 * QTILE + 384];     // ... + 1 / (row scale of dO)[32]
@@ -346,9 +361,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_split16(const float *__re
     const int r = lane & 31, h = lane >> 5;
     const int bh = blockIdx.y, b = bh / H, head = bh % H;
     const int64_t rs = 3 * (int64_t)H * HD, os = (int64_t)H * HD;
-    const float *qb = qkv + (int64_t)b * T * rs + head * HD;
+    const int T = am_len(Tfull, P, C, b), q_lo = am_qlo(P, C, b);      // (attn_rowmap.h: b is a virtual sequence when P > 0)
+    const float *qb = qkv + head * HD;
     const float *kb = qb + H * HD, *vb = qb + 2 * H * HD;
-    const float *gb = dout + (int64_t)b * T * os + head * HD;
+    const float *gb = dout + head * HD;
     const int k0 = blockIdx.x * 128 + w * 32;
     const int key = k0 + r;
     const float c = scale * 1.4426950408889634f;
@@ -358,7 +374,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_split16(const float *__re
     for (int kk = 0; kk < 4; ++kk) {
         float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, v0 = a0, v1 = a0;
         if (key < T) {
-            const float *kp = kb + (int64_t)key * rs + 16 * kk + 8 * h, *vp = vb + (int64_t)key * rs + 16 * kk + 8 * h;
+            const int64_t kr = am_row(Tfull, P, b, key) * rs;
+            const float *kp = kb + kr + 16 * kk + 8 * h, *vp = vb + kr + 16 * kk + 8 * h;
             a0 = *reinterpret_cast<const float4 *>(kp); a1 = *reinterpret_cast<const float4 *>(kp + 4);
             v0 = *reinterpret_cast<const float4 *>(vp); v1 = *reinterpret_cast<const float4 *>(vp + 4);
         }
@@ -373,7 +390,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_split16(const float *__re
 
     float run_v = 1.0f, run_k = 1.0f;                                  // the scales dvt / dkt currently carry
     const int nqt = (T + QT - 1) / QT;
-    const int qt0 = CAUSAL ? (int)(blockIdx.x * 128) / QT : 0;       // queries before the block's first key see none of it
+    // queries before the block's first key see none of it; queries below q_lo belong to the prefix sequence, not to this one
+    const int qt0 = max(CAUSAL ? (int)(blockIdx.x * 128) / QT : 0, q_lo / QT);
     float4 sq[2], sg[2];
     float sl[2], sd[2];                                               // (used by the thread that holds chunk 0 of the row)
     auto load_tile = [&](int qt) {
@@ -382,13 +400,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_split16(const float *__re
             const int cidx = threadIdx.x + 256 * i;
             const int q = qt * QT + (cidx >> 4), ch = cidx & 15;
             sq[i] = sg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            sl[i] = INFINITY; sd[i] = 0.f;                            // +inf -> p = 0 for padded rows
+            sl[i] = INFINITY; sd[i] = 0.f;                            // +inf -> p = 0 for padded rows and rows this sequence does not own
             if (q < T) {
-                sq[i] = *reinterpret_cast<const float4 *>(qb + (int64_t)q * rs + ch * 4);
-                sg[i] = *reinterpret_cast<const float4 *>(gb + (int64_t)q * os + ch * 4);
-                if (ch == 0) {
-                    sl[i] = lse[((int64_t)b * H + head) * T + q] * 1.4426950408889634f;
-                    sd[i] = delta[((int64_t)b * H + head) * T + q];
+                const int64_t qr = am_row(Tfull, P, b, q);
+                sq[i] = *reinterpret_cast<const float4 *>(qb + qr * rs + ch * 4);
+                sg[i] = *reinterpret_cast<const float4 *>(gb + qr * os + ch * 4);
+                if (ch == 0 && q >= q_lo) {
+                    sl[i] = lse[am_stat(Tfull, P, H, b, head, q)] * 1.4426950408889634f;
+                    sd[i] = delta[am_stat(Tfull, P, H, b, head, q)];
                 }
             }
         }
@@ -483,8 +502,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_split16(const float *__re
         __syncthreads();
     }
     if (key < T) {
-        float *ok = dqkv + ((int64_t)b * T + key) * rs + head * HD + H * HD;
-        float *ov = ok + H * HD;
+        // a SHARED key (P > 0, key < P): this virtual sequence's contribution goes to its fp32 partial slot
+        // [b][key][K | V][H * HD]; the slots are folded in a fixed order by attn_prefix_fold_f32 (no atomics)
+        const bool shared = P > 0 && key < P;
+        float *ok = shared ? part + (((int64_t)b * P + key) * 2) * os + head * HD
+                           : dqkv + am_row(Tfull, P, b, key) * rs + head * HD + H * HD;
+        float *ov = ok + (shared ? os : (int64_t)H * HD);
 #pragma unroll
         for (int dtile = 0; dtile < 2; ++dtile)
 #pragma unroll
@@ -503,7 +526,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_split16(const float *__re
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_split16(const float *__restrict__ qkv, const float *__restrict__ dout,
                                                            const float *__restrict__ lse, const float *__restrict__ delta,
-                                                           float *__restrict__ dqkv, int T, int H, float scale)
+                                                           float *__restrict__ dqkv, int Tfull, int H, float scale, int P, int C)
 {
     __shared__ __align__(16) unsigned char smem[6 * TILE];            // K row / K tr / V row images, hi + lo (6 x 8 KiB)
     const int lane = threadIdx.x & 63;
@@ -511,9 +534,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_split16(const float *__res
     const int r = lane & 31, h = lane >> 5;
     const int bh = blockIdx.y, b = bh / H, head = bh % H;
     const int64_t rs = 3 * (int64_t)H * HD, os = (int64_t)H * HD;
-    const float *qb = qkv + (int64_t)b * T * rs + head * HD;
+    const int T = am_len(Tfull, P, C, b), q_lo = am_qlo(P, C, b);
+    const float *qb = qkv + head * HD;
     const float *kb = qb + H * HD, *vb = qb + 2 * H * HD;
-    const float *gb = dout + (int64_t)b * T * os + head * HD;
+    const float *gb = dout + head * HD;
     const int q0 = blockIdx.x * QB + w * 32;
     const int qrow = q0 + r;
     const float c = scale * 1.4426950408889634f;
@@ -524,7 +548,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_split16(const float *__res
     for (int kk = 0; kk < 4; ++kk) {
         float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, g0 = a0, g1 = a0;
         if (qrow < T) {
-            const float *qp = qb + (int64_t)qrow * rs + 16 * kk + 8 * h, *gp = gb + (int64_t)qrow * os + 16 * kk + 8 * h;
+            const int64_t qr = am_row(Tfull, P, b, qrow);
+            const float *qp = qb + qr * rs + 16 * kk + 8 * h, *gp = gb + qr * os + 16 * kk + 8 * h;
             a0 = *reinterpret_cast<const float4 *>(qp); a1 = *reinterpret_cast<const float4 *>(qp + 4);
             g0 = *reinterpret_cast<const float4 *>(gp); g1 = *reinterpret_cast<const float4 *>(gp + 4);
         }
@@ -545,9 +570,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_split16(const float *__res
         g0.x *= gs; g0.y *= gs; g0.z *= gs; g0.w *= gs; g1.x *= gs; g1.y *= gs; g1.z *= gs; g1.w *= gs;
         split8(g0, g1, gh[kk], gl[kk]);
     }
-    const bool own = qrow < T;
-    const float l2 = own ? lse[((int64_t)b * H + head) * T + qrow] * 1.4426950408889634f : INFINITY;
-    const float dl = own ? delta[((int64_t)b * H + head) * T + qrow] * gs : 0.f;
+    const bool own = qrow < T && qrow >= q_lo;
+    const float l2 = own ? lse[am_stat(Tfull, P, H, b, head, qrow)] * 1.4426950408889634f : INFINITY;
+    const float dl = own ? delta[am_stat(Tfull, P, H, b, head, qrow)] * gs : 0.f;
 
     float4 sk[4], sv[4];
     auto load_tile = [&](int kt) {
@@ -557,8 +582,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_split16(const float *__res
             const int kx = kt * KVT + (cidx >> 4), ch = cidx & 15;
             sk[i] = sv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (kx < T) {
-                sk[i] = *reinterpret_cast<const float4 *>(kb + (int64_t)kx * rs + ch * 4);
-                sv[i] = *reinterpret_cast<const float4 *>(vb + (int64_t)kx * rs + ch * 4);
+                const int64_t kr = am_row(Tfull, P, b, kx) * rs;
+                sk[i] = *reinterpret_cast<const float4 *>(kb + kr + ch * 4);
+                sv[i] = *reinterpret_cast<const float4 *>(vb + kr + ch * 4);
             }
         }
     };
@@ -641,7 +667,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_split16(const float *__res
         __syncthreads();
     }
     if (own) {
-        float *oq = dqkv + ((int64_t)b * T + qrow) * rs + head * HD;
+        float *oq = dqkv + am_row(Tfull, P, b, qrow) * rs + head * HD;
 #pragma unroll
         for (int dtile = 0; dtile < 2; ++dtile)
 #pragma unroll
@@ -675,27 +701,34 @@ extern "C" int ppt_attention_fwd_split16(const void *qkv, void *out, float *lse,
 }
 
 
-// Backward of the plain layout (P == 0): qkv / dqkv [Bt * T, 3, H, 64], out / dout [Bt * T, H, 64], lse [Bt, H, T] -- all fp32;
-// delta [Bt, H, T] is a scratch buffer this call fills (rowsum(dO . O)).  The layouts and results of ppt_attention_bwd with dtype
-// PPT_F32, every product on the 16-bit matrix pipe from hi + lo half pairs.
+// Backward: qkv / dqkv [rows, 3, H, 64], out / dout [rows, H, 64], lse and the scratch `delta` in the layouts of ppt_attention_bwd
+// (P == 0: rows = Bt * T, statistics [Bt, H, T]) or ppt_attention_prefix_bwd (P > 0, causal: rows = P + Bt (T - P), statistics
+// [rows, H], `part` = the fp32 workspace of ppt_attention_prefix_workspace_bytes) -- all fp32, the results of those entry points
+// with dtype PPT_F32, every product on the 16-bit matrix pipe from hi + lo half pairs.
 extern "C" int ppt_attention_bwd_split16(const void *qkv, const void *out, const void *dout, const float *lse, float *delta, void *dqkv,
-                                         int Bt, int T, int H, int hd, float scale, int causal, void *stream)
+                                         float *part, int Bt, int T, int P, int H, int hd, float scale, int causal, void *stream)
 {
-    if (!qkv || !out || !dout || !lse || !delta || !dqkv || Bt <= 0 || T <= 0 || H <= 0 || hd != HD) return PPT_EINVAL;
-    if ((((uintptr_t)qkv | (uintptr_t)out | (uintptr_t)dout | (uintptr_t)dqkv) & 15) != 0) return PPT_EINVAL;
+    if (!qkv || !out || !dout || !lse || !delta || !dqkv || Bt <= 0 || T <= 0 || H <= 0 || hd != HD || P < 0 || P >= T) return PPT_EINVAL;
+    if (P > 0 && (!part || !causal)) return PPT_EINVAL;
+    if ((((uintptr_t)qkv | (uintptr_t)out | (uintptr_t)dout | (uintptr_t)dqkv | (uintptr_t)part) & 15) != 0) return PPT_EINVAL;
     hipStream_t s = ppt_stream(stream);
-    const int64_t rows = (int64_t)Bt * T * H;
-    hipLaunchKernelGGL(attn_delta_f32, dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, s, (const float *)out, (const float *)dout, delta, T, H, rows);
+    const int64_t rows = (P > 0 ? (int64_t)P + (int64_t)Bt * (T - P) : (int64_t)Bt * T) * H;
+    hipLaunchKernelGGL(attn_delta_f32, dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, s, (const float *)out, (const float *)dout, delta, T, H, P, rows);
     PPT_CHECK_LAUNCH();
-    dim3 grid((T + 127) / 128, Bt * H);
+    dim3 grid((T + 127) / 128, (Bt + (P > 0)) * H);
     if (grid.y > 65535) return PPT_EUNSUPPORTED;
     if (causal) {
-        hipLaunchKernelGGL((attn_bwd_dq_split16<true>), grid, dim3(256), 0, s, (const float *)qkv, (const float *)dout, lse, delta, (float *)dqkv, T, H, scale);
-        hipLaunchKernelGGL((attn_bwd_dkv_split16<true>), grid, dim3(256), 0, s, (const float *)qkv, (const float *)dout, lse, delta, (float *)dqkv, T, H, scale);
+        hipLaunchKernelGGL((attn_bwd_dq_split16<true>), grid, dim3(256), 0, s, (const float *)qkv, (const float *)dout, lse, delta, (float *)dqkv, T, H, scale, P, Bt);
+        hipLaunchKernelGGL((attn_bwd_dkv_split16<true>), grid, dim3(256), 0, s, (const float *)qkv, (const float *)dout, lse, delta, (float *)dqkv, T, H, scale, P, Bt, part);
     } else {
-        hipLaunchKernelGGL((attn_bwd_dq_split16<false>), grid, dim3(256), 0, s, (const float *)qkv, (const float *)dout, lse, delta, (float *)dqkv, T, H, scale);
-        hipLaunchKernelGGL((attn_bwd_dkv_split16<false>), grid, dim3(256), 0, s, (const float *)qkv, (const float *)dout, lse, delta, (float *)dqkv, T, H, scale);
+        hipLaunchKernelGGL((attn_bwd_dq_split16<false>), grid, dim3(256), 0, s, (const float *)qkv, (const float *)dout, lse, delta, (float *)dqkv, T, H, scale, P, Bt);
+        hipLaunchKernelGGL((attn_bwd_dkv_split16<false>), grid, dim3(256), 0, s, (const float *)qkv, (const float *)dout, lse, delta, (float *)dqkv, T, H, scale, P, Bt, part);
     }
     PPT_CHECK_LAUNCH();
+    if (P > 0) {
+        const int n = P * 2 * H * HD;
+        hipLaunchKernelGGL(attn_prefix_fold_f32, dim3((n + 255) / 256), dim3(256), 0, s, part, Bt + 1, P, H * HD, (float *)dqkv);
+        PPT_CHECK_LAUNCH();
+    }
     return PPT_OK;
 }

@@ -556,7 +556,7 @@ def attention_bwd(qkv, out, dout, lse, Bt, T, H, scale, causal):
     if profiler is not None:
         profiler.begin("attention_bwd", 10.0 * Bt * H * T * T * 64 * (0.5 if causal else 1.0))
     if qkv.dtype == torch.float32 and _SPLIT16 and ATTN_SPLIT16:      # split16 mode: every product from hi + lo half pairs
-        _lib.check(_lib.lib().ppt_attention_bwd_split16(_p(qkv), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), Bt, T, H, 64,
+        _lib.check(_lib.lib().ppt_attention_bwd_split16(_p(qkv), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), None, Bt, T, 0, H, 64,
                                                         scale, int(causal), _stream()), "ppt_attention_bwd_split16")
     else:
         _lib.check(_lib.lib().ppt_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), Bt, T, H, 64,
@@ -602,8 +602,12 @@ def attention_prefix_bwd(qkv, out, dout, lse, C, T, P, H, scale):
     ws = torch.empty((_lib.lib().ppt_attention_prefix_workspace_bytes(C, P, H, 64) // 4,), dtype=torch.float32, device=qkv.device)
     if profiler is not None:
         profiler.begin("attention_bwd", 5.0 * (C * (T * T - P * P) + P * P) * H * 64)
-    _lib.check(_lib.lib().ppt_attention_prefix_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), _p(ws), C, T, P, H, 64,
-                                                   scale, dtype_code(qkv), _stream()), "ppt_attention_prefix_bwd")
+    if qkv.dtype == torch.float32 and _SPLIT16 and ATTN_SPLIT16:
+        _lib.check(_lib.lib().ppt_attention_bwd_split16(_p(qkv), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), _p(ws), C, T, P, H, 64,
+                                                        scale, 1, _stream()), "ppt_attention_bwd_split16")
+    else:
+        _lib.check(_lib.lib().ppt_attention_prefix_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), _p(ws), C, T, P, H, 64,
+                                                       scale, dtype_code(qkv), _stream()), "ppt_attention_prefix_bwd")
     if profiler is not None:
         profiler.end()
     return dqkv

@@ -1715,6 +1715,37 @@ def test_attention_split16_backward_is_fp32_grade(ops, name, Bt, T, H, causal, g
         assert e16 < 3e-6 and e16 < 3 * e32 + 5e-7
 
 
+@pytest.mark.parametrize("C,T,P,H,gscale", [(40, 77, 17, 8, 1.0), (40, 37, 17, 8, 1e-5), (6, 20, 1, 2, 1.0), (3, 150, 130, 2, 1.0)])
+def test_attention_split16_prefix_backward_matches_the_fp32_kernels(ops, C, T, P, H, gscale):
+    """ppt_attention_bwd_split16 in the prefix-shared layout (attn_rowmap.h: the prompt chain's causal attention, the first P
+    positions stored once): against ppt_attention_prefix_bwd on fp32 -- dQ / dK / dV of every physical row, the shared rows'
+    dK / dV being the fixed-order sum over the C + 1 virtual sequences."""
+    g = torch.Generator().manual_seed(T * 7 + P)
+    rows = ops.prefix_rows(C, T, P)
+    qkv = torch.randn(rows, 3 * H * 64, generator=g).cuda()
+    dout = (torch.randn(rows, H * 64, generator=g) * gscale).cuda()
+
+    def run(split):
+        ops.set_split16(split)
+        try:
+            out, lse = ops.attention_prefix_fwd(qkv, C, T, P, H, 0.125)
+            return ops.attention_prefix_bwd(qkv, out, dout, lse, C, T, P, H, 0.125)
+        finally:
+            ops.set_split16(False)
+    d32, d16, d16b = run(False), run(True), run(True)
+    torch.cuda.synchronize()
+    assert torch.equal(d16, d16b)
+    for part, sl in (("dq", slice(0, H * 64)), ("dk", slice(H * 64, 2 * H * 64)), ("dv", slice(2 * H * 64, 3 * H * 64))):
+        for what, rs_ in (("shared rows", slice(0, P)), ("own rows", slice(P, rows))):
+            a, b = d32[rs_, sl].double(), d16[rs_, sl].double()
+            if a.norm().item() == 0.0:             # (a lone first position attends to itself only: its dQ is exactly zero)
+                assert (b.abs().max().item()) < 1e-6 * gscale
+                continue
+            rel = ((a - b).norm() / a.norm()).item()
+            print(f"PARITY split16 prefix attention backward C{C} T{T} P{P} {part} {what}: rel-L2 vs the fp32 kernels {rel:.2e}")
+            assert rel < 2e-6
+
+
 class _CloudsWithDatasetFPS(torch.utils.data.Dataset):
     """The shape of the reference's datasets (data/dataset_3d.py:288-300): __getitem__ seeds nothing, calls
     farthest_point_sample(point, npoint) -- which draws its start with np.random.randint -- and returns the rows."""
