@@ -22,6 +22,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
 
 constexpr int HD = 64, KVT = 64, QB = 128, TILE = KVT * 128;   // bytes per hi (or lo) image of a K or V tile
+constexpr float P_PRE = 1024.0f;                                // forward: P is split as P x 2^10, O carries the factor to the end
 
 __device__ __forceinline__ int k_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ int v_off(int key, int dbyte) { return key * 128 + (dbyte ^ (((key >> 1) & 1) << 6)); }
@@ -147,8 +148,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_split16(const float *__restri
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const float4 vv = *reinterpret_cast<const float4 *>(vl + 32 * dtile + 8 * gq + 4 * h);
-                ot[dtile][4 * gq + 0] = vv.x; ot[dtile][4 * gq + 1] = vv.y;
-                ot[dtile][4 * gq + 2] = vv.z; ot[dtile][4 * gq + 3] = vv.w;
+                ot[dtile][4 * gq + 0] = vv.x * P_PRE; ot[dtile][4 * gq + 1] = vv.y * P_PRE;
+                ot[dtile][4 * gq + 2] = vv.z * P_PRE; ot[dtile][4 * gq + 3] = vv.w * P_PRE;
             }
     }
 
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_split16(const float *__restri
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const float pv = __builtin_amdgcn_exp2f(fmaf(st[sub][e], c, -mn));
-                    st[sub][e] = pv;
+                    st[sub][e] = pv * P_PRE;                          // (P <= 1: x 2^10 keeps a flat softmax's 1 / T inside hi + lo's 22 bits)
                     psum += pv;
                 }
             l = fmaf(l, alpha, psum);
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_split16(const float *__restri
 
     const float lt = xor32_sum(l);
     if (qrow < T && qrow >= q_lo) {
-        const float inv = 1.0f / lt;
+        const float inv = 1.0f / (lt * P_PRE);
         float *ob = out + am_row(Tfull, P, b, qrow) * (H * HD) + head * HD;
 #pragma unroll
         for (int dtile = 0; dtile < 2; ++dtile)
