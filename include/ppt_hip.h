@@ -41,7 +41,9 @@ extern "C" {
                      * ppt_amd/gradscale.py); bf16 stays the format of PointNet++ / PointMLP */
 
 const char *ppt_strerror(int code);
-/* ABI version of this header (currently 6); bumped on any signature change or added entry point.
+/* ABI version of this header (currently 7); bumped on any signature change or added entry point.
+ * 7: ppt_gemm_params.split_overflow (new trailing field: split16 saturates finite values beyond IEEE half's range and counts
+ *    the workgroups that did), ppt_vit_mlp3_bf16 / ppt_vit_mlp3_retile / ppt_vit_proj3_retile (new: csrc/mlp_fused3.hip).
  * 6: ppt_gemm_params.split16 / split_a_pow2 / split_b_pow2 (new trailing fields: fp32 operands as hi + lo half pairs),
  *    ppt_attention_fwd_split16 / ppt_attention_bwd_split16 (new), ppt_pointmlp_cloud_rstd / ppt_pointmlp_pq (new).
  * 5: ppt_labels_check (new), ppt_gemm256 (new: the 256-row macro-tile GEMM core), ppt_set_gemm256 / ppt_get_gemm256 (new),
@@ -157,6 +159,10 @@ typedef struct ppt_gemm_params {
      * outputs) is the fp32 path's.  Large plain problems run on 256 x 128 tiles (csrc/gemm256.hip: gemm256s_kernel), the rest on
      * the register-staged 128 x 128 / 64 x 64 loops -- the same bits either way; split16 == 2 keeps a launch on the loops (A/B). */
     int split16, split_a_pow2, split_b_pow2;
+    /* ABI 7: a FINITE operand value whose scaled magnitude exceeds 65 504 is saturated to +-65 504 before the split (the product
+     * stays finite where the fp32 MFMA's would be; inf / NaN inputs propagate unchanged) and every wave that saturated anything
+     * adds 1 to *split_overflow (device memory, may be NULL: saturation without a report) -- ppt_amd/health.py polls it. */
+    unsigned int *split_overflow;
 } ppt_gemm_params;
 
 #define PPT_A_PLAIN 0

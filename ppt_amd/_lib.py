@@ -30,7 +30,7 @@ class GemmParams(ctypes.Structure):
         ("C2", c_void_p), ("ldc2", c_int64), ("c2_dtype", c_int), ("c2_pre", c_int),
         ("col_sum", c_void_p), ("col_sqsum", c_void_p), ("pool_max", c_void_p), ("pool_dtype", c_int), ("pool_rows", c_int), ("pool_min", c_void_p),
         ("batch", c_int), ("strideA", c_int64), ("strideB", c_int64), ("strideC", c_int64), ("wave_prio", c_int),
-        ("split16", c_int), ("split_a_pow2", c_int), ("split_b_pow2", c_int),
+        ("split16", c_int), ("split_a_pow2", c_int), ("split_b_pow2", c_int), ("split_overflow", c_void_p),
     ]
 
 

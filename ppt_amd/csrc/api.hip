@@ -12,7 +12,7 @@ extern "C" const char *ppt_strerror(int code)
     }
 }
 
-extern "C" int ppt_abi_version(void) { return 6; }   // 2: + ppt_bn_finalize_ws, ppt_rows_stats_f32, ppt_bn_rows_bwd_*; 3: PPT_F16 operands (dtype fields / arguments), ppt_cross_entropy_rows ignore + scale, ppt_adamw_step grad_scale, ppt_bn_rows_bwd_apply half_dtype; 4: see include/ppt_hip.h
+extern "C" int ppt_abi_version(void) { return 7; }   // 2: + ppt_bn_finalize_ws, ppt_rows_stats_f32, ppt_bn_rows_bwd_*; 3: PPT_F16 operands (dtype fields / arguments), ppt_cross_entropy_rows ignore + scale, ppt_adamw_step grad_scale, ppt_bn_rows_bwd_apply half_dtype; 4: see include/ppt_hip.h
 
 static thread_local int g_wave_priority = 0;
 extern "C" void ppt_set_wave_priority(int prio) { g_wave_priority = prio > 0 ? 1 : 0; }

@@ -30,6 +30,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const ppt_gemm_params p)
 {
     static_assert(!SPLIT || sizeof(T) == 4, "split16 is a mode of the fp32-operand kernel");
     const float sa = SPLIT ? pow2f(p.split_a_pow2) : 1.0f, sb = SPLIT ? pow2f(p.split_b_pow2) : 1.0f;
+    uint32_t split_over = 0;                 // (SPLIT: did this thread saturate a value beyond half's range -- gemm_common.h)
     constexpr int WM = BM / 2, WN = BN / 2, TI = WM / 32, TJ = WN / 32, NRA = BM / 32, NRB = BN / 32;
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
     constexpr int STAGE_BYTES = 2 * (A_BYTES + B_BYTES), PARK_BYTES = 4 * WM * WN * 4;
@@ -90,8 +91,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const ppt_gemm_params p)
         finish_A<T, A_MODE, NRA>(SA, p, m0, (S) * BK, tab);                   \
         mask_plain<T, NRB>(SB, p.N, p.K, n0, (S) * BK);                       \
         if constexpr (SPLIT) {                                                \
-            write_stage_split<NRA, BM>(SA, Abuf + ((BUF) & 1) * A_BYTES, sa); \
-            write_stage_split<NRB, BN>(SB, Bbuf + ((BUF) & 1) * B_BYTES, sb); \
+            write_stage_split<NRA, BM>(SA, Abuf + ((BUF) & 1) * A_BYTES, sa, split_over); \
+            write_stage_split<NRB, BN>(SB, Bbuf + ((BUF) & 1) * B_BYTES, sb, split_over); \
         } else {                                                              \
             PPT_DBG_WRITE(write_stage<NRA>(SA, Abuf + ((BUF) & 1) * A_BYTES)); \
             PPT_DBG_WRITE(write_stage<NRB>(SB, Bbuf + ((BUF) & 1) * B_BYTES)); \
@@ -131,7 +132,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const ppt_gemm_params p)
 #undef PPT_STEP
 #undef PPT_WRITE
 #undef PPT_LOAD
-    if constexpr (SPLIT) scale_acc<TI, TJ>(acc, pow2f(-(p.split_a_pow2 + p.split_b_pow2)));
+    if constexpr (SPLIT) {
+        scale_acc<TI, TJ>(acc, pow2f(-(p.split_a_pow2 + p.split_b_pow2)));
+        split_report(split_over, p.split_overflow);
+    }
 
     // ---------------- epilogue ----------------
     // The operand tiles are dead (the loop ends on a barrier): every wave parks its fp32 accumulators in

@@ -473,7 +473,7 @@ __device__ __forceinline__ void load_rows512(Stage<NR> &st, const float *base, i
 
 template <int BM, int BN, int TI, int TJ>
 __device__ __forceinline__ void split256_loop(const ppt_gemm_params &p, const float *A, const float *B, int m0, int n0, unsigned char *smem,
-                                              int arow0, int brow0, int lane, f32x16_t (&acc)[TI][TJ], float sa, float sb)
+                                              int arow0, int brow0, int lane, f32x16_t (&acc)[TI][TJ], float sa, float sb, uint32_t &over)
 {
     constexpr int NRA = BM / 64, NRB = BN / 64, A_BYTES = BM * 128, B_BYTES = BN * 128, BUF = A_BYTES + B_BYTES;
     const int nslab = p.K / 32, last = nslab - 1;
@@ -486,8 +486,8 @@ __device__ __forceinline__ void split256_loop(const ppt_gemm_params &p, const fl
     } while (0)
 #define S256_WRITE(SA, SB, BUFI)                                                                    \
     do {                                                                                            \
-        write_stage_split<NRA, BM, 64>(SA, smem + ((BUFI) & 1) * BUF, sa);                          \
-        write_stage_split<NRB, BN, 64>(SB, smem + ((BUFI) & 1) * BUF + A_BYTES, sb);                \
+        write_stage_split<NRA, BM, 64>(SA, smem + ((BUFI) & 1) * BUF, sa, over);                    \
+        write_stage_split<NRB, BN, 64>(SB, smem + ((BUFI) & 1) * BUF + A_BYTES, sb, over);          \
     } while (0)
 #define S256_X(S) mma_slab_split<TI, TJ, BM, BN>(smem + ((S) & 1) * BUF, smem + ((S) & 1) * BUF + A_BYTES, arow0, brow0, lane, acc)
     // STEP(s): multiply slab s out of LDS (X); the FREE register set (it held slab s) receives slab s + 3; the NEXT set (slab s + 1)
@@ -561,8 +561,10 @@ __global__ __launch_bounds__(NT2, 2) void gemm256s_kernel(const ppt_gemm_params 
         for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    split256_loop<BM, BN, TI, TJ>(p, A, B, m0, n0, smem, wm * WM, wn * WN, lane, acc, sa, sb);
+    uint32_t split_over = 0;
+    split256_loop<BM, BN, TI, TJ>(p, A, B, m0, n0, smem, wm * WM, wn * WN, lane, acc, sa, sb, split_over);
     scale_acc<TI, TJ>(acc, pow2f(-(p.split_a_pow2 + p.split_b_pow2)));
+    split_report(split_over, p.split_overflow);
 
     const int64_t zc = (int64_t)blockIdx.z * p.strideC;
     const int mw = m0 + wm * WM, nw = n0 + wn * WN;

@@ -304,15 +304,29 @@ typedef _Float16 ppt_h2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int lds_off_s(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
 __device__ __forceinline__ float pow2f(int e) { return __uint_as_float((uint32_t)(127 + e) << 23); }
 
+// Range (round 6): half(x * s) is inf beyond 65 504 and lo = half(x * s - inf) is NaN, where the fp32 MFMA this mode
+// stands in for would have produced a finite product.  A FINITE value beyond half's range is therefore SATURATED to +-65 504
+// before the split (lo = 0: the product is finite, and wrong by what was cut off) and counted in `over`; the kernel adds the
+// workgroup's count to *p.split_overflow, which ppt_amd/health.py polls (BIT_SPLIT: the model leaves the split16 mode).  inf and
+// NaN inputs are left alone: they propagate as they do in the fp32 mode.
+constexpr float HALF_MAX = 65504.0f;
+__device__ __forceinline__ float split_saturate(float x, uint32_t &over)
+{
+    const float ax = fabsf(x);
+    const bool cut = ax > HALF_MAX && ax < __builtin_inff();       // (false for NaN and for inf)
+    over |= (uint32_t)cut;
+    return cut ? copysignf(HALF_MAX, x) : x;
+}
+
 template <int NR, int ROWS, int STRIDE = 32>                 // STRIDE = threads / 8: rows one pass of the workgroup covers
-__device__ __forceinline__ void write_stage_split(const Stage<NR> &st, unsigned char *tile, float s)
+__device__ __forceinline__ void write_stage_split(const Stage<NR> &st, unsigned char *tile, float s, uint32_t &over)
 {
     const int t = threadIdx.x, ch = t & 7;
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
         const int row = (t >> 3) + STRIDE * i;
-        const float x[4] = {__uint_as_float(st.v[i].x) * s, __uint_as_float(st.v[i].y) * s, __uint_as_float(st.v[i].z) * s,
-                            __uint_as_float(st.v[i].w) * s};
+        const float x[4] = {split_saturate(__uint_as_float(st.v[i].x) * s, over), split_saturate(__uint_as_float(st.v[i].y) * s, over),
+                            split_saturate(__uint_as_float(st.v[i].z) * s, over), split_saturate(__uint_as_float(st.v[i].w) * s, over)};
         uint32_t H[2], L[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -326,6 +340,12 @@ __device__ __forceinline__ void write_stage_split(const Stage<NR> &st, unsigned 
         *reinterpret_cast<uint2 *>(tile + off) = make_uint2(H[0], H[1]);
         *reinterpret_cast<uint2 *>(tile + ROWS * 64 + off) = make_uint2(L[0], L[1]);
     }
+}
+
+// one atomic per wave that saturated anything (ppt_gemm_params.split_overflow may be NULL: saturation without a report)
+__device__ __forceinline__ void split_report(uint32_t over, unsigned int *counter)
+{
+    if (counter && __builtin_amdgcn_ballot_w64(over != 0) != 0 && (threadIdx.x & 63) == 0) atomicAdd(counter, 1u);
 }
 
 template <int TI, int TJ, int AROWS, int BROWS>

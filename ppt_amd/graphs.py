@@ -105,11 +105,22 @@ def ready_event(t):
     return getattr(t, "_ppt_ready", None)
 
 
-def wait_inputs(stream, tensors):
+def wait_inputs(stream, tensors, main=None, vouched=False):
+    """Order `stream` (an ahead stage's) behind the producers of `tensors`: the copy event a tensor carries (DevicePrefetcher), or
+    -- for a tensor WITHOUT one that the caller has not vouched for either -- the caller's stream `main`.  The second case is the
+    derived tensor: the batch object carried the event, but what the stage reads is `pc.contiguous().float()` / a slice / a `.to()`
+    of it, a NEW tensor produced on the caller's stream that no event covers (the stage, which deliberately does not
+    wait for the caller's stream, could read it before it was written).  Falling back to stream order costs that step its overlap
+    and nothing else.  vouched: Trainer.inputs_ready / eval_inputs_ready -- the caller's promise covers every tensor of the call."""
+    in_order = False
     for t in tensors:
         ev = ready_event(t)
         if ev is not None:
             stream.wait_event(ev)
+        elif not vouched:
+            in_order = True
+    if in_order and main is not None:
+        stream.wait_stream(main)
 
 
 class AheadStage:
@@ -123,14 +134,16 @@ class AheadStage:
         self.slot = 0
         self.free = [None, None]
 
-    def run(self, cache, key, fn, ins, side):
-        """fn(*ins) -> (outputs, keepalive) as for GraphedCall.  -> (outputs of this call, slot)."""
+    def run(self, cache, key, fn, ins, side, vouched=False):
+        """fn(*ins) -> (outputs, keepalive) as for GraphedCall.  -> (outputs of this call, slot).  vouched: the caller promised that
+        `ins` are complete in device memory (Trainer.inputs_ready); otherwise every tensor of `ins` must carry its copy event, or
+        the stage falls back to waiting for the caller's stream (wait_inputs)."""
         main = torch.cuda.current_stream()
         slot = self.slot = 1 - self.slot
         with torch.cuda.stream(side):
             if self.free[slot] is not None:
                 side.wait_event(self.free[slot])
-            wait_inputs(side, ins)                    # (a DevicePrefetcher batch: behind its copy; a vouched-for tensor: nothing)
+            wait_inputs(side, ins, main, vouched)     # (a DevicePrefetcher batch: behind its copy; a vouched-for tensor: nothing)
             outs, _ = cache.get(tuple(key) + (slot,), lambda: GraphedCall(fn, ins))(*ins)
             done = side.record_event()
         for t in ins:

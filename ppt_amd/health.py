@@ -22,6 +22,10 @@ have (tools/fp16_stress.py builds such weights and prints the per-stage ranges).
     BIT_GRAD (the optimizer's skip counter moved although features and loss were finite: a BACKWARD stage overflowed -- with
     gains of 10 the text tower's half gradients do, tools/fp16_stress.py) -> every stage with a 16-bit backward: text tower,
     un-frozen last block, part-seg decoder and head;
+  * split16 (fp32 operands as hi + lo half pairs) has half's RANGE too: its GEMMs saturate a finite operand value beyond 65 504
+    instead of turning it into inf / NaN and count the waves that did (ppt_gemm_params.split_overflow -> BIT_SPLIT here): the
+    model then leaves the split16 products for the fp32 MFMA (`set_precision("fp32")`, or `text_split16 = False` for a mixed-mode
+    text tower that ran on them), with a warning -- the stored values are fp32 either way, so nothing else changes (ADVICE r5);
   * when events keep arriving and nothing is left to demote (bf16 has fp32's range: then it is not a half overflow -- diverging
     training or bad data), or a label is outside [0, C) (BIT_LABEL: ATen raises a device assert there), the Trainer raises
     FloatingPointError / ValueError instead of skipping steps silently.
@@ -31,7 +35,8 @@ import warnings
 
 import torch
 
-BIT_POINT, BIT_LOSS, BIT_GRAD, BIT_LABEL = 1, 2, 4, 8
+BIT_POINT, BIT_LOSS, BIT_GRAD, BIT_LABEL, BIT_SPLIT = 1, 2, 4, 8, 16
+NBITS = 5
 GIVE_UP_AFTER = 3            # consecutive polls with an event that no demotion can answer -> FloatingPointError
 
 
@@ -48,6 +53,15 @@ class Monitor:
         self.skipped_seen = 0
         self.unanswered = 0                 # consecutive polls whose event found nothing left to demote (train.Trainer)
         self.skipped = None                 # the optimizer's device counter of skipped (non-finite) gradient elements (train.Trainer)
+        # split16: the process-wide counter of GEMM waves that saturated an operand beyond half's range (ops.split16_overflow_counter)
+        self.split_counter = None
+        self.host_split = torch.zeros((1,), dtype=torch.int32).pin_memory() if pin else torch.zeros((1,), dtype=torch.int32)
+        self.split_seen = 0
+        if torch.device(device).type == "cuda":
+            from . import ops
+            self.split_counter = ops.split16_overflow_counter(device)
+            self.split_seen = int(self.split_counter.item())          # (events of earlier models / runs in this process are not ours)
+            self.host_split[0] = self.split_seen
 
     def check(self, bit, t):
         """queue the non-finite check of tensor t on the current stream (ppt_health_check).  Every check of a run is queued on
@@ -70,6 +84,10 @@ class Monitor:
         if sk > self.skipped_seen and not (bits & (BIT_POINT | BIT_LOSS | BIT_LABEL)):
             bits |= BIT_GRAD
         self.skipped_seen = sk
+        sp = int(self.host_split.item())
+        if sp != self.split_seen:           # (a wrapping 32-bit counter: any change is an event)
+            bits |= BIT_SPLIT
+        self.split_seen = sp
         self.seen |= bits
         if not bits:
             self.unanswered = 0             # (a clean window: "consecutive" starts over)
@@ -88,6 +106,8 @@ class Monitor:
         if self.every > 0 and step % self.every == 0 and self._pending is None and self.flags.is_cuda:
             self.host.copy_(self.flags, non_blocking=True)
             self.flags.zero_()                                     # (same stream: behind the copy, in front of the next check)
+            if self.split_counter is not None:
+                self.host_split.copy_(self.split_counter, non_blocking=True)
             evs = [torch.cuda.Event()]
             evs[0].record()
             if self.skipped is not None:
@@ -115,11 +135,16 @@ class Monitor:
         bits = int(self.flags.item())
         self.flags.zero_()
         sk = int(self.skipped.item()) if self.skipped is not None else 0
-        v = torch.tensor([float((bits >> b) & 1) for b in range(4)] + [float(sk)], dtype=torch.float64, device=self.flags.device)
+        sp = int(self.split_counter.item()) if self.split_counter is not None else self.split_seen
+        if sp != self.split_seen:
+            bits |= BIT_SPLIT
+        self.split_seen = sp
+        self.host_split[0] = sp
+        v = torch.tensor([float((bits >> b) & 1) for b in range(NBITS)] + [float(sk)], dtype=torch.float64, device=self.flags.device)
         dist.all_reduce(v, op=dist.ReduceOp.MAX, group=group)
         v = v.cpu()
-        self.host[0] = sum(int(v[b].item()) << b for b in range(4))
-        self.host_skipped[0] = int(v[4].item())
+        self.host[0] = sum(int(v[b].item()) << b for b in range(NBITS))
+        self.host_skipped[0] = int(v[NBITS].item())
         self.polls += 1
         return self._resolve()
 
@@ -138,6 +163,9 @@ class Monitor:
         self.flags.zero_()
         if self.skipped is not None:
             self.host_skipped.copy_(self.skipped)
+        if self.split_counter is not None:
+            torch.cuda.synchronize(self.split_counter.device)     # (the GEMMs that add to it run on any stream)
+            self.host_split.copy_(self.split_counter)
         return new | self._resolve()
 
 
@@ -147,6 +175,26 @@ def demote(model, bits):
     done = []
     pe = getattr(model, "point_encoder", None)
     demoted = model.__dict__.setdefault("demoted", set())
+    if bits & BIT_SPLIT:
+        # a split16 GEMM saturated an operand: the values are fp32 in memory, only the PRODUCTS were formed from half pairs --
+        # form them on the fp32 MFMA from here on (slower, fp32's range)
+        if getattr(model, "split16", False):
+            model.set_precision("fp32")
+            done.append("every split16 product (the model now runs in the fp32 mode)")
+        elif getattr(model, "text_split16", False) and getattr(model, "text_precision", None) is torch.float32:
+            model.text_split16 = False
+            done.append("the text tower's split16 products (fp32 MFMA from here on)")
+        if done:
+            if hasattr(model, "reset_caches") and not getattr(model, "split16", False):
+                keep = (model.text_precision, model.text_calibration, model._text_calibrated) if hasattr(model, "text_calibration") else None
+                model.reset_caches()
+                if keep is not None:        # (the calibration's verdict stands: the weights did not change)
+                    model.text_precision, model.text_calibration, model._text_calibrated = keep
+            warnings.warn("ppt_amd: a split16 GEMM operand exceeded IEEE half's range (saturated to +-65 504 for that launch): "
+                          + "; ".join(done), RuntimeWarning, stacklevel=3)
+        bits &= ~BIT_SPLIT
+        if not bits:
+            return done
     point_left = not {"tokenizer", "blocks", "last_block", "decoder"} <= demoted
     if bits & BIT_POINT and point_left:
         # (non-finite features make the loss non-finite too: BIT_LOSS in the same window is this event's echo, not a second one)

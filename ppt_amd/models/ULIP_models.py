@@ -611,6 +611,11 @@ class ULIP_WITH_IMAGE(nn.Module):
         # products from hi + lo half pairs (split16) instead of on the fp32 MFMA; PPT_TEXT_SPLIT16=0: the fp32 MFMA
         self.text_split16 = os.environ.get("PPT_TEXT_SPLIT16", "1") != "0"
         self.split16 = False
+        # split16's operand pre-scales (2^a for activations / gradients, 2^b for weights) are THIS model's: b follows its weight range
+        # (_fit_split16_range, re-run per weight set); handed to ops with the flag by every _cache() call
+        self._split_pow2_default = tuple(ops.SPLIT16_POW2)
+        self.split_pow2 = self._split_pow2_default
+        self._split_fit_pending = True
         self.text_calibration = None        # what calibrate_text_precision measured: {"rel_l2": ..., "threshold": ..., "demoted": bool}
         self._text_calibrated = False
         # stages this model's monitor moved from IEEE half to bf16 (health.demote); ONE set per model, shared with the point
@@ -707,23 +712,31 @@ class ULIP_WITH_IMAGE(nn.Module):
         return self
 
     def _fit_split16_range(self):
-        """split16 multiplies every weight by 2^b (ops.SPLIT16_POW2, default b = 4) before splitting it into hi + lo halves, and
-        half overflows at 65 504: with weights (or BatchNorm-folded weights) beyond ~2 000 the products would be inf.  Checked once
-        per set_precision("split16") on the matrices this model holds: b is lowered (process-wide, with a warning) until
-        4 x max|w| x 2^b stays below half's range -- the factor 4 is room for the BatchNorm folds (w x gamma / sigma)."""
+        """split16 multiplies every weight by 2^b (default b = 4, ops.SPLIT16_POW2 at import) before splitting it into hi + lo
+        halves, and half stops at 65 504: with weights (or BatchNorm-folded weights) beyond ~2 000 the hi halves would saturate.
+        Checked per WEIGHT SET -- set_precision("split16"), and again at the first _cache() after load_state_dict / reset_caches
+        (a fit at set_precision alone never saw a checkpoint loaded afterwards) -- on the matrices this model holds:
+        b is lowered (with a warning) until 4 x max|w| x 2^b stays below half's range; the factor 4 is room for the BatchNorm folds
+        (w x gamma / sigma).  The result is THIS model's (`split_pow2`, handed to ops.set_split16 with the flag by every _cache()
+        call), so one model's fit no longer changes another's."""
+        self._split_fit_pending = False
         mats = [q.detach() for q in self.parameters() if q.dim() >= 2 and q.is_floating_point()]
-        if not mats:
-            return
-        mx = max(float(q.abs().max()) for q in mats)
-        a, b = ops.SPLIT16_POW2
-        b_fit = b
-        while b_fit > -8 and 4.0 * mx * 2.0 ** b_fit >= 32768.0:
-            b_fit -= 1
-        if b_fit != b:
-            import warnings
-            warnings.warn(f"split16: max |weight| = {mx:.4g}; the weight operand's pre-scale is lowered from 2^{b} to 2^{b_fit} "
-                          f"(ops.SPLIT16_POW2) to keep the hi halves inside IEEE half's range")
-            ops.SPLIT16_POW2 = (a, b_fit)
+        a, b = self._split_pow2_default
+        if mats:
+            mx = max(float(q.abs().max()) for q in mats)
+            b_fit = b
+            while b_fit > -8 and 4.0 * mx * 2.0 ** b_fit >= 32768.0:
+                b_fit -= 1
+            if b_fit != b:
+                import warnings
+                warnings.warn(f"split16: max |weight| = {mx:.4g}; the weight operand's pre-scale is lowered from 2^{b} to 2^{b_fit} "
+                              f"(this model's split_pow2) to keep the hi halves inside IEEE half's range")
+            b = b_fit
+        if (a, b) != self.split_pow2:
+            self.split_pow2 = (a, b)
+            self._graphs.clear()                    # (a captured launch carries the pre-scales as kernel arguments)
+            if hasattr(self.point_encoder, "_graphs"):
+                self.point_encoder._graphs.clear()
 
     def _cache(self):
         # The text tower's operand format in the performance mode is IEEE half, not bf16 (PPT_TEXT_F16=0: bf16): same MFMA rate,
@@ -737,7 +750,10 @@ class ULIP_WITH_IMAGE(nn.Module):
         if self._wc is None or self._wc.dtype != want:
             self._wc = engine.WeightCache(want, self.demoted)
         # split16: the whole model's mode, or the text tower alone when its load-time check sent it to fp32 operands
-        ops.set_split16(self.split16 or (want == torch.float32 and self.precision != torch.float32 and self.text_split16))
+        on = self.split16 or (want == torch.float32 and self.precision != torch.float32 and self.text_split16)
+        if on and self._split_fit_pending and not torch.cuda.is_current_stream_capturing():
+            self._fit_split16_range()               # (new weights since the last fit: load_state_dict / reset_caches)
+        ops.set_split16(on, self.split_pow2)
         return self._wc
 
     def _live_state(self):
@@ -803,6 +819,7 @@ class ULIP_WITH_IMAGE(nn.Module):
         self._te_cache = None
         self._chain_prio = None
         self._text_calibrated = False               # new weights: the half-vs-fp32 check of the text tower runs again
+        self._split_fit_pending = True              # ... and so does the range fit of the split16 pre-scale (_cache)
         if self.text_calibration is not None and self.text_calibration.get("demoted"):
             self.text_precision = None
         self.text_calibration = None
@@ -967,12 +984,14 @@ class ULIP_WITH_IMAGE(nn.Module):
             # validate() with resident inputs (eval_inputs_ready): the next batch's FPS + kNN + tokenizer on the grouping stream,
             # under this batch's blocks -- the same ahead stage train.Trainer uses (PointTransformer._group_ahead)
             pe.group_ahead = graphs.shared_group_stream()
+            pe.inputs_vouched = bool(self.eval_inputs_ready)     # (else: only tensors that carry their copy event run ahead)
         try:
             with self._tower_room():
                 pc_embed = self.encode_pc(pc, cls_label) if self.task == 'partseg' else self.encode_pc(pc)
         finally:
             if ahead:
                 pe.group_ahead = None
+                pe.inputs_vouched = False
         if self.health is not None and self.training:
             self.health.check(1, pc_embed)                          # (BIT_POINT)
         if side is not None:

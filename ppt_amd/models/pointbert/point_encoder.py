@@ -421,7 +421,9 @@ class PointTransformer(nn.Module):
         with torch.cuda.stream(side):
             if self._group_free[slot] is not None:
                 side.wait_event(self._group_free[slot])
-            graphs.wait_inputs(side, ins)             # (a DevicePrefetcher batch: behind its copy; a vouched-for tensor: nothing)
+            # (a DevicePrefetcher batch: behind its copy; a vouched-for tensor: nothing; a tensor DERIVED from the batch on the
+            # caller's stream, which no event covers: behind the caller's stream -- graphs.wait_inputs)
+            graphs.wait_inputs(side, ins, main, getattr(self, "inputs_vouched", False))
             grouped, _ = self._graphs.get(key, build)(*ins)
             done = side.record_event()
         for t in ins:
@@ -612,14 +614,14 @@ class PointTransformer_partseg(nn.Module):
                 # writes -- so the next step's backbone runs under this step's decoder (hundreds of small kernels that leave
                 # most of the chip idle) instead of in front of it
                 outs, slot = self._ahead.run(self._graphs, ("partseg_backbone_ahead", (B, N), self.training, self._precision), backbone,
-                                             [pts], self.group_ahead)
+                                             [pts], self.group_ahead, vouched=getattr(self, "inputs_vouched", False))
                 f_a, f_b, f_c, center, c1, c2 = (o.clone() for o in outs)
                 self._ahead.consumed(slot)
             elif self.group_ahead is not None:
                 # the caller vouches that `pts` is complete in memory (train.Trainer.inputs_ready): the grouping stage runs on its
                 # own stream as soon as the step is called -- under the previous iteration's decoder backward (0.3 ms of serial
                 # FPS walks off the head of the caller's stream) -- and only the blocks wait for it (graphs.AheadStage)
-                (center, c1, c2, nbhd), slot = self._ahead.run(self._graphs, ("partseg_group", (B, N)), grouping, [pts], self.group_ahead)
+                (center, c1, c2, nbhd), slot = self._ahead.run(self._graphs, ("partseg_group", (B, N)), grouping, [pts], self.group_ahead, vouched=getattr(self, "inputs_vouched", False))
                 bkey = ("partseg_blocks", (B, N), self.training, self._precision)
                 outs, _ = self._graphs.get(bkey, lambda: graphs.GraphedCall(blocks, [nbhd, center]))(nbhd, center)
                 f_a, f_b, f_c, center = (o.clone() for o in outs)

@@ -182,7 +182,7 @@ class Model(nn.Module):
                         st = st if st else tuple(torch.randint(0, n, (B,), dtype=torch.long, device=x.device) for n in n_src)
                         return tuple(engine.pointmlp_group(x, st, cfg)), None
                     grouped, slot = self._ahead.run(self._graphs, ("pointmlp_group", tuple(xyz.shape), drawn), gfn,
-                                                    [xyz] + ([] if drawn else list(starts)), self.group_ahead)
+                                                    [xyz] + ([] if drawn else list(starts)), self.group_ahead, vouched=getattr(self, "inputs_vouched", False))
                     ng = len(grouped)
                     ins = [xyz] + list(grouped) + (list(masks) if masks is not None else [])
 

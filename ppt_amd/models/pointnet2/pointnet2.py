@@ -134,7 +134,7 @@ class Pointnet2_Msg(nn.Module):
                                                 torch.randint(0, n1, (B,), dtype=torch.long, device=x.device))
                         return tuple(engine.pointnet2_group(x, (s0, s1), levels)), None
                     grouped, slot = self._ahead.run(self._graphs, ("pn2_group", tuple(xyz.shape), drawn), gfn,
-                                                    [xyz] + ([] if drawn else [starts[0], starts[1]]), self.group_ahead)
+                                                    [xyz] + ([] if drawn else [starts[0], starts[1]]), self.group_ahead, vouched=getattr(self, "inputs_vouched", False))
                     ng = len(grouped)
                     ins = list(grouped) + (list(masks) if masks is not None else [])
 

@@ -193,11 +193,29 @@ _SPLIT16 = False
 ATTN_SPLIT16 = os.environ.get("PPT_ATTN_SPLIT16", "1") != "0"      # 0: the split16 mode keeps the fp32 VALU attention forward
 
 
-def set_split16(on):
+def set_split16(on, pow2=None):
     """fp32-operand ops.gemm calls that do not say `split=` themselves use the split16 products from now on (True) or the fp32
-    MFMA (False)."""
-    global _SPLIT16
+    MFMA (False).  pow2: the (A, B) pre-scales of the model that says so (ULIP_WITH_IMAGE.split_pow2: its weight range decides B's,
+    _fit_split16_range) -- every model re-asserts its OWN pair with the flag whenever it fetches its WeightCache, so one model's
+    fit no longer changes another's."""
+    global _SPLIT16, SPLIT16_POW2
     _SPLIT16 = bool(on)
+    if on and pow2 is not None:
+        SPLIT16_POW2 = (int(pow2[0]), int(pow2[1]))
+
+
+_SPLIT_OVERFLOW = {}
+
+
+def split16_overflow_counter(device=None):
+    """The device word (uint32, one per GPU, process-wide, never re-allocated: captured hipGraphs keep its address) to which every
+    split16 GEMM wave that SATURATED a finite operand beyond IEEE half's range adds 1 (ppt_gemm_params.split_overflow).  A counter,
+    not a flag: readers compare with the value they saw last (health.Monitor), nothing ever clears it, so a read on one stream
+    cannot race with an add from another."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    if dev not in _SPLIT_OVERFLOW:
+        _SPLIT_OVERFLOW[dev] = torch.zeros((1,), dtype=torch.int32, device=torch.device("cuda", dev))
+    return _SPLIT_OVERFLOW[dev]
 
 
 def split16_enabled():
@@ -262,6 +280,8 @@ def gemm(A, B, *, out=None, out_dtype=None, M=None, bias=None, act=ACT_NONE, dac
     if split and p.dtype == PPT_F32:
         p.split16 = 2 if core == "tiles" else 1          # ("tiles": keep the launch off the 256 x 128 split kernel -- A/B, tests)
         p.split_a_pow2, p.split_b_pow2 = split if isinstance(split, tuple) else SPLIT16_POW2
+        if not torch.cuda.is_current_stream_capturing() or dev.index in _SPLIT_OVERFLOW:
+            p.split_overflow = _p(split16_overflow_counter(dev))      # (first use outside a capture: the word is allocated there)
     if profiler is not None:
         kk = K if algo_k is None else algo_k
         # ("bf16" names the 16-bit MFMA family of the roofline table: bf16 and fp16 operands run at the same rate)
@@ -1149,10 +1169,13 @@ def gemm_tn_splitk(x_a, x_b, min_blocks=768, max_splits=16):
     Mc = ((M + S - 1) // S + 63) // 64 * 64
     at = transpose(x_a, pad_to=S * Mc)                                  # [N1, S*Mc], zero tail
     bt = transpose(x_b, pad_to=S * Mc)
+    # split16: the pre-scale goes by an operand's ROLE, not by its position -- B is a weight everywhere else (x 2^4), here both
+    # operands are activations / S-scaled gradients, which stay where they are like every other A operand
+    role = (SPLIT16_POW2[0], SPLIT16_POW2[0]) if (_SPLIT16 and at.dtype == torch.float32) else None
     if S == 1:
-        return gemm(at, bt, out_dtype=torch.float32)
+        return gemm(at, bt, out_dtype=torch.float32, split=role)
     part = torch.empty((S * N1, N2), dtype=torch.float32, device=x_a.device)
-    gemm(at[:, :Mc], bt[:, :Mc], out=part, batch=S, strideA=Mc, strideB=Mc, strideC=N1 * N2)
+    gemm(at[:, :Mc], bt[:, :Mc], out=part, batch=S, strideA=Mc, strideB=Mc, strideC=N1 * N2, split=role)
     return reduce_rows(part.view(S, N1 * N2)).view(N1, N2)
 
 

@@ -230,7 +230,9 @@ class Trainer:
         # PPT_HEALTH=0 turns it off, PPT_HEALTH_EVERY sets the poll interval.
         self.health = None
         self.demotions = []
-        if os.environ.get("PPT_HEALTH", "1") != "0" and getattr(model, "precision", None) == torch.bfloat16 and hasattr(model, "health") \
+        # (round 6, ADVICE r5: split16 is a guarded mode too -- its products are formed from IEEE-half pairs, so it has half's range)
+        half_range = getattr(model, "precision", None) == torch.bfloat16 or getattr(model, "split16", False)
+        if os.environ.get("PPT_HEALTH", "1") != "0" and half_range and hasattr(model, "health") \
                 and next(model.parameters()).is_cuda:
             from . import health
             # (under a process group a poll is ONE blocking read + all-reduce so that every rank decides alike: every 200 steps)
@@ -334,6 +336,9 @@ class Trainer:
             if self.bcast is not None and self.broadcast_buffers_every_step:
                 use = False
             pe.group_ahead = graphs.shared_group_stream() if use else None
+            # the promise covers every tensor the stage reads; without it a tensor must carry its own copy event, and one derived
+            # from the batch on this stream (a cast, a slice) sends the stage back behind this stream (graphs.wait_inputs)
+            pe.inputs_vouched = bool(self.inputs_ready)
         tower_own = (self.tower_own_stream and self.inputs_ready and pc.is_cuda and side is not None and self._point_side_frozen
                      and self.fused_head and not self.extra_inputs)
         if hasattr(model, "forward_loss"):
@@ -358,6 +363,7 @@ class Trainer:
         finally:
             if hasattr(pe, "group_ahead"):
                 pe.group_ahead = None       # the vouching covers this call's `pc` only: a forward outside step() stays in order
+                pe.inputs_vouched = False
         if self.health is not None:
             self.health.check(2, loss)                              # (BIT_LOSS; on the caller's stream)
             self.health.check_labels(label, pred.shape[-1], self.criterion.ignore_index)
@@ -414,6 +420,8 @@ class Trainer:
                              "(nn.CrossEntropyLoss raises a device assert there): the loss of that step was NaN and the "
                              "optimizer skipped it -- a DATA error, not a numeric overflow")
         done = health.demote(self.model, new)
+        if new == health.BIT_SPLIT and not done:
+            return                          # (the process-wide split16 counter moved for another model of this process: not ours)
         self.demotions.append((self.it, new, done))
         if done:
             mon.unanswered = 0
@@ -461,7 +469,9 @@ class Trainer:
         from . import ops
         # the non-finite skip exists for the 16-bit backward stages only: in the fp32 parity mode the kernels get no counter and
         # behave as torch.optim.AdamW does -- a NaN gradient reaches the parameter and main_cls.py:205-207 stops the run
-        guard = getattr(self.model, "precision", None) != torch.float32
+        # ... and split16 is NOT that mode: its operands pass through half's range (saturated + counted, health.BIT_SPLIT), its
+        # backward stages are gradient-scaled like the 16-bit ones, so it keeps the skip as well
+        guard = getattr(self.model, "precision", None) != torch.float32 or getattr(self.model, "split16", False)
         if self._skipped is None and guard:
             self._skipped = torch.zeros((1,), dtype=torch.int64, device=params[0][1].device)
             if self.health is not None:

@@ -26,7 +26,7 @@ def test_binding_covers_header():
     from ppt_amd import _lib
     syms = set(declared_symbols()) - {"ppt_strerror"}
     assert syms == set(_lib._SIGNATURES), syms ^ set(_lib._SIGNATURES)
-    assert _lib.lib().ppt_abi_version() == 6
+    assert _lib.lib().ppt_abi_version() == 7
     assert b"invalid" in _lib.lib().ppt_strerror(-1)
 
 

@@ -255,3 +255,30 @@ def test_real_trainable_sets_one_allreduce_per_step(head_type):
     assert r0["views_ok"] and r1["views_ok"] and r0["still_view"] and r1["still_view"]
     assert np.all(r1["rm_mid"] == 3.0)
     assert np.array_equal(r1["rm"], r0["rm"]) and np.allclose(r0["rm"], 0.75)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` started PLAINLY (no torchrun, no WORLD_SIZE) must produce the contract's JSON line: the parent
+    starts one child per rank before any GPU call, relays rank 0's line as its last line and exits with the worst child's code
+    (the reference's launcher contract: main_cls.py:39,47-49, utils/utils.py:104-143).  PPT_BENCH_DRY=gloo swaps the
+    GPU step for a gradient-sized gloo all-reduce so that the plumbing runs here."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["PPT_BENCH_DRY"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    j = json.loads(last)
+    assert j["n_gpus"] == 2 and j["steps"] == 4 and j["dry"] is True and j["scaling"] == "weak"
+    assert j["config"]["parallelism"] == "dp2"
+    pr = j["config"]["ms_per_step_per_rank"]
+    assert 0 < pr["min"] <= pr["max"] and abs(j["ms_per_step"] - pr["max"]) < 1e-3        # MAX over ranks is the step time
+    # ... and a failing rank is the launcher's exit code
+    env["PPT_BENCH_DRY_FAIL_RANK"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode != 0

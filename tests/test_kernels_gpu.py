@@ -1621,6 +1621,53 @@ def test_gemm_split16_is_fp32_grade(ops, M, N, K, kind):
         assert torch.equal(h, ops.gemm(A.half(), Bm.half(), split=False))
 
 
+@pytest.mark.parametrize("M,N,K", [(817, 512, 512), (16416, 384, 1536), (300, 200, 96)])
+def test_gemm_split16_saturates_a_finite_overflow_and_counts_it(ops, M, N, K):
+    """half(x * s) is inf beyond 65 504 and lo = half(x * s - inf) NaN, where the fp32 MFMA this mode stands in for gives a
+    finite product.  The split saturates a FINITE value to +-65 504 (finite result, wrong by what was cut off) and every wave that did
+    adds 1 to the process-wide counter ppt_amd/health.py polls (ppt_gemm_params.split_overflow); inf / NaN inputs propagate as in the
+    fp32 mode and are NOT counted; in-range launches leave the counter alone.  64 x 64, 128 x 128 and 256 x 128 split kernels."""
+    rng = np.random.default_rng(M + N)
+    A = dev(rng.standard_normal((M, K)).astype(np.float32))
+    Bm = dev((rng.standard_normal((N, K)) / math.sqrt(K)).astype(np.float32))
+    cnt = ops.split16_overflow_counter(A.device)
+    torch.cuda.synchronize()
+    c0 = int(cnt.item())
+    ok = ops.gemm(A, Bm, split=True)
+    torch.cuda.synchronize()
+    assert int(cnt.item()) == c0 and torch.isfinite(ok).all()
+    big = A.clone()
+    big[5, 7] = 3.0e6                                       # finite, beyond half's range (A's pre-scale is 2^0)
+    out = ops.gemm(big, Bm, split=True)
+    torch.cuda.synchronize()
+    c1 = int(cnt.item())
+    assert c1 > c0, "the saturation was not counted"
+    assert torch.isfinite(out).all(), "a finite fp32 operand must not become inf / NaN in the split"
+    want = big.clone()
+    want[5, 7] = 65504.0                                    # what the launch multiplied
+    ref = want.double() @ Bm.double().t()
+    assert ((out.double() - ref).norm() / ref.norm()).item() < 2e-6
+    rows = torch.ones(M, dtype=torch.bool, device=A.device)
+    rows[5] = False
+    assert torch.equal(out[rows], ok[rows])                 # every other row: the in-range launch's bits
+    # the WEIGHT operand is pre-scaled by 2^4: 5 000 x 16 is beyond the range too
+    wbig = Bm.clone()
+    wbig[3, 1] = 5000.0
+    out = ops.gemm(A, wbig, split=True)
+    torch.cuda.synchronize()
+    c2 = int(cnt.item())
+    assert c2 > c1 and torch.isfinite(out).all()
+    assert torch.isfinite(ops.gemm(A, wbig, split=(0, 0))).all() and int(cnt.item()) == c2      # ... and inside it at 2^0
+    # inf / NaN inputs are the caller's: they propagate, uncounted
+    bad = A.clone()
+    bad[2, 3] = float("inf")
+    bad[9, 1] = float("nan")
+    out = ops.gemm(bad, Bm, split=True)
+    torch.cuda.synchronize()
+    assert int(cnt.item()) == c2
+    assert not torch.isfinite(out[2]).any() and torch.isnan(out[9]).all() and torch.isfinite(out[rows & (torch.arange(M, device=A.device) != 2) & (torch.arange(M, device=A.device) != 9)]).all()
+
+
 @pytest.mark.parametrize("name,Bt,T,H,causal,P,gain", [
     ("vit", 32, 513, 6, False, 0, 1.0),                     # T = 64 n + 1: the peeled last key
     ("vit, large scores", 8, 513, 6, False, 0, 3.0),

@@ -1449,6 +1449,46 @@ def test_health_monitor_demotes_an_overflowing_half_stage():
     assert not other.demoted and other.text_f16, "a demotion must not leak into other models of the process"
 
 
+def test_split16_mode_is_guarded_and_leaves_on_a_range_overflow():
+    """split16 forms its products from IEEE-half pairs, so it has half's RANGE -- and the Trainer used to treat it
+    as the fp32 mode (no monitor, no non-finite skip in AdamW).  Now: (1) Trainer installs the health monitor for a split16 model and
+    the AdamW kernels keep their skip counter; (2) an activation beyond 65 504 (a LayerNorm gain of 1e6 in the text tower: 1-D, so
+    the weight-range fit cannot see it) is SATURATED by the split -- loss, gradients and parameters stay finite -- and counted;
+    (3) the monitor reports BIT_SPLIT and the model leaves the split16 products for the fp32 MFMA (`precision_name == "fp32"`), with
+    a warning; (4) a split16 model WITHOUT such a value runs its steps without an event."""
+    import warnings
+    from ppt_amd import health
+    from ppt_amd.train import Trainer
+    pc, _ = oracle_inputs()
+    labels = torch.tensor([1, 2, 3, 4]).cuda()
+    with _health_every(1):
+        m, _ = build(0, "split16")
+        m.train()
+        tr = Trainer(m, distributed=False)
+        assert tr.health is not None and m.health is tr.health
+        for _ in range(3):
+            tr.step(pc.cuda(), labels)
+        tr.finish()
+        assert tr._skipped is not None and tr.nonfinite_grad_elements() == 0        # the guard exists, nothing tripped it
+        assert not tr.demotions and m.precision_name == "split16" and not (tr.health.read_now() & health.BIT_SPLIT)
+
+        m, _ = build(0, "split16")
+        with torch.no_grad():
+            m.transformer.resblocks[0].ln_1.weight[3] = 1.0e6
+        m.reset_caches()
+        m.train()
+        tr = Trainer(m, distributed=False)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            for _ in range(4):
+                loss, _ = tr.step(pc.cuda(), labels)
+                tr.finish()
+        assert tr.demotions and tr.demotions[0][1] & health.BIT_SPLIT, tr.demotions
+        assert m.precision_name == "fp32" and not m.split16
+        assert any(issubclass(c.category, RuntimeWarning) and "split16" in str(c.message) for c in caught)
+        assert np.isfinite(loss.item()) and all(bool(torch.isfinite(p).all()) for p in m.parameters())
+
+
 def test_health_monitor_stays_armed_after_an_event():
     """the flag word used to be sticky -- after the first BIT_POINT / BIT_LOSS event nothing new was ever
     reported, so a LATER half-backward overflow was skipped by AdamW every step, silently, for the rest of the run.  Now the word

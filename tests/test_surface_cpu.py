@@ -402,8 +402,10 @@ def test_set_precision_names():
 
 
 def test_split16_range_fit_lowers_the_weight_prescale_for_huge_weights():
-    """set_precision("split16") checks once that 4 x max|w| x 2^b fits IEEE half (the hi halves of the split weights) and lowers b
-    with a warning otherwise (ULIP_WITH_IMAGE._fit_split16_range)."""
+    """The split16 pre-scale of the weight operand is fitted per MODEL and per WEIGHT SET (ULIP_WITH_IMAGE._fit_split16_range): 4 x
+    max|w| x 2^b must fit IEEE half, b is lowered with a warning otherwise; the result is the model's own `split_pow2` (the
+    process-wide default in ops stays what it was -- ADVICE r5: one model's fit must not change another's), every _cache() call hands
+    it to ops with the flag, and load_state_dict / reset_caches re-arm the fit."""
     import warnings
     from types import SimpleNamespace
     import torch
@@ -413,19 +415,72 @@ def test_split16_range_fit_lowers_the_weight_prescale_for_huge_weights():
                            num_learnable_prompt_tokens=32, gpu=0, task='cls', head_type=0, evaluate_3d=False, ulip2=False,
                            synthetic_weights=True)
     m = M.ULIP_PointBERT(args)
+    other = M.ULIP_PointBERT(args)
     old = ops.SPLIT16_POW2
     try:
         with warnings.catch_warnings():
             warnings.simplefilter("error")
             m._fit_split16_range()                       # freshly initialised weights: nothing to do, no warning
-        assert ops.SPLIT16_POW2 == old
+        assert m.split_pow2 == old and not m._split_fit_pending
         with torch.no_grad():
             m.text_projection[0, 0] = 3000.0
         with warnings.catch_warnings(record=True) as w:
             warnings.simplefilter("always")
             m._fit_split16_range()
         assert any("split16" in str(x.message) for x in w)
-        b = ops.SPLIT16_POW2[1]
+        b = m.split_pow2[1]
         assert b < old[1] and 4.0 * 3000.0 * 2.0 ** b < 32768.0 <= 4.0 * 3000.0 * 2.0 ** (b + 1)
+        assert ops.SPLIT16_POW2 == old and other.split_pow2 == old          # nobody else's pre-scale moved
+        # the flag and the pair travel together: whoever fetched its cache last decides what an un-annotated ops.gemm uses
+        ops.set_split16(True, m.split_pow2)
+        assert ops.SPLIT16_POW2 == m.split_pow2
+        ops.set_split16(True, other.split_pow2)
+        assert ops.SPLIT16_POW2 == old
+        ops.set_split16(False)
+        # new weights re-arm the fit (a checkpoint loaded AFTER set_precision("split16") used never to be looked at)
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        sd["text_projection"][0, 0] = 0.01
+        m.load_state_dict(sd)
+        assert m._split_fit_pending
+        m._fit_split16_range()
+        assert m.split_pow2 == old
     finally:
         ops.SPLIT16_POW2 = old
+        ops.set_split16(False)
+
+
+def test_ahead_stage_orders_itself_behind_every_input():
+    """the copy-complete event rides on the batch OBJECT (DevicePrefetcher), but an ahead stage reads what the
+    encoder derives from it -- `pc.contiguous().float()` is the same object for a contiguous fp32 batch and a NEW tensor, produced on
+    the caller's stream and covered by no event, for anything else.  graphs.wait_inputs: event -> wait for it; no event and no
+    promise from the caller -> fall back to the caller's stream (in-order, never a race); promise (Trainer.inputs_ready) -> nothing."""
+    from ppt_amd import graphs
+
+    class FakeStream:
+        def __init__(self):
+            self.calls = []
+
+        def wait_event(self, e):
+            self.calls.append(("event", e))
+
+        def wait_stream(self, s):
+            self.calls.append(("stream", s))
+
+    batch = torch.zeros(2, 8, 3)
+    batch._ppt_ready = "copy-done"
+    same = batch.contiguous().float()
+    assert same is batch and graphs.ready_event(same) == "copy-done"
+    derived = batch.double().float()                                  # what a non-fp32 / sliced batch turns into
+    assert graphs.ready_event(derived) is None
+    s = FakeStream()
+    graphs.wait_inputs(s, [same], main="caller")
+    assert s.calls == [("event", "copy-done")]
+    s = FakeStream()
+    graphs.wait_inputs(s, [derived], main="caller")
+    assert s.calls == [("stream", "caller")], "a tensor without an event must send the stage behind the caller's stream"
+    s = FakeStream()
+    graphs.wait_inputs(s, [same, derived, derived], main="caller")
+    assert s.calls == [("event", "copy-done"), ("stream", "caller")]
+    s = FakeStream()
+    graphs.wait_inputs(s, [derived], main="caller", vouched=True)     # Trainer.inputs_ready: the caller's promise covers it
+    assert s.calls == []
