@@ -693,8 +693,14 @@ def main():
         dist.barrier()                       # rank 0 spends a few seconds more (roofline passes): tear down together
         dist.destroy_process_group()
     if rank == 0:
-        # (after the teardown: RCCL writes a "Librccl path" line to stdout on the way; the JSON line stays the LAST line)
+        # (after the teardown: RCCL writes its version banner / "Librccl path" to the C library's stdout, which is flushed at exit --
+        # i.e. BEHIND anything Python printed.  Flush the C stream first, so that the JSON line stays the LAST line of the output.)
         sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
 
 

@@ -279,6 +279,15 @@ int ppt_vit_mlp_retile(const void *W1, const void *W2, void *W1_tiled, void *W2_
 int ppt_vit_proj_retile(const void *Wp, void *Wp_tiled, void *stream);
 int ppt_vit_mlp_bf16(const ppt_vit_mlp_params *p, void *stream);
 
+/* ABI 7 -- the same contract on a different schedule (csrc/mlp_fused3.hip): 256-unit hidden slabs (every LDS fragment of fc1
+ * feeds two MFMAs), the GELU of slab j + 1 issued between the MFMAs of fc2 on slab j, the fc2 accumulators STARTING at the
+ * residual (x, or x_mid of the proj prologue: no x_mid round trip through memory, no residual read in the epilogue; DropPath's
+ * factor rides on the GELU output), weights through two register rings.  W1 / W2 must come from ppt_vit_mlp3_retile
+ * ([slab 6][wave 8][k-step 12][half 2][lane 64][8] / [slab 6][wave 8][k-step 8][column block 3][lane 64][8]); proj_W from
+ * ppt_vit_proj_retile as before.  With proj_a set, `out` receives only the FINAL rows (x_mid is never written). */
+int ppt_vit_mlp3_retile(const void *W1, const void *W2, void *W1_tiled, void *W2_tiled, void *stream);
+int ppt_vit_mlp3_bf16(const ppt_vit_mlp_params *p, void *stream);
+
 /* ---- LayerNorm --------------------------------------------------------------------------------
  * Replaces nn.LayerNorm at point_encoder.py:65,69,152 and ULIP_models.py:21-27,39,46,176.
  * fwd: xs = x (+ add); y = LN(xs)*w + b.  x, add, xs f32 [M,D] (xs may alias x, may be NULL);

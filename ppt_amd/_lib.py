@@ -102,6 +102,8 @@ _SIGNATURES = {
     "ppt_vit_mlp_retile": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ppt_vit_proj_retile": (c_int, [c_void_p, c_void_p, c_void_p]),
     "ppt_vit_mlp_bf16": (c_int, [ctypes.POINTER(VitMlpParams), c_void_p]),
+    "ppt_vit_mlp3_retile": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ppt_vit_mlp3_bf16": (c_int, [ctypes.POINTER(VitMlpParams), c_void_p]),
     "ppt_rowgemm_bf16": (c_int, [ctypes.POINTER(RowGemmParams), c_void_p]),
     "ppt_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                   c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),

@@ -244,7 +244,7 @@ def mini_pointnet(sd, p, wc, nbhd, bn_train, update_running=True):
 def _mlp_weights(sd, p, wc):
     """fc1 / fc2 of block `p` in the fragment order of csrc/mlp_fused.hip (re-made when a weight's version changes)."""
     w1, w2 = sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc2.weight"]
-    return wc.derived(("vit_mlp_tiled", p), (w1, w2), lambda: ops.vit_mlp_retile(wc.get(w1), wc.get(w2)))
+    return wc.derived(("vit_mlp_tiled", p, ops.VIT_MLP_VARIANT), (w1, w2), lambda: ops.vit_mlp_retile(wc.get(w1), wc.get(w2)))
 
 
 def vit_block_forward(sd, p, wc, x, pos, B, Tn, heads, dp1, dp2, save=None, pos_in_x=False, add_pos_out=False):

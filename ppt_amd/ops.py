@@ -365,13 +365,23 @@ def rows_matmul(a, w_kn, alpha=1.0):
     return out
 
 
-def vit_mlp_retile(w1, w2):
-    """(w1 [1536,384], w2 [384,1536]) bf16 -> the fragment-ordered copies ppt_vit_mlp_bf16 reads (ppt_vit_mlp_retile)."""
+# Which schedule of the fused frozen-block kernel runs (supported switch): 3 = csrc/mlp_fused3.hip (round 6: 256-unit
+# slabs, GELU under fc2's MFMAs, residual kept in the accumulators), 2 = csrc/mlp_fused.hip (rounds 2-5).  The fragment-ordered
+# weight copies differ, so vit_mlp_retile tags what it returns and vit_mlp follows the tag.
+VIT_MLP_VARIANT = int(os.environ.get("PPT_VIT_MLP", "3"))
+
+
+def vit_mlp_retile(w1, w2, variant=None):
+    """(w1 [1536,384], w2 [384,1536]) 16-bit -> the fragment-ordered copies the fused kernel reads (ppt_vit_mlp_retile for
+    variant 2, ppt_vit_mlp3_retile for variant 3; default VIT_MLP_VARIANT)."""
     assert w1.dtype in HALF and w2.dtype == w1.dtype
     _chk(w1, w1.dtype, "w1"); _chk(w2, w1.dtype, "w2")
     assert tuple(w1.shape) == (1536, 384) and tuple(w2.shape) == (384, 1536)
+    variant = VIT_MLP_VARIANT if variant is None else int(variant)
     w1t, w2t = torch.empty_like(w1), torch.empty_like(w2)
-    _lib.check(_lib.lib().ppt_vit_mlp_retile(_p(w1), _p(w2), _p(w1t), _p(w2t), _stream()), "ppt_vit_mlp_retile")
+    fn = _lib.lib().ppt_vit_mlp3_retile if variant == 3 else _lib.lib().ppt_vit_mlp_retile
+    _lib.check(fn(_p(w1), _p(w2), _p(w1t), _p(w2t), _stream()), "ppt_vit_mlp_retile")
+    w1t.ppt_variant = w2t.ppt_variant = variant          # (a plain attribute, like the copy event of data/prefetch.py)
     return w1t, w2t
 
 
@@ -407,7 +417,12 @@ def vit_mlp(x, w1, b1, w2, b2, ln, *, out=None, ln_eps=1e-5, row_scale=None, row
         flops += 2.0 * M * D * D
     if profiler is not None:
         profiler.begin("gemm_bf16", flops, "ppt_vit_mlp_bf16 (" + ("proj + residual + " if proj is not None else "") + "LN + fc1 + GELU + fc2 + residual)")
-    _lib.check(_lib.lib().ppt_vit_mlp_bf16(ctypes.byref(p), _stream()), "ppt_vit_mlp_bf16")
+    variant = getattr(w1, "ppt_variant", 2)                  # (the order the weights were re-tiled in decides the kernel)
+    assert getattr(w2, "ppt_variant", 2) == variant
+    if variant == 3:
+        _lib.check(_lib.lib().ppt_vit_mlp3_bf16(ctypes.byref(p), _stream()), "ppt_vit_mlp3_bf16")
+    else:
+        _lib.check(_lib.lib().ppt_vit_mlp_bf16(ctypes.byref(p), _stream()), "ppt_vit_mlp_bf16")
     if profiler is not None:
         profiler.end()
     return out

@@ -1405,8 +1405,9 @@ def test_prompt_rows_are_the_prompt_learner_splice(ops, position):
 
 
 # ------------------------------------------------------------------ fused ViT MLP (csrc/mlp_fused.hip)
+@pytest.mark.parametrize("variant", [2, 3])              # csrc/mlp_fused.hip / csrc/mlp_fused3.hip (round 6): same contract, same bounds
 @pytest.mark.parametrize("M,rows,pos", [(16416, 513, True), (32832, 513, False), (513, 513, True), (1000, 0, False), (77, 11, True)])
-def test_vit_mlp_matches_the_unfused_chain(ops, M, rows, pos):
+def test_vit_mlp_matches_the_unfused_chain(ops, M, rows, pos, variant):
     """ppt_vit_mlp_bf16 (LayerNorm + fc1 + GELU + fc2 + DropPath + residual (+ pos) in one kernel) against (a) fp32 torch math
     on the bf16-rounded operands the MFMAs see and (b) the unfused kernels (ppt_layernorm_fwd + 2 x ppt_gemm); in place and
     out of place; bit-reproducible."""
@@ -1423,7 +1424,7 @@ def test_vit_mlp_matches_the_unfused_chain(ops, M, rows, pos):
     y = u @ _bf(w2).t() + b2
     want = x + (y * rs.repeat_interleave(rows)[:M, None] if rows else y) + (r2 if pos else 0)
     xd, w1d, w2d = x.cuda(), w1.cuda().to(torch.bfloat16), w2.cuda().to(torch.bfloat16)
-    w1t, w2t = ops.vit_mlp_retile(w1d, w2d)
+    w1t, w2t = ops.vit_mlp_retile(w1d, w2d, variant=variant)
     kw = dict(row_scale=rs.cuda(), row_scale_rows=rows) if rows else {}
     out = torch.empty_like(xd)
     ops.vit_mlp(xd, w1t, b1.cuda(), w2t, b2.cuda(), (gam.cuda(), bet.cuda()), out=out, residual2=r2.cuda() if pos else None, **kw)
@@ -1439,9 +1440,10 @@ def test_vit_mlp_matches_the_unfused_chain(ops, M, rows, pos):
     assert torch.equal(x2, out)
 
 
+@pytest.mark.parametrize("variant", [2, 3])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,rows", [(16416, 513), (1000, 0), (83, 7)])
-def test_vit_mlp_with_the_proj_prologue_matches_proj_then_mlp(ops, M, rows, dtype):
+def test_vit_mlp_with_the_proj_prologue_matches_proj_then_mlp(ops, M, rows, dtype, variant):
     """ppt_vit_mlp_bf16 with proj_a set (x_mid = x + drop_path1 * (a Wp^T + bp) formed in front, then the MLP branch on it)
     against the two launches it replaces -- ppt_rowgemm_bf16 in residual form, then the plain fused MLP -- and against fp32
     torch math on the operands the MFMAs see; in place; bit-reproducible; ragged last chunk."""
@@ -1464,7 +1466,7 @@ def test_vit_mlp_with_the_proj_prologue_matches_proj_then_mlp(ops, M, rows, dtyp
     y2 = u @ rd(w2).t() + b2
     want = xm + (y2 * rs2.repeat_interleave(rows)[:M, None] if rows else y2)
     xd, ad = x.cuda(), a.cuda().to(dtype)
-    w1t, w2t = ops.vit_mlp_retile(w1.cuda().to(dtype), w2.cuda().to(dtype))
+    w1t, w2t = ops.vit_mlp_retile(w1.cuda().to(dtype), w2.cuda().to(dtype), variant=variant)
     wpd = wp.cuda().to(dtype)
     wpt = ops.vit_proj_retile(wpd)
     kw = dict(row_scale=rs2.cuda(), row_scale_rows=rows) if rows else {}
