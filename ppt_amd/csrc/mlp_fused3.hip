@@ -14,7 +14,7 @@
 //       work; its result goes to the other half of a double-buffered slab, ONE barrier per slab;
 //   (3) the fc2 accumulators START at x_mid (the proj prologue's result, or x): the residual never leaves registers -- no x_mid
 //       round trip, no residual read in the epilogue.  DropPath's per-sample factor rides on the GELU output (rs * U) W2 = rs * (U W2);
-//   (4) the weights arrive through two register rings (fc1: 4 k-steps = 8 KiB, fc2: 4 k-steps = 12 KiB per wave) that wrap from one
+//   (4) the weights arrive through two register rings (fc1: 4 k-steps = 8 KiB, fc2: 2 k-steps = 6 KiB per wave) that wrap from one
 //       slab into the next and from the last slab back to the first: the stream never stops at a phase boundary.
 // Arithmetic differs from mlp_fused.hip only in rounding ORDER (residual first instead of last; rs folded before the 16-bit
 // rounding of U): tests/test_kernels_gpu.py holds both to the same bounds against fp32 math on the same operands.
@@ -32,7 +32,7 @@ constexpr int HP = 2 * D + 32, UP = 2 * HC + 32;                   // LDS pitche
 constexpr int H2_BYTES = R * HP, U_BYTES = R * UP;
 constexpr int LDS_BYTES = H2_BYTES + 2 * U_BYTES + (2 * D + HID + D) * 4;
 constexpr int K1 = D / 32, K2 = HC / 32;                           // k-steps of GEMM1 (12) / GEMM2 (8) per slab
-constexpr int D1 = 4, D2 = 4;                                      // ring depths in k-steps (must divide K1 / K2)
+constexpr int D1 = 4, D2 = 2;                                      // ring depths in k-steps (must divide K1 / K2)
 static_assert(K1 % D1 == 0 && K2 % D2 == 0, "ring slots must line up from slab to slab");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 constexpr int W1_BYTES = HID * D * 2, W2_BYTES = D * HID * 2;
@@ -65,8 +65,22 @@ __device__ __forceinline__ float gelu_poly3(float x)
     return fmaf(h, e, h);
 }
 
+// A workgroup barrier for LDS hand-overs ONLY: the LDS operations of this wave are complete (lgkmcnt(0)), global loads stay in
+// flight.  __syncthreads() is a workgroup-scope release + acquire around s_barrier, i.e. s_waitcnt vmcnt(0): every barrier of the
+// slab loop drained the weight rings (in-kernel stamps: ~1 200 cycles per slab at the barrier), and the barrier at the end of the
+// prologue waited for the ring fill it was meant to overlap.  Nothing in this kernel hands GLOBAL data from wave to wave.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 #ifdef PPT_MLP3_STAMP
-#define MLP3_STAMP(j, slot) do { if (lane == 0 && chunk == (int)blockIdx.x) stamps[((size_t)(blockIdx.x * 8 + w) * 8 + (j)) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#ifndef PPT_MLP3_STAMP_CHUNK
+#define PPT_MLP3_STAMP_CHUNK 0           /* which of the workgroup's chunks is stamped (1: the second -- warm instruction cache / TLBs) */
+#endif
+#define MLP3_STAMP(j, slot) do { if (lane == 0 && chunk == (int)(blockIdx.x + PPT_MLP3_STAMP_CHUNK * gridDim.x)) stamps[((size_t)(blockIdx.x * 8 + w) * 8 + (j)) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define MLP3_STAMP(j, slot) do { } while (0)
 #endif
@@ -77,24 +91,38 @@ __global__ __launch_bounds__(512, 2) void vit_mlp3_kernel(const ppt_vit_mlp_para
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char *h2 = smem, *ub = smem + H2_BYTES;
     float *gam = reinterpret_cast<float *>(smem + H2_BYTES + 2 * U_BYTES), *bet = gam + D, *b1s = bet + D, *b2s = b1s + HID;
-    const int lane = threadIdx.x & 63;
+    int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int l15 = lane & 15, kg = lane >> 4;
-
-    for (int c = threadIdx.x; c < D; c += 512) { gam[c] = p.ln_w[c]; bet[c] = p.ln_b[c]; b2s[c] = p.b2 ? p.b2[c] : 0.f; }
-    for (int c = threadIdx.x; c < HID; c += 512) b1s[c] = p.b1 ? p.b1[c] : 0.f;
+    int l15 = lane & 15, kg = lane >> 4, lo16 = lane * 16;
+    // Every phase re-derives its per-lane addresses from an OPAQUE copy of the lane id.  Left alone, hipcc hoists every per-lane
+    // address of the whole kernel (LDS fragment bases, row offsets, statistics slots ...) to the entry, finds no room for ~70 of
+    // them beside the slab loop's 250 registers, spills them there and reloads them where they are used -- and each scratch
+    // reload is followed by s_waitcnt vmcnt(0): in the prologue that drained the residual loads once per row block.
+#define RELANE() do { asm volatile("" : "+v"(lane)); l15 = lane & 15; kg = lane >> 4; lo16 = lane * 16; } while (0)
 
     // fragment-ordered weights (ppt_vit_mlp3_retile): one wave-instruction = 1 KiB of consecutive bytes
     //   W1t[j][w][ks < 12][h < 2][lane][8] = W1[256 j + 32 w + 16 h + l15][32 ks + 8 kg ..)
     //   W2t[j][w][ks < 8][nb < 3][lane][8] = W2[48 w + 16 nb + l15][256 j + 32 ks + 8 kg ..)
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.W1), 0, W1_BYTES, 0x00020000);
     const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.W2), 0, W2_BYTES, 0x00020000);
-    const int lo16 = lane * 16;
-    auto ld1 = [&](int j, int ks, int h) {
-        return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r1, lo16, (((j * 8 + w) * K1 + ks) * 2 + h) * 1024, 0));
+    // Each wave consumes its fragments in the order they lie in memory (24 KiB per slab and weight, then 7 x 24 KiB of the other
+    // waves' to skip), so each ring is fed from ONE running scalar offset.  (First version: offsets computed from (slab, k-step)
+    // at every load -- hipcc kept the ~48 per-k-step constants live in SGPRs across the slab loop, spilled 50 of them into VGPR
+    // lanes and those VGPRs to scratch; every scratch reload is followed by s_waitcnt vmcnt(0), which in the prologue drained the
+    // residual loads fifteen times: 19 000 cycles to ISSUE 25 loads.)  Past the last slab the offset leaves the buffer: such a
+    // buffer load fetches nothing and returns zeros -- no wrap-around prefetch to pay for.
+    constexpr int WAVE_SLAB = 24 * 1024;                                 // bytes of one wave's fragments per slab (either weight)
+    int o1 = 0, o2 = 0;
+    auto next1 = [&](uint4 &fa, uint4 &fb) {                             // the next k-step of the fc1 ring: two fragments
+        fa = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r1, lo16, o1, 0));
+        fb = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r1, lo16 + 1024, o1, 0));
+        o1 += 2048;
     };
-    auto ld2 = [&](int j, int ks, int nb) {
-        return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r2, lo16, (((j * 8 + w) * K2 + ks) * 3 + nb) * 1024, 0));
+    auto next2 = [&](uint4 (&f)[3]) {                                    // the next k-step of the fc2 ring: three fragments
+        f[0] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r2, lo16, o2, 0));
+        f[1] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r2, lo16 + 1024, o2, 0));
+        f[2] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r2, lo16 + 2048, o2, 0));
+        o2 += 3072;
     };
 #ifdef PPT_MLP3_STAMP
     unsigned long long *stamps = (unsigned long long *)p.residual2;
@@ -102,38 +130,67 @@ __global__ __launch_bounds__(512, 2) void vit_mlp3_kernel(const ppt_vit_mlp_para
 
     for (int chunk = blockIdx.x; chunk < p.n_chunks; chunk += gridDim.x) {
         MLP3_STAMP(6, 0);
+        RELANE();
         const int row0 = chunk * p.rows_per_chunk;
         const int nrow = min(p.rows_per_chunk, p.M - row0);
-        __syncthreads();                                                 // constants are in LDS; the previous chunk's readers are done
-        // acc2[rb][nb]: columns 48 w + 16 nb + 4 kg .. + 3 of row 16 rb + l15.  It STARTS as the residual (x, or x_mid below)
+        lds_barrier();                                                   // the previous chunk's readers are done
+        MLP3_STAMP(5, 1);
+        // acc2[rb][nb]: columns 48 w + 16 nb + 4 kg .. + 3 of row 16 rb + l15.  It STARTS as the residual (x, or x_mid below).
+        // The residual rows are requested FIRST, in this layout, and nothing else reads x: the LayerNorm statistics are formed from
+        // the accumulator layout too (first version: a separate 16-threads-per-row LayerNorm pass over x in three dependent
+        // load -> reduce -> write rounds, then a second read of x for the accumulators -- 41 000 cycles of prologue per chunk).
         f32x4_t acc2[RB][3];
-        if (p.proj_a) {
-            // ---- (a) the chunk's rows of the attention output -> LDS image (rows past the chunk: zeros)
-            {
-                const bf16_t *A = (const bf16_t *)p.proj_a;
-                for (int i = threadIdx.x; i < R * (D / 8); i += 512) {
-                    const int lr = i / (D / 8), c8 = i % (D / 8);
-                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                    if (lr < nrow) v = *reinterpret_cast<const uint4 *>(A + (size_t)(row0 + lr) * D + 8 * c8);
-                    *reinterpret_cast<uint4 *>(h2 + lr * HP + 16 * c8) = v;
-                }
+        float rs[RB], rs1[RB];
+        uint4 g1[D1][2], g2[D2][3];                                      // the two weight rings
+        {
+            float4 xv[RB][3];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const int m = row0 + min(16 * rb + l15, nrow - 1);
+#pragma unroll
+                for (int nb = 0; nb < 3; ++nb) xv[rb][nb] = *reinterpret_cast<const float4 *>(p.x + (size_t)m * D + 48 * w + 16 * nb + 4 * kg);
             }
-            __syncthreads();
-            // ---- (b) acc2 = a . Wp^T, Wp in fragment order (ppt_vit_proj_retile: [w][12 nb + ks][lane][8]) four k-steps deep
-            const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.proj_W), 0, 8 * 36 * 64 * 16, 0x00020000);
-            auto pfrag = [&](int nb, int ks) {
-                return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lo16, (w * 36 + nb * 12 + ks) * 1024, 0));
-            };
+            // DropPath's per-sample factors (both branches), per row block of this lane: requested now, used far below
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-                for (int nb = 0; nb < 3; ++nb) acc2[rb][nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            {
+            for (int rb = 0; rb < RB; ++rb) {
+                const int m = row0 + min(16 * rb + l15, nrow - 1);
+                rs[rb] = p.row_scale ? p.row_scale[m / p.row_scale_rows] : 1.0f;
+                rs1[rb] = (p.proj_a && p.proj_row_scale) ? p.proj_row_scale[m / p.proj_row_scale_rows] : 1.0f;
+            }
+            if (chunk == (int)blockIdx.x) {
+                // the per-channel constants -> LDS, once per workgroup, BEHIND the first chunk's loads (in front of them the
+                // kernel's first memory round trip fetched 10 KB and nothing else)
+                for (int c = threadIdx.x; c < D; c += 512) { gam[c] = p.ln_w[c]; bet[c] = p.ln_b[c]; b2s[c] = p.b2 ? p.b2[c] : 0.f; }
+                for (int c = threadIdx.x; c < HID; c += 512) b1s[c] = p.b1 ? p.b1[c] : 0.f;
+            }
+            MLP3_STAMP(5, 2);
+            if (p.proj_a) {
+                // ---- (a) the chunk's rows of the attention output -> LDS image (rows past the chunk: zeros)
+                {
+                    const bf16_t *A = (const bf16_t *)p.proj_a;
+                    for (int i = threadIdx.x; i < R * (D / 8); i += 512) {
+                        const int lr = i / (D / 8), c8 = i % (D / 8);
+                        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                        if (lr < nrow) v = *reinterpret_cast<const uint4 *>(A + (size_t)(row0 + lr) * D + 8 * c8);
+                        *reinterpret_cast<uint4 *>(h2 + lr * HP + 16 * c8) = v;
+                    }
+                }
+                // ---- (b) acc2 = a . Wp^T, Wp in fragment order (ppt_vit_proj_retile: [w][12 nb + ks][lane][8]) four k-steps deep
+                const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.proj_W), 0, 8 * 36 * 64 * 16, 0x00020000);
+                auto pfrag = [&](int nb, int ks) {
+                    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lo16, (w * 36 + nb * 12 + ks) * 1024, 0));
+                };
                 uint4 wf[4][3];
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                     for (int nb = 0; nb < 3; ++nb) wf[ks][nb] = pfrag(nb, ks);
+                lds_barrier();
+                MLP3_STAMP(5, 3);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int nb = 0; nb < 3; ++nb) acc2[rb][nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
                 const unsigned char *ha = h2 + l15 * HP + 16 * kg;
 #pragma unroll
                 for (int ks = 0; ks < K1; ++ks) {
@@ -148,35 +205,57 @@ __global__ __launch_bounds__(512, 2) void vit_mlp3_kernel(const ppt_vit_mlp_para
                         for (int nb = 0; nb < 3; ++nb) wf[ks & 3][nb] = pfrag(nb, ks + 4);
                     }
                 }
+                MLP3_STAMP(5, 4);
+                // ---- (c) x_mid = x + drop_path1 * (acc + bp): STAYS in acc2
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    const float r1 = rs1[rb];
+#pragma unroll
+                    for (int nb = 0; nb < 3; ++nb) {
+                        const int n = 48 * w + 16 * nb + 4 * kg;
+                        const float4 bv = p.proj_b ? *reinterpret_cast<const float4 *>(p.proj_b + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        acc2[rb][nb][0] = (acc2[rb][nb][0] + bv.x) * r1 + xv[rb][nb].x; acc2[rb][nb][1] = (acc2[rb][nb][1] + bv.y) * r1 + xv[rb][nb].y;
+                        acc2[rb][nb][2] = (acc2[rb][nb][2] + bv.z) * r1 + xv[rb][nb].z; acc2[rb][nb][3] = (acc2[rb][nb][3] + bv.w) * r1 + xv[rb][nb].w;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int nb = 0; nb < 3; ++nb) acc2[rb][nb] = f32x4_t{xv[rb][nb].x, xv[rb][nb].y, xv[rb][nb].z, xv[rb][nb].w};
             }
-            // ---- (c) x_mid = x + drop_path1 * (acc + bp): STAYS in acc2; partial row sums -> LDS
+        }
+        MLP3_STAMP(5, 5);
+        RELANE();
+        // the two rings, filled per chunk, BEHIND the residual / proj phase and in front of the statistics' five barriers (kept live
+        // from kernel entry, wrapping from the last slab into the next chunk's first, hipcc spilled all 80 ring registers around
+        // the prologue -- 81 scratch stores right behind the loads)
+        o1 = o2 = w * WAVE_SLAB;
+#pragma unroll
+        for (int s = 0; s < D1; ++s) next1(g1[s][0], g1[s][1]);
+#pragma unroll
+        for (int s = 0; s < D2; ++s) next2(g2[s]);
+        // ---- LayerNorm of the residual rows FROM the accumulator layout (two passes, as nn.LayerNorm): a lane holds 12 of a row's 384
+        // values per row block; the 32 partials of a row (8 waves x 4 lane groups) meet in LDS (the slab buffers are idle until GEMM1)
+        {
             float *psum = reinterpret_cast<float *>(ub);                  // [R][32] partials, then [R] mean / rstd behind them
             float *stat = psum + R * 32;
+            if (p.proj_a) lds_barrier();                                  // every wave is done reading `a` from the image
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
-                const int lr = 16 * rb + l15;
-                const int m = row0 + min(lr, nrow - 1);
-                const float rs1 = p.proj_row_scale ? p.proj_row_scale[m / p.proj_row_scale_rows] : 1.0f;
                 float sum = 0.f;
 #pragma unroll
-                for (int nb = 0; nb < 3; ++nb) {
-                    const int n = 48 * w + 16 * nb + 4 * kg;
-                    const float4 xv = *reinterpret_cast<const float4 *>(p.x + (size_t)m * D + n);
-                    const float4 bv = p.proj_b ? *reinterpret_cast<const float4 *>(p.proj_b + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    acc2[rb][nb][0] = (acc2[rb][nb][0] + bv.x) * rs1 + xv.x; acc2[rb][nb][1] = (acc2[rb][nb][1] + bv.y) * rs1 + xv.y;
-                    acc2[rb][nb][2] = (acc2[rb][nb][2] + bv.z) * rs1 + xv.z; acc2[rb][nb][3] = (acc2[rb][nb][3] + bv.w) * rs1 + xv.w;
-                    sum += (acc2[rb][nb][0] + acc2[rb][nb][1]) + (acc2[rb][nb][2] + acc2[rb][nb][3]);
-                }
-                psum[lr * 32 + 4 * w + kg] = sum;
+                for (int nb = 0; nb < 3; ++nb) sum += (acc2[rb][nb][0] + acc2[rb][nb][1]) + (acc2[rb][nb][2] + acc2[rb][nb][3]);
+                psum[(16 * rb + l15) * 32 + 4 * w + kg] = sum;
             }
-            __syncthreads();                                              // (also: every wave is done reading `a` from the image)
+            lds_barrier();
             if (threadIdx.x < R) {
                 float t = 0.f;
 #pragma unroll
                 for (int i = 0; i < 32; ++i) t += psum[threadIdx.x * 32 + i];
                 stat[threadIdx.x] = t * (1.0f / (float)D);
             }
-            __syncthreads();
+            lds_barrier();
             float mean_r[RB];
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
@@ -189,15 +268,14 @@ __global__ __launch_bounds__(512, 2) void vit_mlp3_kernel(const ppt_vit_mlp_para
                     for (int i = 0; i < 4; ++i) { const float d = acc2[rb][nb][i] - mean_r[rb]; q = fmaf(d, d, q); }
                 psum[lr * 32 + 4 * w + kg] = q;
             }
-            __syncthreads();
+            lds_barrier();
             if (threadIdx.x < R) {
                 float t = 0.f;
 #pragma unroll
                 for (int i = 0; i < 32; ++i) t += psum[threadIdx.x * 32 + i];
                 stat[R + threadIdx.x] = 1.0f / sqrtf(t * (1.0f / (float)D) + p.ln_eps);
             }
-            __syncthreads();
-            // ---- (d) LayerNorm(x_mid) -> the image (rows past the chunk: zeros)
+            lds_barrier();
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 const int lr = 16 * rb + l15;
@@ -213,73 +291,11 @@ __global__ __launch_bounds__(512, 2) void vit_mlp3_kernel(const ppt_vit_mlp_para
                     *reinterpret_cast<uint2 *>(h2 + lr * HP + 2 * n) = o;
                 }
             }
-        } else {
-            // ---- LayerNorm of the chunk's rows -> H2: 16 threads per row, 32 rows per pass; rows past the chunk are zeros
-            const int r = threadIdx.x >> 4, jj = threadIdx.x & 15;
-            for (int pass = 0; pass < (R + 31) / 32; ++pass) {
-                const int lr = pass * 32 + r;
-                if (lr < R) {
-                    unsigned char *dst = h2 + lr * HP;
-                    if (lr < nrow) {
-                        const float *src = p.x + (size_t)(row0 + lr) * D;
-                        float4 xf[D / 64];
-#pragma unroll
-                        for (int i = 0; i < D / 64; ++i) xf[i] = *reinterpret_cast<const float4 *>(src + 4 * (jj + 16 * i));
-                        float s = 0.f;
-#pragma unroll
-                        for (int i = 0; i < D / 64; ++i) s += (xf[i].x + xf[i].y) + (xf[i].z + xf[i].w);
-                        const float mean = row16_sum3(s) * (1.0f / (float)D);
-                        float q = 0.f;
-#pragma unroll
-                        for (int i = 0; i < D / 64; ++i) {
-                            const float d0 = xf[i].x - mean, d1 = xf[i].y - mean, d2 = xf[i].z - mean, d3 = xf[i].w - mean;
-                            q = fmaf(d0, d0, q); q = fmaf(d1, d1, q); q = fmaf(d2, d2, q); q = fmaf(d3, d3, q);
-                        }
-                        const float rstd = 1.0f / sqrtf(row16_sum3(q) * (1.0f / (float)D) + p.ln_eps);
-#pragma unroll
-                        for (int i = 0; i < D / 64; ++i) {
-                            const int cc = 4 * (jj + 16 * i);
-                            const float4 g = *reinterpret_cast<const float4 *>(gam + cc), b = *reinterpret_cast<const float4 *>(bet + cc);
-                            const float o0 = (xf[i].x - mean) * rstd * g.x + b.x, o1 = (xf[i].y - mean) * rstd * g.y + b.y;
-                            const float o2 = (xf[i].z - mean) * rstd * g.z + b.z, o3 = (xf[i].w - mean) * rstd * g.w + b.w;
-                            *reinterpret_cast<uint2 *>(dst + 2 * cc) = make_uint2(h16<F>::pack2(o0, o1), h16<F>::pack2(o2, o3));
-                        }
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < D / 64; ++i) *reinterpret_cast<uint2 *>(dst + 8 * (jj + 16 * i)) = make_uint2(0u, 0u);
-                    }
-                }
-            }
-            // the residual rows in the accumulator layout (a second read of x: L2-warm, the LayerNorm pass above just had them)
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) {
-                const int m = row0 + min(16 * rb + l15, nrow - 1);
-#pragma unroll
-                for (int nb = 0; nb < 3; ++nb) {
-                    const float4 xv = *reinterpret_cast<const float4 *>(p.x + (size_t)m * D + 48 * w + 16 * nb + 4 * kg);
-                    acc2[rb][nb] = f32x4_t{xv.x, xv.y, xv.z, xv.w};
-                }
-            }
         }
-        // DropPath's per-sample factor of the MLP branch, per row block of this lane
-        float rs[RB];
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
-            const int m = row0 + min(16 * rb + l15, nrow - 1);
-            rs[rb] = p.row_scale ? p.row_scale[m / p.row_scale_rows] : 1.0f;
-        }
-        // the two rings, filled per chunk BEHIND the prologue: kept live across it (filled once at kernel entry, wrapping from the
-        // last slab into the next chunk's first) hipcc spilled all 80 ring registers around the prologue -- 81 scratch stores
-        // right behind the loads.  The fill is in flight during the barrier below.
-        uint4 g1[D1][2], g2[D2][3];
-#pragma unroll
-        for (int s = 0; s < D1; ++s) { g1[s][0] = ld1(0, s, 0); g1[s][1] = ld1(0, s, 1); }
-#pragma unroll
-        for (int s = 0; s < D2; ++s)
-#pragma unroll
-            for (int nb = 0; nb < 3; ++nb) g2[s][nb] = ld2(0, s, nb);
-        __syncthreads();                                                 // the image is complete (and psum / stat are dead: ub is free)
+        MLP3_STAMP(5, 6);
+        lds_barrier();                                                   // the image is complete (and psum / stat are dead: ub is free)
         MLP3_STAMP(6, 1);
+        RELANE();
 
         f32x4_t a1[RB][2];
         // GEMM1(jj): a1 = W1[slab jj, this wave's 32 units] . H2^T -- every H2 fragment feeds two MFMAs; the ring slot a k-step used
@@ -288,18 +304,26 @@ __global__ __launch_bounds__(512, 2) void vit_mlp3_kernel(const ppt_vit_mlp_para
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) { a1[rb][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; a1[rb][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
             const unsigned char *ha = h2 + l15 * HP + 16 * kg;
-            const int jn = jj + 1 < NJ ? jj + 1 : 0;
+            // the H2 fragments of k-step ks + 1 are requested before the MFMAs of k-step ks (two register sets): left to itself hipcc
+            // emitted read -> wait -> two MFMAs, one LDS latency per pair (in-kernel stamps: 5 400 cycles for 3 840 of matrix work)
+            uint4 fa[2][RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) fa[0][rb] = *reinterpret_cast<const uint4 *>(ha + rb * 16 * HP);
 #pragma unroll
             for (int ks = 0; ks < K1; ++ks) {
+                if (ks + 1 < K1) {
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) fa[(ks + 1) & 1][rb] = *reinterpret_cast<const uint4 *>(ha + rb * 16 * HP + 64 * (ks + 1));
+                }
                 const uint4 wa = g1[ks % D1][0], wb = g1[ks % D1][1];
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) {
-                    const uint4 f = *reinterpret_cast<const uint4 *>(ha + rb * 16 * HP + 64 * ks);
-                    a1[rb][0] = h16<F>::mfma16(wa, f, a1[rb][0]);
-                    a1[rb][1] = h16<F>::mfma16(wb, f, a1[rb][1]);
+                    a1[rb][0] = h16<F>::mfma16(wa, fa[ks & 1][rb], a1[rb][0]);
+                    a1[rb][1] = h16<F>::mfma16(wb, fa[ks & 1][rb], a1[rb][1]);
                 }
-                if (ks + D1 < K1) { g1[ks % D1][0] = ld1(jj, ks + D1, 0); g1[ks % D1][1] = ld1(jj, ks + D1, 1); }
-                else { g1[ks % D1][0] = ld1(jn, ks + D1 - K1, 0); g1[ks % D1][1] = ld1(jn, ks + D1 - K1, 1); }
+                if (ks + D1 == K1) o1 += 7 * WAVE_SLAB;                   // the ring moves on to this wave's part of the next slab
+                next1(g1[ks % D1][0], g1[ks % D1][1]);
+                __builtin_amdgcn_sched_barrier(0);                        // (k-steps stay in order: the scheduler may not pull reads back behind their use)
             }
         };
         // GELU of pair q = (rb, h) of a1 (slab jj) -> U[jj & 1], scaled by the row's DropPath factor
@@ -316,29 +340,33 @@ __global__ __launch_bounds__(512, 2) void vit_mlp3_kernel(const ppt_vit_mlp_para
         auto gemm2 = [&](int j, auto with_gelu_c) {
             constexpr bool with_gelu = decltype(with_gelu_c)::value;
             const unsigned char *ua = ub + (j & 1) * U_BYTES + l15 * UP + 16 * kg;
-            const int jn = j + 1 < NJ ? j + 1 : 0;
+            uint4 fu[2][RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) fu[0][rb] = *reinterpret_cast<const uint4 *>(ua + rb * 16 * UP);
 #pragma unroll
             for (int ks = 0; ks < K2; ++ks) {
+                if (ks + 1 < K2) {
 #pragma unroll
-                for (int rb = 0; rb < RB; ++rb) {
-                    const uint4 f = *reinterpret_cast<const uint4 *>(ua + rb * 16 * UP + 64 * ks);
-#pragma unroll
-                    for (int nb = 0; nb < 3; ++nb) acc2[rb][nb] = h16<F>::mfma16(g2[ks % D2][nb], f, acc2[rb][nb]);
+                    for (int rb = 0; rb < RB; ++rb) fu[(ks + 1) & 1][rb] = *reinterpret_cast<const uint4 *>(ua + rb * 16 * UP + 64 * (ks + 1));
                 }
 #pragma unroll
-                for (int nb = 0; nb < 3; ++nb)
-                    g2[ks % D2][nb] = ks + D2 < K2 ? ld2(j, ks + D2, nb) : ld2(jn, ks + D2 - K2, nb);
-                if (with_gelu) {                                         // 2 RB = 10 pairs over 8 k-steps
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int nb = 0; nb < 3; ++nb) acc2[rb][nb] = h16<F>::mfma16(g2[ks % D2][nb], fu[ks & 1][rb], acc2[rb][nb]);
+                if (ks + D2 == K2) o2 += 7 * WAVE_SLAB;
+                next2(g2[ks % D2]);
+                if constexpr (with_gelu) {                               // 2 RB = 10 pairs over 8 k-steps
                     gelu_pair(j + 1, ks);
                     if (ks < 2 * RB - K2) gelu_pair(j + 1, K2 + ks);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
 
         gemm1(0);
 #pragma unroll
         for (int q = 0; q < 2 * RB; ++q) gelu_pair(0, q);
-        __syncthreads();
+        lds_barrier();
         MLP3_STAMP(6, 2);
         // (the last slab is peeled: whether a GELU rides between GEMM2's MFMAs is then a compile-time property of the loop body,
         // which stays ONE basic block per slab -- with a run-time flag every k-step ended in a branch)
@@ -348,10 +376,30 @@ __global__ __launch_bounds__(512, 2) void vit_mlp3_kernel(const ppt_vit_mlp_para
             MLP3_STAMP(j, 1);
             gemm2(j, std::true_type{});                                  // reads U[j & 1]; writes U[(j + 1) & 1] (last read by GEMM2(j - 1), before the barrier above)
             MLP3_STAMP(j, 2);
-            __syncthreads();
+            lds_barrier();
             MLP3_STAMP(j, 3);
         }
         MLP3_STAMP(NJ - 1, 0);
+        RELANE();
+        // the next block's "+ pos" rows (residual2): requested in front of the last slab's GEMM2 (the fc1 ring and a1 are dead: 72
+        // registers free), added behind it -- in the epilogue proper each of these loads was a round trip with nothing beside it
+        float4 r2v[RB][3];
+#ifndef PPT_MLP3_STAMP
+        if (p.residual2) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const int m = row0 + min(16 * rb + l15, nrow - 1);
+#pragma unroll
+                for (int nb = 0; nb < 3; ++nb) r2v[rb][nb] = *reinterpret_cast<const float4 *>(p.residual2 + (size_t)m * D + 48 * w + 16 * nb + 4 * kg);
+            }
+        } else
+#endif
+        {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int nb = 0; nb < 3; ++nb) r2v[rb][nb] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         gemm2(NJ - 1, std::false_type{});
         MLP3_STAMP(7, 0);
 
@@ -365,14 +413,8 @@ __global__ __launch_bounds__(512, 2) void vit_mlp3_kernel(const ppt_vit_mlp_para
                 for (int nb = 0; nb < 3; ++nb) {
                     const int n = 48 * w + 16 * nb + 4 * kg;
                     const float4 bv = *reinterpret_cast<const float4 *>(b2s + n);
-                    float4 o = make_float4(fmaf(bv.x, rs[rb], acc2[rb][nb][0]), fmaf(bv.y, rs[rb], acc2[rb][nb][1]),
-                                           fmaf(bv.z, rs[rb], acc2[rb][nb][2]), fmaf(bv.w, rs[rb], acc2[rb][nb][3]));
-#ifndef PPT_MLP3_STAMP
-                    if (p.residual2) {
-                        const float4 r2 = *reinterpret_cast<const float4 *>(p.residual2 + (size_t)m * D + n);
-                        o.x += r2.x; o.y += r2.y; o.z += r2.z; o.w += r2.w;
-                    }
-#endif
+                    const float4 o = make_float4(fmaf(bv.x, rs[rb], acc2[rb][nb][0]) + r2v[rb][nb].x, fmaf(bv.y, rs[rb], acc2[rb][nb][1]) + r2v[rb][nb].y,
+                                                 fmaf(bv.z, rs[rb], acc2[rb][nb][2]) + r2v[rb][nb].z, fmaf(bv.w, rs[rb], acc2[rb][nb][3]) + r2v[rb][nb].w);
                     *reinterpret_cast<float4 *>(p.out + (size_t)m * D + n) = o;
                 }
             }

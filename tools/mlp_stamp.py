@@ -9,6 +9,7 @@ import numpy as np
 import torch
 from ppt_amd import _lib
 
+ctypes.CDLL(os.path.join(ROOT, "ppt_amd", "csrc", "libppt_hip.so"), mode=ctypes.RTLD_GLOBAL)
 L = ctypes.CDLL(os.path.join(ROOT, "tools", "_build", "libmlp_stamp.so"))
 L.ppt_vit_mlp_bf16.restype = ctypes.c_int
 L.ppt_vit_mlp_bf16.argtypes = [ctypes.POINTER(_lib.VitMlpParams), ctypes.c_void_p]
@@ -22,7 +23,7 @@ for B in (32,):
     w2 = (torch.randn(384, 1536, generator=g) * 0.02).cuda().to(torch.bfloat16)
     b1, b2 = torch.randn(1536, generator=g).cuda(), torch.randn(384, generator=g).cuda()
     from ppt_amd import ops
-    w1, w2 = ops.vit_mlp_retile(w1, w2)
+    w1, w2 = ops.vit_mlp_retile(w1, w2, variant=2)
     stamps = torch.zeros(256 * 8 * 14 * 8, dtype=torch.int64, device="cuda")
     p = _lib.VitMlpParams()
     p.x, p.out, p.W1, p.W2, p.ln_w, p.ln_b, p.ln_eps = x.data_ptr(), out.data_ptr(), w1.data_ptr(), w2.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1e-5
