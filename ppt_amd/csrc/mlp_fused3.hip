@@ -49,7 +49,8 @@ __device__ __forceinline__ float row16_sum3(float v)
 // GELU (exact-erf form as an odd polynomial, ppt_act.h) with the saturation folded into a clamp of the erf argument: the
 // polynomial was fitted on |x| < 4 and erf(4 / sqrt 2) = 0.99994, so clamping x to [-4, 4] for the erf factor replaces gelu_poly's
 // compare + copysign + select by one v_med3_f32 (|difference| <= 6.3e-5 * |x| / 2 beyond 4: inside the polynomial's own error).
-__device__ __forceinline__ float gelu_poly3(float x)
+// hs = 0.5 * (the row's DropPath factor): the factor rides on the GELU output for free, (rs * U) W2 = rs * (U W2)
+__device__ __forceinline__ float gelu_poly3(float x, float hs)
 {
     const float xc = __builtin_amdgcn_fmed3f(x, -4.0f, 4.0f);
     const float u = xc * xc;
@@ -61,7 +62,7 @@ __device__ __forceinline__ float gelu_poly3(float x)
     p = fmaf(p, u, -1.323507577e-01f);
     p = fmaf(p, u, 7.976950407e-01f);
     const float e = p * xc;
-    const float h = 0.5f * x;
+    const float h = hs * x;
     return fmaf(h, e, h);
 }
 
@@ -93,12 +94,12 @@ __global__ __launch_bounds__(512, 2) void vit_mlp3_kernel(const ppt_vit_mlp_para
     float *gam = reinterpret_cast<float *>(smem + H2_BYTES + 2 * U_BYTES), *bet = gam + D, *b1s = bet + D, *b2s = b1s + HID;
     int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int l15 = lane & 15, kg = lane >> 4, lo16 = lane * 16;
+    int l15 = lane & 15, kg = lane >> 4, lo16 = lane * 16, tid = threadIdx.x;
     // Every phase re-derives its per-lane addresses from an OPAQUE copy of the lane id.  Left alone, hipcc hoists every per-lane
     // address of the whole kernel (LDS fragment bases, row offsets, statistics slots ...) to the entry, finds no room for ~70 of
     // them beside the slab loop's 250 registers, spills them there and reloads them where they are used -- and each scratch
     // reload is followed by s_waitcnt vmcnt(0): in the prologue that drained the residual loads once per row block.
-#define RELANE() do { asm volatile("" : "+v"(lane)); l15 = lane & 15; kg = lane >> 4; lo16 = lane * 16; } while (0)
+#define RELANE() do { asm volatile("" : "+v"(lane)); l15 = lane & 15; kg = lane >> 4; lo16 = lane * 16; tid = 64 * w + lane; } while (0)
 
     // fragment-ordered weights (ppt_vit_mlp3_retile): one wave-instruction = 1 KiB of consecutive bytes
     //   W1t[j][w][ks < 12][h < 2][lane][8] = W1[256 j + 32 w + 16 h + l15][32 ks + 8 kg ..)
@@ -140,9 +141,32 @@ __global__ __launch_bounds__(512, 2) void vit_mlp3_kernel(const ppt_vit_mlp_para
         // the accumulator layout too (first version: a separate 16-threads-per-row LayerNorm pass over x in three dependent
         // load -> reduce -> write rounds, then a second read of x for the accumulators -- 41 000 cycles of prologue per chunk).
         f32x4_t acc2[RB][3];
-        float rs[RB], rs1[RB];
+        float hrs[RB], rs1[RB];
         uint4 g1[D1][2], g2[D2][3];                                      // the two weight rings
         {
+            // (once per workgroup) the per-channel constants are REQUESTED first and stored to LDS behind the requests below: vmcnt
+            // retires in order, so stored behind requests issued EARLIER the ds_write waited for the residual rows to arrive from HBM
+            float cst[6];
+            const bool first = chunk == (int)blockIdx.x;
+            if (first) {
+                const int c = tid;
+                cst[0] = c < D ? p.ln_w[c] : 0.f; cst[1] = c < D ? p.ln_b[c] : 0.f; cst[2] = (c < D && p.b2) ? p.b2[c] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) cst[3 + i] = p.b1 ? p.b1[c + 512 * i] : 0.f;
+            }
+            // ---- (a) the proj operand: the chunk's rows of the attention output -> LDS image (rows past the chunk: zeros), IN FRONT of
+            // every other request -- vmcnt retires in order, and behind the residual rows' requests these stores waited for HBM to
+            // deliver those first (9 200 cycles from the first request to the image's barrier).  (Held in registers across the
+            // other requests instead, eight uint4 per thread, hipcc spilled 84-136 registers.)
+            if (p.proj_a) {
+                const bf16_t *A = (const bf16_t *)p.proj_a;
+                for (int i = tid; i < R * (D / 8); i += 512) {
+                    const int lr = i / (D / 8), c8 = i % (D / 8);
+                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    if (lr < nrow) v = *reinterpret_cast<const uint4 *>(A + (size_t)(row0 + lr) * D + 8 * c8);
+                    *reinterpret_cast<uint4 *>(h2 + lr * HP + 16 * c8) = v;
+                }
+            }
             float4 xv[RB][3];
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
@@ -154,27 +178,17 @@ __global__ __launch_bounds__(512, 2) void vit_mlp3_kernel(const ppt_vit_mlp_para
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 const int m = row0 + min(16 * rb + l15, nrow - 1);
-                rs[rb] = p.row_scale ? p.row_scale[m / p.row_scale_rows] : 1.0f;
+                hrs[rb] = p.row_scale ? 0.5f * p.row_scale[m / p.row_scale_rows] : 0.5f;     // HALF the MLP branch's DropPath factor
                 rs1[rb] = (p.proj_a && p.proj_row_scale) ? p.proj_row_scale[m / p.proj_row_scale_rows] : 1.0f;
             }
-            if (chunk == (int)blockIdx.x) {
-                // the per-channel constants -> LDS, once per workgroup, BEHIND the first chunk's loads (in front of them the
-                // kernel's first memory round trip fetched 10 KB and nothing else)
-                for (int c = threadIdx.x; c < D; c += 512) { gam[c] = p.ln_w[c]; bet[c] = p.ln_b[c]; b2s[c] = p.b2 ? p.b2[c] : 0.f; }
-                for (int c = threadIdx.x; c < HID; c += 512) b1s[c] = p.b1 ? p.b1[c] : 0.f;
+            if (first) {
+                const int c = tid;
+                if (c < D) { gam[c] = cst[0]; bet[c] = cst[1]; b2s[c] = cst[2]; }
+#pragma unroll
+                for (int i = 0; i < 3; ++i) b1s[c + 512 * i] = cst[3 + i];
             }
             MLP3_STAMP(5, 2);
             if (p.proj_a) {
-                // ---- (a) the chunk's rows of the attention output -> LDS image (rows past the chunk: zeros)
-                {
-                    const bf16_t *A = (const bf16_t *)p.proj_a;
-                    for (int i = threadIdx.x; i < R * (D / 8); i += 512) {
-                        const int lr = i / (D / 8), c8 = i % (D / 8);
-                        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                        if (lr < nrow) v = *reinterpret_cast<const uint4 *>(A + (size_t)(row0 + lr) * D + 8 * c8);
-                        *reinterpret_cast<uint4 *>(h2 + lr * HP + 16 * c8) = v;
-                    }
-                }
                 // ---- (b) acc2 = a . Wp^T, Wp in fragment order (ppt_vit_proj_retile: [w][12 nb + ks][lane][8]) four k-steps deep
                 const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.proj_W), 0, 8 * 36 * 64 * 16, 0x00020000);
                 auto pfrag = [&](int nb, int ks) {
@@ -192,18 +206,24 @@ __global__ __launch_bounds__(512, 2) void vit_mlp3_kernel(const ppt_vit_mlp_para
 #pragma unroll
                     for (int nb = 0; nb < 3; ++nb) acc2[rb][nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
                 const unsigned char *ha = h2 + l15 * HP + 16 * kg;
+                uint4 fp[2][RB];                                          // (the image fragments of k-step ks + 1 requested before the MFMAs of k-step ks: GEMM1 below)
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) fp[0][rb] = *reinterpret_cast<const uint4 *>(ha + rb * 16 * HP);
 #pragma unroll
                 for (int ks = 0; ks < K1; ++ks) {
+                    if (ks + 1 < K1) {
 #pragma unroll
-                    for (int rb = 0; rb < RB; ++rb) {
-                        const uint4 f = *reinterpret_cast<const uint4 *>(ha + rb * 16 * HP + 64 * ks);
-#pragma unroll
-                        for (int nb = 0; nb < 3; ++nb) acc2[rb][nb] = h16<F>::mfma16(wf[ks & 3][nb], f, acc2[rb][nb]);
+                        for (int rb = 0; rb < RB; ++rb) fp[(ks + 1) & 1][rb] = *reinterpret_cast<const uint4 *>(ha + rb * 16 * HP + 64 * (ks + 1));
                     }
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                        for (int nb = 0; nb < 3; ++nb) acc2[rb][nb] = h16<F>::mfma16(wf[ks & 3][nb], fp[ks & 1][rb], acc2[rb][nb]);
                     if (ks + 4 < K1) {
 #pragma unroll
                         for (int nb = 0; nb < 3; ++nb) wf[ks & 3][nb] = pfrag(nb, ks + 4);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 MLP3_STAMP(5, 4);
                 // ---- (c) x_mid = x + drop_path1 * (acc + bp): STAYS in acc2
@@ -249,11 +269,11 @@ __global__ __launch_bounds__(512, 2) void vit_mlp3_kernel(const ppt_vit_mlp_para
                 psum[(16 * rb + l15) * 32 + 4 * w + kg] = sum;
             }
             lds_barrier();
-            if (threadIdx.x < R) {
+            if (tid < R) {
                 float t = 0.f;
 #pragma unroll
-                for (int i = 0; i < 32; ++i) t += psum[threadIdx.x * 32 + i];
-                stat[threadIdx.x] = t * (1.0f / (float)D);
+                for (int i = 0; i < 32; ++i) t += psum[tid * 32 + i];
+                stat[tid] = t * (1.0f / (float)D);
             }
             lds_barrier();
             float mean_r[RB];
@@ -269,11 +289,11 @@ __global__ __launch_bounds__(512, 2) void vit_mlp3_kernel(const ppt_vit_mlp_para
                 psum[lr * 32 + 4 * w + kg] = q;
             }
             lds_barrier();
-            if (threadIdx.x < R) {
+            if (tid < R) {
                 float t = 0.f;
 #pragma unroll
-                for (int i = 0; i < 32; ++i) t += psum[threadIdx.x * 32 + i];
-                stat[R + threadIdx.x] = 1.0f / sqrtf(t * (1.0f / (float)D) + p.ln_eps);
+                for (int i = 0; i < 32; ++i) t += psum[tid * 32 + i];
+                stat[R + tid] = 1.0f / sqrtf(t * (1.0f / (float)D) + p.ln_eps);
             }
             lds_barrier();
 #pragma unroll
@@ -302,7 +322,11 @@ __global__ __launch_bounds__(512, 2) void vit_mlp3_kernel(const ppt_vit_mlp_para
         // is refilled with the k-step D1 further on (of the next slab -- of slab 0 behind the last: the next chunk's -- past the end)
         auto gemm1 = [&](int jj) {
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) { a1[rb][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; a1[rb][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+            for (int h = 0; h < 2; ++h) {                                 // the accumulators START at the fc1 bias (a lane's four hidden units)
+                const float4 bv = *reinterpret_cast<const float4 *>(b1s + jj * HC + 32 * w + 16 * h + 4 * kg);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) a1[rb][h] = f32x4_t{bv.x, bv.y, bv.z, bv.w};
+            }
             const unsigned char *ha = h2 + l15 * HP + 16 * kg;
             // the H2 fragments of k-step ks + 1 are requested before the MFMAs of k-step ks (two register sets): left to itself hipcc
             // emitted read -> wait -> two MFMAs, one LDS latency per pair (in-kernel stamps: 5 400 cycles for 3 840 of matrix work)
@@ -329,10 +353,9 @@ __global__ __launch_bounds__(512, 2) void vit_mlp3_kernel(const ppt_vit_mlp_para
         // GELU of pair q = (rb, h) of a1 (slab jj) -> U[jj & 1], scaled by the row's DropPath factor
         auto gelu_pair = [&](int jj, int q) {
             const int rb = q >> 1, h = q & 1;
-            const float4 bv = *reinterpret_cast<const float4 *>(b1s + jj * HC + 32 * w + 16 * h + 4 * kg);
-            float v[4] = {a1[rb][h][0] + bv.x, a1[rb][h][1] + bv.y, a1[rb][h][2] + bv.z, a1[rb][h][3] + bv.w};
+            float v[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = gelu_poly3(v[i]) * rs[rb];
+            for (int i = 0; i < 4; ++i) v[i] = gelu_poly3(a1[rb][h][i], hrs[rb]);
             *reinterpret_cast<uint2 *>(ub + (jj & 1) * U_BYTES + (16 * rb + l15) * UP + (32 * w + 16 * h + 4 * kg) * 2) =
                 make_uint2(h16<F>::pack2(v[0], v[1]), h16<F>::pack2(v[2], v[3]));
         };
@@ -413,8 +436,9 @@ __global__ __launch_bounds__(512, 2) void vit_mlp3_kernel(const ppt_vit_mlp_para
                 for (int nb = 0; nb < 3; ++nb) {
                     const int n = 48 * w + 16 * nb + 4 * kg;
                     const float4 bv = *reinterpret_cast<const float4 *>(b2s + n);
-                    const float4 o = make_float4(fmaf(bv.x, rs[rb], acc2[rb][nb][0]) + r2v[rb][nb].x, fmaf(bv.y, rs[rb], acc2[rb][nb][1]) + r2v[rb][nb].y,
-                                                 fmaf(bv.z, rs[rb], acc2[rb][nb][2]) + r2v[rb][nb].z, fmaf(bv.w, rs[rb], acc2[rb][nb][3]) + r2v[rb][nb].w);
+                    const float r = 2.0f * hrs[rb];
+                    const float4 o = make_float4(fmaf(bv.x, r, acc2[rb][nb][0]) + r2v[rb][nb].x, fmaf(bv.y, r, acc2[rb][nb][1]) + r2v[rb][nb].y,
+                                                 fmaf(bv.z, r, acc2[rb][nb][2]) + r2v[rb][nb].z, fmaf(bv.w, r, acc2[rb][nb][3]) + r2v[rb][nb].w);
                     *reinterpret_cast<float4 *>(p.out + (size_t)m * D + n) = o;
                 }
             }
