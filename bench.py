@@ -267,12 +267,18 @@ def secondary_runs():
     # *_prefetch (round 5): batches copied from pinned host memory every step through ppt_amd.data.DevicePrefetcher, nothing
     # vouched for -- the unchanged caller's loop with its loader wrapped
     feed = {"PPT_BENCH_FEED": "prefetch"}
+    # C5 (part segmentation) since round 6: the Trainer's first-batch gradient self-check (train.Trainer.calibrate_gradients) finds the
+    # mixed mode's deep decoder gradients 0.11 rel-L2 away from the fp32-grade ones -- inherited from the frozen backbone's 16-bit
+    # forward, no single stage fixes it -- and continues in split16: "C5" is what a caller gets by default,
+    # "C5_mixed16" the same step with the check off (round 5's C5), and the feed variants of C5 compare like with like (check off)
+    mixed = {"PPT_GRAD_CHECK": "off"}
     runs = [("C3", ["--config", "C3"], {}), ("C4", ["--config", "C4"], {}), ("C5", ["--config", "C5"], {}),
+            ("C5_mixed16", ["--config", "C5"], mixed),
             ("C2_eval", ["--config", "C2", "--eval"], {}),
             ("C2_prefetch", ["--config", "C2"], feed), ("C3_prefetch", ["--config", "C3"], feed),
-            ("C5_prefetch", ["--config", "C5"], feed), ("C2_eval_prefetch", ["--config", "C2", "--eval"], feed),
+            ("C5_prefetch", ["--config", "C5"], dict(feed, **mixed)), ("C2_eval_prefetch", ["--config", "C2", "--eval"], feed),
             ("C2_in_order", ["--config", "C2"], in_order), ("C3_in_order", ["--config", "C3"], in_order),
-            ("C5_in_order", ["--config", "C5"], in_order), ("C2_eval_in_order", ["--config", "C2", "--eval"], in_order),
+            ("C5_in_order", ["--config", "C5"], dict(in_order, **mixed)), ("C2_eval_in_order", ["--config", "C2", "--eval"], in_order),
             # the split16 mode (fp32 storage, products from hi + lo half pairs: the fp32 mode's parity bounds) on the other configurations
             ("C3_split16", ["--config", "C3"], {"PPT_BENCH_MODE": "split16"}), ("C5_split16", ["--config", "C5"], {"PPT_BENCH_MODE": "split16"}),
             # the headline step on checkpoint-LIKE weight magnitudes (VERDICT r5 #2c): throughput of the mixed mode AFTER its load-time
@@ -289,6 +295,9 @@ def secondary_runs():
                          "steps": j["steps"], "workload": j["config"]["workload"]}
             if "timing" in j["config"]:
                 out[name]["ms_per_step_median"] = j["config"]["timing"]["ms_per_step_median"]
+            if j["config"].get("gradient_self_check"):
+                out[name]["gradient_self_check"] = j["config"]["gradient_self_check"]
+                out[name]["dtype"] = j["dtype"]
             if "parity" in j:
                 out[name]["parity"] = j["parity"]
                 out[name]["operand_formats"] = j["config"]["operand_formats"]
@@ -669,14 +678,16 @@ def main():
                "warmup": a.warmup, "burn_in": burned, "ms_per_step": round(1e3 * elapsed / a.steps, 3),
                "ms_per_step_median": round(median_ms, 3), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32 as hi+lo f16 pairs" if BENCH_MODE == "split16" else
+               "dtype": "f32 as hi+lo f16 pairs" if (BENCH_MODE == "split16" or getattr(model, "precision_name", "") == "split16") else
                         ("f16" if set(operand_formats(cfg.get("model", "ULIP_PointBERT")).values()) <= {"f16", "f32"} else "f16/bf16"),
                "data": "synthetic",
                "config": {"workload": cfg["name"] + ", train-mode BN + DropPath, fwd + CE(ls 0.2) + bwd + AdamW"
                                       + (", checkpoint-LIKE weight magnitudes (weights.checkpoint_like)" if WEIGHTS == "ckpt_like" else ""), "feed": FEED,
                           "operand_formats": formats_of(model, cfg.get("model", "ULIP_PointBERT")),
                           "per_gpu_batch": PER_GPU_BATCH, "global_batch": PER_GPU_BATCH * world, "npoints": NPOINTS,
-                          "classes": n_classes, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4), "timing": timing},
+                          "classes": n_classes, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4), "timing": timing,
+                          "gradient_self_check": ({k: (round(v, 5) if isinstance(v, float) else v) for k, v in trainer.grad_calibration.items()}
+                                                  if trainer.grad_calibration and trainer.grad_calibration.get("checked") else None)},
                "roofline": roof}
         if world == 1 and not force_dist and not a.no_parity_mode:
             out["parity_mode"] = parity_mode_rate(cfg, pc, label, trainer.extra_inputs, max(3, a.steps // 2), like=trainer)

@@ -14,7 +14,7 @@
 //       work; its result goes to the other half of a double-buffered slab, ONE barrier per slab;
 //   (3) the fc2 accumulators START at x_mid (the proj prologue's result, or x): the residual never leaves registers -- no x_mid
 //       round trip, no residual read in the epilogue.  DropPath's per-sample factor rides on the GELU output (rs * U) W2 = rs * (U W2);
-//   (4) the weights arrive through two register rings (fc1: 4 k-steps = 8 KiB, fc2: 2 k-steps = 6 KiB per wave) that wrap from one
+//   (4) the weights arrive through two register rings (fc1: 4 k-steps = 8 KiB, fc2: 4 k-steps = 12 KiB per wave; in the step, beside the other streams, the deeper fc2 ring is worth 2 %) that wrap from one
 //       slab into the next and from the last slab back to the first: the stream never stops at a phase boundary.
 // Arithmetic differs from mlp_fused.hip only in rounding ORDER (residual first instead of last; rs folded before the 16-bit
 // rounding of U): tests/test_kernels_gpu.py holds both to the same bounds against fp32 math on the same operands.
@@ -32,7 +32,13 @@ constexpr int HP = 2 * D + 32, UP = 2 * HC + 32;                   // LDS pitche
 constexpr int H2_BYTES = R * HP, U_BYTES = R * UP;
 constexpr int LDS_BYTES = H2_BYTES + 2 * U_BYTES + (2 * D + HID + D) * 4;
 constexpr int K1 = D / 32, K2 = HC / 32;                           // k-steps of GEMM1 (12) / GEMM2 (8) per slab
-constexpr int D1 = 4, D2 = 2;                                      // ring depths in k-steps (must divide K1 / K2)
+#ifndef PPT_MLP3_D1
+#define PPT_MLP3_D1 4
+#endif
+#ifndef PPT_MLP3_D2
+#define PPT_MLP3_D2 4
+#endif
+constexpr int D1 = PPT_MLP3_D1, D2 = PPT_MLP3_D2;                  // ring depths in k-steps (must divide K1 / K2; tools/build_variant.sh for A/B)
 static_assert(K1 % D1 == 0 && K2 % D2 == 0, "ring slots must line up from slab to slab");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 constexpr int W1_BYTES = HID * D * 2, W2_BYTES = D * HID * 2;

@@ -107,7 +107,7 @@ def test_train_step_matches_oracle_and_golden(head_type, precision, ltol, gtol):
             assert d < 5e-5, (k, d)
 
 
-@pytest.mark.parametrize("precision", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("precision", [torch.float32, "split16", torch.bfloat16])
 @pytest.mark.parametrize("head_type", [0, 3])
 def test_train_step_on_checkpoint_like_weights(head_type, precision):
     """VERDICT r4 weak #10 / #4b: every other parity number of this repository is on std-0.02 synthetic weights.  Here the SAME train
@@ -135,7 +135,19 @@ def test_train_step_on_checkpoint_like_weights(head_type, precision):
     loss, pred = tr.step(pc.cuda(), torch.from_numpy(g["labels"]).cuda(), check_finite=True)
     tr.finish()
     torch.cuda.synchronize()
-    f32 = precision == torch.float32
+    # Round 6: with a trainable point side (head_type 3) the mixed mode's first-batch GRADIENT self-check (Trainer.calibrate_gradients)
+    # finds its gradients 0.10 away from the fp32-grade ones on these weights -- inherited from the frozen tower's 16-bit forward,
+    # tools/ckpt_like_h3_error.py -- and continues the run in split16: the step below is held to the fp32-grade bounds then.
+    switched = precision == torch.bfloat16 and head_type == 3
+    if precision == torch.bfloat16:
+        cal = tr.grad_calibration
+        print("PARITY ckpt-like gradient self-check:", cal)
+        if head_type == 3:
+            assert cal["checked"] and cal["over"] and cal["worst_rel_l2"] > 3 * cal["threshold"] and cal["mode_after"] == "split16"
+            assert m.precision_name == "split16"
+        else:
+            assert not cal["checked"] and m.precision_name == "mixed16"          # only the PromptLearner trains: the text tower's own check covers it
+    f32 = precision in FP32_GRADE or switched
     rng_ = float(np.abs(g["logits"]).max())
     err = np.abs(pred.detach().cpu().numpy() - g["logits"]).max()
     _bound(f"ckpt-like h{head_type} {precision} logits abs err (|logits| <= {rng_:.0f})", err, 5e-2 if f32 else 1.0)
@@ -155,20 +167,56 @@ def test_train_step_on_checkpoint_like_weights(head_type, precision):
             assert abs(gg.double().norm().item() / float(g["gradnorm_" + k]) - 1.0) < (1e-2 if f32 else 8e-2), k
         # (1-D norm parameters of the un-frozen block are sums with heavy cancellation: measured 0.116 on norm1.weight in the mixed
         # mode, 0.01-0.03 on the weight matrices and the tokens)
-        gb = 1e-2 if f32 else (0.15 if gg.dim() == 1 else 0.12)
+        gb = (1e-2 if precision == torch.float32 else 2e-2) if f32 else (0.15 if gg.dim() == 1 else 0.12)
         if gg.dim() > 1 or f32:
             worst = max(worst, rel)
         assert rel < gb, (k, rel)
-    _bound(f"ckpt-like h{head_type} {precision} worst gradient rel-L2 (matrices / tokens)", worst, 1e-2 if f32 else 0.12)
+    _bound(f"ckpt-like h{head_type} {precision} worst gradient rel-L2 (matrices / tokens)", worst,
+           (1e-2 if precision == torch.float32 else 2e-2) if f32 else 0.12)
     print("PARITY ckpt-like demotions:", tr.demotions, "skipped gradient elements:", tr.nonfinite_grad_elements(),
           "text calibration:", m.text_calibration)
     assert not tr.demotions and tr.nonfinite_grad_elements() == 0 and not m.demoted
-    if not f32:
+    if precision == torch.bfloat16 and not switched:
         # the mode's self-check (ULIP_WITH_IMAGE.calibrate_text_precision) found the half text tower too coarse for THESE weights
         # (tools/ckpt_like_error.py: 14.3 of |logits| <= 72 with it, 0.49 without) and moved it to fp32 operands; on the std-0.02
         # synthetic weights it stays on half (test_text_calibration_keeps_half_on_the_synthetic_weights)
         assert m.text_calibration and m.text_calibration["demoted"] and m.text_precision is torch.float32
         assert m.text_calibration["rel_l2"] > 5 * m.text_calibration["threshold"]
+
+
+def test_gradient_self_check_leaves_no_trace_when_it_passes(monkeypatch):
+    """Trainer.calibrate_gradients (round 6): on the synthetic weights, head_type 3, the mixed mode's gradients are within 2e-2 of the
+    split16 mode's on the first batch (measured ~5e-3), so the run stays in mixed16 -- and the two dry passes leave NOTHING behind:
+    three steps with the check are bit-identical (losses, trained parameters, BatchNorm running statistics, the RNG draws of FPS /
+    DropPath) to three steps with PPT_GRAD_CHECK=off."""
+    from ppt_amd.train import Trainer
+    pc, _ = oracle_inputs()
+    labels = torch.tensor([1, 2, 3, 4]).cuda()
+    outs = {}
+    for policy in ("off", "switch"):
+        monkeypatch.setenv("PPT_GRAD_CHECK", policy)
+        torch.manual_seed(123)
+        torch.cuda.manual_seed(123)
+        m, _ = build(3, torch.bfloat16)
+        m.train()
+        tr = Trainer(m, lr=3e-3, label_smoothing=0.2, distributed=False)
+        losses = []
+        for _ in range(3):
+            loss, _ = tr.step(pc.cuda(), labels)
+            losses.append(loss.item())
+        tr.finish()
+        torch.cuda.synchronize()
+        cal = tr.grad_calibration
+        if policy == "switch":
+            print("PARITY gradient self-check, synthetic weights h3:", cal)
+            assert cal["checked"] and not cal["over"] and cal["worst_rel_l2"] < 0.5 * cal["threshold"] and cal["mode_after"] == "mixed16"
+        else:
+            assert cal == {"checked": False}
+        assert m.precision_name == "mixed16"
+        outs[policy] = (losses, {k: v.detach().clone() for k, v in m.state_dict().items()})
+    assert outs["off"][0] == outs["switch"][0], (outs["off"][0], outs["switch"][0])
+    for k, v in outs["off"][1].items():
+        assert torch.equal(v, outs["switch"][1][k]), k
 
 
 def test_text_calibration_keeps_half_on_the_synthetic_weights():
@@ -1396,9 +1444,10 @@ class _health_every:
     def __enter__(self):
         # (PPT_TEXT_CALIBRATE=0: these tests are about the RUN-TIME monitor; the load-time self-check of the text tower --
         # calibrate_text_precision -- would move the stressed tower to fp32 operands before any step could overflow)
-        self.old = {k: os.environ.get(k) for k in ("PPT_HEALTH_EVERY", "PPT_TEXT_CALIBRATE")}
+        self.old = {k: os.environ.get(k) for k in ("PPT_HEALTH_EVERY", "PPT_TEXT_CALIBRATE", "PPT_GRAD_CHECK")}
         os.environ["PPT_HEALTH_EVERY"] = self.n
         os.environ["PPT_TEXT_CALIBRATE"] = "0"
+        os.environ["PPT_GRAD_CHECK"] = "off"            # (... and likewise the Trainer's first-batch gradient self-check)
 
     def __exit__(self, *a):
         for k, v in self.old.items():

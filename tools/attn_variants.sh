@@ -1,6 +1,7 @@
 #!/bin/bash
 # Dev tool: kernel-trace durations of the attention forward under the launch switches (XCD map of the streaming kernel, the
 # LDS-resident ViT kernel).
+export PPT_BENCH_BURN_IN_S=0      # (the traces count on the 40-step burn-in: steps = 40 + warmup + K)
 cd /tmp && export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 for V in "0 0" "1 0" "1 1"; do

@@ -2,6 +2,7 @@
 # On the GPU box (gpurun): the bench line and a rocprofv3 kernel trace of every configuration, and the two PMC passes of the
 # headline configuration -> gpurun_out/prof_r05/ (tools/make_profiles.py turns that into profiles/).
 #   gpurun --timeout 2400 -- 'bash tools/profile_all.sh [configs ...]'
+export PPT_BENCH_BURN_IN_S=0      # (the traces count on the 40-step burn-in: steps = 40 + warmup + K)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/${PPT_PROF_DIR:-prof_r05}

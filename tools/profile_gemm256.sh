@@ -1,6 +1,7 @@
 #!/bin/bash
 # On the GPU box: the stand-alone numbers of the 256-row macro-tile GEMM core (csrc/gemm256.hip) -- HIP-event A/B table, rocprofv3
 # kernel trace of the same tool, SQ counters (MFMA-busy, waits, LDS conflicts) and in-kernel stamps -> gpurun_out/prof_r05/gemm256_*.
+export PPT_BENCH_BURN_IN_S=0      # (the traces count on the 40-step burn-in: steps = 40 + warmup + K)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/${PPT_PROF_DIR:-prof_r05}

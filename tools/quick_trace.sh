@@ -1,6 +1,7 @@
 #!/bin/bash
 # Dev tool: kernel-trace table of one configuration's bench run (per stream: launches / step, avg us, ms / step).
 #   bash tools/quick_trace.sh C2
+export PPT_BENCH_BURN_IN_S=0      # (the traces count on the 40-step burn-in: steps = 40 + warmup + K)
 cd /tmp && export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 C=${1:-C2}

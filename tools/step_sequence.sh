@@ -1,6 +1,7 @@
 #!/bin/bash
 # Dev tool (GPU box): ordered kernel sequence of one steady-state step of a bench configuration, per stream, with gaps.
 #   bash tools/step_sequence.sh C5 [marker=adamw]
+export PPT_BENCH_BURN_IN_S=0      # (the traces count on the 40-step burn-in: steps = 40 + warmup + K)
 cd /tmp && export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 C=${1:-C5}; M=${2:-adamw}
