@@ -478,9 +478,13 @@ class Trainer:
             torch.cuda.set_rng_state(rng, pc.device)
             torch.set_rng_state(cpu_rng)
         worst, which = 0.0, None
+        # (a tensor whose true gradient is ZERO -- a conv bias in front of a BatchNorm -- holds rounding noise in both modes: its
+        # difference is measured against 1e-4 of the largest tensor norm, not against its own)
+        norms = {n: float(a.norm()) for n, a in g32.items()}
+        floor = 1e-4 * max([v for v in norms.values() if math.isfinite(v)] or [0.0])
         for n, a in g32.items():
             b = g16.get(n)
-            den = float(a.norm())
+            den = max(norms[n], floor)
             if b is None or den == 0.0 or not math.isfinite(den):
                 continue
             rel = float((b - a).norm()) / den
