@@ -1,77 +1,156 @@
-"""Dataset-side FPS from inside DataLoader WORKER processes (VERDICT r4 missing #4).
+"""Dataset-side FPS from inside DataLoader WORKER processes (VERDICT r4 missing #4; round 6: batched, shared memory, tagged).
 
 The reference's datasets call `farthest_point_sample(point, npoint)` in `_get_item` (data/dataset_3d.py:40-61, :295, :366, :583), i.e. in
 the DataLoader's forked workers (`num_workers = args.workers`).  The kernel runs on the HIP device, and a forked worker cannot
 initialise the device.  So the workers do not: `start_fps_service()` -- called ONCE in the main process, before the DataLoader forks its
-workers -- starts a thread that owns a stream and a pair of queues; inside a worker, `ppt_amd.data.farthest_point_sample` sends the
-cloud (and the start index it drew with `np.random.randint`, exactly where the reference draws it) to that thread and gets the selected
-indices back.  The dataset class stays as it is; the main-process thread runs the same `ppt_fps_f32` launch as everywhere else (one cloud
-per launch, ~0.2-1 ms each, off the training streams), so the selected rows are the reference's bit for bit.
+workers -- starts a thread that owns a stream; inside a worker, `ppt_amd.data.farthest_point_sample` hands the cloud (and the start index
+it drew with `np.random.randint`, exactly where the reference draws it) to that thread and gets the selected indices back.  The dataset
+class stays as it is; the main-process thread runs the same `ppt_fps_f32` kernel as everywhere else, so the selected rows are the
+reference's bit for bit.
+
+Round 6:
+  * the thread DRAINS the request queue and launches every pending cloud of equal (N, npoint) as ONE `ppt_fps_f32` call (the kernel
+    takes B clouds, one workgroup each: 8 clouds cost what one costs -- a walk of npoint serial picks);
+  * clouds and indices travel through SHARED MEMORY slots, one per worker (created before the fork, inherited by it); the queues carry
+    five integers per request instead of a pickled 100 KB array each way;
+  * every request carries a tag (pid, counter) that the response echoes: a worker that timed out, raised or was torn down with a
+    request outstanding leaves a late answer in its slot's queue, and the next owner of that worker id -- a second loader alive at the
+    same time shares ids -- discards it instead of taking another cloud's indices; a slot's queue is also drained when a new process
+    first uses it;
+  * the serving loop survives its own exceptions (a failed launch is reported to the workers that asked, the thread keeps serving).
+Throughput: a worker has ONE request outstanding (the dataset calls the function synchronously), so W workers put at most W clouds into
+a launch: W / (walk time + round trip) clouds per second -- at N = 8192 -> 1024 the walk alone is 1.0 ms.
 
     import ppt_amd.data as PD
     PD.start_fps_service()                         # main process, before `DataLoader(..., num_workers=8)` is iterated
     ...                                            # main_cls.py:74-86 unchanged
 """
 import multiprocessing
+import os
+import queue
 import threading
 
 import numpy as np
 
 _SERVICE = None
+MAX_POINTS = int(os.environ.get("PPT_FPS_SERVICE_MAX_POINTS", "16384"))      # per cloud: the size of a worker's shared-memory slot
+MAX_BATCH = 64
 
 
 class FPSService:
-    def __init__(self, max_workers=64, device=None):
+    def __init__(self, max_workers=64, device=None, max_points=MAX_POINTS):
         import torch
-        ctx = multiprocessing.get_context("fork")             # the queues are inherited by the DataLoader's forked workers
+        ctx = multiprocessing.get_context("fork")             # the queues and slots are inherited by the DataLoader's forked workers
         self.req = ctx.Queue()
         self.resp = [ctx.Queue() for _ in range(max_workers)]
+        self.max_points = int(max_points)
+        # one slot per worker id: the cloud's xyz in, the selected indices out (shared memory, mapped before the fork)
+        self.xyz = torch.empty((max_workers, self.max_points, 3), dtype=torch.float32).share_memory_()
+        self.idx = torch.empty((max_workers, self.max_points), dtype=torch.int64).share_memory_()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._stream = None
         self.served = 0
+        self.launches = 0
+        self._owner = {}                                       # worker side: wid -> pid that last used the slot (per process copy)
+        self._seq = 0
         self.thread = threading.Thread(target=self._serve, name="ppt-fps-service", daemon=True)
         self.thread.start()
 
-    def _serve(self):
+    # ------------------------------------------------------------------ main-process thread
+    def _launch(self, wids, N, npoint, starts):
+        """ONE ppt_fps_f32 launch over the clouds in the slots `wids` (all of N points) -> indices [B, npoint] on the host."""
         import torch
         from .. import ops
-        torch.cuda.set_device(self.device)
-        stream = torch.cuda.Stream(self.device)
-        while True:
-            item = self.req.get()
-            if item is None:
-                return
-            wid, xyz, npoint, start = item
-            try:
-                with torch.cuda.stream(stream):
-                    t = torch.from_numpy(np.ascontiguousarray(xyz, dtype=np.float32)).to(self.device).view(1, -1, 3)
-                    st = torch.tensor([int(start)], dtype=torch.int64, device=self.device)
-                    idx, _ = ops.fps(t, int(npoint), st)
-                    out = idx.view(-1).cpu().numpy()           # (synchronises this stream only)
-                self.served += 1
-                self.resp[wid].put(out)
-            except Exception as e:                             # the worker must not hang on a failed launch
-                self.resp[wid].put(e)
+        if self._stream is None:
+            torch.cuda.set_device(self.device)
+            self._stream = torch.cuda.Stream(self.device)
+        with torch.cuda.stream(self._stream):
+            t = self.xyz[torch.tensor(wids), :N].to(self.device)                        # [B, N, 3]
+            st = torch.tensor(starts, dtype=torch.int64, device=self.device)
+            idx, _ = ops.fps(t, int(npoint), st)
+            return idx.cpu()                                                            # (synchronises this stream only)
 
+    def _serve(self):
+        while True:
+            try:
+                item = self.req.get()
+                if item is None:
+                    return
+                batch = [item]
+                while len(batch) < MAX_BATCH:                  # everything that is pending right now rides in the same launch(es)
+                    try:
+                        nxt = self.req.get_nowait()
+                    except queue.Empty:
+                        break
+                    if nxt is None:
+                        self.req.put(None)                     # (stop after this batch)
+                        break
+                    batch.append(nxt)
+                groups = {}
+                for it in batch:                               # (wid, tag, N, npoint, start)
+                    groups.setdefault((it[2], it[3]), []).append(it)
+                for (N, npoint), items in groups.items():
+                    try:
+                        out = self._launch([it[0] for it in items], N, npoint, [it[4] for it in items])
+                        self.launches += 1
+                        for b, it in enumerate(items):
+                            self.idx[it[0], :npoint] = out[b]
+                            self.served += 1
+                            self.resp[it[0]].put((it[1], int(npoint), None))
+                    except Exception as e:                     # the workers must not hang on a failed launch
+                        for it in items:
+                            self.resp[it[0]].put((it[1], 0, f"{type(e).__name__}: {e}"))
+            except Exception:                                  # (a broken queue item: keep serving)
+                continue
+
+    # ------------------------------------------------------------------ worker processes
     def request(self, wid, xyz, npoint, start, timeout=120.0):
-        """Called in a worker process: blocks until the main process has run the launch."""
+        """Called in a worker process: blocks until the main process has run the launch; -> int64 indices [npoint]."""
         if not 0 <= wid < len(self.resp):
             raise RuntimeError(f"ppt_amd FPS service: worker id {wid} beyond the {len(self.resp)} it was started for")
-        self.req.put((wid, np.ascontiguousarray(xyz, dtype=np.float32), int(npoint), int(start)))
-        out = self.resp[wid].get(timeout=timeout)
-        if isinstance(out, Exception):
-            raise out
-        return out
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        N = xyz.shape[0]
+        if N > self.max_points or npoint > self.max_points:
+            raise RuntimeError(f"ppt_amd FPS service: cloud of {N} points beyond the slot size {self.max_points} "
+                               "(PPT_FPS_SERVICE_MAX_POINTS, or start_fps_service(max_points=...))")
+        pid = os.getpid()
+        if self._owner.get(wid) != pid:                        # first use of this slot by this process: stale answers go
+            self._owner[wid] = pid
+            try:
+                while True:
+                    self.resp[wid].get_nowait()
+            except queue.Empty:
+                pass
+        self._seq += 1
+        tag = (pid, self._seq)
+        self.xyz[wid, :N] = __import__("torch").from_numpy(xyz)
+        self.req.put((wid, tag, N, int(npoint), int(start)))
+        import time
+        deadline = time.time() + timeout
+        while True:
+            left = deadline - time.time()
+            if left <= 0:
+                raise TimeoutError(f"ppt_amd FPS service: no answer within {timeout:.0f} s")
+            try:
+                got_tag, n, err = self.resp[wid].get(timeout=left)
+            except queue.Empty:
+                raise TimeoutError(f"ppt_amd FPS service: no answer within {timeout:.0f} s") from None
+            if got_tag != tag:
+                continue                                       # a late answer to somebody else's (or an abandoned) request: not ours
+            if err is not None:
+                raise RuntimeError("ppt_amd FPS service: " + err)
+            return self.idx[wid, :n].numpy().copy()
 
     def stop(self):
         self.req.put(None)
         self.thread.join(timeout=5)
 
 
-def start_fps_service(max_workers=64, device=None):
+def start_fps_service(max_workers=64, device=None, max_points=MAX_POINTS):
     """Start (once per process) the main-process thread that serves dataset-side FPS requests of DataLoader workers."""
     global _SERVICE
     if _SERVICE is None:
-        _SERVICE = FPSService(max_workers=max_workers, device=device)
+        _SERVICE = FPSService(max_workers=max_workers, device=device, max_points=max_points)
     return _SERVICE
 
 

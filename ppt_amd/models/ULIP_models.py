@@ -917,6 +917,13 @@ class ULIP_WITH_IMAGE(nn.Module):
         hi = hi / hi.norm(dim=-1, keepdim=True)
         rel = float(((lo - hi).norm() / hi.norm()).item())
         bad = not (rel <= thr)                      # (NaN -> demote as well)
+        # under a process group every rank must take the SAME decision (a rank that alone re-captures its graphs and runs a slower
+        # chain stalls the others' collective): MAX over the ranks of the verdict and of the measured distance
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            v = torch.tensor([1.0 if bad else 0.0, rel if rel == rel else 1e30], dtype=torch.float64, device=tok.device)
+            dist.all_reduce(v, op=dist.ReduceOp.MAX)
+            bad, rel = bool(v[0].item() > 0), float(v[1].item())
         self.text_calibration = {"rel_l2": rel, "threshold": thr, "demoted": bad}
         self._te_cache = None
         if bad:

@@ -305,6 +305,10 @@ class Trainer:
         # and captured hipGraph made before that points at the orphaned storage
         if hasattr(model, "reset_caches"):
             model.reset_caches()
+            # the text tower's half-vs-fp32 self-check runs HERE, explicitly, on the weights every rank now shares -- not inside
+            # the first step on the text stream; under a process group the verdict is all-reduced (see the method)
+            if hasattr(model, "calibrate_text_precision") and next(model.parameters()).is_cuda:
+                model.calibrate_text_precision()
         else:
             for m in (model, getattr(model, "point_encoder", None)):
                 if hasattr(m, "_sd"):

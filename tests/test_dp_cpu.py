@@ -282,3 +282,60 @@ def test_bench_launches_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300, env=env, cwd=root)
     assert r.returncode != 0
+
+
+def test_fps_service_tags_batches_and_survives_stale_answers():
+    """ppt_amd/data/fps_service.py without a GPU (the launch is replaced by the C oracle's FPS): (1) requests that are pending together
+    ride in ONE launch; (2) indices come back through the shared-memory slot and equal the oracle's; (3) a late answer left in a
+    worker slot's queue by an abandoned request -- another loader's worker with the same id, a timed-out call -- is DISCARDED by its
+    tag instead of being taken for this cloud's indices; (4) a failing launch is reported, and the thread keeps serving."""
+    import threading
+    import time
+    from oracle import oracle as O
+    from ppt_amd.data import fps_service as FS
+
+    class CpuService(FS.FPSService):
+        fail_next = False
+
+        def _launch(self, wids, N, npoint, starts):
+            if self.fail_next:
+                self.fail_next = False
+                raise ValueError("injected launch failure")
+            time.sleep(0.05)                                   # (requests arriving meanwhile are drained into the next launch)
+            out = []
+            for wdx, st in zip(wids, starts):
+                _, idx = O.dataset_farthest_point_sample(self.xyz[wdx, :N].numpy(), npoint, int(st))
+                out.append(torch.from_numpy(np.asarray(idx, dtype=np.int64)))
+            return torch.stack(out)
+
+    svc = CpuService(max_workers=8, device="cpu", max_points=512)
+    try:
+        rng = np.random.default_rng(0)
+        clouds = [rng.standard_normal((300, 3)).astype(np.float32) for _ in range(6)]
+        want = [np.asarray(O.dataset_farthest_point_sample(c, 32, 5 + i)[1], dtype=np.int64) for i, c in enumerate(clouds)]
+        # a stale answer from "another process" sits in slot 2 before anybody asks
+        svc.resp[2].put(((99999, 1), 32, None))
+        got = [None] * 6
+
+        def worker(i):
+            got[i] = svc.request(i, clouds[i], 32, 5 + i, timeout=30)
+        ts = [threading.Thread(target=worker, args=(i,)) for i in range(6)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        for i in range(6):
+            assert np.array_equal(got[i], want[i]), i
+        assert svc.served == 6 and svc.launches < 6, (svc.served, svc.launches)        # batched: fewer launches than clouds
+        # a stale answer arriving while we wait (same process, older tag) is skipped too
+        svc.resp[0].put(((os.getpid(), 0), 32, None))
+        assert np.array_equal(svc.request(0, clouds[3], 32, 8, timeout=30), want[3])
+        # a failing launch reaches the caller as an error, and the service keeps going
+        svc.fail_next = True
+        with pytest.raises(RuntimeError, match="injected launch failure"):
+            svc.request(1, clouds[1], 32, 6, timeout=30)
+        assert np.array_equal(svc.request(1, clouds[1], 32, 6, timeout=30), want[1])
+        with pytest.raises(RuntimeError, match="beyond the slot size"):
+            svc.request(1, np.zeros((600, 3), np.float32), 32, 0)
+    finally:
+        svc.stop()
