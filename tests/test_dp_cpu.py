@@ -284,57 +284,77 @@ def test_bench_launches_its_own_ranks():
     assert r.returncode != 0
 
 
-def test_fps_service_tags_batches_and_survives_stale_answers():
-    """ppt_amd/data/fps_service.py without a GPU (the launch is replaced by the C oracle's FPS): (1) requests that are pending together
-    ride in ONE launch; (2) indices come back through the shared-memory slot and equal the oracle's; (3) a late answer left in a
-    worker slot's queue by an abandoned request -- another loader's worker with the same id, a timed-out call -- is DISCARDED by its
-    tag instead of being taken for this cloud's indices; (4) a failing launch is reported, and the thread keeps serving."""
-    import threading
+def _fps_worker(svc, clouds, first, n, q, tiny_timeout_first):
+    """forked worker of test_fps_service_*: asks for the FPS of clouds[first .. first + n) and reports (index, indices | error text)"""
+    for i in range(first, first + n):
+        try:
+            if tiny_timeout_first and i == first:
+                try:
+                    svc.request(0, clouds[(i + 1) % len(clouds)], 32, 3, timeout=0.002)      # abandoned: its late answer must not be taken below
+                    q.put((i, "no timeout?"))
+                    continue
+                except TimeoutError:
+                    pass
+            q.put((i, svc.request(0, clouds[i], 32, 5 + i, timeout=60)))
+        except Exception as e:
+            q.put((i, f"{type(e).__name__}: {e}"))
+
+
+def test_fps_service_batches_and_never_hands_out_a_stale_answer():
+    """ppt_amd/data/fps_service.py without a GPU (the launch is replaced by the C oracle's FPS), forked workers: (1) requests that are
+    pending together ride in ONE launch; (2) clouds and indices travel through the shared-memory slots and the indices equal the
+    oracle's; (3) slots are claimed per PROCESS (two loaders' workers share worker ids, never a slot); (4) a request abandoned on a
+    timeout leaves a late answer behind -- the next request of that process waits for ITS OWN sequence number and gets its own
+    indices; (5) a failing launch is reported to the workers that asked, and the thread keeps serving."""
+    import multiprocessing
     import time
     from oracle import oracle as O
     from ppt_amd.data import fps_service as FS
 
     class CpuService(FS.FPSService):
-        fail_next = False
-
-        def _launch(self, wids, N, npoint, starts):
-            if self.fail_next:
-                self.fail_next = False
+        def _launch(self, slots, N, npoint, starts):
+            if self._np["err"][0, -1] == 7:                     # (a flag in shared memory the test sets: the next launch fails)
+                self._np["err"][0, -1] = 0
                 raise ValueError("injected launch failure")
-            time.sleep(0.05)                                   # (requests arriving meanwhile are drained into the next launch)
-            out = []
-            for wdx, st in zip(wids, starts):
-                _, idx = O.dataset_farthest_point_sample(self.xyz[wdx, :N].numpy(), npoint, int(st))
-                out.append(torch.from_numpy(np.asarray(idx, dtype=np.int64)))
-            return torch.stack(out)
+            time.sleep(0.05)                                   # (requests arriving meanwhile ride in the next launch)
+            return np.stack([np.asarray(O.dataset_farthest_point_sample(self._np["xyz"][sl, :N].copy(), npoint, int(st))[1], dtype=np.int64)
+                             for sl, st in zip(slots, starts)])
 
     svc = CpuService(max_workers=8, device="cpu", max_points=512)
+    ctx = multiprocessing.get_context("fork")
     try:
         rng = np.random.default_rng(0)
-        clouds = [rng.standard_normal((300, 3)).astype(np.float32) for _ in range(6)]
+        clouds = [rng.standard_normal((300, 3)).astype(np.float32) for _ in range(12)]
         want = [np.asarray(O.dataset_farthest_point_sample(c, 32, 5 + i)[1], dtype=np.int64) for i, c in enumerate(clouds)]
-        # a stale answer from "another process" sits in slot 2 before anybody asks
-        svc.resp[2].put(((99999, 1), 32, None))
-        got = [None] * 6
-
-        def worker(i):
-            got[i] = svc.request(i, clouds[i], 32, 5 + i, timeout=30)
-        ts = [threading.Thread(target=worker, args=(i,)) for i in range(6)]
-        for t in ts:
-            t.start()
-        for t in ts:
-            t.join()
-        for i in range(6):
-            assert np.array_equal(got[i], want[i]), i
-        assert svc.served == 6 and svc.launches < 6, (svc.served, svc.launches)        # batched: fewer launches than clouds
-        # a stale answer arriving while we wait (same process, older tag) is skipped too
-        svc.resp[0].put(((os.getpid(), 0), 32, None))
-        assert np.array_equal(svc.request(0, clouds[3], 32, 8, timeout=30), want[3])
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_fps_worker, args=(svc, clouds, 2 * w, 2, q, w == 0)) for w in range(6)]
+        for pr in procs:
+            pr.start()
+        got = dict(q.get(timeout=120) for _ in range(12))
+        for pr in procs:
+            pr.join(timeout=30)
+        for i in range(12):
+            assert isinstance(got[i], np.ndarray) and np.array_equal(got[i], want[i]), (i, got[i])
+        assert svc.served >= 12 and svc.launches < svc.served, (svc.served, svc.launches)      # batched: fewer launches than clouds
+        owners = svc._np["owner"]
+        assert len(set(int(o) for o in owners if o)) == 6 and os.getpid() not in owners        # one slot per worker PROCESS
         # a failing launch reaches the caller as an error, and the service keeps going
-        svc.fail_next = True
-        with pytest.raises(RuntimeError, match="injected launch failure"):
-            svc.request(1, clouds[1], 32, 6, timeout=30)
-        assert np.array_equal(svc.request(1, clouds[1], 32, 6, timeout=30), want[1])
+        svc._np["err"][0, -1] = 7
+        pr = ctx.Process(target=_fps_worker, args=(svc, clouds, 3, 2, q, False))
+        pr.start()
+        res = dict(q.get(timeout=120) for _ in range(2))
+        pr.join(timeout=30)
+        assert isinstance(res[3], str) and "injected launch failure" in res[3], res[3]
+        assert np.array_equal(res[4], want[4])
+        # the slots of the processes that are gone are reclaimed when the table is full
+        assert (owners != 0).sum() == 7
+        procs = [ctx.Process(target=_fps_worker, args=(svc, clouds, w, 1, q, False)) for w in range(3)]
+        for pr in procs:
+            pr.start()
+        res = dict(q.get(timeout=120) for _ in range(3))
+        for pr in procs:
+            pr.join(timeout=30)
+        assert all(np.array_equal(res[w], want[w]) for w in range(3))
         with pytest.raises(RuntimeError, match="beyond the slot size"):
             svc.request(1, np.zeros((600, 3), np.float32), 32, 0)
     finally:
