@@ -43,7 +43,8 @@ extern "C" {
 const char *ppt_strerror(int code);
 /* ABI version of this header (currently 7); bumped on any signature change or added entry point.
  * 7: ppt_gemm_params.split_overflow (new trailing field: split16 saturates finite values beyond IEEE half's range and counts
- *    the workgroups that did), ppt_vit_mlp3_bf16 / ppt_vit_mlp3_retile / ppt_vit_proj3_retile (new: csrc/mlp_fused3.hip).
+ *    the workgroups that did), ppt_vit_mlp3_bf16 / ppt_vit_mlp3_retile (new: csrc/mlp_fused3.hip), ppt_text_mlp_pair /
+ *    ppt_text_mlp_retile (new: csrc/text_mlp.hip).
  * 6: ppt_gemm_params.split16 / split_a_pow2 / split_b_pow2 (new trailing fields: fp32 operands as hi + lo half pairs),
  *    ppt_attention_fwd_split16 / ppt_attention_bwd_split16 (new), ppt_pointmlp_cloud_rstd / ppt_pointmlp_pq (new).
  * 5: ppt_labels_check (new), ppt_gemm256 (new: the 256-row macro-tile GEMM core), ppt_set_gemm256 / ppt_get_gemm256 (new),
@@ -312,6 +313,29 @@ int ppt_layernorm_fwd_sum(const float *x, const float *bias, const float *parts,
                           void *y, int y_dtype, float *mean, float *rstd, int M, int D, float eps, void *stream);
 int ppt_layernorm_bwd_sum(const float *dy_parts, int S, const float *xs, const float *w, const float *mean, const float *rstd,
                           float *dx, int accumulate_dx, void *dx_copy, int dx_copy_dtype, int M, int D, void *stream);
+
+/* ---- the MLP half of a CLIP text-tower layer as one launch per direction (ABI 7; csrc/text_mlp.hip) -------------------------
+ * Replaces the two Linears + QuickGELU of ResidualAttentionBlock.mlp (ULIP_models.py:41-42, 49-51) on the prompt chain:
+ *   mode 0 (forward):  parts[s] = QuickGELU( A W1[slice s]^T + b1[slice s] ) W2[:, slice s]^T,  pre (optional) = A W1^T + b1
+ *   mode 1 (backward): parts[s] = ( (A W1[slice s]^T) * QuickGELU'(pre[:, slice s]) ) W2[:, slice s]^T
+ * for the eight 256-unit slices of the 2048-wide hidden dimension: A [M, 512] (lda elements per row) and pre [M, 2048] in `dtype`
+ * (PPT_BF16 | PPT_F16), parts [8, M, 512] f32 -- the caller's LayerNorm adds the slices up in order (ppt_layernorm_fwd_sum /
+ * ppt_layernorm_bwd_sum).  W1 [2048, 512] / W2 [512, 2048] row-major 16-bit (forward: c_fc.weight / c_proj.weight; backward:
+ * c_proj.weight^T / c_fc.weight^T) RE-TILED once by ppt_text_mlp_retile.  The hidden activation never exists in memory.
+ * D must be 512 and hidden 2048 (PPT_EUNSUPPORTED otherwise). */
+typedef struct ppt_text_mlp_params {
+    const void *A; int64_t lda;
+    const void *W1; const void *W2;          /* fragment-ordered copies (ppt_text_mlp_retile) */
+    const float *b1;                         /* [2048] or NULL (mode 0 only) */
+    void *pre;                               /* [M, 2048] dtype: written in mode 0 (may be NULL), read in mode 1 */
+    float *parts;                            /* [8, M, 512] */
+    int M, D, hidden;
+    int mode;                                /* 0 forward, 1 backward */
+    int dtype;
+    int wave_prio;                           /* != 0: raised issue priority (0: what ppt_set_wave_priority set) */
+} ppt_text_mlp_params;
+int ppt_text_mlp_retile(const void *W1, const void *W2, void *W1_tiled, void *W2_tiled, void *stream);
+int ppt_text_mlp_pair(const ppt_text_mlp_params *p, void *stream);
 
 /* ---- Attention ---------------------------------------------------------------------------------
  * softmax(scale * q k^T [+ causal mask]) v per (batch, head).  Replaces

@@ -34,6 +34,14 @@ class GemmParams(ctypes.Structure):
     ]
 
 
+class TextMlpParams(ctypes.Structure):
+    """struct ppt_text_mlp_params (include/ppt_hip.h) -- field order must match the header."""
+    _fields_ = [
+        ("A", c_void_p), ("lda", c_int64), ("W1", c_void_p), ("W2", c_void_p), ("b1", c_void_p), ("pre", c_void_p), ("parts", c_void_p),
+        ("M", c_int), ("D", c_int), ("hidden", c_int), ("mode", c_int), ("dtype", c_int), ("wave_prio", c_int),
+    ]
+
+
 class VitMlpParams(ctypes.Structure):
     """struct ppt_vit_mlp_params (include/ppt_hip.h) -- field order must match the header."""
     _fields_ = [
@@ -102,6 +110,8 @@ _SIGNATURES = {
     "ppt_vit_mlp_retile": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ppt_vit_proj_retile": (c_int, [c_void_p, c_void_p, c_void_p]),
     "ppt_vit_mlp_bf16": (c_int, [ctypes.POINTER(VitMlpParams), c_void_p]),
+    "ppt_text_mlp_retile": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ppt_text_mlp_pair": (c_int, [ctypes.POINTER(TextMlpParams), c_void_p]),
     "ppt_vit_mlp3_retile": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ppt_vit_mlp3_bf16": (c_int, [ctypes.POINTER(VitMlpParams), c_void_p]),
     "ppt_rowgemm_bf16": (c_int, [ctypes.POINTER(RowGemmParams), c_void_p]),

@@ -859,6 +859,21 @@ TEXT_SPLITK = os.environ.get("PPT_TEXT_SPLITK", "1") != "0"
 POINTMLP_FUSED_NORM = os.environ.get("PPT_POINTMLP_FUSED_NORM", "1") != "0"
 
 
+# The MLP half of a text layer as ONE launch per direction (csrc/text_mlp.hip: 32-row blocks x 256-unit hidden slices, the hidden
+# activation never in memory, eight partial products summed by the LayerNorm that follows).  Supported switch:
+# PPT_TEXT_MLP_PAIR=0 restores c_fc + split-K c_proj as two launches.
+TEXT_MLP_PAIR = os.environ.get("PPT_TEXT_MLP_PAIR", "1") != "0"
+
+
+def _text_mlp_tiles(sd, p, wcm, backward):
+    """The fragment-ordered weight copies of layer `p` for ops.text_mlp_pair: forward (c_fc.weight, c_proj.weight); backward the
+    transposed pair (c_proj.weight^T [2048, 512], c_fc.weight^T [512, 2048]) -- the dX operands the WeightCache already keeps."""
+    wfc, wpr = sd[p + "mlp.c_fc.weight"], sd[p + "mlp.c_proj.weight"]
+    if backward:
+        return wcm.derived(("text_mlp_tiles_bwd", p), (wfc, wpr), lambda: ops.text_mlp_retile(wcm.get(wpr, "wt"), wcm.get(wfc, "wt")))
+    return wcm.derived(("text_mlp_tiles_fwd", p), (wfc, wpr), lambda: ops.text_mlp_retile(wcm.get(wfc), wcm.get(wpr)))
+
+
 def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=None, prefix=0, rows_in=None):
     """encode_text: prompts [C,L,W] fp32 -> text features [C,E] fp32 (before L2 normalisation).
     save=True keeps what the input-gradient backward needs.
@@ -955,6 +970,18 @@ def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=No
         x_mid = torch.empty_like(x)
         ops.gemm(a, wca.get(sd[p + "attn.out_proj.weight"]), out=x_mid, bias=sd[p + "attn.out_proj.bias"], residual=x)
         pre = torch.empty((M, sd[p + "mlp.c_fc.weight"].shape[0]), dtype=Tm, device=dev) if save else None
+        pair = (TEXT_MLP_PAIR and splitk and i + 1 < layers and Tm in ops.HALF and tuple(sd[p + "mlp.c_fc.weight"].shape) == (2048, 512))
+        if pair:
+            # c_fc + QuickGELU + c_proj in one launch; its eight partial products are this layer's output once the next layer's
+            # LayerNorm has added them to x_mid and the bias (the split-K hand-over below, with 8 slices instead of 4)
+            h2, mean2, rstd2 = ops.layernorm_fwd(x_mid, sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], Tm, save_stats=save)
+            w1t, w2t = _text_mlp_tiles(sd, p, wcm, False)
+            parts = ops.text_mlp_pair(h2, w1t, w2t, bias=sd[p + "mlp.c_fc.bias"], pre=pre)
+            if save:
+                saved["layers"].append(dict(x=x, mean1=mean1, rstd1=rstd1, qkv=qkv, a=a, lse=lse, x_mid=x_mid, mean2=mean2,
+                                            rstd2=rstd2, pre=pre))
+            pending = (x_mid, sd[p + "mlp.c_proj.bias"], parts)
+            continue
         if fuse:
             st2 = stats()
             mean2, rstd2 = st2 if save else (None, None)
@@ -1026,9 +1053,19 @@ def text_tower_backward(sd, wc, s, dout, grad_scale=1.0):
     for i in reversed(range(len(s["layers"]))):
         p = f"transformer.resblocks.{i}."
         ly = s["layers"][i]
-        d_pre = ops.gemm(g_t, wcm.get(sd[p + "mlp.c_proj.weight"], "wt"), out_dtype=Tm, act=ACT_QUICKGELU,
-                         dact_pre=ly["pre"])
-        if splitk:
+        if TEXT_MLP_PAIR and splitk and Tm in ops.HALF and tuple(sd[p + "mlp.c_fc.weight"].shape) == (2048, 512):
+            # the branch's input gradient ((g W_proj) * QuickGELU'(pre)) W_fc in one launch: eight partial products, added up by the
+            # LayerNorm backward that reads them
+            w1t, w2t = _text_mlp_tiles(sd, p, wcm, True)
+            _, g_t = ops.layernorm_bwd_sum(ops.text_mlp_pair(g_t, w1t, w2t, pre=ly["pre"], backward=True), ly["x_mid"],
+                                           sd[p + "ln_2.weight"], ly["mean2"], ly["rstd2"], g, accumulate=True, copy_dtype=Ta)
+            d_pre = None
+        else:
+            d_pre = ops.gemm(g_t, wcm.get(sd[p + "mlp.c_proj.weight"], "wt"), out_dtype=Tm, act=ACT_QUICKGELU,
+                             dact_pre=ly["pre"])
+        if d_pre is None:
+            pass
+        elif splitk:
             # K = 2048 over 817 rows: four K slices, added up by the LayerNorm backward that reads the product (see the forward)
             _, g_t = ops.layernorm_bwd_sum(ops.gemm_splitk(d_pre, wcm.get(sd[p + "mlp.c_fc.weight"], "wt"), 4), ly["x_mid"],
                                            sd[p + "ln_2.weight"], ly["mean2"], ly["rstd2"], g, accumulate=True, copy_dtype=Ta)

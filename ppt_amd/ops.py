@@ -385,6 +385,37 @@ def vit_mlp_retile(w1, w2, variant=None):
     return w1t, w2t
 
 
+def text_mlp_retile(w1, w2):
+    """(w1 [2048, 512], w2 [512, 2048]) 16-bit row-major -> the fragment-ordered copies ppt_text_mlp_pair reads.  Forward:
+    (c_fc.weight, c_proj.weight); backward: (c_proj.weight^T, c_fc.weight^T) -- the same shapes."""
+    assert w1.dtype in HALF and w2.dtype == w1.dtype and tuple(w1.shape) == (2048, 512) and tuple(w2.shape) == (512, 2048)
+    _chk(w1, w1.dtype, "w1"); _chk(w2, w1.dtype, "w2")
+    w1t, w2t = torch.empty_like(w1), torch.empty_like(w2)
+    _lib.check(_lib.lib().ppt_text_mlp_retile(_p(w1), _p(w2), _p(w1t), _p(w2t), _stream()), "ppt_text_mlp_retile")
+    return w1t, w2t
+
+
+def text_mlp_pair(a, w1t, w2t, *, bias=None, pre=None, backward=False):
+    """The MLP half of a CLIP text layer in one launch (csrc/text_mlp.hip) -> the eight slices' partial products [8, M, 512] f32.
+    forward: QuickGELU(a w1^T + bias) w2^T, `pre` (optional, [M, 2048] 16-bit) receives the pre-activation; backward=True:
+    ((a w1^T) * QuickGELU'(pre)) w2^T with w1 / w2 the transposed weights' tiled copies.  The caller's LayerNorm sums the slices
+    (layernorm_fwd_sum / layernorm_bwd_sum)."""
+    assert a.dtype in HALF and a.dim() == 2 and a.shape[1] == 512 and a.stride(1) == 1 and w1t.dtype == a.dtype and w2t.dtype == a.dtype
+    M = a.shape[0]
+    parts = torch.empty((8, M, 512), dtype=torch.float32, device=a.device)
+    p = _lib.TextMlpParams()
+    p.A, p.lda, p.W1, p.W2, p.b1, p.pre, p.parts = _p(a), a.stride(0), _p(w1t), _p(w2t), _p(bias), _p(pre), _p(parts)
+    p.M, p.D, p.hidden, p.mode, p.dtype = M, 512, 2048, int(bool(backward)), dtype_code(a)
+    if pre is not None:
+        assert pre.dtype == a.dtype and tuple(pre.shape) == (M, 2048) and pre.is_contiguous()
+    if profiler is not None:
+        profiler.begin("gemm_bf16", 4.0 * M * 512 * 2048, "ppt_text_mlp_pair (" + ("backward" if backward else "forward") + ")")
+    _lib.check(_lib.lib().ppt_text_mlp_pair(ctypes.byref(p), _stream()), "ppt_text_mlp_pair")
+    if profiler is not None:
+        profiler.end()
+    return parts
+
+
 def vit_proj_retile(wp):
     """attn.proj.weight [384,384] (16-bit) -> the fragment-ordered copy the fused proj prologue of ppt_vit_mlp_bf16 reads."""
     assert wp.dtype in HALF and tuple(wp.shape) == (384, 384)

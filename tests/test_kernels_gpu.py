@@ -1485,6 +1485,52 @@ def test_vit_mlp_with_the_proj_prologue_matches_proj_then_mlp(ops, M, rows, dtyp
     assert torch.equal(again, out)
 
 
+# ------------------------------------------------------------------ the text tower's MLP half in one launch (csrc/text_mlp.hip)
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M", [817, 64, 1480, 5])
+def test_text_mlp_pair_matches_the_two_linears(ops, M, dtype):
+    """ppt_text_mlp_pair (c_fc + QuickGELU + c_proj of a CLIP layer, ULIP_models.py:41-42, as one launch over 64-row blocks x 256-unit
+    hidden slices; the eight slices' partial products are summed by the caller's LayerNorm) against fp32 torch math on the operands the
+    MFMAs see, forward and backward (the branch's input gradient: the tower is frozen), and against the launches it replaces
+    (ppt_gemm with the QuickGELU / derivative epilogue + the split-K product); the saved pre-activation; ragged last block;
+    bit-reproducible."""
+    g = torch.Generator().manual_seed(M)
+    D, Hd = 512, 2048
+    rd = lambda t: t.to(dtype).float()
+    a = torch.randn(M, D, generator=g)
+    w1, b1 = torch.randn(Hd, D, generator=g) * D ** -0.5, 0.1 * torch.randn(Hd, generator=g)
+    w2 = torch.randn(D, Hd, generator=g) * Hd ** -0.5
+    qg = lambda v: v * torch.sigmoid(1.702 * v)
+    pre = rd(a) @ rd(w1).t() + b1
+    want = rd(qg(pre)) @ rd(w2).t()
+    ad, w1d, w2d = a.cuda().to(dtype), w1.cuda().to(dtype), w2.cuda().to(dtype)
+    w1t, w2t = ops.text_mlp_retile(w1d, w2d)
+    pre_out = torch.empty((M, Hd), dtype=dtype, device="cuda")
+    parts = ops.text_mlp_pair(ad, w1t, w2t, bias=b1.cuda(), pre=pre_out)
+    assert parts.shape == (8, M, D)
+    got = parts.sum(0).cpu()
+    tol = (4e-3 if dtype == torch.float16 else 3e-2) * max(1.0, want.abs().max().item())
+    assert (got - want).abs().max().item() < tol
+    assert (pre_out.float().cpu() - pre).abs().max().item() < (2e-3 if dtype == torch.float16 else 2e-2) * max(1.0, pre.abs().max().item())
+    # the launches it replaces
+    f = ops.gemm(ad, w1d, out_dtype=dtype, bias=b1.cuda(), act=ops.ACT_QUICKGELU)
+    ref = ops.gemm(f, w2d, out_dtype=torch.float32)
+    assert (got.cuda() - ref).abs().max().item() < tol / 2
+    assert torch.equal(ops.text_mlp_pair(ad, w1t, w2t, bias=b1.cuda()), parts)          # (no pre output: same partial products, bit for bit)
+    # ---- backward: d h2 = ((d_out W_proj) * QuickGELU'(pre)) W_fc, i.e. W1 = c_proj^T [2048, 512], W2 = c_fc^T [512, 2048]
+    dout = torch.randn(M, D, generator=g)
+    pre_r = rd(pre)
+    sg = torch.sigmoid(1.702 * pre_r)
+    dpre = (rd(dout) @ rd(w2)) * (sg * (1 + 1.702 * pre_r * (1 - sg)))
+    dwant = rd(dpre) @ rd(w1)
+    b1t, b2t = ops.text_mlp_retile(w2d.t().contiguous(), w1d.t().contiguous())
+    dparts = ops.text_mlp_pair(dout.cuda().to(dtype), b1t, b2t, pre=pre_r.cuda().to(dtype), backward=True)
+    dgot = dparts.sum(0).cpu()
+    dtol = (4e-3 if dtype == torch.float16 else 3e-2) * max(1.0, dwant.abs().max().item())
+    assert (dgot - dwant).abs().max().item() < dtol
+    assert torch.equal(ops.text_mlp_pair(dout.cuda().to(dtype), b1t, b2t, pre=pre_r.cuda().to(dtype), backward=True), dparts)
+
+
 @pytest.mark.parametrize("tag,N,M,dup,cols", [("d", 8192, 1024, False, 3), ("e", 2048, 512, True, 6)])
 def test_dataset_fps_is_bit_exact(tag, N, M, dup, cols):
     """ppt_amd.data.farthest_point_sample(point, npoint) (data/dataset_3d.py:40-61 on the FPS kernel): the rows the reference
