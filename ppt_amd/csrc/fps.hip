@@ -88,33 +88,9 @@ __global__ __launch_bounds__(W * 64) void fps_kernel(const float *__restrict__ x
             }
         }
         const uint32_t bits = __float_as_uint(best);
-#ifdef PPT_FPS_KEY64
-        // Measured variant (tools/fps_bench.py with a -DPPT_FPS_KEY64 build): ONE reduction over the 64-bit key
-        // (distance bits << 32) | ~index -- max distance, then lowest index -- instead of the 32-bit max + ballot (+ the rare index
-        // reduction).  There is no 64-bit v_max: every butterfly step is two DPP moves, a 64-bit compare and two selects.
-        uint32_t khi = bits, klo = ~bi;
-#define PPT_KEY64_STEP(CTRL)                                                                                   \
-        {                                                                                                      \
-            const uint32_t ohi = dpp_mov<CTRL, 0xf>(khi), olo = dpp_mov<CTRL, 0xf>(klo);                       \
-            const bool take = (ohi > khi) | ((ohi == khi) & (olo > klo));                                      \
-            khi = take ? ohi : khi; klo = take ? olo : klo;                                                    \
-        }
-        PPT_KEY64_STEP(0xB1) PPT_KEY64_STEP(0x4E) PPT_KEY64_STEP(0x141) PPT_KEY64_STEP(0x140)
-#undef PPT_KEY64_STEP
-        {   // rows -> halves -> wave: the four row winners sit in lanes 0, 16, 32, 48 (any lane of a row holds its row's winner)
-            uint32_t bh = khi, bl = klo;
-#pragma unroll
-            for (int rr = 1; rr < 4; ++rr) {
-                const uint32_t ohi = (uint32_t)__builtin_amdgcn_readlane((int)khi, 16 * rr), olo = (uint32_t)__builtin_amdgcn_readlane((int)klo, 16 * rr);
-                const bool take = (ohi > bh) | ((ohi == bh) & (olo > bl));
-                bh = take ? ohi : bh; bl = take ? olo : bl;
-            }
-            khi = (uint32_t)__builtin_amdgcn_readfirstlane((int)bh); klo = (uint32_t)__builtin_amdgcn_readfirstlane((int)bl);
-        }
-        const uint32_t wmax = khi;
-        const uint32_t widx = ~klo;
-        const int wl = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)__ballot(bi == widx && bits == wmax)) - 1);
-#else
+        // (Removed in round 6, measured in round 4, profiles/r04_fps_variants.md: ONE reduction over the 64-bit key (distance bits
+        // << 32) | ~index instead of the 32-bit max + ballot -- bit-exact, 567 ns per pick against 439; and one wave per cloud
+        // with 16 points per lane -- 579 ns.)
         const uint32_t wmax = wave_reduce_umax(bits);
         // the lane that holds the wave's arg-max: with a single maximal lane (the common case) a ballot names it; equal
         // distances in several lanes (duplicated points) go through the index reduction, lowest index wins
@@ -125,7 +101,6 @@ __global__ __launch_bounds__(W * 64) void fps_kernel(const float *__restrict__ x
         }
         const int wl = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)cand) - 1);
         const uint32_t widx = (uint32_t)__builtin_amdgcn_readlane((int)bi, wl);
-#endif
         fps_slot *sl = slots + (it & 1) * W;
         if constexpr (XYZ_LDS) {
             if (lane == 0) { sl[w].dist_bits = wmax; sl[w].idx = widx; }
@@ -213,9 +188,6 @@ extern "C" int ppt_fps_f32(const float *xyz, int B, int N, int M, const int64_t 
     // points per lane x waves, measured with the cloud in LDS (tools/fps_bench.py, B = 32): more waves only lengthen the
     // barrier and the slot fold -- 8192 points: <8,16> 732 us, <16,8> 495 us, <32,4> 558 us; 2048: <4,8> 300, <8,4> 286,
     // <16,2> 326; 1024: <4,4> 234, <8,2> 244, <16,1> 302
-#ifdef PPT_FPS_ONE_WAVE
-    if (N <= 1024) return launch_fps<16, 1>(xyz, B, N, M, start, out_idx, out_xyz, s);       // measured variant: one wave per cloud, the barrier degenerates
-#endif
     if (N <= 1024) return launch_fps<4, 4>(xyz, B, N, M, start, out_idx, out_xyz, s);
     if (N <= 2048) return launch_fps<8, 4>(xyz, B, N, M, start, out_idx, out_xyz, s);
     if (N <= 4096) return launch_fps<16, 4>(xyz, B, N, M, start, out_idx, out_xyz, s);

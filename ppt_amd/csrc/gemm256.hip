@@ -347,60 +347,10 @@ __global__ __launch_bounds__(NT2, (BN == 256 || EPI < 0) ? 2 : 4) void gemm256_k
 #endif
 }
 
-// ---- the half-height tile: 128 x 256 per 256-thread workgroup, TWO workgroups per CU -------------------------------------------
-// Same wave tile (128 x 64: 4 waves as 1 x 4), 24 KiB stages (A 8 + B 16), three of them: 72 KiB, 200 VGPRs -> two workgroups
-// share a CU and nothing ties them together, so one's epilogue (a CU retires ~12 B/clk of stores: the 64 KiB of a tile take ~5 000
-// cycles, its GELU as long again) runs under the other's K loop.  The price is the fill: 85 FLOP per L2 -> LDS byte instead of 128.
-// For the short-K, wide-N linears (qkv, fc1: K = 384), where the 256 x 256 tile spends as long in its epilogue as in its K loop.
-template <typename T, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm128x256_kernel(const ppt_gemm_params p)
-{
-    constexpr int BM = 128, BN = 256, NSTAGE = 3;
-    constexpr int WM = 128, WN = 64, TI = 4, TJ = 2;
-    constexpr int A_BYTES = BM * ROWH, B_BYTES = BN * ROWH, STAGE = A_BYTES + B_BYTES;
-    constexpr int LOADS = BM / 64 + BN / 64;                                   // LDS-DMA instructions per wave per stage (6)
-    __shared__ __align__(16) unsigned char smem[NSTAGE * STAGE];
-    static_assert(NSTAGE * STAGE >= 4 * 32 * WN * 2, "sliced park");
-    constexpr int BK = ROWH / sizeof(T);
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    PPT_PRIO(p.wave_prio);
-    const int nwg = gridDim.x * gridDim.y;
-    const int lin0 = blockIdx.y * gridDim.x + blockIdx.x;
-    const int q8 = nwg / 8, r8 = nwg % 8, xcd = lin0 % 8;
-    const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + lin0 / 8;
-    const int n0 = (lin % gridDim.x) * BN, m0 = (lin / gridDim.x) * BM;
-    const T *A = reinterpret_cast<const T *>(p.A) + (int64_t)blockIdx.z * p.strideA;
-    const T *B = reinterpret_cast<const T *>(p.B) + (int64_t)blockIdx.z * p.strideB;
-    const int nslab = p.K / BK, last = nslab - 1;
-    auto issue = [&](int slab, int stage) {
-        glds_half8<T, BM, 4>(A, p.lda, p.M, m0, slab * BK, smem + stage * STAGE, w, lane);
-        glds_half8<T, BN, 4>(B, p.ldb, p.N, n0, slab * BK, smem + stage * STAGE + A_BYTES, w, lane);
-    };
-    issue(0, 0);
-    issue(min(1, last), 1);
-    f32x16_t acc[TI][TJ];
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int j = 0; j < TJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    EpiPre<TI, TJ> epre;
-    epilogue_prefetch<TI, TJ, (EPI & EPI_GROUP) != 0>(p, epre, lane, m0, n0 + w * WN);
-    int stage = 0;
-    for (int s = 0; s < nslab; ++s) {
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LOADS) : "memory");      // own pieces of slab s landed (slab s + 1 may fly)
-        __builtin_amdgcn_s_barrier();
-        int nstage = stage + 2; if (nstage >= NSTAGE) nstage -= NSTAGE;
-        issue(min(s + 2, last), nstage);                  // that stage was last read at slab s - 1, before this barrier
-        mma_half8<T, TI, TJ>(smem + stage * STAGE, smem + stage * STAGE + A_BYTES, 0, w * WN, lane, acc);
-        stage = stage + 1 == NSTAGE ? 0 : stage + 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    epilogue_regs_sliced<TI, TJ, EPI>(p, acc, epre, smem + w * (32 * WN * 2), lane, m0, n0 + w * WN, (int64_t)blockIdx.z * p.strideC);
-}
+// (Removed in round 6: the half-height tile -- 128 x 256 per 256-thread workgroup, two workgroups per CU so that one's epilogue
+// runs under the other's K loop.  Measured in round 5 (profiles/r05_gemm_core.md): no gain over the 256 x 256 tile -- fc1 47.4 vs
+// 45.4 us, qkv 31.0 vs 32.2 us at 16 416 rows; what it wins back under the other workgroup's K loop it loses to the 1.5 x fill
+// bytes per FLOP.)
 
 extern "C" int ppt_get_gemm256(void);
 
@@ -420,21 +370,6 @@ int launch256(const ppt_gemm_params &p, int bn, hipStream_t s)
     // partials: qkv, fc1, conv3); everything else takes the LDS walk (EPI = -1), which has no statistics / group term
     int epi = (p.C && reg_epilogue_ok<4>(p, 0)) ? epi_mask(p) : -1;
     if (epi != 0 && epi != EPI_GELU && !(bn == 256 && epi == (EPI_GROUP | EPI_STATS))) epi = -1;
-    // 128 x 256 tiles, two workgroups per CU, up to this K.  Measured (r05): no gain over the 256 x 256 tile -- fc1 47.4 vs 45.4 us,
-    // qkv 31.0 vs 32.2 us at 16 416 rows: what it wins back under the other workgroup's K loop it loses to the 1.5 x fill bytes
-    // per FLOP.  Off by default; PPT_GEMM256_HALF_K=512 to re-measure.
-    static const int half_k = env_int("PPT_GEMM256_HALF_K", 0);
-    if (bn == 256 && epi >= 0 && p.K <= half_k) {
-        dim3 g2((p.N + 255) / 256, (p.M + 127) / 128, batch);
-        if (g2.y > 65535) return PPT_EUNSUPPORTED;
-        switch (epi) {
-        case 0: hipLaunchKernelGGL((gemm128x256_kernel<T, 0>), g2, dim3(256), 0, s, p); break;
-        case EPI_GELU: hipLaunchKernelGGL((gemm128x256_kernel<T, EPI_GELU>), g2, dim3(256), 0, s, p); break;
-        default: hipLaunchKernelGGL((gemm128x256_kernel<T, EPI_GROUP | EPI_STATS>), g2, dim3(256), 0, s, p); break;
-        }
-        PPT_CHECK_LAUNCH();
-        return PPT_OK;
-    }
     if (bn == 256) {
         switch (epi) {
         case 0: hipLaunchKernelGGL((gemm256_kernel<T, 256, 4, 0, PPV>), grid, dim3(NT2), 0, s, p); break;

@@ -28,5 +28,5 @@ for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
 PY
     find "$OUT/gemm256_pmc_$d" -type f ! -name 'counter_summary.csv' -delete
 done
-PPT_GEMM256_HALF_K=0 python3 "$ROOT/tools/gemm256_stamp.py" qkv fc1p fc1 fc2 proj sq4k > "$OUT/gemm256_stamps.log" 2>&1
+python3 "$ROOT/tools/gemm256_stamp.py" qkv fc1p fc1 fc2 proj sq4k > "$OUT/gemm256_stamps.log" 2>&1
 du -sh "$OUT"; tail -30 "$OUT/gemm256_bench.log"
