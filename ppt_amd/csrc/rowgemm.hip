@@ -314,7 +314,16 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(const ppt_rowgemm_param
         RG_STAMP(4);
         load_res(min(t + n_walk, n_tiles - 1));
         t_prev = t;
+        // (round 6) an LDS-only barrier: __syncthreads() is a release + acquire around s_barrier, i.e. s_waitcnt vmcnt(0) -- it
+        // drained the next tiles' row requests and the previous tile's stores at the end of every iteration.  Nothing here hands
+        // GLOBAL data from wave to wave; the A buffers and the C image are LDS.  PPT_RG_SYNC=1 (compile time) restores it for A/B.
+#ifdef PPT_RG_SYNC
         __syncthreads();
+#else
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#endif
         RG_STAMP(5);
     }
     if (t_prev >= 0) store_tile(t_prev, (it - 1) & 1);

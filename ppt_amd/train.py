@@ -332,7 +332,7 @@ class Trainer:
         iteration i+1's point tower overlaps iteration i's text backward.  `loss` and `pred` are ordinary
         tensors of the caller's stream; parameters are final after `finish()`."""
         model = self.model
-        if self.it == 0 and self.grad_calibration is None and not self._dry:
+        if self.grad_calibration is None and not self._dry:      # (the first step of THIS trainer, whatever `it` a resume set)
             self.calibrate_gradients(pc, label)
         side = self._side_used = self._prompt_stream(pc)
         pe = getattr(model, "point_encoder", None)
@@ -689,13 +689,17 @@ def checkpoint_payload(model, optimizer, epoch, best_acc, args, head_type=0, par
     if torch.cuda.is_available():
         torch.cuda.synchronize()           # Trainer.step leaves the optimizer queued on the model's text stream
     opt = reference_optimizer_state(model, optimizer)
+    # One key beyond the reference's (its readers index the keys they know and ignore the rest): the precision mode the run was IN
+    # -- the mixed mode may have left for split16 at its first-batch gradient self-check (Trainer.calibrate_gradients), and a
+    # resumed run must evaluate and continue in that mode, not re-decide (load_prompt_checkpoint applies it).
+    mode = {'ppt_precision': getattr(model, 'precision_name', None)}
     if partseg:
         return {'epoch': epoch + 1, 'state_dict_prompt': model.prompt_learner.state_dict(),
                 'state_dict_partseg': model.point_encoder.state_dict(), 'optimizer': opt, 'best_test_acc': best_acc,
-                'best_mean_class_iou': best_mean_class_iou, 'best_mean_inst_iou': best_mean_inst_iou, 'args': args}
+                'best_mean_class_iou': best_mean_class_iou, 'best_mean_inst_iou': best_mean_inst_iou, 'args': args, **mode}
     return {'epoch': epoch + 1, 'state_dict': model.prompt_learner.state_dict(),
             'last_block': model.point_encoder.blocks.blocks[-1].state_dict() if head_type > 0 else None,
-            'optimizer': opt, 'best_acc': best_acc, 'args': args}
+            'optimizer': opt, 'best_acc': best_acc, 'args': args, **mode}
 
 
 def load_prompt_checkpoint(model, ckpt):
@@ -707,4 +711,7 @@ def load_prompt_checkpoint(model, ckpt):
         model.load_state_dict(blk, strict=False)
     if ckpt.get('state_dict_partseg'):
         model.point_encoder.load_state_dict(ckpt['state_dict_partseg'])
+    mode = ckpt.get('ppt_precision')       # (absent in the reference's own files: the model keeps the mode it was built with)
+    if mode and hasattr(model, "set_precision") and getattr(model, "precision_name", mode) != mode:
+        model.set_precision(mode)
     return model

@@ -153,7 +153,9 @@ def test_checkpoint_payload_roundtrip(tmp_path):
     m, _ = make(3)
     opt = torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-3)
     payload = checkpoint_payload(m, opt, epoch=4, best_acc=91.5, args={"model": "ULIP_PointBERT"}, head_type=3)
-    assert set(payload) == {'epoch', 'state_dict', 'optimizer', 'best_acc', 'args', 'last_block'}
+    # the reference's keys, plus ONE of ours that its readers never look at: the precision mode the run was in (round 6)
+    assert set(payload) == {'epoch', 'state_dict', 'optimizer', 'best_acc', 'args', 'last_block', 'ppt_precision'}
+    assert payload['ppt_precision'] == m.precision_name
     assert list(payload['state_dict']) == ['learnable_tokens'] and 'attn.qkv.weight' in payload['last_block']
     f = tmp_path / "checkpoint_best.pt"
     torch.save(payload, f)
@@ -177,7 +179,7 @@ def test_partseg_checkpoint_payload_uses_the_reference_keys(tmp_path):
     payload = checkpoint_payload(m, opt, epoch=2, best_acc=93.0, args={}, partseg=True, best_mean_class_iou=81.0,
                                  best_mean_inst_iou=84.5)
     assert set(payload) == {'epoch', 'state_dict_prompt', 'state_dict_partseg', 'optimizer', 'best_test_acc',
-                            'best_mean_class_iou', 'best_mean_inst_iou', 'args'}
+                            'best_mean_class_iou', 'best_mean_inst_iou', 'args', 'ppt_precision'}
     assert list(payload['state_dict_prompt']) == ['learnable_tokens'] and payload['best_test_acc'] == 93.0
     f = tmp_path / "checkpoint_best.pt"
     torch.save(payload, f)
