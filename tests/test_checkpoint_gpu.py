@@ -75,7 +75,9 @@ def test_cls_checkpoint_written_on_the_gpu_resumes_bit_identically(head_type, tm
     after_a = {n: p.detach().clone() for n, p in a.named_parameters() if p.requires_grad}
 
     ckpt = torch.load(f, weights_only=False)
-    assert set(ckpt) == {'epoch', 'state_dict', 'optimizer', 'best_acc', 'args', 'last_block'} and ckpt['epoch'] == 1
+    # (the reference's keys + 'ppt_precision': the mode the run was in, which a resumed run continues in -- round 6)
+    assert set(ckpt) == {'epoch', 'state_dict', 'optimizer', 'best_acc', 'args', 'last_block', 'ppt_precision'} and ckpt['epoch'] == 1
+    assert ckpt['ppt_precision'] == a.precision_name
     assert (ckpt['last_block'] is not None) == (head_type > 0)
     b = _cls_model(head_type)
     if head_type:                                   # (Q4: the un-frozen block is random per construction; the checkpoint overrides it)
