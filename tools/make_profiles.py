@@ -15,7 +15,7 @@ import pandas as pd
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # the bf16 MFMA GEMM family (what bench.py's roofline object is about): tile GEMMs, the fused mini-PointNet kernels, the
 # weight-stationary short-K linears and the fused ViT MLP
-GEMM_BF16 = r"gemm_kernel.*<(unsigned short|f16_t)|gemm256_kernel|gemm_tn_kernel|mpn[134]_kernel|rowgemm_kernel|vit_mlp_kernel"
+GEMM_BF16 = r"gemm_kernel.*<(unsigned short|f16_t)|gemm256_kernel|gemm_tn_kernel|mpn[134]_kernel|rowgemm_kernel|vit_mlp_kernel|vit_mlp3_kernel|text_mlp_kernel"
 CONFIGS = ("c2", "c3", "c4", "c5", "mlp")
 TRACE_STEPS = 40 + 5 + 10                   # burn-in + warm-up + timed steps of the traced command
 
