@@ -646,7 +646,7 @@ def main():
         # figure of the newest committed profile of this same command (two --pmc passes: FETCH_SIZE x2 + WRITE_SIZE), labelled
         # with its source; likewise the rocprofv3 kernel-trace fraction of that round beside the live event-bracket one
         traffic = traffic_source = rocprof_family = None
-        for rnd in ("r05", "r04", "r03", "r02", "r01"):
+        for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
             tf = os.path.join(ROOT, "profiles", f"{rnd}_gemm_hbm_traffic.json")
             if a.config == "C2" and os.path.exists(tf):
                 tj = json.load(open(tf))
@@ -654,7 +654,7 @@ def main():
                 traffic_source = f"profiles/{rnd}_gemm_hbm_traffic.json (rocprofv3 --pmc passes of this command, round {rnd[1:]}; not measured in this run)"
                 rocprof_family = tj.get("rocprof_family")
                 break
-        roof = {"bound": "mfma", "kernel": "16-bit (fp16 / bf16) MFMA GEMM family (ppt_amd/csrc/gemm.hip, rowgemm.hip, mlp_fused.hip, mpn1/mpn3/mpn4.hip)",
+        roof = {"bound": "mfma", "kernel": "16-bit (fp16 / bf16) MFMA GEMM family (ppt_amd/csrc/gemm.hip, rowgemm.hip, mlp_fused3.hip, text_mlp.hip, mpn1/mpn3/mpn4.hip)",
                 "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "frac_source": "live HIP-event brackets on the launch stream, dispatch gap subtracted (reads ~8 % above rocprofv3's kernel-only durations)",
