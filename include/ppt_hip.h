@@ -318,7 +318,8 @@ int ppt_layernorm_bwd_sum(const float *dy_parts, int S, const float *xs, const f
  * Replaces the two Linears + QuickGELU of ResidualAttentionBlock.mlp (ULIP_models.py:41-42, 49-51) on the prompt chain:
  *   mode 0 (forward):  parts[s] = QuickGELU( A W1[slice s]^T + b1[slice s] ) W2[:, slice s]^T,  pre (optional) = A W1^T + b1
  *   mode 1 (backward): parts[s] = ( (A W1[slice s]^T) * QuickGELU'(pre[:, slice s]) ) W2[:, slice s]^T
- * for the eight 256-unit slices of the 2048-wide hidden dimension: A [M, 512] (lda elements per row) and pre [M, 2048] in `dtype`
+ * for the eight 256-unit slices of the 2048-wide hidden dimension: A [M, 512] (lda elements per row; fp32 with the LayerNorm prologue
+ * below) and pre [M, 2048] in `dtype`
  * (PPT_BF16 | PPT_F16), parts [8, M, 512] f32 -- the caller's LayerNorm adds the slices up in order (ppt_layernorm_fwd_sum /
  * ppt_layernorm_bwd_sum).  W1 [2048, 512] / W2 [512, 2048] row-major 16-bit (forward: c_fc.weight / c_proj.weight; backward:
  * c_proj.weight^T / c_fc.weight^T) RE-TILED once by ppt_text_mlp_retile.  The hidden activation never exists in memory.
@@ -333,6 +334,10 @@ typedef struct ppt_text_mlp_params {
     int mode;                                /* 0 forward, 1 backward */
     int dtype;
     int wave_prio;                           /* != 0: raised issue priority (0: what ppt_set_wave_priority set) */
+    /* optional LayerNorm prologue (mode 0 only): ln_w != NULL -> A is the FP32 residual stream [M, 512] (lda floats per row) and
+     * LayerNorm(A; ln_w, ln_b, ln_eps) -- ln_2 of the layer, computed in fp32 as ULIP_models.py:21-27 does -- is applied while the rows
+     * are staged; ln_mean / ln_rstd [M] (optional) receive the row statistics for the LayerNorm backward. */
+    const float *ln_w; const float *ln_b; float ln_eps; float *ln_mean; float *ln_rstd;
 } ppt_text_mlp_params;
 int ppt_text_mlp_retile(const void *W1, const void *W2, void *W1_tiled, void *W2_tiled, void *stream);
 int ppt_text_mlp_pair(const ppt_text_mlp_params *p, void *stream);

@@ -39,6 +39,7 @@ class TextMlpParams(ctypes.Structure):
     _fields_ = [
         ("A", c_void_p), ("lda", c_int64), ("W1", c_void_p), ("W2", c_void_p), ("b1", c_void_p), ("pre", c_void_p), ("parts", c_void_p),
         ("M", c_int), ("D", c_int), ("hidden", c_int), ("mode", c_int), ("dtype", c_int), ("wave_prio", c_int),
+        ("ln_w", c_void_p), ("ln_b", c_void_p), ("ln_eps", ctypes.c_float), ("ln_mean", c_void_p), ("ln_rstd", c_void_p),
     ]
 
 

@@ -52,7 +52,20 @@ __device__ __forceinline__ void lds_barrier_t()
     asm volatile("" ::: "memory");
 }
 
-template <typename F, int MODE>
+__device__ __forceinline__ float row16_sum_t(float v)
+{
+    v += __uint_as_float(dpp_mov<0xB1, 0xf>(__float_as_uint(v)));
+    v += __uint_as_float(dpp_mov<0x4E, 0xf>(__float_as_uint(v)));
+    v += __uint_as_float(dpp_mov<0x141, 0xf>(__float_as_uint(v)));
+    v += __uint_as_float(dpp_mov<0x140, 0xf>(__float_as_uint(v)));
+    return v;
+}
+
+// LN (forward only): A is the fp32 residual stream x_mid and ln_2 (ULIP_models.py:21-27, 50: LayerNorm computed in fp32) is applied
+// while the block's rows are staged -- 16 threads per row, two-pass statistics over DPP adds as in rowgemm.hip -- so the LayerNorm
+// launch in front of this kernel goes too; the eight slices' workgroups of a row block recompute it (64 KB of rows each, L2-warm),
+// slice 0 writes the statistics the LayerNorm backward needs.
+template <typename F, int MODE, bool LN>
 __global__ __launch_bounds__(512, 2) void text_mlp_kernel(const ppt_text_mlp_params p)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -83,7 +96,37 @@ __global__ __launch_bounds__(512, 2) void text_mlp_kernel(const ppt_text_mlp_par
     for (int i = 0; i < D1; ++i) next1(g1[i][0], g1[i][1]);
 
     // ---- the block's rows of A -> LDS image (rows past M: zeros)
-    {
+    if constexpr (LN) {
+        static_assert(R == 32 && D == 512, "16 threads per row x 32 rows = the workgroup");
+        const int r = threadIdx.x >> 4, j = threadIdx.x & 15;
+        const float *src = (const float *)p.A + (size_t)(row0 + min(r, nrow - 1)) * p.lda;
+        float4 xf[D / 64];
+#pragma unroll
+        for (int i = 0; i < D / 64; ++i) xf[i] = *reinterpret_cast<const float4 *>(src + 4 * (j + 16 * i));
+        float sm = 0.f;
+#pragma unroll
+        for (int i = 0; i < D / 64; ++i) sm += (xf[i].x + xf[i].y) + (xf[i].z + xf[i].w);
+        const float mean = row16_sum_t(sm) * (1.0f / (float)D);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < D / 64; ++i) {
+            const float d0 = xf[i].x - mean, d1 = xf[i].y - mean, d2 = xf[i].z - mean, d3 = xf[i].w - mean;
+            q = fmaf(d0, d0, q); q = fmaf(d1, d1, q); q = fmaf(d2, d2, q); q = fmaf(d3, d3, q);
+        }
+        const float rstd = 1.0f / sqrtf(row16_sum_t(q) * (1.0f / (float)D) + p.ln_eps);
+        if (p.ln_mean && s == 0 && j == 0 && r < nrow) { p.ln_mean[row0 + r] = mean; p.ln_rstd[row0 + r] = rstd; }
+        unsigned char *dst = ai + r * AP;
+#pragma unroll
+        for (int i = 0; i < D / 64; ++i) {
+            const int c = 4 * (j + 16 * i);
+            const float4 g = *reinterpret_cast<const float4 *>(p.ln_w + c), b = *reinterpret_cast<const float4 *>(p.ln_b + c);
+            uint2 o = make_uint2(0u, 0u);
+            if (r < nrow)
+                o = make_uint2(h16<F>::pack2((xf[i].x - mean) * rstd * g.x + b.x, (xf[i].y - mean) * rstd * g.y + b.y),
+                               h16<F>::pack2((xf[i].z - mean) * rstd * g.z + b.z, (xf[i].w - mean) * rstd * g.w + b.w));
+            *reinterpret_cast<uint2 *>(dst + 2 * c) = o;
+        }
+    } else {
         const F *A = (const F *)p.A;
 #pragma unroll
         for (int it = 0; it < (R * (D / 8) + 511) / 512; ++it) {
@@ -250,24 +293,31 @@ extern "C" int ppt_text_mlp_pair(const ppt_text_mlp_params *pp, void *stream)
     if (p.mode != 0 && p.mode != 1) return PPT_EINVAL;
     if (p.mode == 1 && !p.pre) return PPT_EINVAL;
     if (((uintptr_t)p.A | (uintptr_t)p.W1 | (uintptr_t)p.W2 | (uintptr_t)p.parts | (uintptr_t)p.pre | (uintptr_t)p.b1) & 15) return PPT_EINVAL;
-    if (p.lda % 8) return PPT_EINVAL;
     if (p.wave_prio == 0) p.wave_prio = ppt_get_wave_priority();
+    const bool ln = p.ln_w != nullptr;
+    if (ln && (p.mode != 0 || !p.ln_b || R != 32 || (p.lda % 4) || (((uintptr_t)p.ln_w | (uintptr_t)p.ln_b) & 15))) return PPT_EINVAL;
+    if (!ln && (p.lda % 8)) return PPT_EINVAL;
     static const int attrs_once = [] {
-        (void)hipFuncSetAttribute((const void *)text_mlp_kernel<bf16_t, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute((const void *)text_mlp_kernel<bf16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute((const void *)text_mlp_kernel<f16_t, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute((const void *)text_mlp_kernel<f16_t, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)text_mlp_kernel<bf16_t, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)text_mlp_kernel<bf16_t, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)text_mlp_kernel<f16_t, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)text_mlp_kernel<f16_t, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)text_mlp_kernel<bf16_t, 0, (R == 32)>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)text_mlp_kernel<f16_t, 0, (R == 32)>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         return 0;
     }();
     (void)attrs_once;
     const int grid = NS * ((p.M + R - 1) / R);
     hipStream_t st = ppt_stream(stream);
-    if (p.dtype == PPT_F16) {
-        if (p.mode == 0) hipLaunchKernelGGL((text_mlp_kernel<f16_t, 0>), dim3(grid), dim3(512), LDS_BYTES, st, p);
-        else hipLaunchKernelGGL((text_mlp_kernel<f16_t, 1>), dim3(grid), dim3(512), LDS_BYTES, st, p);
+    if (ln) {
+        if (p.dtype == PPT_F16) hipLaunchKernelGGL((text_mlp_kernel<f16_t, 0, (R == 32)>), dim3(grid), dim3(512), LDS_BYTES, st, p);
+        else hipLaunchKernelGGL((text_mlp_kernel<bf16_t, 0, (R == 32)>), dim3(grid), dim3(512), LDS_BYTES, st, p);
+    } else if (p.dtype == PPT_F16) {
+        if (p.mode == 0) hipLaunchKernelGGL((text_mlp_kernel<f16_t, 0, false>), dim3(grid), dim3(512), LDS_BYTES, st, p);
+        else hipLaunchKernelGGL((text_mlp_kernel<f16_t, 1, false>), dim3(grid), dim3(512), LDS_BYTES, st, p);
     } else {
-        if (p.mode == 0) hipLaunchKernelGGL((text_mlp_kernel<bf16_t, 0>), dim3(grid), dim3(512), LDS_BYTES, st, p);
-        else hipLaunchKernelGGL((text_mlp_kernel<bf16_t, 1>), dim3(grid), dim3(512), LDS_BYTES, st, p);
+        if (p.mode == 0) hipLaunchKernelGGL((text_mlp_kernel<bf16_t, 0, false>), dim3(grid), dim3(512), LDS_BYTES, st, p);
+        else hipLaunchKernelGGL((text_mlp_kernel<bf16_t, 1, false>), dim3(grid), dim3(512), LDS_BYTES, st, p);
     }
     PPT_CHECK_LAUNCH();
     return PPT_OK;

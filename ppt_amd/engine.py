@@ -863,6 +863,7 @@ POINTMLP_FUSED_NORM = os.environ.get("PPT_POINTMLP_FUSED_NORM", "1") != "0"
 # activation never in memory, eight partial products summed by the LayerNorm that follows).  Supported switch:
 # PPT_TEXT_MLP_PAIR=0 restores c_fc + split-K c_proj as two launches.
 TEXT_MLP_PAIR = os.environ.get("PPT_TEXT_MLP_PAIR", "1") != "0"
+TEXT_MLP_PAIR_LN = os.environ.get("PPT_TEXT_MLP_PAIR_LN", "1") != "0"      # ln_2 inside that launch (forward); 0: its own launch in front
 
 
 def _text_mlp_tiles(sd, p, wcm, backward):
@@ -974,9 +975,14 @@ def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=No
         if pair:
             # c_fc + QuickGELU + c_proj in one launch; its eight partial products are this layer's output once the next layer's
             # LayerNorm has added them to x_mid and the bias (the split-K hand-over below, with 8 slices instead of 4)
-            h2, mean2, rstd2 = ops.layernorm_fwd(x_mid, sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], Tm, save_stats=save)
             w1t, w2t = _text_mlp_tiles(sd, p, wcm, False)
-            parts = ops.text_mlp_pair(h2, w1t, w2t, bias=sd[p + "mlp.c_fc.bias"], pre=pre)
+            if TEXT_MLP_PAIR_LN:
+                # ... and ln_2 is applied while the kernel stages its rows: the LayerNorm launch in front of it goes as well
+                parts, mean2, rstd2 = ops.text_mlp_pair(x_mid, w1t, w2t, bias=sd[p + "mlp.c_fc.bias"], pre=pre,
+                                                        ln=(sd[p + "ln_2.weight"], sd[p + "ln_2.bias"]), save_stats=save)
+            else:
+                h2, mean2, rstd2 = ops.layernorm_fwd(x_mid, sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], Tm, save_stats=save)
+                parts = ops.text_mlp_pair(h2, w1t, w2t, bias=sd[p + "mlp.c_fc.bias"], pre=pre)
             if save:
                 saved["layers"].append(dict(x=x, mean1=mean1, rstd1=rstd1, qkv=qkv, a=a, lse=lse, x_mid=x_mid, mean2=mean2,
                                             rstd2=rstd2, pre=pre))

@@ -395,25 +395,38 @@ def text_mlp_retile(w1, w2):
     return w1t, w2t
 
 
-def text_mlp_pair(a, w1t, w2t, *, bias=None, pre=None, backward=False):
+def text_mlp_pair(a, w1t, w2t, *, bias=None, pre=None, backward=False, ln=None, ln_eps=1e-5, save_stats=False):
     """The MLP half of a CLIP text layer in one launch (csrc/text_mlp.hip) -> the eight slices' partial products [8, M, 512] f32.
     forward: QuickGELU(a w1^T + bias) w2^T, `pre` (optional, [M, 2048] 16-bit) receives the pre-activation; backward=True:
     ((a w1^T) * QuickGELU'(pre)) w2^T with w1 / w2 the transposed weights' tiled copies.  The caller's LayerNorm sums the slices
-    (layernorm_fwd_sum / layernorm_bwd_sum)."""
-    assert a.dtype in HALF and a.dim() == 2 and a.shape[1] == 512 and a.stride(1) == 1 and w1t.dtype == a.dtype and w2t.dtype == a.dtype
+    (layernorm_fwd_sum / layernorm_bwd_sum).
+    ln = (weight, bias) (forward only): `a` is the FP32 residual stream and the LayerNorm in front of the branch (ln_2) is applied while
+    the rows are staged; save_stats -> also returns (mean, rstd) [M] for the LayerNorm backward: (parts, mean, rstd)."""
     M = a.shape[0]
+    assert a.dim() == 2 and a.shape[1] == 512 and a.stride(1) == 1 and w1t.dtype in HALF and w2t.dtype == w1t.dtype
+    if ln is None:
+        assert a.dtype == w1t.dtype
+    else:
+        assert a.dtype == torch.float32 and not backward
     parts = torch.empty((8, M, 512), dtype=torch.float32, device=a.device)
     p = _lib.TextMlpParams()
     p.A, p.lda, p.W1, p.W2, p.b1, p.pre, p.parts = _p(a), a.stride(0), _p(w1t), _p(w2t), _p(bias), _p(pre), _p(parts)
-    p.M, p.D, p.hidden, p.mode, p.dtype = M, 512, 2048, int(bool(backward)), dtype_code(a)
+    p.M, p.D, p.hidden, p.mode, p.dtype = M, 512, 2048, int(bool(backward)), dtype_code(w1t)
+    mean = rstd = None
+    if ln is not None:
+        _chk(ln[0], torch.float32, "ln weight"); _chk(ln[1], torch.float32, "ln bias")
+        if save_stats:
+            mean = torch.empty((M,), dtype=torch.float32, device=a.device)
+            rstd = torch.empty((M,), dtype=torch.float32, device=a.device)
+        p.ln_w, p.ln_b, p.ln_eps, p.ln_mean, p.ln_rstd = _p(ln[0]), _p(ln[1]), float(ln_eps), _p(mean), _p(rstd)
     if pre is not None:
-        assert pre.dtype == a.dtype and tuple(pre.shape) == (M, 2048) and pre.is_contiguous()
+        assert pre.dtype == w1t.dtype and tuple(pre.shape) == (M, 2048) and pre.is_contiguous()
     if profiler is not None:
         profiler.begin("gemm_bf16", 4.0 * M * 512 * 2048, "ppt_text_mlp_pair (" + ("backward" if backward else "forward") + ")")
     _lib.check(_lib.lib().ppt_text_mlp_pair(ctypes.byref(p), _stream()), "ppt_text_mlp_pair")
     if profiler is not None:
         profiler.end()
-    return parts
+    return (parts, mean, rstd) if ln is not None else parts
 
 
 def vit_proj_retile(wp):

@@ -1517,6 +1517,15 @@ def test_text_mlp_pair_matches_the_two_linears(ops, M, dtype):
     ref = ops.gemm(f, w2d, out_dtype=torch.float32)
     assert (got.cuda() - ref).abs().max().item() < tol / 2
     assert torch.equal(ops.text_mlp_pair(ad, w1t, w2t, bias=b1.cuda()), parts)          # (no pre output: same partial products, bit for bit)
+    # the LayerNorm prologue (ln_2 applied while the rows are staged): the partial products of LayerNorm-then-launch, bit for bit, and
+    # the statistics of the LayerNorm kernel
+    xres = (torch.randn(M, D, generator=g) * 2 + torch.randn(M, 1, generator=g)).cuda()
+    gam, bet = (1 + 0.1 * torch.randn(D, generator=g)).cuda(), (0.1 * torch.randn(D, generator=g)).cuda()
+    hh, mean, rstd = ops.layernorm_fwd(xres, gam, bet, dtype, save_stats=True)
+    two = ops.text_mlp_pair(hh, w1t, w2t, bias=b1.cuda())
+    one, m1, r1 = ops.text_mlp_pair(xres, w1t, w2t, bias=b1.cuda(), ln=(gam, bet), save_stats=True)
+    assert (one.sum(0) - two.sum(0)).abs().max().item() < tol / 2
+    assert (m1 - mean).abs().max().item() < 1e-5 and ((r1 - rstd) / rstd).abs().max().item() < 1e-5
     # ---- backward: d h2 = ((d_out W_proj) * QuickGELU'(pre)) W_fc, i.e. W1 = c_proj^T [2048, 512], W2 = c_fc^T [512, 2048]
     dout = torch.randn(M, D, generator=g)
     pre_r = rd(pre)
