@@ -525,8 +525,12 @@ def main():
     feed = host_feed((pc, label), max_burn + a.warmup + a.steps) if FEED == "prefetch" else None
     import gc
     gc_mode = os.environ.get("PPT_BENCH_GC", "freeze")
+    # (under a process group every step carries a collective, so every rank must run the SAME number of steps: the burn-in is then a
+    # fixed count -- what one second amounts to at this configuration's single-GPU rate would differ from rank to rank)
+    fixed_burn = BURN_IN_STEPS + int(os.environ.get("PPT_BENCH_BURN_IN_DIST", "320")) if (world > 1 or force_dist) else None
     burned, tb = 0, time.perf_counter()
-    while burned < BURN_IN_STEPS or (time.perf_counter() - tb < burn_s and burned < max_burn):
+    while (burned < fixed_burn) if fixed_burn is not None else \
+            (burned < BURN_IN_STEPS or (time.perf_counter() - tb < burn_s and burned < max_burn)):
         trainer.step(*(next(feed) if feed else (pc, label)))
         burned += 1
         if burned % 20 == 0:
