@@ -44,7 +44,7 @@ const char *ppt_strerror(int code);
 /* ABI version of this header (currently 7); bumped on any signature change or added entry point.
  * 7: ppt_gemm_params.split_overflow (new trailing field: split16 saturates finite values beyond IEEE half's range and counts
  *    the workgroups that did), ppt_vit_mlp3_bf16 / ppt_vit_mlp3_retile (new: csrc/mlp_fused3.hip), ppt_text_mlp_pair /
- *    ppt_text_mlp_retile (new: csrc/text_mlp.hip).
+ *    ppt_text_mlp_retile (new: csrc/text_mlp.hip), ppt_lnlin / ppt_lnlin_retile (new: csrc/lnlin.hip).
  * 6: ppt_gemm_params.split16 / split_a_pow2 / split_b_pow2 (new trailing fields: fp32 operands as hi + lo half pairs),
  *    ppt_attention_fwd_split16 / ppt_attention_bwd_split16 (new), ppt_pointmlp_cloud_rstd / ppt_pointmlp_pq (new).
  * 5: ppt_labels_check (new), ppt_gemm256 (new: the 256-row macro-tile GEMM core), ppt_set_gemm256 / ppt_get_gemm256 (new),
@@ -313,6 +313,22 @@ int ppt_layernorm_fwd_sum(const float *x, const float *bias, const float *parts,
                           void *y, int y_dtype, float *mean, float *rstd, int M, int D, float eps, void *stream);
 int ppt_layernorm_bwd_sum(const float *dy_parts, int S, const float *xs, const float *w, const float *mean, const float *rstd,
                           float *dx, int accumulate_dx, void *dx_copy, int dx_copy_dtype, int M, int D, void *stream);
+
+/* ---- LayerNorm + a K = 384 linear with the rows stationary and the weight streamed (ABI 7; csrc/lnlin.hip) -------------------
+ * C[M, N] (dtype) = LayerNorm(x[M, 384]; ln_w, ln_b, ln_eps) W[N, 384]^T (+ bias): norm1 + qkv of a frozen PointBERT block
+ * (point_encoder.py:46-55, 76).  x f32 (the residual stream, "+ pos" already in it), N a multiple of 384, W the 16-bit weight RE-TILED
+ * once by ppt_lnlin_retile ([slice N/384][wave 8][k-step 12][column block 3][lane 64][8]).  A workgroup = 64 rows x one 384-column
+ * slice, two per CU.  `slices` is set by the library. */
+typedef struct ppt_lnlin_params {
+    const float *x; const void *W; void *C;
+    const float *ln_w; const float *ln_b; float ln_eps;
+    const float *bias;                       /* [N] or NULL */
+    int M, N, K;
+    int dtype;                               /* PPT_BF16 | PPT_F16: W, C and the in-kernel LayerNorm output */
+    int slices;
+} ppt_lnlin_params;
+int ppt_lnlin_retile(const void *W, void *W_tiled, int N, void *stream);
+int ppt_lnlin(const ppt_lnlin_params *p, void *stream);
 
 /* ---- the MLP half of a CLIP text-tower layer as one launch per direction (ABI 7; csrc/text_mlp.hip) -------------------------
  * Replaces the two Linears + QuickGELU of ResidualAttentionBlock.mlp (ULIP_models.py:41-42, 49-51) on the prompt chain:

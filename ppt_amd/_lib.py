@@ -34,6 +34,14 @@ class GemmParams(ctypes.Structure):
     ]
 
 
+class LnLinParams(ctypes.Structure):
+    """struct ppt_lnlin_params (include/ppt_hip.h) -- field order must match the header."""
+    _fields_ = [
+        ("x", c_void_p), ("W", c_void_p), ("C", c_void_p), ("ln_w", c_void_p), ("ln_b", c_void_p), ("ln_eps", ctypes.c_float),
+        ("bias", c_void_p), ("M", c_int), ("N", c_int), ("K", c_int), ("dtype", c_int), ("slices", c_int),
+    ]
+
+
 class TextMlpParams(ctypes.Structure):
     """struct ppt_text_mlp_params (include/ppt_hip.h) -- field order must match the header."""
     _fields_ = [
@@ -111,6 +119,8 @@ _SIGNATURES = {
     "ppt_vit_mlp_retile": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ppt_vit_proj_retile": (c_int, [c_void_p, c_void_p, c_void_p]),
     "ppt_vit_mlp_bf16": (c_int, [ctypes.POINTER(VitMlpParams), c_void_p]),
+    "ppt_lnlin_retile": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "ppt_lnlin": (c_int, [ctypes.POINTER(LnLinParams), c_void_p]),
     "ppt_text_mlp_retile": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ppt_text_mlp_pair": (c_int, [ctypes.POINTER(TextMlpParams), c_void_p]),
     "ppt_vit_mlp3_retile": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -264,14 +264,19 @@ def vit_block_forward(sd, p, wc, x, pos, B, Tn, heads, dp1, dp2, save=None, pos_
         fused_ok = FUSED_MLP and sd[p + "mlp.fc1.weight"].shape[0] == 1536
         mlp = path["mlp"] if (fused_ok or path["mlp"] != "fused") else "rowgemm"
         proj = path["proj"] if not (path["proj"] == "fused" and not (mlp == "fused" and FUSED_PROJ)) else "rowgemm"
-        if pos_in_x and path["qkv"] == "rowgemm":
+        if pos_in_x and path["qkv"] == "lnlin" and sd[p + "attn.qkv.weight"].shape[0] % 384 == 0:
+            # csrc/lnlin.hip (round 6): rows stationary, weight streamed in fragment order, two workgroups per CU
+            wq = sd[p + "attn.qkv.weight"]
+            wqt = wc.derived(("lnlin_tiled", p), (wq,), lambda: ops.lnlin_retile(wc.get(wq)))
+            qkv = ops.lnlin(x, wqt, (sd[p + "norm1.weight"], sd[p + "norm1.bias"]))
+        elif pos_in_x and path["qkv"] in ("rowgemm", "lnlin"):
             qkv = ops.rowgemm(x, wc.get(sd[p + "attn.qkv.weight"]), ln=(sd[p + "norm1.weight"], sd[p + "norm1.bias"]))
         else:           # (the first block: x + pos is formed -- and written back -- by the LayerNorm kernel)
             if pos_in_x:
                 h, _, _ = ops.layernorm_fwd(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], T)
             else:
                 h, _, _ = ops.layernorm_fwd(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], T, add=pos, write_xs=x)
-            if path["qkv"] == "rowgemm":
+            if path["qkv"] in ("rowgemm", "lnlin"):
                 qkv = ops.rowgemm(h, wc.get(sd[p + "attn.qkv.weight"]))
             else:
                 qkv = ops.gemm(h, wc.get(sd[p + "attn.qkv.weight"]), out_dtype=T)

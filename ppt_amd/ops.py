@@ -385,6 +385,34 @@ def vit_mlp_retile(w1, w2, variant=None):
     return w1t, w2t
 
 
+def lnlin_retile(w):
+    """w [N, 384] 16-bit (N a multiple of 384) -> the fragment-ordered copy ppt_lnlin reads."""
+    assert w.dtype in HALF and w.dim() == 2 and w.shape[1] == 384 and w.shape[0] % 384 == 0
+    _chk(w, w.dtype, "w")
+    wt = torch.empty_like(w)
+    _lib.check(_lib.lib().ppt_lnlin_retile(_p(w), _p(wt), w.shape[0], _stream()), "ppt_lnlin_retile")
+    return wt
+
+
+def lnlin(x, wt, ln, *, bias=None, ln_eps=1e-5, out=None):
+    """LayerNorm(x [M, 384] f32; ln = (weight, bias)) @ W^T (+ bias) -> [M, N] in the weight's 16-bit dtype (csrc/lnlin.hip: rows
+    stationary, weight streamed; wt = lnlin_retile(W))."""
+    _chk(x, torch.float32, "x")
+    M, K = x.shape
+    N = wt.shape[0]
+    assert K == 384 and wt.dtype in HALF
+    out = torch.empty((M, N), dtype=wt.dtype, device=x.device) if out is None else out
+    p = _lib.LnLinParams()
+    p.x, p.W, p.C, p.ln_w, p.ln_b, p.ln_eps, p.bias = _p(x), _p(wt), _p(out), _p(ln[0]), _p(ln[1]), float(ln_eps), _p(bias)
+    p.M, p.N, p.K, p.dtype = M, N, K, dtype_code(wt)
+    if profiler is not None:
+        profiler.begin("gemm_bf16", 2.0 * M * N * K, "ppt_lnlin (LayerNorm prologue)")
+    _lib.check(_lib.lib().ppt_lnlin(ctypes.byref(p), _stream()), "ppt_lnlin")
+    if profiler is not None:
+        profiler.end()
+    return out
+
+
 def text_mlp_retile(w1, w2):
     """(w1 [2048, 512], w2 [512, 2048]) 16-bit row-major -> the fragment-ordered copies ppt_text_mlp_pair reads.  Forward:
     (c_fc.weight, c_proj.weight); backward: (c_proj.weight^T, c_fc.weight^T) -- the same shapes."""

@@ -1485,6 +1485,32 @@ def test_vit_mlp_with_the_proj_prologue_matches_proj_then_mlp(ops, M, rows, dtyp
     assert torch.equal(again, out)
 
 
+# ------------------------------------------------------------------ LayerNorm + K = 384 linear, rows stationary (csrc/lnlin.hip)
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,bias", [(16416, 1152, False), (513, 1152, False), (1000, 384, True), (77, 768, True), (32832, 1152, False)])
+def test_lnlin_matches_layernorm_then_linear(ops, M, N, bias, dtype):
+    """ppt_lnlin (norm1 + qkv of a frozen block: 64-row chunks x 384-column slices, the weight streamed in fragment order) against fp32
+    torch math on the operands the MFMAs see and against csrc/rowgemm.hip's weight-stationary form of the same product; ragged last
+    chunk; bit-reproducible."""
+    g = torch.Generator().manual_seed(M + N)
+    D = 384
+    x = torch.randn(M, D, generator=g) * 2 + torch.randn(M, 1, generator=g)
+    gam, bet = 1 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    w = torch.randn(N, D, generator=g) * D ** -0.5
+    b = 0.1 * torch.randn(N, generator=g) if bias else None
+    rd = lambda t: t.to(dtype).float()
+    want = rd(torch.nn.functional.layer_norm(x, (D,), gam, bet, 1e-5)) @ rd(w).t() + (b if bias else 0)
+    xd, wd = x.cuda(), w.cuda().to(dtype)
+    wt = ops.lnlin_retile(wd)
+    got = ops.lnlin(xd, wt, (gam.cuda(), bet.cuda()), bias=b.cuda() if bias else None)
+    assert got.dtype == dtype and got.shape == (M, N)
+    tol = (4e-3 if dtype == torch.float16 else 3e-2) * max(1.0, want.abs().max().item())
+    assert (got.float().cpu() - want).abs().max().item() < tol
+    ref = ops.rowgemm(xd, wd, ln=(gam.cuda(), bet.cuda()), bias=b.cuda() if bias else None)
+    assert (got.float() - ref.float()).abs().max().item() < tol / 2
+    assert torch.equal(ops.lnlin(xd, wt, (gam.cuda(), bet.cuda()), bias=b.cuda() if bias else None), got)
+
+
 # ------------------------------------------------------------------ the text tower's MLP half in one launch (csrc/text_mlp.hip)
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M", [817, 64, 1480, 5])
