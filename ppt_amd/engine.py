@@ -130,7 +130,11 @@ FUSED_MLP = os.environ.get("PPT_FUSED_MLP", "1") != "0"             # LayerNorm 
 FUSED_PROJ = os.environ.get("PPT_FUSED_PROJ", "1") != "0"           # ... with attn.proj + DropPath + residual in front of it (rowgemm path)
 # which kernel each linear of a FROZEN ViT block runs on from ROWGEMM_MIN_ROWS token rows on (vit_block_forward):
 # PPT_BLOCK_QKV = rowgemm | v2, PPT_BLOCK_PROJ = fused | rowgemm | v2, PPT_BLOCK_MLP = fused | rowgemm | v2
-BLOCK_PATH = {"qkv": os.environ.get("PPT_BLOCK_QKV", "rowgemm"), "proj": os.environ.get("PPT_BLOCK_PROJ", "fused"),
+# (round 6: qkv "auto" = csrc/lnlin.hip -- rows stationary, weight streamed, two workgroups per CU -- up to LNLIN_MAX_ROWS token rows,
+# csrc/rowgemm.hip above: alone 33.6 -> 28.0 us at 16 416 rows and a tie (51 us) at 32 832; in the step C2 2.688 -> 2.639 ms with the
+# prompt chain critical (its workgroups do not take whole CUs), C3 5.631 -> 5.678 ms)
+LNLIN_MAX_ROWS = int(os.environ.get("PPT_LNLIN_MAX_ROWS", "24576"))
+BLOCK_PATH = {"qkv": os.environ.get("PPT_BLOCK_QKV", "auto"), "proj": os.environ.get("PPT_BLOCK_PROJ", "fused"),
               "mlp": os.environ.get("PPT_BLOCK_MLP", "fused")}
 _RG = os.environ.get("PPT_ROWGEMM", "")
 ROWGEMM_MIN_ROWS = 1 << 30 if _RG == "0" else (0 if _RG == "1" else 16000)
@@ -261,6 +265,8 @@ def vit_block_forward(sd, p, wc, x, pos, B, Tn, heads, dp1, dp2, save=None, pos_
         #   "fused" (proj / mlp): attn.proj in front of / the whole MLP branch inside csrc/mlp_fused.hip.
         # The residual stream is updated in place; the sums are formed in the same order on every path.
         path = BLOCK_PATH
+        if path["qkv"] == "auto":
+            path = dict(path, qkv="lnlin" if x.shape[0] <= LNLIN_MAX_ROWS else "rowgemm")
         fused_ok = FUSED_MLP and sd[p + "mlp.fc1.weight"].shape[0] == 1536
         mlp = path["mlp"] if (fused_ok or path["mlp"] != "fused") else "rowgemm"
         proj = path["proj"] if not (path["proj"] == "fused" and not (mlp == "fused" and FUSED_PROJ)) else "rowgemm"
