@@ -925,8 +925,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma(const bf16_t *__restr
 // absorb attn_prefix_reduce, is compiled out: the prefix workgroup's walk over all 817 rows is 26 dependent tile iterations
 // of ~1.1 us each -- the next tile's loads are only one iteration ahead -- and made the launch ~29 us instead of ~3 + a 4.5 us
 // reduction: prompt chain alone 1.97 -> 2.33 ms.)
+#ifndef PPT_SHORT_OCC
+#define PPT_SHORT_OCC 2
+#endif
 template <bool CAUSAL, typename F>
-__global__ __launch_bounds__(256, 2) void attn_bwd_short_mfma(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ out,
+__global__ __launch_bounds__(256, PPT_SHORT_OCC) void attn_bwd_short_mfma(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ out,
                                                            const bf16_t *__restrict__ dout, const float *__restrict__ lse,
                                                            bf16_t *__restrict__ dqkv, int Tfull, int H, float scale, int P, int C,
                                                            float *__restrict__ part, int prio)
@@ -935,11 +938,227 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_short_mfma(const bf16_t *__re
     __shared__ __align__(16) unsigned char smem[DQ_SMEM > DKV_SMEM ? DQ_SMEM : DKV_SMEM];
     // gridDim.x == 2: one workgroup per role; == 1: ONE workgroup runs both roles back to back (half the workgroups: with two
     // 208-VGPR workgroups per CU, 656 role workgroups of the 41 x 8 (sequence, head) pairs were two rounds on 512 slots)
+#ifdef PPT_SHORT_ROLE   // (diagnostic build: one role only)
+    if (PPT_SHORT_ROLE == 0) { attn_bwd_dkv_body<F, CAUSAL, true, false>(qkv, out, dout, lse, nullptr, dqkv, Tfull, H, scale, P, C, part, smem, 0, blockIdx.y); return; }
+    if (PPT_SHORT_ROLE == 1) { attn_bwd_dq_body<F, CAUSAL, true>(qkv, out, dout, lse, nullptr, dqkv, Tfull, H, scale, P, C, smem, 0, blockIdx.y); return; }
+    if (PPT_SHORT_ROLE == 2) return;
+#endif
     if (gridDim.x == 1 || blockIdx.x == 0)
         attn_bwd_dkv_body<F, CAUSAL, true, false>(qkv, out, dout, lse, nullptr, dqkv, Tfull, H, scale, P, C, part, smem, 0, blockIdx.y);
     if (gridDim.x == 1) __syncthreads();
     if (gridDim.x == 1 || blockIdx.x == 1)
         attn_bwd_dq_body<F, CAUSAL, true>(qkv, out, dout, lse, nullptr, dqkv, Tfull, H, scale, P, C, smem, 0, blockIdx.y);
+}
+
+
+// The whole backward of a TINY sequence (T <= 64: the CLIP text tower under prompt learning, 37 positions of which 17 are the shared
+// prefix) as ONE pass: attn_bwd_short_mfma above runs the two roles back to back, each with its own trip to global memory (dK / dV:
+// K, V into registers, Q / dO tiles staged; dQ: Q, dO into registers, K / V tiles staged) and with two of its four waves idle
+// (37 keys = two 32-key waves) -- 9.4 + 8.0 us alone, 13 us together, for 0.3 MFLOP per workgroup.  Here every matrix of the
+// (sequence, head) goes to LDS ONCE (row image, and the transposed-read image where a product wants it), delta = rowsum(dO * O) is
+// formed while the rows are staged, and then waves 0-1 run the dK / dV role (32 keys each) WHILE waves 2-3 run the dQ role (32
+// queries each): one global round trip, four busy waves.  Same products in the same order as the two bodies above.
+constexpr int TINY_SMEM = 7 * TILE + 512;
+template <bool CAUSAL, typename F>
+__global__ __launch_bounds__(256, 2) void attn_bwd_tiny_mfma(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ out,
+                                                          const bf16_t *__restrict__ dout, const float *__restrict__ lse,
+                                                          bf16_t *__restrict__ dqkv, int Tfull, int H, float scale, int P, int C,
+                                                          float *__restrict__ part, int prio)
+{
+    PPT_PRIO(prio);
+    __shared__ __align__(16) unsigned char smem[TINY_SMEM];
+    unsigned char *Qr = smem, *Qt = smem + TILE, *Gr = smem + 2 * TILE, *Gt = smem + 3 * TILE, *Kr = smem + 4 * TILE, *Kt = smem + 5 * TILE,
+                  *Vr = smem + 6 * TILE;
+    float *L2 = reinterpret_cast<float *>(smem + 7 * TILE), *DL = L2 + 64;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.y, b = bh / H, head = bh % H;
+    const int64_t rs = 3 * (int64_t)H * HD, os = (int64_t)H * HD;
+    const int T = am_len(Tfull, P, C, b), q_lo = am_qlo(P, C, b);
+    const float c = scale * 1.4426950408889634f;
+
+    // ---- stage: thread = one 16-byte chunk of two rows (rows t >> 3 and 32 + (t >> 3)) of Q, K, V, dO (and O for delta)
+    {
+        uint4 q[2], k[2], v[2], g[2];
+        float dl[2], l2[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 32 * i + (threadIdx.x >> 3), ch = threadIdx.x & 7;
+            q[i] = k[i] = v[i] = g[i] = make_uint4(0, 0, 0, 0);
+            uint4 o = make_uint4(0, 0, 0, 0);
+            l2[i] = INFINITY;
+            const bool own = row < T && row >= q_lo;
+            if (row < T) {
+                const int64_t pr = am_row(Tfull, P, b, row);
+                const bf16_t *qp = qkv + pr * rs + head * HD + ch * 8;
+                q[i] = *reinterpret_cast<const uint4 *>(qp);
+                k[i] = *reinterpret_cast<const uint4 *>(qp + H * HD);
+                v[i] = *reinterpret_cast<const uint4 *>(qp + 2 * H * HD);
+                g[i] = *reinterpret_cast<const uint4 *>(dout + pr * os + head * HD + ch * 8);
+                o = *reinterpret_cast<const uint4 *>(out + pr * os + head * HD + ch * 8);
+                if (own && ch == 0) l2[i] = lse[am_stat(Tfull, P, H, b, head, row)] * 1.4426950408889634f;
+            }
+            float d = dot8_bf16<F>(g[i], o);
+            d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4);
+            dl[i] = own ? d : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 32 * i + (threadIdx.x >> 3), ch = threadIdx.x & 7;
+            *reinterpret_cast<uint4 *>(Qr + k_off(row, ch)) = q[i];
+            *reinterpret_cast<uint4 *>(Qt + v_off(row, ch * 16)) = q[i];
+            *reinterpret_cast<uint4 *>(Gr + k_off(row, ch)) = g[i];
+            *reinterpret_cast<uint4 *>(Gt + v_off(row, ch * 16)) = g[i];
+            *reinterpret_cast<uint4 *>(Kr + k_off(row, ch)) = k[i];
+            *reinterpret_cast<uint4 *>(Kt + v_off(row, ch * 16)) = k[i];
+            *reinterpret_cast<uint4 *>(Vr + k_off(row, ch)) = v[i];
+            if (ch == 0) { L2[row] = l2[i]; DL[row] = dl[i]; }
+        }
+    }
+    __syncthreads();
+    const int g4 = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+    const int tr_row = 4 * (g4 >> 1) + tq;
+    const int tr_dbyte = (16 * (g4 & 1) + 4 * tp) * 2;
+
+    if (w < 2) {
+        // ---- dK / dV of keys 32 w .. 32 w + 31 (attn_bwd_dkv_body with K, V, Q, dO out of LDS)
+        const int k0 = 32 * w, key = k0 + r;
+        if (k0 >= T) return;
+        uint4 kf[4], vf[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            kf[kk] = *reinterpret_cast<const uint4 *>(Kr + k_off(key, 2 * kk + h));
+            vf[kk] = *reinterpret_cast<const uint4 *>(Vr + k_off(key, 2 * kk + h));
+        }
+        f32x16_t dvt[2], dkt[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { dvt[i][e] = 0.f; dkt[i][e] = 0.f; }
+        const int nqt = (T + QT - 1) / QT;
+        for (int qt = q_lo / QT; qt < nqt; ++qt) {
+            if (CAUSAL && qt * QT + QT - 1 < k0) continue;
+            f32x16_t sa, dp;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { sa[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const uint4 qa = *reinterpret_cast<const uint4 *>(Qr + k_off(QT * qt + r, 2 * kk + h));
+                const uint4 ga = *reinterpret_cast<const uint4 *>(Gr + k_off(QT * qt + r, 2 * kk + h));
+                sa = h16<F>::mfma32(qa, kf[kk], sa);
+                dp = h16<F>::mfma32(ga, vf[kk], dp);
+            }
+            const bool diag = CAUSAL && qt * QT < k0 + 32;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const float4 l4 = *reinterpret_cast<const float4 *>(L2 + QT * qt + 8 * gq + 4 * h);
+                const float4 d4 = *reinterpret_cast<const float4 *>(DL + QT * qt + 8 * gq + 4 * h);
+                const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = 4 * gq + j;
+                    float pv = __builtin_amdgcn_exp2f(fmaf(sa[e], c, -lv[j]));
+                    if (diag && key > qt * QT + 8 * gq + 4 * h + j) pv = 0.f;
+                    sa[e] = pv;
+                    dp[e] = pv * (dp[e] - dv[j]) * scale;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const uint4 pf = pack8<F>(sa, s), df = pack8<F>(dp, s);
+#pragma unroll
+                for (int dtile = 0; dtile < 2; ++dtile) {
+                    const uint4 gt = tr_frag(Gt, QT * qt + 16 * s + tr_row, tr_dbyte + 64 * dtile);   // dO^T
+                    dvt[dtile] = h16<F>::mfma32(gt, pf, dvt[dtile]);
+                    const uint4 qt_ = tr_frag(Qt, QT * qt + 16 * s + tr_row, tr_dbyte + 64 * dtile);  // Q^T
+                    dkt[dtile] = h16<F>::mfma32(qt_, df, dkt[dtile]);
+                }
+            }
+        }
+        if (key < T && P > 0 && key < P) {
+            // a SHARED key: the fp32 partial slot of this virtual sequence (folded in a fixed order by attn_prefix_reduce)
+            float *pk = part + (((int64_t)b * P + key) * 2) * os + head * HD, *pv = pk + os;
+#pragma unroll
+            for (int dtile = 0; dtile < 2; ++dtile)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int d = 32 * dtile + 8 * gq + 4 * h;
+                    *reinterpret_cast<float4 *>(pk + d) = make_float4(dkt[dtile][4 * gq], dkt[dtile][4 * gq + 1], dkt[dtile][4 * gq + 2], dkt[dtile][4 * gq + 3]);
+                    *reinterpret_cast<float4 *>(pv + d) = make_float4(dvt[dtile][4 * gq], dvt[dtile][4 * gq + 1], dvt[dtile][4 * gq + 2], dvt[dtile][4 * gq + 3]);
+                }
+        } else if (key < T) {
+            bf16_t *ok = dqkv + am_row(Tfull, P, b, key) * rs + head * HD + H * HD;
+            bf16_t *ov = ok + H * HD;
+#pragma unroll
+            for (int dtile = 0; dtile < 2; ++dtile)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int d = 32 * dtile + 8 * gq + 4 * h;
+                    *reinterpret_cast<uint2 *>(ok + d) = make_uint2(h16<F>::pack2(dkt[dtile][4 * gq], dkt[dtile][4 * gq + 1]),
+                                                                     h16<F>::pack2(dkt[dtile][4 * gq + 2], dkt[dtile][4 * gq + 3]));
+                    *reinterpret_cast<uint2 *>(ov + d) = make_uint2(h16<F>::pack2(dvt[dtile][4 * gq], dvt[dtile][4 * gq + 1]),
+                                                                     h16<F>::pack2(dvt[dtile][4 * gq + 2], dvt[dtile][4 * gq + 3]));
+                }
+        }
+    } else {
+        // ---- dQ of queries 32 (w - 2) .. + 31 (attn_bwd_dq_body with Q, dO, K, V out of LDS; one 64-key tile)
+        const int q0 = 32 * (w - 2), qrow = q0 + r;
+        if (q0 >= T || q0 + 31 < q_lo) return;
+        uint4 qf[4], gf[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            qf[kk] = *reinterpret_cast<const uint4 *>(Qr + k_off(qrow, 2 * kk + h));
+            gf[kk] = *reinterpret_cast<const uint4 *>(Gr + k_off(qrow, 2 * kk + h));
+        }
+        const bool own = qrow < T && qrow >= q_lo;
+        const float l2 = L2[qrow], dl = DL[qrow];
+        f32x16_t dqt[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dqt[i][e] = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            if (32 * sub >= T || (CAUSAL && 32 * sub > q0 + 31)) continue;      // (no unmasked key in this half: it would add zeros)
+            f32x16_t sa, dp;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { sa[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const uint4 ka = *reinterpret_cast<const uint4 *>(Kr + k_off(32 * sub + r, 2 * kk + h));
+                const uint4 va = *reinterpret_cast<const uint4 *>(Vr + k_off(32 * sub + r, 2 * kk + h));
+                sa = h16<F>::mfma32(ka, qf[kk], sa);     // S^T  [key][q]
+                dp = h16<F>::mfma32(va, gf[kk], dp);     // dP^T [key][q]
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float pv = __builtin_amdgcn_exp2f(fmaf(sa[e], c, -l2));
+                const int kx = 32 * sub + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (kx >= T || (CAUSAL && kx > qrow)) pv = 0.f;
+                dp[e] = pv * (dp[e] - dl) * scale;
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const uint4 df = pack8<F>(dp, s);
+#pragma unroll
+                for (int dtile = 0; dtile < 2; ++dtile) {
+                    const uint4 kt_ = tr_frag(Kt, 32 * sub + 16 * s + tr_row, tr_dbyte + 64 * dtile);   // K^T
+                    dqt[dtile] = h16<F>::mfma32(kt_, df, dqt[dtile]);
+                }
+            }
+        }
+        if (own) {
+            bf16_t *oq = dqkv + am_row(Tfull, P, b, qrow) * rs + head * HD;
+#pragma unroll
+            for (int dtile = 0; dtile < 2; ++dtile)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+                    *reinterpret_cast<uint2 *>(oq + 32 * dtile + 8 * gq + 4 * h) =
+                        make_uint2(h16<F>::pack2(dqt[dtile][4 * gq], dqt[dtile][4 * gq + 1]),
+                                   h16<F>::pack2(dqt[dtile][4 * gq + 2], dqt[dtile][4 * gq + 3]));
+        }
+    }
 }
 
 }  // namespace
@@ -993,7 +1212,17 @@ extern "C" int ppt_attention_bwd_short_mfma_bf16(const void *qkv, const void *ou
     if (T > 128) return PPT_EUNSUPPORTED;
     if (((uintptr_t)qkv & 15) || ((uintptr_t)out & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dqkv & 7) || ((uintptr_t)part & 15)) return PPT_EUNSUPPORTED;
     static const int both = [] { const char *e = getenv("PPT_ATTN_SHORT_BOTH"); return e ? atoi(e) : 1; }();
+    static const int tiny = [] { const char *e = getenv("PPT_ATTN_TINY"); return e ? atoi(e) : 1; }();
     const int pairs = (Bt + (P > 0)) * H;
+    if (tiny && T <= 64 && !((uintptr_t)dout & 15)) {
+        const int prio = ppt_get_wave_priority();
+#define PPT_LAUNCH_TINY(CA, TT) hipLaunchKernelGGL((attn_bwd_tiny_mfma<CA, TT>), dim3(1, pairs), dim3(256), 0, s, (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, T, H, scale, P, Bt, part, prio)
+        if (fmt == PPT_F16) { if (causal) PPT_LAUNCH_TINY(true, f16_t); else PPT_LAUNCH_TINY(false, f16_t); }
+        else { if (causal) PPT_LAUNCH_TINY(true, bf16_t); else PPT_LAUNCH_TINY(false, bf16_t); }
+#undef PPT_LAUNCH_TINY
+        PPT_CHECK_LAUNCH();
+        return PPT_OK;
+    }
     dim3 grid(both && 2 * pairs > 512 ? 1 : 2, pairs);    // (two roles per workgroup once the role workgroups would not fit in one round)
     const int prio = ppt_get_wave_priority();
 #define PPT_LAUNCH_SHORT(CA, TT) hipLaunchKernelGGL((attn_bwd_short_mfma<CA, TT>), grid, dim3(256), 0, s, (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, T, H, scale, P, Bt, part, prio)

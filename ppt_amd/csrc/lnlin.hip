@@ -45,6 +45,16 @@ __device__ __forceinline__ void lds_barrier_l()
     asm volatile("" ::: "memory");
 }
 
+// Diagnostic build only (tools/lnlin_stamp.py compiles this file with -DPPT_LNLIN_STAMP into its own library): lane 0 of every wave stores
+// s_memtime at its phase boundaries into the buffer passed as `bias`: [workgroup][wave][8].
+#ifdef PPT_LNLIN_STAMP
+#define LNLIN_STAMP(slot) do { if (lane == 0) reinterpret_cast<unsigned long long *>(const_cast<float *>(p.bias))[((size_t)blockIdx.x * 8 + w) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define LNLIN_BIAS ((const float *)nullptr)
+#else
+#define LNLIN_STAMP(slot) do { } while (0)
+#define LNLIN_BIAS (p.bias)
+#endif
+
 template <typename F>
 __global__ __launch_bounds__(512, 4) void lnlin_kernel(const ppt_lnlin_params p)
 {
@@ -58,6 +68,19 @@ __global__ __launch_bounds__(512, 4) void lnlin_kernel(const ppt_lnlin_params p)
     const int row0 = chunk * R;
     if (row0 >= p.M) return;
     const int nrow = min(R, p.M - row0);
+    LNLIN_STAMP(0);
+
+    // ---- the chunk's rows first (they are what the first phase waits for; in-order return would put them behind the ring's 9 KB per
+    // wave), BOTH passes at once -- a pass requested behind the other's arithmetic cost a second trip to L2 (~2 us of the ~11 a
+    // workgroup lives): 16 threads per row, 32 rows per pass (rows past M: the last row again, zeroed below)
+    const int lr0 = threadIdx.x >> 4, j = threadIdx.x & 15;
+    float4 xf[R / 32][D / 64];
+#pragma unroll
+    for (int pass = 0; pass < R / 32; ++pass) {
+        const float *src = p.x + (size_t)(row0 + min(32 * pass + lr0, nrow - 1)) * D;
+#pragma unroll
+        for (int i = 0; i < D / 64; ++i) xf[pass][i] = *reinterpret_cast<const float4 *>(src + 4 * (j + 16 * i));
+    }
 
     // ---- the weight ring: W in fragment order [slice][wave][ks < 12][nb < 3][lane][8] (ppt_lnlin_retile), first k-steps requested at once
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.W), 0, p.slices * 8 * WAVE_SLICE, 0x00020000);
@@ -70,25 +93,21 @@ __global__ __launch_bounds__(512, 4) void lnlin_kernel(const ppt_lnlin_params p)
     uint4 g[DR][3];
 #pragma unroll
     for (int i = 0; i < DR; ++i) next(g[i]);
+    LNLIN_STAMP(1);
 
-    // ---- LayerNorm of the chunk's rows -> the image: 16 threads per row, 32 rows per pass (rows past M: zeros)
+    // ---- LayerNorm -> the image (two-pass statistics over DPP adds)
     {
-        const int r = threadIdx.x >> 4, j = threadIdx.x & 15;
 #pragma unroll
         for (int pass = 0; pass < R / 32; ++pass) {
-            const int lr = 32 * pass + r;
-            const float *src = p.x + (size_t)(row0 + min(lr, nrow - 1)) * D;
-            float4 xf[D / 64];
-#pragma unroll
-            for (int i = 0; i < D / 64; ++i) xf[i] = *reinterpret_cast<const float4 *>(src + 4 * (j + 16 * i));
+            const int lr = 32 * pass + lr0;
             float sm = 0.f;
 #pragma unroll
-            for (int i = 0; i < D / 64; ++i) sm += (xf[i].x + xf[i].y) + (xf[i].z + xf[i].w);
+            for (int i = 0; i < D / 64; ++i) sm += (xf[pass][i].x + xf[pass][i].y) + (xf[pass][i].z + xf[pass][i].w);
             const float mean = row16_sum_l(sm) * (1.0f / (float)D);
             float q = 0.f;
 #pragma unroll
             for (int i = 0; i < D / 64; ++i) {
-                const float d0 = xf[i].x - mean, d1 = xf[i].y - mean, d2 = xf[i].z - mean, d3 = xf[i].w - mean;
+                const float d0 = xf[pass][i].x - mean, d1 = xf[pass][i].y - mean, d2 = xf[pass][i].z - mean, d3 = xf[pass][i].w - mean;
                 q = fmaf(d0, d0, q); q = fmaf(d1, d1, q); q = fmaf(d2, d2, q); q = fmaf(d3, d3, q);
             }
             const float rstd = 1.0f / sqrtf(row16_sum_l(q) * (1.0f / (float)D) + p.ln_eps);
@@ -99,13 +118,15 @@ __global__ __launch_bounds__(512, 4) void lnlin_kernel(const ppt_lnlin_params p)
                 const float4 gm = *reinterpret_cast<const float4 *>(p.ln_w + c), bt = *reinterpret_cast<const float4 *>(p.ln_b + c);
                 uint2 o = make_uint2(0u, 0u);
                 if (lr < nrow)
-                    o = make_uint2(h16<F>::pack2((xf[i].x - mean) * rstd * gm.x + bt.x, (xf[i].y - mean) * rstd * gm.y + bt.y),
-                                   h16<F>::pack2((xf[i].z - mean) * rstd * gm.z + bt.z, (xf[i].w - mean) * rstd * gm.w + bt.w));
+                    o = make_uint2(h16<F>::pack2((xf[pass][i].x - mean) * rstd * gm.x + bt.x, (xf[pass][i].y - mean) * rstd * gm.y + bt.y),
+                                   h16<F>::pack2((xf[pass][i].z - mean) * rstd * gm.z + bt.z, (xf[pass][i].w - mean) * rstd * gm.w + bt.w));
                 *reinterpret_cast<uint2 *>(dst + 2 * c) = o;
             }
         }
     }
+    LNLIN_STAMP(2);
     lds_barrier_l();
+    LNLIN_STAMP(3);
 
     // ---- C^T[n][m] = W[n][k] image[m][k]: a lane holds four consecutive columns of a row
     f32x4_t acc[RB][3];
@@ -132,14 +153,16 @@ __global__ __launch_bounds__(512, 4) void lnlin_kernel(const ppt_lnlin_params p)
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    LNLIN_STAMP(4);
     lds_barrier_l();                                                     // every wave is done reading the image
+    LNLIN_STAMP(5);
 
     // ---- (+ bias) -> the C tile in LDS -> 16-byte row pieces
     {
         const int ncol = slice * NC + 48 * w;
 #pragma unroll
         for (int nb = 0; nb < 3; ++nb) {
-            const float4 bv = p.bias ? *reinterpret_cast<const float4 *>(p.bias + ncol + 16 * nb + 4 * kg) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 bv = LNLIN_BIAS ? *reinterpret_cast<const float4 *>(LNLIN_BIAS + ncol + 16 * nb + 4 * kg) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
                 *reinterpret_cast<uint2 *>(smem + (16 * rb + l15) * CP + (48 * w + 16 * nb + 4 * kg) * 2) =
@@ -147,6 +170,7 @@ __global__ __launch_bounds__(512, 4) void lnlin_kernel(const ppt_lnlin_params p)
         }
     }
     lds_barrier_l();
+    LNLIN_STAMP(6);
     {
         constexpr int CPR = NC / 8;                                       // 16-byte pieces per row (48)
         F *C = (F *)p.C;
@@ -158,6 +182,7 @@ __global__ __launch_bounds__(512, 4) void lnlin_kernel(const ppt_lnlin_params p)
                     *reinterpret_cast<const uint4 *>(smem + row * CP + 16 * ch);
         }
     }
+    LNLIN_STAMP(7);
 }
 
 // fragment order: Wt[slice][w][ks < 12][nb < 3][lane][8] = W[384 slice + 48 w + 16 nb + l15][32 ks + 8 kg ..)       W [N, 384] row-major
