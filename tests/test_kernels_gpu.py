@@ -1487,7 +1487,7 @@ def test_vit_mlp_with_the_proj_prologue_matches_proj_then_mlp(ops, M, rows, dtyp
 
 # ------------------------------------------------------------------ LayerNorm + K = 384 linear, rows stationary (csrc/lnlin.hip)
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("M,N,bias", [(16416, 1152, False), (513, 1152, False), (1000, 384, True), (77, 768, True), (32832, 1152, False)])
+@pytest.mark.parametrize("M,N,bias", [(16416, 1152, False), (513, 1152, False), (1000, 384, True), (77, 768, True), (32832, 1152, False), (12850, 768, True)])
 def test_lnlin_matches_layernorm_then_linear(ops, M, N, bias, dtype):
     """ppt_lnlin (norm1 + qkv of a frozen block: 64-row chunks x 384-column slices, the weight streamed in fragment order) against fp32
     torch math on the operands the MFMAs see and against csrc/rowgemm.hip's weight-stationary form of the same product; ragged last
