@@ -658,7 +658,7 @@ def main():
                 traffic_source = f"profiles/{rnd}_gemm_hbm_traffic.json (rocprofv3 --pmc passes of this command, round {rnd[1:]}; not measured in this run)"
                 rocprof_family = tj.get("rocprof_family")
                 break
-        roof = {"bound": "mfma", "kernel": "16-bit (fp16 / bf16) MFMA GEMM family (ppt_amd/csrc/gemm.hip, rowgemm.hip, mlp_fused3.hip, text_mlp.hip, mpn1/mpn3/mpn4.hip)",
+        roof = {"bound": "mfma", "kernel": "16-bit (fp16 / bf16) MFMA GEMM family (ppt_amd/csrc/gemm.hip, rowgemm.hip, lnlin.hip, mlp_fused3.hip, text_mlp.hip, mpn1/mpn3/mpn4.hip)",
                 "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "frac_source": "live HIP-event brackets on the launch stream, dispatch gap subtracted (reads ~8 % above rocprofv3's kernel-only durations)",

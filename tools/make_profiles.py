@@ -15,7 +15,7 @@ import pandas as pd
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # the bf16 MFMA GEMM family (what bench.py's roofline object is about): tile GEMMs, the fused mini-PointNet kernels, the
 # weight-stationary short-K linears and the fused ViT MLP
-GEMM_BF16 = r"gemm_kernel.*<(unsigned short|f16_t)|gemm256_kernel|gemm_tn_kernel|mpn[134]_kernel|rowgemm_kernel|vit_mlp_kernel|vit_mlp3_kernel|text_mlp_kernel"
+GEMM_BF16 = r"gemm_kernel.*<(unsigned short|f16_t)|gemm256_kernel|gemm_tn_kernel|mpn[134]_kernel|rowgemm_kernel|vit_mlp_kernel|vit_mlp3_kernel|text_mlp_kernel|lnlin_kernel"
 CONFIGS = ("c2", "c3", "c4", "c5", "mlp")
 TRACE_STEPS = 40 + 5 + 10                   # burn-in + warm-up + timed steps of the traced command
 
@@ -74,7 +74,7 @@ def section(rnd, cfg, d, out):
         nf, nw = int(fam_f["count"].sum()), int(fam_w["count"].sum())
         if cfg == "c2" and nf:
             traffic = {
-                "kernel": "16-bit MFMA GEMM family (gemm_kernel* <unsigned short | f16_t>, gemm_tn_kernel, mpn1 / mpn3 / mpn4_kernel, rowgemm_kernel, vit_mlp_kernel)",
+                "kernel": "16-bit MFMA GEMM family (gemm_kernel* <unsigned short | f16_t>, gemm_tn_kernel, mpn1 / mpn3 / mpn4_kernel, rowgemm_kernel, lnlin_kernel, vit_mlp3_kernel, text_mlp_kernel)",
                 "command": "PPT_HIP_GRAPHS=0 rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) --output-format csv -- "
                            "python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-parity-mode --no-secondary",
                 "launches_counted": nf, "fetch_size_kb_sum": float(fam_f["sum"].sum()), "write_size_kb_sum": float(fam_w["sum"].sum()),

@@ -17,7 +17,12 @@ cfg = bench.CONFIGS[name]
 graphs.shared_text_stream(priority=-1 if cfg["head_type"] == 0 else 0)
 model = bench.build_model(cfg["dataset"], cfg["head_type"], torch.bfloat16, "ULIP_PointBERT", "cls")
 model.train()
-tr = Trainer(model, lr=3e-3, label_smoothing=0.2, distributed=False)
+force_dist = os.environ.get("PPT_FORCE_DIST") == "1"          # the RCCL path with a single rank
+if force_dist:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+tr = Trainer(model, lr=3e-3, label_smoothing=0.2, distributed=force_dist)
 tr.inputs_ready = os.environ.get("PPT_INPUTS_READY", "0") == "1"
 B, N = cfg["batch"], cfg["npoints"]
 pc = torch.from_numpy(W.synth_clouds(B, N, seed=1)[0]).cuda()
