@@ -15,8 +15,8 @@
 // slices of a chunk (consecutive ids / 8) read the same x rows out of one L2.
 // (Measured and removed: 80-row chunks that walk all three slices themselves -- one read and one LayerNorm of the rows, 206 workgroups =
 // one round at 16 416 rows, 1 008 KB taken in per 80 rows instead of 3 x 393 KB per 64 -- as one 8-wave workgroup per CU: 36.5-37.3 us
-// against 28.0 here (79.7 / 51.8 at 32 832 rows), ring depth 4 or 6 alike.  With eight waves a CU streams ~20 B/clk beside its MFMAs, with
-// sixteen in two independent workgroups ~2.4 x that; the bytes saved do not buy back the waves.)
+// against 28.0 here (79.7 / 51.8 at 32 832 rows), ring depth 4 or 6 alike.  With eight waves a CU took in 885 KB in ~26 us beside its MFMAs, with
+// sixteen in two independent workgroups 786 KB in ~13 us; the bytes saved do not buy back the waves.)
 #include "ppt_common.h"
 
 namespace {
