@@ -44,7 +44,9 @@ const char *ppt_strerror(int code);
 /* ABI version of this header (currently 7); bumped on any signature change or added entry point.
  * 7: ppt_gemm_params.split_overflow (new trailing field: split16 saturates finite values beyond IEEE half's range and counts
  *    the workgroups that did), ppt_vit_mlp3_bf16 / ppt_vit_mlp3_retile (new: csrc/mlp_fused3.hip), ppt_text_mlp_pair /
- *    ppt_text_mlp_retile (new: csrc/text_mlp.hip), ppt_lnlin / ppt_lnlin_retile (new: csrc/lnlin.hip).
+ *    ppt_text_mlp_retile (new: csrc/text_mlp.hip), ppt_lnlin / ppt_lnlin_retile (new: csrc/lnlin.hip),
+ *    ppt_text_mlp_retile_split + the split16 fields of ppt_text_mlp_params (csrc/text_mlp_split.hip), ppt_text_lin_split /
+ *    ppt_text_lin_retile_split (csrc/text_lin_split.hip).
  * 6: ppt_gemm_params.split16 / split_a_pow2 / split_b_pow2 (new trailing fields: fp32 operands as hi + lo half pairs),
  *    ppt_attention_fwd_split16 / ppt_attention_bwd_split16 (new), ppt_pointmlp_cloud_rstd / ppt_pointmlp_pq (new).
  * 5: ppt_labels_check (new), ppt_gemm256 (new: the 256-row macro-tile GEMM core), ppt_set_gemm256 / ppt_get_gemm256 (new),
@@ -354,9 +356,35 @@ typedef struct ppt_text_mlp_params {
      * LayerNorm(A; ln_w, ln_b, ln_eps) -- ln_2 of the layer, computed in fp32 as ULIP_models.py:21-27 does -- is applied while the rows
      * are staged; ln_mean / ln_rstd [M] (optional) receive the row statistics for the LayerNorm backward. */
     const float *ln_w; const float *ln_b; float ln_eps; float *ln_mean; float *ln_rstd;
+    /* dtype == PPT_F32: the split16 form (csrc/text_mlp_split.hip) -- A and `pre` are fp32, W1 / W2 the hi + lo half copies of
+     * ppt_text_mlp_retile_split (made with the same split_b_pow2), every product three MFMAs on hi + lo IEEE-half pairs
+     * (ppt_gemm_params.split16); A and the hidden activation are multiplied by 2^split_a_pow2 before they are split; a wave that
+     * saturated a finite value beyond half's range adds 1 to *split_overflow (may be NULL).  No LayerNorm prologue in this form. */
+    int split_a_pow2, split_b_pow2; unsigned int *split_overflow;
 } ppt_text_mlp_params;
 int ppt_text_mlp_retile(const void *W1, const void *W2, void *W1_tiled, void *W2_tiled, void *stream);
+/* fp32 W1 [2048, 512] / W2 [512, 2048] -> the fragment-ordered hi + lo half copies (4 MB each) of the split16 form */
+int ppt_text_mlp_retile_split(const float *W1, const float *W2, void *W1_tiled, void *W2_tiled, int b_pow2, void *stream);
 int ppt_text_mlp_pair(const ppt_text_mlp_params *p, void *stream);
+
+/* ---- one linear of the text tower's attention half on split16 products, rows stationary (ABI 7; csrc/text_lin_split.hip) -------
+ * C[M, N] = A[M, K] W[N, K]^T (+ bias) (+ residual), every product three MFMAs on hi + lo IEEE-half pairs of the fp32 operands
+ * (ppt_gemm_params.split16): nn.MultiheadAttention's in_proj / out_proj of a CLIP ResidualAttentionBlock (ULIP_models.py:38, 45-51)
+ * and their input-gradient products.  K a multiple of 512, N of 256.  K > 512: the K chunks' partial products leave separately,
+ * C = parts[K / 512][M][N] (ldc == N, no bias / residual) for a consumer that adds them up (ppt_layernorm_bwd_sum).
+ * W: the fragment-ordered hi + lo half copy of ppt_text_lin_retile_split (N * K * 4 bytes, made with the same split_b_pow2). */
+typedef struct ppt_text_lin_params {
+    const void *A; int64_t lda;              /* fp32 [M, K] */
+    const void *W;
+    const float *bias;                       /* [N] or NULL */
+    const float *residual; int64_t ld_res;   /* fp32 [M, N] or NULL */
+    float *C; int64_t ldc;
+    int M, N, K;
+    int split_a_pow2, split_b_pow2; unsigned int *split_overflow;
+    int wave_prio;
+} ppt_text_lin_params;
+int ppt_text_lin_retile_split(const float *W, void *W_tiled, int N, int K, int b_pow2, void *stream);
+int ppt_text_lin_split(const ppt_text_lin_params *p, void *stream);
 
 /* ---- Attention ---------------------------------------------------------------------------------
  * softmax(scale * q k^T [+ causal mask]) v per (batch, head).  Replaces

@@ -42,12 +42,22 @@ class LnLinParams(ctypes.Structure):
     ]
 
 
+class TextLinParams(ctypes.Structure):
+    """struct ppt_text_lin_params (include/ppt_hip.h) -- field order must match the header."""
+    _fields_ = [
+        ("A", c_void_p), ("lda", c_int64), ("W", c_void_p), ("bias", c_void_p), ("residual", c_void_p), ("ld_res", c_int64),
+        ("C", c_void_p), ("ldc", c_int64), ("M", c_int), ("N", c_int), ("K", c_int),
+        ("split_a_pow2", c_int), ("split_b_pow2", c_int), ("split_overflow", c_void_p), ("wave_prio", c_int),
+    ]
+
+
 class TextMlpParams(ctypes.Structure):
     """struct ppt_text_mlp_params (include/ppt_hip.h) -- field order must match the header."""
     _fields_ = [
         ("A", c_void_p), ("lda", c_int64), ("W1", c_void_p), ("W2", c_void_p), ("b1", c_void_p), ("pre", c_void_p), ("parts", c_void_p),
         ("M", c_int), ("D", c_int), ("hidden", c_int), ("mode", c_int), ("dtype", c_int), ("wave_prio", c_int),
         ("ln_w", c_void_p), ("ln_b", c_void_p), ("ln_eps", ctypes.c_float), ("ln_mean", c_void_p), ("ln_rstd", c_void_p),
+        ("split_a_pow2", c_int), ("split_b_pow2", c_int), ("split_overflow", c_void_p),
     ]
 
 
@@ -123,6 +133,9 @@ _SIGNATURES = {
     "ppt_lnlin": (c_int, [ctypes.POINTER(LnLinParams), c_void_p]),
     "ppt_text_mlp_retile": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ppt_text_mlp_pair": (c_int, [ctypes.POINTER(TextMlpParams), c_void_p]),
+    "ppt_text_mlp_retile_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "ppt_text_lin_retile_split": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ppt_text_lin_split": (c_int, [ctypes.POINTER(TextLinParams), c_void_p]),
     "ppt_vit_mlp3_retile": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ppt_vit_mlp3_bf16": (c_int, [ctypes.POINTER(VitMlpParams), c_void_p]),
     "ppt_rowgemm_bf16": (c_int, [ctypes.POINTER(RowGemmParams), c_void_p]),

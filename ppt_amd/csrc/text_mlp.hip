@@ -283,17 +283,20 @@ extern "C" int ppt_text_mlp_retile(const void *W1, const void *W2, void *W1t, vo
     return PPT_OK;
 }
 
+extern "C" int ppt_text_mlp_pair_split(const ppt_text_mlp_params *pp, void *stream);     // text_mlp_split.hip
+
 extern "C" int ppt_text_mlp_pair(const ppt_text_mlp_params *pp, void *stream)
 {
     if (!pp) return PPT_EINVAL;
     ppt_text_mlp_params p = *pp;
     if (!p.A || !p.W1 || !p.W2 || !p.parts || p.M <= 0 || p.lda < D) return PPT_EINVAL;
     if (p.D != D || p.hidden != HID) return PPT_EUNSUPPORTED;
-    if (p.dtype != PPT_BF16 && p.dtype != PPT_F16) return PPT_EINVAL;
+    if (p.dtype != PPT_BF16 && p.dtype != PPT_F16 && p.dtype != PPT_F32) return PPT_EINVAL;
     if (p.mode != 0 && p.mode != 1) return PPT_EINVAL;
     if (p.mode == 1 && !p.pre) return PPT_EINVAL;
     if (((uintptr_t)p.A | (uintptr_t)p.W1 | (uintptr_t)p.W2 | (uintptr_t)p.parts | (uintptr_t)p.pre | (uintptr_t)p.b1) & 15) return PPT_EINVAL;
     if (p.wave_prio == 0) p.wave_prio = ppt_get_wave_priority();
+    if (p.dtype == PPT_F32) return ppt_text_mlp_pair_split(&p, stream);          // fp32 operands as hi + lo half pairs (text_mlp_split.hip)
     const bool ln = p.ln_w != nullptr;
     if (ln && (p.mode != 0 || !p.ln_b || R != 32 || (p.lda % 4) || (((uintptr_t)p.ln_w | (uintptr_t)p.ln_b) & 15))) return PPT_EINVAL;
     if (!ln && (p.lda % 8)) return PPT_EINVAL;

@@ -875,12 +875,42 @@ POINTMLP_FUSED_NORM = os.environ.get("PPT_POINTMLP_FUSED_NORM", "1") != "0"
 # PPT_TEXT_MLP_PAIR=0 restores c_fc + split-K c_proj as two launches.
 TEXT_MLP_PAIR = os.environ.get("PPT_TEXT_MLP_PAIR", "1") != "0"
 TEXT_MLP_PAIR_LN = os.environ.get("PPT_TEXT_MLP_PAIR_LN", "1") != "0"      # ln_2 inside that launch (forward); 0: its own launch in front
+# ... and its split16 form (csrc/text_mlp_split.hip) where the text tower runs on fp32 operands as hi + lo half pairs: the whole-model
+# split16 mode, and the mixed mode on weights whose text tower failed its self-check (checkpoint-like magnitudes).  0: the tile GEMMs.
+TEXT_MLP_PAIR_SPLIT = os.environ.get("PPT_TEXT_MLP_PAIR_SPLIT", "1") != "0"
+
+
+# The attention half's four linears of a text layer in that mode on csrc/text_lin_split.hip (rows stationary, weight halves streamed):
+# in_proj, out_proj (+ bias + residual), and their input-gradient products.  0: the split16 tile GEMMs.
+TEXT_LIN_SPLIT = os.environ.get("PPT_TEXT_LIN_SPLIT", "1") != "0"
+
+
+def _text_lin_ok(Ta, width):
+    return Ta == torch.float32 and TEXT_LIN_SPLIT and ops.split16_enabled() and width == 512
+
+
+def _text_lin_tiles(sd, name, wca, transposed=False):
+    """The hi + lo half copy of weight `name` ([N, K]; transposed: of its transpose, the dX operand) for ops.text_lin_split, made with
+    the B pre-scale in force (a new fit re-makes it)."""
+    w = sd[name]
+    b = ops.SPLIT16_POW2[1]
+    return wca.derived(("text_lin_split", name, transposed, b), (w,),
+                       lambda: ops.text_lin_retile_split(wca.get(w, "wt") if transposed else wca.get(w), b))
+
+
+def _text_mlp_pair_ok(Tm):
+    return Tm in ops.HALF or (Tm == torch.float32 and TEXT_MLP_PAIR_SPLIT and ops.split16_enabled())
 
 
 def _text_mlp_tiles(sd, p, wcm, backward):
     """The fragment-ordered weight copies of layer `p` for ops.text_mlp_pair: forward (c_fc.weight, c_proj.weight); backward the
     transposed pair (c_proj.weight^T [2048, 512], c_fc.weight^T [512, 2048]) -- the dX operands the WeightCache already keeps."""
     wfc, wpr = sd[p + "mlp.c_fc.weight"], sd[p + "mlp.c_proj.weight"]
+    if wcm.dtype == torch.float32:          # split16: hi + lo half copies, made with the B pre-scale in force (a new fit re-makes them)
+        b = ops.SPLIT16_POW2[1]
+        if backward:
+            return wcm.derived(("text_mlp_split_bwd", p, b), (wfc, wpr), lambda: ops.text_mlp_retile_split(wcm.get(wpr, "wt"), wcm.get(wfc, "wt"), b))
+        return wcm.derived(("text_mlp_split_fwd", p, b), (wfc, wpr), lambda: ops.text_mlp_retile_split(wcm.get(wfc), wcm.get(wpr), b))
     if backward:
         return wcm.derived(("text_mlp_tiles_bwd", p), (wfc, wpr), lambda: ops.text_mlp_retile(wcm.get(wpr, "wt"), wcm.get(wfc, "wt")))
     return wcm.derived(("text_mlp_tiles_fwd", p), (wfc, wpr), lambda: ops.text_mlp_retile(wcm.get(wfc), wcm.get(wpr)))
@@ -953,6 +983,7 @@ def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=No
     # the residual and the bias -- by the LayerNorm that reads the result anyway (ops.layernorm_fwd_sum): no reduction launch.
     # (16-bit modes and split16; the fp32 parity mode keeps the single-launch summation order)
     splitk = TEXT_SPLITK and (T in ops.HALF or ops.split16_enabled()) and Tm == T and not fuse and M <= 4096 and Wd == 512
+    lin_split = _text_lin_ok(Ta, Wd) and not fuse
     pending = None                  # (x_mid, c_proj bias, partial products) of the previous layer: its output is formed by this layer's LN1
     for i in range(layers):
         p = f"transformer.resblocks.{i}."
@@ -961,7 +992,10 @@ def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=No
             h, mean1, rstd1 = ops.layernorm_fwd_sum(pending[0], pending[1], pending[2], sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], Ta,
                                                     write_xs=x, save_stats=save)
             pending = None
-            qkv = ops.gemm(h, wca.get(sd[p + "attn.in_proj_weight"]), out_dtype=Ta, bias=sd[p + "attn.in_proj_bias"])
+            if lin_split:
+                qkv = ops.text_lin_split(h, _text_lin_tiles(sd, p + "attn.in_proj_weight", wca), bias=sd[p + "attn.in_proj_bias"])
+            else:
+                qkv = ops.gemm(h, wca.get(sd[p + "attn.in_proj_weight"]), out_dtype=Ta, bias=sd[p + "attn.in_proj_bias"])
         elif fuse and add is None:
             # LayerNorm applied while the rows are staged (one node of the prompt chain instead of two); its statistics are
             # kept for the backward
@@ -973,21 +1007,30 @@ def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=No
             h, mean1, rstd1 = ops.layernorm_fwd(xin, sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], Ta, add=add,
                                                 add_rows=add_rows, write_xs=x if add is not None else None,
                                                 save_stats=save)
-            qkv = ops.gemm(h, wca.get(sd[p + "attn.in_proj_weight"]), out_dtype=Ta, bias=sd[p + "attn.in_proj_bias"])
+            if lin_split:
+                qkv = ops.text_lin_split(h, _text_lin_tiles(sd, p + "attn.in_proj_weight", wca), bias=sd[p + "attn.in_proj_bias"])
+            else:
+                qkv = ops.gemm(h, wca.get(sd[p + "attn.in_proj_weight"]), out_dtype=Ta, bias=sd[p + "attn.in_proj_bias"])
         add, add_rows = None, 0
         if P:
             a, lse = ops.attention_prefix_fwd(qkv, C, L, P, heads, ATTN_SCALE, want_lse=save)
         else:
             a, lse = ops.attention_fwd(qkv, C, L, heads, ATTN_SCALE, True, want_lse=save)
         x_mid = torch.empty_like(x)
-        ops.gemm(a, wca.get(sd[p + "attn.out_proj.weight"]), out=x_mid, bias=sd[p + "attn.out_proj.bias"], residual=x)
+        if lin_split:
+            ops.text_lin_split(a, _text_lin_tiles(sd, p + "attn.out_proj.weight", wca), bias=sd[p + "attn.out_proj.bias"], residual=x, out=x_mid)
+        else:
+            ops.gemm(a, wca.get(sd[p + "attn.out_proj.weight"]), out=x_mid, bias=sd[p + "attn.out_proj.bias"], residual=x)
         pre = torch.empty((M, sd[p + "mlp.c_fc.weight"].shape[0]), dtype=Tm, device=dev) if save else None
-        pair = (TEXT_MLP_PAIR and splitk and i + 1 < layers and Tm in ops.HALF and tuple(sd[p + "mlp.c_fc.weight"].shape) == (2048, 512))
+        pair = (TEXT_MLP_PAIR and splitk and i + 1 < layers and _text_mlp_pair_ok(Tm) and tuple(sd[p + "mlp.c_fc.weight"].shape) == (2048, 512))
         if pair:
             # c_fc + QuickGELU + c_proj in one launch; its eight partial products are this layer's output once the next layer's
             # LayerNorm has added them to x_mid and the bias (the split-K hand-over below, with 8 slices instead of 4)
             w1t, w2t = _text_mlp_tiles(sd, p, wcm, False)
-            if TEXT_MLP_PAIR_LN:
+            if Tm == torch.float32:
+                h2, mean2, rstd2 = ops.layernorm_fwd(x_mid, sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], Tm, save_stats=save)
+                parts = ops.text_mlp_pair_split(h2, w1t, w2t, bias=sd[p + "mlp.c_fc.bias"], pre=pre)
+            elif TEXT_MLP_PAIR_LN:
                 # ... and ln_2 is applied while the kernel stages its rows: the LayerNorm launch in front of it goes as well
                 parts, mean2, rstd2 = ops.text_mlp_pair(x_mid, w1t, w2t, bias=sd[p + "mlp.c_fc.bias"], pre=pre,
                                                         ln=(sd[p + "ln_2.weight"], sd[p + "ln_2.bias"]), save_stats=save)
@@ -1066,15 +1109,17 @@ def text_tower_backward(sd, wc, s, dout, grad_scale=1.0):
     wca, wcm = s.get("wca", wc), s.get("wcm", wc)              # (per-half operand precision: diagnostics, see the forward)
     Ta, Tm = wca.dtype, wcm.dtype
     splitk = TEXT_SPLITK and (T in ops.HALF or ops.split16_enabled()) and Ta == T and Tm == T and M <= 4096 and Wd == 512
+    lin_split = _text_lin_ok(Ta, Wd) and splitk and Tm == Ta
     g_t = ops.convert(g, Tm)
     for i in reversed(range(len(s["layers"]))):
         p = f"transformer.resblocks.{i}."
         ly = s["layers"][i]
-        if TEXT_MLP_PAIR and splitk and Tm in ops.HALF and tuple(sd[p + "mlp.c_fc.weight"].shape) == (2048, 512):
+        if TEXT_MLP_PAIR and splitk and _text_mlp_pair_ok(Tm) and tuple(sd[p + "mlp.c_fc.weight"].shape) == (2048, 512):
             # the branch's input gradient ((g W_proj) * QuickGELU'(pre)) W_fc in one launch: eight partial products, added up by the
             # LayerNorm backward that reads them
             w1t, w2t = _text_mlp_tiles(sd, p, wcm, True)
-            _, g_t = ops.layernorm_bwd_sum(ops.text_mlp_pair(g_t, w1t, w2t, pre=ly["pre"], backward=True), ly["x_mid"],
+            pair_fn = ops.text_mlp_pair_split if Tm == torch.float32 else ops.text_mlp_pair
+            _, g_t = ops.layernorm_bwd_sum(pair_fn(g_t, w1t, w2t, pre=ly["pre"], backward=True), ly["x_mid"],
                                            sd[p + "ln_2.weight"], ly["mean2"], ly["rstd2"], g, accumulate=True, copy_dtype=Ta)
             d_pre = None
         else:
@@ -1090,13 +1135,18 @@ def text_tower_backward(sd, wc, s, dout, grad_scale=1.0):
             d_h2 = ops.gemm(d_pre, wcm.get(sd[p + "mlp.c_fc.weight"], "wt"), out_dtype=torch.float32)
             _, _, _, g_t = ops.layernorm_bwd(d_h2, ly["x_mid"], sd[p + "ln_2.weight"], ly["mean2"], ly["rstd2"], dx=g,
                                              accumulate=True, copy_dtype=Ta)
-        d_a = ops.gemm(g_t, wca.get(sd[p + "attn.out_proj.weight"], "wt"), out_dtype=Ta)
+        if lin_split:
+            d_a = ops.text_lin_split(g_t, _text_lin_tiles(sd, p + "attn.out_proj.weight", wca, True))
+        else:
+            d_a = ops.gemm(g_t, wca.get(sd[p + "attn.out_proj.weight"], "wt"), out_dtype=Ta)
         if P:
             d_qkv = ops.attention_prefix_bwd(ly["qkv"], ly["a"], d_a, ly["lse"], C, L, P, heads, ATTN_SCALE)
         else:
             d_qkv = ops.attention_bwd(ly["qkv"], ly["a"], d_a, ly["lse"], C, L, heads, ATTN_SCALE, True)
         if splitk:                  # K = 1536: three slices
-            _, g_t = ops.layernorm_bwd_sum(ops.gemm_splitk(d_qkv, wca.get(sd[p + "attn.in_proj_weight"], "wt"), 3), ly["x"],
+            dparts = (ops.text_lin_split(d_qkv, _text_lin_tiles(sd, p + "attn.in_proj_weight", wca, True)) if lin_split
+                      else ops.gemm_splitk(d_qkv, wca.get(sd[p + "attn.in_proj_weight"], "wt"), 3))
+            _, g_t = ops.layernorm_bwd_sum(dparts, ly["x"],
                                            sd[p + "ln_1.weight"], ly["mean1"], ly["rstd1"], g, accumulate=True, copy_dtype=Tm)
         else:
             d_h = ops.gemm(d_qkv, wca.get(sd[p + "attn.in_proj_weight"], "wt"), out_dtype=torch.float32)

@@ -423,6 +423,87 @@ def text_mlp_retile(w1, w2):
     return w1t, w2t
 
 
+def text_mlp_retile_split(w1, w2, b_pow2=None):
+    """(w1 [2048, 512], w2 [512, 2048]) fp32 row-major -> the fragment-ordered hi + lo half copies (uint8 [4 MB] each) of the split16
+    form of ppt_text_mlp_pair (csrc/text_mlp_split.hip), multiplied by 2^b_pow2 (default: the current SPLIT16_POW2's B scale).  The
+    copies remember the scale they were made with (`.ppt_b_pow2`)."""
+    assert w1.dtype == torch.float32 and w2.dtype == torch.float32 and tuple(w1.shape) == (2048, 512) and tuple(w2.shape) == (512, 2048)
+    _chk(w1, torch.float32, "w1"); _chk(w2, torch.float32, "w2")
+    b = SPLIT16_POW2[1] if b_pow2 is None else int(b_pow2)
+    w1t = torch.empty((2048 * 512 * 4,), dtype=torch.uint8, device=w1.device)
+    w2t = torch.empty((2048 * 512 * 4,), dtype=torch.uint8, device=w1.device)
+    _lib.check(_lib.lib().ppt_text_mlp_retile_split(_p(w1), _p(w2), _p(w1t), _p(w2t), b, _stream()), "ppt_text_mlp_retile_split")
+    w1t.ppt_b_pow2 = w2t.ppt_b_pow2 = b
+    return w1t, w2t
+
+
+def text_mlp_pair_split(a, w1t, w2t, *, bias=None, pre=None, backward=False, a_pow2=None):
+    """text_mlp_pair on fp32 operands multiplied as hi + lo half pairs (split16; csrc/text_mlp_split.hip): a [M, 512] f32, w1t / w2t
+    from text_mlp_retile_split, pre [M, 2048] f32 -> the eight slices' partial products [8, M, 512] f32."""
+    M = a.shape[0]
+    assert a.dim() == 2 and a.shape[1] == 512 and a.stride(1) == 1 and a.dtype == torch.float32 and w1t.dtype == torch.uint8
+    parts = torch.empty((8, M, 512), dtype=torch.float32, device=a.device)
+    p = _lib.TextMlpParams()
+    p.A, p.lda, p.W1, p.W2, p.b1, p.pre, p.parts = _p(a), a.stride(0), _p(w1t), _p(w2t), _p(bias), _p(pre), _p(parts)
+    p.M, p.D, p.hidden, p.mode, p.dtype = M, 512, 2048, int(bool(backward)), PPT_F32
+    p.split_a_pow2 = SPLIT16_POW2[0] if a_pow2 is None else int(a_pow2)
+    p.split_b_pow2 = int(w1t.ppt_b_pow2)
+    if not torch.cuda.is_current_stream_capturing() or a.device.index in _SPLIT_OVERFLOW:
+        p.split_overflow = _p(split16_overflow_counter(a.device))
+    if pre is not None:
+        assert pre.dtype == torch.float32 and tuple(pre.shape) == (M, 2048) and pre.is_contiguous()
+    if profiler is not None:
+        profiler.begin("gemm_f32", 4.0 * M * 512 * 2048, "ppt_text_mlp_pair split16 (" + ("backward" if backward else "forward") + ")")
+    _lib.check(_lib.lib().ppt_text_mlp_pair(ctypes.byref(p), _stream()), "ppt_text_mlp_pair (split16)")
+    if profiler is not None:
+        profiler.end()
+    return parts
+
+
+def text_lin_retile_split(w, b_pow2=None):
+    """w [N, K] fp32 row-major (N a multiple of 256, K of 512) -> the fragment-ordered hi + lo half copy text_lin_split reads (uint8,
+    N * K * 4 bytes), multiplied by 2^b_pow2 (default: the current SPLIT16_POW2's B scale); remembers (N, K, b_pow2)."""
+    assert w.dtype == torch.float32 and w.dim() == 2
+    _chk(w, torch.float32, "w")
+    N, K = w.shape
+    b = SPLIT16_POW2[1] if b_pow2 is None else int(b_pow2)
+    wt = torch.empty((N * K * 4,), dtype=torch.uint8, device=w.device)
+    _lib.check(_lib.lib().ppt_text_lin_retile_split(_p(w), _p(wt), N, K, b, _stream()), "ppt_text_lin_retile_split")
+    wt.ppt_shape, wt.ppt_b_pow2 = (N, K), b
+    return wt
+
+
+def text_lin_split(a, wt, *, bias=None, residual=None, out=None, a_pow2=None):
+    """a [M, K] fp32 @ W^T (+ bias) (+ residual) on split16 products, rows stationary (csrc/text_lin_split.hip; wt =
+    text_lin_retile_split(W)) -> out [M, N] fp32; K > 512: the K / 512 partial products [K / 512, M, N] (no bias / residual)."""
+    N, K = wt.ppt_shape
+    M = a.shape[0]
+    assert a.dtype == torch.float32 and a.dim() == 2 and a.shape[1] == K and a.stride(1) == 1
+    kc = K // 512
+    if kc > 1:
+        assert bias is None and residual is None and out is None
+        out = torch.empty((kc, M, N), dtype=torch.float32, device=a.device)
+    elif out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    p = _lib.TextLinParams()
+    p.A, p.lda, p.W, p.bias = _p(a), a.stride(0), _p(wt), _p(bias)
+    if residual is not None:
+        assert residual.dtype == torch.float32 and residual.stride(-1) == 1
+        p.residual, p.ld_res = _p(residual), residual.stride(-2)
+    p.C, p.ldc = _p(out), (N if kc > 1 else out.stride(0))
+    p.M, p.N, p.K = M, N, K
+    p.split_a_pow2 = SPLIT16_POW2[0] if a_pow2 is None else int(a_pow2)
+    p.split_b_pow2 = int(wt.ppt_b_pow2)
+    if not torch.cuda.is_current_stream_capturing() or a.device.index in _SPLIT_OVERFLOW:
+        p.split_overflow = _p(split16_overflow_counter(a.device))
+    if profiler is not None:
+        profiler.begin("gemm_f32", 2.0 * M * N * K, "ppt_text_lin_split")
+    _lib.check(_lib.lib().ppt_text_lin_split(ctypes.byref(p), _stream()), "ppt_text_lin_split")
+    if profiler is not None:
+        profiler.end()
+    return out
+
+
 def text_mlp_pair(a, w1t, w2t, *, bias=None, pre=None, backward=False, ln=None, ln_eps=1e-5, save_stats=False):
     """The MLP half of a CLIP text layer in one launch (csrc/text_mlp.hip) -> the eight slices' partial products [8, M, 512] f32.
     forward: QuickGELU(a w1^T + bias) w2^T, `pre` (optional, [M, 2048] 16-bit) receives the pre-activation; backward=True:

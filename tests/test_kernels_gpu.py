@@ -1566,6 +1566,99 @@ def test_text_mlp_pair_matches_the_two_linears(ops, M, dtype):
     assert torch.equal(ops.text_mlp_pair(dout.cuda().to(dtype), b1t, b2t, pre=pre_r.cuda().to(dtype), backward=True), dparts)
 
 
+@pytest.mark.parametrize("M", [817, 37, 1480])
+def test_text_mlp_pair_split16_matches_fp64_and_the_split16_gemms(ops, M):
+    """The split16 form of ppt_text_mlp_pair (csrc/text_mlp_split.hip: fp32 operands multiplied as hi + lo IEEE-half pairs, the weights
+    split once by ppt_text_mlp_retile_split) against fp64 math on the fp32 operands -- fp32-GRADE bounds, forward and backward, with
+    outlier channels in the activations -- and against the two split16 tile GEMMs it replaces; the saved fp32 pre-activation; ragged last
+    block; bit-reproducible; a value beyond half's range is saturated and COUNTED."""
+    g = torch.Generator().manual_seed(M)
+    D, Hd = 512, 2048
+    a = torch.randn(M, D, generator=g)
+    a[:, ::37] *= 20.0                                                     # LayerNorm outlier channels
+    w1, b1 = torch.randn(Hd, D, generator=g) * D ** -0.5, 0.1 * torch.randn(Hd, generator=g)
+    w2 = torch.randn(D, Hd, generator=g) * Hd ** -0.5
+    qg = lambda v: v * torch.sigmoid(1.702 * v)
+    pre64 = a.double() @ w1.double().t() + b1.double()
+    want = qg(pre64) @ w2.double().t()
+    ad, w1d, w2d = a.cuda(), w1.cuda(), w2.cuda()
+    w1t, w2t = ops.text_mlp_retile_split(w1d, w2d, 4)
+    pre_out = torch.empty((M, Hd), dtype=torch.float32, device="cuda")
+    parts = ops.text_mlp_pair_split(ad, w1t, w2t, bias=b1.cuda(), pre=pre_out, a_pow2=0)
+    assert parts.shape == (8, M, D)
+    got = parts.double().sum(0).cpu()
+    rel = lambda x, y: ((x - y).norm() / y.norm()).item()
+    assert rel(got, want) < 2e-6, rel(got, want)
+    assert (got - want).abs().max().item() < 2e-5 * want.abs().max().item()
+    assert rel(pre_out.double().cpu(), pre64) < 1e-6
+    # the launches it replaces (same products, another summation order)
+    f = ops.gemm(ad, w1d, out_dtype=torch.float32, bias=b1.cuda(), act=ops.ACT_QUICKGELU, split=(0, 4))
+    ref = ops.gemm(f, w2d, out_dtype=torch.float32, split=(0, 4))
+    assert rel(got, ref.double().cpu()) < 2e-6
+    assert torch.equal(ops.text_mlp_pair_split(ad, w1t, w2t, bias=b1.cuda(), a_pow2=0), parts)
+    # ---- backward: ((d_out W_proj) * QuickGELU'(pre)) W_fc with gradient-sized values
+    dout = torch.randn(M, D, generator=g) * 1e-2
+    sg = torch.sigmoid(1.702 * pre64)
+    dwant = ((dout.double() @ w2.double()) * (sg * (1 + 1.702 * pre64 * (1 - sg)))) @ w1.double()
+    b1t, b2t = ops.text_mlp_retile_split(w2d.t().contiguous(), w1d.t().contiguous(), 4)
+    dparts = ops.text_mlp_pair_split(dout.cuda(), b1t, b2t, pre=pre64.float().cuda(), backward=True, a_pow2=0)
+    dgot = dparts.double().sum(0).cpu()
+    # (1e-2-sized gradients with no pre-scale sit below 2^-2, where hi + lo keep an ABSOLUTE 2^-25: the tile GEMMs share the floor)
+    assert rel(dgot, dwant) < 2e-5, rel(dgot, dwant)
+    d_pre = ops.gemm(dout.cuda(), w2d.t().contiguous(), out_dtype=torch.float32, act=ops.ACT_QUICKGELU, dact_pre=pre64.float().cuda(), split=(0, 4))
+    dref = ops.gemm(d_pre, w1d.t().contiguous(), out_dtype=torch.float32, split=(0, 4))
+    assert rel(dgot, dref.double().cpu()) < 2e-5
+    assert torch.equal(ops.text_mlp_pair_split(dout.cuda(), b1t, b2t, pre=pre64.float().cuda(), backward=True, a_pow2=0), dparts)
+    # ---- range: a finite activation beyond 65 504 x 2^-a_pow2 is saturated (finite result) and counted
+    ctr = ops.split16_overflow_counter()
+    before = int(ctr.item())
+    big = ad.clone()
+    big[0, 3] = 3.0e5
+    out = ops.text_mlp_pair_split(big, w1t, w2t, bias=b1.cuda(), a_pow2=0)
+    assert torch.isfinite(out).all() and int(ctr.item()) > before
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(817, 1536, 512, "bias"), (817, 512, 512, "bias+residual"), (817, 512, 1536, "chunks"), (37, 512, 512, "plain"),
+                                       (1480, 1536, 512, "bias")])
+def test_text_lin_split16_matches_fp64_and_the_split16_gemm(ops, M, N, K, epi):
+    """ppt_text_lin_split (csrc/text_lin_split.hip: a linear of the text tower's attention half on hi + lo half products, rows stationary,
+    the weight halves streamed) against fp64 math on the fp32 operands at fp32-grade bounds and against the split16 tile GEMM: in_proj
+    (bias), out_proj (bias + residual, written over a strided output), the K = 1536 input gradient as three partial products, a ragged
+    block; bit-reproducible; saturation counted."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g)
+    a[:, ::41] *= 15.0
+    w = torch.randn(N, K, generator=g) * K ** -0.5
+    b = 0.1 * torch.randn(N, generator=g) if "bias" in epi else None
+    r = torch.randn(M, N, generator=g) if "residual" in epi else None
+    want = a.double() @ w.double().t() + (b.double() if b is not None else 0) + (r.double() if r is not None else 0)
+    ad, wd = a.cuda(), w.cuda()
+    wt = ops.text_lin_retile_split(wd, 4)
+    kw = dict(bias=b.cuda() if b is not None else None, residual=r.cuda() if r is not None else None, a_pow2=0)
+    got = ops.text_lin_split(ad, wt, **kw)
+    rel = lambda x, y: ((x - y).norm() / y.norm()).item()
+    if epi == "chunks":
+        assert got.shape == (K // 512, M, N)
+        tot = got.double().sum(0).cpu()
+    else:
+        assert got.shape == (M, N)
+        tot = got.double().cpu()
+    assert rel(tot, want) < 2e-6, rel(tot, want)
+    ref = ops.gemm(ad, wd, out_dtype=torch.float32, bias=kw["bias"], residual=kw["residual"], split=(0, 4))
+    assert rel(tot, ref.double().cpu()) < 2e-6
+    assert torch.equal(ops.text_lin_split(ad, wt, **kw), got)
+    if epi == "bias+residual":                              # out= : a strided destination
+        big = torch.zeros((M, N + 64), dtype=torch.float32, device="cuda")
+        ops.text_lin_split(ad, wt, out=big[:, :N], **kw)
+        assert torch.equal(big[:, :N], got) and float(big[:, N:].abs().max()) == 0.0
+    ctr = ops.split16_overflow_counter()
+    before = int(ctr.item())
+    hot = ad.clone()
+    hot[M - 1, 7] = -2.5e5
+    out = ops.text_lin_split(hot, wt, **kw)
+    assert torch.isfinite(out).all() and int(ctr.item()) > before
+
+
 @pytest.mark.parametrize("tag,N,M,dup,cols", [("d", 8192, 1024, False, 3), ("e", 2048, 512, True, 6)])
 def test_dataset_fps_is_bit_exact(tag, N, M, dup, cols):
     """ppt_amd.data.farthest_point_sample(point, npoint) (data/dataset_3d.py:40-61 on the FPS kernel): the rows the reference
