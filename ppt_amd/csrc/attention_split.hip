@@ -300,8 +300,17 @@ __global__ __launch_bounds__(256) void attn_prefix_fold_f32(const float *__restr
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P * 2 * HHD) return;
     float acc = 0.f;
+    const float *src = part + i;
     const int64_t stride = (int64_t)P * 2 * HHD;
-    for (int v = 0; v < nseq; ++v) acc += part[i + v * stride];
+    int v = 0;
+    for (; v + 8 <= nseq; v += 8) {                      // eight loads in flight, added in sequence order (41 dependent loads: 11.3 us)
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = src[(v + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += t[u];
+    }
+    for (; v < nseq; ++v) acc += src[v * stride];
     const int pos = i / (2 * HHD), rem = i - pos * 2 * HHD;
     dqkv[(int64_t)pos * 3 * HHD + HHD + rem] = acc;
 }
