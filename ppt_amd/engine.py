@@ -875,6 +875,7 @@ POINTMLP_FUSED_NORM = os.environ.get("PPT_POINTMLP_FUSED_NORM", "1") != "0"
 # PPT_TEXT_MLP_PAIR=0 restores c_fc + split-K c_proj as two launches.
 TEXT_MLP_PAIR = os.environ.get("PPT_TEXT_MLP_PAIR", "1") != "0"
 TEXT_MLP_PAIR_LN = os.environ.get("PPT_TEXT_MLP_PAIR_LN", "1") != "0"      # ln_2 inside that launch (forward); 0: its own launch in front
+TEXT_MLP_PAIR_LAST = os.environ.get("PPT_TEXT_MLP_PAIR_LAST", "1") != "0"  # the last layer's forward too (its slices summed by an extra LayerNorm launch)
 # ... and its split16 form (csrc/text_mlp_split.hip) where the text tower runs on fp32 operands as hi + lo half pairs: the whole-model
 # split16 mode, and the mixed mode on weights whose text tower failed its self-check (checkpoint-like magnitudes).  0: the tile GEMMs.
 TEXT_MLP_PAIR_SPLIT = os.environ.get("PPT_TEXT_MLP_PAIR_SPLIT", "1") != "0"
@@ -1022,7 +1023,10 @@ def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=No
         else:
             ops.gemm(a, wca.get(sd[p + "attn.out_proj.weight"]), out=x_mid, bias=sd[p + "attn.out_proj.bias"], residual=x)
         pre = torch.empty((M, sd[p + "mlp.c_fc.weight"].shape[0]), dtype=Tm, device=dev) if save else None
-        pair = (TEXT_MLP_PAIR and splitk and i + 1 < layers and _text_mlp_pair_ok(Tm) and tuple(sd[p + "mlp.c_fc.weight"].shape) == (2048, 512))
+        # (the LAST layer has no LayerNorm of a next layer to add its partial products up: ln_final's launch over all rows does it --
+        # its normalised output is not used, the summed rows are; split16: 2 x 41 us of tile GEMMs -> 23 + 6 us)
+        pair = (TEXT_MLP_PAIR and splitk and (i + 1 < layers or TEXT_MLP_PAIR_LAST) and _text_mlp_pair_ok(Tm)
+                and tuple(sd[p + "mlp.c_fc.weight"].shape) == (2048, 512))
         if pair:
             # c_fc + QuickGELU + c_proj in one launch; its eight partial products are this layer's output once the next layer's
             # LayerNorm has added them to x_mid and the bias (the split-K hand-over below, with 8 slices instead of 4)
@@ -1040,7 +1044,13 @@ def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=No
             if save:
                 saved["layers"].append(dict(x=x, mean1=mean1, rstd1=rstd1, qkv=qkv, a=a, lse=lse, x_mid=x_mid, mean2=mean2,
                                             rstd2=rstd2, pre=pre))
-            pending = (x_mid, sd[p + "mlp.c_proj.bias"], parts)
+            if i + 1 < layers:
+                pending = (x_mid, sd[p + "mlp.c_proj.bias"], parts)
+            else:
+                x = torch.empty_like(x_mid)
+                ops.layernorm_fwd_sum(x_mid, sd[p + "mlp.c_proj.bias"], parts, sd["ln_final.weight"], sd["ln_final.bias"], torch.float32,
+                                      write_xs=x)
+                xin = x
             continue
         if fuse:
             st2 = stats()
