@@ -33,8 +33,20 @@ class GraphedCall:
         # polls the events of earlier collectives (the DDP-constructor broadcast, the previous step's all-reduce); in the default
         # "global" mode such a query during a capture aborts the process with hipErrorStreamCaptureUnsupported (seen once the
         # constructor broadcast existed: tests/dist_single_rank.py, head_type 3)
-        with torch.cuda.graph(self.graph, pool=pool, capture_error_mode="thread_local"):
-            self.outputs, self.keepalive = fn(*self.static_in)
+        # ... and no cyclic garbage collection inside the capture: a collection that happens to run there finalises whatever CUDA
+        # objects earlier code left in reference cycles (graphs, events, streams of models that are gone), and a destroy / query of
+        # those is not a capturable operation -- the process aborts ("Fatal Python error: Aborted ... Garbage-collecting" under
+        # GraphedCall.__init__, seen in the full GPU suite once an allocation count shifted).  torch.cuda.graph collects right
+        # before it starts capturing; reference-counted frees inside the capture are the caching allocator's business as before.
+        import gc
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.graph(self.graph, pool=pool, capture_error_mode="thread_local"):
+                self.outputs, self.keepalive = fn(*self.static_in)
+        finally:
+            if gc_was_on:
+                gc.enable()
 
     def pool(self):
         return self.graph.pool()

@@ -1619,3 +1619,35 @@ def test_fp32_mode_keeps_the_reference_nan_behaviour():
     ref.grad = g.clone()
     opt.step()
     assert torch.equal(torch.isnan(ref.detach()), torch.isnan(p)) and torch.equal(ref.detach()[[0, 1, 2]], p[[0, 1, 2]])
+
+
+def test_graph_capture_runs_without_the_cyclic_collector():
+    """graphs.GraphedCall captures with Python's cyclic garbage collector switched off (a collection inside a capture finalises
+    CUDA objects left in reference cycles -- not a capturable operation: the process aborted once in the full suite) and restores
+    the collector's state afterwards, also when the captured function raises."""
+    import gc
+    from ppt_amd import graphs
+    seen = []
+    x = torch.ones(8, device="cuda")
+
+    def fn(t):
+        seen.append(gc.isenabled())
+        return (t * 2,), None
+    assert gc.isenabled()
+    g = graphs.GraphedCall(fn, [x])
+    assert seen == [False] and gc.isenabled()
+    (y,), _ = g(torch.full((8,), 3.0, device="cuda"))
+    torch.cuda.synchronize()
+    assert float(y[0]) == 6.0
+
+    def bad(t):
+        raise ValueError("inside the capture")
+    with pytest.raises(ValueError):
+        graphs.GraphedCall(bad, [x])
+    assert gc.isenabled()
+    gc.disable()
+    try:
+        graphs.GraphedCall(fn, [x])
+        assert not gc.isenabled()                # (a caller that had it off keeps it off)
+    finally:
+        gc.enable()
