@@ -359,7 +359,7 @@ typedef struct ppt_text_mlp_params {
     /* dtype == PPT_F32: the split16 form (csrc/text_mlp_split.hip) -- A and `pre` are fp32, W1 / W2 the hi + lo half copies of
      * ppt_text_mlp_retile_split (made with the same split_b_pow2), every product three MFMAs on hi + lo IEEE-half pairs
      * (ppt_gemm_params.split16); A and the hidden activation are multiplied by 2^split_a_pow2 before they are split; a wave that
-     * saturated a finite value beyond half's range adds 1 to *split_overflow (may be NULL).  No LayerNorm prologue in this form. */
+     * saturated a finite value beyond half's range adds 1 to *split_overflow (may be NULL).  The LayerNorm prologue as above. */
     int split_a_pow2, split_b_pow2; unsigned int *split_overflow;
 } ppt_text_mlp_params;
 int ppt_text_mlp_retile(const void *W1, const void *W2, void *W1_tiled, void *W2_tiled, void *stream);

@@ -55,7 +55,18 @@ __device__ __forceinline__ void split4(const float (&x)[4], uint2 &H, uint2 &L)
     L = make_uint2(l[0], l[1]);
 }
 
-template <int MODE>
+__device__ __forceinline__ float row16_sum_s(float v)
+{
+    v += __uint_as_float(dpp_mov<0xB1, 0xf>(__float_as_uint(v)));
+    v += __uint_as_float(dpp_mov<0x4E, 0xf>(__float_as_uint(v)));
+    v += __uint_as_float(dpp_mov<0x141, 0xf>(__float_as_uint(v)));
+    v += __uint_as_float(dpp_mov<0x140, 0xf>(__float_as_uint(v)));
+    return v;
+}
+
+// LN (forward only): A is the fp32 residual stream x_mid and ln_2 is applied while the block's rows are staged, as in text_mlp.hip
+// (16 threads per row, two-pass statistics over DPP adds; slice 0 writes the statistics the LayerNorm backward needs).
+template <int MODE, bool LN>
 __global__ __launch_bounds__(512, 2) void text_mlp_split_kernel(const ppt_text_mlp_params p)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -88,7 +99,40 @@ __global__ __launch_bounds__(512, 2) void text_mlp_split_kernel(const ppt_text_m
     for (int i = 0; i < D1; ++i) next1(g1[i]);
 
     // ---- the block's rows of A (fp32) -> scaled, saturated, split -> the hi and lo images (rows past M: zeros)
-    {
+    if constexpr (LN) {
+        static_assert(R == 32 && D == 512, "16 threads per row x 32 rows = the workgroup");
+        const int r = threadIdx.x >> 4, j = threadIdx.x & 15;
+        const float *src = (const float *)p.A + (size_t)(row0 + min(r, nrow - 1)) * p.lda;
+        float4 xf[D / 64];
+#pragma unroll
+        for (int i = 0; i < D / 64; ++i) xf[i] = *reinterpret_cast<const float4 *>(src + 4 * (j + 16 * i));
+        float sm = 0.f;
+#pragma unroll
+        for (int i = 0; i < D / 64; ++i) sm += (xf[i].x + xf[i].y) + (xf[i].z + xf[i].w);
+        const float mean = row16_sum_s(sm) * (1.0f / (float)D);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < D / 64; ++i) {
+            const float d0 = xf[i].x - mean, d1 = xf[i].y - mean, d2 = xf[i].z - mean, d3 = xf[i].w - mean;
+            q = fmaf(d0, d0, q); q = fmaf(d1, d1, q); q = fmaf(d2, d2, q); q = fmaf(d3, d3, q);
+        }
+        const float rstd = 1.0f / sqrtf(row16_sum_s(q) * (1.0f / (float)D) + p.ln_eps);
+        if (p.ln_mean && s == 0 && j == 0 && r < nrow) { p.ln_mean[row0 + r] = mean; p.ln_rstd[row0 + r] = rstd; }
+#pragma unroll
+        for (int i = 0; i < D / 64; ++i) {
+            const int c = 4 * (j + 16 * i);
+            const float4 g = *reinterpret_cast<const float4 *>(p.ln_w + c), b = *reinterpret_cast<const float4 *>(p.ln_b + c);
+            float x[4] = {0.f, 0.f, 0.f, 0.f};
+            if (r < nrow) {
+                x[0] = split_saturate(((xf[i].x - mean) * rstd * g.x + b.x) * sa, over); x[1] = split_saturate(((xf[i].y - mean) * rstd * g.y + b.y) * sa, over);
+                x[2] = split_saturate(((xf[i].z - mean) * rstd * g.z + b.z) * sa, over); x[3] = split_saturate(((xf[i].w - mean) * rstd * g.w + b.w) * sa, over);
+            }
+            uint2 H, L;
+            split4(x, H, L);
+            *reinterpret_cast<uint2 *>(ai + r * AP + 2 * c) = H;
+            *reinterpret_cast<uint2 *>(ai + A_BYTES + r * AP + 2 * c) = L;
+        }
+    } else {
         const float *A = (const float *)p.A;
         constexpr int PIECES = R * (D / 4);                          // float4 pieces of the block (4096)
         float4 v[PIECES / 512];
@@ -306,17 +350,21 @@ extern "C" int ppt_text_mlp_retile_split(const float *W1, const float *W2, void 
 extern "C" int ppt_text_mlp_pair_split(const ppt_text_mlp_params *pp, void *stream)
 {
     ppt_text_mlp_params p = *pp;
-    if (p.ln_w || (p.lda % 4) || abs(p.split_a_pow2) > 24 || abs(p.split_b_pow2) > 24) return PPT_EINVAL;
+    if ((p.lda % 4) || abs(p.split_a_pow2) > 24 || abs(p.split_b_pow2) > 24) return PPT_EINVAL;
+    const bool ln = p.ln_w != nullptr;
+    if (ln && (p.mode != 0 || !p.ln_b || (((uintptr_t)p.ln_w | (uintptr_t)p.ln_b) & 15))) return PPT_EINVAL;
     static const int attrs_once = [] {
-        (void)hipFuncSetAttribute((const void *)text_mlp_split_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute((const void *)text_mlp_split_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)text_mlp_split_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)text_mlp_split_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)text_mlp_split_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         return 0;
     }();
     (void)attrs_once;
     const int grid = NS * ((p.M + R - 1) / R);
     hipStream_t st = ppt_stream(stream);
-    if (p.mode == 0) hipLaunchKernelGGL((text_mlp_split_kernel<0>), dim3(grid), dim3(512), LDS_BYTES, st, p);
-    else hipLaunchKernelGGL((text_mlp_split_kernel<1>), dim3(grid), dim3(512), LDS_BYTES, st, p);
+    if (ln) hipLaunchKernelGGL((text_mlp_split_kernel<0, true>), dim3(grid), dim3(512), LDS_BYTES, st, p);
+    else if (p.mode == 0) hipLaunchKernelGGL((text_mlp_split_kernel<0, false>), dim3(grid), dim3(512), LDS_BYTES, st, p);
+    else hipLaunchKernelGGL((text_mlp_split_kernel<1, false>), dim3(grid), dim3(512), LDS_BYTES, st, p);
     PPT_CHECK_LAUNCH();
     return PPT_OK;
 }

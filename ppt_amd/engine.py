@@ -1031,7 +1031,10 @@ def text_tower_forward(sd, wc, prompts, eot_pos, heads, layers, save, eff_len=No
             # c_fc + QuickGELU + c_proj in one launch; its eight partial products are this layer's output once the next layer's
             # LayerNorm has added them to x_mid and the bias (the split-K hand-over below, with 8 slices instead of 4)
             w1t, w2t = _text_mlp_tiles(sd, p, wcm, False)
-            if Tm == torch.float32:
+            if Tm == torch.float32 and TEXT_MLP_PAIR_LN:
+                parts, mean2, rstd2 = ops.text_mlp_pair_split(x_mid, w1t, w2t, bias=sd[p + "mlp.c_fc.bias"], pre=pre,
+                                                              ln=(sd[p + "ln_2.weight"], sd[p + "ln_2.bias"]), save_stats=save)
+            elif Tm == torch.float32:
                 h2, mean2, rstd2 = ops.layernorm_fwd(x_mid, sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], Tm, save_stats=save)
                 parts = ops.text_mlp_pair_split(h2, w1t, w2t, bias=sd[p + "mlp.c_fc.bias"], pre=pre)
             elif TEXT_MLP_PAIR_LN:

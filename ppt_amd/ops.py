@@ -437,7 +437,7 @@ def text_mlp_retile_split(w1, w2, b_pow2=None):
     return w1t, w2t
 
 
-def text_mlp_pair_split(a, w1t, w2t, *, bias=None, pre=None, backward=False, a_pow2=None):
+def text_mlp_pair_split(a, w1t, w2t, *, bias=None, pre=None, backward=False, a_pow2=None, ln=None, ln_eps=1e-5, save_stats=False):
     """text_mlp_pair on fp32 operands multiplied as hi + lo half pairs (split16; csrc/text_mlp_split.hip): a [M, 512] f32, w1t / w2t
     from text_mlp_retile_split, pre [M, 2048] f32 -> the eight slices' partial products [8, M, 512] f32."""
     M = a.shape[0]
@@ -452,12 +452,20 @@ def text_mlp_pair_split(a, w1t, w2t, *, bias=None, pre=None, backward=False, a_p
         p.split_overflow = _p(split16_overflow_counter(a.device))
     if pre is not None:
         assert pre.dtype == torch.float32 and tuple(pre.shape) == (M, 2048) and pre.is_contiguous()
+    mean = rstd = None
+    if ln is not None:              # (forward: `a` is the residual stream, ln_2 applied while the rows are staged; -> (parts, mean, rstd))
+        assert not backward
+        _chk(ln[0], torch.float32, "ln weight"); _chk(ln[1], torch.float32, "ln bias")
+        if save_stats:
+            mean = torch.empty((M,), dtype=torch.float32, device=a.device)
+            rstd = torch.empty((M,), dtype=torch.float32, device=a.device)
+        p.ln_w, p.ln_b, p.ln_eps, p.ln_mean, p.ln_rstd = _p(ln[0]), _p(ln[1]), float(ln_eps), _p(mean), _p(rstd)
     if profiler is not None:
         profiler.begin("gemm_f32", 4.0 * M * 512 * 2048, "ppt_text_mlp_pair split16 (" + ("backward" if backward else "forward") + ")")
     _lib.check(_lib.lib().ppt_text_mlp_pair(ctypes.byref(p), _stream()), "ppt_text_mlp_pair (split16)")
     if profiler is not None:
         profiler.end()
-    return parts
+    return (parts, mean, rstd) if ln is not None else parts
 
 
 def text_lin_retile_split(w, b_pow2=None):

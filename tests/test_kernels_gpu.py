@@ -1596,6 +1596,14 @@ def test_text_mlp_pair_split16_matches_fp64_and_the_split16_gemms(ops, M):
     ref = ops.gemm(f, w2d, out_dtype=torch.float32, split=(0, 4))
     assert rel(got, ref.double().cpu()) < 2e-6
     assert torch.equal(ops.text_mlp_pair_split(ad, w1t, w2t, bias=b1.cuda(), a_pow2=0), parts)
+    # the LayerNorm prologue: the partial products of LayerNorm-then-launch to fp32 rounding, the LayerNorm kernel's statistics
+    xres = (torch.randn(M, D, generator=g) * 2 + torch.randn(M, 1, generator=g)).cuda()
+    gam, bet = (1 + 0.1 * torch.randn(D, generator=g)).cuda(), (0.1 * torch.randn(D, generator=g)).cuda()
+    hh, mean, rstd = ops.layernorm_fwd(xres, gam, bet, torch.float32, save_stats=True)
+    two = ops.text_mlp_pair_split(hh, w1t, w2t, bias=b1.cuda(), a_pow2=0)
+    one, m1, r1 = ops.text_mlp_pair_split(xres, w1t, w2t, bias=b1.cuda(), a_pow2=0, ln=(gam, bet), save_stats=True)
+    assert rel(one.double().sum(0).cpu(), two.double().sum(0).cpu()) < 2e-6
+    assert (m1 - mean).abs().max().item() < 1e-5 and ((r1 - rstd) / rstd).abs().max().item() < 1e-5
     # ---- backward: ((d_out W_proj) * QuickGELU'(pre)) W_fc with gradient-sized values
     dout = torch.randn(M, D, generator=g) * 1e-2
     sg = torch.sigmoid(1.702 * pre64)
